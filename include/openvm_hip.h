@@ -1,0 +1,148 @@
+/*
+ * openvm_hip.h -- C ABI of the MI355X (gfx950) prover backend for openvm-org/stark-backend v2
+ * (SWIRL over BabyBear + Poseidon2).
+ *
+ * This is the drop-in boundary: the functions a Rust `openvm-hip-backend` crate binds with
+ * `extern "C"` exactly like `openvm-cuda-backend` binds its kernels
+ * (reference: the files under crates/cuda-backend/src/cuda/). Conventions follow the reference FFI:
+ *   - every entry returns `int`: 0 on success, otherwise a `hipError_t` value
+ *     (reference: crates/cuda-common/include/launcher.cuh:41-54, crates/cuda-common/src/error.rs:54-60);
+ *     invalid arguments return hipErrorInvalidValue (= 1), cf. merkle_tree.cu:220, supra/ntt.cu:215;
+ *   - field elements cross as raw 32-bit MONTGOMERY words (a Rust `BabyBear` is a
+ *     `repr(transparent)` Montgomery u32, an extension element is `[u32; 4]`, 4-byte aligned);
+ *   - `d_` pointers are device pointers, everything else is host memory;
+ *   - work is enqueued on the given stream; entries that return host values synchronise it.
+ *
+ * Device matrices are column-major planes (row index fastest), as in the reference
+ * (crates/cuda-backend/src/base.rs:8-12). Codewords and Merkle layers are kept in
+ * bit-reversed ("physical") row order; see the per-function notes and DESIGN.md.
+ */
+#ifndef OPENVM_HIP_H
+#define OPENVM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* hipStream_t without requiring the HIP headers. NULL = default stream. */
+typedef void *ovm_stream_t;
+
+/* Fiat-Shamir duplex sponge state (Poseidon2 width 16, rate 8, overwrite mode).
+ * Replaces `DeviceSpongeState` (reference: crates/cuda-backend/src/sponge.rs:39-48). */
+typedef struct ovm_sponge_t {
+    uint32_t state[16];  /* Montgomery words */
+    uint32_t absorb_idx; /* 0 <= absorb_idx < 8 */
+    uint32_t sample_idx; /* 0 <= sample_idx <= 8 */
+} ovm_sponge_t;
+
+/* ---------------------------------------------------------------------------------------
+ * Library / device
+ * ------------------------------------------------------------------------------------- */
+
+/* ABI version of this header. */
+uint32_t ovm_hip_abi_version(void);
+/* Selects the HIP device for the calling thread and builds the twiddle tables.
+ * Replaces `_generate_all_twiddles` / `_generate_partial_twiddles` / `_generate_device_ntt_twiddles`
+ * (reference: crates/cuda-backend/src/cuda/ntt.rs:12-22, batch_ntt_small.rs:49) and
+ * `_cuda_get_sm_count` (device_info.rs:4): *cu_count receives the number of compute units. */
+int ovm_hip_init(int device, uint32_t *cu_count);
+/* Name of a non-zero return code (hipGetErrorName). */
+const char *ovm_hip_error_name(int code);
+
+/* Plain device memory management for callers without a HIP binding of their own
+ * (reference: crates/cuda-common/src/d_buffer.rs, copy.rs). */
+int ovm_hip_malloc(void **d_ptr, size_t bytes);
+int ovm_hip_free(void *d_ptr);
+int ovm_hip_memcpy_h2d(void *d_dst, const void *src, size_t bytes, ovm_stream_t stream);
+int ovm_hip_memcpy_d2h(void *dst, const void *d_src, size_t bytes, ovm_stream_t stream);
+int ovm_hip_memcpy_d2d(void *d_dst, const void *d_src, size_t bytes, ovm_stream_t stream);
+int ovm_hip_memset(void *d_dst, int value, size_t bytes, ovm_stream_t stream);
+int ovm_hip_stream_create(ovm_stream_t *stream);
+int ovm_hip_stream_destroy(ovm_stream_t stream);
+int ovm_hip_stream_synchronize(ovm_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
+ * NTT / Reed-Solomon encode
+ * ------------------------------------------------------------------------------------- */
+
+/* Per column and per 2^l_skip-row chunk: inverse DFT over the chunk, then the subset-zeta
+ * transform over the chunk's index bits ("eval-to-coeff RS message",
+ * reference: crates/stark-backend/src/prover/poly.rs:325-348). d_in/d_out: width columns of
+ * 2^log_height rows; may alias. Replaces `_batch_ntt_small` + `_mle_interpolate_stage*`
+ * as used by crates/cuda-backend/src/stacked_pcs.rs:262-308. */
+int ovm_hip_eval_to_coeff(const uint32_t *d_in, uint32_t *d_out, uint64_t width,
+                          uint32_t log_height, uint32_t l_skip, ovm_stream_t stream);
+
+/* Decimation-in-frequency NTT of `width` columns: input rows [0, 2^log_n_in) in natural order
+ * (rows above that are taken as zero), output 2^log_n rows in BIT-REVERSED order:
+ *   d_out[col * 2^log_n + p] = sum_i in[col][i] * w^(i * bitrev_{log_n}(p)),  w = two_adic_generator(log_n).
+ * d_in columns are 2^log_n_in apart, d_out columns 2^log_n apart. In-place (d_in == d_out) is
+ * allowed when log_n_in == log_n. Replaces `_ct_mixed_radix_narrow` + `_bit_rev`
+ * (reference: crates/cuda-backend/src/cuda/ntt.rs:50-88,161-171). */
+int ovm_hip_ntt_dif(const uint32_t *d_in, uint32_t *d_out, uint64_t width, uint32_t log_n,
+                    uint32_t log_n_in, ovm_stream_t stream);
+/* Same for extension-field columns ([u32;4] entries, base-field twiddles). */
+int ovm_hip_ntt_dif_ext(const uint32_t *d_in, uint32_t *d_out, uint64_t width, uint32_t log_n,
+                        uint32_t log_n_in, ovm_stream_t stream);
+
+/* Reed-Solomon encode of a stacked matrix (`rs_code_matrix`, reference:
+ * crates/stark-backend/src/prover/stacked_pcs.rs:341-367, crates/cuda-backend/src/stacked_pcs.rs:229-337):
+ * codeword column = DFT over the subgroup of order 2^(log_height+log_blowup) of the zero-padded
+ * eval-to-coeff message, stored in bit-reversed row order (physical row p holds natural index
+ * bitrev(p)). d_scratch: width * 2^log_height words (may alias d_stacked if the stacked
+ * evaluations are no longer needed). d_codeword: width * 2^(log_height+log_blowup) words. */
+int ovm_hip_rs_encode(const uint32_t *d_stacked, uint32_t *d_scratch, uint32_t *d_codeword,
+                      uint64_t width, uint32_t log_height, uint32_t l_skip, uint32_t log_blowup,
+                      ovm_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Poseidon2 Merkle tree and transcript proof-of-work (row A5)
+ * ------------------------------------------------------------------------------------- */
+
+/* Sizes, in 32-bit words, of the buffers ovm_hip_merkle_tree needs. */
+uint64_t ovm_hip_merkle_scratch_words(uint32_t log_rows, uint32_t log_rows_per_query);
+uint64_t ovm_hip_merkle_layers_words(uint32_t log_rows, uint32_t log_rows_per_query);
+
+/* Merkle tree of `MerkleTree::new` (reference: crates/stark-backend/src/prover/stacked_pcs.rs:413-485)
+ * over a column-major matrix of 2^log_rows rows given in bit-reversed row order.
+ * d_digest_layers receives the stored layers back to back (2^(log_rows-k) + ... + 1 digests of
+ * 8 words); layer j holds the reference's digest_layers[j][y] at index bitrev_{log_rows-k-j}(y).
+ * The last digest is the root. Replaces `_poseidon2_compressing_row_hashes[_ext]`,
+ * `_poseidon2_strided_compress_layer`, `_poseidon2_adjacent_compress_layer`
+ * (reference: crates/cuda-backend/src/cuda/merkle_tree.rs:18-48). */
+int ovm_hip_merkle_tree(const uint32_t *d_matrix, uint64_t width, uint32_t log_rows,
+                        uint32_t log_rows_per_query, uint32_t *d_scratch, uint32_t *d_digest_layers,
+                        ovm_stream_t stream);
+/* Same for an extension-field matrix (rows absorbed coefficient-wise). */
+int ovm_hip_merkle_tree_ext(const uint32_t *d_matrix, uint64_t width, uint32_t log_rows,
+                            uint32_t log_rows_per_query, uint32_t *d_scratch,
+                            uint32_t *d_digest_layers, ovm_stream_t stream);
+
+/* n independent Poseidon2 permutations of 16-word states, in place (test / micro-benchmark entry;
+ * reference: crates/cuda-common/include/poseidon2.cuh:184-202). */
+int ovm_hip_poseidon2_permute(uint32_t *d_states, uint64_t n, ovm_stream_t stream);
+
+/* Proof-of-work: the MINIMUM canonical witness w such that observing w and sampling yields
+ * `bits` zero low bits (reference: crates/stark-backend/src/transcript/traits.rs:62-89; replaces
+ * `_sponge_grind`, crates/cuda-backend/src/cuda/sponge.rs:13). `sponge` is not modified.
+ * *witness_out is the canonical integer value. Synchronises the stream. */
+int ovm_hip_sponge_grind(const ovm_sponge_t *sponge, uint32_t bits, uint32_t *witness_out,
+                         ovm_stream_t stream);
+
+/* Row gather for query openings: out[r * width + c] = matrix[c][d_row_idx[r]]
+ * (replaces `_matrix_get_rows_fp`, reference: crates/cuda-backend/src/cuda/matrix.rs:24-32). */
+int ovm_hip_gather_rows(const uint32_t *d_matrix, uint64_t width, uint64_t col_stride,
+                        uint32_t words_per_elem, const uint64_t *d_row_idx, uint64_t n_rows,
+                        uint32_t *d_out, ovm_stream_t stream);
+/* Digest gather for Merkle paths: out[i] = layers[d_idx[i]] (8 words each)
+ * (replaces `_query_digest_layers`, reference: crates/cuda-backend/src/cuda/merkle_tree.rs:50-58). */
+int ovm_hip_gather_digests(const uint32_t *d_layers, const uint64_t *d_idx, uint64_t n,
+                           uint32_t *d_out, ovm_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OPENVM_HIP_H */

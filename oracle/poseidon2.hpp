@@ -1,0 +1,191 @@
+// ORACLE — test infrastructure only (see oracle/README.md).
+//
+// Poseidon2-BabyBear width 16 (8 external + 13 internal rounds, x^7 S-box), the row sponge
+// PaddingFreeSponge<16,8,8>, the 2->1 TruncatedPermutation compression and the overwrite-mode
+// DuplexSponge Fiat-Shamir transcript.
+//
+// The permutation itself lives in p3-baby-bear / p3-poseidon2 =0.4.3, which are NOT under
+// /root/reference. Restated from the in-tree numeric copy:
+//   crates/cuda-common/include/poseidon2.cuh:14-67    round constants + internal diagonal
+//   crates/cuda-common/include/poseidon2.cuh:86-202   layer structure (M_E circulant, M_I = 1 + diag)
+//   crates/cuda-backend/cuda/src/merkle_tree.cu:32-51,166-176   row sponge / compress semantics
+//   crates/stark-backend/src/transcript/duplex_sponge.rs:62-83  duplex sponge
+//   crates/stark-backend/src/transcript/traits.rs:46-89         sample_bits / check_witness / grind
+#pragma once
+#include "field.hpp"
+
+namespace oracle {
+
+static const uint32_t RC_INITIAL[64] = {
+    1774958255, 1185780729, 1621102414, 1796380621, 588815102,  1932426223, 1925334750, 747903232,
+    89648862,   360728943,  977184635,  1425273457, 256487465,  1200041953, 572403254,  448208942,
+    1215789478, 944884184,  953948096,  547326025,  646827752,  889997530,  1536873262, 86189867,
+    1065944411, 32019634,   333311454,  456061748,  1963448500, 1827584334, 1391160226, 1348741381,
+    88424255,   104111868,  1763866748, 79691676,   1988915530, 1050669594, 359890076,  573163527,
+    222820492,  159256268,  669703072,  763177444,  889367200,  256335831,  704371273,  25886717,
+    51754520,   1833211857, 454499742,  1384520381, 777848065,  1053320300, 1851729162, 344647910,
+    401996362,  1046925956, 5351995,    1212119315, 754867989,  36972490,   751272725,  506915399};
+static const uint32_t RC_TERMINAL[64] = {
+    1922082829, 1870549801, 1502529704, 1990744480, 1700391016, 1702593455, 321330495,  528965731,
+    183414327,  1886297254, 1178602734, 1923111974, 744004766,  549271463,  1781349648, 542259047,
+    1536158148, 715456982,  503426110,  340311124,  1558555932, 1226350925, 742828095,  1338992758,
+    1641600456, 1843351545, 301835475,  43203215,   386838401,  1520185679, 1235297680, 904680097,
+    1491801617, 1581784677, 913384905,  247083962,  532844013,  107190701,  213827818,  1979521776,
+    1358282574, 1681743681, 1867507480, 1530706910, 507181886,  695185447,  1172395131, 1250800299,
+    1503161625, 817684387,  498481458,  494676004,  1404253825, 108246855,  59414691,   744214112,
+    890862029,  1342765939, 1417398904, 1897591937, 1066647396, 1682806907, 1015795079, 1619482808};
+static const uint32_t RC_INTERNAL[13] = {1518359488, 1765533241, 945325693, 422793067, 311365592,
+                                         1311448267, 1629555936, 1009879353, 190525218, 786108885,
+                                         557776863,  212616710,  605745517};
+// V = [-2, 1, 2, 1/2, 3, 4, -1/2, -3, -4, 1/2^8, 1/4, 1/8, 1/2^27, -1/2^8, -1/16, -1/2^27];
+// internal linear layer is state -> (1*sum) + V .* state.
+static const uint32_t INTERNAL_DIAG[16] = {2013265919, 1,          2,         1006632961,
+                                           3,          4,          1006632960, 2013265918,
+                                           2013265917, 2005401601, 1509949441, 1761607681,
+                                           2013265906, 7864320,    125829120,  15};
+
+inline Fp sbox7(Fp x) {
+    Fp x2 = x * x, x4 = x2 * x2;
+    return x4 * x2 * x;
+}
+
+// 4x4 block [2 3 1 1; 1 2 3 1; 1 1 2 3; 3 1 1 2], then add column sums across the four blocks.
+inline void external_linear(Fp *s) {
+    for (int b = 0; b < 4; b++) {
+        Fp *x = s + 4 * b;
+        Fp y0 = x[0].dbl() + x[1] * Fp(3) + x[2] + x[3];
+        Fp y1 = x[0] + x[1].dbl() + x[2] * Fp(3) + x[3];
+        Fp y2 = x[0] + x[1] + x[2].dbl() + x[3] * Fp(3);
+        Fp y3 = x[0] * Fp(3) + x[1] + x[2] + x[3].dbl();
+        x[0] = y0;
+        x[1] = y1;
+        x[2] = y2;
+        x[3] = y3;
+    }
+    Fp sums[4];
+    for (int j = 0; j < 4; j++) sums[j] = s[j] + s[4 + j] + s[8 + j] + s[12 + j];
+    for (int i = 0; i < 16; i++) s[i] += sums[i % 4];
+}
+
+inline void internal_linear(Fp *s) {
+    Fp sum = Fp::zero();
+    for (int i = 0; i < 16; i++) sum += s[i];
+    for (int i = 0; i < 16; i++) s[i] = sum + s[i] * Fp((uint64_t)INTERNAL_DIAG[i]);
+}
+
+inline void poseidon2_permute(Fp *s) {
+    external_linear(s);
+    for (int r = 0; r < 4; r++) {
+        for (int i = 0; i < 16; i++) s[i] = sbox7(s[i] + Fp((uint64_t)RC_INITIAL[16 * r + i]));
+        external_linear(s);
+    }
+    for (int r = 0; r < 13; r++) {
+        s[0] = sbox7(s[0] + Fp((uint64_t)RC_INTERNAL[r]));
+        internal_linear(s);
+    }
+    for (int r = 0; r < 4; r++) {
+        for (int i = 0; i < 16; i++) s[i] = sbox7(s[i] + Fp((uint64_t)RC_TERMINAL[16 * r + i]));
+        external_linear(s);
+    }
+}
+
+using Digest = std::array<Fp, 8>;
+
+// PaddingFreeSponge<16, 8, 8>::hash_iter (p3-symmetric; device twin merkle_tree.cu:32-51)
+inline Digest hash_slice(const Fp *vals, size_t n) {
+    Fp st[16];
+    for (size_t off = 0; off < n; off += 8) {
+        size_t len = n - off < 8 ? n - off : 8;
+        for (size_t i = 0; i < len; i++) st[i] = vals[off + i];
+        poseidon2_permute(st);
+    }
+    Digest d;
+    for (int i = 0; i < 8; i++) d[i] = st[i];
+    return d;
+}
+inline Digest hash_slice(const std::vector<Fp> &v) { return hash_slice(v.data(), v.size()); }
+
+// TruncatedPermutation<_, 2, 8, 16>::compress (device twin merkle_tree.cu:166-176)
+inline Digest compress(const Digest &l, const Digest &r) {
+    Fp st[16];
+    for (int i = 0; i < 8; i++) {
+        st[i] = l[i];
+        st[8 + i] = r[i];
+    }
+    poseidon2_permute(st);
+    Digest d;
+    for (int i = 0; i < 8; i++) d[i] = st[i];
+    return d;
+}
+
+// stark-backend/src/transcript/duplex_sponge.rs:17-83
+struct Transcript {
+    Fp state[16];
+    unsigned absorb_idx = 0;  // 0 <= absorb_idx < 8
+    unsigned sample_idx = 0;  // 0 <= sample_idx <= 8
+    // every PoW witness this transcript produced, in order (for witness-replay parity runs)
+    std::vector<Fp> pow_log;
+
+    void observe(Fp x) {
+        state[absorb_idx++] = x;
+        if (absorb_idx == 8) {
+            poseidon2_permute(state);
+            absorb_idx = 0;
+            sample_idx = 8;
+        }
+    }
+    Fp sample() {
+        if (absorb_idx != 0 || sample_idx == 0) {
+            poseidon2_permute(state);
+            absorb_idx = 0;
+            sample_idx = 8;
+        }
+        return state[--sample_idx];
+    }
+    void observe_commit(const Digest &d) {
+        for (int i = 0; i < 8; i++) observe(d[i]);
+    }
+    void observe_ext(const EF &x) {
+        for (int i = 0; i < 4; i++) observe(x.c[i]);
+    }
+    EF sample_ext() {
+        EF r;
+        for (int i = 0; i < 4; i++) r.c[i] = sample();
+        return r;
+    }
+    uint64_t sample_bits(unsigned bits) {
+        assert(bits < 32);
+        return (uint64_t)sample().v & ((uint64_t(1) << bits) - 1);
+    }
+    bool check_witness(unsigned bits, Fp w) {
+        if (bits == 0) return true;
+        observe(w);
+        return sample_bits(bits) == 0;
+    }
+    // traits.rs:74-89 uses `find_any` (any valid witness). The oracle — like the product —
+    // returns the MINIMUM valid witness, which is what a single-threaded `find_any` yields.
+    Fp grind(unsigned bits) {
+        if (bits == 0) return Fp::zero();
+        for (uint64_t w = 0; w < P; w++) {
+            Transcript c = fork();
+            if (c.check_witness(bits, Fp(w))) {
+                bool ok = check_witness(bits, Fp(w));
+                assert(ok);
+                (void)ok;
+                pow_log.push_back(Fp(w));
+                return Fp(w);
+            }
+        }
+        assert(false && "no PoW witness");
+        return Fp::zero();
+    }
+    Transcript fork() const {
+        Transcript c;
+        for (int i = 0; i < 16; i++) c.state[i] = state[i];
+        c.absorb_idx = absorb_idx;
+        c.sample_idx = sample_idx;
+        return c;
+    }
+};
+
+}  // namespace oracle

@@ -1,0 +1,218 @@
+"""MI355X (gfx950) prover backend for openvm-org/stark-backend v2 -- Python host side.
+
+This package is a thin ctypes binding over the C ABI declared in ``include/openvm_hip.h``
+(``libopenvm_hip.so``, built in-tree by ``build.sh``). It mirrors the reference's backend
+surface for the prove hot path (``TraceCommitter::commit``, ``MultiRapProver::prove_rap_constraints``,
+``OpeningProver::prove_openings`` -- reference: crates/stark-backend/src/prover/hal.rs:84-138) and is
+what the tests and ``bench.py`` drive. PyTorch is used only as the owner of device memory and
+streams.
+
+The library is REQUIRED: importing the compute entry points without it raises. There is no CPU
+fallback in this package (the CPU restatement under ``oracle/`` is test infrastructure).
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import (POINTER, Structure, c_char_p, c_int, c_size_t, c_uint32, c_uint64,
+                    c_void_p)
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libopenvm_hip.so")
+INCLUDE_DIR = os.path.join(os.path.dirname(_HERE), "include")
+
+P = 2013265921  # 15 * 2^27 + 1
+MONTY_BITS = 32
+
+
+class OvmError(RuntimeError):
+    """A non-zero return code from the C ABI (a hipError_t value)."""
+
+    def __init__(self, code: int, what: str):
+        self.code = code
+        name = _lib().ovm_hip_error_name(code) if _LIB is not None else b"?"
+        super().__init__(f"{what} failed: {code} ({name.decode() if name else '?'})")
+
+
+class SpongeState(Structure):
+    """``ovm_sponge_t`` (reference: crates/cuda-backend/src/sponge.rs:39-48)."""
+
+    _fields_ = [("state", c_uint32 * 16), ("absorb_idx", c_uint32), ("sample_idx", c_uint32)]
+
+
+_LIB = None
+
+# name -> (restype, argtypes); every symbol include/openvm_hip.h declares.
+_u32p = POINTER(c_uint32)
+_u64p = POINTER(c_uint64)
+SIGNATURES = {
+    "ovm_hip_abi_version": (c_uint32, []),
+    "ovm_hip_init": (c_int, [c_int, _u32p]),
+    "ovm_hip_error_name": (c_char_p, [c_int]),
+    "ovm_hip_malloc": (c_int, [POINTER(c_void_p), c_size_t]),
+    "ovm_hip_free": (c_int, [c_void_p]),
+    "ovm_hip_memcpy_h2d": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
+    "ovm_hip_memcpy_d2h": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
+    "ovm_hip_memcpy_d2d": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
+    "ovm_hip_memset": (c_int, [c_void_p, c_int, c_size_t, c_void_p]),
+    "ovm_hip_stream_create": (c_int, [POINTER(c_void_p)]),
+    "ovm_hip_stream_destroy": (c_int, [c_void_p]),
+    "ovm_hip_stream_synchronize": (c_int, [c_void_p]),
+    "ovm_hip_eval_to_coeff": (c_int, [c_void_p, c_void_p, c_uint64, c_uint32, c_uint32, c_void_p]),
+    "ovm_hip_ntt_dif": (c_int, [c_void_p, c_void_p, c_uint64, c_uint32, c_uint32, c_void_p]),
+    "ovm_hip_ntt_dif_ext": (c_int, [c_void_p, c_void_p, c_uint64, c_uint32, c_uint32, c_void_p]),
+    "ovm_hip_rs_encode": (c_int, [c_void_p, c_void_p, c_void_p, c_uint64, c_uint32, c_uint32,
+                                  c_uint32, c_void_p]),
+    "ovm_hip_merkle_scratch_words": (c_uint64, [c_uint32, c_uint32]),
+    "ovm_hip_merkle_layers_words": (c_uint64, [c_uint32, c_uint32]),
+    "ovm_hip_merkle_tree": (c_int, [c_void_p, c_uint64, c_uint32, c_uint32, c_void_p, c_void_p,
+                                    c_void_p]),
+    "ovm_hip_merkle_tree_ext": (c_int, [c_void_p, c_uint64, c_uint32, c_uint32, c_void_p, c_void_p,
+                                        c_void_p]),
+    "ovm_hip_poseidon2_permute": (c_int, [c_void_p, c_uint64, c_void_p]),
+    "ovm_hip_sponge_grind": (c_int, [POINTER(SpongeState), c_uint32, _u32p, c_void_p]),
+    "ovm_hip_gather_rows": (c_int, [c_void_p, c_uint64, c_uint64, c_uint32, c_void_p, c_uint64,
+                                    c_void_p, c_void_p]),
+    "ovm_hip_gather_digests": (c_int, [c_void_p, c_void_p, c_uint64, c_void_p, c_void_p]),
+}
+
+
+def _lib():
+    """Loads libopenvm_hip.so. Raises (never falls back) when it is missing."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} is missing: build it with stark-backend_amd/build.sh "
+                "(or __graft_entry__.build()). There is no CPU fallback.")
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)  # AttributeError if the ABI drifted from the header
+            fn.restype = res
+            fn.argtypes = args
+        _LIB = lib
+    return _LIB
+
+
+def lib():
+    return _lib()
+
+
+def check(code: int, what: str) -> None:
+    if code != 0:
+        raise OvmError(code, what)
+
+
+# ---------------------------------------------------------------------------------------------
+# Field helpers (host, numpy): the ABI carries Montgomery words.
+# ---------------------------------------------------------------------------------------------
+_RINV = pow(1 << MONTY_BITS, P - 2, P)
+
+
+def to_mont(x) -> np.ndarray:
+    """canonical u32 -> Montgomery u32 (x * 2^32 mod P)."""
+    a = np.asarray(x, dtype=np.uint64) % np.uint64(P)
+    return ((a << np.uint64(32)) % np.uint64(P)).astype(np.uint32)
+
+
+def from_mont(x) -> np.ndarray:
+    """Montgomery u32 -> canonical u32."""
+    a = np.asarray(x, dtype=np.uint64)
+    # a * RINV can exceed 64 bits: split RINV into 16-bit halves
+    lo = np.uint64(_RINV & 0xFFFF)
+    hi = np.uint64(_RINV >> 16)
+    r = (a * lo) % np.uint64(P)
+    r = (r + (((a * hi) % np.uint64(P)) << np.uint64(16)) % np.uint64(P)) % np.uint64(P)
+    return r.astype(np.uint32)
+
+
+def bitrev(x, bits: int):
+    """Bit-reverse the low `bits` bits of an int or integer array."""
+    x = np.asarray(x, dtype=np.uint64)
+    r = np.zeros_like(x)
+    for i in range(bits):
+        r |= ((x >> np.uint64(i)) & np.uint64(1)) << np.uint64(bits - 1 - i)
+    return r
+
+
+# ---------------------------------------------------------------------------------------------
+# Device handle
+# ---------------------------------------------------------------------------------------------
+class Device:
+    """One HIP device + stream; owner of the twiddle tables (reference: GpuDevice,
+    crates/cuda-backend/src/device.rs:58-79)."""
+
+    def __init__(self, index: int = 0):
+        import torch
+
+        if not torch.cuda.is_available():
+            raise RuntimeError("no HIP device visible")
+        self.index = index
+        self.torch = torch
+        torch.cuda.set_device(index)
+        cu = c_uint32(0)
+        check(_lib().ovm_hip_init(index, ctypes.byref(cu)), "ovm_hip_init")
+        self.cu_count = cu.value
+
+    # -- memory -------------------------------------------------------------------------
+    @property
+    def stream(self):
+        return c_void_p(self.torch.cuda.current_stream(self.index).cuda_stream)
+
+    def empty(self, n_words: int):
+        return self.torch.empty(int(n_words), dtype=self.torch.int32, device=f"cuda:{self.index}")
+
+    def upload(self, arr: np.ndarray):
+        a = np.ascontiguousarray(arr)
+        if a.dtype == np.uint32:
+            return self.torch.from_numpy(a.view(np.int32).reshape(-1)).to(f"cuda:{self.index}")
+        if a.dtype == np.uint64:
+            return self.torch.from_numpy(a.view(np.int64).reshape(-1)).to(f"cuda:{self.index}")
+        raise TypeError(a.dtype)
+
+    @staticmethod
+    def download(t) -> np.ndarray:
+        a = t.cpu().numpy()
+        return a.view(np.uint32 if a.dtype == np.int32 else np.uint64)
+
+    def sync(self):
+        self.torch.cuda.synchronize(self.index)
+
+    # -- kernels ------------------------------------------------------------------------
+    def eval_to_coeff(self, d_in, d_out, width, log_height, l_skip):
+        check(_lib().ovm_hip_eval_to_coeff(d_in.data_ptr(), d_out.data_ptr(), width, log_height,
+                                           l_skip, self.stream), "ovm_hip_eval_to_coeff")
+
+    def ntt_dif(self, d_in, d_out, width, log_n, log_n_in=None, ext=False):
+        fn = _lib().ovm_hip_ntt_dif_ext if ext else _lib().ovm_hip_ntt_dif
+        check(fn(d_in.data_ptr(), d_out.data_ptr(), width, log_n,
+                 log_n if log_n_in is None else log_n_in, self.stream), "ovm_hip_ntt_dif")
+
+    def rs_encode(self, d_stacked, width, log_height, l_skip, log_blowup, d_scratch=None):
+        if d_scratch is None:
+            d_scratch = self.empty(width << log_height)
+        d_code = self.empty(width << (log_height + log_blowup))
+        check(_lib().ovm_hip_rs_encode(d_stacked.data_ptr(), d_scratch.data_ptr(), d_code.data_ptr(),
+                                       width, log_height, l_skip, log_blowup, self.stream),
+              "ovm_hip_rs_encode")
+        return d_code
+
+    def merkle_tree(self, d_matrix, width, log_rows, log_rows_per_query, ext=False):
+        scratch = self.empty(max(1, _lib().ovm_hip_merkle_scratch_words(log_rows, log_rows_per_query)))
+        layers = self.empty(_lib().ovm_hip_merkle_layers_words(log_rows, log_rows_per_query))
+        fn = _lib().ovm_hip_merkle_tree_ext if ext else _lib().ovm_hip_merkle_tree
+        check(fn(d_matrix.data_ptr(), width, log_rows, log_rows_per_query, scratch.data_ptr(),
+                 layers.data_ptr(), self.stream), "ovm_hip_merkle_tree")
+        return layers
+
+    def poseidon2_permute(self, d_states, n):
+        check(_lib().ovm_hip_poseidon2_permute(d_states.data_ptr(), n, self.stream),
+              "ovm_hip_poseidon2_permute")
+
+    def grind(self, sponge: SpongeState, bits: int) -> int:
+        w = c_uint32(0)
+        check(_lib().ovm_hip_sponge_grind(ctypes.byref(sponge), bits, ctypes.byref(w), self.stream),
+              "ovm_hip_sponge_grind")
+        return w.value

@@ -1,0 +1,24 @@
+#!/usr/bin/env bash
+# Builds libopenvm_hip.so (gfx950 only) in-tree. hipcc cross-compiles without a GPU.
+set -euo pipefail
+here="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
+src="$here/csrc"
+out="$here/libopenvm_hip.so"
+obj="$here/build"
+mkdir -p "$obj"
+HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
+FLAGS=(--offload-arch=gfx950 -O3 -std=c++17 -fPIC -I"$here/../include" -I"$src" -Wall -Wno-unused-function -Wno-unused-variable -Wno-unused-result)
+pids=()
+objs=()
+for f in "$src"/*.hip "$src"/*.cpp; do
+  [ -e "$f" ] || continue
+  o="$obj/$(basename "$f").o"
+  objs+=("$o")
+  if [ ! -e "$o" ] || [ -n "$(find "$src" "$here/../include" -newer "$o" \( -name '*.h' -o -name '*.hpp' \) -print -quit)" ] || [ "$f" -nt "$o" ]; then
+    "$HIPCC" "${FLAGS[@]}" -x hip -c "$f" -o "$o" &
+    pids+=($!)
+  fi
+done
+for p in "${pids[@]:-}"; do [ -n "$p" ] && wait "$p"; done
+"$HIPCC" --offload-arch=gfx950 -shared -fPIC -o "$out" "${objs[@]}"
+echo "built $out"

@@ -1,0 +1,245 @@
+// BabyBear (p = 15*2^27 + 1) in 32-bit Montgomery form (R = 2^32) and its quartic extension
+// F[X]/(X^4 - 11), usable from host C++ and gfx950 device code.
+//
+// The in-memory representation is the one the reference passes across its FFI unchanged: a Rust
+// `BabyBear` is a `repr(transparent)` Montgomery u32, an extension element is `[u32; 4]`
+// (reference: crates/cuda-common/include/fp.h:52-60,184-194 and fpext.h:28-44).
+//
+// CDNA4 notes: 32x32 multiplies are the expensive VALU ops, so `mont_mul` does two full multiplies
+// (lo/hi of a*b) and replaces the multiply by the Montgomery constant M = 2^31 + 2^27 + 1 with
+// shift-adds (v_lshl_add_u32); the multiply by P needs only its high word.
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define BB_HD __host__ __device__ __forceinline__
+#else
+#define BB_HD inline
+#endif
+
+namespace bb {
+
+static constexpr uint32_t P = 0x78000001u;
+static constexpr uint32_t MONTY_M = 0x88000001u;  // -P^-1 ... P * M == 1 (mod 2^32), see fp.h:56
+static constexpr uint32_t R2 = 1172168163u;       // 2^64 mod P
+
+// ---- compile-time helpers (used to bake constants in Montgomery form) ----
+constexpr uint32_t cx_to_mont(uint64_t x) { return (uint32_t)(((x % P) << 32) % P); }
+constexpr uint32_t cx_mulmod(uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)a * b) % P); }
+constexpr uint32_t cx_powmod(uint32_t a, uint64_t e) {
+    uint32_t r = 1;
+    while (e) {
+        if (e & 1) r = cx_mulmod(r, a);
+        a = cx_mulmod(a, a);
+        e >>= 1;
+    }
+    return r;
+}
+
+BB_HD uint32_t mont_reduce(uint64_t x) {
+    // t = (x mod 2^32) * M mod 2^32 ;  u = t * P ;  result = (x - u) / 2^32 (+P if negative)
+    uint32_t lo = (uint32_t)x;
+    uint32_t t = lo + (lo << 27) + (lo << 31);  // lo * (2^31 + 2^27 + 1)
+    uint32_t uh = (uint32_t)(((uint64_t)t * P) >> 32);
+    uint32_t xh = (uint32_t)(x >> 32);
+    uint32_t r = xh - uh;
+    return xh < uh ? r + P : r;
+}
+
+// Same, for x < 4*P^2 (a sum of up to four raw products): one extra conditional subtract.
+BB_HD uint32_t mont_reduce_wide(uint64_t x) {
+    uint32_t r = mont_reduce(x);
+    return r >= P ? r - P : r;
+}
+
+struct Fp {
+    uint32_t v;  // Montgomery word, < P
+
+    BB_HD static Fp raw(uint32_t m) {
+        Fp r;
+        r.v = m;
+        return r;
+    }
+    BB_HD static Fp zero() { return raw(0); }
+    BB_HD static Fp one() { return raw(0x0ffffffeu); }  // 2^32 mod P
+    BB_HD static Fp from_canonical(uint32_t x) { return raw(mont_reduce((uint64_t)x * R2)); }
+    BB_HD uint32_t canonical() const { return mont_reduce((uint64_t)v); }
+
+    BB_HD Fp operator+(Fp o) const {
+        uint32_t s = v + o.v;
+        return raw(s >= P ? s - P : s);
+    }
+    BB_HD Fp operator-(Fp o) const {
+        uint32_t d = v - o.v;
+        return raw(v < o.v ? d + P : d);
+    }
+    BB_HD Fp operator-() const { return raw(v ? P - v : 0); }
+    BB_HD Fp operator*(Fp o) const { return raw(mont_reduce((uint64_t)v * o.v)); }
+    BB_HD Fp &operator+=(Fp o) { return *this = *this + o; }
+    BB_HD Fp &operator-=(Fp o) { return *this = *this - o; }
+    BB_HD Fp &operator*=(Fp o) { return *this = *this * o; }
+    BB_HD bool operator==(Fp o) const { return v == o.v; }
+    BB_HD bool operator!=(Fp o) const { return v != o.v; }
+    BB_HD Fp dbl() const { return *this + *this; }
+    BB_HD Fp square() const { return *this * *this; }
+    BB_HD Fp halve() const { return raw((v >> 1) + ((v & 1) ? (P + 1) / 2 : 0)); }
+    BB_HD Fp pow(uint64_t e) const {
+        Fp b = *this, r = one();
+        while (e) {
+            if (e & 1) r *= b;
+            b *= b;
+            e >>= 1;
+        }
+        return r;
+    }
+    BB_HD Fp exp_power_of_2(unsigned k) const {
+        Fp r = *this;
+        for (unsigned i = 0; i < k; i++) r = r.square();
+        return r;
+    }
+    BB_HD Fp inv() const { return pow(P - 2); }
+};
+
+// Compile-time Montgomery constant.
+template <uint32_t CANON>
+BB_HD Fp fp_const() {
+    return Fp::raw(cx_to_mont(CANON));
+}
+
+// reference: crates/cuda-common/include/fp.h:291-320 (canonical values)
+static constexpr uint32_t TWO_ADIC_GENERATORS[28] = {
+    0x1,        0x78000000, 0x67055c21, 0x5ee99486, 0xbb4c4e4,  0x2d4cc4da, 0x669d6090,
+    0x17b56c64, 0x67456167, 0x688442f9, 0x145e952d, 0x4fe61226, 0x4c734715, 0x11c33e2a,
+    0x62c3d2b1, 0x77cad399, 0x54c131f4, 0x4cabd6a6, 0x5cf5713f, 0x3e9430e8, 0xba067a3,
+    0x18adc27d, 0x21fd55bc, 0x4b859b3d, 0x3bd57996, 0x4483d85a, 0x3a26eef8, 0x1a427a41};
+static constexpr uint32_t GENERATOR = 31;  // p3-baby-bear: multiplicative generator of F*
+
+inline Fp two_adic_generator(unsigned bits) {
+    return Fp::from_canonical(TWO_ADIC_GENERATORS[bits]);
+}
+
+struct alignas(4) FpExt {
+    Fp c[4];
+
+    BB_HD static FpExt zero() {
+        FpExt r;
+        r.c[0] = r.c[1] = r.c[2] = r.c[3] = Fp::zero();
+        return r;
+    }
+    BB_HD static FpExt one() {
+        FpExt r = zero();
+        r.c[0] = Fp::one();
+        return r;
+    }
+    BB_HD static FpExt from_base(Fp a) {
+        FpExt r = zero();
+        r.c[0] = a;
+        return r;
+    }
+    BB_HD FpExt operator+(const FpExt &o) const {
+        FpExt r;
+#pragma unroll
+        for (int i = 0; i < 4; i++) r.c[i] = c[i] + o.c[i];
+        return r;
+    }
+    BB_HD FpExt operator-(const FpExt &o) const {
+        FpExt r;
+#pragma unroll
+        for (int i = 0; i < 4; i++) r.c[i] = c[i] - o.c[i];
+        return r;
+    }
+    BB_HD FpExt operator-() const {
+        FpExt r;
+#pragma unroll
+        for (int i = 0; i < 4; i++) r.c[i] = -c[i];
+        return r;
+    }
+    BB_HD FpExt operator*(Fp s) const {
+        FpExt r;
+#pragma unroll
+        for (int i = 0; i < 4; i++) r.c[i] = c[i] * s;
+        return r;
+    }
+    BB_HD FpExt operator+(Fp s) const {
+        FpExt r = *this;
+        r.c[0] += s;
+        return r;
+    }
+    BB_HD FpExt operator-(Fp s) const {
+        FpExt r = *this;
+        r.c[0] -= s;
+        return r;
+    }
+    BB_HD FpExt operator*(const FpExt &o) const {
+        // Schoolbook product mod X^4 = 11. Cross terms are accumulated as 64-bit sums of raw
+        // products (each < 2^62 / 4 after halving the count) and reduced once per coefficient:
+        // 16 multiplies, 4 + 3 reductions instead of 16+.
+        const Fp *a = c, *b = o.c;
+        const Fp W = fp_const<11>();
+        // high part (terms that wrap): reduce first, multiply by 11, then add
+        Fp h0 = Fp::raw(mont_reduce_wide((uint64_t)a[1].v * b[3].v + (uint64_t)a[2].v * b[2].v +
+                                         (uint64_t)a[3].v * b[1].v));
+        Fp h1 = Fp::raw(mont_reduce((uint64_t)a[2].v * b[3].v + (uint64_t)a[3].v * b[2].v));
+        Fp h2 = a[3] * b[3];
+        FpExt r;
+        r.c[0] = a[0] * b[0] + W * h0;
+        r.c[1] = Fp::raw(mont_reduce((uint64_t)a[0].v * b[1].v + (uint64_t)a[1].v * b[0].v)) + W * h1;
+        r.c[2] = Fp::raw(mont_reduce_wide((uint64_t)a[0].v * b[2].v + (uint64_t)a[1].v * b[1].v +
+                                          (uint64_t)a[2].v * b[0].v)) +
+                 W * h2;
+        r.c[3] = Fp::raw(mont_reduce_wide((uint64_t)a[0].v * b[3].v + (uint64_t)a[1].v * b[2].v +
+                                          (uint64_t)a[2].v * b[1].v + (uint64_t)a[3].v * b[0].v));
+        return r;
+    }
+    BB_HD FpExt &operator+=(const FpExt &o) { return *this = *this + o; }
+    BB_HD FpExt &operator-=(const FpExt &o) { return *this = *this - o; }
+    BB_HD FpExt &operator*=(const FpExt &o) { return *this = *this * o; }
+    BB_HD FpExt &operator*=(Fp o) { return *this = *this * o; }
+    BB_HD bool operator==(const FpExt &o) const {
+        return c[0] == o.c[0] && c[1] == o.c[1] && c[2] == o.c[2] && c[3] == o.c[3];
+    }
+    BB_HD bool operator!=(const FpExt &o) const { return !(*this == o); }
+    BB_HD FpExt dbl() const { return *this + *this; }
+    BB_HD FpExt square() const { return *this * *this; }
+    BB_HD FpExt halve() const {
+        FpExt r;
+#pragma unroll
+        for (int i = 0; i < 4; i++) r.c[i] = c[i].halve();
+        return r;
+    }
+    BB_HD FpExt pow(uint64_t e) const {
+        FpExt b = *this, r = one();
+        while (e) {
+            if (e & 1) r *= b;
+            b *= b;
+            e >>= 1;
+        }
+        return r;
+    }
+    BB_HD FpExt exp_power_of_2(unsigned k) const {
+        FpExt r = *this;
+        for (unsigned i = 0; i < k; i++) r = r.square();
+        return r;
+    }
+    BB_HD FpExt inv() const {
+        // Tower: a = A + X*B over F[Y]/(Y^2 - 11), Y = X^2; a^-1 = (A - X*B) / (A^2 - Y*B^2).
+        const Fp W = fp_const<11>();
+        Fp a0 = c[0], a1 = c[1], a2 = c[2], a3 = c[3];
+        Fp A2_0 = a0 * a0 + W * (a2 * a2), A2_1 = (a0 * a2).dbl();
+        Fp B2_0 = a1 * a1 + W * (a3 * a3), B2_1 = (a1 * a3).dbl();
+        Fp c0 = A2_0 - W * B2_1, c1 = A2_1 - B2_0;
+        Fp n = (c0 * c0 - W * (c1 * c1)).inv();
+        Fp d0 = c0 * n, d1 = -(c1 * n);
+        FpExt r;
+        r.c[0] = a0 * d0 + W * (a2 * d1);
+        r.c[2] = a0 * d1 + a2 * d0;
+        r.c[1] = -(a1 * d0 + W * (a3 * d1));
+        r.c[3] = -(a1 * d1 + a3 * d0);
+        return r;
+    }
+};
+
+BB_HD FpExt operator*(Fp a, const FpExt &b) { return b * a; }
+
+}  // namespace bb

@@ -1,0 +1,55 @@
+// Per-process device context: twiddle tables and small helpers shared by the kernel files.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+
+#include "bb31.h"
+
+#define OVM_CHECK(expr)                                   \
+    do {                                                  \
+        hipError_t _e = (expr);                           \
+        if (_e != hipSuccess) return (int)_e;             \
+    } while (0)
+
+// Kernel launches report through hipGetLastError like the reference's CHECK_KERNEL()
+// (crates/cuda-common/include/launcher.cuh:41-54).
+#define OVM_CHECK_LAUNCH() OVM_CHECK(hipGetLastError())
+
+namespace ovm {
+
+static constexpr unsigned TW_LOG_MAX = 27;  // two-adicity of BabyBear
+static constexpr unsigned TW_LO_BITS = 12;
+static constexpr unsigned TW_HI_BITS = TW_LOG_MAX - TW_LO_BITS;
+
+// omega = two_adic_generator(27).  lo[e] = omega^e (e < 2^12),  hi[e] = omega^(e << 12).
+// Any root of unity of order 2^k | 2^27 is  omega^(e << (27-k)) = hi[..] * lo[..]: two L2-resident
+// loads and one multiply instead of a 2^k-entry table (a 2^25-point transform would need 128 MB).
+struct Twiddles {
+    const bb::Fp *lo;
+    const bb::Fp *hi;
+};
+
+__device__ __forceinline__ bb::Fp tw_pow27(const Twiddles &tw, uint32_t e27) {
+    e27 &= (1u << TW_LOG_MAX) - 1;
+    bb::Fp l = tw.lo[e27 & ((1u << TW_LO_BITS) - 1)];
+    bb::Fp h = tw.hi[e27 >> TW_LO_BITS];
+    return l * h;
+}
+
+// Returns the table for the current device (building it on first use). nullptr on failure.
+const Twiddles *twiddles();
+
+inline unsigned ceil_div(uint64_t a, uint64_t b) { return (unsigned)((a + b - 1) / b); }
+
+__host__ __device__ __forceinline__ uint32_t bitrev32(uint32_t x, unsigned bits) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return bits ? (__brev(x) >> (32 - bits)) : 0;
+#else
+    uint32_t r = 0;
+    for (unsigned i = 0; i < bits; i++) r |= ((x >> i) & 1u) << (bits - 1 - i);
+    return r;
+#endif
+}
+
+}  // namespace ovm

@@ -1,0 +1,288 @@
+// Poseidon2 Merkle commitment (MMCS) over a column-major codeword in PHYSICAL (bit-reversed) row
+// order, plus the proof-of-work grind and opening gathers.
+//
+// Replaces (reference): crates/cuda-backend/cuda/src/merkle_tree.cu:16-79,81-149 (row hashes),
+// :153-177 (compress layers), :185-210 (query digest gather), src/sponge.cu:65-117 (grind),
+// src/matrix.cu:62-80 (row gather); tree semantics from
+// crates/stark-backend/src/prover/stacked_pcs.rs:413-485.
+//
+// Index spaces. The reference tree is defined on natural evaluation indices m; we store row
+// p = bitrev_L(m). With rows_per_query = 2^k and query_stride = 2^(L-k):
+//   * the 2^k leaves {i + t*query_stride} of query i are physical rows g*2^k + bitrev_k(t) with
+//     g = bitrev_{L-k}(i): one contiguous group;
+//   * every layer of the reference tree -- the k strided ones and the adjacent-pair ones above
+//     them -- becomes  out[q] = compress(in[q], in[q + half])  on bit-reversed indices, within a
+//     group for the first k layers and over the whole layer above. All accesses are unit-stride.
+// Stored layer j (j = 0 is the reference's digest_layers[0]) holds entry y at index
+// bitrev_{L-k-j}(y).
+//
+// Roofline: Poseidon2 is integer-ALU bound (~640 32-bit multiplies per permutation), not HBM
+// bound; one lane hashes one row and the codeword is read exactly once with unit stride across
+// the wavefront.
+#include "device_ctx.h"
+#include "openvm_hip.h"
+#include "poseidon2.h"
+
+using bb::Fp;
+using bb::FpExt;
+using p2::Digest;
+
+namespace ovm {
+
+static constexpr int HASH_THREADS = 256;
+
+// One lane = one row. `words_per_elem` is 1 for base-field matrices and 4 for extension-field
+// matrices (stored as [u32;4] per entry); the row is absorbed coefficient-wise.
+template <int WORDS>
+__global__ __launch_bounds__(HASH_THREADS) void hash_rows_kernel(const Fp *__restrict__ mat,
+                                                                 uint64_t width, uint64_t rows,
+                                                                 uint64_t col_stride,
+                                                                 Digest *__restrict__ out) {
+    uint64_t row = (uint64_t)blockIdx.x * HASH_THREADS + threadIdx.x;
+    if (row >= rows) return;
+    Fp s[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) s[i] = Fp::zero();
+    // Absorb 8 words (= CPB columns) per permutation with static register indices.
+    constexpr int CPB = 8 / WORDS;
+    const Fp *src = mat + row * WORDS;
+    const uint64_t cstride = col_stride * WORDS;
+    uint64_t cidx = 0;
+    for (; cidx + CPB <= width; cidx += CPB) {
+#pragma unroll
+        for (int j = 0; j < CPB; j++) {
+            const Fp *p = src + (cidx + j) * cstride;
+            if constexpr (WORDS == 4) {
+                uint4 v = *reinterpret_cast<const uint4 *>(p);
+                s[4 * j + 0] = Fp::raw(v.x);
+                s[4 * j + 1] = Fp::raw(v.y);
+                s[4 * j + 2] = Fp::raw(v.z);
+                s[4 * j + 3] = Fp::raw(v.w);
+            } else {
+                s[j] = p[0];
+            }
+        }
+        p2::permute(s);
+    }
+    if (cidx < width) {
+        // partial tail: overwrite the first words only, stale words stay (padding-free sponge)
+#pragma unroll
+        for (int j = 0; j < CPB; j++) {
+            if (cidx + j < width) {
+                const Fp *p = src + (cidx + j) * cstride;
+#pragma unroll
+                for (int k = 0; k < WORDS; k++) s[WORDS * j + k] = p[k];
+            }
+        }
+        p2::permute(s);
+    }
+    Digest d;
+#pragma unroll
+    for (int i = 0; i < 8; i++) d.d[i] = s[i];
+    out[row] = d;
+}
+
+// out[g*half + q] = compress(in[g*2*half + q], in[g*2*half + q + half]),  q < half
+__global__ __launch_bounds__(HASH_THREADS) void compress_layer_kernel(const Digest *__restrict__ in,
+                                                                      Digest *__restrict__ out,
+                                                                      uint64_t n_out,
+                                                                      uint32_t log_half) {
+    uint64_t o = (uint64_t)blockIdx.x * HASH_THREADS + threadIdx.x;
+    if (o >= n_out) return;
+    uint64_t q = o & ((1ull << log_half) - 1);
+    uint64_t g = o >> log_half;
+    uint64_t left = (g << (log_half + 1)) | q;
+    Digest l = in[left], r = in[left + (1ull << log_half)];
+    out[o] = p2::compress(l, r);
+}
+
+// Proof-of-work search: witness w = base + global thread id; keeps the minimum hit.
+__global__ __launch_bounds__(HASH_THREADS) void grind_kernel(p2::Sponge sponge, uint32_t bits,
+                                                             uint32_t base, uint32_t count,
+                                                             uint32_t *result) {
+    uint32_t i = blockIdx.x * HASH_THREADS + threadIdx.x;
+    if (i >= count) return;
+    uint32_t w = base + i;
+    p2::Sponge s = sponge;
+    s.observe(Fp::from_canonical(w));
+    if (s.sample_bits(bits) == 0) atomicMin(result, w);
+}
+
+__global__ void permute_states_kernel(Fp *states, uint64_t n) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Fp s[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) s[k] = states[i * 16 + k];
+    p2::permute(s);
+#pragma unroll
+    for (int k = 0; k < 16; k++) states[i * 16 + k] = s[k];
+}
+
+// Gather `n_rows` rows (given by physical row index) of a column-major matrix into a row-major
+// buffer of n_rows x width entries.
+template <int WORDS>
+__global__ void gather_rows_kernel(const Fp *__restrict__ mat, uint64_t width, uint64_t col_stride,
+                                   const uint64_t *__restrict__ row_idx, uint64_t n_rows,
+                                   Fp *__restrict__ out) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_rows * width) return;
+    uint64_t r = i / width, cidx = i % width;
+    const Fp *src = mat + (cidx * col_stride + row_idx[r]) * WORDS;
+#pragma unroll
+    for (int k = 0; k < WORDS; k++) out[i * WORDS + k] = src[k];
+}
+
+__global__ void gather_digests_kernel(const Digest *__restrict__ layers,
+                                      const uint64_t *__restrict__ idx, uint64_t n,
+                                      Digest *__restrict__ out) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    out[i] = layers[idx[i]];
+}
+
+template <int WORDS>
+static int merkle_tree_impl(const uint32_t *d_matrix, uint64_t width, uint32_t log_rows,
+                            uint32_t log_rows_per_query, uint32_t *d_scratch,
+                            uint32_t *d_digest_layers, hipStream_t stream) {
+    if (log_rows_per_query > log_rows || log_rows > 30) return (int)hipErrorInvalidValue;
+    const uint64_t rows = 1ull << log_rows;
+    Digest *leaf = (Digest *)d_scratch;          // rows digests
+    Digest *pong = leaf + rows;                  // rows/2 digests (only if k >= 2)
+    Digest *layers = (Digest *)d_digest_layers;  // 2*query_stride - 1 digests
+    hipLaunchKernelGGL(hash_rows_kernel<WORDS>, dim3(ceil_div(rows, HASH_THREADS)),
+                       dim3(HASH_THREADS), 0, stream, (const Fp *)d_matrix, width, rows, rows,
+                       log_rows_per_query == 0 ? layers : leaf);
+    OVM_CHECK_LAUNCH();
+    // k group-local layers: leaf -> ... -> layers[0]
+    const Digest *cur = leaf;
+    uint64_t n = rows;
+    for (uint32_t j = 0; j < log_rows_per_query; j++) {
+        uint64_t n_out = n >> 1;
+        bool last = (j + 1 == log_rows_per_query);
+        Digest *dst = last ? layers : ((cur == leaf) ? pong : leaf);
+        uint32_t log_half = log_rows_per_query - 1 - j;
+        hipLaunchKernelGGL(compress_layer_kernel, dim3(ceil_div(n_out, HASH_THREADS)),
+                           dim3(HASH_THREADS), 0, stream, cur, dst, n_out, log_half);
+        OVM_CHECK_LAUNCH();
+        cur = dst;
+        n = n_out;
+    }
+    // global layers
+    Digest *layer = layers;
+    uint32_t log_n = log_rows - log_rows_per_query;
+    while (log_n > 0) {
+        uint64_t n_out = 1ull << (log_n - 1);
+        Digest *dst = layer + (1ull << log_n);
+        hipLaunchKernelGGL(compress_layer_kernel, dim3(ceil_div(n_out, HASH_THREADS)),
+                           dim3(HASH_THREADS), 0, stream, layer, dst, n_out, log_n - 1);
+        OVM_CHECK_LAUNCH();
+        layer = dst;
+        log_n--;
+    }
+    return 0;
+}
+
+}  // namespace ovm
+
+using namespace ovm;
+
+extern "C" {
+
+uint64_t ovm_hip_merkle_scratch_words(uint32_t log_rows, uint32_t log_rows_per_query) {
+    uint64_t rows = 1ull << log_rows;
+    uint64_t digests = log_rows_per_query == 0 ? 0 : rows + (rows >> 1);
+    return digests * 8;
+}
+uint64_t ovm_hip_merkle_layers_words(uint32_t log_rows, uint32_t log_rows_per_query) {
+    uint64_t qs = 1ull << (log_rows - log_rows_per_query);
+    return (2 * qs - 1) * 8;
+}
+
+int ovm_hip_merkle_tree(const uint32_t *d_matrix, uint64_t width, uint32_t log_rows,
+                        uint32_t log_rows_per_query, uint32_t *d_scratch, uint32_t *d_digest_layers,
+                        ovm_stream_t stream) {
+    return merkle_tree_impl<1>(d_matrix, width, log_rows, log_rows_per_query, d_scratch,
+                               d_digest_layers, (hipStream_t)stream);
+}
+int ovm_hip_merkle_tree_ext(const uint32_t *d_matrix, uint64_t width, uint32_t log_rows,
+                            uint32_t log_rows_per_query, uint32_t *d_scratch,
+                            uint32_t *d_digest_layers, ovm_stream_t stream) {
+    return merkle_tree_impl<4>(d_matrix, width, log_rows, log_rows_per_query, d_scratch,
+                               d_digest_layers, (hipStream_t)stream);
+}
+
+int ovm_hip_poseidon2_permute(uint32_t *d_states, uint64_t n, ovm_stream_t stream) {
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(permute_states_kernel, dim3(ceil_div(n, 256)), dim3(256), 0,
+                       (hipStream_t)stream, (Fp *)d_states, n);
+    OVM_CHECK_LAUNCH();
+    return 0;
+}
+
+int ovm_hip_sponge_grind(const ovm_sponge_t *sponge, uint32_t bits, uint32_t *witness_out,
+                         ovm_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!sponge || !witness_out || bits >= 31) return (int)hipErrorInvalidValue;
+    if (bits == 0) {
+        *witness_out = 0;
+        return 0;
+    }
+    p2::Sponge s;
+    for (int i = 0; i < 16; i++) s.state[i] = Fp::raw(sponge->state[i]);
+    s.absorb_idx = sponge->absorb_idx;
+    s.sample_idx = sponge->sample_idx;
+    if (s.absorb_idx >= 8 || s.sample_idx > 8) return (int)hipErrorInvalidValue;
+    static thread_local uint32_t *d_result = nullptr;
+    if (!d_result) OVM_CHECK(hipMalloc(&d_result, sizeof(uint32_t)));
+    // Expected 2^bits candidates per hit: scan in batches of that size, ascending, so the first
+    // batch with a hit yields the global minimum witness.
+    uint64_t batch = 1ull << (bits < 16 ? 16 : bits);
+    if (batch > (1ull << 24)) batch = 1ull << 24;
+    for (uint64_t base = 0; base < bb::P; base += batch) {
+        uint32_t init = 0xffffffffu;
+        OVM_CHECK(hipMemcpyAsync(d_result, &init, 4, hipMemcpyHostToDevice, stream));
+        uint32_t count = (uint32_t)((bb::P - base) < batch ? (bb::P - base) : batch);
+        hipLaunchKernelGGL(grind_kernel, dim3(ceil_div(count, HASH_THREADS)), dim3(HASH_THREADS), 0,
+                           stream, s, bits, (uint32_t)base, count, d_result);
+        OVM_CHECK_LAUNCH();
+        uint32_t found = 0;
+        OVM_CHECK(hipMemcpyAsync(&found, d_result, 4, hipMemcpyDeviceToHost, stream));
+        OVM_CHECK(hipStreamSynchronize(stream));
+        if (found != 0xffffffffu) {
+            *witness_out = found;
+            return 0;
+        }
+    }
+    return (int)hipErrorNotFound;
+}
+
+int ovm_hip_gather_rows(const uint32_t *d_matrix, uint64_t width, uint64_t col_stride,
+                        uint32_t words_per_elem, const uint64_t *d_row_idx, uint64_t n_rows,
+                        uint32_t *d_out, ovm_stream_t stream) {
+    uint64_t total = n_rows * width;
+    if (total == 0) return 0;
+    if (words_per_elem == 1)
+        hipLaunchKernelGGL(gather_rows_kernel<1>, dim3(ceil_div(total, 256)), dim3(256), 0,
+                           (hipStream_t)stream, (const Fp *)d_matrix, width, col_stride, d_row_idx,
+                           n_rows, (Fp *)d_out);
+    else if (words_per_elem == 4)
+        hipLaunchKernelGGL(gather_rows_kernel<4>, dim3(ceil_div(total, 256)), dim3(256), 0,
+                           (hipStream_t)stream, (const Fp *)d_matrix, width, col_stride, d_row_idx,
+                           n_rows, (Fp *)d_out);
+    else
+        return (int)hipErrorInvalidValue;
+    OVM_CHECK_LAUNCH();
+    return 0;
+}
+
+int ovm_hip_gather_digests(const uint32_t *d_layers, const uint64_t *d_idx, uint64_t n,
+                           uint32_t *d_out, ovm_stream_t stream) {
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(gather_digests_kernel, dim3(ceil_div(n, 256)), dim3(256), 0,
+                       (hipStream_t)stream, (const Digest *)d_layers, d_idx, n, (Digest *)d_out);
+    OVM_CHECK_LAUNCH();
+    return 0;
+}
+
+}  // extern "C"

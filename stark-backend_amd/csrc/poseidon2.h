@@ -1,0 +1,201 @@
+// Poseidon2-BabyBear, width 16, rate 8: permutation, row sponge, 2->1 compression and the
+// duplex-sponge Fiat-Shamir state. Host and gfx950 device code share this header; all values are
+// Montgomery words (bb31.h).
+//
+// Replaces (reference): crates/cuda-common/include/poseidon2.cuh:14-202 (constants, layers),
+// crates/cuda-backend/cuda/src/merkle_tree.cu:32-51,166-176 (row sponge / compress),
+// crates/cuda-backend/cuda/src/sponge.cu:24-62 and crates/stark-backend/src/transcript/
+// duplex_sponge.rs:62-83 (duplex sponge).
+//
+// CDNA4 notes: one lane owns one 16-word state in VGPRs (16 state + ~10 temps, well under the
+// 64-VGPR/8-waves-per-SIMD line); round constants are wave-uniform and compile to scalar
+// literals / s_load, costing no VALU issue. The external 4x4 circulant uses the additive form
+// (7 adds per 4 words); the internal diagonal uses halve/double/shift forms instead of
+// multiplies wherever the diagonal entry is +-2^k.
+#pragma once
+#include "bb31.h"
+
+namespace p2 {
+using bb::Fp;
+
+#define P2_M(x) bb::cx_to_mont(x)
+static constexpr uint32_t RC_INITIAL[64] = {
+    P2_M(1774958255), P2_M(1185780729), P2_M(1621102414), P2_M(1796380621), P2_M(588815102),
+    P2_M(1932426223), P2_M(1925334750), P2_M(747903232),  P2_M(89648862),   P2_M(360728943),
+    P2_M(977184635),  P2_M(1425273457), P2_M(256487465),  P2_M(1200041953), P2_M(572403254),
+    P2_M(448208942),  P2_M(1215789478), P2_M(944884184),  P2_M(953948096),  P2_M(547326025),
+    P2_M(646827752),  P2_M(889997530),  P2_M(1536873262), P2_M(86189867),   P2_M(1065944411),
+    P2_M(32019634),   P2_M(333311454),  P2_M(456061748),  P2_M(1963448500), P2_M(1827584334),
+    P2_M(1391160226), P2_M(1348741381), P2_M(88424255),   P2_M(104111868),  P2_M(1763866748),
+    P2_M(79691676),   P2_M(1988915530), P2_M(1050669594), P2_M(359890076),  P2_M(573163527),
+    P2_M(222820492),  P2_M(159256268),  P2_M(669703072),  P2_M(763177444),  P2_M(889367200),
+    P2_M(256335831),  P2_M(704371273),  P2_M(25886717),   P2_M(51754520),   P2_M(1833211857),
+    P2_M(454499742),  P2_M(1384520381), P2_M(777848065),  P2_M(1053320300), P2_M(1851729162),
+    P2_M(344647910),  P2_M(401996362),  P2_M(1046925956), P2_M(5351995),    P2_M(1212119315),
+    P2_M(754867989),  P2_M(36972490),   P2_M(751272725),  P2_M(506915399)};
+static constexpr uint32_t RC_TERMINAL[64] = {
+    P2_M(1922082829), P2_M(1870549801), P2_M(1502529704), P2_M(1990744480), P2_M(1700391016),
+    P2_M(1702593455), P2_M(321330495),  P2_M(528965731),  P2_M(183414327),  P2_M(1886297254),
+    P2_M(1178602734), P2_M(1923111974), P2_M(744004766),  P2_M(549271463),  P2_M(1781349648),
+    P2_M(542259047),  P2_M(1536158148), P2_M(715456982),  P2_M(503426110),  P2_M(340311124),
+    P2_M(1558555932), P2_M(1226350925), P2_M(742828095),  P2_M(1338992758), P2_M(1641600456),
+    P2_M(1843351545), P2_M(301835475),  P2_M(43203215),   P2_M(386838401),  P2_M(1520185679),
+    P2_M(1235297680), P2_M(904680097),  P2_M(1491801617), P2_M(1581784677), P2_M(913384905),
+    P2_M(247083962),  P2_M(532844013),  P2_M(107190701),  P2_M(213827818),  P2_M(1979521776),
+    P2_M(1358282574), P2_M(1681743681), P2_M(1867507480), P2_M(1530706910), P2_M(507181886),
+    P2_M(695185447),  P2_M(1172395131), P2_M(1250800299), P2_M(1503161625), P2_M(817684387),
+    P2_M(498481458),  P2_M(494676004),  P2_M(1404253825), P2_M(108246855),  P2_M(59414691),
+    P2_M(744214112),  P2_M(890862029),  P2_M(1342765939), P2_M(1417398904), P2_M(1897591937),
+    P2_M(1066647396), P2_M(1682806907), P2_M(1015795079), P2_M(1619482808)};
+static constexpr uint32_t RC_INTERNAL[13] = {
+    P2_M(1518359488), P2_M(1765533241), P2_M(945325693), P2_M(422793067), P2_M(311365592),
+    P2_M(1311448267), P2_M(1629555936), P2_M(1009879353), P2_M(190525218), P2_M(786108885),
+    P2_M(557776863),  P2_M(212616710),  P2_M(605745517)};
+#undef P2_M
+
+static constexpr int WIDTH = 16;
+static constexpr int RATE = 8;
+static constexpr int DIGEST = 8;
+
+BB_HD Fp sbox7(Fp x) {
+    Fp x2 = x * x;
+    Fp x3 = x2 * x;
+    Fp x4 = x2 * x2;
+    return x4 * x3;
+}
+
+// state <- M_E * state, M_E = circ(2*M4, M4, M4, M4), M4 = [2 3 1 1; 1 2 3 1; 1 1 2 3; 3 1 1 2]
+BB_HD void external_linear(Fp *s) {
+#pragma unroll
+    for (int b = 0; b < 4; b++) {
+        Fp *x = s + 4 * b;
+        Fp t01 = x[0] + x[1];
+        Fp t23 = x[2] + x[3];
+        Fp t0123 = t01 + t23;
+        Fp t01123 = t0123 + x[1];
+        Fp t01233 = t0123 + x[3];
+        x[3] = t01233 + x[0].dbl();
+        x[1] = t01123 + x[2].dbl();
+        x[0] = t01123 + t01;
+        x[2] = t01233 + t23;
+    }
+    Fp sums[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) sums[j] = (s[j] + s[4 + j]) + (s[8 + j] + s[12 + j]);
+#pragma unroll
+    for (int i = 0; i < 16; i++) s[i] += sums[i & 3];
+}
+
+// x * 2^-k for a Montgomery word: reduce (x << (32 - k)) -- a single Montgomery reduction, no
+// full multiply (reference: fp.h:205-214 mul_2exp_neg_n).
+template <int K>
+BB_HD Fp mul_2exp_neg(Fp x) {
+    return Fp::raw(bb::mont_reduce((uint64_t)x.v << (32 - K)));
+}
+
+// state <- (J + diag(V)) * state,
+// V = [-2, 1, 2, 1/2, 3, 4, -1/2, -3, -4, 1/2^8, 1/4, 1/8, 1/2^27, -1/2^8, -1/16, -1/2^27]
+BB_HD void internal_linear(Fp *s) {
+    Fp part = s[1];
+#pragma unroll
+    for (int i = 2; i < 16; i++) part += s[i];
+    Fp sum = part + s[0];
+    s[0] = part - s[0];
+    s[1] = sum + s[1];
+    s[2] = sum + s[2].dbl();
+    s[3] = sum + s[3].halve();
+    s[4] = sum + (s[4].dbl() + s[4]);
+    s[5] = sum + s[5].dbl().dbl();
+    s[6] = sum - s[6].halve();
+    s[7] = sum - (s[7].dbl() + s[7]);
+    s[8] = sum - s[8].dbl().dbl();
+    s[9] = sum + mul_2exp_neg<8>(s[9]);
+    s[10] = sum + s[10].halve().halve();
+    s[11] = sum + s[11].halve().halve().halve();
+    s[12] = sum + mul_2exp_neg<27>(s[12]);
+    s[13] = sum - mul_2exp_neg<8>(s[13]);
+    s[14] = sum - mul_2exp_neg<4>(s[14]);
+    s[15] = sum - mul_2exp_neg<27>(s[15]);
+}
+
+BB_HD void permute(Fp *s) {
+    external_linear(s);
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+#pragma unroll
+        for (int i = 0; i < 16; i++) s[i] = sbox7(s[i] + Fp::raw(RC_INITIAL[16 * r + i]));
+        external_linear(s);
+    }
+#pragma unroll
+    for (int r = 0; r < 13; r++) {
+        s[0] = sbox7(s[0] + Fp::raw(RC_INTERNAL[r]));
+        internal_linear(s);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+#pragma unroll
+        for (int i = 0; i < 16; i++) s[i] = sbox7(s[i] + Fp::raw(RC_TERMINAL[16 * r + i]));
+        external_linear(s);
+    }
+}
+
+struct Digest {
+    Fp d[8];
+};
+
+BB_HD Digest compress(const Digest &l, const Digest &r) {
+    Fp s[16];
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        s[i] = l.d[i];
+        s[8 + i] = r.d[i];
+    }
+    permute(s);
+    Digest o;
+#pragma unroll
+    for (int i = 0; i < 8; i++) o.d[i] = s[i];
+    return o;
+}
+
+// Overwrite-mode duplex sponge (transcript). POD so it can cross the C ABI and live on device.
+struct Sponge {
+    Fp state[16];
+    uint32_t absorb_idx;  // 0 <= absorb_idx < 8
+    uint32_t sample_idx;  // 0 <= sample_idx <= 8
+
+    BB_HD void init() {
+        for (int i = 0; i < 16; i++) state[i] = Fp::zero();
+        absorb_idx = 0;
+        sample_idx = 0;
+    }
+    BB_HD void observe(Fp x) {
+        state[absorb_idx++] = x;
+        if (absorb_idx == RATE) {
+            permute(state);
+            absorb_idx = 0;
+            sample_idx = RATE;
+        }
+    }
+    BB_HD Fp sample() {
+        if (absorb_idx != 0 || sample_idx == 0) {
+            permute(state);
+            absorb_idx = 0;
+            sample_idx = RATE;
+        }
+        return state[--sample_idx];
+    }
+    BB_HD void observe_ext(const bb::FpExt &x) {
+        for (int i = 0; i < 4; i++) observe(x.c[i]);
+    }
+    BB_HD bb::FpExt sample_ext() {
+        bb::FpExt r;
+        for (int i = 0; i < 4; i++) r.c[i] = sample();
+        return r;
+    }
+    BB_HD void observe_digest(const Digest &d) {
+        for (int i = 0; i < 8; i++) observe(d.d[i]);
+    }
+    BB_HD uint32_t sample_bits(unsigned bits) { return sample().canonical() & ((1u << bits) - 1); }
+};
+
+}  // namespace p2

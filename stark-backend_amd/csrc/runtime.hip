@@ -1,0 +1,65 @@
+// Library/device entry points: init, error names, device memory and streams.
+// Thin on purpose: callers that already own a HIP binding pass their own pointers and streams.
+// Replaces (reference): crates/cuda-common/src/{common,d_buffer,copy,stream,error}.rs and
+// crates/cuda-backend/cuda/src/device_info.cu.
+#include "device_ctx.h"
+#include "openvm_hip.h"
+
+extern "C" {
+
+uint32_t ovm_hip_abi_version(void) { return 1; }
+
+int ovm_hip_init(int device, uint32_t *cu_count) {
+    OVM_CHECK(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    OVM_CHECK(hipGetDeviceProperties(&prop, device));
+    if (cu_count) *cu_count = (uint32_t)prop.multiProcessorCount;
+    if (!ovm::twiddles()) return (int)hipErrorInitializationError;
+    return 0;
+}
+
+const char *ovm_hip_error_name(int code) { return hipGetErrorName((hipError_t)code); }
+
+int ovm_hip_malloc(void **d_ptr, size_t bytes) {
+    if (!d_ptr) return (int)hipErrorInvalidValue;
+    OVM_CHECK(hipMalloc(d_ptr, bytes ? bytes : 4));
+    return 0;
+}
+int ovm_hip_free(void *d_ptr) {
+    OVM_CHECK(hipFree(d_ptr));
+    return 0;
+}
+int ovm_hip_memcpy_h2d(void *d_dst, const void *src, size_t bytes, ovm_stream_t stream) {
+    OVM_CHECK(hipMemcpyAsync(d_dst, src, bytes, hipMemcpyHostToDevice, (hipStream_t)stream));
+    OVM_CHECK(hipStreamSynchronize((hipStream_t)stream));
+    return 0;
+}
+int ovm_hip_memcpy_d2h(void *dst, const void *d_src, size_t bytes, ovm_stream_t stream) {
+    OVM_CHECK(hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    OVM_CHECK(hipStreamSynchronize((hipStream_t)stream));
+    return 0;
+}
+int ovm_hip_memcpy_d2d(void *d_dst, const void *d_src, size_t bytes, ovm_stream_t stream) {
+    OVM_CHECK(hipMemcpyAsync(d_dst, d_src, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return 0;
+}
+int ovm_hip_memset(void *d_dst, int value, size_t bytes, ovm_stream_t stream) {
+    OVM_CHECK(hipMemsetAsync(d_dst, value, bytes, (hipStream_t)stream));
+    return 0;
+}
+int ovm_hip_stream_create(ovm_stream_t *stream) {
+    hipStream_t s;
+    OVM_CHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    *stream = (ovm_stream_t)s;
+    return 0;
+}
+int ovm_hip_stream_destroy(ovm_stream_t stream) {
+    OVM_CHECK(hipStreamDestroy((hipStream_t)stream));
+    return 0;
+}
+int ovm_hip_stream_synchronize(ovm_stream_t stream) {
+    OVM_CHECK(hipStreamSynchronize((hipStream_t)stream));
+    return 0;
+}
+
+}  // extern "C"
