@@ -87,6 +87,10 @@ def _lib():
             raise ImportError(
                 f"{LIB_PATH} is missing: build it with stark-backend_amd/build.sh "
                 "(or __graft_entry__.build()). There is no CPU fallback.")
+        # PyTorch ships its own HIP runtime; load it first so that this library binds to the same
+        # libamdhip64 (two runtimes in one process do not see each other's devices).
+        import torch  # noqa: F401
+
         lib = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)  # AttributeError if the ABI drifted from the header
