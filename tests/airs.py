@@ -1,0 +1,321 @@
+"""Test AIRs and the proving-key blob (test infrastructure).
+
+Restates, in Python, the reference's symbolic pipeline just far enough to produce the inputs of
+the prove hot path for the reference's own fixture AIRs:
+  * SymbolicExpression ops and degree tracking  crates/stark-backend/src/air_builders/symbolic/symbolic_expression.rs:22-330
+  * DAG builder with dedup + simplifications    crates/stark-backend/src/air_builders/symbolic/dag.rs:95-330
+  * FibonacciAir                                crates/stark-backend/src/test_utils/dummy_airs/fib_air/air.rs:26-52
+  * DummyInteractionAir (sender / receiver)     .../dummy_airs/interaction/dummy_interaction_air.rs:101-131
+  * BenchmarkAir (uniform_runner)               benchmarks/synthetic/src/bin/uniform_runner.rs:79-113
+  * production / test SystemParams              crates/stark-sdk/src/config/mod.rs:121-138, crates/stark-backend/src/config.rs:286-353
+The blob is the flat u32 encoding both the oracle C API and the product C ABI accept
+(include/openvm_hip.h, "proving-key blob").
+"""
+import math
+
+import numpy as np
+
+P = 2013265921
+
+N_VAR, N_IS_FIRST, N_IS_LAST, N_IS_TRANSITION, N_CONST, N_ADD, N_SUB, N_NEG, N_MUL = range(9)
+E_PREP, E_MAIN, E_PUBLIC = 0, 1, 2
+
+
+class Expr:
+    """SymbolicExpression: no folding at this level, only degree tracking."""
+
+    def __init__(self, kind, deg, **kw):
+        self.kind, self.deg = kind, deg
+        self.__dict__.update(kw)
+
+    @staticmethod
+    def lift(x):
+        return x if isinstance(x, Expr) else Expr(N_CONST, 0, value=int(x) % P)
+
+    def __add__(self, o):
+        o = Expr.lift(o)
+        return Expr(N_ADD, max(self.deg, o.deg), x=self, y=o)
+
+    def __sub__(self, o):
+        o = Expr.lift(o)
+        return Expr(N_SUB, max(self.deg, o.deg), x=self, y=o)
+
+    def __mul__(self, o):
+        o = Expr.lift(o)
+        return Expr(N_MUL, self.deg + o.deg, x=self, y=o)
+
+    def __neg__(self):
+        return Expr(N_NEG, self.deg, x=self)
+
+    __radd__ = lambda self, o: Expr.lift(o) + self
+    __rsub__ = lambda self, o: Expr.lift(o) - self
+    __rmul__ = lambda self, o: Expr.lift(o) * self
+
+
+def var(entry, index, part_index=0, offset=0):
+    return Expr(N_VAR, 1 if entry != E_PUBLIC else 0, entry=entry, index=index,
+                part_index=part_index, offset=offset)
+
+
+IS_FIRST = lambda: Expr(N_IS_FIRST, 1)
+IS_LAST = lambda: Expr(N_IS_LAST, 1)
+IS_TRANSITION = lambda: Expr(N_IS_TRANSITION, 1)
+ONE = lambda: Expr(N_CONST, 0, value=1)
+NEG_ONE = lambda: Expr(N_CONST, 0, value=P - 1)
+
+
+class DagBuilder:
+    """dag.rs:143-330"""
+
+    def __init__(self):
+        self.expr_to_idx, self.node_to_idx, self.nodes = {}, {}, []
+
+    def intern(self, node):
+        if node not in self.node_to_idx:
+            self.node_to_idx[node] = len(self.nodes)
+            self.nodes.append(node)
+        return self.node_to_idx[node]
+
+    def const_of(self, idx):
+        n = self.nodes[idx]
+        return n[1] if n[0] == N_CONST else None
+
+    def neg_child(self, idx):
+        n = self.nodes[idx]
+        return n[1] if n[0] == N_NEG else None
+
+    def add(self, e):
+        if id(e) in self.expr_to_idx:
+            return self.expr_to_idx[id(e)]
+        k = e.kind
+        if k == N_VAR:
+            idx = self.intern((N_VAR, e.entry, e.part_index, e.offset, e.index))
+        elif k in (N_IS_FIRST, N_IS_LAST, N_IS_TRANSITION):
+            idx = self.intern((k,))
+        elif k == N_CONST:
+            idx = self.intern((N_CONST, e.value))
+        elif k == N_NEG:
+            c = self.add(e.x)
+            cv = self.const_of(c)
+            idx = self.intern((N_CONST, (-cv) % P)) if cv is not None else self.intern((N_NEG, c))
+        else:
+            l, r = self.add(e.x), self.add(e.y)
+            a, b = self.const_of(l), self.const_of(r)
+            if k == N_ADD:
+                if a is not None and b is not None:
+                    idx = self.intern((N_CONST, (a + b) % P))
+                elif a == 0:
+                    idx = r
+                elif b == 0:
+                    idx = l
+                elif self.neg_child(r) is not None:
+                    idx = self.intern((N_SUB, l, self.neg_child(r)))
+                else:
+                    idx = self.intern((N_ADD, l, r))
+            elif k == N_SUB:
+                if a is not None and b is not None:
+                    idx = self.intern((N_CONST, (a - b) % P))
+                elif b == 0:
+                    idx = l
+                elif self.neg_child(r) is not None:
+                    idx = self.intern((N_ADD, l, self.neg_child(r)))
+                else:
+                    idx = self.intern((N_SUB, l, r))
+            else:
+                if a is not None and b is not None:
+                    idx = self.intern((N_CONST, a * b % P))
+                elif a == 0 or b == 1:
+                    idx = l
+                elif b == 0 or a == 1:
+                    idx = r
+                else:
+                    idx = self.intern((N_MUL, l, r))
+        self.expr_to_idx[id(e)] = idx
+        self._keep = getattr(self, "_keep", [])
+        self._keep.append(e)  # keep ids unique for the builder's lifetime
+        return idx
+
+
+class Air:
+    """Collects constraints / interactions like SymbolicRapBuilder (symbolic/mod.rs:99-258)."""
+
+    def __init__(self, name, common_main_width, num_public_values=0, is_required=True):
+        self.name, self.width, self.num_pvs, self.is_required = name, common_main_width, num_public_values, is_required
+        self.constraints, self.interactions = [], []
+
+    # AirBuilder surface
+    def local(self, i):
+        return var(E_MAIN, i, 0, 0)
+
+    def next(self, i):
+        return var(E_MAIN, i, 0, 1)
+
+    def public(self, i):
+        return var(E_PUBLIC, i)
+
+    def assert_zero(self, x, when=None):
+        x = Expr.lift(x)
+        self.constraints.append(when * x if when is not None else x)
+
+    def assert_eq(self, x, y, when=None):
+        self.assert_zero(Expr.lift(x) - Expr.lift(y), when)
+
+    def assert_bool(self, x):
+        self.assert_zero(x * (x - ONE()))  # p3-field bool_check
+
+    def push_interaction(self, bus, fields, count, count_weight=0):
+        self.interactions.append((bus, [Expr.lift(f) for f in fields], Expr.lift(count), count_weight))
+
+    def finish(self):
+        """build_symbolic_constraints_dag (dag.rs:95-129) + vk facts (keygen/mod.rs:262-310)."""
+        b = DagBuilder()
+        cidx = sorted(set(b.add(c) for c in self.constraints))
+        inter = []
+        for bus, fields, count, cw in self.interactions:
+            msg = [b.add(f) for f in fields]
+            cnt = b.add(count)
+            inter.append((bus, cw, cnt, msg))
+        degs = [c.deg for c in self.constraints]
+        for _, fields, count, _ in self.interactions:
+            degs += [count.deg] + [f.deg for f in fields]
+        need_rot = any(n[0] == N_VAR and n[1] != E_PUBLIC and n[3] > 0 for n in b.nodes)
+        return dict(name=self.name, nodes=list(b.nodes), constraint_idx=cidx, interactions=inter,
+                    need_rot=need_rot, is_required=self.is_required,
+                    max_constraint_degree=max(degs) if degs else 0, num_public_values=self.num_pvs,
+                    common_main_width=self.width)
+
+
+# ---------------------------------------------------------------------------------------------
+def fibonacci_air():
+    a = Air("FibonacciAir", 2, num_public_values=3)
+    pa, pb, px = a.public(0), a.public(1), a.public(2)
+    a.assert_eq(a.local(0), pa, when=IS_FIRST())
+    a.assert_eq(a.local(1), pb, when=IS_FIRST())
+    a.assert_eq(a.local(1), a.next(0), when=IS_TRANSITION())
+    a.assert_eq(a.local(0) + a.local(1), a.next(1), when=IS_TRANSITION())
+    a.assert_eq(a.local(1), px, when=IS_LAST())
+    return a.finish()
+
+
+def fibonacci_trace(a, b, n):
+    rows = [[a % P, b % P]]
+    for _ in range(1, n):
+        rows.append([rows[-1][1], (rows[-1][0] + rows[-1][1]) % P])
+    m = np.array(rows, dtype=np.uint32)          # n x 2
+    return np.ascontiguousarray(m.T).reshape(-1), [a % P, b % P, int(m[-1][1])]
+
+
+def dummy_interaction_air(field_width, is_send, bus):
+    a = Air("DummyInteractionAir", 1 + field_width)
+    count = a.local(0)
+    fields = [a.local(1 + i) for i in range(field_width)]
+    if is_send:
+        a.push_interaction(bus, fields, count)
+    else:
+        a.push_interaction(bus, fields, NEG_ONE() * count)
+    return a.finish()
+
+
+def benchmark_air(num_columns, total_constraints, total_interaction_pairs):
+    a = Air("BenchmarkAir", num_columns)
+    for i in range(total_constraints):
+        a.assert_bool(a.local(i % num_columns))
+    for i in range(total_interaction_pairs):
+        a.push_interaction(0, [a.local(i % num_columns)], ONE())
+        a.push_interaction(0, [a.local(i % num_columns)], NEG_ONE())
+    return a.finish()
+
+
+def uniform_runner_air(cols, constraints_per_col=2.0, interactions_per_col=0.25):
+    """uniform_runner.rs:196-199"""
+    rnd = lambda x: int(math.floor(x + 0.5))  # f64::round (half away from zero)
+    return benchmark_air(cols, rnd(constraints_per_col * cols), rnd(interactions_per_col * cols / 2.0))
+
+
+def splitmix64_bits(seed, n):
+    """Seeded boolean trace (SURVEY §8d config D value distribution R)."""
+    out = np.empty(n, dtype=np.uint32)
+    x = seed & 0xFFFFFFFFFFFFFFFF
+    i = 0
+    while i < n:
+        x = (x + 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF
+        z = x
+        z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & 0xFFFFFFFFFFFFFFFF
+        z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & 0xFFFFFFFFFFFFFFFF
+        z ^= z >> 31
+        k = min(64, n - i)
+        out[i:i + k] = [(z >> b) & 1 for b in range(k)]
+        i += k
+    return out
+
+
+# ---------------------------------------------------------------------------------------------
+def whir_num_queries(log_blowup, log_stacked_height, k_whir, log_final_poly_len, security_bits,
+                     query_phase_pow_bits):
+    """WhirConfig::new, unique-decoding regime (config.rs:286-353)."""
+    protocol = max(security_bits - query_phase_pow_bits, 0)
+    num_rounds = -(-max(log_stacked_height - log_final_poly_len, 0) // k_whir)
+    out, log_inv_rate = [], log_blowup
+    for _ in range(num_rounds):
+        rho = 2.0 ** (-log_inv_rate)
+        per_query = -math.log2((1.0 + rho) / 2.0)
+        out.append(math.ceil(protocol / per_query))
+        log_inv_rate += k_whir - 1
+    return out
+
+
+def make_params(l_skip, n_stack, log_blowup, k_whir, log_final_poly_len, security_bits,
+                mu_pow_bits, folding_pow_bits, query_phase_pow_bits, logup_pow_bits,
+                max_constraint_degree, w_stack):
+    return dict(l_skip=l_skip, n_stack=n_stack, w_stack=w_stack, log_blowup=log_blowup, k_whir=k_whir,
+                mu_pow_bits=mu_pow_bits, query_phase_pow_bits=query_phase_pow_bits,
+                folding_pow_bits=folding_pow_bits, logup_pow_bits=logup_pow_bits,
+                max_constraint_degree=max_constraint_degree,
+                whir_num_queries=whir_num_queries(log_blowup, l_skip + n_stack, k_whir,
+                                                  log_final_poly_len, security_bits, query_phase_pow_bits))
+
+
+def app_params(log_stacked_height):
+    """app_params_with_100_bits_security (stark-sdk/src/config/mod.rs:121-138): l_skip 4,
+    log_blowup 1, k_whir 4, w_stack 2048, pow bits 5/15/20, logup pow 18, max degree 3."""
+    return make_params(4, max(log_stacked_height - 4, 0), 1, 4, 10, 100, 15, 5, 20, 18, 3, 2048)
+
+
+def test_params(l_skip=2, n_stack=8, k_whir=3, log_blowup=1, max_constraint_degree=3):
+    """Toy parameters in the spirit of test_utils/mod.rs:517-583 (security 5 bits, pow 1/2/3,
+    logup pow 2)."""
+    return make_params(l_skip, n_stack, log_blowup, k_whir, 2, 5, 1, 2, 3, 2, max_constraint_degree, 4096)
+
+
+MAGIC = 0x4F564D31
+
+
+def pk_blob(params, airs, vk_pre_hash=None):
+    """Flat u32 proving-key blob (field constants canonical)."""
+    w = [MAGIC, params["l_skip"], params["n_stack"], params["w_stack"], params["log_blowup"],
+         params["k_whir"], params["mu_pow_bits"], params["query_phase_pow_bits"],
+         params["folding_pow_bits"], params["logup_pow_bits"], params["max_constraint_degree"],
+         len(params["whir_num_queries"])] + list(params["whir_num_queries"])
+    w += list(vk_pre_hash) if vk_pre_hash is not None else [(7 * i + 1) % P for i in range(8)]
+    w.append(len(airs))
+    for a in airs:
+        w += [int(a["need_rot"]), int(a["is_required"]), a["max_constraint_degree"],
+              a["num_public_values"], 0, 0, 0, a["common_main_width"], len(a["nodes"])]
+        for n in a["nodes"]:
+            k = n[0]
+            if k == N_VAR:
+                w += [k, n[1], n[2], n[3], n[4], 0]
+            elif k == N_CONST:
+                w += [k, 0, 0, 0, n[1], 0]
+            elif k == N_NEG:
+                w += [k, 0, 0, 0, n[1], 0]
+            elif k in (N_ADD, N_SUB, N_MUL):
+                w += [k, 0, 0, 0, n[1], n[2]]
+            else:
+                w += [k, 0, 0, 0, 0, 0]
+        w.append(len(a["constraint_idx"]))
+        w += a["constraint_idx"]
+        w.append(len(a["interactions"]))
+        for bus, cw, cnt, msg in a["interactions"]:
+            w += [bus, cw, cnt, len(msg)] + msg
+    return np.array(w, dtype=np.uint32)

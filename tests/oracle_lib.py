@@ -148,3 +148,45 @@ class OracleTranscript:
         s = c_uint32(0)
         self.lib.orc_transcript_state(self.h, _p(st), ctypes.byref(a), ctypes.byref(s))
         return st, a.value, s.value
+
+
+def _prove(self, blob, traces, proof_cap=1 << 26):
+    """traces: list of (air_idx, canonical col-major flat u32 trace, height, public values list).
+    Returns dict(proof=bytes, root, r, u, pow)."""
+    lib = self.lib
+    n = len(traces)
+    blob = np.ascontiguousarray(blob, dtype=np.uint32)
+    arrs = [np.ascontiguousarray(t[1], dtype=np.uint32) for t in traces]
+    pvs = [np.ascontiguousarray(t[3], dtype=np.uint32) if len(t[3]) else np.zeros(1, np.uint32) for t in traces]
+    air_idx = np.array([t[0] for t in traces], dtype=np.uint32)
+    heights = np.array([t[2] for t in traces], dtype=np.uint64)
+    npv = np.array([len(t[3]) for t in traces], dtype=np.uint32)
+    tptr = (c_void_p * n)(*[a.ctypes.data for a in arrs])
+    pptr = (c_void_p * n)(*[a.ctypes.data for a in pvs])
+    out = np.zeros(proof_cap, dtype=np.uint8)
+    plen = c_uint64(0)
+    root = np.zeros(8, np.uint32)
+    r = np.zeros(4 * 64, np.uint32); u = np.zeros(4 * 64, np.uint32); pw = np.zeros(256, np.uint32)
+    rl = c_uint32(0); ul = c_uint32(0); pl = c_uint32(0)
+    lib.orc_last_error.restype = ctypes.c_char_p
+    rc = lib.orc_prove(_p(blob), c_uint64(blob.size), c_uint32(n), _p(air_idx), tptr, _p(heights), pptr,
+                       _p(npv), _p(out), c_uint64(proof_cap), ctypes.byref(plen), _p(root), _p(r),
+                       ctypes.byref(rl), _p(u), ctypes.byref(ul), _p(pw), ctypes.byref(pl))
+    if rc != 0:
+        raise RuntimeError("orc_prove: " + lib.orc_last_error().decode())
+    return dict(proof=out[:plen.value].tobytes(), root=root, r=r[:4 * rl.value].reshape(-1, 4),
+                u=u[:4 * ul.value].reshape(-1, 4), pow=pw[:pl.value].copy())
+
+
+def _verify(self, blob, proof: bytes):
+    lib = self.lib
+    blob = np.ascontiguousarray(blob, dtype=np.uint32)
+    buf = np.frombuffer(proof, dtype=np.uint8)
+    lib.orc_last_error.restype = ctypes.c_char_p
+    rc = lib.orc_verify(_p(blob), c_uint64(blob.size), _p(buf), c_uint64(buf.size))
+    if rc != 0:
+        raise RuntimeError("orc_verify: " + lib.orc_last_error().decode())
+
+
+Oracle.prove = _prove
+Oracle.verify = _verify

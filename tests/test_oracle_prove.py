@@ -1,0 +1,81 @@
+"""CPU tests: the oracle PROVER's proofs are accepted by the oracle VERIFIER (an independent
+restatement of the reference verifier), for the reference's fixture AIRs; tampering is rejected."""
+import numpy as np
+import pytest
+
+import airs
+
+P = airs.P
+
+
+def fib_case(log_h, params):
+    air = airs.fibonacci_air()
+    tr, pvs = airs.fibonacci_trace(0, 1, 1 << log_h)
+    return airs.pk_blob(params, [air]), [(0, tr, 1 << log_h, pvs)]
+
+
+def test_fibonacci_dag_shape():
+    air = airs.fibonacci_air()
+    assert air["need_rot"] and air["max_constraint_degree"] == 2
+    assert len(air["constraint_idx"]) == 5 and air["num_public_values"] == 3
+
+
+def test_benchmark_air_dedups_constraints():
+    # uniform_runner: 200 assert_bool on 100 columns collapse to 100 constraints (dag.rs:99-100)
+    air = airs.uniform_runner_air(100)
+    assert len(air["constraint_idx"]) == 100 and len(air["interactions"]) == 26
+    assert air["max_constraint_degree"] == 2 and not air["need_rot"]
+
+
+@pytest.mark.parametrize("log_h,l_skip,n_stack,k_whir", [(4, 2, 4, 2), (6, 2, 6, 3), (5, 3, 5, 2), (1, 2, 3, 1)])
+def test_fibonacci_prove_verify(orc, log_h, l_skip, n_stack, k_whir):
+    params = airs.test_params(l_skip=l_skip, n_stack=n_stack, k_whir=k_whir)
+    blob, traces = fib_case(log_h, params)
+    out = orc.prove(blob, traces)
+    orc.verify(blob, out["proof"])
+    # deterministic
+    assert orc.prove(blob, traces)["proof"] == out["proof"]
+
+
+def test_interactions_prove_verify(orc):
+    """Sender/receiver pair in the shape of InteractionsFixture11 (test_utils/mod.rs:218-255)."""
+    params = airs.test_params(l_skip=2, n_stack=5, k_whir=2)
+    sender = airs.dummy_interaction_air(1, True, 0)
+    receiver = airs.dummy_interaction_air(1, False, 0)
+    s = np.array([[0, 1], [7, 4], [3, 5], [546, 889]], dtype=np.uint32)          # count, field
+    r = np.array([[1, 5], [3, 4], [4, 4], [2, 5], [0, 123], [545, 889], [1, 889], [0, 456]], dtype=np.uint32)
+    blob = airs.pk_blob(params, [sender, receiver])
+    traces = [(0, np.ascontiguousarray(s.T).reshape(-1), 4, []), (1, np.ascontiguousarray(r.T).reshape(-1), 8, [])]
+    out = orc.prove(blob, traces)
+    orc.verify(blob, out["proof"])
+
+
+def test_benchmark_air_prove_verify_and_tamper(orc):
+    params = airs.test_params(l_skip=2, n_stack=6, k_whir=2)
+    air = airs.uniform_runner_air(8)
+    h = 1 << 5
+    tr = airs.splitmix64_bits(0xD15EA5E, 8 * h)
+    blob = airs.pk_blob(params, [air])
+    out = orc.prove(blob, [(0, tr, h, [])])
+    orc.verify(blob, out["proof"])
+    bad = bytearray(out["proof"])
+    bad[len(bad) // 2] ^= 1
+    with pytest.raises(RuntimeError):
+        orc.verify(blob, bytes(bad))
+    # a trace violating the boolean constraints yields a proof the verifier rejects
+    tr2 = tr.copy(); tr2[3] = 2
+    bad_proof = orc.prove(blob, [(0, tr2, h, [])])["proof"]
+    with pytest.raises(RuntimeError):
+        orc.verify(blob, bad_proof)
+
+
+def test_multi_air_mixed_heights(orc):
+    params = airs.test_params(l_skip=2, n_stack=6, k_whir=2)
+    fib = airs.fibonacci_air()
+    bench = airs.uniform_runner_air(8)
+    t1, pv = airs.fibonacci_trace(0, 1, 16)
+    t2 = airs.splitmix64_bits(1, 8 * 64)
+    t3 = airs.splitmix64_bits(2, 8 * 2)        # height 2 < 2^l_skip: lifted trace
+    blob = airs.pk_blob(params, [fib, bench, bench])
+    out = orc.prove(blob, [(0, t1, 16, pv), (1, t2, 64, []), (2, t3, 2, [])])
+    orc.verify(blob, out["proof"])
