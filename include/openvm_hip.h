@@ -142,6 +142,52 @@ int ovm_hip_gather_rows(const uint32_t *d_matrix, uint64_t width, uint64_t col_s
 int ovm_hip_gather_digests(const uint32_t *d_layers, const uint64_t *d_idx, uint64_t n,
                            uint32_t *d_out, ovm_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------
+ * Proving key and the prove entry point
+ * ------------------------------------------------------------------------------------- */
+
+/* Device-side proving key. Replaces `DeviceMultiStarkProvingKey<GpuBackend>` as produced by
+ * `transport_pk_to_device` (reference: crates/stark-backend/src/prover/hal.rs:141-160,
+ * crates/cuda-backend/src/data_transporter.rs:35-79). */
+typedef struct ovm_pk_t ovm_pk_t;
+
+/* Builds a proving key from the flat u32 "proving-key blob" (all field constants CANONICAL):
+ *   0x4F564D31, l_skip, n_stack, w_stack, log_blowup, k_whir, mu_pow_bits, query_phase_pow_bits,
+ *   folding_pow_bits, logup_pow_bits, max_constraint_degree, num_whir_rounds, num_queries[rounds],
+ *   vk_pre_hash[8], num_airs, then per AIR:
+ *     need_rot, is_required, max_constraint_degree, num_public_values, has_preprocessed,
+ *     preprocessed_width, num_cached, cached_width[num_cached], common_main_width,
+ *     num_nodes, nodes[num_nodes] as 6 words (kind, entry, part_index, offset, x, y) with
+ *       kind: 0 Variable, 1 IsFirstRow, 2 IsLastRow, 3 IsTransition, 4 Constant, 5 Add, 6 Sub,
+ *             7 Neg, 8 Mul (reference: crates/stark-backend/src/air_builders/symbolic/dag.rs:20-47);
+ *       entry: 0 Preprocessed, 1 Main, 2 Public (symbolic_variable.rs:13-27);
+ *       x = column index | constant value | left node, y = right node;
+ *     num_constraints, constraint_idx[], num_interactions, then per interaction
+ *     bus_index, count_weight, count_node, message_len, message_nodes[].
+ * This is what the Rust side serialises from `MultiStarkProvingKey::get_vk()` plus `vk_pre_hash`.
+ * Returns hipErrorNotSupported for preprocessed / cached traces (not built yet). */
+int ovm_hip_pk_load(const uint32_t *blob, uint64_t words, ovm_pk_t **pk_out);
+void ovm_hip_pk_free(ovm_pk_t *pk);
+/* Message of the last failing call on this thread (empty if none). */
+const char *ovm_hip_last_error(void);
+
+/* `Coordinator::prove` for traces already resident on the device (reference:
+ * crates/stark-backend/src/prover/mod.rs:104-197 driving hal.rs:84-138): commits the common main
+ * traces, proves the constraints (LogUp-GKR + batch sumcheck) and the openings (stacked reduction
+ * + WHIR), and writes the proof in the reference's canonical byte encoding
+ * (crates/stark-backend/src/proof.rs:226-421) -- `Proof::decode_from_bytes` reads it.
+ *   d_traces[i]: column-major Montgomery words, heights[i] rows (power of two) x the AIR's width.
+ *   public_values[i]: num_public_values[i] Montgomery words (host).
+ *   sponge: transcript state, updated in place (NULL = fresh transcript).
+ *   section_offsets5 (optional): byte offsets of the ends of header / GKR / batch-constraint /
+ *   stacking / WHIR sections.
+ * PoW witnesses are the minimum valid ones. Synchronises the stream. */
+int ovm_hip_prove(const ovm_pk_t *pk, uint32_t n_traces, const uint32_t *air_idx,
+                  const uint32_t *const *d_traces, const uint64_t *heights,
+                  const uint32_t *const *public_values, const uint32_t *num_public_values,
+                  ovm_sponge_t *sponge, uint8_t *proof_out, uint64_t proof_cap, uint64_t *proof_len,
+                  uint64_t *section_offsets5, ovm_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

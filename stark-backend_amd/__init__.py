@@ -76,6 +76,11 @@ SIGNATURES = {
     "ovm_hip_gather_rows": (c_int, [c_void_p, c_uint64, c_uint64, c_uint32, c_void_p, c_uint64,
                                     c_void_p, c_void_p]),
     "ovm_hip_gather_digests": (c_int, [c_void_p, c_void_p, c_uint64, c_void_p, c_void_p]),
+    "ovm_hip_pk_load": (c_int, [c_void_p, c_uint64, POINTER(c_void_p)]),
+    "ovm_hip_pk_free": (None, [c_void_p]),
+    "ovm_hip_last_error": (c_char_p, []),
+    "ovm_hip_prove": (c_int, [c_void_p, c_uint32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                              POINTER(SpongeState), c_void_p, c_uint64, _u64p, _u64p, c_void_p]),
 }
 
 
@@ -220,3 +225,49 @@ class Device:
         check(_lib().ovm_hip_sponge_grind(ctypes.byref(sponge), bits, ctypes.byref(w), self.stream),
               "ovm_hip_sponge_grind")
         return w.value
+
+
+# ---------------------------------------------------------------------------------------------
+# Proving key + prove (mirrors StarkEngine::prove / Coordinator::prove on resident traces)
+# ---------------------------------------------------------------------------------------------
+class ProvingKey:
+    """Device proving key built from the flat u32 blob (see include/openvm_hip.h)."""
+
+    def __init__(self, blob: np.ndarray):
+        b = np.ascontiguousarray(blob, dtype=np.uint32)
+        h = c_void_p(0)
+        check(_lib().ovm_hip_pk_load(b.ctypes.data, b.size, ctypes.byref(h)), "ovm_hip_pk_load")
+        self.handle = h
+
+    def __del__(self):
+        try:
+            if self.handle:
+                _lib().ovm_hip_pk_free(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+
+def _prove(self, pk: ProvingKey, traces, sponge: SpongeState | None = None, proof_cap: int = 1 << 26):
+    """traces: list of (air_idx, device int32 tensor [column-major Montgomery], height,
+    public values as canonical ints). Returns (proof bytes, section end offsets)."""
+    n = len(traces)
+    air_idx = np.array([t[0] for t in traces], dtype=np.uint32)
+    heights = np.array([t[2] for t in traces], dtype=np.uint64)
+    pvs = [to_mont(np.array(t[3], dtype=np.uint32)) if len(t[3]) else np.zeros(1, np.uint32) for t in traces]
+    npv = np.array([len(t[3]) for t in traces], dtype=np.uint32)
+    tptr = (c_void_p * n)(*[t[1].data_ptr() for t in traces])
+    pptr = (c_void_p * n)(*[a.ctypes.data for a in pvs])
+    out = np.zeros(proof_cap, dtype=np.uint8)
+    plen = c_uint64(0)
+    secs = (c_uint64 * 5)()
+    rc = _lib().ovm_hip_prove(pk.handle, n, air_idx.ctypes.data, tptr, heights.ctypes.data, pptr,
+                              npv.ctypes.data, ctypes.byref(sponge) if sponge is not None else None,
+                              out.ctypes.data, proof_cap, ctypes.byref(plen), secs, self.stream)
+    if rc != 0:
+        msg = _lib().ovm_hip_last_error()
+        raise OvmError(rc, f"ovm_hip_prove [{msg.decode() if msg else ''}]")
+    return out[:plen.value].tobytes(), [int(x) for x in secs]
+
+
+Device.prove = _prove

@@ -1,0 +1,96 @@
+// Internal launch API of the sumcheck-stage kernels (stages.hip). All pointers are device
+// pointers unless noted; extension-field buffers are 16-byte aligned arrays of [u32;4].
+#pragma once
+#include "device_ctx.h"
+#include "program.h"
+
+namespace ovm {
+
+// A column of a trace view: value(p) = ptr[(p + rot) & (2^log_height - 1)]  (cyclic lift).
+struct ColDesc {
+    const Fp *ptr;
+    uint32_t log_height;
+    uint32_t rot;
+};
+
+struct Frac {
+    EF p, q;
+};
+
+struct DevProgram {
+    const Instr *code;
+    uint32_t n_instr;
+    uint32_t num_slots;
+    const EF *weights;
+};
+
+static constexpr unsigned MAX_COSETS = 4;
+static constexpr unsigned RED_BLOCKS = 1024;  // grid size of the partial-sum kernels
+static constexpr unsigned RED_THREADS = 256;
+
+// out[k] = sum_b partials[b * K + k]
+int sum_partials(const EF *partials, uint32_t n_blocks, uint32_t K, EF *out, hipStream_t s);
+
+int build_selectors(Fp *sels, uint32_t log_lifted, uint32_t log_height, hipStream_t s);
+int eq_table(const EF *d_point, uint32_t n, EF *out, hipStream_t s);  // out[y] = prod_i (y_i ? x_i : 1-x_i)
+int mobius_eq_table(const EF *d_point, uint32_t n, EF *out, hipStream_t s);
+
+// Coset low-degree extension of the used columns of one trace view.
+//   lde[(k * n_cols_total + col) << log_lifted | p] for k < n_cosets, col in used_cols
+int coset_lde(const ColDesc *d_cols, const uint32_t *d_used, uint32_t n_used, uint32_t n_cols_total,
+              uint32_t log_lifted, uint32_t l_skip, uint32_t n_cosets, const Fp *d_shift_pows, Fp *lde,
+              hipStream_t s);
+
+// Round 0: out[((k * n_out) + o) * N + z] = sum_x eq_xi[x] * program_o(lde_k row (x<<l)+z) (+ add_const for o==1)
+int round0_eval(const DevProgram &prog, const Fp *lde, uint32_t n_cols_total, uint32_t log_lifted, uint32_t l_skip,
+                uint32_t n_cosets, uint32_t n_out, const EF *d_eq_xi, EF add_const, EF *d_partials, EF *d_out,
+                hipStream_t s);
+
+// out[col * (lifted >> l) + x] = sum_z w[z] * col(( x << l) + z)
+int fold_ple(const ColDesc *d_cols, uint32_t n_cols, uint32_t log_lifted, uint32_t l_skip, const EF *d_weights,
+             EF *out, hipStream_t s);
+
+// MLE round on folded EF matrices (n_cols x 2^log_h, column-major):
+//   out[(X-1) * n_out + o] = sum_y eq[y] * program_o(row interpolated at X from rows 2y, 2y+1)
+int mle_round_eval(const DevProgram &prog, const EF *mats, uint32_t n_cols, uint32_t log_h, uint32_t degree,
+                   uint32_t n_out, const EF *d_eq, EF add_const, EF *d_partials, EF *d_out, hipStream_t s);
+
+// out[c * h/2 + y] = in[c*h + 2y] + r * (in[c*h + 2y + 1] - in[c*h + 2y])
+int fold_mle(const EF *in, EF *out, uint32_t n_cols, uint32_t log_h, EF r, hipStream_t s);
+
+// ---- LogUp GKR ----
+int gkr_fill_leaves(Frac *leaves, uint64_t n, EF alpha, hipStream_t s);
+int gkr_eval_leaves(const DevProgram &prog, const EF *d_leaf_const, const ColDesc *d_cols, uint32_t log_height,
+                    const uint64_t *d_leaf_base, const uint32_t *d_leaf_log_len, Fp norm, Frac *leaves,
+                    hipStream_t s);
+int gkr_build_layer(const Frac *child, Frac *parent, uint64_t n_parent, hipStream_t s);
+// records: 4 EF per x (p0,q0,p1,q1); eq: 1 EF per x. n_pairs = number of y.
+int gkr_round(const EF *rec, const EF *eq, uint64_t n_pairs, EF lambda, EF *d_partials, EF *d_out, hipStream_t s);
+int gkr_fold(const EF *rec_in, const EF *eq_in, EF *rec_out, EF *eq_out, uint64_t n_out, EF r, hipStream_t s);
+
+// ---- stacked reduction ----
+// R[v * N + z] for v in {eq, rot1, rot2} over one window of `n_slices` contiguous slices of
+// 2^log_len rows each starting at `base`.
+int stacked_round0(const Fp *base, uint32_t n_slices, uint32_t log_len, uint32_t l_skip, const EF *d_lam_eq,
+                   const EF *d_lam_rot, const EF *d_eq_cube, EF *d_partials, EF *d_out, hipStream_t s);
+// Q[v][x] = sum_i coef_v[i] * q[(col_i * h + row_i + x)] for v in {eq, rot}
+int stacked_combine(const EF *q, const uint64_t *d_slice_off, uint32_t n_slices, uint32_t log_len,
+                    const EF *d_coef_eq, const EF *d_coef_rot, EF *out_eq, EF *out_rot, hipStream_t s);
+// s[X-1] = sum_y Qeq(X,y) eq(X,y) + Qrot(X,y) krot(X,y), X = 1,2 ; vec = 4 columns of 2^log_h
+int stacked_round(const EF *vec4, uint32_t log_h, EF *d_partials, EF *d_out, hipStream_t s);
+
+// ---- WHIR ----
+int whir_mu_batch(const Fp *msg, uint32_t width, uint32_t log_h, const EF *d_mu_pows, uint32_t mu_offset,
+                  EF *f, int accumulate, hipStream_t s);
+// in-place subset-zeta (dir=+1: coeffs->evals) or Moebius (dir=-1: evals->coeffs) over all bits
+int zeta_transform(EF *v, uint32_t log_n, int dir, hipStream_t s);
+int whir_round(const EF *f, const EF *w, uint64_t n_pairs, EF *d_partials, EF *d_out, hipStream_t s);
+int whir_fold(const EF *f_in, const EF *w_in, EF *f_out, EF *w_out, uint64_t n_out, EF alpha, hipStream_t s);
+// out = sum_i coeffs[i] * z^i
+int horner_eval(const EF *coeffs, uint64_t n, EF z, EF *d_partials, EF *d_out, hipStream_t s);
+// w[x] += sum_q gamma_q * eq(x, pow(z_q)) using split tables lo/hi (n_q x 2^half each)
+int whir_w_accumulate(EF *w, uint32_t log_n, const EF *d_tab_lo, const EF *d_tab_hi, uint32_t log_lo,
+                      uint32_t n_q, hipStream_t s);
+int gather_ef(const EF *src, const uint64_t *d_idx, uint64_t n, EF *out, hipStream_t s);
+
+}  // namespace ovm

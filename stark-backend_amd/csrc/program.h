@@ -1,0 +1,242 @@
+// Constraint / interaction programs: the symbolic DAG of one AIR flattened (on the host, once per
+// proof) into a linear register program that one GPU lane interprets per evaluation point.
+//
+// Replaces (reference): the rule compiler + interpreter of the CUDA backend --
+// crates/cuda-backend/src/logup_zerocheck/rules/ (host), cuda/include/{codec,dag_entry,eval_ctx}.cuh
+// (device) -- and, for semantics, crates/stark-backend/src/prover/logup_zerocheck/single.rs:82-153.
+//
+// A program evaluates only the DAG nodes its roots need. Intermediate values live in `slots`
+// assigned by liveness (a value's slot is recycled after its last use), so the per-lane scratch
+// footprint is the DAG's maximum live set, not its size. Leaves (trace cells, constants, public
+// values, selectors) are operands, never slots. Accumulation is part of the program:
+//   ACC  acc, w, x :  out[acc] += W[w] * x        (W: extension-field weights, host supplied)
+//   DEN  w, x      :  den += W[w] * x             (LogUp-GKR leaf mode)
+//   LEAF k, x      :  emit leaf k = (x, den + C[k]); den = 0
+#pragma once
+#include <vector>
+
+#include "host.h"
+
+namespace ovm {
+
+enum Op : uint8_t { OP_ADD = 0, OP_SUB, OP_MUL, OP_NEG, OP_ACC, OP_DEN, OP_LEAF };
+enum OperandKind : uint8_t { K_SLOT = 0, K_COL, K_CONST };
+
+struct Instr {
+    uint8_t op, ak, bk, acc;
+    uint16_t dst, pad;
+    uint32_t a, b;  // operand payloads: slot / flat column / Montgomery constant / weight index
+};
+static_assert(sizeof(Instr) == 16, "Instr is 16 bytes");
+
+struct Program {
+    std::vector<Instr> code;
+    uint32_t num_slots = 0;
+    uint32_t num_weights = 0;
+    std::vector<uint32_t> used_cols;  // flat column indices the program reads (sorted)
+};
+
+// Flat column numbering of one trace's view: 0,1,2 = is_first, is_transition, is_last, then for
+// every matrix of view_mats (preprocessed, cached..., common) its columns, local then (if the AIR
+// needs rotation) next.
+struct ColumnMap {
+    bool need_rot = false;
+    std::vector<size_t> part_width;  // widths of [cached..., common]
+    size_t total = 3;
+    std::vector<size_t> part_base;  // flat index of part p, offset 0
+    void finish() {
+        part_base.clear();
+        size_t cur = 3;
+        for (size_t w : part_width) {
+            part_base.push_back(cur);
+            cur += w * (need_rot ? 2 : 1);
+        }
+        total = cur;
+    }
+    uint32_t col(uint32_t part, uint32_t offset, uint32_t index) const {
+        return (uint32_t)(part_base[part] + (offset ? part_width[part] : 0) + index);
+    }
+};
+
+struct Root {
+    uint32_t node;
+    uint8_t op;      // OP_ACC / OP_DEN / OP_LEAF
+    uint8_t acc;     // accumulator for OP_ACC
+    uint32_t weight; // weight index (ACC, DEN) or leaf index (LEAF)
+};
+
+// Compiles the nodes needed by `roots` (emitted in the given order, each right after its node is
+// available). Public values are folded to constants.
+inline Program compile_program(const AirKey &air, const ColumnMap &cm, const std::vector<Fp> &public_values,
+                               const std::vector<Root> &roots, uint32_t num_weights) {
+    const size_t n = air.nodes.size();
+    std::vector<char> need(n, 0);
+    for (auto &r : roots) need[r.node] = 1;
+    for (size_t i = n; i-- > 0;) {
+        if (!need[i]) continue;
+        const Node &nd = air.nodes[i];
+        if (nd.kind >= N_ADD) {
+            need[nd.left] = 1;
+            if (nd.kind != N_NEG) need[nd.right] = 1;
+        }
+    }
+    // Roots fire strictly in sequence (a LEAF closes the DENs before it): root r fires at time
+    // fire[r] = max node index over roots 0..r. A node's slot is released at the end of the time
+    // step of its last use (last consuming instruction or last root firing on it).
+    std::vector<size_t> fire(roots.size());
+    {
+        size_t f = 0;
+        for (size_t r = 0; r < roots.size(); r++) {
+            f = std::max(f, (size_t)roots[r].node);
+            fire[r] = f;
+        }
+    }
+    std::vector<size_t> last_use(n, 0);
+    for (size_t i = 0; i < n; i++) {
+        if (!need[i]) continue;
+        const Node &nd = air.nodes[i];
+        last_use[i] = std::max(last_use[i], i);
+        if (nd.kind >= N_ADD) {
+            last_use[nd.left] = std::max(last_use[nd.left], i);
+            if (nd.kind != N_NEG) last_use[nd.right] = std::max(last_use[nd.right], i);
+        }
+    }
+    for (size_t r = 0; r < roots.size(); r++)
+        last_use[roots[r].node] = std::max(last_use[roots[r].node], fire[r]);
+    std::vector<std::vector<uint32_t>> release_at(n);
+    for (size_t i = 0; i < n; i++)
+        if (need[i] && air.nodes[i].kind >= N_ADD) release_at[last_use[i]].push_back((uint32_t)i);
+
+    Program prog;
+    prog.num_weights = num_weights;
+    std::vector<int32_t> slot_of(n, -1);
+    std::vector<uint32_t> free_slots;
+    std::vector<char> col_used(cm.total, 0);
+    auto operand = [&](uint32_t node, uint8_t &kind, uint32_t &payload) {
+        const Node &nd = air.nodes[node];
+        switch (nd.kind) {
+            case N_VAR:
+                if (nd.entry == E_PUBLIC) {
+                    kind = K_CONST;
+                    payload = public_values.at(nd.index).v;
+                } else if (nd.entry == E_MAIN) {
+                    kind = K_COL;
+                    payload = cm.col(nd.part_index, nd.offset, nd.index);
+                    col_used[payload] = 1;
+                } else {
+                    throw OvmFail(801, "preprocessed / challenge variables not supported");
+                }
+                break;
+            case N_IS_FIRST: kind = K_COL; payload = 0; col_used[0] = 1; break;
+            case N_IS_TRANSITION: kind = K_COL; payload = 1; col_used[1] = 1; break;
+            case N_IS_LAST: kind = K_COL; payload = 2; col_used[2] = 1; break;
+            case N_CONST: kind = K_CONST; payload = nd.constant.v; break;
+            default:
+                if (slot_of[node] < 0) throw OvmFail(1, "program compiler: value not live");
+                kind = K_SLOT;
+                payload = (uint32_t)slot_of[node];
+        }
+    };
+    size_t next_root = 0;
+    for (size_t i = 0; i < n; i++) {
+        if (need[i] && air.nodes[i].kind >= N_ADD) {
+            const Node &nd = air.nodes[i];
+            Instr in{};
+            in.op = nd.kind == N_ADD ? OP_ADD : nd.kind == N_SUB ? OP_SUB : nd.kind == N_MUL ? OP_MUL : OP_NEG;
+            operand(nd.left, in.ak, in.a);
+            if (nd.kind != N_NEG) operand(nd.right, in.bk, in.b);
+            uint32_t s;
+            if (!free_slots.empty()) {
+                s = free_slots.back();
+                free_slots.pop_back();
+            } else {
+                s = prog.num_slots++;
+            }
+            if (s > 0xFFFF) throw OvmFail(801, "program needs too many slots");
+            slot_of[i] = (int32_t)s;
+            in.dst = (uint16_t)s;
+            prog.code.push_back(in);
+        }
+        while (next_root < roots.size() && fire[next_root] == i) {
+            const Root &r = roots[next_root];
+            Instr in{};
+            in.op = r.op;
+            in.acc = r.acc;
+            operand(r.node, in.ak, in.a);
+            in.b = r.weight;
+            prog.code.push_back(in);
+            next_root++;
+        }
+        for (uint32_t node : release_at[i]) {
+            free_slots.push_back((uint32_t)slot_of[node]);
+            slot_of[node] = -2;
+        }
+    }
+    if (next_root != roots.size()) throw OvmFail(1, "program compiler: roots left over");
+    for (size_t c = 0; c < cm.total; c++)
+        if (col_used[c]) prog.used_cols.push_back((uint32_t)c);
+    if (prog.num_slots == 0) prog.num_slots = 1;
+    return prog;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Interpreter (host and device). `Fetch(col) -> T` supplies trace cells at the current point.
+// ---------------------------------------------------------------------------------------------
+template <class T>
+struct Lift;
+template <>
+struct Lift<Fp> {
+    BB_HD static Fp of(uint32_t mont) { return Fp::raw(mont); }
+};
+template <>
+struct Lift<FpExt> {
+    BB_HD static FpExt of(uint32_t mont) { return FpExt::from_base(Fp::raw(mont)); }
+};
+
+template <class T, class Fetch>
+BB_HD T load_operand(uint8_t kind, uint32_t payload, const T *slots, Fetch &fetch) {
+    if (kind == K_SLOT) return slots[payload];
+    if (kind == K_COL) return fetch(payload);
+    return Lift<T>::of(payload);
+}
+
+// Runs `code`; accumulates into out[0..2) (ACC mode). `slots` is caller-provided scratch.
+template <class T, class Fetch>
+BB_HD void run_program_acc(const Instr *code, uint32_t n_instr, const FpExt *weights, T *slots, Fetch &fetch,
+                           FpExt *out) {
+    for (uint32_t pc = 0; pc < n_instr; pc++) {
+        const Instr in = code[pc];
+        T a = load_operand<T>(in.ak, in.a, slots, fetch);
+        switch (in.op) {
+            case OP_ADD: slots[in.dst] = a + load_operand<T>(in.bk, in.b, slots, fetch); break;
+            case OP_SUB: slots[in.dst] = a - load_operand<T>(in.bk, in.b, slots, fetch); break;
+            case OP_MUL: slots[in.dst] = a * load_operand<T>(in.bk, in.b, slots, fetch); break;
+            case OP_NEG: slots[in.dst] = -a; break;
+            default: out[in.acc] += weights[in.b] * a; break;  // OP_ACC
+        }
+    }
+}
+
+// Leaf mode: `emit(k, numer, denom)` is called per interaction.
+template <class T, class Fetch, class Emit>
+BB_HD void run_program_leaves(const Instr *code, uint32_t n_instr, const FpExt *weights, const FpExt *leaf_const,
+                              T *slots, Fetch &fetch, Emit &emit) {
+    FpExt den = FpExt::zero();
+    for (uint32_t pc = 0; pc < n_instr; pc++) {
+        const Instr in = code[pc];
+        T a = load_operand<T>(in.ak, in.a, slots, fetch);
+        switch (in.op) {
+            case OP_ADD: slots[in.dst] = a + load_operand<T>(in.bk, in.b, slots, fetch); break;
+            case OP_SUB: slots[in.dst] = a - load_operand<T>(in.bk, in.b, slots, fetch); break;
+            case OP_MUL: slots[in.dst] = a * load_operand<T>(in.bk, in.b, slots, fetch); break;
+            case OP_NEG: slots[in.dst] = -a; break;
+            case OP_DEN: den += weights[in.b] * a; break;
+            default:  // OP_LEAF
+                emit(in.b, a, den + leaf_const[in.b]);
+                den = FpExt::zero();
+                break;
+        }
+    }
+}
+
+}  // namespace ovm

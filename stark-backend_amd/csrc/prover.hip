@@ -1,0 +1,1358 @@
+// Host side of the HIP prover device: the three `ProverDevice` stages over resident traces, and
+// the Coordinator flow that strings them together with the Fiat-Shamir transcript.
+//
+// Mirrors (reference): crates/stark-backend/src/prover/mod.rs:104-197 (Coordinator::prove),
+// prover/hal.rs:84-138 (TraceCommitter / MultiRapProver / OpeningProver), and the stage drivers of
+// the CUDA backend it is a peer of: crates/cuda-backend/src/{stacked_pcs.rs:50-88,
+// logup_zerocheck/mod.rs:119-, stacked_reduction.rs, whir.rs:63-420}. The protocol steps and the
+// transcript order are those of crates/stark-backend/src/prover/{logup_zerocheck/mod.rs,
+// stacked_reduction.rs, whir.rs}; which work runs where (device kernels vs host algebra on a
+// handful of extension-field elements) is this backend's design.
+#include <hip/hip_runtime.h>
+
+#include "kernels.h"
+
+namespace ovm {
+
+// ---------------------------------------------------------------------------------------------
+// Device memory helpers
+// ---------------------------------------------------------------------------------------------
+template <class T>
+struct DevBuf {
+    T *p = nullptr;
+    size_t n = 0;
+    DevBuf() {}
+    explicit DevBuf(size_t count) { alloc(count); }
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    DevBuf(DevBuf &&o) noexcept : p(o.p), n(o.n) { o.p = nullptr; o.n = 0; }
+    DevBuf &operator=(DevBuf &&o) noexcept {
+        if (this != &o) {
+            release();
+            p = o.p;
+            n = o.n;
+            o.p = nullptr;
+            o.n = 0;
+        }
+        return *this;
+    }
+    ~DevBuf() { release(); }
+    void alloc(size_t count) {
+        release();
+        n = count;
+        hipError_t e = hipMalloc((void **)&p, (count ? count : 1) * sizeof(T));
+        if (e != hipSuccess) throw OvmFail((int)e, "hipMalloc");
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        n = 0;
+    }
+};
+
+struct Ctx {
+    hipStream_t stream;
+    void sync() const { OVM_THROW_IF(hipStreamSynchronize(stream)); }
+    template <class T>
+    DevBuf<T> upload(const std::vector<T> &v) const {
+        DevBuf<T> b(v.size());
+        if (!v.empty()) {
+            OVM_THROW_IF(hipMemcpyAsync(b.p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, stream));
+            sync();  // the host vector may go away
+        }
+        return b;
+    }
+    template <class T>
+    std::vector<T> download(const T *d, size_t n) const {
+        std::vector<T> v(n);
+        if (n) {
+            OVM_THROW_IF(hipMemcpyAsync(v.data(), d, n * sizeof(T), hipMemcpyDeviceToHost, stream));
+            sync();
+        }
+        return v;
+    }
+};
+
+__global__ void stack_strided_kernel(const Fp *src, Fp *dst, uint64_t n, uint64_t stride) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i * stride] = src[i];
+}
+
+// eq'[x] = eq[x]*a ; krot[x] = b*eq[x] + c*(eq[prev x] - eq[x])
+__global__ void stacked_tables_kernel(const EF *eq_in, uint64_t n, EF a, EF b, EF c, EF *eq_out, EF *krot_out) {
+    uint64_t x = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (x >= n) return;
+    EF e = eq_in[x], ep = eq_in[x == 0 ? n - 1 : x - 1];
+    eq_out[x] = e * a;
+    krot_out[x] = b * e + c * (ep - e);
+}
+
+// tab[q * 2^nb + x] = scale_q * prod_{j < nb} (x_j ? zp[q][b0 + j] : 1 - zp[q][b0 + j])
+__global__ void whir_eq_tables_kernel(const EF *zpows, uint32_t dim, uint32_t b0, uint32_t nb, const EF *scale,
+                                      uint32_t n_q, EF *tab) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= ((uint64_t)n_q << nb)) return;
+    uint32_t q = (uint32_t)(i >> nb), x = (uint32_t)(i & ((1u << nb) - 1));
+    EF acc = scale ? scale[q] : EF::one();
+    for (uint32_t j = 0; j < nb; j++) {
+        EF z = zpows[(uint64_t)q * dim + b0 + j];
+        acc = acc * ((x >> j & 1) ? z : EF::one() - z);
+    }
+    tab[i] = acc;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Inputs / PCS data
+// ---------------------------------------------------------------------------------------------
+struct TraceIn {
+    uint32_t air_idx;
+    const Fp *d_trace;  // column-major, width from the key
+    size_t height;
+    std::vector<Fp> public_values;
+};
+
+struct PcsData {
+    Layout layout;
+    unsigned log_height = 0, log_rows = 0, k = 0;
+    DevBuf<Fp> stacked, msg, codeword;
+    DevBuf<p2::Digest> layers;
+    p2::Digest root;
+    size_t query_stride() const { return size_t(1) << (log_rows - k); }
+};
+
+static inline uint64_t bitrev64(uint64_t x, unsigned bits) {
+    uint64_t r = 0;
+    for (unsigned i = 0; i < bits; i++) r |= ((x >> i) & 1ull) << (bits - 1 - i);
+    return r;
+}
+
+// Physical position of entry y of stored Merkle layer j (see merkle.hip).
+static inline uint64_t layer_entry(uint64_t qs, unsigned lq, unsigned j, uint64_t y) {
+    uint64_t off = 0;
+    for (unsigned m = 0; m < j; m++) off += qs >> m;
+    return off + bitrev64(y, lq - j);
+}
+
+struct Prover {
+    const ProvingKey &pk;
+    Ctx cx;
+    Transcript ts;
+    std::vector<TraceIn> traces;  // sorted
+    ByteWriter out;
+    std::vector<size_t> section_offsets;
+
+    Prover(const ProvingKey &pk_, hipStream_t s) : pk(pk_), cx{s} { ts.stream = s; }
+
+    const Params &P() const { return pk.params; }
+    const AirKey &air(size_t t) const { return pk.airs[traces[t].air_idx]; }
+
+    // -----------------------------------------------------------------------------------------
+    // Stage 1: commit (TraceCommitter::commit)
+    // -----------------------------------------------------------------------------------------
+    PcsData commit() {
+        const unsigned l_skip = P().l_skip, lh = l_skip + P().n_stack;
+        PcsData d;
+        std::vector<std::pair<size_t, unsigned>> meta;
+        size_t total_cells = 0;
+        for (size_t t = 0; t < traces.size(); t++) {
+            size_t w = air(t).common_main_width;
+            meta.push_back({w, log2_strict(traces[t].height)});
+            total_cells += std::max(traces[t].height, size_t(1) << l_skip) * w;
+        }
+        d.layout = Layout(l_skip, lh, meta);
+        const size_t H = size_t(1) << lh, width = (total_cells + H - 1) / H;
+        if (width != d.layout.width) throw OvmFail(1, "stacked width mismatch");
+        d.log_height = lh;
+        d.stacked.alloc(width * H);
+        OVM_THROW_IF(hipMemsetAsync(d.stacked.p, 0, width * H * sizeof(Fp), cx.stream));
+        for (size_t t = 0; t < traces.size(); t++) {
+            size_t w = air(t).common_main_width, h = traces[t].height;
+            if (w == 0) continue;
+            const Slice &s0 = d.layout.cols[d.layout.mat_starts[t]].slice;
+            Fp *dst = d.stacked.p + s0.col_idx * H + s0.row_idx;
+            if (s0.log_height >= l_skip) {
+                // the columns of one trace occupy one contiguous range of the stacked buffer
+                OVM_THROW_IF(hipMemcpyAsync(dst, traces[t].d_trace, w * h * sizeof(Fp), hipMemcpyDeviceToDevice, cx.stream));
+            } else {
+                size_t stride = s0.stride(l_skip), len = s0.len(l_skip);
+                for (size_t j = 0; j < w; j++) {
+                    const Slice &s = d.layout.cols[d.layout.mat_starts[t] + j].slice;
+                    hipLaunchKernelGGL(stack_strided_kernel, dim3(ceil_div(h, 256)), dim3(256), 0, cx.stream,
+                                       traces[t].d_trace + j * h, d.stacked.p + s.col_idx * H + s.row_idx, (uint64_t)h,
+                                       (uint64_t)stride);
+                    (void)len;
+                }
+            }
+        }
+        d.msg.alloc(width * H);
+        OVM_THROW_IF(ovm_hip_eval_to_coeff((const uint32_t *)d.stacked.p, (uint32_t *)d.msg.p, width, lh, l_skip, cx.stream));
+        d.log_rows = lh + P().log_blowup;
+        d.k = P().k_whir;
+        d.codeword.alloc(width << d.log_rows);
+        OVM_THROW_IF(ovm_hip_ntt_dif((const uint32_t *)d.msg.p, (uint32_t *)d.codeword.p, width, d.log_rows, lh, cx.stream));
+        build_tree(d, (const uint32_t *)d.codeword.p, width, false);
+        return d;
+    }
+
+    void build_tree(PcsData &d, const uint32_t *matrix, size_t width, bool ext) {
+        DevBuf<uint32_t> scratch(std::max<uint64_t>(1, ovm_hip_merkle_scratch_words(d.log_rows, d.k)));
+        d.layers.alloc(ovm_hip_merkle_layers_words(d.log_rows, d.k) / 8);
+        if (ext)
+            OVM_THROW_IF(ovm_hip_merkle_tree_ext(matrix, width, d.log_rows, d.k, scratch.p, (uint32_t *)d.layers.p, cx.stream));
+        else
+            OVM_THROW_IF(ovm_hip_merkle_tree(matrix, width, d.log_rows, d.k, scratch.p, (uint32_t *)d.layers.p, cx.stream));
+        d.root = cx.download(d.layers.p + d.layers.n - 1, 1)[0];
+    }
+
+    // -----------------------------------------------------------------------------------------
+    // Per-trace device view
+    // -----------------------------------------------------------------------------------------
+    struct TraceView {
+        ColumnMap cm;
+        unsigned log_height = 0, log_lifted = 0, n_lift = 0;
+        int n = 0;
+        DevBuf<Fp> sels;
+        DevBuf<ColDesc> cols;
+        // folded matrices (EF, column-major, all flat columns), ping-pong
+        DevBuf<EF> mats_a, mats_b;
+        bool mats_in_a = true;
+        unsigned cur_log_h = 0;
+        std::vector<EF> final_row;  // once height 1
+    };
+
+    struct ProgDev {
+        Program prog;
+        DevBuf<Instr> code;
+        DevBuf<EF> weights;
+        DevProgram dev() const { return DevProgram{code.p, (uint32_t)prog.code.size(), prog.num_slots, weights.p}; }
+    };
+    ProgDev make_prog(Program p, const std::vector<EF> &weights) {
+        ProgDev d;
+        d.code = cx.upload(p.code);
+        d.weights = cx.upload(weights);
+        d.prog = std::move(p);
+        return d;
+    }
+
+    // host evaluation of a program on one row (tail rounds)
+    static void host_eval(const Program &p, const std::vector<EF> &weights, const std::vector<EF> &row, EF add_const,
+                          EF out[2]) {
+        std::vector<EF> slots(p.num_slots);
+        auto fetch = [&](uint32_t col) { return row[col]; };
+        out[0] = EF::zero();
+        out[1] = add_const;
+        run_program_acc<EF>(p.code.data(), (uint32_t)p.code.size(), weights.data(), slots.data(), fetch, out);
+    }
+
+    // -----------------------------------------------------------------------------------------
+    // Stage 2: zerocheck + LogUp (MultiRapProver::prove_rap_constraints)
+    // -----------------------------------------------------------------------------------------
+    std::vector<EF> prove_rap_constraints() {
+        const unsigned l_skip = P().l_skip;
+        const size_t N = size_t(1) << l_skip, T = traces.size();
+        const unsigned cdeg_global = P().max_constraint_degree;
+        std::vector<TraceView> tv(T);
+        uint64_t total_interactions = 0;
+        std::vector<std::pair<size_t, unsigned>> imeta;
+        for (size_t t = 0; t < T; t++) {
+            TraceView &v = tv[t];
+            v.log_height = log2_strict(traces[t].height);
+            v.log_lifted = std::max(v.log_height, l_skip);
+            v.n = (int)v.log_height - (int)l_skip;
+            v.n_lift = (unsigned)std::max(v.n, 0);
+            v.cm.need_rot = air(t).need_rot;
+            v.cm.part_width = {air(t).common_main_width};
+            v.cm.finish();
+            size_t ni = air(t).interactions.size();
+            total_interactions += (uint64_t)ni << v.log_lifted;
+            imeta.push_back({ni, v.log_lifted});
+            // device view: selectors + columns
+            v.sels.alloc(size_t(3) << v.log_lifted);
+            OVM_THROW_IF(build_selectors(v.sels.p, v.log_lifted, v.log_height, cx.stream));
+            std::vector<ColDesc> cd(v.cm.total);
+            for (int sidx = 0; sidx < 3; sidx++) cd[sidx] = ColDesc{v.sels.p + ((size_t)sidx << v.log_lifted), v.log_lifted, 0};
+            size_t w = air(t).common_main_width;
+            for (size_t c = 0; c < w; c++) {
+                cd[v.cm.col(0, 0, c)] = ColDesc{traces[t].d_trace + c * traces[t].height, v.log_height, 0};
+                if (v.cm.need_rot) cd[v.cm.col(0, 1, c)] = ColDesc{traces[t].d_trace + c * traces[t].height, v.log_height, 1};
+            }
+            v.cols = cx.upload(cd);
+        }
+        const unsigned n_max = tv[0].n_lift;
+        unsigned n_logup = 0;
+        if (total_interactions) n_logup = (64 - (unsigned)__builtin_clzll(total_interactions)) - l_skip;
+        Layout ilayout(0, l_skip + n_logup, imeta);
+
+        ByteWriter &w = out;
+        Fp logup_pow = ts.grind(P().logup_pow_bits);
+        EF alpha = ts.sample_ext(), beta = ts.sample_ext();
+        size_t max_msg = 0, max_constraints = 0;
+        for (size_t t = 0; t < T; t++)
+            for (auto &it : air(t).interactions) max_msg = std::max(max_msg, it.message.size());
+        for (auto &a : pk.airs) max_constraints = std::max(max_constraints, a.constraint_idx.size());
+        std::vector<EF> beta_pows = powers_of(beta, max_msg + 1);
+
+        // ---- GKR ----
+        std::vector<EF> xi;
+        EF q0_claim = EF::one();
+        std::vector<std::array<EF, 4>> claims;               // p0,p1,q0,q1 per layer
+        std::vector<std::vector<std::array<EF, 3>>> gkr_polys;
+        const unsigned TR = l_skip + n_logup;
+        if (!ilayout.cols.empty()) {
+            const size_t n_leaves = size_t(1) << TR;
+            DevBuf<Frac> tree(2 * n_leaves);
+            OVM_THROW_IF(gkr_fill_leaves(tree.p + n_leaves, n_leaves, alpha, cx.stream));
+            for (size_t t = 0; t < T; t++) {
+                const AirKey &a = air(t);
+                if (a.interactions.empty()) continue;
+                std::vector<Root> roots;
+                std::vector<EF> leaf_const;
+                std::vector<uint64_t> leaf_base;
+                std::vector<uint32_t> leaf_log_len;
+                for (size_t k = 0; k < a.interactions.size(); k++) {
+                    const Interaction &it = a.interactions[k];
+                    for (size_t j = 0; j < it.message.size(); j++) roots.push_back({it.message[j], OP_DEN, 0, (uint32_t)j});
+                    roots.push_back({it.count, OP_LEAF, 0, (uint32_t)k});
+                    leaf_const.push_back(beta_pows[it.message.size()] * fp((uint64_t)it.bus_index + 1) + alpha);
+                    const Slice &s = ilayout.cols[ilayout.mat_starts[t] + k].slice;
+                    leaf_base.push_back(s.row_idx);
+                    leaf_log_len.push_back(s.log_height);
+                }
+                ProgDev pd = make_prog(compile_program(a, tv[t].cm, traces[t].public_values, roots, (uint32_t)beta_pows.size()), beta_pows);
+                auto d_lc = cx.upload(leaf_const);
+                auto d_lb = cx.upload(leaf_base);
+                auto d_ll = cx.upload(leaf_log_len);
+                Fp norm = fp(uint64_t(1) << (tv[t].log_lifted - tv[t].log_height)).inv();
+                OVM_THROW_IF(gkr_eval_leaves(pd.dev(), d_lc.p, tv[t].cols.p, tv[t].log_height, d_lb.p, d_ll.p, norm,
+                                             tree.p + n_leaves, cx.stream));
+                cx.sync();
+            }
+            for (unsigned j = TR; j-- > 0;)
+                OVM_THROW_IF(gkr_build_layer(tree.p + (size_t(2) << j), tree.p + (size_t(1) << j), size_t(1) << j, cx.stream));
+            {
+                auto top = cx.download(tree.p + 1, 3);  // nodes 1, 2, 3
+                if (!is_zero(top[0].p)) throw OvmFail(1, "LogUp: non-zero root sum (interactions do not balance)");
+                q0_claim = top[0].q;
+                ts.observe_ext(q0_claim);
+                claims.push_back({top[1].p, top[2].p, top[1].q, top[2].q});
+            }
+            auto observe_claims = [&](const std::array<EF, 4> &c) {
+                ts.observe_ext(c[0]);
+                ts.observe_ext(c[2]);
+                ts.observe_ext(c[1]);
+                ts.observe_ext(c[3]);
+            };
+            observe_claims(claims[0]);
+            std::vector<EF> xi_prev{ts.sample_ext()};
+            if (TR > 1) {
+                DevBuf<EF> rec_a(size_t(4) << (TR - 2)), rec_b(size_t(4) << (TR - 2));
+                DevBuf<EF> eq_a(size_t(1) << (TR - 1)), eq_b(size_t(1) << (TR - 1));
+                DevBuf<EF> partials(RED_BLOCKS * 4), d_out(4), d_point(TR);
+                for (unsigned round = 1; round < TR; round++) {
+                    EF lambda = ts.sample_ext();
+                    OVM_THROW_IF(hipMemcpyAsync(d_point.p, xi_prev.data(), round * sizeof(EF), hipMemcpyHostToDevice, cx.stream));
+                    OVM_THROW_IF(eq_table(d_point.p, round, eq_a.p, cx.stream));
+                    const EF *rec = (const EF *)(tree.p + (size_t(2) << round));
+                    const EF *eq = eq_a.p;
+                    bool to_b = true;
+                    std::vector<std::array<EF, 3>> polys;
+                    std::vector<EF> rho;
+                    for (unsigned sr = 0; sr < round; sr++) {
+                        uint64_t n_pairs = 1ull << (round - sr - 1);
+                        OVM_THROW_IF(gkr_round(rec, eq, n_pairs, lambda, partials.p, d_out.p, cx.stream));
+                        auto sv = cx.download(d_out.p, 3);
+                        for (auto &e : sv) ts.observe_ext(e);
+                        polys.push_back({sv[0], sv[1], sv[2]});
+                        EF r = ts.sample_ext();
+                        rho.push_back(r);
+                        EF *rec_o = (sr % 2 == 0) ? rec_a.p : rec_b.p;
+                        EF *eq_o = to_b ? eq_b.p : eq_a.p;
+                        OVM_THROW_IF(gkr_fold(rec, eq, rec_o, eq_o, n_pairs, r, cx.stream));
+                        rec = rec_o;
+                        eq = eq_o;
+                        to_b = !to_b;
+                    }
+                    auto fin = cx.download(rec, 4);
+                    claims.push_back({fin[0], fin[2], fin[1], fin[3]});
+                    observe_claims(claims.back());
+                    EF mu = ts.sample_ext();
+                    xi_prev.clear();
+                    xi_prev.push_back(mu);
+                    xi_prev.insert(xi_prev.end(), rho.begin(), rho.end());
+                    gkr_polys.push_back(std::move(polys));
+                }
+            }
+            xi = xi_prev;
+        }
+        const unsigned n_global = std::max(n_max, n_logup);
+        while (xi.size() != l_skip + n_global) xi.push_back(ts.sample_ext());
+
+        // gkr proof bytes
+        w.f(logup_pow);
+        w.e(q0_claim);
+        w.usize(claims.size());
+        for (auto &c : claims)
+            for (auto &x : c) w.e(x);
+        for (auto &round : gkr_polys)
+            for (auto &arr : round)
+                for (auto &x : arr) w.e(x);
+        section_offsets.push_back(w.buf.size());
+
+        EF lambda = ts.sample_ext();
+        std::vector<EF> lambda_pows = powers_of(lambda, std::max<size_t>(max_constraints, 1));
+        const Fp g = fp(bb::GENERATOR), omega_skip = bb::two_adic_generator(l_skip);
+        std::vector<Fp> omega_pows = powers_of(omega_skip, N);
+
+        // ---- programs, eq weights, round 0 ----
+        struct TraceProgs {
+            std::unique_ptr<ProgDev> zc, lg;
+            std::vector<EF> zc_w, lg_w;
+            EF lg_const = EF::zero();
+            std::vector<EF> eq3b;
+        };
+        std::vector<TraceProgs> tp(T);
+        std::vector<std::vector<EF>> sp0(3 * T);
+        DevBuf<EF> partials((size_t)RED_BLOCKS * MAX_COSETS * 2 * N + 64), d_out(MAX_COSETS * 2 * N + 64);
+        for (size_t t = 0; t < T; t++) {
+            const AirKey &a = air(t);
+            TraceView &v = tv[t];
+            unsigned cdeg = a.max_constraint_degree;
+            // eq(xi_3, b) per interaction
+            for (size_t k = 0; k < a.interactions.size(); k++) {
+                const Slice &s = ilayout.cols[ilayout.mat_starts[t] + k].slice;
+                size_t b_int = s.row_idx >> (l_skip + v.n_lift);
+                EF e = EF::one();
+                for (unsigned j = l_skip + v.n_lift; j < l_skip + n_logup; j++) {
+                    e = e * eq1b(xi[j], b_int & 1);
+                    b_int >>= 1;
+                }
+                tp[t].eq3b.push_back(e);
+            }
+            {
+                std::vector<Root> roots;
+                for (size_t i = 0; i < a.constraint_idx.size(); i++) roots.push_back({a.constraint_idx[i], OP_ACC, 0, (uint32_t)i});
+                tp[t].zc_w = lambda_pows;
+                tp[t].zc = std::make_unique<ProgDev>(make_prog(compile_program(a, v.cm, traces[t].public_values, roots, (uint32_t)lambda_pows.size()), lambda_pows));
+            }
+            if (!a.interactions.empty()) {
+                std::vector<Root> roots;
+                std::vector<EF> wts;
+                for (size_t k = 0; k < a.interactions.size(); k++) {
+                    const Interaction &it = a.interactions[k];
+                    for (size_t j = 0; j < it.message.size(); j++) {
+                        roots.push_back({it.message[j], OP_ACC, 1, (uint32_t)wts.size()});
+                        wts.push_back(tp[t].eq3b[k] * beta_pows[j]);
+                    }
+                    roots.push_back({it.count, OP_ACC, 0, (uint32_t)wts.size()});
+                    wts.push_back(tp[t].eq3b[k]);
+                    tp[t].lg_const += tp[t].eq3b[k] * (beta_pows[it.message.size()] * fp((uint64_t)it.bus_index + 1));
+                }
+                tp[t].lg_w = wts;
+                tp[t].lg = std::make_unique<ProgDev>(make_prog(compile_program(a, v.cm, traces[t].public_values, roots, (uint32_t)wts.size()), wts));
+            }
+            // eq(xi[l_skip..l_skip+n_lift], x)
+            DevBuf<EF> d_eq(size_t(1) << v.n_lift);
+            {
+                std::vector<EF> pt(xi.begin() + l_skip, xi.begin() + l_skip + v.n_lift);
+                auto d_pt = cx.upload(pt);
+                OVM_THROW_IF(eq_table(d_pt.p, v.n_lift, d_eq.p, cx.stream));
+                cx.sync();
+            }
+            unsigned zc_cosets = cdeg ? cdeg - 1 : 0, lg_cosets = tp[t].lg ? cdeg : 0;
+            unsigned n_cosets = std::max(zc_cosets, lg_cosets);
+            if (n_cosets > MAX_COSETS) throw OvmFail(801, "constraint degree too large");
+            if (n_cosets) {
+                std::vector<char> usedm(v.cm.total, 0);
+                for (auto c : tp[t].zc->prog.used_cols) usedm[c] = 1;
+                if (tp[t].lg)
+                    for (auto c : tp[t].lg->prog.used_cols) usedm[c] = 1;
+                std::vector<uint32_t> used;
+                for (size_t c = 0; c < usedm.size(); c++)
+                    if (usedm[c]) used.push_back((uint32_t)c);
+                std::vector<Fp> shift_pows(n_cosets * N);
+                for (unsigned k = 0; k < n_cosets; k++) {
+                    Fp sh = g.pow(k + 1), cur = Fp::one();
+                    for (size_t i = 0; i < N; i++) {
+                        shift_pows[k * N + i] = cur;
+                        cur *= sh;
+                    }
+                }
+                auto d_used = cx.upload(used);
+                auto d_sp = cx.upload(shift_pows);
+                DevBuf<Fp> lde((size_t)n_cosets * v.cm.total << v.log_lifted);
+                OVM_THROW_IF(coset_lde(v.cols.p, d_used.p, (uint32_t)used.size(), (uint32_t)v.cm.total, v.log_lifted, l_skip,
+                                       n_cosets, d_sp.p, lde.p, cx.stream));
+                if (zc_cosets) {
+                    OVM_THROW_IF(round0_eval(tp[t].zc->dev(), lde.p, (uint32_t)v.cm.total, v.log_lifted, l_skip, zc_cosets, 1,
+                                             d_eq.p, EF::zero(), partials.p, d_out.p, cx.stream));
+                    auto ev = cx.download(d_out.p, (size_t)zc_cosets * N);
+                    std::vector<std::vector<EF>> ce(zc_cosets, std::vector<EF>(N));
+                    for (unsigned k = 0; k < zc_cosets; k++) {
+                        Fp zinv = (g.pow(k + 1).exp_power_of_2(l_skip) - Fp::one()).inv();
+                        for (size_t z = 0; z < N; z++) ce[k][z] = ev[k * N + z] * zinv;
+                    }
+                    std::vector<EF> q = from_coset_evals(ce, l_skip);
+                    unsigned deg = cdeg * (unsigned)(N - 1);
+                    std::vector<EF> coeffs(deg + 1);
+                    for (size_t i = 0; i <= deg; i++) {
+                        EF c = i < q.size() ? -q[i] : EF::zero();
+                        if (i >= N && i - N < q.size()) c += q[i - N];
+                        coeffs[i] = c;
+                    }
+                    sp0[2 * T + t] = std::move(coeffs);
+                }
+                if (lg_cosets) {
+                    OVM_THROW_IF(round0_eval(tp[t].lg->dev(), lde.p, (uint32_t)v.cm.total, v.log_lifted, l_skip, lg_cosets, 2,
+                                             d_eq.p, tp[t].lg_const, partials.p, d_out.p, cx.stream));
+                    auto ev = cx.download(d_out.p, (size_t)lg_cosets * 2 * N);
+                    std::vector<std::vector<EF>> cn(lg_cosets, std::vector<EF>(N)), cden(lg_cosets, std::vector<EF>(N));
+                    for (unsigned k = 0; k < lg_cosets; k++)
+                        for (size_t z = 0; z < N; z++) {
+                            cn[k][z] = ev[(k * 2 + 0) * N + z];
+                            cden[k][z] = ev[(k * 2 + 1) * N + z];
+                        }
+                    Fp norm = fp(uint64_t(1) << (v.log_lifted - v.log_height)).inv();
+                    std::vector<EF> pn = from_coset_evals(cn, l_skip), pd = from_coset_evals(cden, l_skip);
+                    for (auto &x : pn) x = x * norm;
+                    sp0[2 * t] = std::move(pn);
+                    sp0[2 * t + 1] = std::move(pd);
+                }
+                cx.sync();
+            } else if (cdeg != 0) {
+                sp0[2 * T + t] = std::vector<EF>(cdeg * (N - 1) + 1, EF::zero());
+            }
+        }
+
+        // ---- s_0 assembly (host; a few dozen extension-field elements) ----
+        const unsigned sp0_deg = cdeg_global * (unsigned)(N - 1), s_deg = cdeg_global + 1, s0_deg = s_deg * (unsigned)(N - 1);
+        const size_t large = size_t(1) << log2_ceil(s0_deg + 1);
+        auto mul_by = [&](std::vector<EF> a, const std::vector<EF> &eqev) {
+            a.resize(large, EF::zero());
+            a = small_dft(a, false);
+            for (size_t i = 0; i < large; i++) a[i] = a[i] * eqev[i];
+            return small_dft(a, true);
+        };
+        std::vector<std::vector<EF>> s0_logup(2 * T);
+        {
+            std::vector<EF> eqc = small_dft(eq_hypercube(std::vector<EF>(xi.begin(), xi.begin() + l_skip)), true);
+            eqc.resize(large, EF::zero());
+            std::vector<EF> eqev = small_dft(eqc, false);
+            for (size_t i = 0; i < 2 * T; i++) {
+                std::vector<EF> c(sp0[i].begin(), sp0[i].begin() + std::min(sp0[i].size(), (size_t)sp0_deg + 1));
+                s0_logup[i] = mul_by(std::move(c), eqev);
+            }
+        }
+        std::vector<EF> numer_terms, denom_terms;
+        for (size_t t = 0; t < T; t++) {
+            EF sums[2];
+            for (int dnm = 0; dnm < 2; dnm++) {
+                EF s = EF::zero();
+                for (size_t j = 0; j <= s0_deg; j += N) s += s0_logup[2 * t + dnm][j];
+                sums[dnm] = s * fp(N);
+            }
+            ts.observe_ext(sums[0]);
+            ts.observe_ext(sums[1]);
+            numer_terms.push_back(sums[0]);
+            denom_terms.push_back(sums[1]);
+        }
+        EF mu = ts.sample_ext();
+        std::vector<EF> mu_pows = powers_of(mu, 3 * T);
+        std::vector<EF> s0_zc;
+        {
+            Fp n_inv = Fp::one().halve().pow(l_skip);
+            std::vector<EF> eqc(N);
+            EF xp = xi[0];
+            for (size_t i = 0; i < N; i++) {
+                eqc[i] = xp * n_inv;
+                xp = xp * xi[0];
+            }
+            std::reverse(eqc.begin(), eqc.end());
+            eqc[0] = ef(n_inv);
+            eqc.resize(large, EF::zero());
+            std::vector<EF> eqev = small_dft(eqc, false);
+            std::vector<EF> c(large, EF::zero());
+            for (size_t j = 0; j <= sp0_deg; j++)
+                for (size_t t = 0; t < T; t++)
+                    if (j < sp0[2 * T + t].size()) c[j] += mu_pows[2 * T + t] * sp0[2 * T + t][j];
+            s0_zc = mul_by(std::move(c), eqev);
+        }
+        std::vector<EF> s0(s0_deg + 1);
+        for (size_t j = 0; j <= s0_deg; j++) {
+            EF c = s0_zc[j];
+            for (size_t i = 0; i < 2 * T; i++) c += mu_pows[i] * s0_logup[i][j];
+            ts.observe_ext(c);
+            s0[j] = c;
+        }
+        std::vector<EF> r;
+        EF r0 = ts.sample_ext();
+        r.push_back(r0);
+        EF prev_s = horner(s0, r0);
+
+        // ---- fold at r_0 ----
+        {
+            // barycentric weights: L_z(r) = omega^z (r^N - 1) / (N (r - omega^z))
+            EF rn = r0.exp_power_of_2(l_skip) - Fp::one();
+            Fp ninv = fp(N).inv();
+            std::vector<EF> wts(N);
+            for (size_t z = 0; z < N; z++) wts[z] = rn * (r0 - omega_pows[z]).inv() * (omega_pows[z] * ninv);
+            auto d_w = cx.upload(wts);
+            for (size_t t = 0; t < T; t++) {
+                TraceView &v = tv[t];
+                size_t h = size_t(1) << v.n_lift;
+                v.mats_a.alloc(v.cm.total * h);
+                v.mats_b.alloc(v.cm.total * std::max<size_t>(h / 2, 1));
+                OVM_THROW_IF(fold_ple(v.cols.p, (uint32_t)v.cm.total, v.log_lifted, l_skip, d_w.p, v.mats_a.p, cx.stream));
+                v.cur_log_h = v.n_lift;
+                v.mats_in_a = true;
+                if (v.n_lift == 0) v.final_row = cx.download(v.mats_a.p, v.cm.total);
+            }
+            cx.sync();
+        }
+        std::vector<EF> eq_ns{eq_uni(l_skip, xi[0], r0)};
+        EF eq_sharp0 = EF::zero();
+        {
+            std::vector<EF> eqx = eq_hypercube(std::vector<EF>(xi.begin(), xi.begin() + l_skip));
+            for (size_t z = 0; z < N; z++) eq_sharp0 += eq_uni(l_skip, r0, ef(omega_pows[z])) * eqx[z];
+        }
+        std::vector<EF> eq_sharp_ns{eq_sharp0};
+
+        // ---- MLE rounds ----
+        std::vector<EF> zc_tilde(T, EF::zero());
+        std::vector<std::array<EF, 2>> lg_tilde(T, {EF::zero(), EF::zero()});
+        std::vector<std::vector<EF>> round_polys;
+        DevBuf<EF> d_eqr(size_t(1) << std::max(n_max, 1u)), d_pt(std::max(n_max, 1u));
+        for (unsigned round = 1; round <= n_max; round++) {
+            EF r_prev = r[round - 1];
+            std::vector<std::vector<EF>> sp(3 * T);
+            for (size_t t = 0; t < T; t++) {
+                TraceView &v = tv[t];
+                const AirKey &a = air(t);
+                bool has_int = !a.interactions.empty();
+                Fp norm = fp(uint64_t(1) << (v.log_lifted - v.log_height)).inv();
+                if (round > v.n_lift) {
+                    if (round == v.n_lift + 1) {
+                        EF o[2];
+                        host_eval(tp[t].zc->prog, tp[t].zc_w, v.final_row, EF::zero(), o);
+                        zc_tilde[t] = eq_ns.back() * o[0];
+                        if (has_int) {
+                            host_eval(tp[t].lg->prog, tp[t].lg_w, v.final_row, tp[t].lg_const, o);
+                            lg_tilde[t] = {eq_sharp_ns.back() * o[0] * norm, eq_sharp_ns.back() * o[1]};
+                        }
+                    } else {
+                        zc_tilde[t] *= r_prev;
+                        lg_tilde[t][0] *= r_prev;
+                        lg_tilde[t][1] *= r_prev;
+                    }
+                    sp[2 * T + t] = {zc_tilde[t]};
+                    sp[2 * t] = has_int ? std::vector<EF>{lg_tilde[t][0]} : std::vector<EF>(cdeg_global, EF::zero());
+                    sp[2 * t + 1] = has_int ? std::vector<EF>{lg_tilde[t][1]} : std::vector<EF>(cdeg_global, EF::zero());
+                } else {
+                    unsigned log_num_y = v.n_lift - round;
+                    // eq over xi[l_skip + round .. l_skip + n_lift]
+                    if (log_num_y) OVM_THROW_IF(hipMemcpyAsync(d_pt.p, xi.data() + l_skip + round, log_num_y * sizeof(EF), hipMemcpyHostToDevice, cx.stream));
+                    OVM_THROW_IF(eq_table(d_pt.p, log_num_y, d_eqr.p, cx.stream));
+                    const EF *mats = v.mats_in_a ? v.mats_a.p : v.mats_b.p;
+                    OVM_THROW_IF(mle_round_eval(tp[t].zc->dev(), mats, (uint32_t)v.cm.total, v.cur_log_h, cdeg_global, 1, d_eqr.p,
+                                                EF::zero(), partials.p, d_out.p, cx.stream));
+                    auto ev = cx.download(d_out.p, 8);
+                    sp[2 * T + t].resize(cdeg_global);
+                    for (unsigned i = 0; i < cdeg_global; i++) sp[2 * T + t][i] = ev[2 * i];
+                    if (has_int) {
+                        OVM_THROW_IF(mle_round_eval(tp[t].lg->dev(), mats, (uint32_t)v.cm.total, v.cur_log_h, cdeg_global, 2,
+                                                    d_eqr.p, tp[t].lg_const, partials.p, d_out.p, cx.stream));
+                        auto e2 = cx.download(d_out.p, 8);
+                        sp[2 * t].resize(cdeg_global);
+                        sp[2 * t + 1].resize(cdeg_global);
+                        for (unsigned i = 0; i < cdeg_global; i++) {
+                            sp[2 * t][i] = e2[2 * i] * norm;
+                            sp[2 * t + 1][i] = e2[2 * i + 1];
+                        }
+                    } else {
+                        sp[2 * t] = std::vector<EF>(cdeg_global, EF::zero());
+                        sp[2 * t + 1] = std::vector<EF>(cdeg_global, EF::zero());
+                    }
+                }
+            }
+            size_t tail_start = T;
+            for (size_t t = 0; t < T; t++)
+                if ((int)round > tv[t].n) {
+                    tail_start = t;
+                    break;
+                }
+            std::vector<EF> head_zc(cdeg_global, EF::zero()), head_lg(cdeg_global, EF::zero());
+            EF sp_tail = EF::zero();
+            for (size_t t = 0; t < T; t++) {
+                size_t zi = 2 * T + t, ni = 2 * t, di = 2 * t + 1;
+                if (t < tail_start) {
+                    for (unsigned i = 0; i < cdeg_global; i++) {
+                        head_zc[i] += mu_pows[zi] * sp[zi][i];
+                        head_lg[i] += mu_pows[ni] * sp[ni][i] + mu_pows[di] * sp[di][i];
+                    }
+                } else {
+                    sp_tail += mu_pows[zi] * sp[zi][0] + mu_pows[ni] * sp[ni][0] + mu_pows[di] * sp[di][0];
+                }
+            }
+            std::vector<EF> head(s_deg, EF::zero());
+            for (unsigned i = 0; i < cdeg_global; i++) head[i + 1] = eq_ns[round - 1] * head_zc[i] + eq_sharp_ns[round - 1] * head_lg[i];
+            EF xi_cur = xi[l_skip + round - 1];
+            head[0] = (prev_s - xi_cur * head[1] - sp_tail) * (EF::one() - xi_cur).inv();
+            std::vector<Fp> pts(s_deg);
+            for (unsigned i = 0; i < s_deg; i++) pts[i] = fp(i);
+            std::vector<EF> coeffs = lagrange_coeffs(pts, head);
+            coeffs.push_back(EF::zero());
+            EF b = EF::one() - xi_cur, a2 = xi_cur - b;
+            for (size_t i = s_deg; i-- > 0;) coeffs[i + 1] = a2 * coeffs[i] + b * coeffs[i + 1];
+            coeffs[0] = coeffs[0] * b;
+            coeffs[1] += sp_tail;
+            std::vector<EF> be(s_deg);
+            for (unsigned i = 1; i <= s_deg; i++) {
+                be[i - 1] = horner(coeffs, ef_u64(i));
+                ts.observe_ext(be[i - 1]);
+            }
+            round_polys.push_back(be);
+            EF rr = ts.sample_ext();
+            r.push_back(rr);
+            prev_s = horner(coeffs, rr);
+            for (size_t t = 0; t < T; t++) {
+                TraceView &v = tv[t];
+                if (v.cur_log_h == 0) continue;
+                const EF *in = v.mats_in_a ? v.mats_a.p : v.mats_b.p;
+                EF *o = v.mats_in_a ? v.mats_b.p : v.mats_a.p;
+                OVM_THROW_IF(fold_mle(in, o, (uint32_t)v.cm.total, v.cur_log_h, rr, cx.stream));
+                v.mats_in_a = !v.mats_in_a;
+                v.cur_log_h--;
+                if (v.cur_log_h == 0) v.final_row = cx.download(o, v.cm.total);
+            }
+            EF eqr = eq1(xi_cur, rr);
+            eq_ns.push_back(eq_ns[round - 1] * eqr);
+            eq_sharp_ns.push_back(eq_sharp_ns[round - 1] * eqr);
+        }
+
+        // ---- openings ----
+        std::vector<std::vector<EF>> openings(T);
+        for (size_t t = 0; t < T; t++) {
+            TraceView &v = tv[t];
+            size_t wd = air(t).common_main_width;
+            for (size_t c = 0; c < wd; c++) {
+                openings[t].push_back(v.final_row[v.cm.col(0, 0, c)]);
+                if (v.cm.need_rot) openings[t].push_back(v.final_row[v.cm.col(0, 1, c)]);
+            }
+        }
+        for (size_t t = 0; t < T; t++) {
+            if (tv[t].cm.need_rot) {
+                for (auto &x : openings[t]) ts.observe_ext(x);
+            } else {
+                for (auto &x : openings[t]) {
+                    ts.observe_ext(x);
+                    ts.observe_ext(EF::zero());
+                }
+            }
+        }
+        column_openings = openings;
+
+        // batch constraint proof bytes
+        w.e_slice(numer_terms);
+        for (auto &x : denom_terms) w.e(x);
+        w.e_slice(s0);
+        w.usize(round_polys.size());
+        if (!round_polys.empty()) {
+            w.usize(round_polys[0].size());
+            for (auto &rp : round_polys)
+                for (auto &x : rp) w.e(x);
+        }
+        for (size_t t = 0; t < T; t++) {
+            w.usize(1);
+            w.e_slice(openings[t]);
+        }
+        section_offsets.push_back(w.buf.size());
+        return r;
+    }
+    std::vector<std::vector<EF>> column_openings;
+
+    // -----------------------------------------------------------------------------------------
+    // Stage 3: stacked opening reduction + WHIR (OpeningProver::prove_openings)
+    // -----------------------------------------------------------------------------------------
+    void prove_openings(PcsData &pcs, const std::vector<EF> &r) {
+        const unsigned l_skip = P().l_skip, n_stack = P().n_stack;
+        const size_t N = size_t(1) << l_skip, H = size_t(1) << (l_skip + n_stack);
+        const size_t width = pcs.layout.width;
+        ByteWriter &w = out;
+        const Fp g = fp(bb::GENERATOR), omega_skip = bb::two_adic_generator(l_skip);
+        std::vector<Fp> omega_pows = powers_of(omega_skip, N);
+
+        EF lambda = ts.sample_ext();
+        struct TV {
+            Slice s;
+            size_t leq;
+            long lrot;
+        };
+        std::vector<TV> tvs;
+        size_t li = 0;
+        for (auto &sc : pcs.layout.cols) {
+            TV t{sc.slice, li, -1};
+            li++;
+            if (air(sc.mat_idx).need_rot) t.lrot = (long)li;
+            li++;
+            tvs.push_back(t);
+        }
+        std::vector<EF> lam = powers_of(lambda, li);
+        std::vector<size_t> win;
+        for (size_t i = 0; i < tvs.size(); i++)
+            if (i == 0 || tvs[i].s.log_height != tvs[i - 1].s.log_height) win.push_back(i);
+        win.push_back(tvs.size());
+        const size_t W = win.size() - 1;
+        const EF r0 = r[0];
+        const EF eq_const = eq_uni_at_one(l_skip, r0 * omega_skip);
+
+        struct Window {
+            unsigned log_height, n_lift, cur_log_h;
+            int n;
+            DevBuf<EF> eq_cube, vec_a, vec_b;
+            bool in_a = true;
+            EF eq_fin = EF::zero(), krot_fin = EF::zero();
+        };
+        std::vector<Window> ws(W);
+        DevBuf<EF> partials((size_t)RED_BLOCKS * 3 * N + 64), d_out(3 * N + 64);
+        const unsigned s0_deg = 2 * (unsigned)(N - 1);
+        std::vector<EF> s0(s0_deg + 1, EF::zero());
+        for (size_t wi = 0; wi < W; wi++) {
+            Window &wd = ws[wi];
+            size_t w0 = win[wi], w1 = win[wi + 1];
+            wd.log_height = tvs[w0].s.log_height;
+            wd.n = (int)wd.log_height - (int)l_skip;
+            wd.n_lift = (unsigned)std::max(wd.n, 0);
+            wd.eq_cube.alloc(size_t(1) << wd.n_lift);
+            {
+                std::vector<EF> pt(r.begin() + 1, r.begin() + 1 + wd.n_lift);
+                auto d_pt = cx.upload(pt);
+                OVM_THROW_IF(eq_table(d_pt.p, wd.n_lift, wd.eq_cube.p, cx.stream));
+            }
+            std::vector<EF> leq, lrot;
+            for (size_t i = w0; i < w1; i++) {
+                leq.push_back(lam[tvs[i].leq]);
+                lrot.push_back(tvs[i].lrot >= 0 ? lam[(size_t)tvs[i].lrot] : EF::zero());
+            }
+            auto d_leq = cx.upload(leq);
+            auto d_lrot = cx.upload(lrot);
+            unsigned log_len = std::max(wd.log_height, l_skip);
+            const Fp *base = pcs.stacked.p + tvs[w0].s.col_idx * H + tvs[w0].s.row_idx;
+            OVM_THROW_IF(stacked_round0(base, (uint32_t)(w1 - w0), log_len, l_skip, d_leq.p, d_lrot.p, wd.eq_cube.p,
+                                        partials.p, d_out.p, cx.stream));
+            auto R = cx.download(d_out.p, 3 * N);
+            // host: chunk-aggregated vectors -> coset evaluations with the univariate factors
+            std::vector<std::vector<EF>> coef(3);
+            for (int v = 0; v < 3; v++) coef[v] = small_dft(std::vector<EF>(R.begin() + v * N, R.begin() + (v + 1) * N), true);
+            std::vector<std::vector<EF>> e0(2, std::vector<EF>(N)), e1(2, std::vector<EF>(N));
+            for (unsigned k = 0; k < 2; k++) {
+                Fp shift = g.pow(k + 1);
+                for (size_t z = 0; z < N; z++) {
+                    Fp zp = shift * omega_pows[z];
+                    EF lde[3];
+                    for (int v = 0; v < 3; v++) lde[v] = horner_fp(coef[v], zp);
+                    unsigned l = l_skip;
+                    Fp omega = omega_skip;
+                    EF r_uni = r0;
+                    if (wd.n < 0) {
+                        l = l_skip + wd.n;
+                        omega = omega_skip.exp_power_of_2((unsigned)(-wd.n));
+                        r_uni = r0.exp_power_of_2((unsigned)(-wd.n));
+                    }
+                    Fp ind = in_uni(l_skip, wd.n, zp);
+                    EF equ = eq_uni(l, ef(zp), r_uni), equ_rot = eq_uni(l, ef(zp), r_uni * omega);
+                    Fp equ1 = eq_uni_at_one(l_skip, zp);
+                    e0[k][z] = equ * lde[0] * ind;
+                    e1[k][z] = (equ_rot * lde[1] + eq_const * equ1 * lde[2]) * ind;
+                }
+            }
+            std::vector<EF> p0 = from_coset_evals(e0, l_skip), p1 = from_coset_evals(e1, l_skip);
+            for (size_t i = 0; i <= s0_deg; i++) s0[i] += p0[i] + p1[i];
+        }
+        for (auto &c : s0) ts.observe_ext(c);
+        std::vector<EF> u;
+        EF u0 = ts.sample_ext();
+        u.push_back(u0);
+
+        // fold the stacked matrix at u_0
+        DevBuf<EF> q_a(width << n_stack), q_b(width << (n_stack ? n_stack - 1 : 0));
+        bool q_in_a = true;
+        unsigned q_log_h = n_stack;
+        {
+            EF un = u0.exp_power_of_2(l_skip) - Fp::one();
+            Fp ninv = fp(N).inv();
+            std::vector<EF> wts(N);
+            for (size_t z = 0; z < N; z++) wts[z] = un * (u0 - omega_pows[z]).inv() * (omega_pows[z] * ninv);
+            auto d_w = cx.upload(wts);
+            std::vector<ColDesc> cd(width);
+            for (size_t c = 0; c < width; c++) cd[c] = ColDesc{pcs.stacked.p + c * H, l_skip + n_stack, 0};
+            auto d_cd = cx.upload(cd);
+            OVM_THROW_IF(fold_ple(d_cd.p, (uint32_t)width, l_skip + n_stack, l_skip, d_w.p, q_a.p, cx.stream));
+            cx.sync();
+        }
+        // per-window tables and combined vectors
+        std::vector<EF> eq_ub(tvs.size(), EF::one());
+        {
+            EF eq_u0r0 = eq_uni(l_skip, u0, r0), eq_u0r0_rot = eq_uni(l_skip, u0, r0 * omega_skip), eq_u01 = eq_uni_at_one(l_skip, u0);
+            for (size_t wi = 0; wi < W; wi++) {
+                Window &wd = ws[wi];
+                size_t w0 = win[wi], w1 = win[wi + 1], hw = size_t(1) << wd.n_lift;
+                EF ind = in_uni(l_skip, wd.n, u0), equ = eq_u0r0, equ_rot = eq_u0r0_rot;
+                if (wd.n < 0) {
+                    Fp omega = omega_skip.exp_power_of_2((unsigned)(-wd.n));
+                    EF rr = r0.exp_power_of_2((unsigned)(-wd.n));
+                    unsigned l = l_skip + wd.n;
+                    equ = eq_uni(l, u0, rr);
+                    equ_rot = eq_uni(l, u0, rr * omega);
+                }
+                wd.vec_a.alloc(4 * hw);
+                wd.vec_b.alloc(4 * std::max<size_t>(hw / 2, 1));
+                hipLaunchKernelGGL(stacked_tables_kernel, dim3(ceil_div(hw, 256)), dim3(256), 0, cx.stream, wd.eq_cube.p,
+                                   (uint64_t)hw, ind * equ, ind * equ_rot, ind * eq_const * eq_u01, wd.vec_a.p + 2 * hw,
+                                   wd.vec_a.p + 3 * hw);
+                std::vector<uint64_t> off;
+                std::vector<EF> ce, cr;
+                for (size_t i = w0; i < w1; i++) {
+                    off.push_back(((uint64_t)tvs[i].s.col_idx << n_stack) + (tvs[i].s.row_idx >> l_skip));
+                    ce.push_back(lam[tvs[i].leq]);
+                    cr.push_back(tvs[i].lrot >= 0 ? lam[(size_t)tvs[i].lrot] : EF::zero());
+                }
+                auto d_off = cx.upload(off);
+                auto d_ce = cx.upload(ce);
+                auto d_cr = cx.upload(cr);
+                OVM_THROW_IF(stacked_combine(q_a.p, d_off.p, (uint32_t)(w1 - w0), wd.n_lift, d_ce.p, d_cr.p, wd.vec_a.p,
+                                             wd.vec_a.p + hw, cx.stream));
+                cx.sync();
+                wd.cur_log_h = wd.n_lift;
+                wd.in_a = true;
+                if (wd.n_lift == 0) {
+                    auto fin = cx.download(wd.vec_a.p, 4);
+                    wd.eq_fin = fin[2];
+                    wd.krot_fin = fin[3];
+                }
+            }
+        }
+        std::vector<std::array<EF, 2>> st_polys;
+        DevBuf<uint64_t> d_gidx(2 * tvs.size() + 2);
+        DevBuf<EF> d_gout(2 * tvs.size() + 2);
+        for (unsigned round = 1; round <= n_stack; round++) {
+            std::array<EF, 2> batch{EF::zero(), EF::zero()};
+            const EF *q_cur = q_in_a ? q_a.p : q_b.p;
+            // tail slices: gather their two entries
+            std::vector<uint64_t> gidx;
+            std::vector<size_t> gslice;
+            for (size_t wi = 0; wi < W; wi++)
+                if (round > ws[wi].n_lift)
+                    for (size_t i = win[wi]; i < win[wi + 1]; i++) {
+                        uint64_t row_start = (tvs[i].s.row_idx >> (l_skip + round)) << 1;
+                        gidx.push_back(((uint64_t)tvs[i].s.col_idx << q_log_h) + row_start);
+                        gidx.push_back(((uint64_t)tvs[i].s.col_idx << q_log_h) + row_start + 1);
+                        gslice.push_back(i);
+                    }
+            std::vector<EF> gv;
+            if (!gidx.empty()) {
+                OVM_THROW_IF(hipMemcpyAsync(d_gidx.p, gidx.data(), gidx.size() * 8, hipMemcpyHostToDevice, cx.stream));
+                OVM_THROW_IF(gather_ef(q_cur, d_gidx.p, gidx.size(), d_gout.p, cx.stream));
+                gv = cx.download(d_gout.p, gidx.size());
+            }
+            size_t gi = 0;
+            for (size_t wi = 0; wi < W; wi++) {
+                Window &wd = ws[wi];
+                if (round <= wd.n_lift) {
+                    const EF *vec = wd.in_a ? wd.vec_a.p : wd.vec_b.p;
+                    OVM_THROW_IF(stacked_round(vec, wd.cur_log_h, partials.p, d_out.p, cx.stream));
+                    auto sv = cx.download(d_out.p, 2);
+                    batch[0] += sv[0];
+                    batch[1] += sv[1];
+                } else {
+                    for (size_t i = win[wi]; i < win[wi + 1]; i++, gi++) {
+                        EF t0 = gv[2 * gi], t1 = gv[2 * gi + 1];
+                        size_t b = (tvs[i].s.row_idx >> (l_skip + round - 1)) & 1;
+                        for (unsigned X = 1; X <= 2; X++) {
+                            EF x = ef_u64(X);
+                            EF q = t0 + (t1 - t0) * x;
+                            EF ub = eq_ub[i] * eq1b(x, b);
+                            EF acc = lam[tvs[i].leq] * q * (wd.eq_fin * ub);
+                            if (tvs[i].lrot >= 0) acc += lam[(size_t)tvs[i].lrot] * q * (wd.krot_fin * ub);
+                            batch[X - 1] += acc;
+                        }
+                    }
+                }
+            }
+            for (auto &e : batch) ts.observe_ext(e);
+            st_polys.push_back(batch);
+            EF ur = ts.sample_ext();
+            u.push_back(ur);
+            {
+                EF *qo = q_in_a ? q_b.p : q_a.p;
+                OVM_THROW_IF(fold_mle(q_cur, qo, (uint32_t)width, q_log_h, ur, cx.stream));
+                q_in_a = !q_in_a;
+                q_log_h--;
+            }
+            for (size_t wi = 0; wi < W; wi++) {
+                Window &wd = ws[wi];
+                if (wd.cur_log_h == 0) continue;
+                const EF *in = wd.in_a ? wd.vec_a.p : wd.vec_b.p;
+                EF *o = wd.in_a ? wd.vec_b.p : wd.vec_a.p;
+                OVM_THROW_IF(fold_mle(in, o, 4, wd.cur_log_h, ur, cx.stream));
+                wd.in_a = !wd.in_a;
+                wd.cur_log_h--;
+                if (wd.cur_log_h == 0) {
+                    auto fin = cx.download(o, 4);
+                    wd.eq_fin = fin[2];
+                    wd.krot_fin = fin[3];
+                }
+            }
+            for (size_t i = 0; i < tvs.size(); i++) {
+                unsigned n_lift = tvs[i].s.log_height > l_skip ? tvs[i].s.log_height - l_skip : 0;
+                if (round > n_lift) eq_ub[i] = eq_ub[i] * eq1b(ur, (tvs[i].s.row_idx >> (l_skip + round - 1)) & 1);
+            }
+        }
+        std::vector<EF> stacking_openings = cx.download(q_in_a ? q_a.p : q_b.p, width);
+        for (auto &c : stacking_openings) ts.observe_ext(c);
+        q_a.release();
+        q_b.release();
+        for (auto &wd : ws) {
+            wd.vec_a.release();
+            wd.vec_b.release();
+            wd.eq_cube.release();
+        }
+        // stacking proof bytes
+        w.e_slice(s0);
+        w.usize(st_polys.size());
+        for (auto &a : st_polys)
+            for (auto &x : a) w.e(x);
+        w.usize(1);
+        w.e_slice(stacking_openings);
+        section_offsets.push_back(w.buf.size());
+
+        // ---------------- WHIR ----------------
+        std::vector<EF> u_cube;
+        {
+            EF cur = u[0];
+            for (unsigned i = 0; i < l_skip; i++) {
+                u_cube.push_back(cur);
+                cur = cur.square();
+            }
+            u_cube.insert(u_cube.end(), u.begin() + 1, u.end());
+        }
+        const unsigned k_whir = P().k_whir, log_blowup = P().log_blowup;
+        const size_t n_rounds = P().whir_num_queries.size();
+        Fp mu_pow_witness = ts.grind(P().mu_pow_bits);
+        EF mu = ts.sample_ext();
+        unsigned m = l_skip + n_stack;
+        DevBuf<EF> f_a(size_t(1) << m), f_b(size_t(1) << (m - 1)), w_a(size_t(1) << m), w_b(size_t(1) << (m - 1));
+        {
+            std::vector<EF> mu_pows = powers_of(mu, width);
+            auto d_mu = cx.upload(mu_pows);
+            OVM_THROW_IF(whir_mu_batch(pcs.msg.p, (uint32_t)width, m, d_mu.p, 0, f_a.p, 0, cx.stream));
+            OVM_THROW_IF(zeta_transform(f_a.p, m, +1, cx.stream));
+            auto d_u = cx.upload(u_cube);
+            OVM_THROW_IF(mobius_eq_table(d_u.p, m, w_a.p, cx.stream));
+            cx.sync();
+        }
+        bool fw_in_a = true;
+        std::vector<std::array<EF, 2>> whir_polys;
+        std::vector<p2::Digest> codeword_commits;
+        std::vector<EF> ood_values, final_poly;
+        std::vector<Fp> folding_pows, query_pows;
+        std::vector<std::vector<std::vector<Fp>>> init_rows;       // per query: 2^k rows x width
+        std::vector<std::vector<p2::Digest>> init_proofs;           // per query
+        std::vector<std::vector<std::vector<EF>>> cw_values;        // per round, per query: 2^k
+        std::vector<std::vector<std::vector<p2::Digest>>> cw_proofs;
+        unsigned log_rs = m + log_blowup;
+        PcsData g_prev;  // previous round's codeword tree (EF, width 1)
+        DevBuf<EF> d_red((size_t)RED_BLOCKS * 2 + 8), d_red_out(8);
+        for (size_t wr = 0; wr < n_rounds; wr++) {
+            const bool is_last = wr + 1 == n_rounds;
+            for (unsigned rd = 0; rd < k_whir; rd++) {
+                const EF *f = fw_in_a ? f_a.p : f_b.p, *wv = fw_in_a ? w_a.p : w_b.p;
+                uint64_t half = 1ull << (m - rd - 1);
+                OVM_THROW_IF(whir_round(f, wv, half, d_red.p, d_red_out.p, cx.stream));
+                auto sv = cx.download(d_red_out.p, 2);
+                ts.observe_ext(sv[0]);
+                ts.observe_ext(sv[1]);
+                whir_polys.push_back({sv[0], sv[1]});
+                folding_pows.push_back(ts.grind(P().folding_pow_bits));
+                EF al = ts.sample_ext();
+                OVM_THROW_IF(whir_fold(f, wv, fw_in_a ? f_b.p : f_a.p, fw_in_a ? w_b.p : w_a.p, half, al, cx.stream));
+                fw_in_a = !fw_in_a;
+            }
+            const unsigned m_new = m - k_whir;
+            EF *f_cur = fw_in_a ? f_a.p : f_b.p, *w_cur = fw_in_a ? w_a.p : w_b.p;
+            // g = f(alpha, .) in coefficient form
+            DevBuf<EF> g_coeffs(size_t(1) << m_new);
+            OVM_THROW_IF(hipMemcpyAsync(g_coeffs.p, f_cur, sizeof(EF) << m_new, hipMemcpyDeviceToDevice, cx.stream));
+            OVM_THROW_IF(zeta_transform(g_coeffs.p, m_new, -1, cx.stream));
+            PcsData g_tree;
+            EF z0 = EF::zero();
+            if (!is_last) {
+                g_tree.log_rows = log_rs - 1;
+                g_tree.k = k_whir;
+                DevBuf<EF> g_rs(size_t(1) << g_tree.log_rows);
+                OVM_THROW_IF(ovm_hip_ntt_dif_ext((const uint32_t *)g_coeffs.p, (uint32_t *)g_rs.p, 1, g_tree.log_rows, m_new, cx.stream));
+                build_tree(g_tree, (const uint32_t *)g_rs.p, 1, true);
+                g_tree.codeword = DevBuf<Fp>();
+                g_tree_codeword = std::move(g_rs);
+                ts.observe_digest(g_tree.root);
+                codeword_commits.push_back(g_tree.root);
+                z0 = ts.sample_ext();
+                OVM_THROW_IF(horner_eval(g_coeffs.p, 1ull << m_new, z0, d_red.p, d_red_out.p, cx.stream));
+                EF opened = cx.download(d_red_out.p, 1)[0];
+                ts.observe_ext(opened);
+                ood_values.push_back(opened);
+            } else {
+                final_poly = cx.download(g_coeffs.p, size_t(1) << m_new);
+                for (auto &c : final_poly) ts.observe_ext(c);
+            }
+            const unsigned lq = log_rs - k_whir;
+            Fp omega = bb::two_adic_generator(lq);
+            size_t nq = P().whir_num_queries[wr];
+            query_pows.push_back(ts.grind(P().query_phase_pow_bits));
+            std::vector<uint64_t> qidx(nq);
+            for (auto &q : qidx) q = ts.sample_bits(lq);
+            // opened rows + Merkle paths
+            {
+                const uint64_t qs = 1ull << lq;
+                std::vector<uint64_t> rows, didx;
+                for (uint64_t i : qidx) {
+                    uint64_t grp = bitrev64(i, lq);
+                    for (uint64_t t = 0; t < (1ull << k_whir); t++) rows.push_back((grp << k_whir) + bitrev64(t, k_whir));
+                    for (unsigned j = 0; j < lq; j++) didx.push_back(layer_entry(qs, lq, j, (i >> j) ^ 1));
+                }
+                auto d_rows = cx.upload(rows);
+                auto d_didx = cx.upload(didx);
+                DevBuf<p2::Digest> d_dig(std::max<size_t>(didx.size(), 1));
+                if (wr == 0) {
+                    DevBuf<Fp> d_vals(std::max<size_t>(rows.size() * width, 1));
+                    OVM_THROW_IF(ovm_hip_gather_rows((const uint32_t *)pcs.codeword.p, width, 1ull << pcs.log_rows, 1, d_rows.p,
+                                                     rows.size(), (uint32_t *)d_vals.p, cx.stream));
+                    OVM_THROW_IF(ovm_hip_gather_digests((const uint32_t *)pcs.layers.p, d_didx.p, didx.size(), (uint32_t *)d_dig.p, cx.stream));
+                    auto vals = cx.download(d_vals.p, rows.size() * width);
+                    auto digs = cx.download(d_dig.p, didx.size());
+                    for (size_t q = 0; q < nq; q++) {
+                        std::vector<std::vector<Fp>> qr;
+                        for (size_t t = 0; t < (size_t(1) << k_whir); t++) {
+                            size_t ro = (q << k_whir) + t;
+                            qr.emplace_back(vals.begin() + ro * width, vals.begin() + (ro + 1) * width);
+                        }
+                        init_rows.push_back(std::move(qr));
+                        init_proofs.emplace_back(digs.begin() + q * lq, digs.begin() + (q + 1) * lq);
+                    }
+                } else {
+                    DevBuf<EF> d_vals(std::max<size_t>(rows.size(), 1));
+                    OVM_THROW_IF(gather_ef(prev_codeword.p, d_rows.p, rows.size(), d_vals.p, cx.stream));
+                    OVM_THROW_IF(ovm_hip_gather_digests((const uint32_t *)g_prev.layers.p, d_didx.p, didx.size(), (uint32_t *)d_dig.p, cx.stream));
+                    auto vals = cx.download(d_vals.p, rows.size());
+                    auto digs = cx.download(d_dig.p, didx.size());
+                    std::vector<std::vector<EF>> rv;
+                    std::vector<std::vector<p2::Digest>> rp;
+                    for (size_t q = 0; q < nq; q++) {
+                        rv.emplace_back(vals.begin() + (q << k_whir), vals.begin() + ((q + 1) << k_whir));
+                        rp.emplace_back(digs.begin() + q * lq, digs.begin() + (q + 1) * lq);
+                    }
+                    cw_values.push_back(std::move(rv));
+                    cw_proofs.push_back(std::move(rp));
+                }
+            }
+            g_prev = std::move(g_tree);
+            prev_codeword = std::move(g_tree_codeword);
+            EF gamma = ts.sample_ext();
+            if (!is_last) {
+                // w += gamma * eq(., pow(z0)) + sum_i gamma^(i+2) * eq(., pow(z_i))
+                const size_t n_q = nq + 1;
+                std::vector<EF> zp(n_q * m_new), scale(n_q);
+                {
+                    EF cur = z0;
+                    for (unsigned j = 0; j < m_new; j++) {
+                        zp[j] = cur;
+                        cur = cur.square();
+                    }
+                    scale[0] = gamma;
+                    EF gp = gamma * gamma;
+                    for (size_t q = 0; q < nq; q++) {
+                        Fp zc = omega.pow(qidx[q]);
+                        for (unsigned j = 0; j < m_new; j++) {
+                            zp[(q + 1) * m_new + j] = ef(zc);
+                            zc = zc.square();
+                        }
+                        scale[q + 1] = gp;
+                        gp = gp * gamma;
+                    }
+                }
+                unsigned log_lo = m_new / 2, log_hi = m_new - log_lo;
+                auto d_zp = cx.upload(zp);
+                auto d_sc = cx.upload(scale);
+                DevBuf<EF> tlo(n_q << log_lo), thi(n_q << log_hi);
+                hipLaunchKernelGGL(whir_eq_tables_kernel, dim3(ceil_div((uint64_t)n_q << log_lo, 256)), dim3(256), 0, cx.stream,
+                                   d_zp.p, m_new, 0u, log_lo, d_sc.p, (uint32_t)n_q, tlo.p);
+                hipLaunchKernelGGL(whir_eq_tables_kernel, dim3(ceil_div((uint64_t)n_q << log_hi, 256)), dim3(256), 0, cx.stream,
+                                   d_zp.p, m_new, log_lo, log_hi, (const EF *)nullptr, (uint32_t)n_q, thi.p);
+                OVM_THROW_IF(whir_w_accumulate(w_cur, m_new, tlo.p, thi.p, log_lo, (uint32_t)n_q, cx.stream));
+                cx.sync();
+            }
+            m = m_new;
+            log_rs -= 1;
+        }
+        // whir proof bytes
+        w.f(mu_pow_witness);
+        w.usize(whir_polys.size());
+        for (auto &a : whir_polys)
+            for (auto &x : a) w.e(x);
+        w.usize(codeword_commits.size());
+        for (auto &d : codeword_commits) w.digest(d);
+        for (auto &x : ood_values) w.e(x);
+        for (auto &x : folding_pows) w.f(x);
+        for (auto &x : query_pows) w.f(x);
+        w.usize(1);
+        w.usize(init_rows.size());
+        if (!init_rows.empty()) {
+            w.usize(init_proofs[0].size());
+            w.usize(width);
+            for (auto &qr : init_rows)
+                for (auto &row : qr)
+                    for (auto &x : row) w.f(x);
+            for (auto &pr : init_proofs)
+                for (auto &d : pr) w.digest(d);
+        }
+        for (auto &round : cw_values) {
+            w.usize(round.size());
+            for (auto &q : round)
+                for (auto &x : q) w.e(x);
+        }
+        size_t first_depth = 0;
+        if (n_rounds > 1 && !init_rows.empty()) first_depth = cw_proofs[0][0].size();
+        w.usize(first_depth);
+        for (auto &round : cw_proofs)
+            for (auto &pr : round)
+                for (auto &d : pr) w.digest(d);
+        w.e_slice(final_poly);
+        section_offsets.push_back(w.buf.size());
+    }
+    DevBuf<EF> g_tree_codeword, prev_codeword;
+
+    // -----------------------------------------------------------------------------------------
+    // Coordinator::prove
+    // -----------------------------------------------------------------------------------------
+    void prove(std::vector<TraceIn> in) {
+        traces = std::move(in);
+        std::stable_sort(traces.begin(), traces.end(), [](const TraceIn &a, const TraceIn &b) {
+            if (a.height != b.height) return a.height > b.height;
+            return a.air_idx < b.air_idx;
+        });
+        for (auto &t : traces) {
+            if (t.air_idx >= pk.airs.size()) throw OvmFail(1, "air index out of range");
+            if (t.public_values.size() != pk.airs[t.air_idx].num_public_values) throw OvmFail(1, "public values length");
+        }
+        ts.observe_digest(pk.vk_pre_hash);
+        PcsData pcs = commit();
+        const size_t num_airs = pk.airs.size();
+        std::vector<int> present(num_airs, -1);
+        for (size_t t = 0; t < traces.size(); t++) present[traces[t].air_idx] = (int)t;
+        ts.observe_digest(pcs.root);
+        for (size_t a = 0; a < num_airs; a++) {
+            if (!pk.airs[a].is_required) ts.observe(present[a] >= 0 ? Fp::one() : Fp::zero());
+            if (present[a] >= 0) {
+                ts.observe(fp(log2_strict(traces[present[a]].height)));
+                for (auto &pv : traces[present[a]].public_values) ts.observe(pv);
+            }
+        }
+        // proof header
+        out.u32(3);  // CODEC_VERSION
+        out.digest(pcs.root);
+        out.usize(num_airs);
+        for (size_t a = 0; a < num_airs; a += 8) {
+            uint8_t b = 0;
+            for (size_t j = 0; j < 8 && a + j < num_airs; j++)
+                if (present[a + j] >= 0) b |= (uint8_t)(1u << j);
+            out.u8(b);
+        }
+        for (size_t a = 0; a < num_airs; a++)
+            if (present[a] >= 0) {
+                out.usize(log2_strict(traces[present[a]].height));
+                out.usize(0);  // cached commitments
+            }
+        out.usize(num_airs);
+        for (size_t a = 0; a < num_airs; a++) {
+            if (present[a] >= 0) {
+                out.usize(traces[present[a]].public_values.size());
+                for (auto &pv : traces[present[a]].public_values) out.f(pv);
+            } else {
+                out.usize(0);
+            }
+        }
+        section_offsets.push_back(out.buf.size());
+        std::vector<EF> r = prove_rap_constraints();
+        prove_openings(pcs, r);
+    }
+};
+
+}  // namespace ovm
+
+using namespace ovm;
+
+extern "C" {
+
+int ovm_hip_pk_load(const uint32_t *blob, uint64_t words, ovm_pk_t **pk_out) {
+    if (!blob || !pk_out) return (int)hipErrorInvalidValue;
+    try {
+        auto *pk = new ProvingKey(parse_pk_blob(blob, words));
+        *pk_out = reinterpret_cast<ovm_pk_t *>(pk);
+        return 0;
+    } catch (const OvmFail &e) {
+        return e.code;
+    } catch (...) {
+        return (int)hipErrorUnknown;
+    }
+}
+
+void ovm_hip_pk_free(ovm_pk_t *pk) { delete reinterpret_cast<ProvingKey *>(pk); }
+
+static thread_local std::string g_last_error;
+const char *ovm_hip_last_error(void) { return g_last_error.c_str(); }
+
+int ovm_hip_prove(const ovm_pk_t *pk_, uint32_t n_traces, const uint32_t *air_idx, const uint32_t *const *d_traces,
+                  const uint64_t *heights, const uint32_t *const *public_values, const uint32_t *num_public_values,
+                  ovm_sponge_t *sponge, uint8_t *proof_out, uint64_t proof_cap, uint64_t *proof_len,
+                  uint64_t *section_offsets5, ovm_stream_t stream) {
+    if (!pk_ || !proof_len || n_traces == 0) return (int)hipErrorInvalidValue;
+    const ProvingKey &pk = *reinterpret_cast<const ProvingKey *>(pk_);
+    try {
+        if (!twiddles()) return (int)hipErrorInitializationError;
+        Prover pr(pk, (hipStream_t)stream);
+        if (sponge) {
+            for (int i = 0; i < 16; i++) pr.ts.s.state[i] = Fp::raw(sponge->state[i]);
+            pr.ts.s.absorb_idx = sponge->absorb_idx;
+            pr.ts.s.sample_idx = sponge->sample_idx;
+        }
+        std::vector<TraceIn> in;
+        for (uint32_t t = 0; t < n_traces; t++) {
+            TraceIn ti;
+            ti.air_idx = air_idx[t];
+            ti.d_trace = (const Fp *)d_traces[t];
+            ti.height = heights[t];
+            if (ti.height == 0 || (ti.height & (ti.height - 1))) return (int)hipErrorInvalidValue;
+            for (uint32_t i = 0; i < (num_public_values ? num_public_values[t] : 0); i++)
+                ti.public_values.push_back(Fp::raw(public_values[t][i]));
+            in.push_back(std::move(ti));
+        }
+        pr.prove(std::move(in));
+        *proof_len = pr.out.buf.size();
+        if (section_offsets5)
+            for (size_t i = 0; i < 5 && i < pr.section_offsets.size(); i++) section_offsets5[i] = pr.section_offsets[i];
+        if (sponge) {
+            for (int i = 0; i < 16; i++) sponge->state[i] = pr.ts.s.state[i].v;
+            sponge->absorb_idx = pr.ts.s.absorb_idx;
+            sponge->sample_idx = pr.ts.s.sample_idx;
+        }
+        if (pr.out.buf.size() > proof_cap || !proof_out) return (int)hipErrorInvalidValue;
+        memcpy(proof_out, pr.out.buf.data(), pr.out.buf.size());
+        return 0;
+    } catch (const OvmFail &e) {
+        g_last_error = e.what();
+        return e.code ? e.code : (int)hipErrorUnknown;
+    } catch (const std::exception &e) {
+        g_last_error = e.what();
+        return (int)hipErrorUnknown;
+    }
+}
+
+}  // extern "C"

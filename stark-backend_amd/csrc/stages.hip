@@ -1,0 +1,723 @@
+// Kernels of the sumcheck stages: LogUp-GKR, zerocheck / logup batch sumcheck (round 0 on cosets
+// and the multilinear rounds), stacked opening reduction and WHIR folding.
+//
+// Replaces (reference, all under crates/cuda-backend/cuda/src/): logup_zerocheck/gkr_input.cu,
+// gkr.cu, zerocheck_round0.cu, logup_round0.cu, mle.cu, utils.cu (fold_ple), sumcheck.cu (folds,
+// block reductions), stacked_reduction.cu, whir.cu, poly.cu (eq tables, Horner). Algorithms
+// follow the protocol as specified by crates/stark-backend/src/prover/{sumcheck,stacked_reduction,
+// whir}.rs and prover/logup_zerocheck/; the decomposition into kernels is this backend's own.
+//
+// Shape of every reduction kernel: a fixed grid of RED_BLOCKS x RED_THREADS lanes strides over
+// the domain with unit-stride (coalesced) accesses, keeps its partial sums in registers, reduces
+// them through wave shuffles and LDS, and writes one record per workgroup; `sum_partials`
+// finishes. Field addition is exact, so the result does not depend on the schedule.
+#include "kernels.h"
+
+namespace ovm {
+
+// ---- extension-field memory access (16-byte vectors) ----------------------------------------
+__device__ __forceinline__ EF ld_ef(const EF *p) {
+    uint4 v = *reinterpret_cast<const uint4 *>(p);
+    EF r;
+    r.c[0] = Fp::raw(v.x);
+    r.c[1] = Fp::raw(v.y);
+    r.c[2] = Fp::raw(v.z);
+    r.c[3] = Fp::raw(v.w);
+    return r;
+}
+__device__ __forceinline__ void st_ef(EF *p, const EF &x) {
+    *reinterpret_cast<uint4 *>(p) = make_uint4(x.c[0].v, x.c[1].v, x.c[2].v, x.c[3].v);
+}
+
+__device__ __forceinline__ EF wave_sum(EF v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        EF o;
+#pragma unroll
+        for (int c = 0; c < 4; c++) o.c[c] = Fp::raw(__shfl_down(v.c[c].v, off));
+        v = v + o;
+    }
+    return v;
+}
+
+// Sum K values per lane over the workgroup; lane 0 stores them at out[0..K).
+template <int K>
+__device__ void block_sum_store(EF (&v)[K], EF *out) {
+    __shared__ EF sh[(RED_THREADS / 64) * K];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        EF s = wave_sum(v[k]);
+        if (lane == 0) sh[wave * K + k] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < K) {
+        EF s = sh[threadIdx.x];
+        for (int w = 1; w < (int)(blockDim.x >> 6); w++) s = s + sh[w * K + threadIdx.x];
+        st_ef(out + threadIdx.x, s);
+    }
+    __syncthreads();
+}
+
+__global__ void sum_partials_kernel(const EF *partials, uint32_t n_blocks, uint32_t K, EF *out) {
+    const uint32_t k = blockIdx.x;
+    EF acc[1] = {EF::zero()};
+    for (uint32_t b = threadIdx.x; b < n_blocks; b += blockDim.x) acc[0] = acc[0] + ld_ef(partials + (size_t)b * K + k);
+    block_sum_store<1>(acc, out + k);
+}
+
+int sum_partials(const EF *partials, uint32_t n_blocks, uint32_t K, EF *out, hipStream_t s) {
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(K), dim3(RED_THREADS), 0, s, partials, n_blocks, K, out);
+    OVM_CHECK_LAUNCH();
+    return 0;
+}
+
+static inline uint32_t red_grid(uint64_t work_items) {
+    uint64_t b = (work_items + RED_THREADS - 1) / RED_THREADS;
+    if (b < 1) b = 1;
+    return (uint32_t)(b > RED_BLOCKS ? RED_BLOCKS : b);
+}
+
+// ---- selectors and eq tables -----------------------------------------------------------------
+__global__ void build_selectors_kernel(Fp *sels, uint32_t log_lifted, uint32_t log_height) {
+    uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint64_t lifted = 1ull << log_lifted, h = 1ull << log_height;
+    if (p >= lifted) return;
+    uint64_t i = p & (h - 1);
+    sels[p] = i == 0 ? Fp::one() : Fp::zero();
+    sels[lifted + p] = i == h - 1 ? Fp::zero() : Fp::one();
+    sels[2 * lifted + p] = i == h - 1 ? Fp::one() : Fp::zero();
+}
+int build_selectors(Fp *sels, uint32_t log_lifted, uint32_t log_height, hipStream_t s) {
+    uint64_t n = 1ull << log_lifted;
+    hipLaunchKernelGGL(build_selectors_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, s, sels, log_lifted, log_height);
+    OVM_CHECK_LAUNCH();
+    return 0;
+}
+
+template <bool MOBIUS>
+__global__ void eq_table_kernel(const EF *point, uint32_t n, EF *out) {
+    uint64_t y = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (y >= (1ull << n)) return;
+    EF acc = EF::one();
+    for (uint32_t i = 0; i < n; i++) {
+        EF x = ld_ef(point + i);
+        EF f;
+        if (MOBIUS)
+            f = (y >> i & 1) ? x : EF::one() - x.dbl();
+        else
+            f = (y >> i & 1) ? x : EF::one() - x;
+        acc = acc * f;
+    }
+    st_ef(out + y, acc);
+}
+int eq_table(const EF *d_point, uint32_t n, EF *out, hipStream_t s) {
+    hipLaunchKernelGGL(eq_table_kernel<false>, dim3(ceil_div(1ull << n, 256)), dim3(256), 0, s, d_point, n, out);
+    OVM_CHECK_LAUNCH();
+    return 0;
+}
+int mobius_eq_table(const EF *d_point, uint32_t n, EF *out, hipStream_t s) {
+    hipLaunchKernelGGL(eq_table_kernel<true>, dim3(ceil_div(1ull << n, 256)), dim3(256), 0, s, d_point, n, out);
+    OVM_CHECK_LAUNCH();
+    return 0;
+}
+
+// ---- coset LDE of 2^l_skip-row chunks --------------------------------------------------------
+static constexpr int LDE_THREADS = 256;
+static constexpr uint32_t LDE_TILE_LOG = 11;
+
+__global__ __launch_bounds__(LDE_THREADS) void coset_lde_kernel(const ColDesc *cols, const uint32_t *used,
+                                                                uint32_t n_cols_total, uint32_t log_lifted,
+                                                                uint32_t l_skip, uint32_t tile_log,
+                                                                uint32_t n_cosets, const Fp *shift_pows,
+                                                                Fp inv_n, Fp *lde, Twiddles tw) {
+    extern __shared__ Fp lds[];
+    const uint32_t tile = 1u << tile_log;
+    Fp *coef = lds, *work = lds + tile;
+    const uint32_t col = used[blockIdx.y];
+    const ColDesc cd = cols[col];
+    const uint64_t base = (uint64_t)blockIdx.x << tile_log;
+    const uint64_t hmask = (1ull << cd.log_height) - 1;
+    for (uint32_t i = threadIdx.x; i < tile; i += LDE_THREADS) coef[i] = cd.ptr[(base + i + cd.rot) & hmask];
+    __syncthreads();
+    const uint32_t half = tile >> 1, N = 1u << l_skip;
+    // inverse DIF over the chunk bits: natural -> bit-reversed coefficients
+    for (uint32_t k = 0; k < l_skip; k++) {
+        const uint32_t bit = l_skip - 1 - k, lo_mask = (1u << bit) - 1;
+        for (uint32_t bf = threadIdx.x; bf < half; bf += LDE_THREADS) {
+            uint32_t i0 = ((bf & ~lo_mask) << 1) | (bf & lo_mask), i1 = i0 | (1u << bit);
+            uint32_t e = i0 & lo_mask;
+            uint32_t e27 = (uint32_t)(((1u << TW_LOG_MAX) - ((uint64_t)e << (TW_LOG_MAX - bit - 1))) & ((1u << TW_LOG_MAX) - 1));
+            Fp a = coef[i0], b = coef[i1];
+            coef[i0] = a + b;
+            Fp d = a - b;
+            coef[i1] = e ? d * tw_pow27(tw, e27) : d;
+        }
+        __syncthreads();
+    }
+    for (uint32_t c = 0; c < n_cosets; c++) {
+        // twist: coefficient of degree i (stored at bitrev position) times shift^i / N
+        for (uint32_t i = threadIdx.x; i < tile; i += LDE_THREADS) {
+            uint32_t deg = bitrev32(i & (N - 1), l_skip);
+            work[i] = coef[i] * (shift_pows[c * N + deg] * inv_n);
+        }
+        __syncthreads();
+        // forward DIT: bit-reversed coefficients -> natural evaluations
+        for (uint32_t bit = 0; bit < l_skip; bit++) {
+            const uint32_t lo_mask = (1u << bit) - 1;
+            for (uint32_t bf = threadIdx.x; bf < half; bf += LDE_THREADS) {
+                uint32_t i0 = ((bf & ~lo_mask) << 1) | (bf & lo_mask), i1 = i0 | (1u << bit);
+                uint32_t e = i0 & lo_mask;
+                Fp a = work[i0], b = work[i1];
+                if (e) b = b * tw_pow27(tw, e << (TW_LOG_MAX - bit - 1));
+                work[i0] = a + b;
+                work[i1] = a - b;
+            }
+            __syncthreads();
+        }
+        Fp *dst = lde + (((uint64_t)c * n_cols_total + col) << log_lifted) + base;
+        for (uint32_t i = threadIdx.x; i < tile; i += LDE_THREADS) dst[i] = work[i];
+        __syncthreads();
+    }
+}
+
+int coset_lde(const ColDesc *d_cols, const uint32_t *d_used, uint32_t n_used, uint32_t n_cols_total,
+              uint32_t log_lifted, uint32_t l_skip, uint32_t n_cosets, const Fp *d_shift_pows, Fp *lde,
+              hipStream_t s) {
+    if (n_used == 0 || n_cosets == 0) return 0;
+    const Twiddles *tw = twiddles();
+    if (!tw || l_skip > LDE_TILE_LOG || l_skip > log_lifted) return (int)hipErrorInvalidValue;
+    uint32_t tile_log = log_lifted < LDE_TILE_LOG ? log_lifted : LDE_TILE_LOG;
+    dim3 grid(1u << (log_lifted - tile_log), n_used);
+    Fp inv_n = Fp::from_canonical(1u << l_skip).inv();
+    hipLaunchKernelGGL(coset_lde_kernel, grid, dim3(LDE_THREADS), 2 * sizeof(Fp) << tile_log, s, d_cols, d_used,
+                       n_cols_total, log_lifted, l_skip, tile_log, n_cosets, d_shift_pows, inv_n, lde, *tw);
+    OVM_CHECK_LAUNCH();
+    return 0;
+}
+
+// ---- round 0 evaluation ----------------------------------------------------------------------
+struct LdeFetch {
+    const Fp *base;  // lde of coset k, column 0
+    uint32_t log_lifted;
+    uint64_t p;
+    __device__ Fp operator()(uint32_t col) const { return base[((uint64_t)col << log_lifted) + p]; }
+};
+
+template <int NS>
+__global__ __launch_bounds__(RED_THREADS) void round0_eval_kernel(DevProgram prog, const Fp *lde,
+                                                                  uint32_t n_cols_total, uint32_t log_lifted,
+                                                                  uint32_t l_skip, uint32_t n_cosets,
+                                                                  uint32_t n_out, const EF *eq_xi, EF add_const,
+                                                                  EF *partials) {
+    __shared__ EF sh[RED_THREADS];
+    const uint32_t N = 1u << l_skip;
+    const uint64_t total = 1ull << log_lifted;
+    const uint64_t stride = (uint64_t)gridDim.x * RED_THREADS;  // multiple of N (N <= RED_THREADS)
+    EF sums[MAX_COSETS * 2];
+#pragma unroll
+    for (int i = 0; i < (int)(MAX_COSETS * 2); i++) sums[i] = EF::zero();
+    Fp slots[NS];
+    for (uint64_t p = (uint64_t)blockIdx.x * RED_THREADS + threadIdx.x; p < total; p += stride) {
+        EF eq = ld_ef(eq_xi + (p >> l_skip));
+        for (uint32_t k = 0; k < n_cosets; k++) {
+            LdeFetch fetch{lde + (((uint64_t)k * n_cols_total) << log_lifted), log_lifted, p};
+            EF out[2] = {EF::zero(), add_const};
+            run_program_acc<Fp>(prog.code, prog.n_instr, prog.weights, slots, fetch, out);
+            sums[2 * k] = sums[2 * k] + eq * out[0];
+            if (n_out > 1) sums[2 * k + 1] = sums[2 * k + 1] + eq * out[1];
+        }
+    }
+    // reduce over lanes with equal z = tid mod N
+    for (uint32_t k = 0; k < n_cosets; k++)
+        for (uint32_t o = 0; o < n_out; o++) {
+            sh[threadIdx.x] = sums[2 * k + o];
+            __syncthreads();
+            if (threadIdx.x < N) {
+                EF acc = sh[threadIdx.x];
+                for (uint32_t j = threadIdx.x + N; j < RED_THREADS; j += N) acc = acc + sh[j];
+                st_ef(partials + ((size_t)blockIdx.x * n_cosets * n_out + k * n_out + o) * N + threadIdx.x, acc);
+            }
+            __syncthreads();
+        }
+}
+
+#define DISPATCH_SLOTS(NSLOTS, CALL)                      \
+    do {                                                  \
+        if ((NSLOTS) <= 8) { CALL(8); }                   \
+        else if ((NSLOTS) <= 32) { CALL(32); }            \
+        else if ((NSLOTS) <= 128) { CALL(128); }          \
+        else if ((NSLOTS) <= 512) { CALL(512); }          \
+        else return (int)hipErrorNotSupported;            \
+    } while (0)
+
+int round0_eval(const DevProgram &prog, const Fp *lde, uint32_t n_cols_total, uint32_t log_lifted, uint32_t l_skip,
+                uint32_t n_cosets, uint32_t n_out, const EF *d_eq_xi, EF add_const, EF *d_partials, EF *d_out,
+                hipStream_t s) {
+    if (n_cosets == 0) return 0;
+    if (n_cosets > MAX_COSETS || n_out > 2 || (1u << l_skip) > RED_THREADS) return (int)hipErrorInvalidValue;
+    uint32_t grid = red_grid(1ull << log_lifted);
+#define CALL(NS)                                                                                              \
+    hipLaunchKernelGGL(round0_eval_kernel<NS>, dim3(grid), dim3(RED_THREADS), 0, s, prog, lde, n_cols_total, \
+                       log_lifted, l_skip, n_cosets, n_out, d_eq_xi, add_const, d_partials)
+    DISPATCH_SLOTS(prog.num_slots, CALL);
+#undef CALL
+    OVM_CHECK_LAUNCH();
+    return sum_partials(d_partials, grid, n_cosets * n_out << l_skip, d_out, s);
+}
+
+// ---- fold_ple: evaluate each chunk's interpolant at r via barycentric weights ---------------
+__global__ void fold_ple_kernel(const ColDesc *cols, uint32_t log_lifted, uint32_t l_skip, const EF *weights,
+                                EF *out) {
+    const uint64_t nx = 1ull << (log_lifted - l_skip);
+    uint64_t x = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (x >= nx) return;
+    const ColDesc cd = cols[blockIdx.y];
+    const uint64_t hmask = (1ull << cd.log_height) - 1;
+    EF acc = EF::zero();
+    for (uint32_t z = 0; z < (1u << l_skip); z++) {
+        Fp v = cd.ptr[((x << l_skip) + z + cd.rot) & hmask];
+        acc = acc + ld_ef(weights + z) * v;
+    }
+    st_ef(out + (uint64_t)blockIdx.y * nx + x, acc);
+}
+int fold_ple(const ColDesc *d_cols, uint32_t n_cols, uint32_t log_lifted, uint32_t l_skip, const EF *d_weights,
+             EF *out, hipStream_t s) {
+    if (n_cols == 0) return 0;
+    uint64_t nx = 1ull << (log_lifted - l_skip);
+    hipLaunchKernelGGL(fold_ple_kernel, dim3(ceil_div(nx, 256), n_cols), dim3(256), 0, s, d_cols, log_lifted, l_skip,
+                       d_weights, out);
+    OVM_CHECK_LAUNCH();
+    return 0;
+}
+
+// ---- multilinear rounds ----------------------------------------------------------------------
+struct MleFetch {
+    const EF *mats;
+    uint32_t log_h;
+    uint64_t y;
+    Fp x;
+    __device__ EF operator()(uint32_t col) const {
+        const EF *p = mats + ((uint64_t)col << log_h) + 2 * y;
+        EF t0 = ld_ef(p), t1 = ld_ef(p + 1);
+        return t0 + (t1 - t0) * x;
+    }
+};
+
+template <int NS>
+__global__ __launch_bounds__(RED_THREADS) void mle_round_kernel(DevProgram prog, const EF *mats, uint32_t log_h,
+                                                                uint32_t degree, uint32_t n_out, const EF *eq,
+                                                                EF add_const, EF *partials) {
+    const uint64_t n_y = 1ull << (log_h - 1);
+    const uint64_t stride = (uint64_t)gridDim.x * RED_THREADS;
+    EF sums[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) sums[i] = EF::zero();
+    EF slots[NS];
+    for (uint64_t y = (uint64_t)blockIdx.x * RED_THREADS + threadIdx.x; y < n_y; y += stride) {
+        EF e = ld_ef(eq + y);
+        for (uint32_t xi = 1; xi <= degree; xi++) {
+            MleFetch fetch{mats, log_h, y, Fp::from_canonical(xi)};
+            EF out[2] = {EF::zero(), add_const};
+            run_program_acc<EF>(prog.code, prog.n_instr, prog.weights, slots, fetch, out);
+            sums[2 * (xi - 1)] = sums[2 * (xi - 1)] + e * out[0];
+            if (n_out > 1) sums[2 * (xi - 1) + 1] = sums[2 * (xi - 1) + 1] + e * out[1];
+        }
+    }
+    block_sum_store<8>(sums, partials + (size_t)blockIdx.x * 8);
+}
+
+int mle_round_eval(const DevProgram &prog, const EF *mats, uint32_t n_cols, uint32_t log_h, uint32_t degree,
+                   uint32_t n_out, const EF *d_eq, EF add_const, EF *d_partials, EF *d_out, hipStream_t s) {
+    if (degree > 4 || n_out > 2 || log_h == 0) return (int)hipErrorInvalidValue;
+    uint32_t grid = red_grid(1ull << (log_h - 1));
+#define CALL(NS)                                                                                          \
+    hipLaunchKernelGGL(mle_round_kernel<NS>, dim3(grid), dim3(RED_THREADS), 0, s, prog, mats, log_h, degree, \
+                       n_out, d_eq, add_const, d_partials)
+    DISPATCH_SLOTS(prog.num_slots, CALL);
+#undef CALL
+    OVM_CHECK_LAUNCH();
+    return sum_partials(d_partials, grid, 8, d_out, s);  // out[2*(X-1)+o]
+}
+
+__global__ void fold_mle_kernel(const EF *in, EF *out, uint32_t log_h, EF r) {
+    const uint64_t h2 = 1ull << (log_h - 1);
+    uint64_t y = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (y >= h2) return;
+    const EF *p = in + ((uint64_t)blockIdx.y << log_h) + 2 * y;
+    EF t0 = ld_ef(p), t1 = ld_ef(p + 1);
+    st_ef(out + (uint64_t)blockIdx.y * h2 + y, t0 + (t1 - t0) * r);
+}
+int fold_mle(const EF *in, EF *out, uint32_t n_cols, uint32_t log_h, EF r, hipStream_t s) {
+    if (n_cols == 0 || log_h == 0) return 0;
+    hipLaunchKernelGGL(fold_mle_kernel, dim3(ceil_div(1ull << (log_h - 1), 256), n_cols), dim3(256), 0, s, in, out,
+                       log_h, r);
+    OVM_CHECK_LAUNCH();
+    return 0;
+}
+
+// ---- LogUp GKR -------------------------------------------------------------------------------
+__device__ __forceinline__ void st_frac(Frac *p, const EF &a, const EF &b) {
+    st_ef(&p->p, a);
+    st_ef(&p->q, b);
+}
+__global__ void gkr_fill_kernel(Frac *leaves, uint64_t n, EF alpha) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) st_frac(leaves + i, EF::zero(), alpha);
+}
+int gkr_fill_leaves(Frac *leaves, uint64_t n, EF alpha, hipStream_t s) {
+    hipLaunchKernelGGL(gkr_fill_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, s, leaves, n, alpha);
+    OVM_CHECK_LAUNCH();
+    return 0;
+}
+
+struct BaseFetch {
+    const ColDesc *cols;
+    uint64_t row;
+    __device__ Fp operator()(uint32_t col) const {
+        const ColDesc cd = cols[col];
+        return cd.ptr[(row + cd.rot) & ((1ull << cd.log_height) - 1)];
+    }
+};
+struct LeafEmit {
+    Frac *leaves;
+    const uint64_t *leaf_base;
+    const uint32_t *leaf_log_len;
+    uint32_t log_height;
+    uint64_t row;
+    Fp norm;
+    __device__ void operator()(uint32_t k, Fp numer, const EF &den) const {
+        EF p = EF::from_base(numer * norm);
+        uint64_t len = 1ull << leaf_log_len[k];
+        for (uint64_t off = 0; off < len; off += 1ull << log_height) st_frac(leaves + leaf_base[k] + off + row, p, den);
+    }
+};
+
+template <int NS>
+__global__ void gkr_leaves_kernel(DevProgram prog, const EF *leaf_const, const ColDesc *cols, uint32_t log_height,
+                                  const uint64_t *leaf_base, const uint32_t *leaf_log_len, Fp norm, Frac *leaves) {
+    uint64_t row = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= (1ull << log_height)) return;
+    Fp slots[NS];
+    BaseFetch fetch{cols, row};
+    LeafEmit emit{leaves, leaf_base, leaf_log_len, log_height, row, norm};
+    run_program_leaves<Fp>(prog.code, prog.n_instr, prog.weights, leaf_const, slots, fetch, emit);
+}
+int gkr_eval_leaves(const DevProgram &prog, const EF *d_leaf_const, const ColDesc *d_cols, uint32_t log_height,
+                    const uint64_t *d_leaf_base, const uint32_t *d_leaf_log_len, Fp norm, Frac *leaves,
+                    hipStream_t s) {
+    uint32_t grid = ceil_div(1ull << log_height, 256);
+#define CALL(NS)                                                                                           \
+    hipLaunchKernelGGL(gkr_leaves_kernel<NS>, dim3(grid), dim3(256), 0, s, prog, d_leaf_const, d_cols, log_height, \
+                       d_leaf_base, d_leaf_log_len, norm, leaves)
+    DISPATCH_SLOTS(prog.num_slots, CALL);
+#undef CALL
+    OVM_CHECK_LAUNCH();
+    return 0;
+}
+
+__global__ void gkr_build_kernel(const Frac *child, Frac *parent, uint64_t n_parent) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_parent) return;
+    EF p0 = ld_ef(&child[2 * i].p), q0 = ld_ef(&child[2 * i].q);
+    EF p1 = ld_ef(&child[2 * i + 1].p), q1 = ld_ef(&child[2 * i + 1].q);
+    st_frac(parent + i, p0 * q1 + q0 * p1, q0 * q1);
+}
+int gkr_build_layer(const Frac *child, Frac *parent, uint64_t n_parent, hipStream_t s) {
+    hipLaunchKernelGGL(gkr_build_kernel, dim3(ceil_div(n_parent, 256)), dim3(256), 0, s, child, parent, n_parent);
+    OVM_CHECK_LAUNCH();
+    return 0;
+}
+
+__global__ __launch_bounds__(RED_THREADS) void gkr_round_kernel(const EF *rec, const EF *eq, uint64_t n_pairs,
+                                                                EF lambda, EF *partials) {
+    const uint64_t stride = (uint64_t)gridDim.x * RED_THREADS;
+    EF sums[3] = {EF::zero(), EF::zero(), EF::zero()};
+    for (uint64_t y = (uint64_t)blockIdx.x * RED_THREADS + threadIdx.x; y < n_pairs; y += stride) {
+        const EF *r0 = rec + 8 * y;  // records 2y and 2y+1, 4 EF each
+        EF a[4], d[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            a[i] = ld_ef(r0 + i);
+            d[i] = ld_ef(r0 + 4 + i) - a[i];
+        }
+        EF e0 = ld_ef(eq + 2 * y), ed = ld_ef(eq + 2 * y + 1) - e0;
+        EF e = e0;
+#pragma unroll
+        for (int xi = 0; xi < 3; xi++) {
+            e = e + ed;
+#pragma unroll
+            for (int i = 0; i < 4; i++) a[i] = a[i] + d[i];
+            // (p0, q0, p1, q1) at X = xi+1
+            EF pq = a[0] * a[3] + a[2] * a[1];
+            EF qq = a[1] * a[3];
+            sums[xi] = sums[xi] + e * (pq + lambda * qq);
+        }
+    }
+    block_sum_store<3>(sums, partials + (size_t)blockIdx.x * 3);
+}
+int gkr_round(const EF *rec, const EF *eq, uint64_t n_pairs, EF lambda, EF *d_partials, EF *d_out, hipStream_t s) {
+    uint32_t grid = red_grid(n_pairs);
+    hipLaunchKernelGGL(gkr_round_kernel, dim3(grid), dim3(RED_THREADS), 0, s, rec, eq, n_pairs, lambda, d_partials);
+    OVM_CHECK_LAUNCH();
+    return sum_partials(d_partials, grid, 3, d_out, s);
+}
+
+__global__ void gkr_fold_kernel(const EF *rec_in, const EF *eq_in, EF *rec_out, EF *eq_out, uint64_t n_out, EF r) {
+    uint64_t y = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (y >= n_out) return;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        EF a = ld_ef(rec_in + 8 * y + i), b = ld_ef(rec_in + 8 * y + 4 + i);
+        st_ef(rec_out + 4 * y + i, a + (b - a) * r);
+    }
+    EF e0 = ld_ef(eq_in + 2 * y), e1 = ld_ef(eq_in + 2 * y + 1);
+    st_ef(eq_out + y, e0 + (e1 - e0) * r);
+}
+int gkr_fold(const EF *rec_in, const EF *eq_in, EF *rec_out, EF *eq_out, uint64_t n_out, EF r, hipStream_t s) {
+    hipLaunchKernelGGL(gkr_fold_kernel, dim3(ceil_div(n_out, 256)), dim3(256), 0, s, rec_in, eq_in, rec_out, eq_out,
+                       n_out, r);
+    OVM_CHECK_LAUNCH();
+    return 0;
+}
+
+// ---- stacked reduction -----------------------------------------------------------------------
+__global__ __launch_bounds__(RED_THREADS) void stacked_round0_kernel(const Fp *base, uint32_t n_slices,
+                                                                     uint32_t log_len, uint32_t l_skip,
+                                                                     const EF *lam_eq, const EF *lam_rot,
+                                                                     const EF *eq_cube, EF *partials) {
+    __shared__ EF sh[RED_THREADS];
+    const uint32_t N = 1u << l_skip;
+    const uint64_t total = 1ull << log_len, stride = (uint64_t)gridDim.x * RED_THREADS;
+    const uint64_t nx = total >> l_skip;
+    EF sums[3] = {EF::zero(), EF::zero(), EF::zero()};
+    for (uint64_t p = (uint64_t)blockIdx.x * RED_THREADS + threadIdx.x; p < total; p += stride) {
+        EF qe = EF::zero(), qr = EF::zero();
+        for (uint32_t i = 0; i < n_slices; i++) {
+            Fp v = base[((uint64_t)i << log_len) + p];
+            qe = qe + ld_ef(lam_eq + i) * v;
+            qr = qr + ld_ef(lam_rot + i) * v;
+        }
+        uint64_t x = p >> l_skip, xp = x == 0 ? nx - 1 : x - 1;
+        EF ec = ld_ef(eq_cube + x), ecp = ld_ef(eq_cube + xp);
+        sums[0] = sums[0] + ec * qe;
+        sums[1] = sums[1] + ec * qr;
+        sums[2] = sums[2] + (ecp - ec) * qr;
+    }
+    for (uint32_t v = 0; v < 3; v++) {
+        sh[threadIdx.x] = sums[v];
+        __syncthreads();
+        if (threadIdx.x < N) {
+            EF acc = sh[threadIdx.x];
+            for (uint32_t j = threadIdx.x + N; j < RED_THREADS; j += N) acc = acc + sh[j];
+            st_ef(partials + ((size_t)blockIdx.x * 3 + v) * N + threadIdx.x, acc);
+        }
+        __syncthreads();
+    }
+}
+int stacked_round0(const Fp *base, uint32_t n_slices, uint32_t log_len, uint32_t l_skip, const EF *d_lam_eq,
+                   const EF *d_lam_rot, const EF *d_eq_cube, EF *d_partials, EF *d_out, hipStream_t s) {
+    if ((1u << l_skip) > RED_THREADS) return (int)hipErrorInvalidValue;
+    uint32_t grid = red_grid(1ull << log_len);
+    hipLaunchKernelGGL(stacked_round0_kernel, dim3(grid), dim3(RED_THREADS), 0, s, base, n_slices, log_len, l_skip,
+                       d_lam_eq, d_lam_rot, d_eq_cube, d_partials);
+    OVM_CHECK_LAUNCH();
+    return sum_partials(d_partials, grid, 3u << l_skip, d_out, s);
+}
+
+__global__ void stacked_combine_kernel(const EF *q, const uint64_t *slice_off, uint32_t n_slices, uint32_t log_len,
+                                       const EF *coef_eq, const EF *coef_rot, EF *out_eq, EF *out_rot) {
+    uint64_t x = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (x >= (1ull << log_len)) return;
+    EF ae = EF::zero(), ar = EF::zero();
+    for (uint32_t i = 0; i < n_slices; i++) {
+        EF v = ld_ef(q + slice_off[i] + x);
+        ae = ae + ld_ef(coef_eq + i) * v;
+        ar = ar + ld_ef(coef_rot + i) * v;
+    }
+    st_ef(out_eq + x, ae);
+    st_ef(out_rot + x, ar);
+}
+int stacked_combine(const EF *q, const uint64_t *d_slice_off, uint32_t n_slices, uint32_t log_len,
+                    const EF *d_coef_eq, const EF *d_coef_rot, EF *out_eq, EF *out_rot, hipStream_t s) {
+    hipLaunchKernelGGL(stacked_combine_kernel, dim3(ceil_div(1ull << log_len, 256)), dim3(256), 0, s, q, d_slice_off,
+                       n_slices, log_len, d_coef_eq, d_coef_rot, out_eq, out_rot);
+    OVM_CHECK_LAUNCH();
+    return 0;
+}
+
+__global__ __launch_bounds__(RED_THREADS) void stacked_round_kernel(const EF *vec4, uint32_t log_h, EF *partials) {
+    const uint64_t h = 1ull << log_h, n_y = h >> 1, stride = (uint64_t)gridDim.x * RED_THREADS;
+    const EF *qe = vec4, *qr = vec4 + h, *eq = vec4 + 2 * h, *kr = vec4 + 3 * h;
+    EF sums[2] = {EF::zero(), EF::zero()};
+    for (uint64_t y = (uint64_t)blockIdx.x * RED_THREADS + threadIdx.x; y < n_y; y += stride) {
+        EF a0 = ld_ef(qe + 2 * y), a1 = ld_ef(qe + 2 * y + 1), b0 = ld_ef(qr + 2 * y), b1 = ld_ef(qr + 2 * y + 1);
+        EF e0 = ld_ef(eq + 2 * y), e1 = ld_ef(eq + 2 * y + 1), k0 = ld_ef(kr + 2 * y), k1 = ld_ef(kr + 2 * y + 1);
+        // X = 1
+        sums[0] = sums[0] + a1 * e1 + b1 * k1;
+        // X = 2: v(2) = 2 v1 - v0
+        EF a2 = a1.dbl() - a0, b2 = b1.dbl() - b0, e2 = e1.dbl() - e0, k2 = k1.dbl() - k0;
+        sums[1] = sums[1] + a2 * e2 + b2 * k2;
+    }
+    block_sum_store<2>(sums, partials + (size_t)blockIdx.x * 2);
+}
+int stacked_round(const EF *vec4, uint32_t log_h, EF *d_partials, EF *d_out, hipStream_t s) {
+    uint32_t grid = red_grid(1ull << (log_h - 1));
+    hipLaunchKernelGGL(stacked_round_kernel, dim3(grid), dim3(RED_THREADS), 0, s, vec4, log_h, d_partials);
+    OVM_CHECK_LAUNCH();
+    return sum_partials(d_partials, grid, 2, d_out, s);
+}
+
+// ---- WHIR ------------------------------------------------------------------------------------
+__global__ void whir_mu_batch_kernel(const Fp *msg, uint32_t width, uint32_t log_h, const EF *mu_pows,
+                                     uint32_t mu_offset, EF *f, int accumulate) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (1ull << log_h)) return;
+    EF acc = accumulate ? ld_ef(f + i) : EF::zero();
+    for (uint32_t j = 0; j < width; j++) acc = acc + ld_ef(mu_pows + mu_offset + j) * msg[((uint64_t)j << log_h) + i];
+    st_ef(f + i, acc);
+}
+int whir_mu_batch(const Fp *msg, uint32_t width, uint32_t log_h, const EF *d_mu_pows, uint32_t mu_offset, EF *f,
+                  int accumulate, hipStream_t s) {
+    hipLaunchKernelGGL(whir_mu_batch_kernel, dim3(ceil_div(1ull << log_h, 256)), dim3(256), 0, s, msg, width, log_h,
+                       d_mu_pows, mu_offset, f, accumulate);
+    OVM_CHECK_LAUNCH();
+    return 0;
+}
+
+// One pass of up to ZT_BITS butterfly stages (bits [b0, b0+nb)) of the subset-zeta / Moebius
+// transform, staged through LDS: tile = 2^nb x 2^c elements, c low bits contiguous.
+static constexpr uint32_t ZT_TILE_LOG = 11;
+__global__ __launch_bounds__(256) void zeta_pass_kernel(EF *v, uint32_t log_n, uint32_t b0, uint32_t nb, uint32_t c,
+                                                        int dir) {
+    extern __shared__ unsigned char zsm[];
+    EF *tile = reinterpret_cast<EF *>(zsm);
+    const uint32_t tile_size = 1u << (nb + c), c_mask = (1u << c) - 1;
+    // position = (hi << (b0 + nb)) | (t << b0) | (mid << c) | cc   (c <= b0)
+    const uint64_t tile_id = blockIdx.x;
+    const uint64_t mid = tile_id & ((1ull << (b0 - c)) - 1), hi = tile_id >> (b0 - c);
+    const uint64_t base = (hi << (b0 + nb)) | (mid << c);
+    for (uint32_t l = threadIdx.x; l < tile_size; l += 256) {
+        uint64_t p = base | ((uint64_t)(l >> c) << b0) | (l & c_mask);
+        tile[l] = ld_ef(v + p);
+    }
+    __syncthreads();
+    for (uint32_t k = 0; k < nb; k++) {
+        const uint32_t lbit = k + c, lo_mask = (1u << lbit) - 1;
+        for (uint32_t bf = threadIdx.x; bf < (tile_size >> 1); bf += 256) {
+            uint32_t l0 = ((bf & ~lo_mask) << 1) | (bf & lo_mask), l1 = l0 | (1u << lbit);
+            tile[l1] = dir > 0 ? tile[l1] + tile[l0] : tile[l1] - tile[l0];
+        }
+        __syncthreads();
+    }
+    for (uint32_t l = threadIdx.x; l < tile_size; l += 256) {
+        uint64_t p = base | ((uint64_t)(l >> c) << b0) | (l & c_mask);
+        st_ef(v + p, tile[l]);
+    }
+}
+int zeta_transform(EF *v, uint32_t log_n, int dir, hipStream_t s) {
+    // low bits first in one contiguous pass, then strided passes of up to ZT_TILE_LOG-4 bits
+    uint32_t b = 0;
+    while (b < log_n) {
+        uint32_t nb, c;
+        if (b == 0) {
+            nb = log_n < ZT_TILE_LOG ? log_n : ZT_TILE_LOG;
+            c = 0;
+        } else {
+            c = 4;  // 16 EF = 256 B runs
+            nb = log_n - b < ZT_TILE_LOG - c ? log_n - b : ZT_TILE_LOG - c;
+        }
+        uint32_t tiles = 1u << (log_n - nb - c);
+        hipLaunchKernelGGL(zeta_pass_kernel, dim3(tiles), dim3(256), sizeof(EF) << (nb + c), s, v, log_n, b, nb, c, dir);
+        OVM_CHECK_LAUNCH();
+        b += nb;
+    }
+    return 0;
+}
+
+__global__ __launch_bounds__(RED_THREADS) void whir_round_kernel(const EF *f, const EF *w, uint64_t n_pairs,
+                                                                 EF *partials) {
+    const uint64_t stride = (uint64_t)gridDim.x * RED_THREADS;
+    EF sums[2] = {EF::zero(), EF::zero()};
+    for (uint64_t y = (uint64_t)blockIdx.x * RED_THREADS + threadIdx.x; y < n_pairs; y += stride) {
+        EF f0 = ld_ef(f + 2 * y), f1 = ld_ef(f + 2 * y + 1), w0 = ld_ef(w + 2 * y), w1 = ld_ef(w + 2 * y + 1);
+        sums[0] = sums[0] + f1 * w1;
+        sums[1] = sums[1] + (f1.dbl() - f0) * (w1.dbl() - w0);
+    }
+    block_sum_store<2>(sums, partials + (size_t)blockIdx.x * 2);
+}
+int whir_round(const EF *f, const EF *w, uint64_t n_pairs, EF *d_partials, EF *d_out, hipStream_t s) {
+    uint32_t grid = red_grid(n_pairs);
+    hipLaunchKernelGGL(whir_round_kernel, dim3(grid), dim3(RED_THREADS), 0, s, f, w, n_pairs, d_partials);
+    OVM_CHECK_LAUNCH();
+    return sum_partials(d_partials, grid, 2, d_out, s);
+}
+
+__global__ void whir_fold_kernel(const EF *f_in, const EF *w_in, EF *f_out, EF *w_out, uint64_t n_out, EF alpha) {
+    uint64_t y = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (y >= n_out) return;
+    EF f0 = ld_ef(f_in + 2 * y), f1 = ld_ef(f_in + 2 * y + 1), w0 = ld_ef(w_in + 2 * y), w1 = ld_ef(w_in + 2 * y + 1);
+    st_ef(f_out + y, f0 + alpha * (f1 - f0));
+    st_ef(w_out + y, w0 + alpha * (w1 - w0));
+}
+int whir_fold(const EF *f_in, const EF *w_in, EF *f_out, EF *w_out, uint64_t n_out, EF alpha, hipStream_t s) {
+    hipLaunchKernelGGL(whir_fold_kernel, dim3(ceil_div(n_out, 256)), dim3(256), 0, s, f_in, w_in, f_out, w_out, n_out,
+                       alpha);
+    OVM_CHECK_LAUNCH();
+    return 0;
+}
+
+// sum_i c_i z^i: each lane Horner-evaluates a contiguous run of HORNER_RUN coefficients and scales
+// by z^(run start).
+static constexpr uint32_t HORNER_RUN = 16;
+__global__ __launch_bounds__(RED_THREADS) void horner_kernel(const EF *coeffs, uint64_t n, EF z, EF z_run,
+                                                             EF *partials) {
+    const uint64_t n_runs = (n + HORNER_RUN - 1) / HORNER_RUN, stride = (uint64_t)gridDim.x * RED_THREADS;
+    EF sums[1] = {EF::zero()};
+    for (uint64_t r = (uint64_t)blockIdx.x * RED_THREADS + threadIdx.x; r < n_runs; r += stride) {
+        uint64_t lo = r * HORNER_RUN, hi = lo + HORNER_RUN < n ? lo + HORNER_RUN : n;
+        EF acc = EF::zero();
+        for (uint64_t i = hi; i-- > lo;) acc = acc * z + ld_ef(coeffs + i);
+        sums[0] = sums[0] + acc * z_run.pow(r);
+    }
+    block_sum_store<1>(sums, partials + blockIdx.x);
+}
+int horner_eval(const EF *coeffs, uint64_t n, EF z, EF *d_partials, EF *d_out, hipStream_t s) {
+    uint32_t grid = red_grid((n + HORNER_RUN - 1) / HORNER_RUN);
+    hipLaunchKernelGGL(horner_kernel, dim3(grid), dim3(RED_THREADS), 0, s, coeffs, n, z, z.pow(HORNER_RUN), d_partials);
+    OVM_CHECK_LAUNCH();
+    return sum_partials(d_partials, grid, 1, d_out, s);
+}
+
+// tab_lo[q * 2^log_lo + x_lo] (already scaled by gamma_q), tab_hi[q * 2^(log_n - log_lo) + x_hi]
+__global__ void whir_w_accumulate_kernel(EF *w, uint32_t log_n, const EF *tab_lo, const EF *tab_hi, uint32_t log_lo,
+                                         uint32_t n_q) {
+    uint64_t x = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (x >= (1ull << log_n)) return;
+    uint64_t lo = x & ((1ull << log_lo) - 1), hi = x >> log_lo;
+    const uint32_t log_hi = log_n - log_lo;
+    EF acc = ld_ef(w + x);
+    for (uint32_t q = 0; q < n_q; q++)
+        acc = acc + ld_ef(tab_lo + ((uint64_t)q << log_lo) + lo) * ld_ef(tab_hi + ((uint64_t)q << log_hi) + hi);
+    st_ef(w + x, acc);
+}
+int whir_w_accumulate(EF *w, uint32_t log_n, const EF *d_tab_lo, const EF *d_tab_hi, uint32_t log_lo, uint32_t n_q,
+                      hipStream_t s) {
+    hipLaunchKernelGGL(whir_w_accumulate_kernel, dim3(ceil_div(1ull << log_n, 256)), dim3(256), 0, s, w, log_n,
+                       d_tab_lo, d_tab_hi, log_lo, n_q);
+    OVM_CHECK_LAUNCH();
+    return 0;
+}
+
+__global__ void gather_ef_kernel(const EF *src, const uint64_t *idx, uint64_t n, EF *out) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) st_ef(out + i, ld_ef(src + idx[i]));
+}
+int gather_ef(const EF *src, const uint64_t *d_idx, uint64_t n, EF *out, hipStream_t s) {
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(gather_ef_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, s, src, d_idx, n, out);
+    OVM_CHECK_LAUNCH();
+    return 0;
+}
+
+}  // namespace ovm

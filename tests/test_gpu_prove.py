@@ -1,0 +1,57 @@
+"""GPU parity: the whole prove path through the C ABI produces proof bytes identical to the CPU
+oracle's (which the oracle's restatement of the reference verifier accepts)."""
+import numpy as np
+import pytest
+
+import airs
+
+pytestmark = pytest.mark.gpu
+SECTIONS = ["header", "gkr", "batch_constraints", "stacking", "whir"]
+
+
+def run_case(dev, pkg, orc, params, air_list, traces):
+    blob = airs.pk_blob(params, air_list)
+    want = orc.prove(blob, traces)
+    orc.verify(blob, want["proof"])
+    pk = pkg.ProvingKey(blob)
+    dtr = [(a, dev.upload(pkg.to_mont(np.asarray(tr, dtype=np.uint32))), h, pv) for a, tr, h, pv in traces]
+    got, secs = dev.prove(pk, dtr)
+    if got != want["proof"]:
+        n = min(len(got), len(want["proof"]))
+        first = next((i for i in range(n) if got[i] != want["proof"][i]), n)
+        sec = next((SECTIONS[k] for k, e in enumerate(secs) if first < e), "tail")
+        pytest.fail(f"proof differs at byte {first} (section {sec}); lengths {len(got)} vs {len(want['proof'])}; sections {secs}")
+    orc.verify(blob, got)
+
+
+@pytest.mark.parametrize("log_h,l_skip,n_stack,k_whir", [(4, 2, 4, 2), (6, 2, 6, 3), (5, 3, 5, 2), (1, 2, 3, 1)])
+def test_fibonacci(dev, pkg, orc, log_h, l_skip, n_stack, k_whir):
+    params = airs.test_params(l_skip=l_skip, n_stack=n_stack, k_whir=k_whir)
+    tr, pvs = airs.fibonacci_trace(0, 1, 1 << log_h)
+    run_case(dev, pkg, orc, params, [airs.fibonacci_air()], [(0, tr, 1 << log_h, pvs)])
+
+
+def test_interactions(dev, pkg, orc):
+    params = airs.test_params(l_skip=2, n_stack=5, k_whir=2)
+    s = np.array([[0, 1], [7, 4], [3, 5], [546, 889]], dtype=np.uint32)
+    r = np.array([[1, 5], [3, 4], [4, 4], [2, 5], [0, 123], [545, 889], [1, 889], [0, 456]], dtype=np.uint32)
+    traces = [(0, np.ascontiguousarray(s.T).reshape(-1), 4, []), (1, np.ascontiguousarray(r.T).reshape(-1), 8, [])]
+    run_case(dev, pkg, orc, params, [airs.dummy_interaction_air(1, True, 0), airs.dummy_interaction_air(1, False, 0)], traces)
+
+
+@pytest.mark.parametrize("cols,log_h,l_skip,n_stack,k_whir", [(8, 5, 2, 6, 2), (20, 8, 4, 8, 4), (100, 10, 4, 12, 4)])
+def test_benchmark_air(dev, pkg, orc, cols, log_h, l_skip, n_stack, k_whir):
+    params = airs.test_params(l_skip=l_skip, n_stack=n_stack, k_whir=k_whir)
+    h = 1 << log_h
+    tr = airs.splitmix64_bits(0xD15EA5E, cols * h)
+    run_case(dev, pkg, orc, params, [airs.uniform_runner_air(cols)], [(0, tr, h, [])])
+
+
+def test_multi_air_mixed_heights(dev, pkg, orc):
+    params = airs.test_params(l_skip=2, n_stack=6, k_whir=2)
+    bench = airs.uniform_runner_air(8)
+    t1, pv = airs.fibonacci_trace(0, 1, 16)
+    t2 = airs.splitmix64_bits(1, 8 * 64)
+    t3 = airs.splitmix64_bits(2, 8 * 2)
+    run_case(dev, pkg, orc, params, [airs.fibonacci_air(), bench, bench],
+             [(0, t1, 16, pv), (1, t2, 64, []), (2, t3, 2, [])])
