@@ -1,0 +1,146 @@
+#!/usr/bin/env python3
+"""Headline benchmark: prove a synthetic 2^22-row x 100-column BabyBear AIR (uniform_runner shape,
+app parameters, blowup 2) on N MI355X GPUs, one process per GPU.
+
+    python bench.py --gpus N --steps K --warmup W
+
+A "step" is one full `prove` (commit + LogUp-GKR + batch sumcheck + stacked reduction + WHIR) of
+one trace that is already resident in HBM. For N > 1 every rank proves its own AIR instance
+(independent proofs, weak scaling, no data-path collective -- DESIGN.md "Multi-GPU"); rank 0
+prints ONE JSON line. `roofline` is for the dominant kernel (live HIP-event timing on the launch
+stream); `cpu_baseline` times the CPU oracle on a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--log-rows", type=int, default=22)
+    ap.add_argument("--cols", type=int, default=100)
+    ap.add_argument("--log-stacked-height", type=int, default=24)
+    ap.add_argument("--cpu-log-rows", type=int, default=16, help="rows of the CPU-baseline sample")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import __graft_entry__ as ge
+    import airs
+
+    pkg = ge._load_pkg()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+        dist = dist_mod
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+    dev = pkg.Device(local_rank)
+
+    # ---- workload: uniform_runner BenchmarkAir (benchmarks/synthetic/src/bin/uniform_runner.rs) ----
+    log_rows, cols = args.log_rows, args.cols
+    h = 1 << log_rows
+    params = airs.app_params(args.log_stacked_height)
+    air = airs.uniform_runner_air(cols)
+    pk = pkg.ProvingKey(airs.pk_blob(params, [air]))
+    gen = torch.Generator(device=f"cuda:{local_rank}")
+    gen.manual_seed(0xD15EA5E + rank)
+    bits = torch.randint(0, 2, (cols * h,), dtype=torch.int32, device=f"cuda:{local_rank}", generator=gen)
+    one_mont = int(pkg.to_mont(np.array([1], dtype=np.uint32))[0])
+    trace = bits * one_mont  # boolean cells in Montgomery form, column-major
+    del bits
+    traces = [(0, trace, h, [])]
+    cells = cols * h
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    proof = b""
+    for _ in range(args.warmup):
+        proof, _ = dev.prove(pk, traces)
+    pkg.profile_enable(True)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        proof, _ = dev.prove(pk, traces)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    prof = pkg.profile_report()
+    pkg.profile_enable(False)
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        value = world * cells * args.steps / elapsed
+        # dominant kernel = the label with the largest device time
+        stages = {k: v[1] / args.steps for k, v in prof.items()}
+        dom = max(stages, key=lambda k: stages[k]) if stages else None
+        roof = None
+        if "merkle.hash_rows" in prof:
+            calls, total_ms = prof["merkle.hash_rows"]
+            rows = 1 << (args.log_stacked_height + params["log_blowup"])
+            width = (cols * h) >> args.log_stacked_height
+            # algorithmic bytes per launch: read the codeword once + write one digest per row
+            algo_bytes = 4 * rows * width + 32 * rows
+            avg_s = total_ms / calls * 1e-3
+            achieved = algo_bytes / avg_s / 1e9
+            roof = {"kernel": "hash_rows_kernel<1> (Poseidon2 leaf hash; integer-ALU bound, see DESIGN.md)",
+                    "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                    "avg_launch_ms": round(total_ms / calls, 3), "algorithmic_bytes": algo_bytes}
+        cpu = None
+        if not args.no_cpu_baseline:
+            import oracle_lib
+            orc = oracle_lib.load()
+            lr = args.cpu_log_rows
+            p2 = airs.app_params(args.log_stacked_height - (log_rows - lr))
+            blob = airs.pk_blob(p2, [air])
+            tr = airs.splitmix64_bits(0xD15EA5E, cols << lr)
+            c0 = time.perf_counter()
+            orc.prove(blob, [(0, tr, 1 << lr, [])])
+            cdt = time.perf_counter() - c0
+            cpu = {"value": round((cols << lr) / cdt, 1), "unit": "cells/s", "cores": os.cpu_count(), "kind": "port",
+                   "sample": f"C++ oracle (OpenMP), one prove of 2^{lr} x {cols} BenchmarkAir, app params with "
+                             f"log_stacked_height {args.log_stacked_height - (log_rows - lr)}, {cdt:.1f} s"}
+        line = {
+            "metric": "trace_cells_per_sec", "value": round(value, 1), "unit": "cells/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
+            "prove_ms": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u32 (BabyBear Montgomery; F_p^4 challenges)", "data": "synthetic",
+            "config": {"workload": f"uniform_runner BenchmarkAir 2^{log_rows} rows x {cols} cols per GPU, "
+                                   f"200 boolean constraints, 13 send/receive pairs, app params "
+                                   f"(l_skip 4, n_stack {args.log_stacked_height - 4}, log_blowup 1, k_whir 4, "
+                                   f"PoW 18/15/5/20 bits), seeded random boolean trace",
+                       "proof_bytes": len(proof), "parallelism": f"replicas x{world}"},
+            "roofline": roof, "cpu_baseline": cpu,
+            "stage_ms": {k: round(v, 3) for k, v in sorted(stages.items(), key=lambda kv: -kv[1])},
+            "dominant_stage": dom,
+        }
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -52,6 +52,13 @@ int ovm_hip_init(int device, uint32_t *cu_count);
 /* Name of a non-zero return code (hipGetErrorName). */
 const char *ovm_hip_error_name(int code);
 
+/* Per-stage timing with HIP events on the launching stream (reference: the `tracing` spans /
+ * NVTX ranges of crates/stark-sdk/src/{metrics_tracing,nvtx_tracing}.rs). enable(1) resets and
+ * starts recording, enable(0) stops. report() synchronises the device and writes one
+ * "label calls total_ms" line per label; returns the buffer size needed. */
+int ovm_hip_profile_enable(int on);
+uint64_t ovm_hip_profile_report(char *buf, uint64_t cap);
+
 /* Plain device memory management for callers without a HIP binding of their own
  * (reference: crates/cuda-common/src/d_buffer.rs, copy.rs). */
 int ovm_hip_malloc(void **d_ptr, size_t bytes);

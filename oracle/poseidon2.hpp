@@ -166,14 +166,24 @@ struct Transcript {
     // returns the MINIMUM valid witness, which is what a single-threaded `find_any` yields.
     Fp grind(unsigned bits) {
         if (bits == 0) return Fp::zero();
-        for (uint64_t w = 0; w < P; w++) {
-            Transcript c = fork();
-            if (c.check_witness(bits, Fp(w))) {
-                bool ok = check_witness(bits, Fp(w));
+        // scan ascending batches in parallel; the smallest hit of the first batch with a hit is
+        // the global minimum
+        const uint64_t BATCH = 1 << 14;
+        for (uint64_t base = 0; base < P; base += BATCH) {
+            uint64_t best = UINT64_MAX;
+#pragma omp parallel for reduction(min : best)
+            for (long long i = 0; i < (long long)BATCH; i++) {
+                uint64_t w = base + (uint64_t)i;
+                if (w >= P) continue;
+                Transcript c = fork();
+                if (c.check_witness(bits, Fp(w)) && w < best) best = w;
+            }
+            if (best != UINT64_MAX) {
+                bool ok = check_witness(bits, Fp(best));
                 assert(ok);
                 (void)ok;
-                pow_log.push_back(Fp(w));
-                return Fp(w);
+                pow_log.push_back(Fp(best));
+                return Fp(best);
             }
         }
         assert(false && "no PoW witness");

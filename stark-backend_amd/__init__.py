@@ -51,6 +51,8 @@ SIGNATURES = {
     "ovm_hip_abi_version": (c_uint32, []),
     "ovm_hip_init": (c_int, [c_int, _u32p]),
     "ovm_hip_error_name": (c_char_p, [c_int]),
+    "ovm_hip_profile_enable": (c_int, [c_int]),
+    "ovm_hip_profile_report": (c_uint64, [c_char_p, c_uint64]),
     "ovm_hip_malloc": (c_int, [POINTER(c_void_p), c_size_t]),
     "ovm_hip_free": (c_int, [c_void_p]),
     "ovm_hip_memcpy_h2d": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
@@ -271,3 +273,18 @@ def _prove(self, pk: ProvingKey, traces, sponge: SpongeState | None = None, proo
 
 
 Device.prove = _prove
+
+
+def profile_enable(on: bool) -> None:
+    _lib().ovm_hip_profile_enable(1 if on else 0)
+
+
+def profile_report() -> dict:
+    """{label: (calls, total_ms)} measured with HIP events on the launching stream."""
+    buf = ctypes.create_string_buffer(1 << 16)
+    _lib().ovm_hip_profile_report(buf, len(buf))
+    out = {}
+    for line in buf.value.decode().splitlines():
+        label, calls, ms = line.rsplit(" ", 2)
+        out[label] = (int(calls), float(ms))
+    return out

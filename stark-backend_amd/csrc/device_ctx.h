@@ -40,6 +40,18 @@ __device__ __forceinline__ bb::Fp tw_pow27(const Twiddles &tw, uint32_t e27) {
 // Returns the table for the current device (building it on first use). nullptr on failure.
 const Twiddles *twiddles();
 
+// Optional per-stage timing with HIP events recorded on the launching stream (bench.py reads it
+// through ovm_hip_profile_*). Off by default: no events are created.
+struct ProfScope {
+    int slot = -1;
+    hipStream_t stream;
+    ProfScope(const char *label, hipStream_t s);
+    ~ProfScope();
+};
+#define OVM_PROF_CAT2(a, b) a##b
+#define OVM_PROF_CAT(a, b) OVM_PROF_CAT2(a, b)
+#define OVM_PROF(label, stream) ovm::ProfScope OVM_PROF_CAT(_prof_scope_, __LINE__)(label, stream)
+
 inline unsigned ceil_div(uint64_t a, uint64_t b) { return (unsigned)((a + b - 1) / b); }
 
 __host__ __device__ __forceinline__ uint32_t bitrev32(uint32_t x, unsigned bits) {

@@ -150,10 +150,14 @@ static int merkle_tree_impl(const uint32_t *d_matrix, uint64_t width, uint32_t l
     Digest *leaf = (Digest *)d_scratch;          // rows digests
     Digest *pong = leaf + rows;                  // rows/2 digests (only if k >= 2)
     Digest *layers = (Digest *)d_digest_layers;  // 2*query_stride - 1 digests
-    hipLaunchKernelGGL(hash_rows_kernel<WORDS>, dim3(ceil_div(rows, HASH_THREADS)),
-                       dim3(HASH_THREADS), 0, stream, (const Fp *)d_matrix, width, rows, rows,
-                       log_rows_per_query == 0 ? layers : leaf);
-    OVM_CHECK_LAUNCH();
+    {
+        OVM_PROF(WORDS == 1 ? "merkle.hash_rows" : "merkle.hash_rows_ext", stream);
+        hipLaunchKernelGGL(hash_rows_kernel<WORDS>, dim3(ceil_div(rows, HASH_THREADS)),
+                           dim3(HASH_THREADS), 0, stream, (const Fp *)d_matrix, width, rows, rows,
+                           log_rows_per_query == 0 ? layers : leaf);
+        OVM_CHECK_LAUNCH();
+    }
+    OVM_PROF("merkle.compress_layers", stream);
     // k group-local layers: leaf -> ... -> layers[0]
     const Digest *cur = leaf;
     uint64_t n = rows;
@@ -233,6 +237,7 @@ int ovm_hip_sponge_grind(const ovm_sponge_t *sponge, uint32_t bits, uint32_t *wi
     s.absorb_idx = sponge->absorb_idx;
     s.sample_idx = sponge->sample_idx;
     if (s.absorb_idx >= 8 || s.sample_idx > 8) return (int)hipErrorInvalidValue;
+    OVM_PROF("grind", stream);
     static thread_local uint32_t *d_result = nullptr;
     if (!d_result) OVM_CHECK(hipMalloc(&d_result, sizeof(uint32_t)));
     // Expected 2^bits candidates per hit: scan in batches of that size, ascending, so the first

@@ -211,6 +211,7 @@ static int dif_ntt(const T *in, T *out, uint64_t width, uint32_t L, uint32_t log
     const uint32_t r_max = tile_log - C_LOG;
     uint32_t strided = L > tile_log ? L - tile_log : 0;
     uint32_t n_strided = (strided + r_max - 1) / r_max;
+    OVM_PROF(sizeof(T) == 4 ? "ntt.dif_passes" : "ntt.dif_passes_ext", stream);
     uint32_t s = 0;
     const T *src = in;
     uint64_t src_stride = in_col_stride;
@@ -254,6 +255,7 @@ int ovm_hip_eval_to_coeff(const uint32_t *d_in, uint32_t *d_out, uint64_t width,
     if (width == 0) return 0;
     const Twiddles *tw = twiddles();
     if (!tw) return (int)hipErrorInvalidValue;
+    OVM_PROF("ntt.eval_to_coeff", stream);
     uint32_t tile_log = log_height < (uint32_t)NTT_TILE_LOG ? log_height : (uint32_t)NTT_TILE_LOG;
     dim3 grid(1u << (log_height - tile_log), (unsigned)width);
     Fp inv_chunk = Fp::from_canonical(1u << l_skip).inv();

@@ -164,6 +164,7 @@ struct Prover {
         if (width != d.layout.width) throw OvmFail(1, "stacked width mismatch");
         d.log_height = lh;
         d.stacked.alloc(width * H);
+        OVM_PROF("commit.stack", cx.stream);
         OVM_THROW_IF(hipMemsetAsync(d.stacked.p, 0, width * H * sizeof(Fp), cx.stream));
         for (size_t t = 0; t < traces.size(); t++) {
             size_t w = air(t).common_main_width, h = traces[t].height;
@@ -301,6 +302,7 @@ struct Prover {
         if (!ilayout.cols.empty()) {
             const size_t n_leaves = size_t(1) << TR;
             DevBuf<Frac> tree(2 * n_leaves);
+            ProfScope *ps_leaves = new ProfScope("gkr.leaves", cx.stream);
             OVM_THROW_IF(gkr_fill_leaves(tree.p + n_leaves, n_leaves, alpha, cx.stream));
             for (size_t t = 0; t < T; t++) {
                 const AirKey &a = air(t);
@@ -327,8 +329,13 @@ struct Prover {
                                              tree.p + n_leaves, cx.stream));
                 cx.sync();
             }
+            delete ps_leaves;
+            {
+            OVM_PROF("gkr.build_tree", cx.stream);
             for (unsigned j = TR; j-- > 0;)
                 OVM_THROW_IF(gkr_build_layer(tree.p + (size_t(2) << j), tree.p + (size_t(1) << j), size_t(1) << j, cx.stream));
+            }
+            OVM_PROF("gkr.layer_sumchecks", cx.stream);
             {
                 auto top = cx.download(tree.p + 1, 3);  // nodes 1, 2, 3
                 if (!is_zero(top[0].p)) throw OvmFail(1, "LogUp: non-zero root sum (interactions do not balance)");
@@ -480,9 +487,13 @@ struct Prover {
                 auto d_used = cx.upload(used);
                 auto d_sp = cx.upload(shift_pows);
                 DevBuf<Fp> lde((size_t)n_cosets * v.cm.total << v.log_lifted);
+                {
+                OVM_PROF("round0.coset_lde", cx.stream);
                 OVM_THROW_IF(coset_lde(v.cols.p, d_used.p, (uint32_t)used.size(), (uint32_t)v.cm.total, v.log_lifted, l_skip,
                                        n_cosets, d_sp.p, lde.p, cx.stream));
+                }
                 if (zc_cosets) {
+                    OVM_PROF("round0.zerocheck", cx.stream);
                     OVM_THROW_IF(round0_eval(tp[t].zc->dev(), lde.p, (uint32_t)v.cm.total, v.log_lifted, l_skip, zc_cosets, 1,
                                              d_eq.p, EF::zero(), partials.p, d_out.p, cx.stream));
                     auto ev = cx.download(d_out.p, (size_t)zc_cosets * N);
@@ -502,6 +513,7 @@ struct Prover {
                     sp0[2 * T + t] = std::move(coeffs);
                 }
                 if (lg_cosets) {
+                    OVM_PROF("round0.logup", cx.stream);
                     OVM_THROW_IF(round0_eval(tp[t].lg->dev(), lde.p, (uint32_t)v.cm.total, v.log_lifted, l_skip, lg_cosets, 2,
                                              d_eq.p, tp[t].lg_const, partials.p, d_out.p, cx.stream));
                     auto ev = cx.download(d_out.p, (size_t)lg_cosets * 2 * N);
@@ -596,6 +608,7 @@ struct Prover {
             std::vector<EF> wts(N);
             for (size_t z = 0; z < N; z++) wts[z] = rn * (r0 - omega_pows[z]).inv() * (omega_pows[z] * ninv);
             auto d_w = cx.upload(wts);
+            OVM_PROF("constraints.fold_ple", cx.stream);
             for (size_t t = 0; t < T; t++) {
                 TraceView &v = tv[t];
                 size_t h = size_t(1) << v.n_lift;
@@ -621,6 +634,7 @@ struct Prover {
         std::vector<std::array<EF, 2>> lg_tilde(T, {EF::zero(), EF::zero()});
         std::vector<std::vector<EF>> round_polys;
         DevBuf<EF> d_eqr(size_t(1) << std::max(n_max, 1u)), d_pt(std::max(n_max, 1u));
+        OVM_PROF("constraints.mle_rounds", cx.stream);
         for (unsigned round = 1; round <= n_max; round++) {
             EF r_prev = r[round - 1];
             std::vector<std::vector<EF>> sp(3 * T);
@@ -815,6 +829,7 @@ struct Prover {
         DevBuf<EF> partials((size_t)RED_BLOCKS * 3 * N + 64), d_out(3 * N + 64);
         const unsigned s0_deg = 2 * (unsigned)(N - 1);
         std::vector<EF> s0(s0_deg + 1, EF::zero());
+        ProfScope *ps_st0 = new ProfScope("stacked.round0", cx.stream);
         for (size_t wi = 0; wi < W; wi++) {
             Window &wd = ws[wi];
             size_t w0 = win[wi], w1 = win[wi + 1];
@@ -867,6 +882,7 @@ struct Prover {
             std::vector<EF> p0 = from_coset_evals(e0, l_skip), p1 = from_coset_evals(e1, l_skip);
             for (size_t i = 0; i <= s0_deg; i++) s0[i] += p0[i] + p1[i];
         }
+        delete ps_st0;
         for (auto &c : s0) ts.observe_ext(c);
         std::vector<EF> u;
         EF u0 = ts.sample_ext();
@@ -876,6 +892,7 @@ struct Prover {
         DevBuf<EF> q_a(width << n_stack), q_b(width << (n_stack ? n_stack - 1 : 0));
         bool q_in_a = true;
         unsigned q_log_h = n_stack;
+        ProfScope *ps_stf = new ProfScope("stacked.fold_ple", cx.stream);
         {
             EF un = u0.exp_power_of_2(l_skip) - Fp::one();
             Fp ninv = fp(N).inv();
@@ -930,6 +947,8 @@ struct Prover {
                 }
             }
         }
+        delete ps_stf;
+        ProfScope *ps_str = new ProfScope("stacked.mle_rounds", cx.stream);
         std::vector<std::array<EF, 2>> st_polys;
         DevBuf<uint64_t> d_gidx(2 * tvs.size() + 2);
         DevBuf<EF> d_gout(2 * tvs.size() + 2);
@@ -1006,6 +1025,7 @@ struct Prover {
                 if (round > n_lift) eq_ub[i] = eq_ub[i] * eq1b(ur, (tvs[i].s.row_idx >> (l_skip + round - 1)) & 1);
             }
         }
+        delete ps_str;
         std::vector<EF> stacking_openings = cx.download(q_in_a ? q_a.p : q_b.p, width);
         for (auto &c : stacking_openings) ts.observe_ext(c);
         q_a.release();
@@ -1041,6 +1061,7 @@ struct Prover {
         unsigned m = l_skip + n_stack;
         DevBuf<EF> f_a(size_t(1) << m), f_b(size_t(1) << (m - 1)), w_a(size_t(1) << m), w_b(size_t(1) << (m - 1));
         {
+            OVM_PROF("whir.mu_batch", cx.stream);
             std::vector<EF> mu_pows = powers_of(mu, width);
             auto d_mu = cx.upload(mu_pows);
             OVM_THROW_IF(whir_mu_batch(pcs.msg.p, (uint32_t)width, m, d_mu.p, 0, f_a.p, 0, cx.stream));
@@ -1063,6 +1084,7 @@ struct Prover {
         DevBuf<EF> d_red((size_t)RED_BLOCKS * 2 + 8), d_red_out(8);
         for (size_t wr = 0; wr < n_rounds; wr++) {
             const bool is_last = wr + 1 == n_rounds;
+            ProfScope *ps_ws = new ProfScope("whir.sumcheck_fold", cx.stream);
             for (unsigned rd = 0; rd < k_whir; rd++) {
                 const EF *f = fw_in_a ? f_a.p : f_b.p, *wv = fw_in_a ? w_a.p : w_b.p;
                 uint64_t half = 1ull << (m - rd - 1);
@@ -1076,6 +1098,8 @@ struct Prover {
                 OVM_THROW_IF(whir_fold(f, wv, fw_in_a ? f_b.p : f_a.p, fw_in_a ? w_b.p : w_a.p, half, al, cx.stream));
                 fw_in_a = !fw_in_a;
             }
+            delete ps_ws;
+            ProfScope *ps_wc = new ProfScope("whir.rs_commit", cx.stream);
             const unsigned m_new = m - k_whir;
             EF *f_cur = fw_in_a ? f_a.p : f_b.p, *w_cur = fw_in_a ? w_a.p : w_b.p;
             // g = f(alpha, .) in coefficient form
@@ -1103,6 +1127,7 @@ struct Prover {
                 final_poly = cx.download(g_coeffs.p, size_t(1) << m_new);
                 for (auto &c : final_poly) ts.observe_ext(c);
             }
+            delete ps_wc;
             const unsigned lq = log_rs - k_whir;
             Fp omega = bb::two_adic_generator(lq);
             size_t nq = P().whir_num_queries[wr];
@@ -1111,6 +1136,7 @@ struct Prover {
             for (auto &q : qidx) q = ts.sample_bits(lq);
             // opened rows + Merkle paths
             {
+                OVM_PROF("whir.queries", cx.stream);
                 const uint64_t qs = 1ull << lq;
                 std::vector<uint64_t> rows, didx;
                 for (uint64_t i : qidx) {
@@ -1158,6 +1184,7 @@ struct Prover {
             EF gamma = ts.sample_ext();
             if (!is_last) {
                 // w += gamma * eq(., pow(z0)) + sum_i gamma^(i+2) * eq(., pow(z_i))
+                OVM_PROF("whir.w_accumulate", cx.stream);
                 const size_t n_q = nq + 1;
                 std::vector<EF> zp(n_q * m_new), scale(n_q);
                 {

@@ -5,7 +5,72 @@
 #include "device_ctx.h"
 #include "openvm_hip.h"
 
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+namespace ovm {
+namespace {
+struct ProfRec {
+    const char *label;
+    hipEvent_t a, b;
+};
+bool g_prof_on = false;
+std::vector<ProfRec> g_prof;
+}  // namespace
+
+ProfScope::ProfScope(const char *label, hipStream_t s) : stream(s) {
+    if (!g_prof_on) return;
+    ProfRec r{label, nullptr, nullptr};
+    if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return;
+    (void)hipEventRecord(r.a, s);
+    slot = (int)g_prof.size();
+    g_prof.push_back(r);
+}
+ProfScope::~ProfScope() {
+    if (slot >= 0) (void)hipEventRecord(g_prof[slot].b, stream);
+}
+}  // namespace ovm
+
 extern "C" {
+
+int ovm_hip_profile_enable(int on) {
+    for (auto &r : ovm::g_prof) {
+        (void)hipEventDestroy(r.a);
+        (void)hipEventDestroy(r.b);
+    }
+    ovm::g_prof.clear();
+    ovm::g_prof_on = on != 0;
+    return 0;
+}
+
+// Writes "label calls total_ms\n" lines (aggregated per label) into buf; returns bytes needed.
+uint64_t ovm_hip_profile_report(char *buf, uint64_t cap) {
+    (void)hipDeviceSynchronize();
+    std::map<std::string, std::pair<uint64_t, double>> agg;
+    std::vector<std::string> order;
+    for (auto &r : ovm::g_prof) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, r.a, r.b) != hipSuccess) continue;
+        if (!agg.count(r.label)) order.push_back(r.label);
+        auto &e = agg[r.label];
+        e.first++;
+        e.second += ms;
+    }
+    std::string out;
+    for (auto &l : order) {
+        char line[256];
+        snprintf(line, sizeof line, "%s %llu %.6f\n", l.c_str(), (unsigned long long)agg[l].first, agg[l].second);
+        out += line;
+    }
+    if (buf && cap) {
+        size_t n = out.size() < cap - 1 ? out.size() : cap - 1;
+        memcpy(buf, out.data(), n);
+        buf[n] = 0;
+    }
+    return out.size() + 1;
+}
 
 uint32_t ovm_hip_abi_version(void) { return 1; }
 
