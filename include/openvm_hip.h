@@ -175,6 +175,9 @@ typedef struct ovm_pk_t ovm_pk_t;
  * Returns hipErrorNotSupported for preprocessed / cached traces (not built yet). */
 int ovm_hip_pk_load(const uint32_t *blob, uint64_t words, ovm_pk_t **pk_out);
 void ovm_hip_pk_free(ovm_pk_t *pk);
+/* Returns the calling thread's cached device blocks to the driver (the prover recycles its
+ * buffers between proofs; reference: VPMM pool, crates/cuda-common/src/memory_manager/). */
+int ovm_hip_trim(void);
 /* Message of the last failing call on this thread (empty if none). */
 const char *ovm_hip_last_error(void);
 

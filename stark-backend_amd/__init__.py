@@ -81,6 +81,7 @@ SIGNATURES = {
     "ovm_hip_pk_load": (c_int, [c_void_p, c_uint64, POINTER(c_void_p)]),
     "ovm_hip_pk_free": (None, [c_void_p]),
     "ovm_hip_last_error": (c_char_p, []),
+    "ovm_hip_trim": (c_int, []),
     "ovm_hip_prove": (c_int, [c_void_p, c_uint32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                               POINTER(SpongeState), c_void_p, c_uint64, _u64p, _u64p, c_void_p]),
 }

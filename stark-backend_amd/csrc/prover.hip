@@ -10,6 +10,9 @@
 // handful of extension-field elements) is this backend's design.
 #include <hip/hip_runtime.h>
 
+#include <chrono>
+#include <cstdlib>
+
 #include "kernels.h"
 
 namespace ovm {
@@ -17,6 +20,58 @@ namespace ovm {
 // ---------------------------------------------------------------------------------------------
 // Device memory helpers
 // ---------------------------------------------------------------------------------------------
+// Caching device allocator: freed blocks go to a per-device free list instead of back to the
+// driver and are handed out again (best fit) by later requests. A proof requests the same sizes
+// every time, so after the first proof no hipMalloc / hipFree happens at all (those cost hundreds
+// of milliseconds for multi-GB buffers and synchronise the device). All work of a prover runs on
+// one stream, so reuse is stream-ordered by construction. This is the role the reference gives its
+// VPMM pool (crates/cuda-common/src/memory_manager/); `ovm_hip_trim` returns the cache to the driver.
+struct BlockCache {
+    std::multimap<size_t, void *> free_blocks;  // size -> ptr
+    std::map<void *, size_t> live;
+    size_t cached_bytes = 0;
+    void *get(size_t bytes) {
+        bytes = (bytes + 255) & ~size_t(255);
+        auto it = free_blocks.lower_bound(bytes);
+        if (it != free_blocks.end() && it->first <= bytes + bytes / 8 + 4096) {
+            void *p = it->second;
+            size_t sz = it->first;
+            free_blocks.erase(it);
+            cached_bytes -= sz;
+            live[p] = sz;
+            return p;
+        }
+        void *p = nullptr;
+        hipError_t e = hipMalloc(&p, bytes);
+        if (e != hipSuccess) {
+            trim();
+            e = hipMalloc(&p, bytes);
+        }
+        if (e != hipSuccess) throw OvmFail((int)e, "hipMalloc");
+        live[p] = bytes;
+        return p;
+    }
+    void put(void *p) {
+        auto it = live.find(p);
+        if (it == live.end()) return;
+        free_blocks.emplace(it->second, p);
+        cached_bytes += it->second;
+        live.erase(it);
+    }
+    void trim() {
+        (void)hipDeviceSynchronize();
+        for (auto &b : free_blocks) (void)hipFree(b.second);
+        free_blocks.clear();
+        cached_bytes = 0;
+    }
+};
+inline BlockCache &block_cache() {
+    static thread_local BlockCache caches[16];
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    return caches[dev & 15];
+}
+
 template <class T>
 struct DevBuf {
     T *p = nullptr;
@@ -40,11 +95,10 @@ struct DevBuf {
     void alloc(size_t count) {
         release();
         n = count;
-        hipError_t e = hipMalloc((void **)&p, (count ? count : 1) * sizeof(T));
-        if (e != hipSuccess) throw OvmFail((int)e, "hipMalloc");
+        p = (T *)block_cache().get((count ? count : 1) * sizeof(T));
     }
     void release() {
-        if (p) (void)hipFree(p);
+        if (p) block_cache().put(p);
         p = nullptr;
         n = 0;
     }
@@ -133,7 +187,21 @@ static inline uint64_t layer_entry(uint64_t qs, unsigned lq, unsigned j, uint64_
     return off + bitrev64(y, lq - j);
 }
 
+struct WallTrace {
+    bool on;
+    std::chrono::steady_clock::time_point t0;
+    WallTrace() : on(getenv("OVM_TRACE") != nullptr), t0(std::chrono::steady_clock::now()) {}
+    void mark(const char *what) {
+        if (!on) return;
+        (void)hipDeviceSynchronize();
+        auto t1 = std::chrono::steady_clock::now();
+        fprintf(stderr, "[ovm] %-28s %9.3f ms\n", what, std::chrono::duration<double, std::milli>(t1 - t0).count());
+        t0 = t1;
+    }
+};
+
 struct Prover {
+    WallTrace wt;
     const ProvingKey &pk;
     Ctx cx;
     Transcript ts;
@@ -141,7 +209,9 @@ struct Prover {
     ByteWriter out;
     std::vector<size_t> section_offsets;
 
-    Prover(const ProvingKey &pk_, hipStream_t s) : pk(pk_), cx{s} { ts.stream = s; }
+    Prover(const ProvingKey &pk_, hipStream_t s) : pk(pk_), cx{s} {
+        ts.stream = s;
+    }
 
     const Params &P() const { return pk.params; }
     const AirKey &air(size_t t) const { return pk.airs[traces[t].air_idx]; }
@@ -332,9 +402,11 @@ struct Prover {
             delete ps_leaves;
             {
             OVM_PROF("gkr.build_tree", cx.stream);
+            wt.mark("rap.gkr.leaves");
             for (unsigned j = TR; j-- > 0;)
                 OVM_THROW_IF(gkr_build_layer(tree.p + (size_t(2) << j), tree.p + (size_t(1) << j), size_t(1) << j, cx.stream));
             }
+            wt.mark("rap.gkr.build");
             OVM_PROF("gkr.layer_sumchecks", cx.stream);
             {
                 auto top = cx.download(tree.p + 1, 3);  // nodes 1, 2, 3
@@ -391,6 +463,7 @@ struct Prover {
             }
             xi = xi_prev;
         }
+        wt.mark("rap.gkr");
         const unsigned n_global = std::max(n_max, n_logup);
         while (xi.size() != l_skip + n_global) xi.push_back(ts.sample_ext());
 
@@ -535,6 +608,7 @@ struct Prover {
             }
         }
 
+        wt.mark("rap.round0");
         // ---- s_0 assembly (host; a few dozen extension-field elements) ----
         const unsigned sp0_deg = cdeg_global * (unsigned)(N - 1), s_deg = cdeg_global + 1, s0_deg = s_deg * (unsigned)(N - 1);
         const size_t large = size_t(1) << log2_ceil(s0_deg + 1);
@@ -600,6 +674,7 @@ struct Prover {
         r.push_back(r0);
         EF prev_s = horner(s0, r0);
 
+        wt.mark("rap.s0_host");
         // ---- fold at r_0 ----
         {
             // barycentric weights: L_z(r) = omega^z (r^N - 1) / (N (r - omega^z))
@@ -629,6 +704,7 @@ struct Prover {
         }
         std::vector<EF> eq_sharp_ns{eq_sharp0};
 
+        wt.mark("rap.fold_ple");
         // ---- MLE rounds ----
         std::vector<EF> zc_tilde(T, EF::zero());
         std::vector<std::array<EF, 2>> lg_tilde(T, {EF::zero(), EF::zero()});
@@ -742,6 +818,7 @@ struct Prover {
             eq_sharp_ns.push_back(eq_sharp_ns[round - 1] * eqr);
         }
 
+        wt.mark("rap.mle_rounds");
         // ---- openings ----
         std::vector<std::vector<EF>> openings(T);
         for (size_t t = 0; t < T; t++) {
@@ -1044,6 +1121,7 @@ struct Prover {
         w.e_slice(stacking_openings);
         section_offsets.push_back(w.buf.size());
 
+        wt.mark("openings.stacked");
         // ---------------- WHIR ----------------
         std::vector<EF> u_cube;
         {
@@ -1270,7 +1348,9 @@ struct Prover {
             if (t.public_values.size() != pk.airs[t.air_idx].num_public_values) throw OvmFail(1, "public values length");
         }
         ts.observe_digest(pk.vk_pre_hash);
+        wt.mark("setup");
         PcsData pcs = commit();
+        wt.mark("commit");
         const size_t num_airs = pk.airs.size();
         std::vector<int> present(num_airs, -1);
         for (size_t t = 0; t < traces.size(); t++) present[traces[t].air_idx] = (int)t;
@@ -1308,7 +1388,9 @@ struct Prover {
         }
         section_offsets.push_back(out.buf.size());
         std::vector<EF> r = prove_rap_constraints();
+        wt.mark("rap_constraints.rest");
         prove_openings(pcs, r);
+        wt.mark("openings.whir");
     }
 };
 
@@ -1332,6 +1414,11 @@ int ovm_hip_pk_load(const uint32_t *blob, uint64_t words, ovm_pk_t **pk_out) {
 }
 
 void ovm_hip_pk_free(ovm_pk_t *pk) { delete reinterpret_cast<ProvingKey *>(pk); }
+
+int ovm_hip_trim(void) {
+    block_cache().trim();
+    return 0;
+}
 
 static thread_local std::string g_last_error;
 const char *ovm_hip_last_error(void) { return g_last_error.c_str(); }
