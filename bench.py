@@ -85,10 +85,7 @@ def main():
     elapsed = time.perf_counter() - t0
     prof = pkg.profile_report()
     pkg.profile_enable(False)
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = pkg.max_over_ranks(elapsed, f"cuda:{local_rank}")
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3

@@ -289,3 +289,16 @@ def profile_report() -> dict:
         label, calls, ms = line.rsplit(" ", 2)
         out[label] = (int(calls), float(ms))
     return out
+
+
+def max_over_ranks(value: float, device: str = "cpu") -> float:
+    """Whole-job time of a multi-process run: MAX over ranks (all-reduce on the initialised
+    torch.distributed group -- RCCL on GPUs, gloo on CPU); identity when not distributed."""
+    import torch
+    import torch.distributed as dist
+
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return float(value)
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())

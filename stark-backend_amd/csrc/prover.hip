@@ -234,7 +234,7 @@ struct Prover {
         if (width != d.layout.width) throw OvmFail(1, "stacked width mismatch");
         d.log_height = lh;
         d.stacked.alloc(width * H);
-        OVM_PROF("commit.stack", cx.stream);
+        ProfScope *ps_stack = new ProfScope("commit.stack", cx.stream);
         OVM_THROW_IF(hipMemsetAsync(d.stacked.p, 0, width * H * sizeof(Fp), cx.stream));
         for (size_t t = 0; t < traces.size(); t++) {
             size_t w = air(t).common_main_width, h = traces[t].height;
@@ -255,6 +255,7 @@ struct Prover {
                 }
             }
         }
+        delete ps_stack;
         d.msg.alloc(width * H);
         OVM_THROW_IF(ovm_hip_eval_to_coeff((const uint32_t *)d.stacked.p, (uint32_t *)d.msg.p, width, lh, l_skip, cx.stream));
         d.log_rows = lh + P().log_blowup;
