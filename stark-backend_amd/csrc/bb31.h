@@ -5,9 +5,11 @@
 // `BabyBear` is a `repr(transparent)` Montgomery u32, an extension element is `[u32; 4]`
 // (reference: crates/cuda-common/include/fp.h:52-60,184-194 and fpext.h:28-44).
 //
-// CDNA4 notes: 32x32 multiplies are the expensive VALU ops, so `mont_mul` does two full multiplies
-// (lo/hi of a*b) and replaces the multiply by the Montgomery constant M = 2^31 + 2^27 + 1 with
-// shift-adds (v_lshl_add_u32); the multiply by P needs only its high word.
+// CDNA4 notes (measured with tools/ubench_int.hip on MI355X): v_mul_lo_u32 and v_mul_hi_u32 issue
+// at the same rate as v_lshl_add_u32 / v_min_u32 (~4.5 cycles per wave-instruction per SIMD);
+// v_mad_u64_u32 costs two of them. So a Montgomery multiply is priced by its INSTRUCTION COUNT:
+// 4 multiplies (a*b lo/hi, lo*M, hi(t*P)) + subtract + a 2-instruction branch-free correction
+// `min(r, r + P)`. No 64-bit compares, no vcc, no shift-add tricks (they are not cheaper here).
 #pragma once
 #include <stdint.h>
 
@@ -37,20 +39,45 @@ constexpr uint32_t cx_powmod(uint32_t a, uint64_t e) {
     return r;
 }
 
-BB_HD uint32_t mont_reduce(uint64_t x) {
-    // t = (x mod 2^32) * M mod 2^32 ;  u = t * P ;  result = (x - u) / 2^32 (+P if negative)
-    uint32_t lo = (uint32_t)x;
-    uint32_t t = lo + (lo << 27) + (lo << 31);  // lo * (2^31 + 2^27 + 1)
-    uint32_t uh = (uint32_t)(((uint64_t)t * P) >> 32);
-    uint32_t xh = (uint32_t)(x >> 32);
-    uint32_t r = xh - uh;
-    return xh < uh ? r + P : r;
+BB_HD uint32_t umin32(uint32_t a, uint32_t b) { return a < b ? a : b; }
+
+BB_HD uint32_t mulhi32(uint32_t a, uint32_t b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __umulhi(a, b);
+#else
+    return (uint32_t)(((uint64_t)a * b) >> 32);
+#endif
 }
 
-// Same, for x < 4*P^2 (a sum of up to four raw products): one extra conditional subtract.
+// x < 2^32 * P  ->  x * 2^-32 mod P, in [0, P).
+//   t = lo(x) * M mod 2^32 ; u = t * P has the same low word as x, so (x - u) / 2^32 = hi(x) - hi(u),
+//   which lies in (-P, P); `min(r, r + P)` (unsigned, wrapping) adds P exactly when it is negative.
+BB_HD uint32_t mont_reduce(uint64_t x) {
+    uint32_t lo = (uint32_t)x, xh = (uint32_t)(x >> 32);
+    uint32_t t = lo * MONTY_M;
+    uint32_t uh = mulhi32(t, P);
+    uint32_t r = xh - uh;
+    return umin32(r, r + P);
+}
+
+// Same, for x < 4*P^2 (a sum of up to four raw products): hi(x) may reach ~1.9 P, so the
+// difference lies in (-P, 1.9 P) and needs one correction in each direction.
 BB_HD uint32_t mont_reduce_wide(uint64_t x) {
-    uint32_t r = mont_reduce(x);
-    return r >= P ? r - P : r;
+    uint32_t lo = (uint32_t)x, xh = (uint32_t)(x >> 32);
+    uint32_t t = lo * MONTY_M;
+    uint32_t uh = mulhi32(t, P);
+    uint32_t r = xh - uh;
+    if (xh < uh) r += P;
+    return umin32(r, r - P);
+}
+
+// a * b * 2^-32 mod P for a, b < P, from two 32-bit multiplies instead of one 64-bit one.
+BB_HD uint32_t mont_mul(uint32_t a, uint32_t b) {
+    uint32_t lo = a * b, xh = mulhi32(a, b);
+    uint32_t t = lo * MONTY_M;
+    uint32_t uh = mulhi32(t, P);
+    uint32_t r = xh - uh;
+    return umin32(r, r + P);
 }
 
 struct Fp {
@@ -67,15 +94,15 @@ struct Fp {
     BB_HD uint32_t canonical() const { return mont_reduce((uint64_t)v); }
 
     BB_HD Fp operator+(Fp o) const {
-        uint32_t s = v + o.v;
-        return raw(s >= P ? s - P : s);
+        uint32_t s = v + o.v;  // < 2P < 2^32
+        return raw(umin32(s, s - P));
     }
     BB_HD Fp operator-(Fp o) const {
-        uint32_t d = v - o.v;
-        return raw(v < o.v ? d + P : d);
+        uint32_t d = v - o.v;  // wraps iff negative
+        return raw(umin32(d, d + P));
     }
     BB_HD Fp operator-() const { return raw(v ? P - v : 0); }
-    BB_HD Fp operator*(Fp o) const { return raw(mont_reduce((uint64_t)v * o.v)); }
+    BB_HD Fp operator*(Fp o) const { return raw(mont_mul(v, o.v)); }
     BB_HD Fp &operator+=(Fp o) { return *this = *this + o; }
     BB_HD Fp &operator-=(Fp o) { return *this = *this - o; }
     BB_HD Fp &operator*=(Fp o) { return *this = *this * o; }

@@ -66,6 +66,9 @@ int gkr_eval_leaves(const DevProgram &prog, const EF *d_leaf_const, const ColDes
 int gkr_build_layer(const Frac *child, Frac *parent, uint64_t n_parent, hipStream_t s);
 // records: 4 EF per x (p0,q0,p1,q1); eq: 1 EF per x. n_pairs = number of y.
 int gkr_round(const EF *rec, const EF *eq, uint64_t n_pairs, EF lambda, EF *d_partials, EF *d_out, hipStream_t s);
+// fold the previous round with r and return the NEXT round's sums over the n_pairs folded pairs
+int gkr_fold_round(const EF *rec_in, const EF *eq_in, EF *rec_out, EF *eq_out, uint64_t n_pairs, EF r, EF lambda,
+                   EF *d_partials, EF *d_out, hipStream_t s);
 int gkr_fold(const EF *rec_in, const EF *eq_in, EF *rec_out, EF *eq_out, uint64_t n_out, EF r, hipStream_t s);
 
 // ---- stacked reduction ----

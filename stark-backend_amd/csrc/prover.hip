@@ -437,20 +437,33 @@ struct Prover {
                     bool to_b = true;
                     std::vector<std::array<EF, 3>> polys;
                     std::vector<EF> rho;
+                    EF r_prev = EF::zero();
                     for (unsigned sr = 0; sr < round; sr++) {
                         uint64_t n_pairs = 1ull << (round - sr - 1);
-                        OVM_THROW_IF(gkr_round(rec, eq, n_pairs, lambda, partials.p, d_out.p, cx.stream));
+                        if (sr == 0) {
+                            OVM_THROW_IF(gkr_round(rec, eq, n_pairs, lambda, partials.p, d_out.p, cx.stream));
+                        } else {
+                            // fold sub-round sr-1 with r_prev and get this sub-round's sums in one pass
+                            EF *rec_o = (sr % 2 == 1) ? rec_a.p : rec_b.p;
+                            EF *eq_o = to_b ? eq_b.p : eq_a.p;
+                            OVM_THROW_IF(gkr_fold_round(rec, eq, rec_o, eq_o, n_pairs, r_prev, lambda, partials.p, d_out.p,
+                                                        cx.stream));
+                            rec = rec_o;
+                            eq = eq_o;
+                            to_b = !to_b;
+                        }
                         auto sv = cx.download(d_out.p, 3);
                         for (auto &e : sv) ts.observe_ext(e);
                         polys.push_back({sv[0], sv[1], sv[2]});
-                        EF r = ts.sample_ext();
-                        rho.push_back(r);
-                        EF *rec_o = (sr % 2 == 0) ? rec_a.p : rec_b.p;
+                        r_prev = ts.sample_ext();
+                        rho.push_back(r_prev);
+                    }
+                    {
+                        // last fold: one record (the layer claims)
+                        EF *rec_o = (round % 2 == 1) ? rec_a.p : rec_b.p;
                         EF *eq_o = to_b ? eq_b.p : eq_a.p;
-                        OVM_THROW_IF(gkr_fold(rec, eq, rec_o, eq_o, n_pairs, r, cx.stream));
+                        OVM_THROW_IF(gkr_fold(rec, eq, rec_o, eq_o, 1, r_prev, cx.stream));
                         rec = rec_o;
-                        eq = eq_o;
-                        to_b = !to_b;
                     }
                     auto fin = cx.download(rec, 4);
                     claims.push_back({fin[0], fin[2], fin[1], fin[3]});

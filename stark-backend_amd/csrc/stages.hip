@@ -111,15 +111,36 @@ __global__ void eq_table_kernel(const EF *point, uint32_t n, EF *out) {
     }
     st_ef(out + y, acc);
 }
-int eq_table(const EF *d_point, uint32_t n, EF *out, hipStream_t s) {
-    hipLaunchKernelGGL(eq_table_kernel<false>, dim3(ceil_div(1ull << n, 256)), dim3(256), 0, s, d_point, n, out);
+// One doubling step: entries [0, 2^k) hold the table over variables 0..k-1.
+//   eq:     out[y + 2^k] = out[y] * x_k ;  out[y] = out[y] - out[y + 2^k]          (= out[y] * (1 - x_k))
+//   mobius: out[y + 2^k] = out[y] * x_k ;  out[y] = out[y] - 2 * out[y + 2^k]      (= out[y] * (1 - 2 x_k))
+// One extension multiply per pair, so a 2^n table costs 2^n multiplies in total instead of n * 2^n.
+template <bool MOBIUS>
+__global__ void eq_double_kernel(const EF *point, uint32_t k, EF *out) {
+    uint64_t y = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (y >= (1ull << k)) return;
+    EF lo = ld_ef(out + y);
+    EF hi = lo * ld_ef(point + k);
+    st_ef(out + y + (1ull << k), hi);
+    st_ef(out + y, MOBIUS ? lo - hi.dbl() : lo - hi);
+}
+
+static constexpr uint32_t EQ_DIRECT_BITS = 10;
+
+template <bool MOBIUS>
+static int eq_table_impl(const EF *d_point, uint32_t n, EF *out, hipStream_t s) {
+    uint32_t n0 = n < EQ_DIRECT_BITS ? n : EQ_DIRECT_BITS;
+    hipLaunchKernelGGL(eq_table_kernel<MOBIUS>, dim3(ceil_div(1ull << n0, 256)), dim3(256), 0, s, d_point, n0, out);
     OVM_CHECK_LAUNCH();
+    for (uint32_t k = n0; k < n; k++) {
+        hipLaunchKernelGGL(eq_double_kernel<MOBIUS>, dim3(ceil_div(1ull << k, 256)), dim3(256), 0, s, d_point, k, out);
+        OVM_CHECK_LAUNCH();
+    }
     return 0;
 }
+int eq_table(const EF *d_point, uint32_t n, EF *out, hipStream_t s) { return eq_table_impl<false>(d_point, n, out, s); }
 int mobius_eq_table(const EF *d_point, uint32_t n, EF *out, hipStream_t s) {
-    hipLaunchKernelGGL(eq_table_kernel<true>, dim3(ceil_div(1ull << n, 256)), dim3(256), 0, s, d_point, n, out);
-    OVM_CHECK_LAUNCH();
-    return 0;
+    return eq_table_impl<true>(d_point, n, out, s);
 }
 
 // ---- coset LDE of 2^l_skip-row chunks --------------------------------------------------------
@@ -459,6 +480,53 @@ __global__ __launch_bounds__(RED_THREADS) void gkr_round_kernel(const EF *rec, c
 int gkr_round(const EF *rec, const EF *eq, uint64_t n_pairs, EF lambda, EF *d_partials, EF *d_out, hipStream_t s) {
     uint32_t grid = red_grid(n_pairs);
     hipLaunchKernelGGL(gkr_round_kernel, dim3(grid), dim3(RED_THREADS), 0, s, rec, eq, n_pairs, lambda, d_partials);
+    OVM_CHECK_LAUNCH();
+    return sum_partials(d_partials, grid, 3, d_out, s);
+}
+
+// Fused "fold with r, then next round's sums": output pair y is built from input records
+// 4y..4y+3 (and eq entries 4y..4y+3); the two folded records are stored and immediately used for
+// the degree-3 round sums, so every sub-round after the first is ONE pass over the data.
+__global__ __launch_bounds__(RED_THREADS) void gkr_fold_round_kernel(const EF *rec_in, const EF *eq_in,
+                                                                     EF *rec_out, EF *eq_out, uint64_t n_pairs,
+                                                                     EF r, EF lambda, EF *partials) {
+    const uint64_t stride = (uint64_t)gridDim.x * RED_THREADS;
+    EF sums[3] = {EF::zero(), EF::zero(), EF::zero()};
+    for (uint64_t y = (uint64_t)blockIdx.x * RED_THREADS + threadIdx.x; y < n_pairs; y += stride) {
+        EF a[4], d[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            EF u0 = ld_ef(rec_in + 16 * y + i), u1 = ld_ef(rec_in + 16 * y + 4 + i);
+            EF v0 = ld_ef(rec_in + 16 * y + 8 + i), v1 = ld_ef(rec_in + 16 * y + 12 + i);
+            EF f0 = u0 + (u1 - u0) * r, f1 = v0 + (v1 - v0) * r;
+            st_ef(rec_out + 8 * y + i, f0);
+            st_ef(rec_out + 8 * y + 4 + i, f1);
+            a[i] = f0;
+            d[i] = f1 - f0;
+        }
+        EF e00 = ld_ef(eq_in + 4 * y), e01 = ld_ef(eq_in + 4 * y + 1), e10 = ld_ef(eq_in + 4 * y + 2),
+           e11 = ld_ef(eq_in + 4 * y + 3);
+        EF e0 = e00 + (e01 - e00) * r, e1 = e10 + (e11 - e10) * r;
+        st_ef(eq_out + 2 * y, e0);
+        st_ef(eq_out + 2 * y + 1, e1);
+        EF e = e0, ed = e1 - e0;
+#pragma unroll
+        for (int xi = 0; xi < 3; xi++) {
+            e = e + ed;
+#pragma unroll
+            for (int i = 0; i < 4; i++) a[i] = a[i] + d[i];
+            EF pq = a[0] * a[3] + a[2] * a[1];
+            EF qq = a[1] * a[3];
+            sums[xi] = sums[xi] + e * (pq + lambda * qq);
+        }
+    }
+    block_sum_store<3>(sums, partials + (size_t)blockIdx.x * 3);
+}
+int gkr_fold_round(const EF *rec_in, const EF *eq_in, EF *rec_out, EF *eq_out, uint64_t n_pairs, EF r, EF lambda,
+                   EF *d_partials, EF *d_out, hipStream_t s) {
+    uint32_t grid = red_grid(n_pairs);
+    hipLaunchKernelGGL(gkr_fold_round_kernel, dim3(grid), dim3(RED_THREADS), 0, s, rec_in, eq_in, rec_out, eq_out,
+                       n_pairs, r, lambda, d_partials);
     OVM_CHECK_LAUNCH();
     return sum_partials(d_partials, grid, 3, d_out, s);
 }
