@@ -104,6 +104,28 @@ struct DevBuf {
     }
 };
 
+// Per-thread pinned staging buffer: the sumcheck loops read a handful of extension-field elements
+// back per round, and a D2H copy into pageable memory takes a slow bounce-buffer path.
+struct PinnedStage {
+    void *p = nullptr;
+    size_t bytes = 0;
+    void *get(size_t need) {
+        if (need > bytes) {
+            if (p) (void)hipHostFree(p);
+            bytes = need < (1u << 20) ? (1u << 20) : need;
+            if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) {
+                p = nullptr;
+                bytes = 0;
+            }
+        }
+        return p;
+    }
+};
+inline PinnedStage &pinned_stage() {
+    static thread_local PinnedStage st;
+    return st;
+}
+
 struct Ctx {
     hipStream_t stream;
     void sync() const { OVM_THROW_IF(hipStreamSynchronize(stream)); }
@@ -111,8 +133,15 @@ struct Ctx {
     DevBuf<T> upload(const std::vector<T> &v) const {
         DevBuf<T> b(v.size());
         if (!v.empty()) {
-            OVM_THROW_IF(hipMemcpyAsync(b.p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, stream));
-            sync();  // the host vector may go away
+            const size_t bytes = v.size() * sizeof(T);
+            void *stage = bytes <= (1u << 20) ? pinned_stage().get(bytes) : nullptr;
+            if (stage) {
+                memcpy(stage, v.data(), bytes);
+                OVM_THROW_IF(hipMemcpyAsync(b.p, stage, bytes, hipMemcpyHostToDevice, stream));
+            } else {
+                OVM_THROW_IF(hipMemcpyAsync(b.p, v.data(), bytes, hipMemcpyHostToDevice, stream));
+            }
+            sync();  // the host vector / staging buffer may be reused
         }
         return b;
     }
@@ -120,8 +149,16 @@ struct Ctx {
     std::vector<T> download(const T *d, size_t n) const {
         std::vector<T> v(n);
         if (n) {
-            OVM_THROW_IF(hipMemcpyAsync(v.data(), d, n * sizeof(T), hipMemcpyDeviceToHost, stream));
-            sync();
+            const size_t bytes = n * sizeof(T);
+            void *stage = bytes <= (1u << 20) ? pinned_stage().get(bytes) : nullptr;
+            if (stage) {
+                OVM_THROW_IF(hipMemcpyAsync(stage, d, bytes, hipMemcpyDeviceToHost, stream));
+                sync();
+                memcpy(v.data(), stage, bytes);
+            } else {
+                OVM_THROW_IF(hipMemcpyAsync(v.data(), d, bytes, hipMemcpyDeviceToHost, stream));
+                sync();
+            }
         }
         return v;
     }
