@@ -189,6 +189,161 @@ __global__ __launch_bounds__(NTT_THREADS) void dif_pass_kernel(const T *in, T *o
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Radix-16 register passes (transforms of 2^9 points and more).
+// A lane owns 16 elements that differ in a 4-bit window of the tile index and runs 4 DIF stages
+// on them in registers; LDS is touched once per 4 stages (exchange), not once per stage.
+// Twiddles of the window whose lowest bit is global position bit b (S = 2^b):
+//   stage k (k = 0..3) uses  w^(2^k) * omega_(16 >> k)^j ,  w = omega_(16 S)^(p mod S),
+// i.e. ONE table lookup per lane per window; the small roots are compile-time constants. In the
+// last window of the contiguous pass S = 1, so it needs no data-dependent twiddle at all.
+// ---------------------------------------------------------------------------------------------
+#define W16C(j) bb::cx_to_mont(bb::cx_powmod(bb::TWO_ADIC_GENERATORS[4], j))
+static constexpr uint32_t W16[8] = {W16C(0), W16C(1), W16C(2), W16C(3), W16C(4), W16C(5), W16C(6), W16C(7)};
+#undef W16C
+
+// NB stages on the low NB bits of the register index (upper bits = independent groups).
+template <class T, int NB, bool HAS_W>
+__device__ __forceinline__ void radix_dif(T (&x)[16], Fp w0) {
+    Fp wk = w0;
+#pragma unroll
+    for (int k = 0; k < NB; k++) {
+        const int bit = NB - 1 - k, half = 1 << bit;
+#pragma unroll
+        for (int j = 0; j < half; j++) {
+            const Fp cj = Fp::raw(W16[j << (3 - bit)]);
+            const Fp tw = HAS_W ? (j == 0 ? wk : wk * cj) : cj;
+#pragma unroll
+            for (int g = 0; g < 16; g += 2 * half) {
+                const int v = g + j;
+                T a = x[v], b = x[v + half];
+                x[v] = a + b;
+                T d = a - b;
+                x[v + half] = (!HAS_W && j == 0) ? d : d * tw;
+            }
+        }
+        if (HAS_W) wk = wk.square();
+    }
+}
+
+// One pass over tiles of 2^TL elements. Strided form (c > 0): r = 8 stages s0..s0+7, tile =
+// 2^8 x 2^c. Contiguous form (c == 0): the last `r` stages of the transform on 2^TL consecutive
+// positions, as windows of 4 from the top and a final window [3..0] doing the r mod 4 (or 4)
+// lowest stages.
+template <class T, int TL>
+__global__ __launch_bounds__(1 << (TL - 4)) void dif16_pass_kernel(const T *in, T *out, uint32_t L,
+                                                                   uint32_t log_n_in, uint32_t s0, uint32_t r,
+                                                                   uint32_t c, uint64_t in_col_stride,
+                                                                   uint64_t out_col_stride, Twiddles tw) {
+    __shared__ T tile[1 << TL];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t beta = L - s0 - r;  // global bit of the lowest stage of this pass
+    uint64_t pos_base;
+    if (c > 0) {
+        const uint64_t mid = blockIdx.x & ((1ull << (beta - c)) - 1), hi = blockIdx.x >> (beta - c);
+        pos_base = (hi << (beta + r)) | (mid << c);
+    } else {
+        pos_base = (uint64_t)blockIdx.x << TL;
+    }
+    const uint32_t c_mask = (1u << c) - 1;
+    auto pos_of = [&](uint32_t l) -> uint64_t {
+        return c > 0 ? (pos_base | ((uint64_t)(l >> c) << beta) | (l & c_mask)) : (pos_base | l);
+    };
+    auto gbit_of = [&](uint32_t lbit) -> uint32_t { return (c > 0 && lbit >= c) ? beta + (lbit - c) : lbit; };
+    const T *in_col = in + (uint64_t)blockIdx.y * in_col_stride;
+    T *out_col = out + (uint64_t)blockIdx.y * out_col_stride;
+    const uint64_t n_in = 1ull << log_n_in;
+
+    // window list: full windows from the top of the pass's stage bits, then the final one
+    const uint32_t top = c > 0 ? c + r : r;          // one past the highest active tile bit
+    const uint32_t n_full = c > 0 ? r / 4 : (r - 1) / 4;  // contiguous: keep 1..4 stages for the last window
+    const uint32_t last_nb = c > 0 ? 0 : r - 4 * n_full;  // 1..4 (contiguous only)
+    T x[16];
+    uint32_t bl = top - 4;
+    auto l_of = [&](uint32_t v) -> uint32_t {
+        return ((tid >> bl) << (bl + 4)) | (v << bl) | (tid & ((1u << bl) - 1));
+    };
+    const uint32_t n_windows = n_full + (last_nb ? 1 : 0);
+    for (uint32_t wdx = 0; wdx < n_windows; wdx++) {
+        const bool is_last_partial = (last_nb != 0) && (wdx == n_full);
+        bl = is_last_partial ? 0 : top - 4 * (wdx + 1);
+        if (wdx == 0) {
+#pragma unroll
+            for (int v = 0; v < 16; v++) {
+                uint64_t p = pos_of(l_of(v));
+                x[v] = p < n_in ? in_col[p] : T::zero();
+            }
+        } else {
+#pragma unroll
+            for (int v = 0; v < 16; v++) x[v] = tile[l_of(v)];
+            __syncthreads();
+        }
+        if (is_last_partial) {
+            switch (last_nb) {
+                case 1: radix_dif<T, 1, false>(x, Fp::one()); break;
+                case 2: radix_dif<T, 2, false>(x, Fp::one()); break;
+                case 3: radix_dif<T, 3, false>(x, Fp::one()); break;
+                default: radix_dif<T, 4, false>(x, Fp::one()); break;
+            }
+        } else {
+            const uint32_t gb = gbit_of(bl);  // S = 2^gb
+            const uint64_t p0 = pos_of(l_of(0));
+            const uint32_t q = (uint32_t)(p0 & ((1ull << gb) - 1));
+            Fp w0 = tw_pow27(tw, q << (TW_LOG_MAX - gb - 4));
+            radix_dif<T, 4, true>(x, w0);
+        }
+        if (wdx + 1 < n_windows) {
+#pragma unroll
+            for (int v = 0; v < 16; v++) tile[l_of(v)] = x[v];
+            __syncthreads();
+        }
+    }
+#pragma unroll
+    for (int v = 0; v < 16; v++) out_col[pos_of(l_of(v))] = x[v];
+}
+
+template <class T, int TL>
+static int launch_dif16(const T *src, T *out, uint64_t width, uint32_t L, uint32_t log_n_in, uint32_t s0, uint32_t r,
+                        uint32_t c, uint64_t src_stride, uint64_t out_stride, const Twiddles &tw, hipStream_t stream) {
+    dim3 grid(1u << (L - TL), (unsigned)width);
+    hipLaunchKernelGGL((dif16_pass_kernel<T, TL>), grid, dim3(1 << (TL - 4)), 0, stream, src, out, L, log_n_in, s0, r,
+                       c, src_stride, out_stride, tw);
+    OVM_CHECK_LAUNCH();
+    return 0;
+}
+
+template <class T>
+static int dif_ntt16(const T *in, T *out, uint64_t width, uint32_t L, uint32_t log_n_in, uint64_t in_col_stride,
+                     uint64_t out_col_stride, const Twiddles &tw, hipStream_t stream) {
+    constexpr bool BASE = sizeof(T) == 4;
+    const uint32_t TL = BASE ? (L >= 13 ? 13 : (L >= 11 ? 11 : 9)) : (L >= 11 ? 11 : 9);
+    const uint32_t ns = L > TL ? (L - TL + 7) / 8 : 0;  // strided passes of 8 stages
+    const uint32_t rc = L - 8 * ns;                      // stages of the contiguous pass (1..TL)
+    const uint32_t c = TL - 8;
+    OVM_PROF(BASE ? "ntt.dif_passes" : "ntt.dif_passes_ext", stream);
+    const T *src = in;
+    uint64_t src_stride = in_col_stride;
+    uint32_t src_log_n = log_n_in, s = 0;
+    auto launch = [&](uint32_t r, uint32_t cc) -> int {
+        if (BASE) {
+            if (TL == 13) return launch_dif16<T, 13>(src, out, width, L, src_log_n, s, r, cc, src_stride, out_col_stride, tw, stream);
+            if (TL == 11) return launch_dif16<T, 11>(src, out, width, L, src_log_n, s, r, cc, src_stride, out_col_stride, tw, stream);
+            return launch_dif16<T, 9>(src, out, width, L, src_log_n, s, r, cc, src_stride, out_col_stride, tw, stream);
+        }
+        if (TL == 11) return launch_dif16<T, 11>(src, out, width, L, src_log_n, s, r, cc, src_stride, out_col_stride, tw, stream);
+        return launch_dif16<T, 9>(src, out, width, L, src_log_n, s, r, cc, src_stride, out_col_stride, tw, stream);
+    };
+    for (uint32_t i = 0; i < ns; i++) {
+        int rc_ = launch(8, c);
+        if (rc_) return rc_;
+        s += 8;
+        src = out;
+        src_stride = out_col_stride;
+        src_log_n = L;
+    }
+    return launch(rc, 0);
+}
+
 // Plans and launches the passes of a 2^L-point DIF on `width` columns.
 template <class T>
 static int dif_ntt(const T *in, T *out, uint64_t width, uint32_t L, uint32_t log_n_in,
@@ -204,6 +359,7 @@ static int dif_ntt(const T *in, T *out, uint64_t width, uint32_t L, uint32_t log
                                      hipMemcpyDeviceToDevice, stream));
         return 0;
     }
+    if (L >= 9) return dif_ntt16<T>(in, out, width, L, log_n_in, in_col_stride, out_col_stride, *tw, stream);
     // Elements per tile: 32 KiB of LDS for both Fp and FpExt tiles.
     const uint32_t tile_log = sizeof(T) == 4 ? NTT_TILE_LOG : NTT_TILE_LOG - 2;
     const uint32_t C_LOG = 6;  // strided passes move runs of 64 rows (256 B for Fp)
