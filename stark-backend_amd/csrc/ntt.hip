@@ -235,7 +235,10 @@ __global__ __launch_bounds__(1 << (TL - 4)) void dif16_pass_kernel(const T *in, 
                                                                    uint32_t log_n_in, uint32_t s0, uint32_t r,
                                                                    uint32_t c, uint64_t in_col_stride,
                                                                    uint64_t out_col_stride, Twiddles tw) {
-    __shared__ T tile[1 << TL];
+    // Padded by one element per 16 so that a lane reading its 16 consecutive elements (last window)
+    // and lanes reading consecutive elements (all other windows) are both bank-conflict free.
+    __shared__ T tile[(1 << TL) + (1 << (TL - 4))];
+    auto pad = [](uint32_t l) -> uint32_t { return l + (l >> 4); };
     const uint32_t tid = threadIdx.x;
     const uint32_t beta = L - s0 - r;  // global bit of the lowest stage of this pass
     uint64_t pos_base;
@@ -275,7 +278,7 @@ __global__ __launch_bounds__(1 << (TL - 4)) void dif16_pass_kernel(const T *in, 
             }
         } else {
 #pragma unroll
-            for (int v = 0; v < 16; v++) x[v] = tile[l_of(v)];
+            for (int v = 0; v < 16; v++) x[v] = tile[pad(l_of(v))];
             __syncthreads();
         }
         if (is_last_partial) {
@@ -294,9 +297,22 @@ __global__ __launch_bounds__(1 << (TL - 4)) void dif16_pass_kernel(const T *in, 
         }
         if (wdx + 1 < n_windows) {
 #pragma unroll
-            for (int v = 0; v < 16; v++) tile[l_of(v)] = x[v];
+            for (int v = 0; v < 16; v++) tile[pad(l_of(v))] = x[v];
             __syncthreads();
         }
+    }
+    if (c == 0 && bl == 0) {
+        // the last window left every lane with 16 CONSECUTIVE positions: transpose through LDS so
+        // that consecutive lanes store consecutive positions (256 B per wave-store)
+#pragma unroll
+        for (int v = 0; v < 16; v++) tile[pad(l_of(v))] = x[v];
+        __syncthreads();
+#pragma unroll
+        for (int v = 0; v < 16; v++) {
+            uint32_t l = (uint32_t)v * (1u << (TL - 4)) + tid;
+            out_col[pos_base | l] = tile[pad(l)];
+        }
+        return;
     }
 #pragma unroll
     for (int v = 0; v < 16; v++) out_col[pos_of(l_of(v))] = x[v];
