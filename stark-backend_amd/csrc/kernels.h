@@ -55,6 +55,11 @@ int fold_ple(const ColDesc *d_cols, uint32_t n_cols, uint32_t log_lifted, uint32
 int mle_round_eval(const DevProgram &prog, const EF *mats, uint32_t n_cols, uint32_t log_h, uint32_t degree,
                    uint32_t n_out, const EF *d_eq, EF add_const, EF *d_partials, EF *d_out, hipStream_t s);
 
+// Same sums from a grouped program: grid = (y blocks, X = 1..degree, group); out[2*(X-1)+o].
+int mle_round_eval_grouped(const Instr *d_code, const uint32_t *d_off, uint32_t n_groups, uint32_t max_slots,
+                           const EF *d_weights, const EF *mats, uint32_t log_h, uint32_t degree, uint32_t n_out,
+                           const EF *d_eq, EF add_const, EF *d_partials, EF *d_out, hipStream_t s);
+
 // out[c * h/2 + y] = in[c*h + 2y] + r * (in[c*h + 2y + 1] - in[c*h + 2y])
 int fold_mle(const EF *in, EF *out, uint32_t n_cols, uint32_t log_h, EF r, hipStream_t s);
 

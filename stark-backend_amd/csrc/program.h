@@ -179,6 +179,33 @@ inline Program compile_program(const AirKey &air, const ColumnMap &cm, const std
     return prog;
 }
 
+// The same roots split into `n_groups` independent sub-programs (consecutive runs of roots). All
+// root ops here are additive (ACC), so the groups' outputs simply add; shared DAG nodes are
+// recomputed per group. Used by the multilinear rounds, where the number of evaluation points
+// shrinks every round and one lane interpreting the whole DAG serially is latency-bound: groups
+// (and the X points) become extra grid dimensions instead.
+struct GroupedProgram {
+    std::vector<Instr> code;
+    std::vector<uint32_t> off;  // n_groups + 1 offsets into code
+    uint32_t max_slots = 1;
+};
+inline GroupedProgram compile_grouped(const AirKey &air, const ColumnMap &cm, const std::vector<Fp> &public_values,
+                                      const std::vector<Root> &roots, uint32_t num_weights, uint32_t n_groups) {
+    GroupedProgram g;
+    if (n_groups < 1) n_groups = 1;
+    if (n_groups > roots.size()) n_groups = roots.empty() ? 1 : (uint32_t)roots.size();
+    g.off.push_back(0);
+    for (uint32_t k = 0; k < n_groups; k++) {
+        size_t lo = roots.size() * k / n_groups, hi = roots.size() * (k + 1) / n_groups;
+        std::vector<Root> sub(roots.begin() + lo, roots.begin() + hi);
+        Program p = compile_program(air, cm, public_values, sub, num_weights);
+        g.code.insert(g.code.end(), p.code.begin(), p.code.end());
+        g.off.push_back((uint32_t)g.code.size());
+        g.max_slots = std::max(g.max_slots, p.num_slots);
+    }
+    return g;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Interpreter (host and device). `Fetch(col) -> T` supplies trace cells at the current point.
 // ---------------------------------------------------------------------------------------------

@@ -535,8 +535,22 @@ struct Prover {
         std::vector<Fp> omega_pows = powers_of(omega_skip, N);
 
         // ---- programs, eq weights, round 0 ----
+        struct GroupedDev {
+            GroupedProgram gp;
+            DevBuf<Instr> code;
+            DevBuf<uint32_t> off;
+        };
+        static constexpr uint32_t MLE_GROUPS = 16;
+        auto make_grouped = [&](GroupedProgram gp) {
+            auto g = std::make_unique<GroupedDev>();
+            g->code = cx.upload(gp.code);
+            g->off = cx.upload(gp.off);
+            g->gp = std::move(gp);
+            return g;
+        };
         struct TraceProgs {
             std::unique_ptr<ProgDev> zc, lg;
+            std::unique_ptr<GroupedDev> zc_g, lg_g;
             std::vector<EF> zc_w, lg_w;
             EF lg_const = EF::zero();
             std::vector<EF> eq3b;
@@ -564,6 +578,8 @@ struct Prover {
                 for (size_t i = 0; i < a.constraint_idx.size(); i++) roots.push_back({a.constraint_idx[i], OP_ACC, 0, (uint32_t)i});
                 tp[t].zc_w = lambda_pows;
                 tp[t].zc = std::make_unique<ProgDev>(make_prog(compile_program(a, v.cm, traces[t].public_values, roots, (uint32_t)lambda_pows.size()), lambda_pows));
+                if (v.n_lift > 0)
+                    tp[t].zc_g = make_grouped(compile_grouped(a, v.cm, traces[t].public_values, roots, (uint32_t)lambda_pows.size(), MLE_GROUPS));
             }
             if (!a.interactions.empty()) {
                 std::vector<Root> roots;
@@ -580,6 +596,8 @@ struct Prover {
                 }
                 tp[t].lg_w = wts;
                 tp[t].lg = std::make_unique<ProgDev>(make_prog(compile_program(a, v.cm, traces[t].public_values, roots, (uint32_t)wts.size()), wts));
+                if (v.n_lift > 0)
+                    tp[t].lg_g = make_grouped(compile_grouped(a, v.cm, traces[t].public_values, roots, (uint32_t)wts.size(), MLE_GROUPS));
             }
             // eq(xi[l_skip..l_skip+n_lift], x)
             DevBuf<EF> d_eq(size_t(1) << v.n_lift);
@@ -761,6 +779,7 @@ struct Prover {
         std::vector<std::array<EF, 2>> lg_tilde(T, {EF::zero(), EF::zero()});
         std::vector<std::vector<EF>> round_polys;
         DevBuf<EF> d_eqr(size_t(1) << std::max(n_max, 1u)), d_pt(std::max(n_max, 1u));
+        DevBuf<EF> mle_partials((size_t)RED_BLOCKS * MLE_GROUPS * 8 + 64);
         OVM_PROF("constraints.mle_rounds", cx.stream);
         for (unsigned round = 1; round <= n_max; round++) {
             EF r_prev = r[round - 1];
@@ -793,14 +812,23 @@ struct Prover {
                     if (log_num_y) OVM_THROW_IF(hipMemcpyAsync(d_pt.p, xi.data() + l_skip + round, log_num_y * sizeof(EF), hipMemcpyHostToDevice, cx.stream));
                     OVM_THROW_IF(eq_table(d_pt.p, log_num_y, d_eqr.p, cx.stream));
                     const EF *mats = v.mats_in_a ? v.mats_a.p : v.mats_b.p;
-                    OVM_THROW_IF(mle_round_eval(tp[t].zc->dev(), mats, (uint32_t)v.cm.total, v.cur_log_h, cdeg_global, 1, d_eqr.p,
-                                                EF::zero(), partials.p, d_out.p, cx.stream));
+                    {
+                        const GroupedDev &gd = *tp[t].zc_g;
+                        OVM_THROW_IF(mle_round_eval_grouped(gd.code.p, gd.off.p, (uint32_t)gd.gp.off.size() - 1, gd.gp.max_slots,
+                                                            tp[t].zc->weights.p, mats, v.cur_log_h, cdeg_global, 1, d_eqr.p,
+                                                            EF::zero(), mle_partials.p, d_out.p, cx.stream));
+                    }
                     auto ev = cx.download(d_out.p, 8);
                     sp[2 * T + t].resize(cdeg_global);
                     for (unsigned i = 0; i < cdeg_global; i++) sp[2 * T + t][i] = ev[2 * i];
                     if (has_int) {
-                        OVM_THROW_IF(mle_round_eval(tp[t].lg->dev(), mats, (uint32_t)v.cm.total, v.cur_log_h, cdeg_global, 2,
-                                                    d_eqr.p, tp[t].lg_const, partials.p, d_out.p, cx.stream));
+                        {
+                            const GroupedDev &gd = *tp[t].lg_g;
+                            OVM_THROW_IF(mle_round_eval_grouped(gd.code.p, gd.off.p, (uint32_t)gd.gp.off.size() - 1,
+                                                                gd.gp.max_slots, tp[t].lg->weights.p, mats, v.cur_log_h,
+                                                                cdeg_global, 2, d_eqr.p, tp[t].lg_const, mle_partials.p,
+                                                                d_out.p, cx.stream));
+                        }
                         auto e2 = cx.download(d_out.p, 8);
                         sp[2 * t].resize(cdeg_global);
                         sp[2 * t + 1].resize(cdeg_global);

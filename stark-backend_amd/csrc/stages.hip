@@ -361,6 +361,48 @@ int mle_round_eval(const DevProgram &prog, const EF *mats, uint32_t n_cols, uint
     return sum_partials(d_partials, grid, 8, d_out, s);  // out[2*(X-1)+o]
 }
 
+template <int NS>
+__global__ __launch_bounds__(RED_THREADS) void mle_round_grouped_kernel(const Instr *code, const uint32_t *off,
+                                                                        const EF *weights, const EF *mats,
+                                                                        uint32_t log_h, uint32_t n_out, const EF *eq,
+                                                                        EF add_const, EF *partials) {
+    const uint64_t n_y = 1ull << (log_h - 1);
+    const uint64_t stride = (uint64_t)gridDim.x * RED_THREADS;
+    const uint32_t xi = blockIdx.y + 1, grp = blockIdx.z, K = 2 * gridDim.y;
+    const Instr *gcode = code + off[grp];
+    const uint32_t n_instr = off[grp + 1] - off[grp];
+    EF sums[2] = {EF::zero(), EF::zero()};
+    EF slots[NS];
+    for (uint64_t y = (uint64_t)blockIdx.x * RED_THREADS + threadIdx.x; y < n_y; y += stride) {
+        EF e = ld_ef(eq + y);
+        MleFetch fetch{mats, log_h, y, Fp::from_canonical(xi)};
+        EF out[2] = {EF::zero(), grp == 0 ? add_const : EF::zero()};
+        run_program_acc<EF>(gcode, n_instr, weights, slots, fetch, out);
+        sums[0] = sums[0] + e * out[0];
+        if (n_out > 1) sums[1] = sums[1] + e * out[1];
+    }
+    block_sum_store<2>(sums, partials + ((size_t)(blockIdx.x * gridDim.z + grp)) * K + 2 * blockIdx.y);
+}
+
+int mle_round_eval_grouped(const Instr *d_code, const uint32_t *d_off, uint32_t n_groups, uint32_t max_slots,
+                           const EF *d_weights, const EF *mats, uint32_t log_h, uint32_t degree, uint32_t n_out,
+                           const EF *d_eq, EF add_const, EF *d_partials, EF *d_out, hipStream_t s) {
+    if (degree == 0 || degree > 4 || n_out > 2 || log_h == 0 || n_groups == 0) return (int)hipErrorInvalidValue;
+    uint32_t gx = red_grid(1ull << (log_h - 1));
+    // keep the total grid near RED_BLOCKS workgroups
+    uint32_t cap = RED_BLOCKS / (degree * n_groups);
+    if (cap < 1) cap = 1;
+    if (gx > cap) gx = cap;
+    dim3 grid(gx, degree, n_groups);
+#define CALL(NS)                                                                                               \
+    hipLaunchKernelGGL(mle_round_grouped_kernel<NS>, grid, dim3(RED_THREADS), 0, s, d_code, d_off, d_weights, mats, \
+                       log_h, n_out, d_eq, add_const, d_partials)
+    DISPATCH_SLOTS(max_slots, CALL);
+#undef CALL
+    OVM_CHECK_LAUNCH();
+    return sum_partials(d_partials, gx * n_groups, 2 * degree, d_out, s);
+}
+
 __global__ void fold_mle_kernel(const EF *in, EF *out, uint32_t log_h, EF r) {
     const uint64_t h2 = 1ull << (log_h - 1);
     uint64_t y = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
