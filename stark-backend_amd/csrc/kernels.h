@@ -25,7 +25,7 @@ struct DevProgram {
 };
 
 static constexpr unsigned MAX_COSETS = 4;
-static constexpr unsigned RED_BLOCKS = 1024;  // grid size of the partial-sum kernels
+static constexpr unsigned RED_BLOCKS = 2048;  // grid cap of the partial-sum kernels (8 workgroups per CU)
 static constexpr unsigned RED_THREADS = 256;
 
 // out[k] = sum_b partials[b * K + k]
