@@ -102,9 +102,19 @@ def main():
             algo_bytes = 4 * rows * width + 32 * rows
             avg_s = total_ms / calls * 1e-3
             achieved = algo_bytes / avg_s / 1e9
+            # measured HBM bytes per launch: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this
+            # command (profiles/r01/pmc_hbm_traffic_*.json, gfx950 x2 fetch correction applied); only valid
+            # for the default workload, null otherwise
+            traffic = None
+            pmc = os.path.join(ROOT, "profiles", "r01", "pmc_hbm_traffic_v2.json")
+            if (log_rows, cols, args.log_stacked_height) == (22, 100, 24) and os.path.exists(pmc):
+                k = json.load(open(pmc))["kernels"].get("hash_rows_kernel<1>")
+                if k:
+                    traffic = (k["fetch_bytes_corrected"] + k["write_bytes"]) // k["launches_per_prove"]
             roof = {"kernel": "hash_rows_kernel<1> (Poseidon2 leaf hash; integer-ALU bound, see DESIGN.md)",
                     "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                    "traffic_source": "profiles/r01/pmc_hbm_traffic_v2.json (PMC pass, not live)" if traffic else None,
                     "avg_launch_ms": round(total_ms / calls, 3), "algorithmic_bytes": algo_bytes}
         cpu = None
         if not args.no_cpu_baseline:
