@@ -13,8 +13,19 @@ struct ColDesc {
     uint32_t rot;
 };
 
-struct Frac {
-    EF p, q;
+// Limb-planar arrays (GKR data): limb k of element i is p[k * stride + i]; stride is a multiple
+// of 4 and p is 16-byte aligned so 2/4 consecutive elements are one vector access per plane.
+struct EFPlanes {
+    uint32_t *p;
+    uint64_t stride;
+};
+// Fractions: numerator limbs in planes 0..3, denominator limbs in planes 4..7.
+struct FracPlanes {
+    uint32_t *p;
+    uint64_t stride;
+    BB_HD uint32_t *P() const { return p; }
+    BB_HD uint32_t *Q() const { return p + 4 * stride; }
+    BB_HD FracPlanes at(uint64_t first) const { return FracPlanes{p + first, stride}; }
 };
 
 struct DevProgram {
@@ -63,18 +74,21 @@ int mle_round_eval_grouped(const Instr *d_code, const uint32_t *d_off, uint32_t 
 // out[c * h/2 + y] = in[c*h + 2y] + r * (in[c*h + 2y + 1] - in[c*h + 2y])
 int fold_mle(const EF *in, EF *out, uint32_t n_cols, uint32_t log_h, EF r, hipStream_t s);
 
-// ---- LogUp GKR ----
-int gkr_fill_leaves(Frac *leaves, uint64_t n, EF alpha, hipStream_t s);
+// ---- LogUp GKR ----  (layer format: record x = fractions 2x, 2x+1 = (p0,q0),(p1,q1))
+int eq_table_planes(const EF *d_point, uint32_t n, EFPlanes out, hipStream_t s);
+int gkr_fill_leaves(FracPlanes leaves, uint64_t n, EF alpha, hipStream_t s);
 int gkr_eval_leaves(const DevProgram &prog, const EF *d_leaf_const, const ColDesc *d_cols, uint32_t log_height,
-                    const uint64_t *d_leaf_base, const uint32_t *d_leaf_log_len, Fp norm, Frac *leaves,
+                    const uint64_t *d_leaf_base, const uint32_t *d_leaf_log_len, Fp norm, FracPlanes leaves,
                     hipStream_t s);
-int gkr_build_layer(const Frac *child, Frac *parent, uint64_t n_parent, hipStream_t s);
-// records: 4 EF per x (p0,q0,p1,q1); eq: 1 EF per x. n_pairs = number of y.
-int gkr_round(const EF *rec, const EF *eq, uint64_t n_pairs, EF lambda, EF *d_partials, EF *d_out, hipStream_t s);
+int gkr_build_layer(FracPlanes child, FracPlanes parent, uint64_t n_parent, hipStream_t s);
+// out[2i], out[2i+1] = (p, q) of fractions first .. first+n (n <= 64), AoS, for the host
+int gkr_read_fracs(FracPlanes t, uint64_t first, uint32_t n, EF *out, hipStream_t s);
+int gkr_round(FracPlanes rec, EFPlanes eq, uint64_t n_pairs, EF lambda, EF *d_partials, EF *d_out, hipStream_t s);
 // fold the previous round with r and return the NEXT round's sums over the n_pairs folded pairs
-int gkr_fold_round(const EF *rec_in, const EF *eq_in, EF *rec_out, EF *eq_out, uint64_t n_pairs, EF r, EF lambda,
+int gkr_fold_round(FracPlanes in, EFPlanes eq_in, FracPlanes out, EFPlanes eq_out, uint64_t n_pairs, EF r, EF lambda,
                    EF *d_partials, EF *d_out, hipStream_t s);
-int gkr_fold(const EF *rec_in, const EF *eq_in, EF *rec_out, EF *eq_out, uint64_t n_out, EF r, hipStream_t s);
+// two records -> out4 = (p0, q0, p1, q1) folded at r (AoS, for the host)
+int gkr_fold_final(FracPlanes in, EF r, EF *out4, hipStream_t s);
 
 // ---- stacked reduction ----
 // R[v * N + z] for v in {eq, rot1, rot2} over one window of `n_slices` contiguous slices of

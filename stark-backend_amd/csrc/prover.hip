@@ -409,9 +409,12 @@ struct Prover {
         const unsigned TR = l_skip + n_logup;
         if (!ilayout.cols.empty()) {
             const size_t n_leaves = size_t(1) << TR;
-            DevBuf<Frac> tree(2 * n_leaves);
+            // heap-ordered fraction tree (node 1 = root, layer j at [2^j, 2^(j+1))), 8 limb planes
+            const uint64_t tree_stride = std::max<uint64_t>(2 * n_leaves, 4);
+            DevBuf<uint32_t> tree_buf(8 * tree_stride);
+            const FracPlanes tree{tree_buf.p, tree_stride};
             ProfScope *ps_leaves = new ProfScope("gkr.leaves", cx.stream);
-            OVM_THROW_IF(gkr_fill_leaves(tree.p + n_leaves, n_leaves, alpha, cx.stream));
+            OVM_THROW_IF(gkr_fill_leaves(tree.at(n_leaves), n_leaves, alpha, cx.stream));
             for (size_t t = 0; t < T; t++) {
                 const AirKey &a = air(t);
                 if (a.interactions.empty()) continue;
@@ -434,7 +437,7 @@ struct Prover {
                 auto d_ll = cx.upload(leaf_log_len);
                 Fp norm = fp(uint64_t(1) << (tv[t].log_lifted - tv[t].log_height)).inv();
                 OVM_THROW_IF(gkr_eval_leaves(pd.dev(), d_lc.p, tv[t].cols.p, tv[t].log_height, d_lb.p, d_ll.p, norm,
-                                             tree.p + n_leaves, cx.stream));
+                                             tree.at(n_leaves), cx.stream));
                 cx.sync();
             }
             delete ps_leaves;
@@ -442,16 +445,18 @@ struct Prover {
             OVM_PROF("gkr.build_tree", cx.stream);
             wt.mark("rap.gkr.leaves");
             for (unsigned j = TR; j-- > 0;)
-                OVM_THROW_IF(gkr_build_layer(tree.p + (size_t(2) << j), tree.p + (size_t(1) << j), size_t(1) << j, cx.stream));
+                OVM_THROW_IF(gkr_build_layer(tree.at(size_t(2) << j), tree.at(size_t(1) << j), size_t(1) << j, cx.stream));
             }
             wt.mark("rap.gkr.build");
             OVM_PROF("gkr.layer_sumchecks", cx.stream);
             {
-                auto top = cx.download(tree.p + 1, 3);  // nodes 1, 2, 3
-                if (!is_zero(top[0].p)) throw OvmFail(1, "LogUp: non-zero root sum (interactions do not balance)");
-                q0_claim = top[0].q;
+                DevBuf<EF> d_top(6);
+                OVM_THROW_IF(gkr_read_fracs(tree, 1, 3, d_top.p, cx.stream));
+                auto top = cx.download(d_top.p, 6);  // (p, q) of nodes 1, 2, 3
+                if (!is_zero(top[0])) throw OvmFail(1, "LogUp: non-zero root sum (interactions do not balance)");
+                q0_claim = top[1];
                 ts.observe_ext(q0_claim);
-                claims.push_back({top[1].p, top[2].p, top[1].q, top[2].q});
+                claims.push_back({top[2], top[4], top[3], top[5]});
             }
             auto observe_claims = [&](const std::array<EF, 4> &c) {
                 ts.observe_ext(c[0]);
@@ -462,16 +467,18 @@ struct Prover {
             observe_claims(claims[0]);
             std::vector<EF> xi_prev{ts.sample_ext()};
             if (TR > 1) {
-                DevBuf<EF> rec_a(size_t(4) << (TR - 2)), rec_b(size_t(4) << (TR - 2));
-                DevBuf<EF> eq_a(size_t(1) << (TR - 1)), eq_b(size_t(1) << (TR - 1));
+                // fold buffers in layer format (8 limb planes) and eq tables (4 limb planes)
+                const uint64_t wcap = std::max<uint64_t>(uint64_t(1) << (TR - 1), 4);
+                DevBuf<uint32_t> rec_a(8 * wcap), rec_b(8 * wcap), eq_a(4 * wcap), eq_b(4 * wcap);
+                const FracPlanes recs[2] = {{rec_a.p, wcap}, {rec_b.p, wcap}};
+                const EFPlanes eqs[2] = {{eq_a.p, wcap}, {eq_b.p, wcap}};
                 DevBuf<EF> partials(RED_BLOCKS * 4), d_out(4), d_point(TR);
                 for (unsigned round = 1; round < TR; round++) {
                     EF lambda = ts.sample_ext();
                     OVM_THROW_IF(hipMemcpyAsync(d_point.p, xi_prev.data(), round * sizeof(EF), hipMemcpyHostToDevice, cx.stream));
-                    OVM_THROW_IF(eq_table(d_point.p, round, eq_a.p, cx.stream));
-                    const EF *rec = (const EF *)(tree.p + (size_t(2) << round));
-                    const EF *eq = eq_a.p;
-                    bool to_b = true;
+                    OVM_THROW_IF(eq_table_planes(d_point.p, round, eqs[0], cx.stream));
+                    FracPlanes rec = tree.at(size_t(2) << round);
+                    EFPlanes eq = eqs[0];
                     std::vector<std::array<EF, 3>> polys;
                     std::vector<EF> rho;
                     EF r_prev = EF::zero();
@@ -481,13 +488,10 @@ struct Prover {
                             OVM_THROW_IF(gkr_round(rec, eq, n_pairs, lambda, partials.p, d_out.p, cx.stream));
                         } else {
                             // fold sub-round sr-1 with r_prev and get this sub-round's sums in one pass
-                            EF *rec_o = (sr % 2 == 1) ? rec_a.p : rec_b.p;
-                            EF *eq_o = to_b ? eq_b.p : eq_a.p;
-                            OVM_THROW_IF(gkr_fold_round(rec, eq, rec_o, eq_o, n_pairs, r_prev, lambda, partials.p, d_out.p,
-                                                        cx.stream));
-                            rec = rec_o;
-                            eq = eq_o;
-                            to_b = !to_b;
+                            OVM_THROW_IF(gkr_fold_round(rec, eq, recs[sr & 1], eqs[sr & 1], n_pairs, r_prev, lambda,
+                                                        partials.p, d_out.p, cx.stream));
+                            rec = recs[sr & 1];
+                            eq = eqs[sr & 1];
                         }
                         auto sv = cx.download(d_out.p, 3);
                         for (auto &e : sv) ts.observe_ext(e);
@@ -495,14 +499,9 @@ struct Prover {
                         r_prev = ts.sample_ext();
                         rho.push_back(r_prev);
                     }
-                    {
-                        // last fold: one record (the layer claims)
-                        EF *rec_o = (round % 2 == 1) ? rec_a.p : rec_b.p;
-                        EF *eq_o = to_b ? eq_b.p : eq_a.p;
-                        OVM_THROW_IF(gkr_fold(rec, eq, rec_o, eq_o, 1, r_prev, cx.stream));
-                        rec = rec_o;
-                    }
-                    auto fin = cx.download(rec, 4);
+                    // last fold: one record (the layer claims)
+                    OVM_THROW_IF(gkr_fold_final(rec, r_prev, d_out.p, cx.stream));
+                    auto fin = cx.download(d_out.p, 4);
                     claims.push_back({fin[0], fin[2], fin[1], fin[3]});
                     observe_claims(claims.back());
                     EF mu = ts.sample_ext();

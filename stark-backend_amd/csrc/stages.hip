@@ -95,8 +95,29 @@ int build_selectors(Fp *sels, uint32_t log_lifted, uint32_t log_height, hipStrea
     return 0;
 }
 
-template <bool MOBIUS>
-__global__ void eq_table_kernel(const EF *point, uint32_t n, EF *out) {
+// Output policies: 16-byte AoS elements, or limb planes (used by the GKR kernels).
+struct EqOutAos {
+    EF *p;
+    __device__ EF ld(uint64_t i) const { return ld_ef(p + i); }
+    __device__ void st(uint64_t i, const EF &x) const { st_ef(p + i, x); }
+};
+struct EqOutPlanes {
+    uint32_t *p;
+    uint64_t stride;
+    __device__ EF ld(uint64_t i) const {
+        EF r;
+#pragma unroll
+        for (int k = 0; k < 4; k++) r.c[k] = Fp::raw(p[k * stride + i]);
+        return r;
+    }
+    __device__ void st(uint64_t i, const EF &x) const {
+#pragma unroll
+        for (int k = 0; k < 4; k++) p[k * stride + i] = x.c[k].v;
+    }
+};
+
+template <bool MOBIUS, class Out>
+__global__ void eq_table_kernel(const EF *point, uint32_t n, Out out) {
     uint64_t y = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (y >= (1ull << n)) return;
     EF acc = EF::one();
@@ -109,38 +130,45 @@ __global__ void eq_table_kernel(const EF *point, uint32_t n, EF *out) {
             f = (y >> i & 1) ? x : EF::one() - x;
         acc = acc * f;
     }
-    st_ef(out + y, acc);
+    out.st(y, acc);
 }
 // One doubling step: entries [0, 2^k) hold the table over variables 0..k-1.
 //   eq:     out[y + 2^k] = out[y] * x_k ;  out[y] = out[y] - out[y + 2^k]          (= out[y] * (1 - x_k))
 //   mobius: out[y + 2^k] = out[y] * x_k ;  out[y] = out[y] - 2 * out[y + 2^k]      (= out[y] * (1 - 2 x_k))
 // One extension multiply per pair, so a 2^n table costs 2^n multiplies in total instead of n * 2^n.
-template <bool MOBIUS>
-__global__ void eq_double_kernel(const EF *point, uint32_t k, EF *out) {
+template <bool MOBIUS, class Out>
+__global__ void eq_double_kernel(const EF *point, uint32_t k, Out out) {
     uint64_t y = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (y >= (1ull << k)) return;
-    EF lo = ld_ef(out + y);
+    EF lo = out.ld(y);
     EF hi = lo * ld_ef(point + k);
-    st_ef(out + y + (1ull << k), hi);
-    st_ef(out + y, MOBIUS ? lo - hi.dbl() : lo - hi);
+    out.st(y + (1ull << k), hi);
+    out.st(y, MOBIUS ? lo - hi.dbl() : lo - hi);
 }
 
 static constexpr uint32_t EQ_DIRECT_BITS = 10;
 
-template <bool MOBIUS>
-static int eq_table_impl(const EF *d_point, uint32_t n, EF *out, hipStream_t s) {
+template <bool MOBIUS, class Out>
+static int eq_table_impl(const EF *d_point, uint32_t n, Out out, hipStream_t s) {
     uint32_t n0 = n < EQ_DIRECT_BITS ? n : EQ_DIRECT_BITS;
-    hipLaunchKernelGGL(eq_table_kernel<MOBIUS>, dim3(ceil_div(1ull << n0, 256)), dim3(256), 0, s, d_point, n0, out);
+    hipLaunchKernelGGL((eq_table_kernel<MOBIUS, Out>), dim3(ceil_div(1ull << n0, 256)), dim3(256), 0, s, d_point, n0,
+                       out);
     OVM_CHECK_LAUNCH();
     for (uint32_t k = n0; k < n; k++) {
-        hipLaunchKernelGGL(eq_double_kernel<MOBIUS>, dim3(ceil_div(1ull << k, 256)), dim3(256), 0, s, d_point, k, out);
+        hipLaunchKernelGGL((eq_double_kernel<MOBIUS, Out>), dim3(ceil_div(1ull << k, 256)), dim3(256), 0, s, d_point,
+                           k, out);
         OVM_CHECK_LAUNCH();
     }
     return 0;
 }
-int eq_table(const EF *d_point, uint32_t n, EF *out, hipStream_t s) { return eq_table_impl<false>(d_point, n, out, s); }
+int eq_table(const EF *d_point, uint32_t n, EF *out, hipStream_t s) {
+    return eq_table_impl<false>(d_point, n, EqOutAos{out}, s);
+}
+int eq_table_planes(const EF *d_point, uint32_t n, EFPlanes out, hipStream_t s) {
+    return eq_table_impl<false>(d_point, n, EqOutPlanes{out.p, out.stride}, s);
+}
 int mobius_eq_table(const EF *d_point, uint32_t n, EF *out, hipStream_t s) {
-    return eq_table_impl<true>(d_point, n, out, s);
+    return eq_table_impl<true>(d_point, n, EqOutAos{out}, s);
 }
 
 // ---- coset LDE of 2^l_skip-row chunks --------------------------------------------------------
@@ -420,15 +448,61 @@ int fold_mle(const EF *in, EF *out, uint32_t n_cols, uint32_t log_h, EF r, hipSt
 }
 
 // ---- LogUp GKR -------------------------------------------------------------------------------
-__device__ __forceinline__ void st_frac(Frac *p, const EF &a, const EF &b) {
-    st_ef(&p->p, a);
-    st_ef(&p->q, b);
+// All GKR data (the fraction tree, the fold buffers, the eq tables) is LIMB-PLANAR: limb k of
+// element i lives at base[k * stride + i]. A lane that needs the 2, 4 or 8 consecutive elements
+// of its pair therefore issues one dwordx2/x4 load per limb plane and consecutive lanes touch
+// consecutive addresses -- every load and store instruction of every sub-round is unit-stride
+// across the wavefront, at any fold depth. (With 16-byte AoS elements a lane streamed 256 B of
+// its own and the PMC counters showed 4-5x the algorithmic HBM traffic; profiles/r01.)
+//
+// "Layer format": an array of 2m fractions; record x (the sumcheck's evaluation point x) is
+// (p0, q0, p1, q1) = (P[2x], Q[2x], P[2x+1], Q[2x+1]). A tree layer is in this format by
+// construction, and the folded buffers keep it.
+__device__ __forceinline__ EF ldp(const uint32_t *b, uint64_t st, uint64_t i) {
+    EF r;
+#pragma unroll
+    for (int k = 0; k < 4; k++) r.c[k] = Fp::raw(b[k * st + i]);
+    return r;
 }
-__global__ void gkr_fill_kernel(Frac *leaves, uint64_t n, EF alpha) {
+__device__ __forceinline__ void stp(uint32_t *b, uint64_t st, uint64_t i, const EF &x) {
+#pragma unroll
+    for (int k = 0; k < 4; k++) b[k * st + i] = x.c[k].v;
+}
+__device__ __forceinline__ void ldp2(const uint32_t *b, uint64_t st, uint64_t i, EF &e0, EF &e1) {
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        uint2 v = *reinterpret_cast<const uint2 *>(b + k * st + i);
+        e0.c[k] = Fp::raw(v.x);
+        e1.c[k] = Fp::raw(v.y);
+    }
+}
+__device__ __forceinline__ void stp2(uint32_t *b, uint64_t st, uint64_t i, const EF &e0, const EF &e1) {
+#pragma unroll
+    for (int k = 0; k < 4; k++) *reinterpret_cast<uint2 *>(b + k * st + i) = make_uint2(e0.c[k].v, e1.c[k].v);
+}
+__device__ __forceinline__ void ldp4(const uint32_t *b, uint64_t st, uint64_t i, EF (&e)[4]) {
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        uint4 v = *reinterpret_cast<const uint4 *>(b + k * st + i);
+        e[0].c[k] = Fp::raw(v.x);
+        e[1].c[k] = Fp::raw(v.y);
+        e[2].c[k] = Fp::raw(v.z);
+        e[3].c[k] = Fp::raw(v.w);
+    }
+}
+__device__ __forceinline__ void stp4(uint32_t *b, uint64_t st, uint64_t i, const EF (&e)[4]) {
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+        *reinterpret_cast<uint4 *>(b + k * st + i) = make_uint4(e[0].c[k].v, e[1].c[k].v, e[2].c[k].v, e[3].c[k].v);
+}
+
+__global__ void gkr_fill_kernel(FracPlanes leaves, uint64_t n, EF alpha) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) st_frac(leaves + i, EF::zero(), alpha);
+    if (i >= n) return;
+    stp(leaves.P(), leaves.stride, i, EF::zero());
+    stp(leaves.Q(), leaves.stride, i, alpha);
 }
-int gkr_fill_leaves(Frac *leaves, uint64_t n, EF alpha, hipStream_t s) {
+int gkr_fill_leaves(FracPlanes leaves, uint64_t n, EF alpha, hipStream_t s) {
     hipLaunchKernelGGL(gkr_fill_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, s, leaves, n, alpha);
     OVM_CHECK_LAUNCH();
     return 0;
@@ -443,22 +517,27 @@ struct BaseFetch {
     }
 };
 struct LeafEmit {
-    Frac *leaves;
+    FracPlanes leaves;
     const uint64_t *leaf_base;
     const uint32_t *leaf_log_len;
     uint32_t log_height;
     uint64_t row;
     Fp norm;
     __device__ void operator()(uint32_t k, Fp numer, const EF &den) const {
-        EF p = EF::from_base(numer * norm);
+        const Fp p = numer * norm;  // base-field numerator: limbs 1..3 stay zero
         uint64_t len = 1ull << leaf_log_len[k];
-        for (uint64_t off = 0; off < len; off += 1ull << log_height) st_frac(leaves + leaf_base[k] + off + row, p, den);
+        for (uint64_t off = 0; off < len; off += 1ull << log_height) {
+            const uint64_t i = leaf_base[k] + off + row;
+            stp(leaves.P(), leaves.stride, i, EF::from_base(p));
+            stp(leaves.Q(), leaves.stride, i, den);
+        }
     }
 };
 
 template <int NS>
 __global__ void gkr_leaves_kernel(DevProgram prog, const EF *leaf_const, const ColDesc *cols, uint32_t log_height,
-                                  const uint64_t *leaf_base, const uint32_t *leaf_log_len, Fp norm, Frac *leaves) {
+                                  const uint64_t *leaf_base, const uint32_t *leaf_log_len, Fp norm,
+                                  FracPlanes leaves) {
     uint64_t row = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (row >= (1ull << log_height)) return;
     Fp slots[NS];
@@ -467,7 +546,7 @@ __global__ void gkr_leaves_kernel(DevProgram prog, const EF *leaf_const, const C
     run_program_leaves<Fp>(prog.code, prog.n_instr, prog.weights, leaf_const, slots, fetch, emit);
 }
 int gkr_eval_leaves(const DevProgram &prog, const EF *d_leaf_const, const ColDesc *d_cols, uint32_t log_height,
-                    const uint64_t *d_leaf_base, const uint32_t *d_leaf_log_len, Fp norm, Frac *leaves,
+                    const uint64_t *d_leaf_base, const uint32_t *d_leaf_log_len, Fp norm, FracPlanes leaves,
                     hipStream_t s) {
     uint32_t grid = ceil_div(1ull << log_height, 256);
 #define CALL(NS)                                                                                           \
@@ -479,47 +558,71 @@ int gkr_eval_leaves(const DevProgram &prog, const EF *d_leaf_const, const ColDes
     return 0;
 }
 
-__global__ void gkr_build_kernel(const Frac *child, Frac *parent, uint64_t n_parent) {
+// parent[i] = child[2i] + child[2i+1] as fractions
+__global__ void gkr_build_kernel(FracPlanes child, FracPlanes parent, uint64_t n_parent) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_parent) return;
-    EF p0 = ld_ef(&child[2 * i].p), q0 = ld_ef(&child[2 * i].q);
-    EF p1 = ld_ef(&child[2 * i + 1].p), q1 = ld_ef(&child[2 * i + 1].q);
-    st_frac(parent + i, p0 * q1 + q0 * p1, q0 * q1);
+    EF p0, p1, q0, q1;
+    ldp2(child.P(), child.stride, 2 * i, p0, p1);
+    ldp2(child.Q(), child.stride, 2 * i, q0, q1);
+    stp(parent.P(), parent.stride, i, p0 * q1 + q0 * p1);
+    stp(parent.Q(), parent.stride, i, q0 * q1);
 }
-int gkr_build_layer(const Frac *child, Frac *parent, uint64_t n_parent, hipStream_t s) {
+int gkr_build_layer(FracPlanes child, FracPlanes parent, uint64_t n_parent, hipStream_t s) {
     hipLaunchKernelGGL(gkr_build_kernel, dim3(ceil_div(n_parent, 256)), dim3(256), 0, s, child, parent, n_parent);
     OVM_CHECK_LAUNCH();
     return 0;
 }
 
-__global__ __launch_bounds__(RED_THREADS) void gkr_round_kernel(const EF *rec, const EF *eq, uint64_t n_pairs,
+__global__ void gkr_read_kernel(FracPlanes t, uint64_t first, uint32_t n, EF *out) {
+    uint32_t i = threadIdx.x;
+    if (i >= n) return;
+    st_ef(out + 2 * i, ldp(t.P(), t.stride, first + i));
+    st_ef(out + 2 * i + 1, ldp(t.Q(), t.stride, first + i));
+}
+int gkr_read_fracs(FracPlanes t, uint64_t first, uint32_t n, EF *out, hipStream_t s) {
+    hipLaunchKernelGGL(gkr_read_kernel, dim3(1), dim3(64), 0, s, t, first, n, out);
+    OVM_CHECK_LAUNCH();
+    return 0;
+}
+
+// sums[X-1] += e(X) * (p0 q1 + p1 q0 + lambda q0 q1)(X) for X = 1, 2, 3 where every quantity is
+// the line through its values on records a (X = 0) and b (X = 1).
+__device__ __forceinline__ void gkr_pair_sums(EF (&a)[4], const EF (&b)[4], EF e0, EF e1, const EF &lambda,
+                                              EF (&sums)[3]) {
+    EF d[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) d[i] = b[i] - a[i];
+    EF ed = e1 - e0, e = e0;
+#pragma unroll
+    for (int xi = 0; xi < 3; xi++) {
+        e = e + ed;
+#pragma unroll
+        for (int i = 0; i < 4; i++) a[i] = a[i] + d[i];
+        // (p0, q0, p1, q1) at X = xi+1
+        EF pq = a[0] * a[3] + a[2] * a[1];
+        EF qq = a[1] * a[3];
+        sums[xi] = sums[xi] + e * (pq + lambda * qq);
+    }
+}
+
+__global__ __launch_bounds__(RED_THREADS) void gkr_round_kernel(FracPlanes rec, EFPlanes eq, uint64_t n_pairs,
                                                                 EF lambda, EF *partials) {
     const uint64_t stride = (uint64_t)gridDim.x * RED_THREADS;
     EF sums[3] = {EF::zero(), EF::zero(), EF::zero()};
     for (uint64_t y = (uint64_t)blockIdx.x * RED_THREADS + threadIdx.x; y < n_pairs; y += stride) {
-        const EF *r0 = rec + 8 * y;  // records 2y and 2y+1, 4 EF each
-        EF a[4], d[4];
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-            a[i] = ld_ef(r0 + i);
-            d[i] = ld_ef(r0 + 4 + i) - a[i];
-        }
-        EF e0 = ld_ef(eq + 2 * y), ed = ld_ef(eq + 2 * y + 1) - e0;
-        EF e = e0;
-#pragma unroll
-        for (int xi = 0; xi < 3; xi++) {
-            e = e + ed;
-#pragma unroll
-            for (int i = 0; i < 4; i++) a[i] = a[i] + d[i];
-            // (p0, q0, p1, q1) at X = xi+1
-            EF pq = a[0] * a[3] + a[2] * a[1];
-            EF qq = a[1] * a[3];
-            sums[xi] = sums[xi] + e * (pq + lambda * qq);
-        }
+        EF p[4], q[4];  // fractions 4y..4y+3 = records 2y (entries 0,1) and 2y+1 (entries 2,3)
+        ldp4(rec.P(), rec.stride, 4 * y, p);
+        ldp4(rec.Q(), rec.stride, 4 * y, q);
+        EF e0, e1;
+        ldp2(eq.p, eq.stride, 2 * y, e0, e1);
+        EF a[4] = {p[0], q[0], p[1], q[1]};
+        const EF b[4] = {p[2], q[2], p[3], q[3]};
+        gkr_pair_sums(a, b, e0, e1, lambda, sums);
     }
     block_sum_store<3>(sums, partials + (size_t)blockIdx.x * 3);
 }
-int gkr_round(const EF *rec, const EF *eq, uint64_t n_pairs, EF lambda, EF *d_partials, EF *d_out, hipStream_t s) {
+int gkr_round(FracPlanes rec, EFPlanes eq, uint64_t n_pairs, EF lambda, EF *d_partials, EF *d_out, hipStream_t s) {
     uint32_t grid = red_grid(n_pairs);
     hipLaunchKernelGGL(gkr_round_kernel, dim3(grid), dim3(RED_THREADS), 0, s, rec, eq, n_pairs, lambda, d_partials);
     OVM_CHECK_LAUNCH();
@@ -527,66 +630,65 @@ int gkr_round(const EF *rec, const EF *eq, uint64_t n_pairs, EF lambda, EF *d_pa
 }
 
 // Fused "fold with r, then next round's sums": output pair y is built from input records
-// 4y..4y+3 (and eq entries 4y..4y+3); the two folded records are stored and immediately used for
-// the degree-3 round sums, so every sub-round after the first is ONE pass over the data.
-__global__ __launch_bounds__(RED_THREADS) void gkr_fold_round_kernel(const EF *rec_in, const EF *eq_in,
-                                                                     EF *rec_out, EF *eq_out, uint64_t n_pairs,
-                                                                     EF r, EF lambda, EF *partials) {
+// 4y..4y+3 = fractions 8y..8y+7 (and eq entries 4y..4y+3); the two folded records (fractions
+// 4y..4y+3 of the output) are stored and immediately used for the degree-3 round sums, so every
+// sub-round after the first is ONE pass over the data.
+__global__ __launch_bounds__(RED_THREADS) void gkr_fold_round_kernel(FracPlanes in, EFPlanes eq_in, FracPlanes out,
+                                                                     EFPlanes eq_out, uint64_t n_pairs, EF r,
+                                                                     EF lambda, EF *partials) {
     const uint64_t stride = (uint64_t)gridDim.x * RED_THREADS;
     EF sums[3] = {EF::zero(), EF::zero(), EF::zero()};
     for (uint64_t y = (uint64_t)blockIdx.x * RED_THREADS + threadIdx.x; y < n_pairs; y += stride) {
-        EF a[4], d[4];
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-            EF u0 = ld_ef(rec_in + 16 * y + i), u1 = ld_ef(rec_in + 16 * y + 4 + i);
-            EF v0 = ld_ef(rec_in + 16 * y + 8 + i), v1 = ld_ef(rec_in + 16 * y + 12 + i);
-            EF f0 = u0 + (u1 - u0) * r, f1 = v0 + (v1 - v0) * r;
-            st_ef(rec_out + 8 * y + i, f0);
-            st_ef(rec_out + 8 * y + 4 + i, f1);
-            a[i] = f0;
-            d[i] = f1 - f0;
+        EF fp[4], fq[4];
+        {
+            EF u[4], v[4];
+            ldp4(in.P(), in.stride, 8 * y, u);      // records 4y, 4y+1
+            ldp4(in.P(), in.stride, 8 * y + 4, v);  // records 4y+2, 4y+3
+            fp[0] = u[0] + (u[2] - u[0]) * r;
+            fp[1] = u[1] + (u[3] - u[1]) * r;
+            fp[2] = v[0] + (v[2] - v[0]) * r;
+            fp[3] = v[1] + (v[3] - v[1]) * r;
+            stp4(out.P(), out.stride, 4 * y, fp);
+            ldp4(in.Q(), in.stride, 8 * y, u);
+            ldp4(in.Q(), in.stride, 8 * y + 4, v);
+            fq[0] = u[0] + (u[2] - u[0]) * r;
+            fq[1] = u[1] + (u[3] - u[1]) * r;
+            fq[2] = v[0] + (v[2] - v[0]) * r;
+            fq[3] = v[1] + (v[3] - v[1]) * r;
+            stp4(out.Q(), out.stride, 4 * y, fq);
         }
-        EF e00 = ld_ef(eq_in + 4 * y), e01 = ld_ef(eq_in + 4 * y + 1), e10 = ld_ef(eq_in + 4 * y + 2),
-           e11 = ld_ef(eq_in + 4 * y + 3);
-        EF e0 = e00 + (e01 - e00) * r, e1 = e10 + (e11 - e10) * r;
-        st_ef(eq_out + 2 * y, e0);
-        st_ef(eq_out + 2 * y + 1, e1);
-        EF e = e0, ed = e1 - e0;
-#pragma unroll
-        for (int xi = 0; xi < 3; xi++) {
-            e = e + ed;
-#pragma unroll
-            for (int i = 0; i < 4; i++) a[i] = a[i] + d[i];
-            EF pq = a[0] * a[3] + a[2] * a[1];
-            EF qq = a[1] * a[3];
-            sums[xi] = sums[xi] + e * (pq + lambda * qq);
-        }
+        EF e[4];
+        ldp4(eq_in.p, eq_in.stride, 4 * y, e);
+        EF e0 = e[0] + (e[1] - e[0]) * r, e1 = e[2] + (e[3] - e[2]) * r;
+        stp2(eq_out.p, eq_out.stride, 2 * y, e0, e1);
+        EF a[4] = {fp[0], fq[0], fp[1], fq[1]};
+        const EF b[4] = {fp[2], fq[2], fp[3], fq[3]};
+        gkr_pair_sums(a, b, e0, e1, lambda, sums);
     }
     block_sum_store<3>(sums, partials + (size_t)blockIdx.x * 3);
 }
-int gkr_fold_round(const EF *rec_in, const EF *eq_in, EF *rec_out, EF *eq_out, uint64_t n_pairs, EF r, EF lambda,
+int gkr_fold_round(FracPlanes in, EFPlanes eq_in, FracPlanes out, EFPlanes eq_out, uint64_t n_pairs, EF r, EF lambda,
                    EF *d_partials, EF *d_out, hipStream_t s) {
     uint32_t grid = red_grid(n_pairs);
-    hipLaunchKernelGGL(gkr_fold_round_kernel, dim3(grid), dim3(RED_THREADS), 0, s, rec_in, eq_in, rec_out, eq_out,
-                       n_pairs, r, lambda, d_partials);
+    hipLaunchKernelGGL(gkr_fold_round_kernel, dim3(grid), dim3(RED_THREADS), 0, s, in, eq_in, out, eq_out, n_pairs, r,
+                       lambda, d_partials);
     OVM_CHECK_LAUNCH();
     return sum_partials(d_partials, grid, 3, d_out, s);
 }
 
-__global__ void gkr_fold_kernel(const EF *rec_in, const EF *eq_in, EF *rec_out, EF *eq_out, uint64_t n_out, EF r) {
-    uint64_t y = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (y >= n_out) return;
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-        EF a = ld_ef(rec_in + 8 * y + i), b = ld_ef(rec_in + 8 * y + 4 + i);
-        st_ef(rec_out + 4 * y + i, a + (b - a) * r);
-    }
-    EF e0 = ld_ef(eq_in + 2 * y), e1 = ld_ef(eq_in + 2 * y + 1);
-    st_ef(eq_out + y, e0 + (e1 - e0) * r);
+// Last fold of a layer: two records -> the layer's claims, written as out[0..4) = (p0, q0, p1, q1).
+__global__ void gkr_fold_final_kernel(FracPlanes in, EF r, EF *out) {
+    if (threadIdx.x != 0) return;
+    EF p[4], q[4];
+    ldp4(in.P(), in.stride, 0, p);
+    ldp4(in.Q(), in.stride, 0, q);
+    st_ef(out + 0, p[0] + (p[2] - p[0]) * r);
+    st_ef(out + 1, q[0] + (q[2] - q[0]) * r);
+    st_ef(out + 2, p[1] + (p[3] - p[1]) * r);
+    st_ef(out + 3, q[1] + (q[3] - q[1]) * r);
 }
-int gkr_fold(const EF *rec_in, const EF *eq_in, EF *rec_out, EF *eq_out, uint64_t n_out, EF r, hipStream_t s) {
-    hipLaunchKernelGGL(gkr_fold_kernel, dim3(ceil_div(n_out, 256)), dim3(256), 0, s, rec_in, eq_in, rec_out, eq_out,
-                       n_out, r);
+int gkr_fold_final(FracPlanes in, EF r, EF *out4, hipStream_t s) {
+    hipLaunchKernelGGL(gkr_fold_final_kernel, dim3(1), dim3(64), 0, s, in, r, out4);
     OVM_CHECK_LAUNCH();
     return 0;
 }
