@@ -80,6 +80,27 @@ BB_HD uint32_t mont_mul(uint32_t a, uint32_t b) {
     return umin32(r, r + P);
 }
 
+// Signed Montgomery product: a * b * 2^-32 mod P as a representative in (-P, P), for int32
+// |a| <= P, |b| < P. x = a*b = xh*2^32 + lo and t*P have equal low words, so xh - hi(t*P) is
+// exact; |xh| < 0.47 P and |hi(t*P)| <= P/2 bound the result without any correction step. Chains
+// of multiplies (the Poseidon2 S-box) run on these and canonicalise once at the end.
+BB_HD int32_t mulhi_i32(int32_t a, int32_t b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __mulhi(a, b);
+#else
+    return (int32_t)(((int64_t)a * b) >> 32);
+#endif
+}
+BB_HD int32_t smont_mul(int32_t a, int32_t b) {
+    uint32_t lo = (uint32_t)a * (uint32_t)b;
+    int32_t xh = mulhi_i32(a, b);
+    int32_t t = (int32_t)(lo * MONTY_M);
+    int32_t uh = mulhi_i32(t, (int32_t)P);
+    return xh - uh;
+}
+// representative in (-P, P) -> canonical word
+BB_HD uint32_t from_signed(int32_t r) { return umin32((uint32_t)r, (uint32_t)r + P); }
+
 struct Fp {
     uint32_t v;  // Montgomery word, < P
 
