@@ -35,12 +35,23 @@ struct DevProgram {
     const EF *weights;
 };
 
+// Destination of a reduction (stages.hip "last workgroup finishes"): per-workgroup partial
+// records, a self-resetting arrival counter, and a host-mapped mailbox (out + flag) that the host
+// spins on -- one launch per sumcheck round, no D2H copy, no stream synchronisation.
+struct RedOut {
+    EF *partials;       // device scratch, >= (number of workgroups) * K
+    uint32_t *counter;  // device, zero before the launch; the last workgroup resets it
+    EF *out;            // device-visible address of the K results (host-mapped)
+    uint32_t *flag;     // device-visible address of the completion flag (host-mapped), may be null
+    uint32_t seq;       // value stored to *flag once out[] is visible to the host
+};
+
 static constexpr unsigned MAX_COSETS = 4;
 static constexpr unsigned RED_BLOCKS = 2048;  // grid cap of the partial-sum kernels (8 workgroups per CU)
 static constexpr unsigned RED_THREADS = 256;
 
-// out[k] = sum_b partials[b * K + k]
-int sum_partials(const EF *partials, uint32_t n_blocks, uint32_t K, EF *out, hipStream_t s);
+// ro.out[k] = sum_b ro.partials[b * K + k], then the flag (for reductions with many outputs)
+int sum_partials(const RedOut &ro, uint32_t n_blocks, uint32_t K, hipStream_t s);
 
 int build_selectors(Fp *sels, uint32_t log_lifted, uint32_t log_height, hipStream_t s);
 int eq_table(const EF *d_point, uint32_t n, EF *out, hipStream_t s);  // out[y] = prod_i (y_i ? x_i : 1-x_i)
@@ -54,8 +65,7 @@ int coset_lde(const ColDesc *d_cols, const uint32_t *d_used, uint32_t n_used, ui
 
 // Round 0: out[((k * n_out) + o) * N + z] = sum_x eq_xi[x] * program_o(lde_k row (x<<l)+z) (+ add_const for o==1)
 int round0_eval(const DevProgram &prog, const Fp *lde, uint32_t n_cols_total, uint32_t log_lifted, uint32_t l_skip,
-                uint32_t n_cosets, uint32_t n_out, const EF *d_eq_xi, EF add_const, EF *d_partials, EF *d_out,
-                hipStream_t s);
+                uint32_t n_cosets, uint32_t n_out, const EF *d_eq_xi, EF add_const, const RedOut &ro, hipStream_t s);
 
 // out[col * (lifted >> l) + x] = sum_z w[z] * col(( x << l) + z)
 int fold_ple(const ColDesc *d_cols, uint32_t n_cols, uint32_t log_lifted, uint32_t l_skip, const EF *d_weights,
@@ -64,12 +74,12 @@ int fold_ple(const ColDesc *d_cols, uint32_t n_cols, uint32_t log_lifted, uint32
 // MLE round on folded EF matrices (n_cols x 2^log_h, column-major):
 //   out[(X-1) * n_out + o] = sum_y eq[y] * program_o(row interpolated at X from rows 2y, 2y+1)
 int mle_round_eval(const DevProgram &prog, const EF *mats, uint32_t n_cols, uint32_t log_h, uint32_t degree,
-                   uint32_t n_out, const EF *d_eq, EF add_const, EF *d_partials, EF *d_out, hipStream_t s);
+                   uint32_t n_out, const EF *d_eq, EF add_const, const RedOut &ro, hipStream_t s);
 
 // Same sums from a grouped program: grid = (y blocks, X = 1..degree, group); out[2*(X-1)+o].
 int mle_round_eval_grouped(const Instr *d_code, const uint32_t *d_off, uint32_t n_groups, uint32_t max_slots,
                            const EF *d_weights, const EF *mats, uint32_t log_h, uint32_t degree, uint32_t n_out,
-                           const EF *d_eq, EF add_const, EF *d_partials, EF *d_out, hipStream_t s);
+                           const EF *d_eq, EF add_const, const RedOut &ro, hipStream_t s);
 
 // out[c * h/2 + y] = in[c*h + 2y] + r * (in[c*h + 2y + 1] - in[c*h + 2y])
 int fold_mle(const EF *in, EF *out, uint32_t n_cols, uint32_t log_h, EF r, hipStream_t s);
@@ -82,34 +92,34 @@ int gkr_eval_leaves(const DevProgram &prog, const EF *d_leaf_const, const ColDes
                     hipStream_t s);
 int gkr_build_layer(FracPlanes child, FracPlanes parent, uint64_t n_parent, hipStream_t s);
 // out[2i], out[2i+1] = (p, q) of fractions first .. first+n (n <= 64), AoS, for the host
-int gkr_read_fracs(FracPlanes t, uint64_t first, uint32_t n, EF *out, hipStream_t s);
-int gkr_round(FracPlanes rec, EFPlanes eq, uint64_t n_pairs, EF lambda, EF *d_partials, EF *d_out, hipStream_t s);
+int gkr_read_fracs(FracPlanes t, uint64_t first, uint32_t n, const RedOut &ro, hipStream_t s);
+int gkr_round(FracPlanes rec, EFPlanes eq, uint64_t n_pairs, EF lambda, const RedOut &ro, hipStream_t s);
 // fold the previous round with r and return the NEXT round's sums over the n_pairs folded pairs
 int gkr_fold_round(FracPlanes in, EFPlanes eq_in, FracPlanes out, EFPlanes eq_out, uint64_t n_pairs, EF r, EF lambda,
-                   EF *d_partials, EF *d_out, hipStream_t s);
+                   const RedOut &ro, hipStream_t s);
 // two records -> out4 = (p0, q0, p1, q1) folded at r (AoS, for the host)
-int gkr_fold_final(FracPlanes in, EF r, EF *out4, hipStream_t s);
+int gkr_fold_final(FracPlanes in, EF r, const RedOut &ro, hipStream_t s);
 
 // ---- stacked reduction ----
 // R[v * N + z] for v in {eq, rot1, rot2} over one window of `n_slices` contiguous slices of
 // 2^log_len rows each starting at `base`.
 int stacked_round0(const Fp *base, uint32_t n_slices, uint32_t log_len, uint32_t l_skip, const EF *d_lam_eq,
-                   const EF *d_lam_rot, const EF *d_eq_cube, EF *d_partials, EF *d_out, hipStream_t s);
+                   const EF *d_lam_rot, const EF *d_eq_cube, const RedOut &ro, hipStream_t s);
 // Q[v][x] = sum_i coef_v[i] * q[(col_i * h + row_i + x)] for v in {eq, rot}
 int stacked_combine(const EF *q, const uint64_t *d_slice_off, uint32_t n_slices, uint32_t log_len,
                     const EF *d_coef_eq, const EF *d_coef_rot, EF *out_eq, EF *out_rot, hipStream_t s);
 // s[X-1] = sum_y Qeq(X,y) eq(X,y) + Qrot(X,y) krot(X,y), X = 1,2 ; vec = 4 columns of 2^log_h
-int stacked_round(const EF *vec4, uint32_t log_h, EF *d_partials, EF *d_out, hipStream_t s);
+int stacked_round(const EF *vec4, uint32_t log_h, const RedOut &ro, hipStream_t s);
 
 // ---- WHIR ----
 int whir_mu_batch(const Fp *msg, uint32_t width, uint32_t log_h, const EF *d_mu_pows, uint32_t mu_offset,
                   EF *f, int accumulate, hipStream_t s);
 // in-place subset-zeta (dir=+1: coeffs->evals) or Moebius (dir=-1: evals->coeffs) over all bits
 int zeta_transform(EF *v, uint32_t log_n, int dir, hipStream_t s);
-int whir_round(const EF *f, const EF *w, uint64_t n_pairs, EF *d_partials, EF *d_out, hipStream_t s);
+int whir_round(const EF *f, const EF *w, uint64_t n_pairs, const RedOut &ro, hipStream_t s);
 int whir_fold(const EF *f_in, const EF *w_in, EF *f_out, EF *w_out, uint64_t n_out, EF alpha, hipStream_t s);
 // out = sum_i coeffs[i] * z^i
-int horner_eval(const EF *coeffs, uint64_t n, EF z, EF *d_partials, EF *d_out, hipStream_t s);
+int horner_eval(const EF *coeffs, uint64_t n, EF z, const RedOut &ro, hipStream_t s);
 // w[x] += sum_q gamma_q * eq(x, pow(z_q)) using split tables lo/hi (n_q x 2^half each)
 int whir_w_accumulate(EF *w, uint32_t log_n, const EF *d_tab_lo, const EF *d_tab_hi, uint32_t log_lo,
                       uint32_t n_q, hipStream_t s);

@@ -10,8 +10,10 @@
 // handful of extension-field elements) is this backend's design.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <chrono>
 #include <cstdlib>
+#include <cstring>
 
 #include "kernels.h"
 
@@ -124,6 +126,67 @@ struct PinnedStage {
 inline PinnedStage &pinned_stage() {
     static thread_local PinnedStage st;
     return st;
+}
+
+// Host mailbox of the reduction kernels: a host-mapped, coherent page the last workgroup of a
+// reduction writes its results and a sequence flag into; the host spins on the flag instead of
+// issuing a D2H copy and a stream synchronisation per sumcheck round.
+struct Mailbox {
+    static constexpr size_t SLOTS = 4096;  // extension-field results per reduction
+    struct Page {
+        uint32_t flag;
+        uint32_t pad[3];
+        EF data[SLOTS];
+    };
+    Page *h = nullptr, *d = nullptr;
+    uint32_t *d_counter = nullptr;
+    uint32_t seq = 0;
+    void init() {
+        if (h) return;
+        void *hp = nullptr, *dp = nullptr;
+        OVM_THROW_IF(hipHostMalloc(&hp, sizeof(Page), hipHostMallocMapped | hipHostMallocCoherent));
+        OVM_THROW_IF(hipHostGetDevicePointer(&dp, hp, 0));
+        memset(hp, 0, sizeof(Page));
+        h = (Page *)hp;
+        d = (Page *)dp;
+        OVM_THROW_IF(hipMalloc((void **)&d_counter, 64));
+    }
+    // call once per prove, before the first reduction (a failed launch may have left the counter dirty)
+    void reset(hipStream_t s) {
+        init();
+        OVM_THROW_IF(hipMemsetAsync(d_counter, 0, 64, s));
+    }
+    RedOut arm(EF *partials) {
+        ++seq;
+        return RedOut{partials, d_counter, d->data, &d->flag, seq};
+    }
+    // Wait for the reduction armed last and copy out its first n results.
+    std::vector<EF> take(size_t n, hipStream_t s) {
+        if (n > SLOTS) throw OvmFail((int)hipErrorInvalidValue, "mailbox: too many results");
+        volatile uint32_t *flag = &h->flag;
+        uint64_t spins = 0;
+        auto t0 = std::chrono::steady_clock::now();
+        while (*flag != seq) {
+            if ((++spins & 0xFFFF) == 0) {
+                // a faulted kernel never raises the flag: look at the stream from time to time
+                hipError_t q = hipStreamQuery(s);
+                if (q != hipSuccess && q != hipErrorNotReady) throw OvmFail((int)q, "reduction kernel failed");
+                if (q == hipSuccess && *flag != seq &&
+                    std::chrono::steady_clock::now() - t0 > std::chrono::seconds(30))
+                    throw OvmFail((int)hipErrorUnknown, "mailbox: stream idle but no result arrived");
+            }
+        }
+        std::atomic_thread_fence(std::memory_order_acquire);
+        std::vector<EF> v(n);
+        memcpy((void *)v.data(), (const void *)h->data, n * sizeof(EF));
+        return v;
+    }
+};
+inline Mailbox &mailbox() {
+    static thread_local Mailbox boxes[16];
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    return boxes[dev & 15];
 }
 
 struct Ctx {
@@ -241,13 +304,15 @@ struct Prover {
     WallTrace wt;
     const ProvingKey &pk;
     Ctx cx;
+    Mailbox &mb;
     Transcript ts;
     std::vector<TraceIn> traces;  // sorted
     ByteWriter out;
     std::vector<size_t> section_offsets;
 
-    Prover(const ProvingKey &pk_, hipStream_t s) : pk(pk_), cx{s} {
+    Prover(const ProvingKey &pk_, hipStream_t s) : pk(pk_), cx{s}, mb(mailbox()) {
         ts.stream = s;
+        mb.reset(s);
     }
 
     const Params &P() const { return pk.params; }
@@ -450,9 +515,8 @@ struct Prover {
             wt.mark("rap.gkr.build");
             OVM_PROF("gkr.layer_sumchecks", cx.stream);
             {
-                DevBuf<EF> d_top(6);
-                OVM_THROW_IF(gkr_read_fracs(tree, 1, 3, d_top.p, cx.stream));
-                auto top = cx.download(d_top.p, 6);  // (p, q) of nodes 1, 2, 3
+                OVM_THROW_IF(gkr_read_fracs(tree, 1, 3, mb.arm(nullptr), cx.stream));
+                auto top = mb.take(6, cx.stream);  // (p, q) of nodes 1, 2, 3
                 if (!is_zero(top[0])) throw OvmFail(1, "LogUp: non-zero root sum (interactions do not balance)");
                 q0_claim = top[1];
                 ts.observe_ext(q0_claim);
@@ -472,7 +536,7 @@ struct Prover {
                 DevBuf<uint32_t> rec_a(8 * wcap), rec_b(8 * wcap), eq_a(4 * wcap), eq_b(4 * wcap);
                 const FracPlanes recs[2] = {{rec_a.p, wcap}, {rec_b.p, wcap}};
                 const EFPlanes eqs[2] = {{eq_a.p, wcap}, {eq_b.p, wcap}};
-                DevBuf<EF> partials(RED_BLOCKS * 4), d_out(4), d_point(TR);
+                DevBuf<EF> partials(RED_BLOCKS * 4), d_point(TR);
                 for (unsigned round = 1; round < TR; round++) {
                     EF lambda = ts.sample_ext();
                     OVM_THROW_IF(hipMemcpyAsync(d_point.p, xi_prev.data(), round * sizeof(EF), hipMemcpyHostToDevice, cx.stream));
@@ -485,23 +549,23 @@ struct Prover {
                     for (unsigned sr = 0; sr < round; sr++) {
                         uint64_t n_pairs = 1ull << (round - sr - 1);
                         if (sr == 0) {
-                            OVM_THROW_IF(gkr_round(rec, eq, n_pairs, lambda, partials.p, d_out.p, cx.stream));
+                            OVM_THROW_IF(gkr_round(rec, eq, n_pairs, lambda, mb.arm(partials.p), cx.stream));
                         } else {
                             // fold sub-round sr-1 with r_prev and get this sub-round's sums in one pass
                             OVM_THROW_IF(gkr_fold_round(rec, eq, recs[sr & 1], eqs[sr & 1], n_pairs, r_prev, lambda,
-                                                        partials.p, d_out.p, cx.stream));
+                                                        mb.arm(partials.p), cx.stream));
                             rec = recs[sr & 1];
                             eq = eqs[sr & 1];
                         }
-                        auto sv = cx.download(d_out.p, 3);
+                        auto sv = mb.take(3, cx.stream);
                         for (auto &e : sv) ts.observe_ext(e);
                         polys.push_back({sv[0], sv[1], sv[2]});
                         r_prev = ts.sample_ext();
                         rho.push_back(r_prev);
                     }
                     // last fold: one record (the layer claims)
-                    OVM_THROW_IF(gkr_fold_final(rec, r_prev, d_out.p, cx.stream));
-                    auto fin = cx.download(d_out.p, 4);
+                    OVM_THROW_IF(gkr_fold_final(rec, r_prev, mb.arm(nullptr), cx.stream));
+                    auto fin = mb.take(4, cx.stream);
                     claims.push_back({fin[0], fin[2], fin[1], fin[3]});
                     observe_claims(claims.back());
                     EF mu = ts.sample_ext();
@@ -556,7 +620,7 @@ struct Prover {
         };
         std::vector<TraceProgs> tp(T);
         std::vector<std::vector<EF>> sp0(3 * T);
-        DevBuf<EF> partials((size_t)RED_BLOCKS * MAX_COSETS * 2 * N + 64), d_out(MAX_COSETS * 2 * N + 64);
+        DevBuf<EF> partials((size_t)RED_BLOCKS * MAX_COSETS * 2 * N + 64);
         for (size_t t = 0; t < T; t++) {
             const AirKey &a = air(t);
             TraceView &v = tv[t];
@@ -636,8 +700,8 @@ struct Prover {
                 if (zc_cosets) {
                     OVM_PROF("round0.zerocheck", cx.stream);
                     OVM_THROW_IF(round0_eval(tp[t].zc->dev(), lde.p, (uint32_t)v.cm.total, v.log_lifted, l_skip, zc_cosets, 1,
-                                             d_eq.p, EF::zero(), partials.p, d_out.p, cx.stream));
-                    auto ev = cx.download(d_out.p, (size_t)zc_cosets * N);
+                                             d_eq.p, EF::zero(), mb.arm(partials.p), cx.stream));
+                    auto ev = mb.take((size_t)zc_cosets * N, cx.stream);
                     std::vector<std::vector<EF>> ce(zc_cosets, std::vector<EF>(N));
                     for (unsigned k = 0; k < zc_cosets; k++) {
                         Fp zinv = (g.pow(k + 1).exp_power_of_2(l_skip) - Fp::one()).inv();
@@ -656,8 +720,8 @@ struct Prover {
                 if (lg_cosets) {
                     OVM_PROF("round0.logup", cx.stream);
                     OVM_THROW_IF(round0_eval(tp[t].lg->dev(), lde.p, (uint32_t)v.cm.total, v.log_lifted, l_skip, lg_cosets, 2,
-                                             d_eq.p, tp[t].lg_const, partials.p, d_out.p, cx.stream));
-                    auto ev = cx.download(d_out.p, (size_t)lg_cosets * 2 * N);
+                                             d_eq.p, tp[t].lg_const, mb.arm(partials.p), cx.stream));
+                    auto ev = mb.take((size_t)lg_cosets * 2 * N, cx.stream);
                     std::vector<std::vector<EF>> cn(lg_cosets, std::vector<EF>(N)), cden(lg_cosets, std::vector<EF>(N));
                     for (unsigned k = 0; k < lg_cosets; k++)
                         for (size_t z = 0; z < N; z++) {
@@ -815,9 +879,9 @@ struct Prover {
                         const GroupedDev &gd = *tp[t].zc_g;
                         OVM_THROW_IF(mle_round_eval_grouped(gd.code.p, gd.off.p, (uint32_t)gd.gp.off.size() - 1, gd.gp.max_slots,
                                                             tp[t].zc->weights.p, mats, v.cur_log_h, cdeg_global, 1, d_eqr.p,
-                                                            EF::zero(), mle_partials.p, d_out.p, cx.stream));
+                                                            EF::zero(), mb.arm(mle_partials.p), cx.stream));
                     }
-                    auto ev = cx.download(d_out.p, 8);
+                    auto ev = mb.take(8, cx.stream);
                     sp[2 * T + t].resize(cdeg_global);
                     for (unsigned i = 0; i < cdeg_global; i++) sp[2 * T + t][i] = ev[2 * i];
                     if (has_int) {
@@ -825,10 +889,10 @@ struct Prover {
                             const GroupedDev &gd = *tp[t].lg_g;
                             OVM_THROW_IF(mle_round_eval_grouped(gd.code.p, gd.off.p, (uint32_t)gd.gp.off.size() - 1,
                                                                 gd.gp.max_slots, tp[t].lg->weights.p, mats, v.cur_log_h,
-                                                                cdeg_global, 2, d_eqr.p, tp[t].lg_const, mle_partials.p,
-                                                                d_out.p, cx.stream));
+                                                                cdeg_global, 2, d_eqr.p, tp[t].lg_const,
+                                                                mb.arm(mle_partials.p), cx.stream));
                         }
-                        auto e2 = cx.download(d_out.p, 8);
+                        auto e2 = mb.take(8, cx.stream);
                         sp[2 * t].resize(cdeg_global);
                         sp[2 * t + 1].resize(cdeg_global);
                         for (unsigned i = 0; i < cdeg_global; i++) {
@@ -981,7 +1045,7 @@ struct Prover {
             EF eq_fin = EF::zero(), krot_fin = EF::zero();
         };
         std::vector<Window> ws(W);
-        DevBuf<EF> partials((size_t)RED_BLOCKS * 3 * N + 64), d_out(3 * N + 64);
+        DevBuf<EF> partials((size_t)RED_BLOCKS * 3 * N + 64);
         const unsigned s0_deg = 2 * (unsigned)(N - 1);
         std::vector<EF> s0(s0_deg + 1, EF::zero());
         ProfScope *ps_st0 = new ProfScope("stacked.round0", cx.stream);
@@ -1007,8 +1071,8 @@ struct Prover {
             unsigned log_len = std::max(wd.log_height, l_skip);
             const Fp *base = pcs.stacked.p + tvs[w0].s.col_idx * H + tvs[w0].s.row_idx;
             OVM_THROW_IF(stacked_round0(base, (uint32_t)(w1 - w0), log_len, l_skip, d_leq.p, d_lrot.p, wd.eq_cube.p,
-                                        partials.p, d_out.p, cx.stream));
-            auto R = cx.download(d_out.p, 3 * N);
+                                        mb.arm(partials.p), cx.stream));
+            auto R = mb.take(3 * N, cx.stream);
             // host: chunk-aggregated vectors -> coset evaluations with the univariate factors
             std::vector<std::vector<EF>> coef(3);
             for (int v = 0; v < 3; v++) coef[v] = small_dft(std::vector<EF>(R.begin() + v * N, R.begin() + (v + 1) * N), true);
@@ -1132,8 +1196,8 @@ struct Prover {
                 Window &wd = ws[wi];
                 if (round <= wd.n_lift) {
                     const EF *vec = wd.in_a ? wd.vec_a.p : wd.vec_b.p;
-                    OVM_THROW_IF(stacked_round(vec, wd.cur_log_h, partials.p, d_out.p, cx.stream));
-                    auto sv = cx.download(d_out.p, 2);
+                    OVM_THROW_IF(stacked_round(vec, wd.cur_log_h, mb.arm(partials.p), cx.stream));
+                    auto sv = mb.take(2, cx.stream);
                     batch[0] += sv[0];
                     batch[1] += sv[1];
                 } else {
@@ -1237,15 +1301,15 @@ struct Prover {
         std::vector<std::vector<std::vector<p2::Digest>>> cw_proofs;
         unsigned log_rs = m + log_blowup;
         PcsData g_prev;  // previous round's codeword tree (EF, width 1)
-        DevBuf<EF> d_red((size_t)RED_BLOCKS * 2 + 8), d_red_out(8);
+        DevBuf<EF> d_red((size_t)RED_BLOCKS * 2 + 8);
         for (size_t wr = 0; wr < n_rounds; wr++) {
             const bool is_last = wr + 1 == n_rounds;
             ProfScope *ps_ws = new ProfScope("whir.sumcheck_fold", cx.stream);
             for (unsigned rd = 0; rd < k_whir; rd++) {
                 const EF *f = fw_in_a ? f_a.p : f_b.p, *wv = fw_in_a ? w_a.p : w_b.p;
                 uint64_t half = 1ull << (m - rd - 1);
-                OVM_THROW_IF(whir_round(f, wv, half, d_red.p, d_red_out.p, cx.stream));
-                auto sv = cx.download(d_red_out.p, 2);
+                OVM_THROW_IF(whir_round(f, wv, half, mb.arm(d_red.p), cx.stream));
+                auto sv = mb.take(2, cx.stream);
                 ts.observe_ext(sv[0]);
                 ts.observe_ext(sv[1]);
                 whir_polys.push_back({sv[0], sv[1]});
@@ -1275,8 +1339,8 @@ struct Prover {
                 ts.observe_digest(g_tree.root);
                 codeword_commits.push_back(g_tree.root);
                 z0 = ts.sample_ext();
-                OVM_THROW_IF(horner_eval(g_coeffs.p, 1ull << m_new, z0, d_red.p, d_red_out.p, cx.stream));
-                EF opened = cx.download(d_red_out.p, 1)[0];
+                OVM_THROW_IF(horner_eval(g_coeffs.p, 1ull << m_new, z0, mb.arm(d_red.p), cx.stream));
+                EF opened = mb.take(1, cx.stream)[0];
                 ts.observe_ext(opened);
                 ood_values.push_back(opened);
             } else {

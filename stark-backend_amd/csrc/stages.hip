@@ -40,9 +40,11 @@ __device__ __forceinline__ EF wave_sum(EF v) {
     return v;
 }
 
-// Sum K values per lane over the workgroup; lane 0 stores them at out[0..K).
-template <int K>
-__device__ void block_sum_store(EF (&v)[K], EF *out) {
+// Sum K values per lane over the workgroup; lanes 0..K-1 store them at out[0..K). With SYS the
+// stores are followed by a system-scope fence (out is a host mailbox), otherwise by a device-scope
+// one (out is a partials record another workgroup will read).
+template <int K, bool SYS = false>
+__device__ void block_sum_store(EF (&v)[K], EF *out, bool fence = true) {
     __shared__ EF sh[(RED_THREADS / 64) * K];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
@@ -55,20 +57,88 @@ __device__ void block_sum_store(EF (&v)[K], EF *out) {
         EF s = sh[threadIdx.x];
         for (int w = 1; w < (int)(blockDim.x >> 6); w++) s = s + sh[w * K + threadIdx.x];
         st_ef(out + threadIdx.x, s);
+        if (SYS)
+            __threadfence_system();
+        else if (fence)
+            __threadfence();
     }
     __syncthreads();
 }
 
-__global__ void sum_partials_kernel(const EF *partials, uint32_t n_blocks, uint32_t K, EF *out) {
-    const uint32_t k = blockIdx.x;
-    EF acc[1] = {EF::zero()};
-    for (uint32_t b = threadIdx.x; b < n_blocks; b += blockDim.x) acc[0] = acc[0] + ld_ef(partials + (size_t)b * K + k);
-    block_sum_store<1>(acc, out + k);
+// Make everything this thread stored visible to the host, then raise the mailbox flag.
+__device__ __forceinline__ void publish(const RedOut &ro) {
+    if (ro.flag) {
+        __threadfence_system();
+        *(volatile uint32_t *)ro.flag = ro.seq;
+    }
 }
 
-int sum_partials(const EF *partials, uint32_t n_blocks, uint32_t K, EF *out, hipStream_t s) {
-    hipLaunchKernelGGL(sum_partials_kernel, dim3(K), dim3(RED_THREADS), 0, s, partials, n_blocks, K, out);
+// Tail of every reduction kernel ("last workgroup finishes"): each workgroup has stored its
+// partial records ro.partials[b * K + k] through block_sum_store; the workgroup that arrives last
+// at the counter sums the n_records records, writes the K totals to ro.out (a host-mapped mailbox)
+// and raises the flag the host is spinning on. No second launch, no device-to-host copy, no
+// stream synchronisation per sumcheck round. Field addition is exact and commutative, so the
+// arrival order does not change the result.
+template <int KMAX>
+__device__ void finish_reduction(const RedOut &ro, uint32_t n_records, uint32_t K) {
+    if (ro.counter == nullptr) return;  // large grid: sum_partials finishes (see red_finish)
+    __shared__ uint32_t s_last;
+    if (threadIdx.x == 0) {
+        const uint32_t total = gridDim.x * gridDim.y * gridDim.z;
+        s_last = total == 1 || atomicAdd(ro.counter, 1u) == total - 1;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();
+    EF acc[KMAX];
+#pragma unroll
+    for (int k = 0; k < KMAX; k++) acc[k] = EF::zero();
+    for (uint32_t b = threadIdx.x; b < n_records; b += RED_THREADS) {
+#pragma unroll
+        for (int k = 0; k < KMAX; k++)
+            if ((uint32_t)k < K) acc[k] = acc[k] + ld_ef(ro.partials + (size_t)b * K + k);
+    }
+    block_sum_store<KMAX, true>(acc, ro.out);  // KMAX totals (entries >= K are zero)
+    if (threadIdx.x == 0) {
+        *ro.counter = 0;
+        publish(ro);
+    }
+}
+
+// Large-K variant as its own launch: block k sums entry k of every record; the last block raises
+// the flag.
+__global__ void sum_partials_kernel(RedOut ro, uint32_t n_blocks, uint32_t K) {
+    const uint32_t k = blockIdx.x;
+    EF acc[1] = {EF::zero()};
+    for (uint32_t b = threadIdx.x; b < n_blocks; b += blockDim.x) acc[0] = acc[0] + ld_ef(ro.partials + (size_t)b * K + k);
+    block_sum_store<1, true>(acc, ro.out + k);
+    __shared__ uint32_t s_last;
+    if (threadIdx.x == 0) s_last = atomicAdd(ro.counter, 1u) == gridDim.x - 1;
+    __syncthreads();
+    if (s_last && threadIdx.x == 0) {
+        *ro.counter = 0;
+        publish(ro);
+    }
+}
+
+int sum_partials(const RedOut &ro, uint32_t n_blocks, uint32_t K, hipStream_t s) {
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(K), dim3(RED_THREADS), 0, s, ro, n_blocks, K);
     OVM_CHECK_LAUNCH();
+    return 0;
+}
+
+// Every agent-scope release on gfx950 writes the XCD's L2 back; with thousands of workgroups doing
+// it the tail costs ~50 ns per workgroup (measured: +100 us on a 2048-workgroup launch). So the
+// in-kernel finish is used for grids of at most FINISH_INLINE_MAX workgroups -- the latency-bound
+// rounds, which are most of them -- and larger grids take one extra sum_partials launch.
+static constexpr uint32_t FINISH_INLINE_MAX = 64;
+static inline RedOut red_inline(const RedOut &ro, uint32_t total_blocks) {
+    RedOut r = ro;
+    if (total_blocks > FINISH_INLINE_MAX) r.counter = nullptr;
+    return r;
+}
+static inline int red_finish(const RedOut &ro, uint32_t total_blocks, uint32_t n_records, uint32_t K, hipStream_t s) {
+    if (total_blocks > FINISH_INLINE_MAX) return sum_partials(ro, n_records, K, s);
     return 0;
 }
 
@@ -301,18 +371,18 @@ __global__ __launch_bounds__(RED_THREADS) void round0_eval_kernel(DevProgram pro
     } while (0)
 
 int round0_eval(const DevProgram &prog, const Fp *lde, uint32_t n_cols_total, uint32_t log_lifted, uint32_t l_skip,
-                uint32_t n_cosets, uint32_t n_out, const EF *d_eq_xi, EF add_const, EF *d_partials, EF *d_out,
+                uint32_t n_cosets, uint32_t n_out, const EF *d_eq_xi, EF add_const, const RedOut &ro,
                 hipStream_t s) {
     if (n_cosets == 0) return 0;
     if (n_cosets > MAX_COSETS || n_out > 2 || (1u << l_skip) > RED_THREADS) return (int)hipErrorInvalidValue;
     uint32_t grid = red_grid(1ull << log_lifted);
 #define CALL(NS)                                                                                              \
     hipLaunchKernelGGL(round0_eval_kernel<NS>, dim3(grid), dim3(RED_THREADS), 0, s, prog, lde, n_cols_total, \
-                       log_lifted, l_skip, n_cosets, n_out, d_eq_xi, add_const, d_partials)
+                       log_lifted, l_skip, n_cosets, n_out, d_eq_xi, add_const, ro.partials)
     DISPATCH_SLOTS(prog.num_slots, CALL);
 #undef CALL
     OVM_CHECK_LAUNCH();
-    return sum_partials(d_partials, grid, n_cosets * n_out << l_skip, d_out, s);
+    return sum_partials(ro, grid, n_cosets * n_out << l_skip, s);
 }
 
 // ---- fold_ple: evaluate each chunk's interpolant at r via barycentric weights ---------------
@@ -356,7 +426,7 @@ struct MleFetch {
 template <int NS>
 __global__ __launch_bounds__(RED_THREADS) void mle_round_kernel(DevProgram prog, const EF *mats, uint32_t log_h,
                                                                 uint32_t degree, uint32_t n_out, const EF *eq,
-                                                                EF add_const, EF *partials) {
+                                                                EF add_const, RedOut ro) {
     const uint64_t n_y = 1ull << (log_h - 1);
     const uint64_t stride = (uint64_t)gridDim.x * RED_THREADS;
     EF sums[8];
@@ -373,27 +443,28 @@ __global__ __launch_bounds__(RED_THREADS) void mle_round_kernel(DevProgram prog,
             if (n_out > 1) sums[2 * (xi - 1) + 1] = sums[2 * (xi - 1) + 1] + e * out[1];
         }
     }
-    block_sum_store<8>(sums, partials + (size_t)blockIdx.x * 8);
+    block_sum_store<8>(sums, ro.partials + (size_t)blockIdx.x * 8, ro.counter != nullptr);
+    finish_reduction<8>(ro, gridDim.x, 8);
 }
 
 int mle_round_eval(const DevProgram &prog, const EF *mats, uint32_t n_cols, uint32_t log_h, uint32_t degree,
-                   uint32_t n_out, const EF *d_eq, EF add_const, EF *d_partials, EF *d_out, hipStream_t s) {
+                   uint32_t n_out, const EF *d_eq, EF add_const, const RedOut &ro, hipStream_t s) {
     if (degree > 4 || n_out > 2 || log_h == 0) return (int)hipErrorInvalidValue;
     uint32_t grid = red_grid(1ull << (log_h - 1));
 #define CALL(NS)                                                                                          \
     hipLaunchKernelGGL(mle_round_kernel<NS>, dim3(grid), dim3(RED_THREADS), 0, s, prog, mats, log_h, degree, \
-                       n_out, d_eq, add_const, d_partials)
+                       n_out, d_eq, add_const, red_inline(ro, grid))
     DISPATCH_SLOTS(prog.num_slots, CALL);
 #undef CALL
     OVM_CHECK_LAUNCH();
-    return sum_partials(d_partials, grid, 8, d_out, s);  // out[2*(X-1)+o]
+    return red_finish(ro, grid, grid, 8, s);  // out[2*(X-1)+o]
 }
 
 template <int NS>
 __global__ __launch_bounds__(RED_THREADS) void mle_round_grouped_kernel(const Instr *code, const uint32_t *off,
                                                                         const EF *weights, const EF *mats,
                                                                         uint32_t log_h, uint32_t n_out, const EF *eq,
-                                                                        EF add_const, EF *partials) {
+                                                                        EF add_const, RedOut ro) {
     const uint64_t n_y = 1ull << (log_h - 1);
     const uint64_t stride = (uint64_t)gridDim.x * RED_THREADS;
     const uint32_t xi = blockIdx.y + 1, grp = blockIdx.z, K = 2 * gridDim.y;
@@ -409,12 +480,13 @@ __global__ __launch_bounds__(RED_THREADS) void mle_round_grouped_kernel(const In
         sums[0] = sums[0] + e * out[0];
         if (n_out > 1) sums[1] = sums[1] + e * out[1];
     }
-    block_sum_store<2>(sums, partials + ((size_t)(blockIdx.x * gridDim.z + grp)) * K + 2 * blockIdx.y);
+    block_sum_store<2>(sums, ro.partials + ((size_t)(blockIdx.x * gridDim.z + grp)) * K + 2 * blockIdx.y, ro.counter != nullptr);
+    finish_reduction<8>(ro, gridDim.x * gridDim.z, K);
 }
 
 int mle_round_eval_grouped(const Instr *d_code, const uint32_t *d_off, uint32_t n_groups, uint32_t max_slots,
                            const EF *d_weights, const EF *mats, uint32_t log_h, uint32_t degree, uint32_t n_out,
-                           const EF *d_eq, EF add_const, EF *d_partials, EF *d_out, hipStream_t s) {
+                           const EF *d_eq, EF add_const, const RedOut &ro, hipStream_t s) {
     if (degree == 0 || degree > 4 || n_out > 2 || log_h == 0 || n_groups == 0) return (int)hipErrorInvalidValue;
     uint32_t gx = red_grid(1ull << (log_h - 1));
     // keep the total grid near RED_BLOCKS workgroups
@@ -424,11 +496,12 @@ int mle_round_eval_grouped(const Instr *d_code, const uint32_t *d_off, uint32_t 
     dim3 grid(gx, degree, n_groups);
 #define CALL(NS)                                                                                               \
     hipLaunchKernelGGL(mle_round_grouped_kernel<NS>, grid, dim3(RED_THREADS), 0, s, d_code, d_off, d_weights, mats, \
-                       log_h, n_out, d_eq, add_const, d_partials)
+                       log_h, n_out, d_eq, add_const, red_inline(ro, gx * degree * n_groups))
     DISPATCH_SLOTS(max_slots, CALL);
 #undef CALL
     OVM_CHECK_LAUNCH();
-    return sum_partials(d_partials, gx * n_groups, 2 * degree, d_out, s);
+    // only out[0 .. 2 * degree) is defined
+    return red_finish(ro, gx * degree * n_groups, gx * n_groups, 2 * degree, s);
 }
 
 __global__ void fold_mle_kernel(const EF *in, EF *out, uint32_t log_h, EF r) {
@@ -574,14 +647,18 @@ int gkr_build_layer(FracPlanes child, FracPlanes parent, uint64_t n_parent, hipS
     return 0;
 }
 
-__global__ void gkr_read_kernel(FracPlanes t, uint64_t first, uint32_t n, EF *out) {
+__global__ void gkr_read_kernel(FracPlanes t, uint64_t first, uint32_t n, RedOut ro) {
     uint32_t i = threadIdx.x;
-    if (i >= n) return;
-    st_ef(out + 2 * i, ldp(t.P(), t.stride, first + i));
-    st_ef(out + 2 * i + 1, ldp(t.Q(), t.stride, first + i));
+    if (i < n) {
+        st_ef(ro.out + 2 * i, ldp(t.P(), t.stride, first + i));
+        st_ef(ro.out + 2 * i + 1, ldp(t.Q(), t.stride, first + i));
+        __threadfence_system();
+    }
+    __syncthreads();
+    if (i == 0) publish(ro);
 }
-int gkr_read_fracs(FracPlanes t, uint64_t first, uint32_t n, EF *out, hipStream_t s) {
-    hipLaunchKernelGGL(gkr_read_kernel, dim3(1), dim3(64), 0, s, t, first, n, out);
+int gkr_read_fracs(FracPlanes t, uint64_t first, uint32_t n, const RedOut &ro, hipStream_t s) {
+    hipLaunchKernelGGL(gkr_read_kernel, dim3(1), dim3(64), 0, s, t, first, n, ro);
     OVM_CHECK_LAUNCH();
     return 0;
 }
@@ -607,7 +684,7 @@ __device__ __forceinline__ void gkr_pair_sums(EF (&a)[4], const EF (&b)[4], EF e
 }
 
 __global__ __launch_bounds__(RED_THREADS) void gkr_round_kernel(FracPlanes rec, EFPlanes eq, uint64_t n_pairs,
-                                                                EF lambda, EF *partials) {
+                                                                EF lambda, RedOut ro) {
     const uint64_t stride = (uint64_t)gridDim.x * RED_THREADS;
     EF sums[3] = {EF::zero(), EF::zero(), EF::zero()};
     for (uint64_t y = (uint64_t)blockIdx.x * RED_THREADS + threadIdx.x; y < n_pairs; y += stride) {
@@ -620,13 +697,15 @@ __global__ __launch_bounds__(RED_THREADS) void gkr_round_kernel(FracPlanes rec, 
         const EF b[4] = {p[2], q[2], p[3], q[3]};
         gkr_pair_sums(a, b, e0, e1, lambda, sums);
     }
-    block_sum_store<3>(sums, partials + (size_t)blockIdx.x * 3);
+    block_sum_store<3>(sums, ro.partials + (size_t)blockIdx.x * 3, ro.counter != nullptr);
+    finish_reduction<3>(ro, gridDim.x, 3);
 }
-int gkr_round(FracPlanes rec, EFPlanes eq, uint64_t n_pairs, EF lambda, EF *d_partials, EF *d_out, hipStream_t s) {
+int gkr_round(FracPlanes rec, EFPlanes eq, uint64_t n_pairs, EF lambda, const RedOut &ro, hipStream_t s) {
     uint32_t grid = red_grid(n_pairs);
-    hipLaunchKernelGGL(gkr_round_kernel, dim3(grid), dim3(RED_THREADS), 0, s, rec, eq, n_pairs, lambda, d_partials);
+    hipLaunchKernelGGL(gkr_round_kernel, dim3(grid), dim3(RED_THREADS), 0, s, rec, eq, n_pairs, lambda,
+                       red_inline(ro, grid));
     OVM_CHECK_LAUNCH();
-    return sum_partials(d_partials, grid, 3, d_out, s);
+    return red_finish(ro, grid, grid, 3, s);
 }
 
 // Fused "fold with r, then next round's sums": output pair y is built from input records
@@ -635,7 +714,7 @@ int gkr_round(FracPlanes rec, EFPlanes eq, uint64_t n_pairs, EF lambda, EF *d_pa
 // sub-round after the first is ONE pass over the data.
 __global__ __launch_bounds__(RED_THREADS) void gkr_fold_round_kernel(FracPlanes in, EFPlanes eq_in, FracPlanes out,
                                                                      EFPlanes eq_out, uint64_t n_pairs, EF r,
-                                                                     EF lambda, EF *partials) {
+                                                                     EF lambda, RedOut ro) {
     const uint64_t stride = (uint64_t)gridDim.x * RED_THREADS;
     EF sums[3] = {EF::zero(), EF::zero(), EF::zero()};
     for (uint64_t y = (uint64_t)blockIdx.x * RED_THREADS + threadIdx.x; y < n_pairs; y += stride) {
@@ -665,20 +744,22 @@ __global__ __launch_bounds__(RED_THREADS) void gkr_fold_round_kernel(FracPlanes 
         const EF b[4] = {fp[2], fq[2], fp[3], fq[3]};
         gkr_pair_sums(a, b, e0, e1, lambda, sums);
     }
-    block_sum_store<3>(sums, partials + (size_t)blockIdx.x * 3);
+    block_sum_store<3>(sums, ro.partials + (size_t)blockIdx.x * 3, ro.counter != nullptr);
+    finish_reduction<3>(ro, gridDim.x, 3);
 }
 int gkr_fold_round(FracPlanes in, EFPlanes eq_in, FracPlanes out, EFPlanes eq_out, uint64_t n_pairs, EF r, EF lambda,
-                   EF *d_partials, EF *d_out, hipStream_t s) {
+                   const RedOut &ro, hipStream_t s) {
     uint32_t grid = red_grid(n_pairs);
     hipLaunchKernelGGL(gkr_fold_round_kernel, dim3(grid), dim3(RED_THREADS), 0, s, in, eq_in, out, eq_out, n_pairs, r,
-                       lambda, d_partials);
+                       lambda, red_inline(ro, grid));
     OVM_CHECK_LAUNCH();
-    return sum_partials(d_partials, grid, 3, d_out, s);
+    return red_finish(ro, grid, grid, 3, s);
 }
 
 // Last fold of a layer: two records -> the layer's claims, written as out[0..4) = (p0, q0, p1, q1).
-__global__ void gkr_fold_final_kernel(FracPlanes in, EF r, EF *out) {
+__global__ void gkr_fold_final_kernel(FracPlanes in, EF r, RedOut ro) {
     if (threadIdx.x != 0) return;
+    EF *out = ro.out;
     EF p[4], q[4];
     ldp4(in.P(), in.stride, 0, p);
     ldp4(in.Q(), in.stride, 0, q);
@@ -686,9 +767,10 @@ __global__ void gkr_fold_final_kernel(FracPlanes in, EF r, EF *out) {
     st_ef(out + 1, q[0] + (q[2] - q[0]) * r);
     st_ef(out + 2, p[1] + (p[3] - p[1]) * r);
     st_ef(out + 3, q[1] + (q[3] - q[1]) * r);
+    publish(ro);
 }
-int gkr_fold_final(FracPlanes in, EF r, EF *out4, hipStream_t s) {
-    hipLaunchKernelGGL(gkr_fold_final_kernel, dim3(1), dim3(64), 0, s, in, r, out4);
+int gkr_fold_final(FracPlanes in, EF r, const RedOut &ro, hipStream_t s) {
+    hipLaunchKernelGGL(gkr_fold_final_kernel, dim3(1), dim3(64), 0, s, in, r, ro);
     OVM_CHECK_LAUNCH();
     return 0;
 }
@@ -728,13 +810,13 @@ __global__ __launch_bounds__(RED_THREADS) void stacked_round0_kernel(const Fp *b
     }
 }
 int stacked_round0(const Fp *base, uint32_t n_slices, uint32_t log_len, uint32_t l_skip, const EF *d_lam_eq,
-                   const EF *d_lam_rot, const EF *d_eq_cube, EF *d_partials, EF *d_out, hipStream_t s) {
+                   const EF *d_lam_rot, const EF *d_eq_cube, const RedOut &ro, hipStream_t s) {
     if ((1u << l_skip) > RED_THREADS) return (int)hipErrorInvalidValue;
     uint32_t grid = red_grid(1ull << log_len);
     hipLaunchKernelGGL(stacked_round0_kernel, dim3(grid), dim3(RED_THREADS), 0, s, base, n_slices, log_len, l_skip,
-                       d_lam_eq, d_lam_rot, d_eq_cube, d_partials);
+                       d_lam_eq, d_lam_rot, d_eq_cube, ro.partials);
     OVM_CHECK_LAUNCH();
-    return sum_partials(d_partials, grid, 3u << l_skip, d_out, s);
+    return sum_partials(ro, grid, 3u << l_skip, s);
 }
 
 __global__ void stacked_combine_kernel(const EF *q, const uint64_t *slice_off, uint32_t n_slices, uint32_t log_len,
@@ -758,7 +840,7 @@ int stacked_combine(const EF *q, const uint64_t *d_slice_off, uint32_t n_slices,
     return 0;
 }
 
-__global__ __launch_bounds__(RED_THREADS) void stacked_round_kernel(const EF *vec4, uint32_t log_h, EF *partials) {
+__global__ __launch_bounds__(RED_THREADS) void stacked_round_kernel(const EF *vec4, uint32_t log_h, RedOut ro) {
     const uint64_t h = 1ull << log_h, n_y = h >> 1, stride = (uint64_t)gridDim.x * RED_THREADS;
     const EF *qe = vec4, *qr = vec4 + h, *eq = vec4 + 2 * h, *kr = vec4 + 3 * h;
     EF sums[2] = {EF::zero(), EF::zero()};
@@ -771,13 +853,14 @@ __global__ __launch_bounds__(RED_THREADS) void stacked_round_kernel(const EF *ve
         EF a2 = a1.dbl() - a0, b2 = b1.dbl() - b0, e2 = e1.dbl() - e0, k2 = k1.dbl() - k0;
         sums[1] = sums[1] + a2 * e2 + b2 * k2;
     }
-    block_sum_store<2>(sums, partials + (size_t)blockIdx.x * 2);
+    block_sum_store<2>(sums, ro.partials + (size_t)blockIdx.x * 2, ro.counter != nullptr);
+    finish_reduction<2>(ro, gridDim.x, 2);
 }
-int stacked_round(const EF *vec4, uint32_t log_h, EF *d_partials, EF *d_out, hipStream_t s) {
+int stacked_round(const EF *vec4, uint32_t log_h, const RedOut &ro, hipStream_t s) {
     uint32_t grid = red_grid(1ull << (log_h - 1));
-    hipLaunchKernelGGL(stacked_round_kernel, dim3(grid), dim3(RED_THREADS), 0, s, vec4, log_h, d_partials);
+    hipLaunchKernelGGL(stacked_round_kernel, dim3(grid), dim3(RED_THREADS), 0, s, vec4, log_h, red_inline(ro, grid));
     OVM_CHECK_LAUNCH();
-    return sum_partials(d_partials, grid, 2, d_out, s);
+    return red_finish(ro, grid, grid, 2, s);
 }
 
 // ---- WHIR ------------------------------------------------------------------------------------
@@ -848,7 +931,7 @@ int zeta_transform(EF *v, uint32_t log_n, int dir, hipStream_t s) {
 }
 
 __global__ __launch_bounds__(RED_THREADS) void whir_round_kernel(const EF *f, const EF *w, uint64_t n_pairs,
-                                                                 EF *partials) {
+                                                                 RedOut ro) {
     const uint64_t stride = (uint64_t)gridDim.x * RED_THREADS;
     EF sums[2] = {EF::zero(), EF::zero()};
     for (uint64_t y = (uint64_t)blockIdx.x * RED_THREADS + threadIdx.x; y < n_pairs; y += stride) {
@@ -856,13 +939,14 @@ __global__ __launch_bounds__(RED_THREADS) void whir_round_kernel(const EF *f, co
         sums[0] = sums[0] + f1 * w1;
         sums[1] = sums[1] + (f1.dbl() - f0) * (w1.dbl() - w0);
     }
-    block_sum_store<2>(sums, partials + (size_t)blockIdx.x * 2);
+    block_sum_store<2>(sums, ro.partials + (size_t)blockIdx.x * 2, ro.counter != nullptr);
+    finish_reduction<2>(ro, gridDim.x, 2);
 }
-int whir_round(const EF *f, const EF *w, uint64_t n_pairs, EF *d_partials, EF *d_out, hipStream_t s) {
+int whir_round(const EF *f, const EF *w, uint64_t n_pairs, const RedOut &ro, hipStream_t s) {
     uint32_t grid = red_grid(n_pairs);
-    hipLaunchKernelGGL(whir_round_kernel, dim3(grid), dim3(RED_THREADS), 0, s, f, w, n_pairs, d_partials);
+    hipLaunchKernelGGL(whir_round_kernel, dim3(grid), dim3(RED_THREADS), 0, s, f, w, n_pairs, red_inline(ro, grid));
     OVM_CHECK_LAUNCH();
-    return sum_partials(d_partials, grid, 2, d_out, s);
+    return red_finish(ro, grid, grid, 2, s);
 }
 
 __global__ void whir_fold_kernel(const EF *f_in, const EF *w_in, EF *f_out, EF *w_out, uint64_t n_out, EF alpha) {
@@ -883,7 +967,7 @@ int whir_fold(const EF *f_in, const EF *w_in, EF *f_out, EF *w_out, uint64_t n_o
 // by z^(run start).
 static constexpr uint32_t HORNER_RUN = 16;
 __global__ __launch_bounds__(RED_THREADS) void horner_kernel(const EF *coeffs, uint64_t n, EF z, EF z_run,
-                                                             EF *partials) {
+                                                             RedOut ro) {
     const uint64_t n_runs = (n + HORNER_RUN - 1) / HORNER_RUN, stride = (uint64_t)gridDim.x * RED_THREADS;
     EF sums[1] = {EF::zero()};
     for (uint64_t r = (uint64_t)blockIdx.x * RED_THREADS + threadIdx.x; r < n_runs; r += stride) {
@@ -892,13 +976,15 @@ __global__ __launch_bounds__(RED_THREADS) void horner_kernel(const EF *coeffs, u
         for (uint64_t i = hi; i-- > lo;) acc = acc * z + ld_ef(coeffs + i);
         sums[0] = sums[0] + acc * z_run.pow(r);
     }
-    block_sum_store<1>(sums, partials + blockIdx.x);
+    block_sum_store<1>(sums, ro.partials + blockIdx.x, ro.counter != nullptr);
+    finish_reduction<1>(ro, gridDim.x, 1);
 }
-int horner_eval(const EF *coeffs, uint64_t n, EF z, EF *d_partials, EF *d_out, hipStream_t s) {
+int horner_eval(const EF *coeffs, uint64_t n, EF z, const RedOut &ro, hipStream_t s) {
     uint32_t grid = red_grid((n + HORNER_RUN - 1) / HORNER_RUN);
-    hipLaunchKernelGGL(horner_kernel, dim3(grid), dim3(RED_THREADS), 0, s, coeffs, n, z, z.pow(HORNER_RUN), d_partials);
+    hipLaunchKernelGGL(horner_kernel, dim3(grid), dim3(RED_THREADS), 0, s, coeffs, n, z, z.pow(HORNER_RUN),
+                       red_inline(ro, grid));
     OVM_CHECK_LAUNCH();
-    return sum_partials(d_partials, grid, 1, d_out, s);
+    return red_finish(ro, grid, grid, 1, s);
 }
 
 // tab_lo[q * 2^log_lo + x_lo] (already scaled by gamma_q), tab_hi[q * 2^(log_n - log_lo) + x_hi]
