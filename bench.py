@@ -35,6 +35,8 @@ def main():
     ap.add_argument("--log-stacked-height", type=int, default=24)
     ap.add_argument("--cpu-log-rows", type=int, default=16, help="rows of the CPU-baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--zero-trace", action="store_true",
+                    help="all-zero trace (what the reference's uniform_runner proves) instead of seeded random bits")
     args = ap.parse_args()
 
     import torch
@@ -64,6 +66,8 @@ def main():
     bits = torch.randint(0, 2, (cols * h,), dtype=torch.int32, device=f"cuda:{local_rank}", generator=gen)
     one_mont = int(pkg.to_mont(np.array([1], dtype=np.uint32))[0])
     trace = bits * one_mont  # boolean cells in Montgomery form, column-major
+    if args.zero_trace:
+        trace.zero_()
     del bits
     traces = [(0, trace, h, [])]
     cells = cols * h
@@ -130,6 +134,9 @@ def main():
             cpu = {"value": round((cols << lr) / cdt, 1), "unit": "cells/s", "cores": os.cpu_count(), "kind": "port",
                    "sample": f"C++ oracle (OpenMP), one prove of 2^{lr} x {cols} BenchmarkAir, app params with "
                              f"log_stacked_height {args.log_stacked_height - (log_rows - lr)}, {cdt:.1f} s"}
+        # ~60 algorithmic HBM bytes per trace cell end to end for this configuration
+        # (6 trace passes + codeword write/read at blowup 2 + the 2^27-leaf fraction tree)
+        e2e_gbs = 60.0 * cells / (elapsed / args.steps) / 1e9
         line = {
             "metric": "trace_cells_per_sec", "value": round(value, 1), "unit": "cells/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
@@ -138,9 +145,11 @@ def main():
             "config": {"workload": f"uniform_runner BenchmarkAir 2^{log_rows} rows x {cols} cols per GPU, "
                                    f"200 boolean constraints, 13 send/receive pairs, app params "
                                    f"(l_skip 4, n_stack {args.log_stacked_height - 4}, log_blowup 1, k_whir 4, "
-                                   f"PoW 18/15/5/20 bits), seeded random boolean trace",
+                                   f"PoW 18/15/5/20 bits), " + ("all-zero trace" if args.zero_trace else "seeded random boolean trace"),
                        "proof_bytes": len(proof), "parallelism": f"replicas x{world}"},
             "roofline": roof, "cpu_baseline": cpu,
+            "end_to_end": {"algorithmic_bytes_per_cell": 60, "achieved_GBps": round(e2e_gbs, 1),
+                           "frac_of_hbm_peak": round(e2e_gbs / HBM_PEAK_GBS, 4)},
             "stage_ms": {k: round(v, 3) for k, v in sorted(stages.items(), key=lambda kv: -kv[1])},
             "dominant_stage": dom,
         }

@@ -55,3 +55,58 @@ def test_multi_air_mixed_heights(dev, pkg, orc):
     t3 = airs.splitmix64_bits(2, 8 * 2)
     run_case(dev, pkg, orc, params, [airs.fibonacci_air(), bench, bench],
              [(0, t1, 16, pv), (1, t2, 64, []), (2, t3, 2, [])])
+
+
+# ---- full BASELINE sizes: size-independent properties (the oracle cannot prove these in seconds,
+# but its verifier restatement checks any proof in milliseconds) -----------------------------------
+def _config_d(pkg, dev, log_rows, cols, log_stacked, zero=False):
+    import torch
+    h = 1 << log_rows
+    params = airs.app_params(log_stacked)
+    blob = airs.pk_blob(params, [airs.uniform_runner_air(cols)])
+    pk = pkg.ProvingKey(blob)
+    if zero:
+        trace = torch.zeros(cols * h, dtype=torch.int32, device="cuda:0")
+    else:
+        gen = torch.Generator(device="cuda:0")
+        gen.manual_seed(0xD15EA5E)
+        bits = torch.randint(0, 2, (cols * h,), dtype=torch.int32, device="cuda:0", generator=gen)
+        trace = bits * int(pkg.to_mont(np.array([1], dtype=np.uint32))[0])
+    return blob, pk, trace, h
+
+
+@pytest.mark.parametrize("zero", [False, True], ids=["random-bits", "all-zero"])
+def test_config_d_full_size_verifies(dev, pkg, orc, zero):
+    """BASELINE config D (2^22 x 100, app params, log_stacked_height 24): the proof is accepted by the
+    verifier, proving twice gives identical bytes, and a flipped byte in any section is rejected."""
+    blob, pk, trace, h = _config_d(pkg, dev, 22, 100, 24, zero)
+    proof, secs = dev.prove(pk, [(0, trace, h, [])])
+    orc.verify(blob, proof)
+    proof2, _ = dev.prove(pk, [(0, trace, h, [])])
+    assert proof2 == proof, "prove is not deterministic"
+    starts = [0] + list(secs[:-1])
+    for name, a, b in zip(SECTIONS, starts, secs):
+        if b - a < 8:
+            continue
+        bad = bytearray(proof)
+        bad[(a + b) // 2] ^= 1
+        with pytest.raises(Exception):
+            orc.verify(blob, bytes(bad))
+
+
+def test_config_c_shape_verifies(dev, pkg, orc):
+    """BASELINE config C shape: 4 AIRs x 2^20 rows x 100 columns with LogUp in one proof."""
+    import torch
+    params = airs.app_params(24)
+    air = airs.uniform_runner_air(100)
+    blob = airs.pk_blob(params, [air, air, air, air])
+    pk = pkg.ProvingKey(blob)
+    h = 1 << 20
+    one = int(pkg.to_mont(np.array([1], dtype=np.uint32))[0])
+    traces = []
+    for i in range(4):
+        gen = torch.Generator(device="cuda:0")
+        gen.manual_seed(0xD15EA5E + i)
+        traces.append((i, torch.randint(0, 2, (100 * h,), dtype=torch.int32, device="cuda:0", generator=gen) * one, h, []))
+    proof, _ = dev.prove(pk, traces)
+    orc.verify(blob, proof)
