@@ -531,37 +531,43 @@ struct Prover {
             observe_claims(claims[0]);
             std::vector<EF> xi_prev{ts.sample_ext()};
             if (TR > 1) {
-                // fold buffers in layer format (8 limb planes) and eq tables (4 limb planes)
+                // fold buffers in layer format (8 limb planes) and the eq heap (4 limb planes)
                 const uint64_t wcap = std::max<uint64_t>(uint64_t(1) << (TR - 1), 4);
-                DevBuf<uint32_t> rec_a(8 * wcap), rec_b(8 * wcap), eq_a(4 * wcap), eq_b(4 * wcap);
+                DevBuf<uint32_t> rec_a(8 * wcap), rec_b(8 * wcap), eq_buf(4 * wcap);
                 const FracPlanes recs[2] = {{rec_a.p, wcap}, {rec_b.p, wcap}};
-                const EFPlanes eqs[2] = {{eq_a.p, wcap}, {eq_b.p, wcap}};
+                const EFPlanes heap{eq_buf.p, wcap};
                 DevBuf<EF> partials(RED_BLOCKS * 4), d_point(TR);
                 for (unsigned round = 1; round < TR; round++) {
                     EF lambda = ts.sample_ext();
                     OVM_THROW_IF(hipMemcpyAsync(d_point.p, xi_prev.data(), round * sizeof(EF), hipMemcpyHostToDevice, cx.stream));
-                    OVM_THROW_IF(eq_table_planes(d_point.p, round, eqs[0], cx.stream));
+                    OVM_THROW_IF(eq_heap(d_point.p, round, heap, cx.stream));
                     FracPlanes rec = tree.at(size_t(2) << round);
-                    EFPlanes eq = eqs[0];
                     std::vector<std::array<EF, 3>> polys;
                     std::vector<EF> rho;
                     EF r_prev = EF::zero();
+                    EF c_bound = EF::one();  // prod_{i < sr} eq1(xi_i, r_i)
                     for (unsigned sr = 0; sr < round; sr++) {
-                        uint64_t n_pairs = 1ull << (round - sr - 1);
+                        const uint64_t n_pairs = 1ull << (round - sr - 1);
+                        const EFPlanes eq{heap.p + n_pairs, heap.stride};  // depth round-1-sr of the heap
                         if (sr == 0) {
                             OVM_THROW_IF(gkr_round(rec, eq, n_pairs, lambda, mb.arm(partials.p), cx.stream));
                         } else {
                             // fold sub-round sr-1 with r_prev and get this sub-round's sums in one pass
-                            OVM_THROW_IF(gkr_fold_round(rec, eq, recs[sr & 1], eqs[sr & 1], n_pairs, r_prev, lambda,
-                                                        mb.arm(partials.p), cx.stream));
+                            OVM_THROW_IF(gkr_fold_round(rec, eq, recs[sr & 1], n_pairs, r_prev, lambda, mb.arm(partials.p),
+                                                        cx.stream));
                             rec = recs[sr & 1];
-                            eq = eqs[sr & 1];
                         }
                         auto sv = mb.take(3, cx.stream);
+                        // s(X) = c_bound * eq1(xi_sr, X) * S'(X); eq1(a, X) = a X + (1-a)(1-X) = a, 3a-1, 5a-2 at X = 1, 2, 3
+                        const EF a = xi_prev[sr];
+                        const EF a2 = a.dbl(), a3 = a2 + a, a5 = a3 + a2;
+                        const EF w[3] = {c_bound * a, c_bound * (a3 - EF::one()), c_bound * (a5 - EF::one().dbl())};
+                        for (int i = 0; i < 3; i++) sv[i] = sv[i] * w[i];
                         for (auto &e : sv) ts.observe_ext(e);
                         polys.push_back({sv[0], sv[1], sv[2]});
                         r_prev = ts.sample_ext();
                         rho.push_back(r_prev);
+                        c_bound = c_bound * (a * r_prev + (EF::one() - a) * (EF::one() - r_prev));
                     }
                     // last fold: one record (the layer claims)
                     OVM_THROW_IF(gkr_fold_final(rec, r_prev, mb.arm(nullptr), cx.stream));

@@ -663,17 +663,19 @@ int gkr_read_fracs(FracPlanes t, uint64_t first, uint32_t n, const RedOut &ro, h
     return 0;
 }
 
-// sums[X-1] += e(X) * (p0 q1 + p1 q0 + lambda q0 q1)(X) for X = 1, 2, 3 where every quantity is
-// the line through its values on records a (X = 0) and b (X = 1).
-__device__ __forceinline__ void gkr_pair_sums(EF (&a)[4], const EF (&b)[4], EF e0, EF e1, const EF &lambda,
+// sums[X-1] += e * (p0 q1 + p1 q0 + lambda q0 q1)(X) for X = 1, 2, 3 where every quantity is the
+// line through its values on records a (X = 0) and b (X = 1). The eq polynomial is FACTORED: the
+// weight e = eq(xi_rest, y) covers only the variables not yet bound; the factor of the current
+// variable, eq1(xi_sr, X), and the product over the bound ones multiply the three sums on the host
+// (prover.hip). That makes the eq table half the size, read-only (never folded) and one load per
+// pair instead of four loads and two stores.
+__device__ __forceinline__ void gkr_pair_sums(EF (&a)[4], const EF (&b)[4], const EF &e, const EF &lambda,
                                               EF (&sums)[3]) {
     EF d[4];
 #pragma unroll
     for (int i = 0; i < 4; i++) d[i] = b[i] - a[i];
-    EF ed = e1 - e0, e = e0;
 #pragma unroll
     for (int xi = 0; xi < 3; xi++) {
-        e = e + ed;
 #pragma unroll
         for (int i = 0; i < 4; i++) a[i] = a[i] + d[i];
         // (p0, q0, p1, q1) at X = xi+1
@@ -681,6 +683,41 @@ __device__ __forceinline__ void gkr_pair_sums(EF (&a)[4], const EF (&b)[4], EF e
         EF qq = a[1] * a[3];
         sums[xi] = sums[xi] + e * (pq + lambda * qq);
     }
+}
+
+// Heap of partial eq tables for one layer: node 1 = 1; node i at depth k has children
+// H[2i] = H[i] * (1 - x), H[2i+1] = H[i] * x with x = point[n-1-k]. Depth k (nodes 2^k .. 2^(k+1))
+// is the table over the LAST k variables, low bit = variable n-k: exactly the weights sub-round
+// n-1-k needs, so one build serves every sub-round of the layer.
+static constexpr uint32_t EQ_HEAP_DIRECT_DEPTH = 10;
+__global__ void eq_heap_top_kernel(const EF *point, uint32_t n, uint32_t max_depth, EFPlanes heap) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;  // heap node
+    if (i == 0 || i >= (2u << max_depth)) return;
+    const uint32_t k = 31 - __clz(i), y = i - (1u << k);
+    EF acc = EF::one();
+    for (uint32_t j = 0; j < k; j++) {
+        EF x = ld_ef(point + (n - k + j));
+        acc = acc * ((y >> j & 1) ? x : EF::one() - x);
+    }
+    stp(heap.p, heap.stride, i, acc);
+}
+__global__ void eq_heap_level_kernel(const EF *point, uint32_t n, uint32_t k, EFPlanes heap) {
+    const uint64_t i = (1ull << k) + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (2ull << k)) return;
+    EF lo = ldp(heap.p, heap.stride, i);
+    EF hi = lo * ld_ef(point + (n - 1 - k));
+    stp2(heap.p, heap.stride, 2 * i, lo - hi, hi);
+}
+int eq_heap(const EF *d_point, uint32_t n, EFPlanes heap, hipStream_t s) {
+    if (n == 0) return (int)hipErrorInvalidValue;
+    const uint32_t top = n - 1 < EQ_HEAP_DIRECT_DEPTH ? n - 1 : EQ_HEAP_DIRECT_DEPTH;
+    hipLaunchKernelGGL(eq_heap_top_kernel, dim3(ceil_div(2ull << top, 256)), dim3(256), 0, s, d_point, n, top, heap);
+    OVM_CHECK_LAUNCH();
+    for (uint32_t k = top; k + 1 < n; k++) {
+        hipLaunchKernelGGL(eq_heap_level_kernel, dim3(ceil_div(1ull << k, 256)), dim3(256), 0, s, d_point, n, k, heap);
+        OVM_CHECK_LAUNCH();
+    }
+    return 0;
 }
 
 __global__ __launch_bounds__(RED_THREADS) void gkr_round_kernel(FracPlanes rec, EFPlanes eq, uint64_t n_pairs,
@@ -691,11 +728,10 @@ __global__ __launch_bounds__(RED_THREADS) void gkr_round_kernel(FracPlanes rec, 
         EF p[4], q[4];  // fractions 4y..4y+3 = records 2y (entries 0,1) and 2y+1 (entries 2,3)
         ldp4(rec.P(), rec.stride, 4 * y, p);
         ldp4(rec.Q(), rec.stride, 4 * y, q);
-        EF e0, e1;
-        ldp2(eq.p, eq.stride, 2 * y, e0, e1);
+        const EF e = ldp(eq.p, eq.stride, y);
         EF a[4] = {p[0], q[0], p[1], q[1]};
         const EF b[4] = {p[2], q[2], p[3], q[3]};
-        gkr_pair_sums(a, b, e0, e1, lambda, sums);
+        gkr_pair_sums(a, b, e, lambda, sums);
     }
     block_sum_store<3>(sums, ro.partials + (size_t)blockIdx.x * 3, ro.counter != nullptr);
     finish_reduction<3>(ro, gridDim.x, 3);
@@ -709,12 +745,11 @@ int gkr_round(FracPlanes rec, EFPlanes eq, uint64_t n_pairs, EF lambda, const Re
 }
 
 // Fused "fold with r, then next round's sums": output pair y is built from input records
-// 4y..4y+3 = fractions 8y..8y+7 (and eq entries 4y..4y+3); the two folded records (fractions
-// 4y..4y+3 of the output) are stored and immediately used for the degree-3 round sums, so every
-// sub-round after the first is ONE pass over the data.
-__global__ __launch_bounds__(RED_THREADS) void gkr_fold_round_kernel(FracPlanes in, EFPlanes eq_in, FracPlanes out,
-                                                                     EFPlanes eq_out, uint64_t n_pairs, EF r,
-                                                                     EF lambda, RedOut ro) {
+// 4y..4y+3 = fractions 8y..8y+7; the two folded records (fractions 4y..4y+3 of the output) are
+// stored and immediately used for the degree-3 round sums with weight eq[y], so every sub-round
+// after the first is ONE pass over the data.
+__global__ __launch_bounds__(RED_THREADS) void gkr_fold_round_kernel(FracPlanes in, EFPlanes eq, FracPlanes out,
+                                                                     uint64_t n_pairs, EF r, EF lambda, RedOut ro) {
     const uint64_t stride = (uint64_t)gridDim.x * RED_THREADS;
     EF sums[3] = {EF::zero(), EF::zero(), EF::zero()};
     for (uint64_t y = (uint64_t)blockIdx.x * RED_THREADS + threadIdx.x; y < n_pairs; y += stride) {
@@ -736,22 +771,19 @@ __global__ __launch_bounds__(RED_THREADS) void gkr_fold_round_kernel(FracPlanes 
             fq[3] = v[1] + (v[3] - v[1]) * r;
             stp4(out.Q(), out.stride, 4 * y, fq);
         }
-        EF e[4];
-        ldp4(eq_in.p, eq_in.stride, 4 * y, e);
-        EF e0 = e[0] + (e[1] - e[0]) * r, e1 = e[2] + (e[3] - e[2]) * r;
-        stp2(eq_out.p, eq_out.stride, 2 * y, e0, e1);
+        const EF e = ldp(eq.p, eq.stride, y);
         EF a[4] = {fp[0], fq[0], fp[1], fq[1]};
         const EF b[4] = {fp[2], fq[2], fp[3], fq[3]};
-        gkr_pair_sums(a, b, e0, e1, lambda, sums);
+        gkr_pair_sums(a, b, e, lambda, sums);
     }
     block_sum_store<3>(sums, ro.partials + (size_t)blockIdx.x * 3, ro.counter != nullptr);
     finish_reduction<3>(ro, gridDim.x, 3);
 }
-int gkr_fold_round(FracPlanes in, EFPlanes eq_in, FracPlanes out, EFPlanes eq_out, uint64_t n_pairs, EF r, EF lambda,
-                   const RedOut &ro, hipStream_t s) {
+int gkr_fold_round(FracPlanes in, EFPlanes eq, FracPlanes out, uint64_t n_pairs, EF r, EF lambda, const RedOut &ro,
+                   hipStream_t s) {
     uint32_t grid = red_grid(n_pairs);
-    hipLaunchKernelGGL(gkr_fold_round_kernel, dim3(grid), dim3(RED_THREADS), 0, s, in, eq_in, out, eq_out, n_pairs, r,
-                       lambda, red_inline(ro, grid));
+    hipLaunchKernelGGL(gkr_fold_round_kernel, dim3(grid), dim3(RED_THREADS), 0, s, in, eq, out, n_pairs, r, lambda,
+                       red_inline(ro, grid));
     OVM_CHECK_LAUNCH();
     return red_finish(ro, grid, grid, 3, s);
 }
