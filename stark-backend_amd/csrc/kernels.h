@@ -89,18 +89,19 @@ int eq_table_planes(const EF *d_point, uint32_t n, EFPlanes out, hipStream_t s);
 // heap[2^k + y] = eq(point[n-k .. n), y) for k = 0 .. n-1 (2^n entries, node 1 = 1): the weights of
 // sub-round n-1-k of a layer sumcheck whose eq factor is split off (stages.hip)
 int eq_heap(const EF *d_point, uint32_t n, EFPlanes heap, hipStream_t s);
-int gkr_fill_leaves(FracPlanes leaves, uint64_t n, EF alpha, hipStream_t s);
+// p_base: leaf numerators are base-field, only limb plane 0 of P is written / read (stages.hip)
+int gkr_fill_leaves(FracPlanes leaves, uint64_t n, EF alpha, bool p_base, hipStream_t s);
 int gkr_eval_leaves(const DevProgram &prog, const EF *d_leaf_const, const ColDesc *d_cols, uint32_t log_height,
                     const uint64_t *d_leaf_base, const uint32_t *d_leaf_log_len, Fp norm, FracPlanes leaves,
                     hipStream_t s);
-int gkr_build_layer(FracPlanes child, FracPlanes parent, uint64_t n_parent, hipStream_t s);
+int gkr_build_layer(FracPlanes child, FracPlanes parent, uint64_t n_parent, bool child_p_base, hipStream_t s);
 // out[2i], out[2i+1] = (p, q) of fractions first .. first+n (n <= 64), AoS, for the host
 int gkr_read_fracs(FracPlanes t, uint64_t first, uint32_t n, const RedOut &ro, hipStream_t s);
 // out[X-1] = sum_y eq[y] * (p0 q1 + p1 q0 + lambda q0 q1)(X, y), X = 1..3 (eq: n_pairs weights)
-int gkr_round(FracPlanes rec, EFPlanes eq, uint64_t n_pairs, EF lambda, const RedOut &ro, hipStream_t s);
+int gkr_round(FracPlanes rec, bool p_base, EFPlanes eq, uint64_t n_pairs, EF lambda, const RedOut &ro, hipStream_t s);
 // fold the previous round with r and return the NEXT round's sums over the n_pairs folded pairs
-int gkr_fold_round(FracPlanes in, EFPlanes eq, FracPlanes out, uint64_t n_pairs, EF r, EF lambda, const RedOut &ro,
-                   hipStream_t s);
+int gkr_fold_round(FracPlanes in, bool in_p_base, EFPlanes eq, FracPlanes out, uint64_t n_pairs, EF r, EF lambda,
+                   const RedOut &ro, hipStream_t s);
 // two records -> out4 = (p0, q0, p1, q1) folded at r (AoS, for the host)
 int gkr_fold_final(FracPlanes in, EF r, const RedOut &ro, hipStream_t s);
 

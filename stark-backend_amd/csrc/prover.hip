@@ -479,7 +479,9 @@ struct Prover {
             DevBuf<uint32_t> tree_buf(8 * tree_stride);
             const FracPlanes tree{tree_buf.p, tree_stride};
             ProfScope *ps_leaves = new ProfScope("gkr.leaves", cx.stream);
-            OVM_THROW_IF(gkr_fill_leaves(tree.at(n_leaves), n_leaves, alpha, cx.stream));
+            // big trees: only limb 0 of the leaf numerators exists (small ones are read through generic paths)
+            const bool p_base = TR >= 12;
+            OVM_THROW_IF(gkr_fill_leaves(tree.at(n_leaves), n_leaves, alpha, p_base, cx.stream));
             for (size_t t = 0; t < T; t++) {
                 const AirKey &a = air(t);
                 if (a.interactions.empty()) continue;
@@ -510,7 +512,7 @@ struct Prover {
             OVM_PROF("gkr.build_tree", cx.stream);
             wt.mark("rap.gkr.leaves");
             for (unsigned j = TR; j-- > 0;)
-                OVM_THROW_IF(gkr_build_layer(tree.at(size_t(2) << j), tree.at(size_t(1) << j), size_t(1) << j, cx.stream));
+                OVM_THROW_IF(gkr_build_layer(tree.at(size_t(2) << j), tree.at(size_t(1) << j), size_t(1) << j, p_base && j + 1 == TR, cx.stream));
             }
             wt.mark("rap.gkr.build");
             OVM_PROF("gkr.layer_sumchecks", cx.stream);
@@ -550,10 +552,10 @@ struct Prover {
                         const uint64_t n_pairs = 1ull << (round - sr - 1);
                         const EFPlanes eq{heap.p + n_pairs, heap.stride};  // depth round-1-sr of the heap
                         if (sr == 0) {
-                            OVM_THROW_IF(gkr_round(rec, eq, n_pairs, lambda, mb.arm(partials.p), cx.stream));
+                            OVM_THROW_IF(gkr_round(rec, p_base && round + 1 == TR, eq, n_pairs, lambda, mb.arm(partials.p), cx.stream));
                         } else {
                             // fold sub-round sr-1 with r_prev and get this sub-round's sums in one pass
-                            OVM_THROW_IF(gkr_fold_round(rec, eq, recs[sr & 1], n_pairs, r_prev, lambda, mb.arm(partials.p),
+                            OVM_THROW_IF(gkr_fold_round(rec, p_base && round + 1 == TR && sr == 1, eq, recs[sr & 1], n_pairs, r_prev, lambda, mb.arm(partials.p),
                                                         cx.stream));
                             rec = recs[sr & 1];
                         }

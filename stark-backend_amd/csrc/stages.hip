@@ -569,14 +569,33 @@ __device__ __forceinline__ void stp4(uint32_t *b, uint64_t st, uint64_t i, const
         *reinterpret_cast<uint4 *>(b + k * st + i) = make_uint4(e[0].c[k].v, e[1].c[k].v, e[2].c[k].v, e[3].c[k].v);
 }
 
-__global__ void gkr_fill_kernel(FracPlanes leaves, uint64_t n, EF alpha) {
+// Leaf numerators are base-field values (count * norm): limbs 1..3 of the leaf layer's P planes
+// are identically zero. With p_base the leaf layer's readers (PBASE kernels below) load limb 0
+// only and nobody writes or reads the other three planes -- 3/8 of the leaf layer's traffic.
+__device__ __forceinline__ void ldp2_base(const uint32_t *b, uint64_t i, EF &e0, EF &e1) {
+    uint2 v = *reinterpret_cast<const uint2 *>(b + i);
+    e0 = EF::from_base(Fp::raw(v.x));
+    e1 = EF::from_base(Fp::raw(v.y));
+}
+__device__ __forceinline__ void ldp4_base(const uint32_t *b, uint64_t i, EF (&e)[4]) {
+    uint4 v = *reinterpret_cast<const uint4 *>(b + i);
+    e[0] = EF::from_base(Fp::raw(v.x));
+    e[1] = EF::from_base(Fp::raw(v.y));
+    e[2] = EF::from_base(Fp::raw(v.z));
+    e[3] = EF::from_base(Fp::raw(v.w));
+}
+
+__global__ void gkr_fill_kernel(FracPlanes leaves, uint64_t n, EF alpha, bool p_base) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    stp(leaves.P(), leaves.stride, i, EF::zero());
+    if (p_base)
+        leaves.P()[i] = 0;
+    else
+        stp(leaves.P(), leaves.stride, i, EF::zero());
     stp(leaves.Q(), leaves.stride, i, alpha);
 }
-int gkr_fill_leaves(FracPlanes leaves, uint64_t n, EF alpha, hipStream_t s) {
-    hipLaunchKernelGGL(gkr_fill_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, s, leaves, n, alpha);
+int gkr_fill_leaves(FracPlanes leaves, uint64_t n, EF alpha, bool p_base, hipStream_t s) {
+    hipLaunchKernelGGL(gkr_fill_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, s, leaves, n, alpha, p_base);
     OVM_CHECK_LAUNCH();
     return 0;
 }
@@ -601,7 +620,7 @@ struct LeafEmit {
         uint64_t len = 1ull << leaf_log_len[k];
         for (uint64_t off = 0; off < len; off += 1ull << log_height) {
             const uint64_t i = leaf_base[k] + off + row;
-            stp(leaves.P(), leaves.stride, i, EF::from_base(p));
+            leaves.P()[i] = p.v;  // limbs 1..3 are zero: written by the fill, or never read (p_base)
             stp(leaves.Q(), leaves.stride, i, den);
         }
     }
@@ -632,17 +651,26 @@ int gkr_eval_leaves(const DevProgram &prog, const EF *d_leaf_const, const ColDes
 }
 
 // parent[i] = child[2i] + child[2i+1] as fractions
+template <bool PBASE>
 __global__ void gkr_build_kernel(FracPlanes child, FracPlanes parent, uint64_t n_parent) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_parent) return;
     EF p0, p1, q0, q1;
-    ldp2(child.P(), child.stride, 2 * i, p0, p1);
+    if (PBASE)
+        ldp2_base(child.P(), 2 * i, p0, p1);
+    else
+        ldp2(child.P(), child.stride, 2 * i, p0, p1);
     ldp2(child.Q(), child.stride, 2 * i, q0, q1);
     stp(parent.P(), parent.stride, i, p0 * q1 + q0 * p1);
     stp(parent.Q(), parent.stride, i, q0 * q1);
 }
-int gkr_build_layer(FracPlanes child, FracPlanes parent, uint64_t n_parent, hipStream_t s) {
-    hipLaunchKernelGGL(gkr_build_kernel, dim3(ceil_div(n_parent, 256)), dim3(256), 0, s, child, parent, n_parent);
+int gkr_build_layer(FracPlanes child, FracPlanes parent, uint64_t n_parent, bool child_p_base, hipStream_t s) {
+    if (child_p_base)
+        hipLaunchKernelGGL(gkr_build_kernel<true>, dim3(ceil_div(n_parent, 256)), dim3(256), 0, s, child, parent,
+                           n_parent);
+    else
+        hipLaunchKernelGGL(gkr_build_kernel<false>, dim3(ceil_div(n_parent, 256)), dim3(256), 0, s, child, parent,
+                           n_parent);
     OVM_CHECK_LAUNCH();
     return 0;
 }
@@ -720,13 +748,17 @@ int eq_heap(const EF *d_point, uint32_t n, EFPlanes heap, hipStream_t s) {
     return 0;
 }
 
+template <bool PBASE>
 __global__ __launch_bounds__(RED_THREADS) void gkr_round_kernel(FracPlanes rec, EFPlanes eq, uint64_t n_pairs,
                                                                 EF lambda, RedOut ro) {
     const uint64_t stride = (uint64_t)gridDim.x * RED_THREADS;
     EF sums[3] = {EF::zero(), EF::zero(), EF::zero()};
     for (uint64_t y = (uint64_t)blockIdx.x * RED_THREADS + threadIdx.x; y < n_pairs; y += stride) {
         EF p[4], q[4];  // fractions 4y..4y+3 = records 2y (entries 0,1) and 2y+1 (entries 2,3)
-        ldp4(rec.P(), rec.stride, 4 * y, p);
+        if (PBASE)
+            ldp4_base(rec.P(), 4 * y, p);
+        else
+            ldp4(rec.P(), rec.stride, 4 * y, p);
         ldp4(rec.Q(), rec.stride, 4 * y, q);
         const EF e = ldp(eq.p, eq.stride, y);
         EF a[4] = {p[0], q[0], p[1], q[1]};
@@ -736,10 +768,14 @@ __global__ __launch_bounds__(RED_THREADS) void gkr_round_kernel(FracPlanes rec, 
     block_sum_store<3>(sums, ro.partials + (size_t)blockIdx.x * 3, ro.counter != nullptr);
     finish_reduction<3>(ro, gridDim.x, 3);
 }
-int gkr_round(FracPlanes rec, EFPlanes eq, uint64_t n_pairs, EF lambda, const RedOut &ro, hipStream_t s) {
+int gkr_round(FracPlanes rec, bool p_base, EFPlanes eq, uint64_t n_pairs, EF lambda, const RedOut &ro, hipStream_t s) {
     uint32_t grid = red_grid(n_pairs);
-    hipLaunchKernelGGL(gkr_round_kernel, dim3(grid), dim3(RED_THREADS), 0, s, rec, eq, n_pairs, lambda,
-                       red_inline(ro, grid));
+    if (p_base)
+        hipLaunchKernelGGL(gkr_round_kernel<true>, dim3(grid), dim3(RED_THREADS), 0, s, rec, eq, n_pairs, lambda,
+                           red_inline(ro, grid));
+    else
+        hipLaunchKernelGGL(gkr_round_kernel<false>, dim3(grid), dim3(RED_THREADS), 0, s, rec, eq, n_pairs, lambda,
+                           red_inline(ro, grid));
     OVM_CHECK_LAUNCH();
     return red_finish(ro, grid, grid, 3, s);
 }
@@ -748,6 +784,7 @@ int gkr_round(FracPlanes rec, EFPlanes eq, uint64_t n_pairs, EF lambda, const Re
 // 4y..4y+3 = fractions 8y..8y+7; the two folded records (fractions 4y..4y+3 of the output) are
 // stored and immediately used for the degree-3 round sums with weight eq[y], so every sub-round
 // after the first is ONE pass over the data.
+template <bool PBASE>
 __global__ __launch_bounds__(RED_THREADS) void gkr_fold_round_kernel(FracPlanes in, EFPlanes eq, FracPlanes out,
                                                                      uint64_t n_pairs, EF r, EF lambda, RedOut ro) {
     const uint64_t stride = (uint64_t)gridDim.x * RED_THREADS;
@@ -756,8 +793,13 @@ __global__ __launch_bounds__(RED_THREADS) void gkr_fold_round_kernel(FracPlanes 
         EF fp[4], fq[4];
         {
             EF u[4], v[4];
-            ldp4(in.P(), in.stride, 8 * y, u);      // records 4y, 4y+1
-            ldp4(in.P(), in.stride, 8 * y + 4, v);  // records 4y+2, 4y+3
+            if (PBASE) {
+                ldp4_base(in.P(), 8 * y, u);
+                ldp4_base(in.P(), 8 * y + 4, v);
+            } else {
+                ldp4(in.P(), in.stride, 8 * y, u);      // records 4y, 4y+1
+                ldp4(in.P(), in.stride, 8 * y + 4, v);  // records 4y+2, 4y+3
+            }
             fp[0] = u[0] + (u[2] - u[0]) * r;
             fp[1] = u[1] + (u[3] - u[1]) * r;
             fp[2] = v[0] + (v[2] - v[0]) * r;
@@ -779,11 +821,15 @@ __global__ __launch_bounds__(RED_THREADS) void gkr_fold_round_kernel(FracPlanes 
     block_sum_store<3>(sums, ro.partials + (size_t)blockIdx.x * 3, ro.counter != nullptr);
     finish_reduction<3>(ro, gridDim.x, 3);
 }
-int gkr_fold_round(FracPlanes in, EFPlanes eq, FracPlanes out, uint64_t n_pairs, EF r, EF lambda, const RedOut &ro,
-                   hipStream_t s) {
+int gkr_fold_round(FracPlanes in, bool in_p_base, EFPlanes eq, FracPlanes out, uint64_t n_pairs, EF r, EF lambda,
+                   const RedOut &ro, hipStream_t s) {
     uint32_t grid = red_grid(n_pairs);
-    hipLaunchKernelGGL(gkr_fold_round_kernel, dim3(grid), dim3(RED_THREADS), 0, s, in, eq, out, n_pairs, r, lambda,
-                       red_inline(ro, grid));
+    if (in_p_base)
+        hipLaunchKernelGGL(gkr_fold_round_kernel<true>, dim3(grid), dim3(RED_THREADS), 0, s, in, eq, out, n_pairs, r,
+                           lambda, red_inline(ro, grid));
+    else
+        hipLaunchKernelGGL(gkr_fold_round_kernel<false>, dim3(grid), dim3(RED_THREADS), 0, s, in, eq, out, n_pairs, r,
+                           lambda, red_inline(ro, grid));
     OVM_CHECK_LAUNCH();
     return red_finish(ro, grid, grid, 3, s);
 }
