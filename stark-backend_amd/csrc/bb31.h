@@ -60,15 +60,15 @@ BB_HD uint32_t mont_reduce(uint64_t x) {
     return umin32(r, r + P);
 }
 
-// Same, for x < 4*P^2 (a sum of up to four raw products): hi(x) may reach ~1.9 P, so the
-// difference lies in (-P, 1.9 P) and needs one correction in each direction.
+// Same, for x < 4*P^2 (a sum of up to four raw products): hi(x) may reach ~1.9 P, so it is
+// brought below P first (sub + min), after which the usual single correction applies.
 BB_HD uint32_t mont_reduce_wide(uint64_t x) {
     uint32_t lo = (uint32_t)x, xh = (uint32_t)(x >> 32);
+    xh = umin32(xh, xh - P);
     uint32_t t = lo * MONTY_M;
     uint32_t uh = mulhi32(t, P);
     uint32_t r = xh - uh;
-    if (xh < uh) r += P;
-    return umin32(r, r - P);
+    return umin32(r, r + P);
 }
 
 // a * b * 2^-32 mod P for a, b < P, from two 32-bit multiplies instead of one 64-bit one.
@@ -219,27 +219,39 @@ struct alignas(4) FpExt {
         r.c[0] -= s;
         return r;
     }
-    BB_HD FpExt operator*(const FpExt &o) const {
-        // Schoolbook product mod X^4 = 11. Cross terms are accumulated as 64-bit sums of raw
-        // products (each < 2^62 / 4 after halving the count) and reduced once per coefficient:
-        // 16 multiplies, 4 + 3 reductions instead of 16+.
-        const Fp *a = c, *b = o.c;
+    // Schoolbook product mod X^4 = 11 with the wrap-around factor folded into the right operand:
+    // with w_k = 11 b_k every coefficient is ONE 64-bit sum of four raw products (< 4 P^2 < 2^64)
+    // and one Montgomery reduction -- 16 multiply-adds and 4 reductions. The three w_k cost a
+    // multiply each, paid once per right operand: kernels that multiply many values by the same
+    // challenge (folds by r, lambda, eq weights) precompute them (Pre).
+    struct Pre {
+        Fp b[4];
+        Fp w[3];  // 11 * b[1..3]
+    };
+    BB_HD Pre pre() const {
         const Fp W = fp_const<11>();
-        // high part (terms that wrap): reduce first, multiply by 11, then add
-        Fp h0 = Fp::raw(mont_reduce_wide((uint64_t)a[1].v * b[3].v + (uint64_t)a[2].v * b[2].v +
-                                         (uint64_t)a[3].v * b[1].v));
-        Fp h1 = Fp::raw(mont_reduce((uint64_t)a[2].v * b[3].v + (uint64_t)a[3].v * b[2].v));
-        Fp h2 = a[3] * b[3];
+        Pre p;
+#pragma unroll
+        for (int i = 0; i < 4; i++) p.b[i] = c[i];
+#pragma unroll
+        for (int i = 0; i < 3; i++) p.w[i] = c[i + 1] * W;
+        return p;
+    }
+    BB_HD FpExt operator*(const Pre &o) const {
+        const Fp *a = c;
+        const Fp *b = o.b, *w = o.w - 1;  // w[k] = 11 b[k], k = 1..3
         FpExt r;
-        r.c[0] = a[0] * b[0] + W * h0;
-        r.c[1] = Fp::raw(mont_reduce((uint64_t)a[0].v * b[1].v + (uint64_t)a[1].v * b[0].v)) + W * h1;
+        r.c[0] = Fp::raw(mont_reduce_wide((uint64_t)a[0].v * b[0].v + (uint64_t)a[1].v * w[3].v +
+                                          (uint64_t)a[2].v * w[2].v + (uint64_t)a[3].v * w[1].v));
+        r.c[1] = Fp::raw(mont_reduce_wide((uint64_t)a[0].v * b[1].v + (uint64_t)a[1].v * b[0].v +
+                                          (uint64_t)a[2].v * w[3].v + (uint64_t)a[3].v * w[2].v));
         r.c[2] = Fp::raw(mont_reduce_wide((uint64_t)a[0].v * b[2].v + (uint64_t)a[1].v * b[1].v +
-                                          (uint64_t)a[2].v * b[0].v)) +
-                 W * h2;
+                                          (uint64_t)a[2].v * b[0].v + (uint64_t)a[3].v * w[3].v));
         r.c[3] = Fp::raw(mont_reduce_wide((uint64_t)a[0].v * b[3].v + (uint64_t)a[1].v * b[2].v +
                                           (uint64_t)a[2].v * b[1].v + (uint64_t)a[3].v * b[0].v));
         return r;
     }
+    BB_HD FpExt operator*(const FpExt &o) const { return *this * o.pre(); }
     BB_HD FpExt &operator+=(const FpExt &o) { return *this = *this + o; }
     BB_HD FpExt &operator-=(const FpExt &o) { return *this = *this - o; }
     BB_HD FpExt &operator*=(const FpExt &o) { return *this = *this * o; }

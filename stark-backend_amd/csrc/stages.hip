@@ -697,19 +697,22 @@ int gkr_read_fracs(FracPlanes t, uint64_t first, uint32_t n, const RedOut &ro, h
 // variable, eq1(xi_sr, X), and the product over the bound ones multiply the three sums on the host
 // (prover.hip). That makes the eq table half the size, read-only (never folded) and one load per
 // pair instead of four loads and two stores.
-__device__ __forceinline__ void gkr_pair_sums(EF (&a)[4], const EF (&b)[4], const EF &e, const EF &lambda,
+__device__ __forceinline__ void gkr_pair_sums(EF (&a)[4], const EF (&b)[4], const EF &e_in, const EF::Pre &lambda,
                                               EF (&sums)[3]) {
-    EF d[4];
-#pragma unroll
-    for (int i = 0; i < 4; i++) d[i] = b[i] - a[i];
+    const EF::Pre e = e_in.pre();
+    // p0 q1 + p1 q0 + lambda q0 q1 = p0 q1 + q0 (p1 + lambda q1); t = p1 + lambda q1 is again a
+    // line in X, so lambda costs two multiplies per pair instead of one per point: 11 extension
+    // multiplies per pair (these kernels are multiply-bound, not bandwidth-bound).
+    const EF d0 = b[0] - a[0], d1 = b[1] - a[1], d3 = b[3] - a[3];
+    EF t = a[2] + a[3] * lambda;
+    const EF td = (b[2] - a[2]) + d3 * lambda;
 #pragma unroll
     for (int xi = 0; xi < 3; xi++) {
-#pragma unroll
-        for (int i = 0; i < 4; i++) a[i] = a[i] + d[i];
-        // (p0, q0, p1, q1) at X = xi+1
-        EF pq = a[0] * a[3] + a[2] * a[1];
-        EF qq = a[1] * a[3];
-        sums[xi] = sums[xi] + e * (pq + lambda * qq);
+        a[0] = a[0] + d0;
+        a[1] = a[1] + d1;
+        a[3] = a[3] + d3;
+        t = t + td;
+        sums[xi] = sums[xi] + (a[0] * a[3] + a[1] * t) * e;
     }
 }
 
@@ -750,8 +753,9 @@ int eq_heap(const EF *d_point, uint32_t n, EFPlanes heap, hipStream_t s) {
 
 template <bool PBASE>
 __global__ __launch_bounds__(RED_THREADS) void gkr_round_kernel(FracPlanes rec, EFPlanes eq, uint64_t n_pairs,
-                                                                EF lambda, RedOut ro) {
+                                                                EF lambda_in, RedOut ro) {
     const uint64_t stride = (uint64_t)gridDim.x * RED_THREADS;
+    const EF::Pre lambda = lambda_in.pre();
     EF sums[3] = {EF::zero(), EF::zero(), EF::zero()};
     for (uint64_t y = (uint64_t)blockIdx.x * RED_THREADS + threadIdx.x; y < n_pairs; y += stride) {
         EF p[4], q[4];  // fractions 4y..4y+3 = records 2y (entries 0,1) and 2y+1 (entries 2,3)
@@ -786,8 +790,10 @@ int gkr_round(FracPlanes rec, bool p_base, EFPlanes eq, uint64_t n_pairs, EF lam
 // after the first is ONE pass over the data.
 template <bool PBASE>
 __global__ __launch_bounds__(RED_THREADS) void gkr_fold_round_kernel(FracPlanes in, EFPlanes eq, FracPlanes out,
-                                                                     uint64_t n_pairs, EF r, EF lambda, RedOut ro) {
+                                                                     uint64_t n_pairs, EF r_in, EF lambda_in,
+                                                                     RedOut ro) {
     const uint64_t stride = (uint64_t)gridDim.x * RED_THREADS;
+    const EF::Pre r = r_in.pre(), lambda = lambda_in.pre();
     EF sums[3] = {EF::zero(), EF::zero(), EF::zero()};
     for (uint64_t y = (uint64_t)blockIdx.x * RED_THREADS + threadIdx.x; y < n_pairs; y += stride) {
         EF fp[4], fq[4];
