@@ -305,6 +305,8 @@ struct Prover {
     const ProvingKey &pk;
     Ctx cx;
     Mailbox &mb;
+    // test hook: take the GKR fallback path (three evaluation points from the device) on every sub-round
+    const bool force_three_points = std::getenv("OVM_GKR_THREE_POINTS") != nullptr;
     Transcript ts;
     std::vector<TraceIn> traces;  // sorted
     ByteWriter out;
@@ -548,28 +550,47 @@ struct Prover {
                     std::vector<EF> rho;
                     EF r_prev = EF::zero();
                     EF c_bound = EF::one();  // prod_{i < sr} eq1(xi_i, r_i)
+                    // the layer's sumcheck claim: previous claims interpolated at mu = xi_prev[0], batched with lambda
+                    const auto &pc = claims.back();  // p0, p1, q0, q1
+                    EF claim = (pc[0] + (pc[1] - pc[0]) * xi_prev[0]) + lambda * (pc[2] + (pc[3] - pc[2]) * xi_prev[0]);
+                    const EF inv2 = EF::from_base(fp(2).inv());
                     for (unsigned sr = 0; sr < round; sr++) {
                         const uint64_t n_pairs = 1ull << (round - sr - 1);
                         const EFPlanes eq{heap.p + n_pairs, heap.stride};  // depth round-1-sr of the heap
+                        // s(X) = c_bound * eq1(a, X) * S(X), a = xi_sr, S quadratic. The device returns S(1), S(2);
+                        // S(0) follows from the claim s(0) + s(1) unless c_bound * (1 - a) = 0 (then: three points).
+                        const EF a = xi_prev[sr];
+                        const EF w0 = c_bound * (EF::one() - a);
+                        const unsigned n_points = (is_zero(w0) || force_three_points) ? 3 : 2;
                         if (sr == 0) {
-                            OVM_THROW_IF(gkr_round(rec, p_base && round + 1 == TR, eq, n_pairs, lambda, mb.arm(partials.p), cx.stream));
+                            OVM_THROW_IF(gkr_round(rec, p_base && round + 1 == TR, eq, n_pairs, lambda, n_points,
+                                                   mb.arm(partials.p), cx.stream));
                         } else {
                             // fold sub-round sr-1 with r_prev and get this sub-round's sums in one pass
-                            OVM_THROW_IF(gkr_fold_round(rec, p_base && round + 1 == TR && sr == 1, eq, recs[sr & 1], n_pairs, r_prev, lambda, mb.arm(partials.p),
-                                                        cx.stream));
+                            OVM_THROW_IF(gkr_fold_round(rec, p_base && round + 1 == TR && sr == 1, eq, recs[sr & 1], n_pairs,
+                                                        r_prev, lambda, n_points, mb.arm(partials.p), cx.stream));
                             rec = recs[sr & 1];
                         }
-                        auto sv = mb.take(3, cx.stream);
-                        // s(X) = c_bound * eq1(xi_sr, X) * S'(X); eq1(a, X) = a X + (1-a)(1-X) = a, 3a-1, 5a-2 at X = 1, 2, 3
-                        const EF a = xi_prev[sr];
+                        auto S = mb.take(n_points, cx.stream);  // S(1), S(2)[, S(3)]
+                        // eq1(a, X) = a X + (1-a)(1-X) = a, 3a-1, 5a-2 at X = 1, 2, 3
                         const EF a2 = a.dbl(), a3 = a2 + a, a5 = a3 + a2;
                         const EF w[3] = {c_bound * a, c_bound * (a3 - EF::one()), c_bound * (a5 - EF::one().dbl())};
-                        for (int i = 0; i < 3; i++) sv[i] = sv[i] * w[i];
+                        EF S0;
+                        if (n_points == 2) {
+                            S0 = (claim - w[0] * S[0]) * w0.inv();
+                            S.push_back(S0 - (S[0].dbl() + S[0]) + (S[1].dbl() + S[1]));  // S(3): third difference = 0
+                        } else {
+                            S0 = (S[0].dbl() + S[0]) - (S[1].dbl() + S[1]) + S[2];
+                        }
+                        std::array<EF, 3> sv = {S[0] * w[0], S[1] * w[1], S[2] * w[2]};
                         for (auto &e : sv) ts.observe_ext(e);
-                        polys.push_back({sv[0], sv[1], sv[2]});
+                        polys.push_back(sv);
                         r_prev = ts.sample_ext();
                         rho.push_back(r_prev);
                         c_bound = c_bound * (a * r_prev + (EF::one() - a) * (EF::one() - r_prev));
+                        // next claim s(r) = c_bound' * S(r), S through (0, S0), (1, S1), (2, S2)
+                        const EF rm1 = r_prev - EF::one(), rm2 = rm1 - EF::one();
+                        claim = c_bound * (S0 * (rm1 * rm2) * inv2 - S[0] * (r_prev * rm2) + S[1] * (r_prev * rm1) * inv2);
                     }
                     // last fold: one record (the layer claims)
                     OVM_THROW_IF(gkr_fold_final(rec, r_prev, mb.arm(nullptr), cx.stream));

@@ -504,7 +504,8 @@ int mle_round_eval_grouped(const Instr *d_code, const uint32_t *d_off, uint32_t 
     return red_finish(ro, gx * degree * n_groups, gx * n_groups, 2 * degree, s);
 }
 
-__global__ void fold_mle_kernel(const EF *in, EF *out, uint32_t log_h, EF r) {
+__global__ void fold_mle_kernel(const EF *in, EF *out, uint32_t log_h, EF r_in) {
+    const EF::Pre r = r_in.pre();
     const uint64_t h2 = 1ull << (log_h - 1);
     uint64_t y = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (y >= h2) return;
@@ -697,8 +698,13 @@ int gkr_read_fracs(FracPlanes t, uint64_t first, uint32_t n, const RedOut &ro, h
 // variable, eq1(xi_sr, X), and the product over the bound ones multiply the three sums on the host
 // (prover.hip). That makes the eq table half the size, read-only (never folded) and one load per
 // pair instead of four loads and two stores.
+//
+// NP = 2: only X = 1, 2. What is summed is a QUADRATIC in X once the eq factor is split off, and
+// the host knows the round's claim s(0) + s(1), so two points determine it (prover.hip); NP = 3
+// is the fallback for the (probability ~2^-124) challenges that make that division impossible.
+template <int NP>
 __device__ __forceinline__ void gkr_pair_sums(EF (&a)[4], const EF (&b)[4], const EF &e_in, const EF::Pre &lambda,
-                                              EF (&sums)[3]) {
+                                              EF (&sums)[NP]) {
     const EF::Pre e = e_in.pre();
     // p0 q1 + p1 q0 + lambda q0 q1 = p0 q1 + q0 (p1 + lambda q1); t = p1 + lambda q1 is again a
     // line in X, so lambda costs two multiplies per pair instead of one per point: 11 extension
@@ -707,7 +713,7 @@ __device__ __forceinline__ void gkr_pair_sums(EF (&a)[4], const EF (&b)[4], cons
     EF t = a[2] + a[3] * lambda;
     const EF td = (b[2] - a[2]) + d3 * lambda;
 #pragma unroll
-    for (int xi = 0; xi < 3; xi++) {
+    for (int xi = 0; xi < NP; xi++) {
         a[0] = a[0] + d0;
         a[1] = a[1] + d1;
         a[3] = a[3] + d3;
@@ -751,12 +757,14 @@ int eq_heap(const EF *d_point, uint32_t n, EFPlanes heap, hipStream_t s) {
     return 0;
 }
 
-template <bool PBASE>
+template <bool PBASE, int NP>
 __global__ __launch_bounds__(RED_THREADS) void gkr_round_kernel(FracPlanes rec, EFPlanes eq, uint64_t n_pairs,
                                                                 EF lambda_in, RedOut ro) {
     const uint64_t stride = (uint64_t)gridDim.x * RED_THREADS;
     const EF::Pre lambda = lambda_in.pre();
-    EF sums[3] = {EF::zero(), EF::zero(), EF::zero()};
+    EF sums[NP];
+#pragma unroll
+    for (int i = 0; i < NP; i++) sums[i] = EF::zero();
     for (uint64_t y = (uint64_t)blockIdx.x * RED_THREADS + threadIdx.x; y < n_pairs; y += stride) {
         EF p[4], q[4];  // fractions 4y..4y+3 = records 2y (entries 0,1) and 2y+1 (entries 2,3)
         if (PBASE)
@@ -767,34 +775,41 @@ __global__ __launch_bounds__(RED_THREADS) void gkr_round_kernel(FracPlanes rec, 
         const EF e = ldp(eq.p, eq.stride, y);
         EF a[4] = {p[0], q[0], p[1], q[1]};
         const EF b[4] = {p[2], q[2], p[3], q[3]};
-        gkr_pair_sums(a, b, e, lambda, sums);
+        gkr_pair_sums<NP>(a, b, e, lambda, sums);
     }
-    block_sum_store<3>(sums, ro.partials + (size_t)blockIdx.x * 3, ro.counter != nullptr);
-    finish_reduction<3>(ro, gridDim.x, 3);
+    block_sum_store<NP>(sums, ro.partials + (size_t)blockIdx.x * NP, ro.counter != nullptr);
+    finish_reduction<NP>(ro, gridDim.x, NP);
 }
-int gkr_round(FracPlanes rec, bool p_base, EFPlanes eq, uint64_t n_pairs, EF lambda, const RedOut &ro, hipStream_t s) {
+int gkr_round(FracPlanes rec, bool p_base, EFPlanes eq, uint64_t n_pairs, EF lambda, uint32_t n_points,
+              const RedOut &ro, hipStream_t s) {
+    if (n_points != 2 && n_points != 3) return (int)hipErrorInvalidValue;
     uint32_t grid = red_grid(n_pairs);
-    if (p_base)
-        hipLaunchKernelGGL(gkr_round_kernel<true>, dim3(grid), dim3(RED_THREADS), 0, s, rec, eq, n_pairs, lambda,
-                           red_inline(ro, grid));
-    else
-        hipLaunchKernelGGL(gkr_round_kernel<false>, dim3(grid), dim3(RED_THREADS), 0, s, rec, eq, n_pairs, lambda,
-                           red_inline(ro, grid));
+#define CALL(PB, NP)                                                                                             \
+    hipLaunchKernelGGL((gkr_round_kernel<PB, NP>), dim3(grid), dim3(RED_THREADS), 0, s, rec, eq, n_pairs, lambda, \
+                       red_inline(ro, grid))
+    if (p_base) {
+        if (n_points == 2) CALL(true, 2); else CALL(true, 3);
+    } else {
+        if (n_points == 2) CALL(false, 2); else CALL(false, 3);
+    }
+#undef CALL
     OVM_CHECK_LAUNCH();
-    return red_finish(ro, grid, grid, 3, s);
+    return red_finish(ro, grid, grid, n_points, s);
 }
 
 // Fused "fold with r, then next round's sums": output pair y is built from input records
 // 4y..4y+3 = fractions 8y..8y+7; the two folded records (fractions 4y..4y+3 of the output) are
 // stored and immediately used for the degree-3 round sums with weight eq[y], so every sub-round
 // after the first is ONE pass over the data.
-template <bool PBASE>
+template <bool PBASE, int NP>
 __global__ __launch_bounds__(RED_THREADS) void gkr_fold_round_kernel(FracPlanes in, EFPlanes eq, FracPlanes out,
                                                                      uint64_t n_pairs, EF r_in, EF lambda_in,
                                                                      RedOut ro) {
     const uint64_t stride = (uint64_t)gridDim.x * RED_THREADS;
     const EF::Pre r = r_in.pre(), lambda = lambda_in.pre();
-    EF sums[3] = {EF::zero(), EF::zero(), EF::zero()};
+    EF sums[NP];
+#pragma unroll
+    for (int i = 0; i < NP; i++) sums[i] = EF::zero();
     for (uint64_t y = (uint64_t)blockIdx.x * RED_THREADS + threadIdx.x; y < n_pairs; y += stride) {
         EF fp[4], fq[4];
         {
@@ -822,22 +837,26 @@ __global__ __launch_bounds__(RED_THREADS) void gkr_fold_round_kernel(FracPlanes 
         const EF e = ldp(eq.p, eq.stride, y);
         EF a[4] = {fp[0], fq[0], fp[1], fq[1]};
         const EF b[4] = {fp[2], fq[2], fp[3], fq[3]};
-        gkr_pair_sums(a, b, e, lambda, sums);
+        gkr_pair_sums<NP>(a, b, e, lambda, sums);
     }
-    block_sum_store<3>(sums, ro.partials + (size_t)blockIdx.x * 3, ro.counter != nullptr);
-    finish_reduction<3>(ro, gridDim.x, 3);
+    block_sum_store<NP>(sums, ro.partials + (size_t)blockIdx.x * NP, ro.counter != nullptr);
+    finish_reduction<NP>(ro, gridDim.x, NP);
 }
 int gkr_fold_round(FracPlanes in, bool in_p_base, EFPlanes eq, FracPlanes out, uint64_t n_pairs, EF r, EF lambda,
-                   const RedOut &ro, hipStream_t s) {
+                   uint32_t n_points, const RedOut &ro, hipStream_t s) {
+    if (n_points != 2 && n_points != 3) return (int)hipErrorInvalidValue;
     uint32_t grid = red_grid(n_pairs);
-    if (in_p_base)
-        hipLaunchKernelGGL(gkr_fold_round_kernel<true>, dim3(grid), dim3(RED_THREADS), 0, s, in, eq, out, n_pairs, r,
-                           lambda, red_inline(ro, grid));
-    else
-        hipLaunchKernelGGL(gkr_fold_round_kernel<false>, dim3(grid), dim3(RED_THREADS), 0, s, in, eq, out, n_pairs, r,
-                           lambda, red_inline(ro, grid));
+#define CALL(PB, NP)                                                                                               \
+    hipLaunchKernelGGL((gkr_fold_round_kernel<PB, NP>), dim3(grid), dim3(RED_THREADS), 0, s, in, eq, out, n_pairs, r, \
+                       lambda, red_inline(ro, grid))
+    if (in_p_base) {
+        if (n_points == 2) CALL(true, 2); else CALL(true, 3);
+    } else {
+        if (n_points == 2) CALL(false, 2); else CALL(false, 3);
+    }
+#undef CALL
     OVM_CHECK_LAUNCH();
-    return red_finish(ro, grid, grid, 3, s);
+    return red_finish(ro, grid, grid, n_points, s);
 }
 
 // Last fold of a layer: two records -> the layer's claims, written as out[0..4) = (p0, q0, p1, q1).
@@ -1033,12 +1052,13 @@ int whir_round(const EF *f, const EF *w, uint64_t n_pairs, const RedOut &ro, hip
     return red_finish(ro, grid, grid, 2, s);
 }
 
-__global__ void whir_fold_kernel(const EF *f_in, const EF *w_in, EF *f_out, EF *w_out, uint64_t n_out, EF alpha) {
+__global__ void whir_fold_kernel(const EF *f_in, const EF *w_in, EF *f_out, EF *w_out, uint64_t n_out, EF alpha_in) {
     uint64_t y = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (y >= n_out) return;
+    const EF::Pre alpha = alpha_in.pre();
     EF f0 = ld_ef(f_in + 2 * y), f1 = ld_ef(f_in + 2 * y + 1), w0 = ld_ef(w_in + 2 * y), w1 = ld_ef(w_in + 2 * y + 1);
-    st_ef(f_out + y, f0 + alpha * (f1 - f0));
-    st_ef(w_out + y, w0 + alpha * (w1 - w0));
+    st_ef(f_out + y, f0 + (f1 - f0) * alpha);
+    st_ef(w_out + y, w0 + (w1 - w0) * alpha);
 }
 int whir_fold(const EF *f_in, const EF *w_in, EF *f_out, EF *w_out, uint64_t n_out, EF alpha, hipStream_t s) {
     hipLaunchKernelGGL(whir_fold_kernel, dim3(ceil_div(n_out, 256)), dim3(256), 0, s, f_in, w_in, f_out, w_out, n_out,

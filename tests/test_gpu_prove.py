@@ -110,3 +110,13 @@ def test_config_c_shape_verifies(dev, pkg, orc):
         traces.append((i, torch.randint(0, 2, (100 * h,), dtype=torch.int32, device="cuda:0", generator=gen) * one, h, []))
     proof, _ = dev.prove(pk, traces)
     orc.verify(blob, proof)
+
+
+def test_gkr_three_point_fallback(dev, pkg, orc, monkeypatch):
+    """The GKR sub-rounds normally take two evaluation points from the device and derive the third
+    from the running claim; the fallback for degenerate challenges must give the same bytes."""
+    monkeypatch.setenv("OVM_GKR_THREE_POINTS", "1")
+    params = airs.test_params(l_skip=4, n_stack=8, k_whir=4)
+    h = 1 << 8
+    tr = airs.splitmix64_bits(0xD15EA5E, 20 * h)
+    run_case(dev, pkg, orc, params, [airs.uniform_runner_air(20)], [(0, tr, h, [])])
