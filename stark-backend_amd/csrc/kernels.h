@@ -59,6 +59,7 @@ int mobius_eq_table(const EF *d_point, uint32_t n, EF *out, hipStream_t s);
 
 // Coset low-degree extension of the used columns of one trace view.
 //   lde[(k * n_cols_total + col) << log_lifted | p] for k < n_cosets, col in used_cols
+//   d_shift_pows[k * 2^l_skip + i] = shift_k^i / 2^l_skip
 int coset_lde(const ColDesc *d_cols, const uint32_t *d_used, uint32_t n_used, uint32_t n_cols_total,
               uint32_t log_lifted, uint32_t l_skip, uint32_t n_cosets, const Fp *d_shift_pows, Fp *lde,
               hipStream_t s);

@@ -712,7 +712,7 @@ struct Prover {
                     if (usedm[c]) used.push_back((uint32_t)c);
                 std::vector<Fp> shift_pows(n_cosets * N);
                 for (unsigned k = 0; k < n_cosets; k++) {
-                    Fp sh = g.pow(k + 1), cur = Fp::one();
+                    Fp sh = g.pow(k + 1), cur = fp((uint64_t)N).inv();  // shift^i / N: iDFT scale folded in
                     for (size_t i = 0; i < N; i++) {
                         shift_pows[k * N + i] = cur;
                         cur *= sh;

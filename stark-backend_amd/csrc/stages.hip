@@ -300,17 +300,101 @@ __global__ __launch_bounds__(LDE_THREADS) void coset_lde_kernel(const ColDesc *c
     }
 }
 
+// Register form for 16-row chunks (l_skip = 4, the production parameter): a lane owns one chunk.
+// Every twiddle is a compile-time constant (powers of omega_16), so the chunk costs 17 multiplies
+// for the inverse transform and 16 + 17 per coset instead of 32 generic ones per transform with a
+// table lookup each, and there is no LDS traffic or barrier at all.
+#define W16P(j) bb::cx_to_mont(bb::cx_powmod(bb::TWO_ADIC_GENERATORS[4], (j)))
+static constexpr uint32_t LDE_W16[8] = {W16P(0), W16P(1), W16P(2), W16P(3), W16P(4), W16P(5), W16P(6), W16P(7)};
+static constexpr uint32_t LDE_W16_INV[8] = {W16P(0),  W16P(15), W16P(14), W16P(13),
+                                            W16P(12), W16P(11), W16P(10), W16P(9)};
+#undef W16P
+__device__ __forceinline__ constexpr int bitrev4(int i) {
+    return ((i & 1) << 3) | ((i & 2) << 1) | ((i & 4) >> 1) | ((i & 8) >> 3);
+}
+
+__global__ __launch_bounds__(256) void coset_lde16_kernel(const ColDesc *cols, const uint32_t *used,
+                                                          uint32_t n_cols_total, uint32_t log_lifted,
+                                                          uint32_t n_cosets, const Fp *twist, Fp *lde) {
+    const uint64_t chunk = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (chunk >= (1ull << (log_lifted - 4))) return;
+    const uint32_t col = used[blockIdx.y];
+    const ColDesc cd = cols[col];
+    const uint64_t hmask = (1ull << cd.log_height) - 1, base = chunk << 4;
+    Fp x[16];
+    if (cd.rot == 0 && cd.log_height >= 4) {
+        const uint4 *src = reinterpret_cast<const uint4 *>(cd.ptr + (base & hmask));
+#pragma unroll
+        for (int v = 0; v < 4; v++) {
+            uint4 q = src[v];
+            x[4 * v] = Fp::raw(q.x);
+            x[4 * v + 1] = Fp::raw(q.y);
+            x[4 * v + 2] = Fp::raw(q.z);
+            x[4 * v + 3] = Fp::raw(q.w);
+        }
+    } else {
+#pragma unroll
+        for (int z = 0; z < 16; z++) x[z] = cd.ptr[(base + z + cd.rot) & hmask];
+    }
+    // inverse DIF, natural -> bit-reversed coefficients (unscaled; 1/16 is folded into `twist`)
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int bit = 3 - k, half = 1 << bit;
+#pragma unroll
+        for (int j = 0; j < half; j++) {
+#pragma unroll
+            for (int g = 0; g < 16; g += 2 * half) {
+                Fp a = x[g + j], b = x[g + j + half];
+                x[g + j] = a + b;
+                Fp d = a - b;
+                x[g + j + half] = j == 0 ? d : d * Fp::raw(LDE_W16_INV[j << (3 - bit)]);
+            }
+        }
+    }
+    for (uint32_t c = 0; c < n_cosets; c++) {
+        Fp y[16];
+        // twist: the coefficient of degree bitrev(i) sits in register i
+#pragma unroll
+        for (int i = 0; i < 16; i++) y[i] = x[i] * twist[c * 16 + bitrev4(i)];
+        // forward DIT, bit-reversed coefficients -> natural evaluations
+#pragma unroll
+        for (int bit = 0; bit < 4; bit++) {
+            const int half = 1 << bit;
+#pragma unroll
+            for (int g = 0; g < 16; g += 2 * half) {
+#pragma unroll
+                for (int j = 0; j < half; j++) {
+                    Fp a = y[g + j], b = y[g + j + half];
+                    if (j) b = b * Fp::raw(LDE_W16[j << (3 - bit)]);
+                    y[g + j] = a + b;
+                    y[g + j + half] = a - b;
+                }
+            }
+        }
+        uint4 *dst = reinterpret_cast<uint4 *>(lde + (((uint64_t)c * n_cols_total + col) << log_lifted) + base);
+#pragma unroll
+        for (int v = 0; v < 4; v++) dst[v] = make_uint4(y[4 * v].v, y[4 * v + 1].v, y[4 * v + 2].v, y[4 * v + 3].v);
+    }
+}
+
 int coset_lde(const ColDesc *d_cols, const uint32_t *d_used, uint32_t n_used, uint32_t n_cols_total,
               uint32_t log_lifted, uint32_t l_skip, uint32_t n_cosets, const Fp *d_shift_pows, Fp *lde,
               hipStream_t s) {
     if (n_used == 0 || n_cosets == 0) return 0;
     const Twiddles *tw = twiddles();
     if (!tw || l_skip > LDE_TILE_LOG || l_skip > log_lifted) return (int)hipErrorInvalidValue;
+    // d_shift_pows[k * N + i] = shift_k^i / N (the caller folds 1/N in)
+    if (l_skip == 4) {
+        dim3 grid16((unsigned)ceil_div(1ull << (log_lifted - 4), 256), n_used);
+        hipLaunchKernelGGL(coset_lde16_kernel, grid16, dim3(256), 0, s, d_cols, d_used, n_cols_total, log_lifted,
+                           n_cosets, d_shift_pows, lde);
+        OVM_CHECK_LAUNCH();
+        return 0;
+    }
     uint32_t tile_log = log_lifted < LDE_TILE_LOG ? log_lifted : LDE_TILE_LOG;
     dim3 grid(1u << (log_lifted - tile_log), n_used);
-    Fp inv_n = Fp::from_canonical(1u << l_skip).inv();
     hipLaunchKernelGGL(coset_lde_kernel, grid, dim3(LDE_THREADS), 2 * sizeof(Fp) << tile_log, s, d_cols, d_used,
-                       n_cols_total, log_lifted, l_skip, tile_log, n_cosets, d_shift_pows, inv_n, lde, *tw);
+                       n_cols_total, log_lifted, l_skip, tile_log, n_cosets, d_shift_pows, Fp::one(), lde, *tw);
     OVM_CHECK_LAUNCH();
     return 0;
 }
