@@ -122,6 +122,55 @@ __global__ __launch_bounds__(NTT_THREADS) void eval_to_coeff_kernel(
     }
 }
 
+// Register form of the message transform for 16-row chunks (l_skip = 4): a lane owns one chunk,
+// all twiddles are compile-time powers of omega_16^-1, no LDS. In register i sits the coefficient
+// of degree bitrev4(i) after the DIF; the zeta transform runs on register-index bits (it is
+// invariant under the bit permutation) and the store undoes the permutation.
+#define W16P(j) bb::cx_to_mont(bb::cx_powmod(bb::TWO_ADIC_GENERATORS[4], (j)))
+static constexpr uint32_t W16_INV[8] = {W16P(0), W16P(15), W16P(14), W16P(13), W16P(12), W16P(11), W16P(10), W16P(9)};
+#undef W16P
+__global__ __launch_bounds__(256) void eval_to_coeff16_kernel(const Fp *__restrict__ in, Fp *__restrict__ out,
+                                                              uint64_t n_chunks, Fp inv_chunk) {
+    const uint64_t chunk = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (chunk >= n_chunks) return;
+    Fp x[16];
+    const uint4 *src = reinterpret_cast<const uint4 *>(in + (chunk << 4));
+#pragma unroll
+    for (int v = 0; v < 4; v++) {
+        uint4 q = src[v];
+        x[4 * v] = Fp::raw(q.x);
+        x[4 * v + 1] = Fp::raw(q.y);
+        x[4 * v + 2] = Fp::raw(q.z);
+        x[4 * v + 3] = Fp::raw(q.w);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int bit = 3 - k, half = 1 << bit;
+#pragma unroll
+        for (int j = 0; j < half; j++) {
+#pragma unroll
+            for (int g = 0; g < 16; g += 2 * half) {
+                Fp a = x[g + j], b = x[g + j + half];
+                x[g + j] = a + b;
+                Fp d = a - b;
+                x[g + j + half] = j == 0 ? d : d * Fp::raw(W16_INV[j << (3 - bit)]);
+            }
+        }
+    }
+#pragma unroll
+    for (int bit = 0; bit < 4; bit++) {
+#pragma unroll
+        for (int i = 0; i < 16; i++)
+            if (i & (1 << bit)) x[i] = x[i] + x[i ^ (1 << bit)];
+    }
+    auto br = [](int i) { return ((i & 1) << 3) | ((i & 2) << 1) | ((i & 4) >> 1) | ((i & 8) >> 3); };
+    uint4 *dst = reinterpret_cast<uint4 *>(out + (chunk << 4));
+#pragma unroll
+    for (int v = 0; v < 4; v++)
+        dst[v] = make_uint4((x[br(4 * v)] * inv_chunk).v, (x[br(4 * v + 1)] * inv_chunk).v,
+                            (x[br(4 * v + 2)] * inv_chunk).v, (x[br(4 * v + 3)] * inv_chunk).v);
+}
+
 // ---------------------------------------------------------------------------------------------
 // One DIF pass: stages s0 .. s0+r-1 of a 2^L-point transform on every column.
 //   position p = (hi << (beta + r)) | (t << beta) | (mid << c) | cc ,  beta = L - s0 - r >= c
@@ -428,6 +477,14 @@ int ovm_hip_eval_to_coeff(const uint32_t *d_in, uint32_t *d_out, uint64_t width,
     const Twiddles *tw = twiddles();
     if (!tw) return (int)hipErrorInvalidValue;
     OVM_PROF("ntt.eval_to_coeff", stream);
+    if (l_skip == 4) {
+        // columns are contiguous (column stride = 2^log_height), so the chunks of all columns form one array
+        const uint64_t n_chunks = width << (log_height - 4);
+        hipLaunchKernelGGL(eval_to_coeff16_kernel, dim3((unsigned)((n_chunks + 255) / 256)), dim3(256), 0, stream,
+                           (const Fp *)d_in, (Fp *)d_out, n_chunks, Fp::from_canonical(16).inv());
+        OVM_CHECK_LAUNCH();
+        return 0;
+    }
     uint32_t tile_log = log_height < (uint32_t)NTT_TILE_LOG ? log_height : (uint32_t)NTT_TILE_LOG;
     dim3 grid(1u << (log_height - tile_log), (unsigned)width);
     Fp inv_chunk = Fp::from_canonical(1u << l_skip).inv();
