@@ -114,8 +114,8 @@ BB_HD void internal_linear(Fp *s) {
     s[7] = sum - (s[7].dbl() + s[7]);
     s[8] = sum - s[8].dbl().dbl();
     s[9] = sum + mul_2exp_neg<8>(s[9]);
-    s[10] = sum + s[10].halve().halve();
-    s[11] = sum + s[11].halve().halve().halve();
+    s[10] = sum + mul_2exp_neg<2>(s[10]);
+    s[11] = sum + mul_2exp_neg<3>(s[11]);
     s[12] = sum + mul_2exp_neg<27>(s[12]);
     s[13] = sum - mul_2exp_neg<8>(s[13]);
     s[14] = sum - mul_2exp_neg<4>(s[14]);

@@ -269,6 +269,7 @@ struct PcsData {
     Layout layout;
     unsigned log_height = 0, log_rows = 0, k = 0;
     DevBuf<Fp> stacked, msg, codeword;
+    const Fp *stacked_view = nullptr;  // the stacked matrix: `stacked`, or the caller's trace when that IS the matrix
     DevBuf<p2::Digest> layers;
     p2::Digest root;
     size_t query_stride() const { return size_t(1) << (log_rows - k); }
@@ -337,10 +338,20 @@ struct Prover {
         const size_t H = size_t(1) << lh, width = (total_cells + H - 1) / H;
         if (width != d.layout.width) throw OvmFail(1, "stacked width mismatch");
         d.log_height = lh;
-        d.stacked.alloc(width * H);
         ProfScope *ps_stack = new ProfScope("commit.stack", cx.stream);
-        OVM_THROW_IF(hipMemsetAsync(d.stacked.p, 0, width * H * sizeof(Fp), cx.stream));
-        for (size_t t = 0; t < traces.size(); t++) {
+        // Column-major traces stack by concatenation, so ONE trace that fills the matrix exactly already is
+        // the stacked matrix (config D: 100 columns of 2^22 = 25 columns of 2^24): no copy, the trace is
+        // only ever read. Otherwise: one device copy per trace into a zero-padded buffer.
+        const bool alias = traces.size() == 1 && traces[0].height >= (size_t(1) << l_skip) &&
+                           traces[0].height * air(0).common_main_width == width * H;
+        if (alias) {
+            d.stacked_view = traces[0].d_trace;
+        } else {
+            d.stacked.alloc(width * H);
+            d.stacked_view = d.stacked.p;
+            OVM_THROW_IF(hipMemsetAsync(d.stacked.p, 0, width * H * sizeof(Fp), cx.stream));
+        }
+        for (size_t t = 0; t < traces.size() && !alias; t++) {
             size_t w = air(t).common_main_width, h = traces[t].height;
             if (w == 0) continue;
             const Slice &s0 = d.layout.cols[d.layout.mat_starts[t]].slice;
@@ -361,7 +372,7 @@ struct Prover {
         }
         delete ps_stack;
         d.msg.alloc(width * H);
-        OVM_THROW_IF(ovm_hip_eval_to_coeff((const uint32_t *)d.stacked.p, (uint32_t *)d.msg.p, width, lh, l_skip, cx.stream));
+        OVM_THROW_IF(ovm_hip_eval_to_coeff((const uint32_t *)d.stacked_view, (uint32_t *)d.msg.p, width, lh, l_skip, cx.stream));
         d.log_rows = lh + P().log_blowup;
         d.k = P().k_whir;
         d.codeword.alloc(width << d.log_rows);
@@ -1098,7 +1109,7 @@ struct Prover {
             auto d_leq = cx.upload(leq);
             auto d_lrot = cx.upload(lrot);
             unsigned log_len = std::max(wd.log_height, l_skip);
-            const Fp *base = pcs.stacked.p + tvs[w0].s.col_idx * H + tvs[w0].s.row_idx;
+            const Fp *base = pcs.stacked_view + tvs[w0].s.col_idx * H + tvs[w0].s.row_idx;
             OVM_THROW_IF(stacked_round0(base, (uint32_t)(w1 - w0), log_len, l_skip, d_leq.p, d_lrot.p, wd.eq_cube.p,
                                         mb.arm(partials.p), cx.stream));
             auto R = mb.take(3 * N, cx.stream);
@@ -1148,7 +1159,7 @@ struct Prover {
             for (size_t z = 0; z < N; z++) wts[z] = un * (u0 - omega_pows[z]).inv() * (omega_pows[z] * ninv);
             auto d_w = cx.upload(wts);
             std::vector<ColDesc> cd(width);
-            for (size_t c = 0; c < width; c++) cd[c] = ColDesc{pcs.stacked.p + c * H, l_skip + n_stack, 0};
+            for (size_t c = 0; c < width; c++) cd[c] = ColDesc{pcs.stacked_view + c * H, l_skip + n_stack, 0};
             auto d_cd = cx.upload(cd);
             OVM_THROW_IF(fold_ple(d_cd.p, (uint32_t)width, l_skip + n_stack, l_skip, d_w.p, q_a.p, cx.stream));
             cx.sync();
