@@ -33,7 +33,7 @@ def main():
     ap.add_argument("--log-rows", type=int, default=22)
     ap.add_argument("--cols", type=int, default=100)
     ap.add_argument("--log-stacked-height", type=int, default=24)
-    ap.add_argument("--cpu-log-rows", type=int, default=16, help="rows of the CPU-baseline sample")
+    ap.add_argument("--cpu-log-rows", type=int, default=18, help="rows of the CPU-baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--zero-trace", action="store_true",
                     help="all-zero trace (what the reference's uniform_runner proves) instead of seeded random bits")
@@ -110,7 +110,7 @@ def main():
             # command (profiles/r01/pmc_hbm_traffic_*.json, gfx950 x2 fetch correction applied); only valid
             # for the default workload, null otherwise
             traffic = None
-            pmc = os.path.join(ROOT, "profiles", "r01", "pmc_hbm_traffic_v2.json")
+            pmc = os.path.join(ROOT, "profiles", "r01", "pmc_hbm_traffic_v5.json")
             if (log_rows, cols, args.log_stacked_height) == (22, 100, 24) and os.path.exists(pmc):
                 k = json.load(open(pmc))["kernels"].get("hash_rows_kernel<1>")
                 if k:
@@ -118,8 +118,18 @@ def main():
             roof = {"kernel": "hash_rows_kernel<1> (Poseidon2 leaf hash; integer-ALU bound, see DESIGN.md)",
                     "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                    "traffic_source": "profiles/r01/pmc_hbm_traffic_v2.json (PMC pass, not live)" if traffic else None,
+                    "traffic_source": "profiles/r01/pmc_hbm_traffic_v5.json (PMC pass, not live)" if traffic else None,
                     "avg_launch_ms": round(total_ms / calls, 3), "algorithmic_bytes": algo_bytes}
+            # The kernel is VALU-issue bound, not HBM bound: report that view too. 7233 VALU instructions per
+            # permutation (static count, tools/isa_count.py on merkle.hip); nominal issue peak = CUs x 4 SIMDs x
+            # 16 lanes x clock = one wave64 instruction per 4 cycles per SIMD.
+            perms = rows * ((width + 7) // 8)
+            props = torch.cuda.get_device_properties(local_rank)
+            valu_peak = props.multi_processor_count * 4 * 16 * 2.4e9
+            roof["issue_bound"] = {"valu_instr_per_permutation": 7233, "permutations": perms,
+                                   "achieved_Tlaneops": round(7233 * perms / avg_s / 1e12, 2),
+                                   "nominal_peak_Tlaneops": round(valu_peak / 1e12, 2),
+                                   "frac": round(7233 * perms / avg_s / valu_peak, 3)}
         cpu = None
         if not args.no_cpu_baseline:
             import oracle_lib
