@@ -181,6 +181,47 @@ int ovm_hip_trim(void);
 /* Message of the last failing call on this thread (empty if none). */
 const char *ovm_hip_last_error(void);
 
+/* ---- stage-level entries: the three backend traits of crates/stark-backend/src/prover/hal.rs ----
+ * A Rust `HipDevice` implements TraceCommitter / MultiRapProver / OpeningProver with one call each
+ * and leaves `Coordinator::prove` (prover/mod.rs:104-197), the proof header and the transcript
+ * observations between the stages to the reference's own code. The sponge is the host twin of the
+ * transcript state (reference: DeviceSpongeState, crates/cuda-backend/src/sponge.rs:39-48), read
+ * at entry and written back at exit. Traces may be passed in any order; the stages sort them as
+ * `ProvingContext::into_sorted` does (prover/types.rs:137-148). */
+typedef struct ovm_pcs ovm_pcs_t; /* opaque StackedPcsData: stacked matrix, codeword, Merkle layers */
+
+/* TraceCommitter::commit (hal.rs:84-87; CUDA backend: crates/cuda-backend/src/stacked_pcs.rs:
+ * 229-337 + merkle_tree.rs): stack, eval->coeff, RS encode, Merkle tree. commitment_out = root
+ * (Montgomery words). When one trace fills the stacked matrix exactly the PCS data aliases the
+ * trace buffer instead of copying it: keep the traces alive until prove_openings has returned
+ * (the reference's ctx owns them for exactly that long, hal.rs:123-137). Synchronises the stream. */
+int ovm_hip_commit(const ovm_pk_t *pk, uint32_t n_traces, const uint32_t *air_idx,
+                   const uint32_t *const *d_traces, const uint64_t *heights, uint32_t commitment_out[8],
+                   ovm_pcs_t **pcs_out, ovm_stream_t stream);
+void ovm_hip_pcs_free(ovm_pcs_t *pcs);
+
+/* MultiRapProver::prove_rap_constraints (hal.rs:94-112; CUDA backend: crates/cuda-backend/src/
+ * logup_zerocheck/mod.rs): LogUp PoW + GKR, zerocheck/logup batch sumcheck, column openings.
+ * out = GkrProof bytes (gkr_len) followed by BatchConstraintProof bytes, each in the encoding of
+ * proof.rs:226-421 (`GkrProof::decode` / `BatchConstraintProof::decode` read them).
+ * r_out = the sumcheck point (the trait's `Artifacts = Vec<EF>`), 4 Montgomery words per element,
+ * r_len elements. Synchronises the stream. */
+int ovm_hip_prove_rap_constraints(const ovm_pk_t *pk, uint32_t n_traces, const uint32_t *air_idx,
+                                  const uint32_t *const *d_traces, const uint64_t *heights,
+                                  const uint32_t *const *public_values, const uint32_t *num_public_values,
+                                  ovm_sponge_t *sponge, uint8_t *out, uint64_t out_cap, uint64_t *gkr_len,
+                                  uint64_t *total_len, uint32_t *r_out, uint32_t r_cap, uint32_t *r_len,
+                                  ovm_stream_t stream);
+
+/* OpeningProver::prove_openings (hal.rs:118-138; CUDA backend: stacked_reduction.rs + whir.rs):
+ * stacked opening reduction and WHIR over the common-main PCS data (consumed logically: free it
+ * afterwards). out = StackingProof bytes (stacking_len) followed by WhirProof bytes.
+ * Synchronises the stream. */
+int ovm_hip_prove_openings(const ovm_pk_t *pk, uint32_t n_traces, const uint32_t *air_idx,
+                           const uint64_t *heights, ovm_pcs_t *common_main, const uint32_t *r, uint32_t r_len,
+                           ovm_sponge_t *sponge, uint8_t *out, uint64_t out_cap, uint64_t *stacking_len,
+                           uint64_t *total_len, ovm_stream_t stream);
+
 /* `Coordinator::prove` for traces already resident on the device (reference:
  * crates/stark-backend/src/prover/mod.rs:104-197 driving hal.rs:84-138): commits the common main
  * traces, proves the constraints (LogUp-GKR + batch sumcheck) and the openings (stacked reduction

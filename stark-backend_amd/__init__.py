@@ -82,6 +82,13 @@ SIGNATURES = {
     "ovm_hip_pk_free": (None, [c_void_p]),
     "ovm_hip_last_error": (c_char_p, []),
     "ovm_hip_trim": (c_int, []),
+    "ovm_hip_commit": (c_int, [c_void_p, c_uint32, c_void_p, c_void_p, c_void_p, c_void_p, POINTER(c_void_p), c_void_p]),
+    "ovm_hip_pcs_free": (None, [c_void_p]),
+    "ovm_hip_prove_rap_constraints": (c_int, [c_void_p, c_uint32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                              POINTER(SpongeState), c_void_p, c_uint64, _u64p, _u64p, c_void_p,
+                                              c_uint32, _u32p, c_void_p]),
+    "ovm_hip_prove_openings": (c_int, [c_void_p, c_uint32, c_void_p, c_void_p, c_void_p, c_void_p, c_uint32,
+                                       POINTER(SpongeState), c_void_p, c_uint64, _u64p, _u64p, c_void_p]),
     "ovm_hip_prove": (c_int, [c_void_p, c_uint32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                               POINTER(SpongeState), c_void_p, c_uint64, _u64p, _u64p, c_void_p]),
 }
@@ -274,6 +281,93 @@ def _prove(self, pk: ProvingKey, traces, sponge: SpongeState | None = None, proo
 
 
 Device.prove = _prove
+
+
+# ---- stage-level entries (TraceCommitter / MultiRapProver / OpeningProver, hal.rs:84-138) ------
+class PcsData:
+    """Opaque ``ovm_pcs_t`` handle returned by ``Device.commit_traces``."""
+
+    def __init__(self, handle, root):
+        self.handle = handle
+        self.root = root  # 8 Montgomery words
+
+    def free(self):
+        if self.handle:
+            _lib().ovm_hip_pcs_free(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def _stage_args(traces):
+    n = len(traces)
+    air_idx = np.array([t[0] for t in traces], dtype=np.uint32)
+    heights = np.array([t[2] for t in traces], dtype=np.uint64)
+    tptr = (c_void_p * n)(*[t[1].data_ptr() for t in traces])
+    return n, air_idx, heights, tptr
+
+
+def _fail(rc, what):
+    msg = _lib().ovm_hip_last_error()
+    raise OvmError(rc, f"{what} [{msg.decode() if msg else ''}]")
+
+
+def _commit_traces(self, pk: ProvingKey, traces) -> PcsData:
+    """TraceCommitter::commit. traces as for ``prove`` (public values ignored)."""
+    n, air_idx, heights, tptr = _stage_args(traces)
+    root = np.zeros(8, dtype=np.uint32)
+    h = c_void_p(0)
+    rc = _lib().ovm_hip_commit(pk.handle, n, air_idx.ctypes.data, tptr, heights.ctypes.data, root.ctypes.data,
+                               ctypes.byref(h), self.stream)
+    if rc != 0:
+        _fail(rc, "ovm_hip_commit")
+    return PcsData(h, root)
+
+
+def _prove_rap_constraints(self, pk: ProvingKey, traces, sponge: SpongeState, cap: int = 1 << 24):
+    """MultiRapProver::prove_rap_constraints. Returns (GkrProof bytes, BatchConstraintProof bytes,
+    r as an (n, 4) array of Montgomery words); ``sponge`` is updated in place."""
+    n, air_idx, heights, tptr = _stage_args(traces)
+    pvs = [to_mont(np.array(t[3], dtype=np.uint32)) if len(t[3]) else np.zeros(1, np.uint32) for t in traces]
+    npv = np.array([len(t[3]) for t in traces], dtype=np.uint32)
+    pptr = (c_void_p * n)(*[a.ctypes.data for a in pvs])
+    out = np.zeros(cap, dtype=np.uint8)
+    gkr_len, total = c_uint64(0), c_uint64(0)
+    r = np.zeros(4 * 256, dtype=np.uint32)
+    r_len = c_uint32(0)
+    rc = _lib().ovm_hip_prove_rap_constraints(pk.handle, n, air_idx.ctypes.data, tptr, heights.ctypes.data, pptr,
+                                              npv.ctypes.data, ctypes.byref(sponge), out.ctypes.data, cap,
+                                              ctypes.byref(gkr_len), ctypes.byref(total), r.ctypes.data, 256,
+                                              ctypes.byref(r_len), self.stream)
+    if rc != 0:
+        _fail(rc, "ovm_hip_prove_rap_constraints")
+    b = out[:total.value].tobytes()
+    return b[:gkr_len.value], b[gkr_len.value:], r[:4 * r_len.value].reshape(-1, 4).copy()
+
+
+def _prove_openings(self, pk: ProvingKey, traces, pcs: PcsData, r: np.ndarray, sponge: SpongeState,
+                    cap: int = 1 << 26):
+    """OpeningProver::prove_openings. Returns (StackingProof bytes, WhirProof bytes)."""
+    n, air_idx, heights, _ = _stage_args(traces)
+    rr = np.ascontiguousarray(r, dtype=np.uint32).reshape(-1)
+    out = np.zeros(cap, dtype=np.uint8)
+    st_len, total = c_uint64(0), c_uint64(0)
+    rc = _lib().ovm_hip_prove_openings(pk.handle, n, air_idx.ctypes.data, heights.ctypes.data, pcs.handle,
+                                       rr.ctypes.data, rr.size // 4, ctypes.byref(sponge), out.ctypes.data, cap,
+                                       ctypes.byref(st_len), ctypes.byref(total), self.stream)
+    if rc != 0:
+        _fail(rc, "ovm_hip_prove_openings")
+    b = out[:total.value].tobytes()
+    return b[:st_len.value], b[st_len.value:]
+
+
+Device.commit_traces = _commit_traces
+Device.prove_rap_constraints = _prove_rap_constraints
+Device.prove_openings = _prove_openings
 
 
 def profile_enable(on: bool) -> None:

@@ -1519,7 +1519,8 @@ struct Prover {
     // -----------------------------------------------------------------------------------------
     // Coordinator::prove
     // -----------------------------------------------------------------------------------------
-    void prove(std::vector<TraceIn> in) {
+    // ProvingContext::into_sorted (prover/types.rs:137-148): height descending, AIR index ascending
+    void set_traces(std::vector<TraceIn> in, bool need_public_values = true) {
         traces = std::move(in);
         std::stable_sort(traces.begin(), traces.end(), [](const TraceIn &a, const TraceIn &b) {
             if (a.height != b.height) return a.height > b.height;
@@ -1527,8 +1528,13 @@ struct Prover {
         });
         for (auto &t : traces) {
             if (t.air_idx >= pk.airs.size()) throw OvmFail(1, "air index out of range");
-            if (t.public_values.size() != pk.airs[t.air_idx].num_public_values) throw OvmFail(1, "public values length");
+            if (need_public_values && t.public_values.size() != pk.airs[t.air_idx].num_public_values)
+                throw OvmFail(1, "public values length");
         }
+    }
+
+    void prove(std::vector<TraceIn> in) {
+        set_traces(std::move(in));
         ts.observe_digest(pk.vk_pre_hash);
         wt.mark("setup");
         PcsData pcs = commit();
@@ -1580,6 +1586,53 @@ struct Prover {
 
 using namespace ovm;
 
+static thread_local std::string g_last_error;
+
+namespace {
+std::vector<TraceIn> traces_from_abi(uint32_t n_traces, const uint32_t *air_idx, const uint32_t *const *d_traces,
+                                     const uint64_t *heights, const uint32_t *const *public_values,
+                                     const uint32_t *num_public_values) {
+    std::vector<TraceIn> in;
+    for (uint32_t t = 0; t < n_traces; t++) {
+        TraceIn ti;
+        ti.air_idx = air_idx[t];
+        ti.d_trace = d_traces ? (const Fp *)d_traces[t] : nullptr;
+        ti.height = heights[t];
+        if (ti.height == 0 || (ti.height & (ti.height - 1))) throw OvmFail((int)hipErrorInvalidValue, "trace height");
+        for (uint32_t i = 0; i < (num_public_values ? num_public_values[t] : 0); i++)
+            ti.public_values.push_back(Fp::raw(public_values[t][i]));
+        in.push_back(std::move(ti));
+    }
+    return in;
+}
+void sponge_in(Prover &pr, const ovm_sponge_t *sponge) {
+    if (!sponge) return;
+    for (int i = 0; i < 16; i++) pr.ts.s.state[i] = Fp::raw(sponge->state[i]);
+    pr.ts.s.absorb_idx = sponge->absorb_idx;
+    pr.ts.s.sample_idx = sponge->sample_idx;
+}
+void sponge_out(const Prover &pr, ovm_sponge_t *sponge) {
+    if (!sponge) return;
+    for (int i = 0; i < 16; i++) sponge->state[i] = pr.ts.s.state[i].v;
+    sponge->absorb_idx = pr.ts.s.absorb_idx;
+    sponge->sample_idx = pr.ts.s.sample_idx;
+}
+template <class F>
+int guarded(F &&f) {
+    try {
+        if (!twiddles()) return (int)hipErrorInitializationError;
+        return f();
+    } catch (const OvmFail &e) {
+        g_last_error = e.what();
+        return e.code ? e.code : (int)hipErrorUnknown;
+    } catch (const std::exception &e) {
+        g_last_error = e.what();
+        return (int)hipErrorUnknown;
+    }
+}
+}  // namespace
+
+
 extern "C" {
 
 int ovm_hip_pk_load(const uint32_t *blob, uint64_t words, ovm_pk_t **pk_out) {
@@ -1602,7 +1655,6 @@ int ovm_hip_trim(void) {
     return 0;
 }
 
-static thread_local std::string g_last_error;
 const char *ovm_hip_last_error(void) { return g_last_error.c_str(); }
 
 int ovm_hip_prove(const ovm_pk_t *pk_, uint32_t n_traces, const uint32_t *air_idx, const uint32_t *const *d_traces,
@@ -1649,6 +1701,73 @@ int ovm_hip_prove(const ovm_pk_t *pk_, uint32_t n_traces, const uint32_t *air_id
         g_last_error = e.what();
         return (int)hipErrorUnknown;
     }
+}
+
+int ovm_hip_commit(const ovm_pk_t *pk_, uint32_t n_traces, const uint32_t *air_idx, const uint32_t *const *d_traces,
+                   const uint64_t *heights, uint32_t commitment_out[8], ovm_pcs_t **pcs_out, ovm_stream_t stream) {
+    if (!pk_ || !pcs_out || !commitment_out || n_traces == 0 || !d_traces) return (int)hipErrorInvalidValue;
+    const ProvingKey &pk = *reinterpret_cast<const ProvingKey *>(pk_);
+    return guarded([&]() -> int {
+        Prover pr(pk, (hipStream_t)stream);
+        pr.set_traces(traces_from_abi(n_traces, air_idx, d_traces, heights, nullptr, nullptr), false);
+        auto *pcs = new PcsData(pr.commit());
+        pr.cx.sync();
+        for (int i = 0; i < 8; i++) commitment_out[i] = pcs->root.d[i].v;
+        *pcs_out = reinterpret_cast<ovm_pcs_t *>(pcs);
+        return 0;
+    });
+}
+
+void ovm_hip_pcs_free(ovm_pcs_t *pcs) { delete reinterpret_cast<PcsData *>(pcs); }
+
+int ovm_hip_prove_rap_constraints(const ovm_pk_t *pk_, uint32_t n_traces, const uint32_t *air_idx,
+                                  const uint32_t *const *d_traces, const uint64_t *heights,
+                                  const uint32_t *const *public_values, const uint32_t *num_public_values,
+                                  ovm_sponge_t *sponge, uint8_t *out, uint64_t out_cap, uint64_t *gkr_len,
+                                  uint64_t *total_len, uint32_t *r_out, uint32_t r_cap, uint32_t *r_len,
+                                  ovm_stream_t stream) {
+    if (!pk_ || !sponge || !total_len || !r_len || n_traces == 0 || !d_traces) return (int)hipErrorInvalidValue;
+    const ProvingKey &pk = *reinterpret_cast<const ProvingKey *>(pk_);
+    return guarded([&]() -> int {
+        Prover pr(pk, (hipStream_t)stream);
+        sponge_in(pr, sponge);
+        pr.set_traces(traces_from_abi(n_traces, air_idx, d_traces, heights, public_values, num_public_values));
+        std::vector<EF> r = pr.prove_rap_constraints();
+        pr.cx.sync();
+        sponge_out(pr, sponge);
+        if (gkr_len) *gkr_len = pr.section_offsets.empty() ? 0 : pr.section_offsets[0];
+        *total_len = pr.out.buf.size();
+        *r_len = (uint32_t)r.size();
+        if (pr.out.buf.size() > out_cap || !out || r.size() > r_cap || !r_out) return (int)hipErrorInvalidValue;
+        memcpy(out, pr.out.buf.data(), pr.out.buf.size());
+        for (size_t i = 0; i < r.size(); i++)
+            for (int k = 0; k < 4; k++) r_out[4 * i + k] = r[i].c[k].v;
+        return 0;
+    });
+}
+
+int ovm_hip_prove_openings(const ovm_pk_t *pk_, uint32_t n_traces, const uint32_t *air_idx, const uint64_t *heights,
+                           ovm_pcs_t *common_main, const uint32_t *r, uint32_t r_len, ovm_sponge_t *sponge,
+                           uint8_t *out, uint64_t out_cap, uint64_t *stacking_len, uint64_t *total_len,
+                           ovm_stream_t stream) {
+    if (!pk_ || !sponge || !total_len || !common_main || !r || n_traces == 0) return (int)hipErrorInvalidValue;
+    const ProvingKey &pk = *reinterpret_cast<const ProvingKey *>(pk_);
+    return guarded([&]() -> int {
+        Prover pr(pk, (hipStream_t)stream);
+        sponge_in(pr, sponge);
+        pr.set_traces(traces_from_abi(n_traces, air_idx, nullptr, heights, nullptr, nullptr), false);
+        std::vector<EF> rv(r_len);
+        for (uint32_t i = 0; i < r_len; i++)
+            for (int k = 0; k < 4; k++) rv[i].c[k] = Fp::raw(r[4 * i + k]);
+        pr.prove_openings(*reinterpret_cast<PcsData *>(common_main), rv);
+        pr.cx.sync();
+        sponge_out(pr, sponge);
+        if (stacking_len) *stacking_len = pr.section_offsets.empty() ? 0 : pr.section_offsets[0];
+        *total_len = pr.out.buf.size();
+        if (pr.out.buf.size() > out_cap || !out) return (int)hipErrorInvalidValue;
+        memcpy(out, pr.out.buf.data(), pr.out.buf.size());
+        return 0;
+    });
 }
 
 }  // extern "C"

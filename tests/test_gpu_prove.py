@@ -120,3 +120,52 @@ def test_gkr_three_point_fallback(dev, pkg, orc, monkeypatch):
     h = 1 << 8
     tr = airs.splitmix64_bits(0xD15EA5E, 20 * h)
     run_case(dev, pkg, orc, params, [airs.uniform_runner_air(20)], [(0, tr, h, [])])
+
+
+def test_stage_level_entries_match_monolithic(dev, pkg, orc):
+    """commit / prove_rap_constraints / prove_openings (the three hal.rs traits) driven by a
+    coordinator on the caller's side -- here prover/mod.rs:110-175 restated on the oracle's
+    transcript -- give exactly the sections of the monolithic ovm_hip_prove proof."""
+    params = airs.test_params(l_skip=2, n_stack=6, k_whir=2)
+    bench = airs.uniform_runner_air(8)
+    air_list = [airs.fibonacci_air(), bench, bench]
+    t1, pv = airs.fibonacci_trace(0, 1, 16)
+    traces = [(0, t1, 16, pv), (1, airs.splitmix64_bits(1, 8 * 64), 64, []), (2, airs.splitmix64_bits(2, 8 * 2), 2, [])]
+    blob = airs.pk_blob(params, air_list)
+    pk = pkg.ProvingKey(blob)
+    dtr = [(a, dev.upload(pkg.to_mont(np.asarray(tr, dtype=np.uint32))), h, p) for a, tr, h, p in traces]
+    final = pkg.SpongeState()
+    mono, secs = dev.prove(pk, dtr, sponge=None)
+    orc.verify(blob, mono)
+
+    pcs = dev.commit_traces(pk, dtr)
+    root = pkg.from_mont(pcs.root)
+    assert root.astype("<u4").tobytes() == mono[4:36]
+    ts = orc.transcript()
+    for x in [(7 * i + 1) % airs.P for i in range(8)]:  # vk_pre_hash of airs.pk_blob
+        ts.observe(x)
+    for x in root:
+        ts.observe(int(x))
+    by_air = {a: (h, p) for a, _, h, p in traces}
+    for a, air in enumerate(air_list):
+        if not air["is_required"]:
+            ts.observe(1 if a in by_air else 0)
+        if a in by_air:
+            h, p = by_air[a]
+            ts.observe(h.bit_length() - 1)
+            for x in p:
+                ts.observe(int(x))
+    st, ai, si = ts.state()
+    sponge = pkg.SpongeState()
+    for i, x in enumerate(pkg.to_mont(st)):
+        sponge.state[i] = int(x)
+    sponge.absorb_idx, sponge.sample_idx = ai, si
+
+    gkr, batch, r = dev.prove_rap_constraints(pk, dtr, sponge)
+    assert gkr == mono[secs[0]:secs[1]]
+    assert batch == mono[secs[1]:secs[2]]
+    stacking, whir = dev.prove_openings(pk, dtr, pcs, r, sponge)
+    assert stacking == mono[secs[2]:secs[3]]
+    assert whir == mono[secs[3]:secs[4]]
+    pcs.free()
+    del final
