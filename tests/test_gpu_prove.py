@@ -169,3 +169,20 @@ def test_stage_level_entries_match_monolithic(dev, pkg, orc):
     assert whir == mono[secs[3]:secs[4]]
     pcs.free()
     del final
+
+
+import test_oracle_golden as _golden
+
+
+@pytest.mark.skipif(not _golden.reference_cases(), reason="no reference proofs (run tools/gen_golden.rs)")
+@pytest.mark.parametrize("path", _golden.reference_cases())
+def test_reference_golden_proofs(dev, pkg, path):
+    """When real reference output is present: ovm_hip_prove must reproduce it byte for byte."""
+    import json
+    doc = json.load(open(path))
+    blob = np.array(doc["pk_blob"], dtype=np.uint32)
+    pk = pkg.ProvingKey(blob)
+    dtr = [(t["air_idx"], dev.upload(pkg.to_mont(np.array(t["values"], dtype=np.uint32))), t["height"],
+            t["public_values"]) for t in doc["traces"]]
+    got, _ = dev.prove(pk, dtr)
+    assert got == bytes.fromhex(doc["proof_hex"])
