@@ -139,16 +139,25 @@ class DagBuilder:
 class Air:
     """Collects constraints / interactions like SymbolicRapBuilder (symbolic/mod.rs:99-258)."""
 
-    def __init__(self, name, common_main_width, num_public_values=0, is_required=True):
+    def __init__(self, name, common_main_width, num_public_values=0, is_required=True, preprocessed_width=0,
+                 cached_main_widths=()):
         self.name, self.width, self.num_pvs, self.is_required = name, common_main_width, num_public_values, is_required
+        self.preprocessed_width, self.cached_widths = preprocessed_width, list(cached_main_widths)
         self.constraints, self.interactions = [], []
 
-    # AirBuilder surface
+    # AirBuilder surface. Main partitions: cached_0 .. cached_{m-1}, then the common main as part m
+    # (symbolic/mod.rs:117-127).
     def local(self, i):
-        return var(E_MAIN, i, 0, 0)
+        return var(E_MAIN, i, len(self.cached_widths), 0)
 
     def next(self, i):
-        return var(E_MAIN, i, 0, 1)
+        return var(E_MAIN, i, len(self.cached_widths), 1)
+
+    def cached(self, part, i, offset=0):
+        return var(E_MAIN, i, part, offset)
+
+    def preprocessed(self, i, offset=0):
+        return var(E_PREP, i, 0, offset)
 
     def public(self, i):
         return var(E_PUBLIC, i)
@@ -182,7 +191,8 @@ class Air:
         return dict(name=self.name, nodes=list(b.nodes), constraint_idx=cidx, interactions=inter,
                     need_rot=need_rot, is_required=self.is_required,
                     max_constraint_degree=max(degs) if degs else 0, num_public_values=self.num_pvs,
-                    common_main_width=self.width)
+                    common_main_width=self.width, preprocessed_width=self.preprocessed_width,
+                    cached_main_widths=list(self.cached_widths))
 
 
 # ---------------------------------------------------------------------------------------------
@@ -205,10 +215,16 @@ def fibonacci_trace(a, b, n):
     return np.ascontiguousarray(m.T).reshape(-1), [a % P, b % P, int(m[-1][1])]
 
 
-def dummy_interaction_air(field_width, is_send, bus):
-    a = Air("DummyInteractionAir", 1 + field_width)
-    count = a.local(0)
-    fields = [a.local(1 + i) for i in range(field_width)]
+def dummy_interaction_air(field_width, is_send, bus, partition=False):
+    """dummy_interaction_air.rs:94-121; `partition`: count in the common main, fields in cached main 0."""
+    if partition:
+        a = Air("DummyInteractionAir", 1, cached_main_widths=[field_width])
+        count = a.local(0)
+        fields = [a.cached(0, i) for i in range(field_width)]
+    else:
+        a = Air("DummyInteractionAir", 1 + field_width)
+        count = a.local(0)
+        fields = [a.local(1 + i) for i in range(field_width)]
     if is_send:
         a.push_interaction(bus, fields, count)
     else:
@@ -290,8 +306,12 @@ def test_params(l_skip=2, n_stack=8, k_whir=3, log_blowup=1, max_constraint_degr
 MAGIC = 0x4F564D31
 
 
-def pk_blob(params, airs, vk_pre_hash=None):
-    """Flat u32 proving-key blob (field constants canonical)."""
+PREP_MAGIC = 0x50524550
+
+
+def pk_blob(params, airs, vk_pre_hash=None, preprocessed=None):
+    """Flat u32 proving-key blob (field constants canonical). `preprocessed`: {air position:
+    (canonical column-major values, height)} for the AIRs with a preprocessed trace."""
     w = [MAGIC, params["l_skip"], params["n_stack"], params["w_stack"], params["log_blowup"],
          params["k_whir"], params["mu_pow_bits"], params["query_phase_pow_bits"],
          params["folding_pow_bits"], params["logup_pow_bits"], params["max_constraint_degree"],
@@ -299,8 +319,10 @@ def pk_blob(params, airs, vk_pre_hash=None):
     w += list(vk_pre_hash) if vk_pre_hash is not None else [(7 * i + 1) % P for i in range(8)]
     w.append(len(airs))
     for a in airs:
+        cw = a.get("cached_main_widths", [])
+        pw = a.get("preprocessed_width", 0)
         w += [int(a["need_rot"]), int(a["is_required"]), a["max_constraint_degree"],
-              a["num_public_values"], 0, 0, 0, a["common_main_width"], len(a["nodes"])]
+              a["num_public_values"], int(pw > 0), pw, len(cw)] + list(cw) + [a["common_main_width"], len(a["nodes"])]
         for n in a["nodes"]:
             k = n[0]
             if k == N_VAR:
@@ -318,4 +340,77 @@ def pk_blob(params, airs, vk_pre_hash=None):
         w.append(len(a["interactions"]))
         for bus, cw, cnt, msg in a["interactions"]:
             w += [bus, cw, cnt, len(msg)] + msg
+    if any(a.get("preprocessed_width", 0) for a in airs):
+        w.append(PREP_MAGIC)
+        for i, a in enumerate(airs):
+            if a.get("preprocessed_width", 0):
+                vals, h = preprocessed[i]
+                assert len(vals) == a["preprocessed_width"] * h
+                w.append(h)
+                w += [int(x) for x in vals]
     return np.array(w, dtype=np.uint32)
+
+
+# ---- fixtures with preprocessed / cached traces (test_utils/mod.rs:261-436) -------------------
+def fibonacci_selector_air():
+    """fib_selector_air/air.rs:55-113 (interactions disabled): the selector is a 1-column
+    preprocessed trace."""
+    a = Air("FibonacciSelectorAir", 2, num_public_values=3, preprocessed_width=1)
+    pa, pb, px = a.public(0), a.public(1), a.public(2)
+    sel = a.preprocessed(0)
+    left, right, nleft, nright = a.local(0), a.local(1), a.next(0), a.next(1)
+    a.assert_eq(left, pa, when=IS_FIRST())
+    a.assert_eq(right, pb, when=IS_FIRST())
+    a.assert_eq(right, nleft, when=IS_TRANSITION() * sel)
+    a.assert_eq(left, nleft, when=IS_TRANSITION() * (sel - ONE()))
+    a.assert_eq(left + right, nright, when=IS_TRANSITION() * sel)
+    a.assert_eq(right, nright, when=IS_TRANSITION() * (sel - ONE()))
+    a.assert_eq(right, px, when=IS_LAST())
+    return a.finish()
+
+
+def fibonacci_selector_trace(a, b, sels):
+    """fib_selector_air/trace.rs:7-22 + get_conditional_fib_number; returns (col-major trace, pvs)."""
+    rows = [[a % P, b % P]]
+    for i in range(1, len(sels)):
+        l, r = rows[-1]
+        rows.append([r, (l + r) % P] if sels[i - 1] else [l, r])
+    tr = np.array(rows, dtype=np.uint32).T.reshape(-1).copy()
+    return tr, [a % P, b % P, rows[-1][1]]
+
+
+def preprocessed_cached_air(num_cached_parts):
+    """preprocessed_cached_air/air.rs:49-120: 1 preprocessed selector column, 1 common column,
+    `num_cached_parts` cached single-column partitions."""
+    a = Air("PreprocessedCachedAir", 1, preprocessed_width=1, cached_main_widths=[1] * num_cached_parts)
+    pl, pn = a.preprocessed(0), a.preprocessed(0, 1)
+    cl, cn = a.local(0), a.next(0)
+    a.assert_zero(pl * (pl - ONE()))
+    a.assert_zero(cl, when=IS_FIRST())
+    a.assert_zero((cn - cl) - ONE(), when=IS_TRANSITION())  # assert_one
+    prev_l, prev_n = cl, cn
+    for part in range(num_cached_parts):
+        kl, kn = a.cached(part, 0), a.cached(part, 0, 1)
+        a.assert_eq(prev_l + pl, kl)
+        a.assert_eq(prev_n + pn, kn, when=IS_TRANSITION())
+        prev_l, prev_n = kl, kn
+    return a.finish()
+
+
+def preprocessed_cached_traces(sels, num_cached_parts):
+    """test_utils/mod.rs:373-400: common = 0..n; cached part p = i + (p+1)*sel[i]."""
+    n = len(sels)
+    common = np.arange(n, dtype=np.uint32)
+    cached = np.concatenate([np.array([(i + (p + 1) * int(sels[i])) % P for i in range(n)], dtype=np.uint32)
+                             for p in range(num_cached_parts)])
+    return common, cached
+
+
+def cached_fixture_11():
+    """CachedFixture11 (test_utils/mod.rs:265-331): partitioned sender/receiver; returns
+    (airs, traces) with traces = (air_idx, common, height, pvs, cached)."""
+    airs_ = [dummy_interaction_air(1, True, 0, partition=True), dummy_interaction_air(1, False, 0, partition=True)]
+    traces = [(0, np.array([0, 3, 7, 546], np.uint32), 4, [], np.array([1, 5, 4, 889], np.uint32)),
+              (1, np.array([1, 3, 4, 2, 0, 545, 1, 0], np.uint32), 8, [],
+               np.array([5, 4, 4, 5, 123, 889, 889, 456], np.uint32))]
+    return airs_, traces

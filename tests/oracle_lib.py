@@ -151,8 +151,8 @@ class OracleTranscript:
 
 
 def _prove(self, blob, traces, proof_cap=1 << 26):
-    """traces: list of (air_idx, canonical col-major flat u32 trace, height, public values list).
-    Returns dict(proof=bytes, root, r, u, pow)."""
+    """traces: list of (air_idx, canonical col-major flat u32 trace, height, public values list
+    [, cached partitions concatenated, col-major]). Returns dict(proof=bytes, root, r, u, pow)."""
     lib = self.lib
     n = len(traces)
     blob = np.ascontiguousarray(blob, dtype=np.uint32)
@@ -163,13 +163,15 @@ def _prove(self, blob, traces, proof_cap=1 << 26):
     npv = np.array([len(t[3]) for t in traces], dtype=np.uint32)
     tptr = (c_void_p * n)(*[a.ctypes.data for a in arrs])
     pptr = (c_void_p * n)(*[a.ctypes.data for a in pvs])
+    carrs = [np.ascontiguousarray(t[4], dtype=np.uint32) if len(t) > 4 and t[4] is not None else None for t in traces]
+    cptr = (c_void_p * n)(*[a.ctypes.data if a is not None else None for a in carrs])
     out = np.zeros(proof_cap, dtype=np.uint8)
     plen = c_uint64(0)
     root = np.zeros(8, np.uint32)
     r = np.zeros(4 * 64, np.uint32); u = np.zeros(4 * 64, np.uint32); pw = np.zeros(256, np.uint32)
     rl = c_uint32(0); ul = c_uint32(0); pl = c_uint32(0)
     lib.orc_last_error.restype = ctypes.c_char_p
-    rc = lib.orc_prove(_p(blob), c_uint64(blob.size), c_uint32(n), _p(air_idx), tptr, _p(heights), pptr,
+    rc = lib.orc_prove(_p(blob), c_uint64(blob.size), c_uint32(n), _p(air_idx), tptr, _p(heights), cptr, pptr,
                        _p(npv), _p(out), c_uint64(proof_cap), ctypes.byref(plen), _p(root), _p(r),
                        ctypes.byref(rl), _p(u), ctypes.byref(ul), _p(pw), ctypes.byref(pl))
     if rc != 0:
