@@ -171,10 +171,19 @@ typedef struct ovm_pk_t ovm_pk_t;
  *       x = column index | constant value | left node, y = right node;
  *     num_constraints, constraint_idx[], num_interactions, then per interaction
  *     bus_index, count_weight, count_node, message_len, message_nodes[].
- * This is what the Rust side serialises from `MultiStarkProvingKey::get_vk()` plus `vk_pre_hash`.
- * Returns hipErrorNotSupported for preprocessed / cached traces (not built yet). */
-int ovm_hip_pk_load(const uint32_t *blob, uint64_t words, ovm_pk_t **pk_out);
+ * Main variables: part_index 0..num_cached-1 are the cached main partitions, part_index num_cached
+ * is the common main (air_builders/symbolic/mod.rs:117-127).
+ * If any AIR has a preprocessed trace the blob ends with: 0x50524550 ('PREP'), then for every such
+ * AIR in order: height, preprocessed_width*height canonical values, column-major. The key uploads
+ * and commits each of them on `stream` (keygen/mod.rs:283-300, hal.rs:141-150) and synchronises.
+ * This is what the Rust side serialises from `MultiStarkProvingKey` (vk + preprocessed traces)
+ * plus `vk_pre_hash`. */
+int ovm_hip_pk_load(const uint32_t *blob, uint64_t words, ovm_pk_t **pk_out, ovm_stream_t stream);
 void ovm_hip_pk_free(ovm_pk_t *pk);
+/* Commitment (Montgomery words) of AIR air_idx's preprocessed trace as committed at load time --
+ * must equal `vk.preprocessed_data.commit` (keygen/types.rs:99-107). hipErrorInvalidValue if the
+ * AIR has none. */
+int ovm_hip_pk_preprocessed_commitment(const ovm_pk_t *pk, uint32_t air_idx, uint32_t commitment_out[8]);
 /* Returns the calling thread's cached device blocks to the driver (the prover recycles its
  * buffers between proofs; reference: VPMM pool, crates/cuda-common/src/memory_manager/). */
 int ovm_hip_trim(void);
@@ -190,14 +199,32 @@ const char *ovm_hip_last_error(void);
  * `ProvingContext::into_sorted` does (prover/types.rs:137-148). */
 typedef struct ovm_pcs ovm_pcs_t; /* opaque StackedPcsData: stacked matrix, codeword, Merkle layers */
 
+/* One AIR's proving input (reference: AirProvingContext, prover/types.rs:59-73). POD. */
+typedef struct ovm_trace {
+    uint32_t air_idx;               /* position in the key's AIR list */
+    uint32_t num_public_values;
+    const uint32_t *d_common_main;  /* device, column-major Montgomery words: height x common_main_width */
+    uint64_t height;                /* power of two */
+    const uint32_t *public_values;  /* host, Montgomery words */
+    uint32_t num_cached;            /* = the AIR's number of cached main partitions */
+    uint32_t _pad;
+    ovm_pcs_t *const *cached;       /* host array of handles from ovm_hip_commit_matrix, partition order */
+} ovm_trace_t;
+
 /* TraceCommitter::commit (hal.rs:84-87; CUDA backend: crates/cuda-backend/src/stacked_pcs.rs:
- * 229-337 + merkle_tree.rs): stack, eval->coeff, RS encode, Merkle tree. commitment_out = root
- * (Montgomery words). When one trace fills the stacked matrix exactly the PCS data aliases the
- * trace buffer instead of copying it: keep the traces alive until prove_openings has returned
- * (the reference's ctx owns them for exactly that long, hal.rs:123-137). Synchronises the stream. */
-int ovm_hip_commit(const ovm_pk_t *pk, uint32_t n_traces, const uint32_t *air_idx,
-                   const uint32_t *const *d_traces, const uint64_t *heights, uint32_t commitment_out[8],
+ * 229-337 + merkle_tree.rs) of the common mains of `traces`: stack, eval->coeff, RS encode, Merkle
+ * tree. commitment_out = root (Montgomery words). When one trace fills the stacked matrix exactly
+ * the PCS data aliases the trace buffer instead of copying it: keep the traces alive until
+ * prove_openings has returned (the reference's ctx owns them for exactly that long,
+ * hal.rs:123-137). Synchronises the stream. */
+int ovm_hip_commit(const ovm_pk_t *pk, uint32_t n_traces, const ovm_trace_t *traces, uint32_t commitment_out[8],
                    ovm_pcs_t **pcs_out, ovm_stream_t stream);
+/* The same for ONE matrix of any width: how a cached main partition is committed before proving
+ * (reference callers: `stacked_commit(.., &[&cached])`, test_utils/mod.rs:297-318; the result is a
+ * CommittedTraceData, prover/types.rs:18-25). The handle keeps pointing at d_matrix: keep it alive
+ * as long as the handle. */
+int ovm_hip_commit_matrix(const ovm_pk_t *pk, const uint32_t *d_matrix, uint64_t width, uint64_t height,
+                          uint32_t commitment_out[8], ovm_pcs_t **pcs_out, ovm_stream_t stream);
 void ovm_hip_pcs_free(ovm_pcs_t *pcs);
 
 /* MultiRapProver::prove_rap_constraints (hal.rs:94-112; CUDA backend: crates/cuda-backend/src/
@@ -206,38 +233,32 @@ void ovm_hip_pcs_free(ovm_pcs_t *pcs);
  * proof.rs:226-421 (`GkrProof::decode` / `BatchConstraintProof::decode` read them).
  * r_out = the sumcheck point (the trait's `Artifacts = Vec<EF>`), 4 Montgomery words per element,
  * r_len elements. Synchronises the stream. */
-int ovm_hip_prove_rap_constraints(const ovm_pk_t *pk, uint32_t n_traces, const uint32_t *air_idx,
-                                  const uint32_t *const *d_traces, const uint64_t *heights,
-                                  const uint32_t *const *public_values, const uint32_t *num_public_values,
+int ovm_hip_prove_rap_constraints(const ovm_pk_t *pk, uint32_t n_traces, const ovm_trace_t *traces,
                                   ovm_sponge_t *sponge, uint8_t *out, uint64_t out_cap, uint64_t *gkr_len,
                                   uint64_t *total_len, uint32_t *r_out, uint32_t r_cap, uint32_t *r_len,
                                   ovm_stream_t stream);
 
 /* OpeningProver::prove_openings (hal.rs:118-138; CUDA backend: stacked_reduction.rs + whir.rs):
- * stacked opening reduction and WHIR over the common-main PCS data (consumed logically: free it
- * afterwards). out = StackingProof bytes (stacking_len) followed by WhirProof bytes.
- * Synchronises the stream. */
-int ovm_hip_prove_openings(const ovm_pk_t *pk, uint32_t n_traces, const uint32_t *air_idx,
-                           const uint64_t *heights, ovm_pcs_t *common_main, const uint32_t *r, uint32_t r_len,
-                           ovm_sponge_t *sponge, uint8_t *out, uint64_t out_cap, uint64_t *stacking_len,
-                           uint64_t *total_len, ovm_stream_t stream);
+ * stacked opening reduction and WHIR over all commitments -- the common main, then per trace its
+ * preprocessed commitment (from the key) and its cached mains (cpu-backend/src/device.rs:147-172).
+ * out = StackingProof bytes (stacking_len) followed by WhirProof bytes. d_common_main and
+ * public_values of `traces` are not read. Synchronises the stream. */
+int ovm_hip_prove_openings(const ovm_pk_t *pk, uint32_t n_traces, const ovm_trace_t *traces, ovm_pcs_t *common_main,
+                           const uint32_t *r, uint32_t r_len, ovm_sponge_t *sponge, uint8_t *out, uint64_t out_cap,
+                           uint64_t *stacking_len, uint64_t *total_len, ovm_stream_t stream);
 
 /* `Coordinator::prove` for traces already resident on the device (reference:
  * crates/stark-backend/src/prover/mod.rs:104-197 driving hal.rs:84-138): commits the common main
  * traces, proves the constraints (LogUp-GKR + batch sumcheck) and the openings (stacked reduction
  * + WHIR), and writes the proof in the reference's canonical byte encoding
  * (crates/stark-backend/src/proof.rs:226-421) -- `Proof::decode_from_bytes` reads it.
- *   d_traces[i]: column-major Montgomery words, heights[i] rows (power of two) x the AIR's width.
- *   public_values[i]: num_public_values[i] Montgomery words (host).
  *   sponge: transcript state, updated in place (NULL = fresh transcript).
  *   section_offsets5 (optional): byte offsets of the ends of header / GKR / batch-constraint /
  *   stacking / WHIR sections.
  * PoW witnesses are the minimum valid ones. Synchronises the stream. */
-int ovm_hip_prove(const ovm_pk_t *pk, uint32_t n_traces, const uint32_t *air_idx,
-                  const uint32_t *const *d_traces, const uint64_t *heights,
-                  const uint32_t *const *public_values, const uint32_t *num_public_values,
-                  ovm_sponge_t *sponge, uint8_t *proof_out, uint64_t proof_cap, uint64_t *proof_len,
-                  uint64_t *section_offsets5, ovm_stream_t stream);
+int ovm_hip_prove(const ovm_pk_t *pk, uint32_t n_traces, const ovm_trace_t *traces, ovm_sponge_t *sponge,
+                  uint8_t *proof_out, uint64_t proof_cap, uint64_t *proof_len, uint64_t *section_offsets5,
+                  ovm_stream_t stream);
 
 #ifdef __cplusplus
 }

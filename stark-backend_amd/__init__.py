@@ -36,6 +36,14 @@ class OvmError(RuntimeError):
         super().__init__(f"{what} failed: {code} ({name.decode() if name else '?'})")
 
 
+class TraceStruct(Structure):
+    """``ovm_trace_t`` (reference: AirProvingContext, prover/types.rs:59-73)."""
+
+    _fields_ = [("air_idx", c_uint32), ("num_public_values", c_uint32), ("d_common_main", c_void_p),
+                ("height", c_uint64), ("public_values", c_void_p), ("num_cached", c_uint32), ("_pad", c_uint32),
+                ("cached", c_void_p)]
+
+
 class SpongeState(Structure):
     """``ovm_sponge_t`` (reference: crates/cuda-backend/src/sponge.rs:39-48)."""
 
@@ -78,19 +86,20 @@ SIGNATURES = {
     "ovm_hip_gather_rows": (c_int, [c_void_p, c_uint64, c_uint64, c_uint32, c_void_p, c_uint64,
                                     c_void_p, c_void_p]),
     "ovm_hip_gather_digests": (c_int, [c_void_p, c_void_p, c_uint64, c_void_p, c_void_p]),
-    "ovm_hip_pk_load": (c_int, [c_void_p, c_uint64, POINTER(c_void_p)]),
+    "ovm_hip_pk_load": (c_int, [c_void_p, c_uint64, POINTER(c_void_p), c_void_p]),
     "ovm_hip_pk_free": (None, [c_void_p]),
+    "ovm_hip_pk_preprocessed_commitment": (c_int, [c_void_p, c_uint32, c_void_p]),
     "ovm_hip_last_error": (c_char_p, []),
     "ovm_hip_trim": (c_int, []),
-    "ovm_hip_commit": (c_int, [c_void_p, c_uint32, c_void_p, c_void_p, c_void_p, c_void_p, POINTER(c_void_p), c_void_p]),
+    "ovm_hip_commit": (c_int, [c_void_p, c_uint32, c_void_p, c_void_p, POINTER(c_void_p), c_void_p]),
+    "ovm_hip_commit_matrix": (c_int, [c_void_p, c_void_p, c_uint64, c_uint64, c_void_p, POINTER(c_void_p), c_void_p]),
     "ovm_hip_pcs_free": (None, [c_void_p]),
-    "ovm_hip_prove_rap_constraints": (c_int, [c_void_p, c_uint32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-                                              POINTER(SpongeState), c_void_p, c_uint64, _u64p, _u64p, c_void_p,
-                                              c_uint32, _u32p, c_void_p]),
-    "ovm_hip_prove_openings": (c_int, [c_void_p, c_uint32, c_void_p, c_void_p, c_void_p, c_void_p, c_uint32,
+    "ovm_hip_prove_rap_constraints": (c_int, [c_void_p, c_uint32, c_void_p, POINTER(SpongeState), c_void_p, c_uint64,
+                                              _u64p, _u64p, c_void_p, c_uint32, _u32p, c_void_p]),
+    "ovm_hip_prove_openings": (c_int, [c_void_p, c_uint32, c_void_p, c_void_p, c_void_p, c_uint32,
                                        POINTER(SpongeState), c_void_p, c_uint64, _u64p, _u64p, c_void_p]),
-    "ovm_hip_prove": (c_int, [c_void_p, c_uint32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-                              POINTER(SpongeState), c_void_p, c_uint64, _u64p, _u64p, c_void_p]),
+    "ovm_hip_prove": (c_int, [c_void_p, c_uint32, c_void_p, POINTER(SpongeState), c_void_p, c_uint64, _u64p, _u64p,
+                              c_void_p]),
 }
 
 
@@ -243,11 +252,20 @@ class Device:
 class ProvingKey:
     """Device proving key built from the flat u32 blob (see include/openvm_hip.h)."""
 
-    def __init__(self, blob: np.ndarray):
+    def __init__(self, blob: np.ndarray, stream=None):
         b = np.ascontiguousarray(blob, dtype=np.uint32)
         h = c_void_p(0)
-        check(_lib().ovm_hip_pk_load(b.ctypes.data, b.size, ctypes.byref(h)), "ovm_hip_pk_load")
+        rc = _lib().ovm_hip_pk_load(b.ctypes.data, b.size, ctypes.byref(h), stream)
+        if rc != 0:
+            msg = _lib().ovm_hip_last_error()
+            raise OvmError(rc, f"ovm_hip_pk_load [{msg.decode() if msg else ''}]")
         self.handle = h
+
+    def preprocessed_commitment(self, air_idx: int) -> np.ndarray:
+        out = np.zeros(8, dtype=np.uint32)
+        check(_lib().ovm_hip_pk_preprocessed_commitment(self.handle, air_idx, out.ctypes.data),
+              "ovm_hip_pk_preprocessed_commitment")
+        return out
 
     def __del__(self):
         try:
@@ -258,38 +276,13 @@ class ProvingKey:
             pass
 
 
-def _prove(self, pk: ProvingKey, traces, sponge: SpongeState | None = None, proof_cap: int = 1 << 26):
-    """traces: list of (air_idx, device int32 tensor [column-major Montgomery], height,
-    public values as canonical ints). Returns (proof bytes, section end offsets)."""
-    n = len(traces)
-    air_idx = np.array([t[0] for t in traces], dtype=np.uint32)
-    heights = np.array([t[2] for t in traces], dtype=np.uint64)
-    pvs = [to_mont(np.array(t[3], dtype=np.uint32)) if len(t[3]) else np.zeros(1, np.uint32) for t in traces]
-    npv = np.array([len(t[3]) for t in traces], dtype=np.uint32)
-    tptr = (c_void_p * n)(*[t[1].data_ptr() for t in traces])
-    pptr = (c_void_p * n)(*[a.ctypes.data for a in pvs])
-    out = np.zeros(proof_cap, dtype=np.uint8)
-    plen = c_uint64(0)
-    secs = (c_uint64 * 5)()
-    rc = _lib().ovm_hip_prove(pk.handle, n, air_idx.ctypes.data, tptr, heights.ctypes.data, pptr,
-                              npv.ctypes.data, ctypes.byref(sponge) if sponge is not None else None,
-                              out.ctypes.data, proof_cap, ctypes.byref(plen), secs, self.stream)
-    if rc != 0:
-        msg = _lib().ovm_hip_last_error()
-        raise OvmError(rc, f"ovm_hip_prove [{msg.decode() if msg else ''}]")
-    return out[:plen.value].tobytes(), [int(x) for x in secs]
-
-
-Device.prove = _prove
-
-
-# ---- stage-level entries (TraceCommitter / MultiRapProver / OpeningProver, hal.rs:84-138) ------
 class PcsData:
-    """Opaque ``ovm_pcs_t`` handle returned by ``Device.commit_traces``."""
+    """Opaque ``ovm_pcs_t`` handle (``Device.commit_traces`` / ``Device.commit_matrix``)."""
 
-    def __init__(self, handle, root):
+    def __init__(self, handle, root, keep=None):
         self.handle = handle
         self.root = root  # 8 Montgomery words
+        self._keep = keep  # the committed tensor: the handle points into it
 
     def free(self):
         if self.handle:
@@ -303,12 +296,25 @@ class PcsData:
             pass
 
 
-def _stage_args(traces):
+def _trace_structs(traces):
+    """traces: list of (air_idx, device int32 tensor [column-major Montgomery], height, public values
+    as canonical ints [, list of PcsData for the cached main partitions]). Returns (array, keepalive)."""
     n = len(traces)
-    air_idx = np.array([t[0] for t in traces], dtype=np.uint32)
-    heights = np.array([t[2] for t in traces], dtype=np.uint64)
-    tptr = (c_void_p * n)(*[t[1].data_ptr() for t in traces])
-    return n, air_idx, heights, tptr
+    arr = (TraceStruct * n)()
+    keep = []
+    for i, t in enumerate(traces):
+        pv = to_mont(np.array(t[3], dtype=np.uint32)) if len(t[3]) else np.zeros(1, np.uint32)
+        cached = list(t[4]) if len(t) > 4 and t[4] is not None else []
+        handles = (c_void_p * max(len(cached), 1))(*[c.handle for c in cached])
+        keep += [pv, handles, cached]
+        arr[i].air_idx = t[0]
+        arr[i].num_public_values = len(t[3])
+        arr[i].d_common_main = t[1].data_ptr() if t[1] is not None else None
+        arr[i].height = t[2]
+        arr[i].public_values = pv.ctypes.data
+        arr[i].num_cached = len(cached)
+        arr[i].cached = ctypes.cast(handles, c_void_p)
+    return arr, keep
 
 
 def _fail(rc, what):
@@ -316,31 +322,54 @@ def _fail(rc, what):
     raise OvmError(rc, f"{what} [{msg.decode() if msg else ''}]")
 
 
+def _prove(self, pk: ProvingKey, traces, sponge: SpongeState | None = None, proof_cap: int = 1 << 26):
+    """Coordinator::prove on resident traces. Returns (proof bytes, section end offsets)."""
+    arr, keep = _trace_structs(traces)
+    out = np.zeros(proof_cap, dtype=np.uint8)
+    plen = c_uint64(0)
+    secs = (c_uint64 * 5)()
+    rc = _lib().ovm_hip_prove(pk.handle, len(traces), arr, ctypes.byref(sponge) if sponge is not None else None,
+                              out.ctypes.data, proof_cap, ctypes.byref(plen), secs, self.stream)
+    if rc != 0:
+        _fail(rc, "ovm_hip_prove")
+    return out[:plen.value].tobytes(), [int(x) for x in secs]
+
+
+Device.prove = _prove
+
+
+# ---- stage-level entries (TraceCommitter / MultiRapProver / OpeningProver, hal.rs:84-138) ------
 def _commit_traces(self, pk: ProvingKey, traces) -> PcsData:
-    """TraceCommitter::commit. traces as for ``prove`` (public values ignored)."""
-    n, air_idx, heights, tptr = _stage_args(traces)
+    """TraceCommitter::commit of the common mains."""
+    arr, keep = _trace_structs(traces)
     root = np.zeros(8, dtype=np.uint32)
     h = c_void_p(0)
-    rc = _lib().ovm_hip_commit(pk.handle, n, air_idx.ctypes.data, tptr, heights.ctypes.data, root.ctypes.data,
-                               ctypes.byref(h), self.stream)
+    rc = _lib().ovm_hip_commit(pk.handle, len(traces), arr, root.ctypes.data, ctypes.byref(h), self.stream)
     if rc != 0:
         _fail(rc, "ovm_hip_commit")
-    return PcsData(h, root)
+    return PcsData(h, root, keep=[t[1] for t in traces])
+
+
+def _commit_matrix(self, pk: ProvingKey, tensor, width: int, height: int) -> PcsData:
+    """Single-matrix commitment (a cached main partition)."""
+    root = np.zeros(8, dtype=np.uint32)
+    h = c_void_p(0)
+    rc = _lib().ovm_hip_commit_matrix(pk.handle, tensor.data_ptr(), width, height, root.ctypes.data, ctypes.byref(h),
+                                      self.stream)
+    if rc != 0:
+        _fail(rc, "ovm_hip_commit_matrix")
+    return PcsData(h, root, keep=tensor)
 
 
 def _prove_rap_constraints(self, pk: ProvingKey, traces, sponge: SpongeState, cap: int = 1 << 24):
     """MultiRapProver::prove_rap_constraints. Returns (GkrProof bytes, BatchConstraintProof bytes,
     r as an (n, 4) array of Montgomery words); ``sponge`` is updated in place."""
-    n, air_idx, heights, tptr = _stage_args(traces)
-    pvs = [to_mont(np.array(t[3], dtype=np.uint32)) if len(t[3]) else np.zeros(1, np.uint32) for t in traces]
-    npv = np.array([len(t[3]) for t in traces], dtype=np.uint32)
-    pptr = (c_void_p * n)(*[a.ctypes.data for a in pvs])
+    arr, keep = _trace_structs(traces)
     out = np.zeros(cap, dtype=np.uint8)
     gkr_len, total = c_uint64(0), c_uint64(0)
     r = np.zeros(4 * 256, dtype=np.uint32)
     r_len = c_uint32(0)
-    rc = _lib().ovm_hip_prove_rap_constraints(pk.handle, n, air_idx.ctypes.data, tptr, heights.ctypes.data, pptr,
-                                              npv.ctypes.data, ctypes.byref(sponge), out.ctypes.data, cap,
+    rc = _lib().ovm_hip_prove_rap_constraints(pk.handle, len(traces), arr, ctypes.byref(sponge), out.ctypes.data, cap,
                                               ctypes.byref(gkr_len), ctypes.byref(total), r.ctypes.data, 256,
                                               ctypes.byref(r_len), self.stream)
     if rc != 0:
@@ -352,19 +381,20 @@ def _prove_rap_constraints(self, pk: ProvingKey, traces, sponge: SpongeState, ca
 def _prove_openings(self, pk: ProvingKey, traces, pcs: PcsData, r: np.ndarray, sponge: SpongeState,
                     cap: int = 1 << 26):
     """OpeningProver::prove_openings. Returns (StackingProof bytes, WhirProof bytes)."""
-    n, air_idx, heights, _ = _stage_args(traces)
+    arr, keep = _trace_structs(traces)
     rr = np.ascontiguousarray(r, dtype=np.uint32).reshape(-1)
     out = np.zeros(cap, dtype=np.uint8)
     st_len, total = c_uint64(0), c_uint64(0)
-    rc = _lib().ovm_hip_prove_openings(pk.handle, n, air_idx.ctypes.data, heights.ctypes.data, pcs.handle,
-                                       rr.ctypes.data, rr.size // 4, ctypes.byref(sponge), out.ctypes.data, cap,
-                                       ctypes.byref(st_len), ctypes.byref(total), self.stream)
+    rc = _lib().ovm_hip_prove_openings(pk.handle, len(traces), arr, pcs.handle, rr.ctypes.data, rr.size // 4,
+                                       ctypes.byref(sponge), out.ctypes.data, cap, ctypes.byref(st_len),
+                                       ctypes.byref(total), self.stream)
     if rc != 0:
         _fail(rc, "ovm_hip_prove_openings")
     b = out[:total.value].tobytes()
     return b[:st_len.value], b[st_len.value:]
 
 
+Device.commit_matrix = _commit_matrix
 Device.commit_traces = _commit_traces
 Device.prove_rap_constraints = _prove_rap_constraints
 Device.prove_openings = _prove_openings

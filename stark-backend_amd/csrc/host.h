@@ -79,6 +79,11 @@ struct AirKey {
     bool need_rot = false, is_required = true;
     unsigned max_constraint_degree = 0, num_public_values = 0;
     size_t common_main_width = 0;
+    size_t preprocessed_width = 0;       // 0 = no preprocessed trace
+    std::vector<size_t> cached_widths;   // cached main partitions (part_index 0..m-1; common main is part m)
+    // host copy of the preprocessed trace from the blob's PREP section (column-major, Montgomery)
+    std::vector<Fp> preprocessed_vals;
+    size_t preprocessed_height = 0;
 };
 struct ProvingKey {
     Params params;
@@ -117,12 +122,12 @@ inline ProvingKey parse_pk_blob(const uint32_t *w, size_t n) {
         air.max_constraint_degree = next();
         air.num_public_values = next();
         uint32_t has_pre = next();
-        next();  // preprocessed width
+        air.preprocessed_width = next();
+        if (!has_pre) air.preprocessed_width = 0;
+        if (has_pre && air.preprocessed_width == 0) throw OvmFail(1, "preprocessed trace of width 0");
         uint32_t num_cached = next();
-        for (uint32_t c = 0; c < num_cached; c++) next();
+        for (uint32_t c = 0; c < num_cached; c++) air.cached_widths.push_back(next());
         air.common_main_width = next();
-        if (has_pre || num_cached)
-            throw OvmFail(801 /* hipErrorNotSupported */, "preprocessed / cached traces not supported yet");
         uint32_t nn = next();
         for (uint32_t k = 0; k < nn; k++) {
             Node nd;
@@ -152,6 +157,20 @@ inline ProvingKey parse_pk_blob(const uint32_t *w, size_t n) {
             air.interactions.push_back(it);
         }
         pk.airs.push_back(std::move(air));
+    }
+    // trailing section: 'PREP', then per AIR with a preprocessed trace: height, width*height values
+    bool any_pre = false;
+    for (auto &a : pk.airs) any_pre |= a.preprocessed_width != 0;
+    if (any_pre) {
+        if (next() != 0x50524550u) throw OvmFail(1, "pk blob: preprocessed section missing");
+        for (auto &a : pk.airs) {
+            if (!a.preprocessed_width) continue;
+            a.preprocessed_height = next();
+            if (a.preprocessed_height == 0 || (a.preprocessed_height & (a.preprocessed_height - 1)))
+                throw OvmFail(1, "preprocessed trace height");
+            a.preprocessed_vals.resize(a.preprocessed_width * a.preprocessed_height);
+            for (auto &v : a.preprocessed_vals) v = fp(next());
+        }
     }
     return pk;
 }

@@ -39,14 +39,21 @@ struct Program {
 // Flat column numbering of one trace's view: 0,1,2 = is_first, is_transition, is_last, then for
 // every matrix of view_mats (preprocessed, cached..., common) its columns, local then (if the AIR
 // needs rotation) next.
+// Flat column numbering of one trace view, in the reference's row_parts order
+// (logup_zerocheck/single.rs:147-158): selectors 0..2, then per matrix [local cols, rotated cols]
+// for the preprocessed trace (if any), the cached main partitions, the common main.
 struct ColumnMap {
     bool need_rot = false;
+    size_t pre_width = 0;            // preprocessed trace width (0 = none)
     std::vector<size_t> part_width;  // widths of [cached..., common]
     size_t total = 3;
+    size_t pre_base = 3;
     std::vector<size_t> part_base;  // flat index of part p, offset 0
     void finish() {
         part_base.clear();
         size_t cur = 3;
+        pre_base = cur;
+        cur += pre_width * (need_rot ? 2 : 1);
         for (size_t w : part_width) {
             part_base.push_back(cur);
             cur += w * (need_rot ? 2 : 1);
@@ -55,6 +62,9 @@ struct ColumnMap {
     }
     uint32_t col(uint32_t part, uint32_t offset, uint32_t index) const {
         return (uint32_t)(part_base[part] + (offset ? part_width[part] : 0) + index);
+    }
+    uint32_t pre_col(uint32_t offset, uint32_t index) const {
+        return (uint32_t)(pre_base + (offset ? pre_width : 0) + index);
     }
 };
 
@@ -120,11 +130,20 @@ inline Program compile_program(const AirKey &air, const ColumnMap &cm, const std
                     kind = K_CONST;
                     payload = public_values.at(nd.index).v;
                 } else if (nd.entry == E_MAIN) {
+                    if (nd.part_index >= cm.part_width.size() || nd.index >= cm.part_width[nd.part_index] ||
+                        (nd.offset && !cm.need_rot))
+                        throw OvmFail(1, "main variable out of range");
                     kind = K_COL;
                     payload = cm.col(nd.part_index, nd.offset, nd.index);
                     col_used[payload] = 1;
+                } else if (nd.entry == E_PREPROCESSED) {
+                    if (nd.index >= cm.pre_width || (nd.offset && !cm.need_rot))
+                        throw OvmFail(1, "preprocessed variable out of range");
+                    kind = K_COL;
+                    payload = cm.pre_col(nd.offset, nd.index);
+                    col_used[payload] = 1;
                 } else {
-                    throw OvmFail(801, "preprocessed / challenge variables not supported");
+                    throw OvmFail(801, "challenge variables not supported");
                 }
                 break;
             case N_IS_FIRST: kind = K_COL; payload = 0; col_used[0] = 1; break;

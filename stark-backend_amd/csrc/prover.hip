@@ -55,7 +55,10 @@ struct BlockCache {
     }
     void put(void *p) {
         auto it = live.find(p);
-        if (it == live.end()) return;
+        if (it == live.end()) {
+            (void)hipFree(p);  // allocated through another thread's cache (a key freed off-thread)
+            return;
+        }
         free_blocks.emplace(it->second, p);
         cached_bytes += it->second;
         live.erase(it);
@@ -258,11 +261,13 @@ __global__ void whir_eq_tables_kernel(const EF *zpows, uint32_t dim, uint32_t b0
 // ---------------------------------------------------------------------------------------------
 // Inputs / PCS data
 // ---------------------------------------------------------------------------------------------
+struct PcsData;
 struct TraceIn {
     uint32_t air_idx;
-    const Fp *d_trace;  // column-major, width from the key
+    const Fp *d_trace;  // common main, column-major, width from the key
     size_t height;
     std::vector<Fp> public_values;
+    std::vector<const PcsData *> cached;  // committed cached main partitions, in partition order
 };
 
 struct PcsData {
@@ -270,6 +275,10 @@ struct PcsData {
     unsigned log_height = 0, log_rows = 0, k = 0;
     DevBuf<Fp> stacked, msg, codeword;
     const Fp *stacked_view = nullptr;  // the stacked matrix: `stacked`, or the caller's trace when that IS the matrix
+    // single-matrix commitments (preprocessed / cached main): the committed trace itself
+    const Fp *mat_ptr = nullptr;
+    size_t mat_w = 0, mat_h = 0;
+    DevBuf<Fp> own_mat;  // backing store when the commitment owns the trace (preprocessed, from the key blob)
     DevBuf<p2::Digest> layers;
     p2::Digest root;
     size_t query_stride() const { return size_t(1) << (log_rows - k); }
@@ -301,8 +310,16 @@ struct WallTrace {
     }
 };
 
+// Proving key on the device: the parsed key plus, per AIR, the committed preprocessed trace
+// (DeviceStarkProvingKey::preprocessed_data, prover/types.rs:43-50); null where the AIR has none.
+struct DeviceKey {
+    ProvingKey pk;
+    std::vector<std::unique_ptr<PcsData>> pre;
+};
+
 struct Prover {
     WallTrace wt;
+    const DeviceKey &dk;
     const ProvingKey &pk;
     Ctx cx;
     Mailbox &mb;
@@ -313,26 +330,44 @@ struct Prover {
     ByteWriter out;
     std::vector<size_t> section_offsets;
 
-    Prover(const ProvingKey &pk_, hipStream_t s) : pk(pk_), cx{s}, mb(mailbox()) {
+    Prover(const DeviceKey &dk_, hipStream_t s) : dk(dk_), pk(dk_.pk), cx{s}, mb(mailbox()) {
         ts.stream = s;
         mb.reset(s);
     }
 
     const Params &P() const { return pk.params; }
     const AirKey &air(size_t t) const { return pk.airs[traces[t].air_idx]; }
+    const PcsData *pre_of(size_t t) const {
+        const uint32_t a = traces[t].air_idx;
+        return a < dk.pre.size() ? dk.pre[a].get() : nullptr;
+    }
 
     // -----------------------------------------------------------------------------------------
     // Stage 1: commit (TraceCommitter::commit)
     // -----------------------------------------------------------------------------------------
+    struct MatIn {
+        const Fp *ptr;
+        size_t w, h;
+    };
     PcsData commit() {
+        std::vector<MatIn> mats;
+        for (size_t t = 0; t < traces.size(); t++) mats.push_back({traces[t].d_trace, air(t).common_main_width, traces[t].height});
+        return commit_mats(mats);
+    }
+    // stacked_commit (stacked_pcs.rs:103-140) of column-major device matrices sorted by height (descending)
+    PcsData commit_mats(const std::vector<MatIn> &mats) {
         const unsigned l_skip = P().l_skip, lh = l_skip + P().n_stack;
         PcsData d;
         std::vector<std::pair<size_t, unsigned>> meta;
         size_t total_cells = 0;
-        for (size_t t = 0; t < traces.size(); t++) {
-            size_t w = air(t).common_main_width;
-            meta.push_back({w, log2_strict(traces[t].height)});
-            total_cells += std::max(traces[t].height, size_t(1) << l_skip) * w;
+        for (auto &m : mats) {
+            meta.push_back({m.w, log2_strict(m.h)});
+            total_cells += std::max(m.h, size_t(1) << l_skip) * m.w;
+        }
+        if (mats.size() == 1) {
+            d.mat_ptr = mats[0].ptr;
+            d.mat_w = mats[0].w;
+            d.mat_h = mats[0].h;
         }
         d.layout = Layout(l_skip, lh, meta);
         const size_t H = size_t(1) << lh, width = (total_cells + H - 1) / H;
@@ -342,29 +377,28 @@ struct Prover {
         // Column-major traces stack by concatenation, so ONE trace that fills the matrix exactly already is
         // the stacked matrix (config D: 100 columns of 2^22 = 25 columns of 2^24): no copy, the trace is
         // only ever read. Otherwise: one device copy per trace into a zero-padded buffer.
-        const bool alias = traces.size() == 1 && traces[0].height >= (size_t(1) << l_skip) &&
-                           traces[0].height * air(0).common_main_width == width * H;
+        const bool alias = mats.size() == 1 && mats[0].h >= (size_t(1) << l_skip) && mats[0].h * mats[0].w == width * H;
         if (alias) {
-            d.stacked_view = traces[0].d_trace;
+            d.stacked_view = mats[0].ptr;
         } else {
             d.stacked.alloc(width * H);
             d.stacked_view = d.stacked.p;
             OVM_THROW_IF(hipMemsetAsync(d.stacked.p, 0, width * H * sizeof(Fp), cx.stream));
         }
-        for (size_t t = 0; t < traces.size() && !alias; t++) {
-            size_t w = air(t).common_main_width, h = traces[t].height;
+        for (size_t t = 0; t < mats.size() && !alias; t++) {
+            size_t w = mats[t].w, h = mats[t].h;
             if (w == 0) continue;
             const Slice &s0 = d.layout.cols[d.layout.mat_starts[t]].slice;
             Fp *dst = d.stacked.p + s0.col_idx * H + s0.row_idx;
             if (s0.log_height >= l_skip) {
                 // the columns of one trace occupy one contiguous range of the stacked buffer
-                OVM_THROW_IF(hipMemcpyAsync(dst, traces[t].d_trace, w * h * sizeof(Fp), hipMemcpyDeviceToDevice, cx.stream));
+                OVM_THROW_IF(hipMemcpyAsync(dst, mats[t].ptr, w * h * sizeof(Fp), hipMemcpyDeviceToDevice, cx.stream));
             } else {
                 size_t stride = s0.stride(l_skip), len = s0.len(l_skip);
                 for (size_t j = 0; j < w; j++) {
                     const Slice &s = d.layout.cols[d.layout.mat_starts[t] + j].slice;
                     hipLaunchKernelGGL(stack_strided_kernel, dim3(ceil_div(h, 256)), dim3(256), 0, cx.stream,
-                                       traces[t].d_trace + j * h, d.stacked.p + s.col_idx * H + s.row_idx, (uint64_t)h,
+                                       mats[t].ptr + j * h, d.stacked.p + s.col_idx * H + s.row_idx, (uint64_t)h,
                                        (uint64_t)stride);
                     (void)len;
                 }
@@ -448,7 +482,9 @@ struct Prover {
             v.n = (int)v.log_height - (int)l_skip;
             v.n_lift = (unsigned)std::max(v.n, 0);
             v.cm.need_rot = air(t).need_rot;
-            v.cm.part_width = {air(t).common_main_width};
+            v.cm.pre_width = air(t).preprocessed_width;
+            v.cm.part_width = air(t).cached_widths;
+            v.cm.part_width.push_back(air(t).common_main_width);
             v.cm.finish();
             size_t ni = air(t).interactions.size();
             total_interactions += (uint64_t)ni << v.log_lifted;
@@ -458,11 +494,28 @@ struct Prover {
             OVM_THROW_IF(build_selectors(v.sels.p, v.log_lifted, v.log_height, cx.stream));
             std::vector<ColDesc> cd(v.cm.total);
             for (int sidx = 0; sidx < 3; sidx++) cd[sidx] = ColDesc{v.sels.p + ((size_t)sidx << v.log_lifted), v.log_lifted, 0};
-            size_t w = air(t).common_main_width;
-            for (size_t c = 0; c < w; c++) {
-                cd[v.cm.col(0, 0, c)] = ColDesc{traces[t].d_trace + c * traces[t].height, v.log_height, 0};
-                if (v.cm.need_rot) cd[v.cm.col(0, 1, c)] = ColDesc{traces[t].d_trace + c * traces[t].height, v.log_height, 1};
+            const size_t h = traces[t].height;
+            auto put_mat = [&](const Fp *ptr, size_t w, uint32_t base) {
+                for (size_t c = 0; c < w; c++) {
+                    cd[base + c] = ColDesc{ptr + c * h, v.log_height, 0};
+                    if (v.cm.need_rot) cd[base + w + c] = ColDesc{ptr + c * h, v.log_height, 1};
+                }
+            };
+            if (v.cm.pre_width) {
+                const PcsData *pp = pre_of(t);
+                if (!pp || pp->mat_h != h || pp->mat_w != v.cm.pre_width)
+                    throw OvmFail(1, "preprocessed trace missing or of the wrong shape");
+                put_mat(pp->mat_ptr, pp->mat_w, v.cm.pre_col(0, 0));
             }
+            const size_t n_cached = air(t).cached_widths.size();
+            if (traces[t].cached.size() != n_cached) throw OvmFail(1, "cached main partitions: wrong count");
+            for (size_t k = 0; k < n_cached; k++) {
+                const PcsData *cp = traces[t].cached[k];
+                if (!cp || cp->mat_h != h || cp->mat_w != air(t).cached_widths[k] || !cp->mat_ptr)
+                    throw OvmFail(1, "cached main partition of the wrong shape");
+                put_mat(cp->mat_ptr, cp->mat_w, v.cm.col((uint32_t)k, 0, 0));
+            }
+            put_mat(traces[t].d_trace, air(t).common_main_width, v.cm.col((uint32_t)n_cached, 0, 0));
             v.cols = cx.upload(cd);
         }
         const unsigned n_max = tv[0].n_lift;
@@ -1001,27 +1054,34 @@ struct Prover {
         }
 
         wt.mark("rap.mle_rounds");
-        // ---- openings ----
-        std::vector<std::vector<EF>> openings(T);
+        // ---- openings ---- (cpu.rs:644-694, mod.rs:408-424): per trace the parts [common main,
+        // preprocessed?, cached_0, ...], each as (claim, rotated claim) pairs when the AIR needs rotation
+        std::vector<std::vector<std::vector<EF>>> openings(T);
         for (size_t t = 0; t < T; t++) {
             TraceView &v = tv[t];
-            size_t wd = air(t).common_main_width;
-            for (size_t c = 0; c < wd; c++) {
-                openings[t].push_back(v.final_row[v.cm.col(0, 0, c)]);
-                if (v.cm.need_rot) openings[t].push_back(v.final_row[v.cm.col(0, 1, c)]);
-            }
-        }
-        for (size_t t = 0; t < T; t++) {
-            if (tv[t].cm.need_rot) {
-                for (auto &x : openings[t]) ts.observe_ext(x);
-            } else {
-                for (auto &x : openings[t]) {
-                    ts.observe_ext(x);
-                    ts.observe_ext(EF::zero());
+            auto part = [&](size_t wd, uint32_t base) {
+                std::vector<EF> o;
+                for (size_t c = 0; c < wd; c++) {
+                    o.push_back(v.final_row[base + c]);
+                    if (v.cm.need_rot) o.push_back(v.final_row[base + wd + c]);
                 }
-            }
+                return o;
+            };
+            const size_t n_cached = air(t).cached_widths.size();
+            openings[t].push_back(part(air(t).common_main_width, v.cm.col((uint32_t)n_cached, 0, 0)));
+            if (v.cm.pre_width) openings[t].push_back(part(v.cm.pre_width, v.cm.pre_col(0, 0)));
+            for (size_t k = 0; k < n_cached; k++)
+                openings[t].push_back(part(air(t).cached_widths[k], v.cm.col((uint32_t)k, 0, 0)));
         }
-        column_openings = openings;
+        auto observe_part = [&](const std::vector<EF> &o, bool rot) {
+            for (auto &x : o) {
+                ts.observe_ext(x);
+                if (!rot) ts.observe_ext(EF::zero());
+            }
+        };
+        for (size_t t = 0; t < T; t++) observe_part(openings[t][0], tv[t].cm.need_rot);  // common mains first
+        for (size_t t = 0; t < T; t++)
+            for (size_t k = 1; k < openings[t].size(); k++) observe_part(openings[t][k], tv[t].cm.need_rot);
 
         // batch constraint proof bytes
         w.e_slice(numer_terms);
@@ -1034,44 +1094,75 @@ struct Prover {
                 for (auto &x : rp) w.e(x);
         }
         for (size_t t = 0; t < T; t++) {
-            w.usize(1);
-            w.e_slice(openings[t]);
+            w.usize(openings[t].size());
+            for (auto &o : openings[t]) w.e_slice(o);
         }
         section_offsets.push_back(w.buf.size());
         return r;
     }
-    std::vector<std::vector<EF>> column_openings;
 
     // -----------------------------------------------------------------------------------------
     // Stage 3: stacked opening reduction + WHIR (OpeningProver::prove_openings)
     // -----------------------------------------------------------------------------------------
-    void prove_openings(PcsData &pcs, const std::vector<EF> &r) {
+    // `commits`: the common-main commitment first, then per trace (sorted order) its preprocessed
+    // commitment (if any) and its cached mains (cpu-backend/src/device.rs:147-172).
+    std::vector<const PcsData *> gather_commits(const PcsData &common, std::vector<std::vector<bool>> &need_rot) const {
+        std::vector<const PcsData *> commits{&common};
+        need_rot.clear();
+        need_rot.emplace_back();
+        for (size_t t = 0; t < traces.size(); t++) need_rot[0].push_back(air(t).need_rot);
+        for (size_t t = 0; t < traces.size(); t++) {
+            if (air(t).preprocessed_width) {
+                if (!pre_of(t)) throw OvmFail(1, "preprocessed commitment missing");
+                commits.push_back(pre_of(t));
+                need_rot.push_back({air(t).need_rot});
+            }
+            for (auto *c : traces[t].cached) {
+                commits.push_back(c);
+                need_rot.push_back({air(t).need_rot});
+            }
+        }
+        return commits;
+    }
+
+    void prove_openings(const PcsData &common_main, const std::vector<EF> &r) {
         const unsigned l_skip = P().l_skip, n_stack = P().n_stack;
         const size_t N = size_t(1) << l_skip, H = size_t(1) << (l_skip + n_stack);
-        const size_t width = pcs.layout.width;
+        std::vector<std::vector<bool>> need_rot_per_commit;
+        const std::vector<const PcsData *> commits = gather_commits(common_main, need_rot_per_commit);
+        // the stacked matrices of all commitments side by side: commitment c owns columns [coff[c], coff[c+1])
+        std::vector<size_t> coff{0};
+        for (auto *c : commits) {
+            if (c->log_height != l_skip + n_stack) throw OvmFail(1, "commitment with a different stacked height");
+            coff.push_back(coff.back() + c->layout.width);
+        }
+        const size_t width = coff.back();
         ByteWriter &w = out;
         const Fp g = fp(bb::GENERATOR), omega_skip = bb::two_adic_generator(l_skip);
         std::vector<Fp> omega_pows = powers_of(omega_skip, N);
 
         EF lambda = ts.sample_ext();
         struct TV {
+            size_t com;
             Slice s;
             size_t leq;
             long lrot;
         };
         std::vector<TV> tvs;
         size_t li = 0;
-        for (auto &sc : pcs.layout.cols) {
-            TV t{sc.slice, li, -1};
-            li++;
-            if (air(sc.mat_idx).need_rot) t.lrot = (long)li;
-            li++;
-            tvs.push_back(t);
-        }
+        for (size_t com = 0; com < commits.size(); com++)
+            for (auto &sc : commits[com]->layout.cols) {
+                TV t{com, sc.slice, li, -1};
+                li++;
+                if (need_rot_per_commit[com][sc.mat_idx]) t.lrot = (long)li;
+                li++;
+                tvs.push_back(t);
+            }
         std::vector<EF> lam = powers_of(lambda, li);
+        // windows: runs of slices of one height inside one commitment (contiguous in that stacked matrix)
         std::vector<size_t> win;
         for (size_t i = 0; i < tvs.size(); i++)
-            if (i == 0 || tvs[i].s.log_height != tvs[i - 1].s.log_height) win.push_back(i);
+            if (i == 0 || tvs[i].s.log_height != tvs[i - 1].s.log_height || tvs[i].com != tvs[i - 1].com) win.push_back(i);
         win.push_back(tvs.size());
         const size_t W = win.size() - 1;
         const EF r0 = r[0];
@@ -1109,7 +1200,7 @@ struct Prover {
             auto d_leq = cx.upload(leq);
             auto d_lrot = cx.upload(lrot);
             unsigned log_len = std::max(wd.log_height, l_skip);
-            const Fp *base = pcs.stacked_view + tvs[w0].s.col_idx * H + tvs[w0].s.row_idx;
+            const Fp *base = commits[tvs[w0].com]->stacked_view + tvs[w0].s.col_idx * H + tvs[w0].s.row_idx;
             OVM_THROW_IF(stacked_round0(base, (uint32_t)(w1 - w0), log_len, l_skip, d_leq.p, d_lrot.p, wd.eq_cube.p,
                                         mb.arm(partials.p), cx.stream));
             auto R = mb.take(3 * N, cx.stream);
@@ -1159,7 +1250,9 @@ struct Prover {
             for (size_t z = 0; z < N; z++) wts[z] = un * (u0 - omega_pows[z]).inv() * (omega_pows[z] * ninv);
             auto d_w = cx.upload(wts);
             std::vector<ColDesc> cd(width);
-            for (size_t c = 0; c < width; c++) cd[c] = ColDesc{pcs.stacked_view + c * H, l_skip + n_stack, 0};
+            for (size_t com = 0; com < commits.size(); com++)
+                for (size_t c = 0; c < commits[com]->layout.width; c++)
+                    cd[coff[com] + c] = ColDesc{commits[com]->stacked_view + c * H, l_skip + n_stack, 0};
             auto d_cd = cx.upload(cd);
             OVM_THROW_IF(fold_ple(d_cd.p, (uint32_t)width, l_skip + n_stack, l_skip, d_w.p, q_a.p, cx.stream));
             cx.sync();
@@ -1187,7 +1280,7 @@ struct Prover {
                 std::vector<uint64_t> off;
                 std::vector<EF> ce, cr;
                 for (size_t i = w0; i < w1; i++) {
-                    off.push_back(((uint64_t)tvs[i].s.col_idx << n_stack) + (tvs[i].s.row_idx >> l_skip));
+                    off.push_back(((uint64_t)(coff[tvs[i].com] + tvs[i].s.col_idx) << n_stack) + (tvs[i].s.row_idx >> l_skip));
                     ce.push_back(lam[tvs[i].leq]);
                     cr.push_back(tvs[i].lrot >= 0 ? lam[(size_t)tvs[i].lrot] : EF::zero());
                 }
@@ -1221,8 +1314,9 @@ struct Prover {
                 if (round > ws[wi].n_lift)
                     for (size_t i = win[wi]; i < win[wi + 1]; i++) {
                         uint64_t row_start = (tvs[i].s.row_idx >> (l_skip + round)) << 1;
-                        gidx.push_back(((uint64_t)tvs[i].s.col_idx << q_log_h) + row_start);
-                        gidx.push_back(((uint64_t)tvs[i].s.col_idx << q_log_h) + row_start + 1);
+                        const uint64_t gcol = coff[tvs[i].com] + tvs[i].s.col_idx;
+                        gidx.push_back((gcol << q_log_h) + row_start);
+                        gidx.push_back((gcol << q_log_h) + row_start + 1);
                         gslice.push_back(i);
                     }
             std::vector<EF> gv;
@@ -1299,8 +1393,9 @@ struct Prover {
         w.usize(st_polys.size());
         for (auto &a : st_polys)
             for (auto &x : a) w.e(x);
-        w.usize(1);
-        w.e_slice(stacking_openings);
+        w.usize(commits.size());
+        for (size_t com = 0; com < commits.size(); com++)
+            w.e_slice(std::vector<EF>(stacking_openings.begin() + coff[com], stacking_openings.begin() + coff[com + 1]));
         section_offsets.push_back(w.buf.size());
 
         wt.mark("openings.stacked");
@@ -1324,7 +1419,9 @@ struct Prover {
             OVM_PROF("whir.mu_batch", cx.stream);
             std::vector<EF> mu_pows = powers_of(mu, width);
             auto d_mu = cx.upload(mu_pows);
-            OVM_THROW_IF(whir_mu_batch(pcs.msg.p, (uint32_t)width, m, d_mu.p, 0, f_a.p, 0, cx.stream));
+            for (size_t com = 0; com < commits.size(); com++)
+                OVM_THROW_IF(whir_mu_batch(commits[com]->msg.p, (uint32_t)commits[com]->layout.width, m, d_mu.p,
+                                           (uint32_t)coff[com], f_a.p, com ? 1 : 0, cx.stream));
             OVM_THROW_IF(zeta_transform(f_a.p, m, +1, cx.stream));
             auto d_u = cx.upload(u_cube);
             OVM_THROW_IF(mobius_eq_table(d_u.p, m, w_a.p, cx.stream));
@@ -1335,8 +1432,9 @@ struct Prover {
         std::vector<p2::Digest> codeword_commits;
         std::vector<EF> ood_values, final_poly;
         std::vector<Fp> folding_pows, query_pows;
-        std::vector<std::vector<std::vector<Fp>>> init_rows;       // per query: 2^k rows x width
-        std::vector<std::vector<p2::Digest>> init_proofs;           // per query
+        // per commitment, per query: 2^k rows x that commitment's width / the Merkle path
+        std::vector<std::vector<std::vector<std::vector<Fp>>>> init_rows(commits.size());
+        std::vector<std::vector<std::vector<p2::Digest>>> init_proofs(commits.size());
         std::vector<std::vector<std::vector<EF>>> cw_values;        // per round, per query: 2^k
         std::vector<std::vector<std::vector<p2::Digest>>> cw_proofs;
         unsigned log_rs = m + log_blowup;
@@ -1408,20 +1506,24 @@ struct Prover {
                 auto d_didx = cx.upload(didx);
                 DevBuf<p2::Digest> d_dig(std::max<size_t>(didx.size(), 1));
                 if (wr == 0) {
-                    DevBuf<Fp> d_vals(std::max<size_t>(rows.size() * width, 1));
-                    OVM_THROW_IF(ovm_hip_gather_rows((const uint32_t *)pcs.codeword.p, width, 1ull << pcs.log_rows, 1, d_rows.p,
-                                                     rows.size(), (uint32_t *)d_vals.p, cx.stream));
-                    OVM_THROW_IF(ovm_hip_gather_digests((const uint32_t *)pcs.layers.p, d_didx.p, didx.size(), (uint32_t *)d_dig.p, cx.stream));
-                    auto vals = cx.download(d_vals.p, rows.size() * width);
-                    auto digs = cx.download(d_dig.p, didx.size());
-                    for (size_t q = 0; q < nq; q++) {
-                        std::vector<std::vector<Fp>> qr;
-                        for (size_t t = 0; t < (size_t(1) << k_whir); t++) {
-                            size_t ro = (q << k_whir) + t;
-                            qr.emplace_back(vals.begin() + ro * width, vals.begin() + (ro + 1) * width);
+                    for (size_t com = 0; com < commits.size(); com++) {
+                        const PcsData &pcs = *commits[com];
+                        const size_t cw = pcs.layout.width;
+                        DevBuf<Fp> d_vals(std::max<size_t>(rows.size() * cw, 1));
+                        OVM_THROW_IF(ovm_hip_gather_rows((const uint32_t *)pcs.codeword.p, cw, 1ull << pcs.log_rows, 1, d_rows.p,
+                                                         rows.size(), (uint32_t *)d_vals.p, cx.stream));
+                        OVM_THROW_IF(ovm_hip_gather_digests((const uint32_t *)pcs.layers.p, d_didx.p, didx.size(), (uint32_t *)d_dig.p, cx.stream));
+                        auto vals = cx.download(d_vals.p, rows.size() * cw);
+                        auto digs = cx.download(d_dig.p, didx.size());
+                        for (size_t q = 0; q < nq; q++) {
+                            std::vector<std::vector<Fp>> qr;
+                            for (size_t t = 0; t < (size_t(1) << k_whir); t++) {
+                                size_t ro = (q << k_whir) + t;
+                                qr.emplace_back(vals.begin() + ro * cw, vals.begin() + (ro + 1) * cw);
+                            }
+                            init_rows[com].push_back(std::move(qr));
+                            init_proofs[com].emplace_back(digs.begin() + q * lq, digs.begin() + (q + 1) * lq);
                         }
-                        init_rows.push_back(std::move(qr));
-                        init_proofs.emplace_back(digs.begin() + q * lq, digs.begin() + (q + 1) * lq);
                     }
                 } else {
                     DevBuf<EF> d_vals(std::max<size_t>(rows.size(), 1));
@@ -1489,16 +1591,18 @@ struct Prover {
         for (auto &x : ood_values) w.e(x);
         for (auto &x : folding_pows) w.f(x);
         for (auto &x : query_pows) w.f(x);
-        w.usize(1);
-        w.usize(init_rows.size());
-        if (!init_rows.empty()) {
-            w.usize(init_proofs[0].size());
-            w.usize(width);
-            for (auto &qr : init_rows)
-                for (auto &row : qr)
-                    for (auto &x : row) w.f(x);
-            for (auto &pr : init_proofs)
-                for (auto &d : pr) w.digest(d);
+        w.usize(commits.size());
+        w.usize(init_rows[0].size());
+        if (!init_rows[0].empty()) {
+            w.usize(init_proofs[0][0].size());
+            for (auto *c : commits) w.usize(c->layout.width);
+            for (auto &cr : init_rows)
+                for (auto &qr : cr)
+                    for (auto &row : qr)
+                        for (auto &x : row) w.f(x);
+            for (auto &cp : init_proofs)
+                for (auto &pr : cp)
+                    for (auto &d : pr) w.digest(d);
         }
         for (auto &round : cw_values) {
             w.usize(round.size());
@@ -1506,7 +1610,7 @@ struct Prover {
                 for (auto &x : q) w.e(x);
         }
         size_t first_depth = 0;
-        if (n_rounds > 1 && !init_rows.empty()) first_depth = cw_proofs[0][0].size();
+        if (n_rounds > 1 && !init_rows[0].empty()) first_depth = cw_proofs[0][0].size();
         w.usize(first_depth);
         for (auto &round : cw_proofs)
             for (auto &pr : round)
@@ -1546,8 +1650,16 @@ struct Prover {
         for (size_t a = 0; a < num_airs; a++) {
             if (!pk.airs[a].is_required) ts.observe(present[a] >= 0 ? Fp::one() : Fp::zero());
             if (present[a] >= 0) {
-                ts.observe(fp(log2_strict(traces[present[a]].height)));
-                for (auto &pv : traces[present[a]].public_values) ts.observe(pv);
+                const size_t t = (size_t)present[a];
+                // prover/mod.rs:156-170: a preprocessed commitment stands in for the height
+                if (pk.airs[a].preprocessed_width) {
+                    if (!pre_of(t)) throw OvmFail(1, "preprocessed commitment missing");
+                    ts.observe_digest(pre_of(t)->root);
+                } else {
+                    ts.observe(fp(log2_strict(traces[t].height)));
+                }
+                for (auto *c : traces[t].cached) ts.observe_digest(c->root);
+                for (auto &pv : traces[t].public_values) ts.observe(pv);
             }
         }
         // proof header
@@ -1563,7 +1675,8 @@ struct Prover {
         for (size_t a = 0; a < num_airs; a++)
             if (present[a] >= 0) {
                 out.usize(log2_strict(traces[present[a]].height));
-                out.usize(0);  // cached commitments
+                out.usize(traces[present[a]].cached.size());
+                for (auto *c : traces[present[a]].cached) out.digest(c->root);
             }
         out.usize(num_airs);
         for (size_t a = 0; a < num_airs; a++) {
@@ -1589,18 +1702,20 @@ using namespace ovm;
 static thread_local std::string g_last_error;
 
 namespace {
-std::vector<TraceIn> traces_from_abi(uint32_t n_traces, const uint32_t *air_idx, const uint32_t *const *d_traces,
-                                     const uint64_t *heights, const uint32_t *const *public_values,
-                                     const uint32_t *num_public_values) {
+std::vector<TraceIn> traces_from_abi(uint32_t n_traces, const ovm_trace_t *tr) {
+    if (!tr) throw OvmFail((int)hipErrorInvalidValue, "traces");
     std::vector<TraceIn> in;
     for (uint32_t t = 0; t < n_traces; t++) {
         TraceIn ti;
-        ti.air_idx = air_idx[t];
-        ti.d_trace = d_traces ? (const Fp *)d_traces[t] : nullptr;
-        ti.height = heights[t];
+        ti.air_idx = tr[t].air_idx;
+        ti.d_trace = (const Fp *)tr[t].d_common_main;
+        ti.height = tr[t].height;
         if (ti.height == 0 || (ti.height & (ti.height - 1))) throw OvmFail((int)hipErrorInvalidValue, "trace height");
-        for (uint32_t i = 0; i < (num_public_values ? num_public_values[t] : 0); i++)
-            ti.public_values.push_back(Fp::raw(public_values[t][i]));
+        for (uint32_t i = 0; i < tr[t].num_public_values; i++) ti.public_values.push_back(Fp::raw(tr[t].public_values[i]));
+        for (uint32_t i = 0; i < tr[t].num_cached; i++) {
+            if (!tr[t].cached || !tr[t].cached[i]) throw OvmFail((int)hipErrorInvalidValue, "cached main handle");
+            ti.cached.push_back(reinterpret_cast<const PcsData *>(tr[t].cached[i]));
+        }
         in.push_back(std::move(ti));
     }
     return in;
@@ -1635,20 +1750,41 @@ int guarded(F &&f) {
 
 extern "C" {
 
-int ovm_hip_pk_load(const uint32_t *blob, uint64_t words, ovm_pk_t **pk_out) {
+int ovm_hip_pk_load(const uint32_t *blob, uint64_t words, ovm_pk_t **pk_out, ovm_stream_t stream) {
     if (!blob || !pk_out) return (int)hipErrorInvalidValue;
-    try {
-        auto *pk = new ProvingKey(parse_pk_blob(blob, words));
-        *pk_out = reinterpret_cast<ovm_pk_t *>(pk);
+    return guarded([&]() -> int {
+        auto dk = std::make_unique<DeviceKey>();
+        dk->pk = parse_pk_blob(blob, words);
+        dk->pre.resize(dk->pk.airs.size());
+        // keygen's part of the device work: upload and commit every preprocessed trace on its own
+        // (keygen/mod.rs:283-300; DeviceDataTransporter::transport_pk_to_device, hal.rs:141-150)
+        for (size_t a = 0; a < dk->pk.airs.size(); a++) {
+            const AirKey &air = dk->pk.airs[a];
+            if (!air.preprocessed_width) continue;
+            Prover pr(*dk, (hipStream_t)stream);
+            DevBuf<Fp> dev(air.preprocessed_vals.size());
+            OVM_THROW_IF(hipMemcpyAsync(dev.p, air.preprocessed_vals.data(), air.preprocessed_vals.size() * sizeof(Fp),
+                                        hipMemcpyHostToDevice, (hipStream_t)stream));
+            auto pcs = std::make_unique<PcsData>(
+                pr.commit_mats({{dev.p, air.preprocessed_width, air.preprocessed_height}}));
+            pr.cx.sync();
+            pcs->own_mat = std::move(dev);
+            dk->pre[a] = std::move(pcs);
+        }
+        *pk_out = reinterpret_cast<ovm_pk_t *>(dk.release());
         return 0;
-    } catch (const OvmFail &e) {
-        return e.code;
-    } catch (...) {
-        return (int)hipErrorUnknown;
-    }
+    });
 }
 
-void ovm_hip_pk_free(ovm_pk_t *pk) { delete reinterpret_cast<ProvingKey *>(pk); }
+void ovm_hip_pk_free(ovm_pk_t *pk) { delete reinterpret_cast<DeviceKey *>(pk); }
+
+int ovm_hip_pk_preprocessed_commitment(const ovm_pk_t *pk_, uint32_t air_idx, uint32_t commitment_out[8]) {
+    if (!pk_ || !commitment_out) return (int)hipErrorInvalidValue;
+    const DeviceKey &dk = *reinterpret_cast<const DeviceKey *>(pk_);
+    if (air_idx >= dk.pre.size() || !dk.pre[air_idx]) return (int)hipErrorInvalidValue;
+    for (int i = 0; i < 8; i++) commitment_out[i] = dk.pre[air_idx]->root.d[i].v;
+    return 0;
+}
 
 int ovm_hip_trim(void) {
     block_cache().trim();
@@ -1657,60 +1793,48 @@ int ovm_hip_trim(void) {
 
 const char *ovm_hip_last_error(void) { return g_last_error.c_str(); }
 
-int ovm_hip_prove(const ovm_pk_t *pk_, uint32_t n_traces, const uint32_t *air_idx, const uint32_t *const *d_traces,
-                  const uint64_t *heights, const uint32_t *const *public_values, const uint32_t *num_public_values,
-                  ovm_sponge_t *sponge, uint8_t *proof_out, uint64_t proof_cap, uint64_t *proof_len,
-                  uint64_t *section_offsets5, ovm_stream_t stream) {
-    if (!pk_ || !proof_len || n_traces == 0) return (int)hipErrorInvalidValue;
-    const ProvingKey &pk = *reinterpret_cast<const ProvingKey *>(pk_);
-    try {
-        if (!twiddles()) return (int)hipErrorInitializationError;
-        Prover pr(pk, (hipStream_t)stream);
-        if (sponge) {
-            for (int i = 0; i < 16; i++) pr.ts.s.state[i] = Fp::raw(sponge->state[i]);
-            pr.ts.s.absorb_idx = sponge->absorb_idx;
-            pr.ts.s.sample_idx = sponge->sample_idx;
-        }
-        std::vector<TraceIn> in;
-        for (uint32_t t = 0; t < n_traces; t++) {
-            TraceIn ti;
-            ti.air_idx = air_idx[t];
-            ti.d_trace = (const Fp *)d_traces[t];
-            ti.height = heights[t];
-            if (ti.height == 0 || (ti.height & (ti.height - 1))) return (int)hipErrorInvalidValue;
-            for (uint32_t i = 0; i < (num_public_values ? num_public_values[t] : 0); i++)
-                ti.public_values.push_back(Fp::raw(public_values[t][i]));
-            in.push_back(std::move(ti));
-        }
-        pr.prove(std::move(in));
+int ovm_hip_prove(const ovm_pk_t *pk_, uint32_t n_traces, const ovm_trace_t *traces, ovm_sponge_t *sponge,
+                  uint8_t *proof_out, uint64_t proof_cap, uint64_t *proof_len, uint64_t *section_offsets5,
+                  ovm_stream_t stream) {
+    if (!pk_ || !proof_len || n_traces == 0 || !traces) return (int)hipErrorInvalidValue;
+    const DeviceKey &dk = *reinterpret_cast<const DeviceKey *>(pk_);
+    return guarded([&]() -> int {
+        Prover pr(dk, (hipStream_t)stream);
+        sponge_in(pr, sponge);
+        pr.prove(traces_from_abi(n_traces, traces));
         *proof_len = pr.out.buf.size();
         if (section_offsets5)
             for (size_t i = 0; i < 5 && i < pr.section_offsets.size(); i++) section_offsets5[i] = pr.section_offsets[i];
-        if (sponge) {
-            for (int i = 0; i < 16; i++) sponge->state[i] = pr.ts.s.state[i].v;
-            sponge->absorb_idx = pr.ts.s.absorb_idx;
-            sponge->sample_idx = pr.ts.s.sample_idx;
-        }
+        sponge_out(pr, sponge);
         if (pr.out.buf.size() > proof_cap || !proof_out) return (int)hipErrorInvalidValue;
         memcpy(proof_out, pr.out.buf.data(), pr.out.buf.size());
         return 0;
-    } catch (const OvmFail &e) {
-        g_last_error = e.what();
-        return e.code ? e.code : (int)hipErrorUnknown;
-    } catch (const std::exception &e) {
-        g_last_error = e.what();
-        return (int)hipErrorUnknown;
-    }
+    });
 }
 
-int ovm_hip_commit(const ovm_pk_t *pk_, uint32_t n_traces, const uint32_t *air_idx, const uint32_t *const *d_traces,
-                   const uint64_t *heights, uint32_t commitment_out[8], ovm_pcs_t **pcs_out, ovm_stream_t stream) {
-    if (!pk_ || !pcs_out || !commitment_out || n_traces == 0 || !d_traces) return (int)hipErrorInvalidValue;
-    const ProvingKey &pk = *reinterpret_cast<const ProvingKey *>(pk_);
+int ovm_hip_commit(const ovm_pk_t *pk_, uint32_t n_traces, const ovm_trace_t *traces, uint32_t commitment_out[8],
+                   ovm_pcs_t **pcs_out, ovm_stream_t stream) {
+    if (!pk_ || !pcs_out || !commitment_out || n_traces == 0 || !traces) return (int)hipErrorInvalidValue;
+    const DeviceKey &dk = *reinterpret_cast<const DeviceKey *>(pk_);
     return guarded([&]() -> int {
-        Prover pr(pk, (hipStream_t)stream);
-        pr.set_traces(traces_from_abi(n_traces, air_idx, d_traces, heights, nullptr, nullptr), false);
+        Prover pr(dk, (hipStream_t)stream);
+        pr.set_traces(traces_from_abi(n_traces, traces), false);
         auto *pcs = new PcsData(pr.commit());
+        pr.cx.sync();
+        for (int i = 0; i < 8; i++) commitment_out[i] = pcs->root.d[i].v;
+        *pcs_out = reinterpret_cast<ovm_pcs_t *>(pcs);
+        return 0;
+    });
+}
+
+int ovm_hip_commit_matrix(const ovm_pk_t *pk_, const uint32_t *d_matrix, uint64_t width, uint64_t height,
+                          uint32_t commitment_out[8], ovm_pcs_t **pcs_out, ovm_stream_t stream) {
+    if (!pk_ || !pcs_out || !commitment_out || !d_matrix || width == 0 || height == 0 || (height & (height - 1)))
+        return (int)hipErrorInvalidValue;
+    const DeviceKey &dk = *reinterpret_cast<const DeviceKey *>(pk_);
+    return guarded([&]() -> int {
+        Prover pr(dk, (hipStream_t)stream);
+        auto *pcs = new PcsData(pr.commit_mats({{(const Fp *)d_matrix, (size_t)width, (size_t)height}}));
         pr.cx.sync();
         for (int i = 0; i < 8; i++) commitment_out[i] = pcs->root.d[i].v;
         *pcs_out = reinterpret_cast<ovm_pcs_t *>(pcs);
@@ -1720,18 +1844,16 @@ int ovm_hip_commit(const ovm_pk_t *pk_, uint32_t n_traces, const uint32_t *air_i
 
 void ovm_hip_pcs_free(ovm_pcs_t *pcs) { delete reinterpret_cast<PcsData *>(pcs); }
 
-int ovm_hip_prove_rap_constraints(const ovm_pk_t *pk_, uint32_t n_traces, const uint32_t *air_idx,
-                                  const uint32_t *const *d_traces, const uint64_t *heights,
-                                  const uint32_t *const *public_values, const uint32_t *num_public_values,
+int ovm_hip_prove_rap_constraints(const ovm_pk_t *pk_, uint32_t n_traces, const ovm_trace_t *traces,
                                   ovm_sponge_t *sponge, uint8_t *out, uint64_t out_cap, uint64_t *gkr_len,
                                   uint64_t *total_len, uint32_t *r_out, uint32_t r_cap, uint32_t *r_len,
                                   ovm_stream_t stream) {
-    if (!pk_ || !sponge || !total_len || !r_len || n_traces == 0 || !d_traces) return (int)hipErrorInvalidValue;
-    const ProvingKey &pk = *reinterpret_cast<const ProvingKey *>(pk_);
+    if (!pk_ || !sponge || !total_len || !r_len || n_traces == 0 || !traces) return (int)hipErrorInvalidValue;
+    const DeviceKey &dk = *reinterpret_cast<const DeviceKey *>(pk_);
     return guarded([&]() -> int {
-        Prover pr(pk, (hipStream_t)stream);
+        Prover pr(dk, (hipStream_t)stream);
         sponge_in(pr, sponge);
-        pr.set_traces(traces_from_abi(n_traces, air_idx, d_traces, heights, public_values, num_public_values));
+        pr.set_traces(traces_from_abi(n_traces, traces));
         std::vector<EF> r = pr.prove_rap_constraints();
         pr.cx.sync();
         sponge_out(pr, sponge);
@@ -1746,20 +1868,19 @@ int ovm_hip_prove_rap_constraints(const ovm_pk_t *pk_, uint32_t n_traces, const 
     });
 }
 
-int ovm_hip_prove_openings(const ovm_pk_t *pk_, uint32_t n_traces, const uint32_t *air_idx, const uint64_t *heights,
-                           ovm_pcs_t *common_main, const uint32_t *r, uint32_t r_len, ovm_sponge_t *sponge,
-                           uint8_t *out, uint64_t out_cap, uint64_t *stacking_len, uint64_t *total_len,
-                           ovm_stream_t stream) {
-    if (!pk_ || !sponge || !total_len || !common_main || !r || n_traces == 0) return (int)hipErrorInvalidValue;
-    const ProvingKey &pk = *reinterpret_cast<const ProvingKey *>(pk_);
+int ovm_hip_prove_openings(const ovm_pk_t *pk_, uint32_t n_traces, const ovm_trace_t *traces, ovm_pcs_t *common_main,
+                           const uint32_t *r, uint32_t r_len, ovm_sponge_t *sponge, uint8_t *out, uint64_t out_cap,
+                           uint64_t *stacking_len, uint64_t *total_len, ovm_stream_t stream) {
+    if (!pk_ || !sponge || !total_len || !common_main || !r || n_traces == 0 || !traces) return (int)hipErrorInvalidValue;
+    const DeviceKey &dk = *reinterpret_cast<const DeviceKey *>(pk_);
     return guarded([&]() -> int {
-        Prover pr(pk, (hipStream_t)stream);
+        Prover pr(dk, (hipStream_t)stream);
         sponge_in(pr, sponge);
-        pr.set_traces(traces_from_abi(n_traces, air_idx, nullptr, heights, nullptr, nullptr), false);
+        pr.set_traces(traces_from_abi(n_traces, traces), false);
         std::vector<EF> rv(r_len);
         for (uint32_t i = 0; i < r_len; i++)
             for (int k = 0; k < 4; k++) rv[i].c[k] = Fp::raw(r[4 * i + k]);
-        pr.prove_openings(*reinterpret_cast<PcsData *>(common_main), rv);
+        pr.prove_openings(*reinterpret_cast<const PcsData *>(common_main), rv);
         pr.cx.sync();
         sponge_out(pr, sponge);
         if (stacking_len) *stacking_len = pr.section_offsets.empty() ? 0 : pr.section_offsets[0];

@@ -72,7 +72,7 @@ uint64_t ovm_hip_profile_report(char *buf, uint64_t cap) {
     return out.size() + 1;
 }
 
-uint32_t ovm_hip_abi_version(void) { return 1; }
+uint32_t ovm_hip_abi_version(void) { return 2; }
 
 int ovm_hip_init(int device, uint32_t *cu_count) {
     OVM_CHECK(hipSetDevice(device));

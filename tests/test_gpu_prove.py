@@ -186,3 +186,63 @@ def test_reference_golden_proofs(dev, pkg, path):
             t["public_values"]) for t in doc["traces"]]
     got, _ = dev.prove(pk, dtr)
     assert got == bytes.fromhex(doc["proof_hex"])
+
+
+# ---- preprocessed / cached-main traces (reference fixtures test_utils/mod.rs:261-436) ----
+def run_partitioned(dev, pkg, orc, params, air_list, traces, preprocessed=None):
+    """traces: (air_idx, common, height, pvs[, cached partitions concatenated])."""
+    blob = airs.pk_blob(params, air_list, preprocessed=preprocessed)
+    want = orc.prove(blob, traces)
+    orc.verify(blob, want["proof"])
+    pk = pkg.ProvingKey(blob)
+    dtr = []
+    for t in traces:
+        a, tr, h, pv = t[:4]
+        cached = []
+        if len(t) > 4 and t[4] is not None:
+            off = 0
+            for w in air_list[a]["cached_main_widths"]:
+                part = dev.upload(pkg.to_mont(np.asarray(t[4][off:off + w * h], dtype=np.uint32)))
+                cached.append(dev.commit_matrix(pk, part, w, h))
+                off += w * h
+        dtr.append((a, dev.upload(pkg.to_mont(np.asarray(tr, dtype=np.uint32))), h, pv, cached))
+    got, secs = dev.prove(pk, dtr)
+    if got != want["proof"]:
+        n = min(len(got), len(want["proof"]))
+        first = next((i for i in range(n) if got[i] != want["proof"][i]), n)
+        sec = next((SECTIONS[k] for k, e in enumerate(secs) if first < e), "tail")
+        pytest.fail(f"proof differs at byte {first} (section {sec}); lengths {len(got)} vs {len(want['proof'])}")
+    orc.verify(blob, got)
+
+
+@pytest.mark.parametrize("log_h", [1, 3, 5])
+def test_preprocessed_fib(dev, pkg, orc, log_h):
+    sels = [i % 2 == 0 for i in range(1 << log_h)]
+    tr, pvs = airs.fibonacci_selector_trace(0, 1, sels)
+    pre = {0: (np.array([int(s) for s in sels], np.uint32), len(sels))}
+    run_partitioned(dev, pkg, orc, airs.test_params(), [airs.fibonacci_selector_air()], [(0, tr, len(sels), pvs)], pre)
+
+
+def test_cached_fixture_11(dev, pkg, orc):
+    air_list, traces = airs.cached_fixture_11()
+    run_partitioned(dev, pkg, orc, airs.test_params(), air_list, traces)
+
+
+@pytest.mark.parametrize("parts", [1, 3])
+def test_preprocessed_and_cached(dev, pkg, orc, parts):
+    sels = [i % 2 == 0 for i in range(16)]
+    common, cached = airs.preprocessed_cached_traces(sels, parts)
+    pre = {0: (np.array([int(s) for s in sels], np.uint32), len(sels))}
+    run_partitioned(dev, pkg, orc, airs.test_params(), [airs.preprocessed_cached_air(parts)],
+                    [(0, common, len(sels), [], cached)], pre)
+
+
+def test_mixture_fixture(dev, pkg, orc):
+    c_airs, c_traces = airs.cached_fixture_11()
+    sels = [i % 2 == 0 for i in range(8)]
+    ptr, ppv = airs.fibonacci_selector_trace(0, 1, sels)
+    ftr, fpv = airs.fibonacci_trace(0, 1, 16)
+    air_list = [airs.fibonacci_air()] + c_airs + [airs.fibonacci_selector_air()]
+    pre = {3: (np.array([int(s) for s in sels], np.uint32), len(sels))}
+    traces = [(0, ftr, 16, fpv)] + [(a + 1, c, h, p, k) for a, c, h, p, k in c_traces] + [(3, ptr, len(sels), ppv)]
+    run_partitioned(dev, pkg, orc, airs.test_params(), air_list, traces, pre)
