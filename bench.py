@@ -34,6 +34,8 @@ def main():
     ap.add_argument("--cols", type=int, default=100)
     ap.add_argument("--log-stacked-height", type=int, default=24)
     ap.add_argument("--cpu-log-rows", type=int, default=18, help="rows of the CPU-baseline sample")
+    ap.add_argument("--log-blowup", type=int, default=1,
+                    help="1 = app parameters (the headline config); 2 = leaf-like parameters of BASELINE config E")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--zero-trace", action="store_true",
                     help="all-zero trace (what the reference's uniform_runner proves) instead of seeded random bits")
@@ -58,7 +60,8 @@ def main():
     # ---- workload: uniform_runner BenchmarkAir (benchmarks/synthetic/src/bin/uniform_runner.rs) ----
     log_rows, cols = args.log_rows, args.cols
     h = 1 << log_rows
-    params = airs.app_params(args.log_stacked_height)
+    params = (airs.app_params(args.log_stacked_height) if args.log_blowup == 1
+              else airs.stress_params(args.log_stacked_height, args.log_blowup))
     air = airs.uniform_runner_air(cols)
     pk = pkg.ProvingKey(airs.pk_blob(params, [air]))
     gen = torch.Generator(device=f"cuda:{local_rank}")
@@ -135,7 +138,8 @@ def main():
             import oracle_lib
             orc = oracle_lib.load()
             lr = args.cpu_log_rows
-            p2 = airs.app_params(args.log_stacked_height - (log_rows - lr))
+            small = args.log_stacked_height - (log_rows - lr)
+            p2 = airs.app_params(small) if args.log_blowup == 1 else airs.stress_params(small, args.log_blowup)
             blob = airs.pk_blob(p2, [air])
             tr = airs.splitmix64_bits(0xD15EA5E, cols << lr)
             c0 = time.perf_counter()
@@ -154,8 +158,9 @@ def main():
             "dtype": "u32 (BabyBear Montgomery; F_p^4 challenges)", "data": "synthetic",
             "config": {"workload": f"uniform_runner BenchmarkAir 2^{log_rows} rows x {cols} cols per GPU, "
                                    f"200 boolean constraints, 13 send/receive pairs, app params "
-                                   f"(l_skip 4, n_stack {args.log_stacked_height - 4}, log_blowup 1, k_whir 4, "
-                                   f"PoW 18/15/5/20 bits), " + ("all-zero trace" if args.zero_trace else "seeded random boolean trace"),
+                                   f"(l_skip 4, n_stack {args.log_stacked_height - 4}, log_blowup {args.log_blowup}, k_whir 4, "
+                                   f"PoW {params['logup_pow_bits']}/{params['mu_pow_bits']}/"
+                                   f"{params['folding_pow_bits']}/{params['query_phase_pow_bits']} bits), " + ("all-zero trace" if args.zero_trace else "seeded random boolean trace"),
                        "proof_bytes": len(proof), "parallelism": f"replicas x{world}"},
             "roofline": roof, "cpu_baseline": cpu,
             "end_to_end": {"algorithmic_bytes_per_cell": 60, "achieved_GBps": round(e2e_gbs, 1),

@@ -414,3 +414,10 @@ def cached_fixture_11():
               (1, np.array([1, 3, 4, 2, 0, 545, 1, 0], np.uint32), 8, [],
                np.array([5, 4, 4, 5, 123, 889, 889, 456], np.uint32))]
     return airs_, traces
+
+
+def stress_params(log_stacked_height, log_blowup=2, max_constraint_degree=4):
+    """BASELINE config E: leaf-like production parameters (stark-sdk/src/config/mod.rs:140-168:
+    l_skip 4, log_blowup 2, folding pow 4, mu pow 13, degree 4) at a chosen stacked height."""
+    return make_params(4, max(log_stacked_height - 4, 0), log_blowup, 4, 10, 100, 13, 4, 20, 18,
+                       max_constraint_degree, 2048)

@@ -246,3 +246,36 @@ def test_mixture_fixture(dev, pkg, orc):
     pre = {3: (np.array([int(s) for s in sels], np.uint32), len(sels))}
     traces = [(0, ftr, 16, fpv)] + [(a + 1, c, h, p, k) for a, c, h, p, k in c_traces] + [(3, ptr, len(sels), ppv)]
     run_partitioned(dev, pkg, orc, airs.test_params(), air_list, traces, pre)
+
+
+def test_blowup4_degree4_parity(dev, pkg, orc):
+    """Leaf-like parameters (log_blowup 2, global constraint degree 4 -> 3 zerocheck / 4 logup cosets)
+    at a size the oracle proves in seconds: byte-exact."""
+    params = airs.stress_params(12)
+    params["logup_pow_bits"] = 4
+    params["query_phase_pow_bits"] = 4
+    params["mu_pow_bits"] = 4
+    h = 1 << 10
+    tr = airs.splitmix64_bits(0xD15EA5E, 20 * h)
+    run_case(dev, pkg, orc, params, [airs.uniform_runner_air(20)], [(0, tr, h, [])])
+
+
+def test_config_e_full_size_verifies(dev, pkg, orc):
+    """BASELINE config E: 2^24 rows x 100 columns, blowup 4 (codeword 26.8 GB, 2^29-leaf LogUp tree):
+    the proof must be accepted by the verifier restatement."""
+    import torch
+    free, _ = torch.cuda.mem_get_info()
+    if free < 200 * (1 << 30):
+        pytest.skip("needs ~200 GB of free HBM")
+    params = airs.stress_params(24)
+    blob = airs.pk_blob(params, [airs.uniform_runner_air(100)])
+    pk = pkg.ProvingKey(blob)
+    h = 1 << 24
+    gen = torch.Generator(device="cuda:0")
+    gen.manual_seed(0xD15EA5E)
+    trace = torch.randint(0, 2, (100 * h,), dtype=torch.int32, device="cuda:0", generator=gen)
+    trace *= int(pkg.to_mont(np.array([1], dtype=np.uint32))[0])
+    proof, _ = dev.prove(pk, [(0, trace, h, [])])
+    orc.verify(blob, proof)
+    del trace
+    pkg._lib().ovm_hip_trim()
