@@ -421,3 +421,53 @@ def stress_params(log_stacked_height, log_blowup=2, max_constraint_degree=4):
     l_skip 4, log_blowup 2, folding pow 4, mu pow 13, degree 4) at a chosen stacked height."""
     return make_params(4, max(log_stacked_height - 4, 0), log_blowup, 4, 10, 100, 13, 4, 20, 18,
                        max_constraint_degree, 2048)
+
+
+# ---- synthetic replay of a captured OpenVM workload (SURVEY §8(f) N3) --------------------------
+def load_reth_shapes():
+    """tests/golden/reth_block_23992138_shapes.json.gz (derived by tools/make_reth_shapes.py)."""
+    import gzip
+    import json
+    import os
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reth_block_23992138_shapes.json.gz")
+    with gzip.open(path, "rb") as f:
+        return json.loads(f.read().decode())["segments"]
+
+
+def synthetic_air(rec):
+    """SyntheticAir::from_shape + eval (benchmarks/synthetic/src/synthetic_air.rs:86-232) for one shape
+    record [log_height, common_main_width, num_constraints, num_interactions, max_constraint_degree,
+    num_distinct_buses, message_lens, count_weights]. Column 0 is the all-zero 'kill column'. Returns
+    (air, width)."""
+    _, cm_width, n_constraints, n_inter, max_deg, n_buses, msg_lens, cws = rec
+    width = max(cm_width, (max(msg_lens) if msg_lens else 0) + 1, 1)
+    n_buses = max(n_buses, 1)
+    degree = max(max_deg, 1)
+    a = Air("SyntheticAir", width)
+    slots = 2 * width
+    for c in range(n_constraints):
+        idx, term = c, None
+        for _ in range(degree):
+            slot = idx % slots
+            idx //= slots
+            col = a.local(slot) if slot < width else a.next(slot - width)
+            term = col if term is None else term * col
+        a.assert_zero(term)
+    for i in range(n_inter):
+        msg_len = min(msg_lens[i] if i < len(msg_lens) else min(width - 1, 4), width - 1)
+        fields = [a.local((j + 1) % width) for j in range(msg_len)]
+        count = a.local(0)
+        a.push_interaction(i % n_buses, fields, count if i % 2 == 0 else NEG_ONE() * count,
+                           cws[i] if i < len(cws) else 0)
+    return a.finish(), width
+
+
+def synthetic_segment(seg, max_log_height):
+    """(air list, [(air_idx, log_height, width)]) for one captured segment, heights clamped as
+    synthetic_runner.rs:196-203 does (and raised to 2 rows)."""
+    air_list, shapes = [], []
+    for i, rec in enumerate(seg["airs"]):
+        air, width = synthetic_air(rec)
+        air_list.append(air)
+        shapes.append((i, max(min(rec[0], max_log_height), 1), width))
+    return air_list, shapes

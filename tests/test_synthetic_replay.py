@@ -1,0 +1,66 @@
+"""Synthetic replay of a captured OpenVM workload (the reference's benchmarks/synthetic: 209 proving
+segments of a reth block, ~30 AIRs each with the real circuits' widths, constraint counts/degrees,
+interaction counts and message lengths). Shapes come from the derived fixture
+tests/golden/reth_block_23992138_shapes.json.gz; AIRs are rebuilt as synthetic_air.rs does."""
+import numpy as np
+import pytest
+
+import airs
+
+SEGS = airs.load_reth_shapes()
+
+
+def _pick():
+    """a small, a Keccak-bearing (widest AIR) and the most populated segment"""
+    widest = max(range(len(SEGS)), key=lambda i: max(r[1] for r in SEGS[i]["airs"]))
+    most = max(range(len(SEGS)), key=lambda i: len(SEGS[i]["airs"]))
+    return sorted({0, widest, most})
+
+
+def _case(seg_i, max_log_height, params):
+    air_list, shapes = airs.synthetic_segment(SEGS[seg_i], max_log_height)
+    blob = airs.pk_blob(params, air_list)
+    return blob, shapes
+
+
+def test_fixture_shape():
+    assert len(SEGS) == 209 and sum(len(s["airs"]) for s in SEGS) == 6382
+    assert all(s["deg"] == 4 for s in SEGS)
+
+
+def test_oracle_proves_a_clamped_segment(orc):
+    params = airs.test_params(l_skip=2, n_stack=8, k_whir=3, max_constraint_degree=4)
+    blob, shapes = _case(0, 4, params)
+    traces = [(i, np.zeros(w << lh, np.uint32), 1 << lh, []) for i, lh, w in shapes]
+    out = orc.prove(blob, traces)
+    orc.verify(blob, out["proof"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seg_i", _pick())
+def test_gpu_matches_oracle_on_clamped_segments(dev, pkg, orc, seg_i):
+    """All AIR shapes of a segment at heights <= 2^5: HIP proof byte-identical to the oracle's."""
+    import torch
+    params = airs.test_params(l_skip=2, n_stack=8, k_whir=3, max_constraint_degree=4)
+    blob, shapes = _case(seg_i, 5, params)
+    traces = [(i, np.zeros(w << lh, np.uint32), 1 << lh, []) for i, lh, w in shapes]
+    want = orc.prove(blob, traces)["proof"]
+    orc.verify(blob, want)
+    pk = pkg.ProvingKey(blob)
+    dtr = [(i, torch.zeros(w << lh, dtype=torch.int32, device="cuda:0"), 1 << lh, []) for i, lh, w in shapes]
+    got, _ = dev.prove(pk, dtr)
+    assert got == want
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seg_i", _pick()[1:])
+def test_gpu_full_size_segments_verify(dev, pkg, orc, seg_i):
+    """The same segments at their captured heights (<= 2^22) under app parameters: verifier accepts."""
+    import torch
+    params = airs.app_params(22)
+    params["max_constraint_degree"] = 4  # the captured global degree (the profile predates APP_MAX = 3)
+    blob, shapes = _case(seg_i, 22, params)
+    pk = pkg.ProvingKey(blob)
+    dtr = [(i, torch.zeros(w << lh, dtype=torch.int32, device="cuda:0"), 1 << lh, []) for i, lh, w in shapes]
+    proof, _ = dev.prove(pk, dtr)
+    orc.verify(blob, proof)
