@@ -109,22 +109,35 @@ struct DevBuf {
     }
 };
 
-// Per-thread pinned staging buffer: the sumcheck loops read a handful of extension-field elements
-// back per round, and a D2H copy into pageable memory takes a slow bounce-buffer path.
+// Per-thread pinned staging arena. Uploads are bump-allocated from it and issued asynchronously
+// (a D2H/H2D copy from pageable memory takes a slow bounce-buffer path and an upload that
+// synchronises per call costs ~20 us: with tens of AIRs per proof those add up). The arena is
+// rewound whenever the stream is known to be idle past every issued copy (Ctx::sync, Mailbox::wait).
 struct PinnedStage {
-    void *p = nullptr;
-    size_t bytes = 0;
-    void *get(size_t need) {
-        if (need > bytes) {
-            if (p) (void)hipHostFree(p);
-            bytes = need < (1u << 20) ? (1u << 20) : need;
-            if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) {
-                p = nullptr;
-                bytes = 0;
-            }
+    char *p = nullptr;
+    size_t bytes = 0, used = 0;
+    void ensure(size_t need) {
+        if (need <= bytes) return;
+        if (p) (void)hipHostFree(p);
+        bytes = std::max<size_t>(need, size_t(16) << 20);
+        used = 0;
+        void *q = nullptr;
+        if (hipHostMalloc(&q, bytes, hipHostMallocDefault) != hipSuccess) {
+            q = nullptr;
+            bytes = 0;
         }
-        return p;
+        p = (char *)q;
     }
+    // nullptr when the request does not fit any more: the caller synchronises, rewinds and retries
+    void *bump(size_t need) {
+        need = (need + 63) & ~size_t(63);
+        if (!p) ensure(need);
+        if (!p || used + need > bytes) return nullptr;
+        void *r = p + used;
+        used += need;
+        return r;
+    }
+    void rewind() { used = 0; }
 };
 inline PinnedStage &pinned_stage() {
     static thread_local PinnedStage st;
@@ -135,7 +148,7 @@ inline PinnedStage &pinned_stage() {
 // reduction writes its results and a sequence flag into; the host spins on the flag instead of
 // issuing a D2H copy and a stream synchronisation per sumcheck round.
 struct Mailbox {
-    static constexpr size_t SLOTS = 4096;  // extension-field results per reduction
+    static constexpr size_t SLOTS = 65536;  // extension-field result slots (1 MiB page)
     struct Page {
         uint32_t flag;
         uint32_t pad[3];
@@ -159,13 +172,26 @@ struct Mailbox {
         init();
         OVM_THROW_IF(hipMemsetAsync(d_counter, 0, 64, s));
     }
-    RedOut arm(EF *partials) {
+    // Results of this reduction go to slots [slot, slot + K). Several reductions may be in flight on
+    // the stream with disjoint slot ranges; they complete in stream order, so waiting for the one
+    // armed last makes all of them readable.
+    RedOut arm(EF *partials, size_t slot = 0) {
+        if (slot + 64 > SLOTS) throw OvmFail((int)hipErrorInvalidValue, "mailbox: slot out of range");
         ++seq;
-        return RedOut{partials, d_counter, d->data, &d->flag, seq};
+        return RedOut{partials, d_counter, d->data + slot, &d->flag, seq};
     }
     // Wait for the reduction armed last and copy out its first n results.
     std::vector<EF> take(size_t n, hipStream_t s) {
-        if (n > SLOTS) throw OvmFail((int)hipErrorInvalidValue, "mailbox: too many results");
+        wait(s);
+        return read(0, n);
+    }
+    std::vector<EF> read(size_t slot, size_t n) const {
+        if (slot + n > SLOTS) throw OvmFail((int)hipErrorInvalidValue, "mailbox: too many results");
+        std::vector<EF> v(n);
+        memcpy((void *)v.data(), (const void *)(h->data + slot), n * sizeof(EF));
+        return v;
+    }
+    void wait(hipStream_t s) {
         volatile uint32_t *flag = &h->flag;
         uint64_t spins = 0;
         auto t0 = std::chrono::steady_clock::now();
@@ -180,9 +206,7 @@ struct Mailbox {
             }
         }
         std::atomic_thread_fence(std::memory_order_acquire);
-        std::vector<EF> v(n);
-        memcpy((void *)v.data(), (const void *)h->data, n * sizeof(EF));
-        return v;
+        pinned_stage().rewind();  // every copy issued before that reduction has completed
     }
 };
 inline Mailbox &mailbox() {
@@ -194,20 +218,31 @@ inline Mailbox &mailbox() {
 
 struct Ctx {
     hipStream_t stream;
-    void sync() const { OVM_THROW_IF(hipStreamSynchronize(stream)); }
+    void sync() const {
+        OVM_THROW_IF(hipStreamSynchronize(stream));
+        pinned_stage().rewind();
+    }
+    // Asynchronous: the host vector is copied into the staging arena before returning, the device
+    // copy is ordered on the stream before every later launch.
     template <class T>
     DevBuf<T> upload(const std::vector<T> &v) const {
         DevBuf<T> b(v.size());
         if (!v.empty()) {
             const size_t bytes = v.size() * sizeof(T);
-            void *stage = bytes <= (1u << 20) ? pinned_stage().get(bytes) : nullptr;
+            PinnedStage &ps = pinned_stage();
+            void *stage = ps.bump(bytes);
+            if (!stage) {
+                sync();
+                ps.ensure(bytes);
+                stage = ps.bump(bytes);
+            }
             if (stage) {
                 memcpy(stage, v.data(), bytes);
                 OVM_THROW_IF(hipMemcpyAsync(b.p, stage, bytes, hipMemcpyHostToDevice, stream));
             } else {
                 OVM_THROW_IF(hipMemcpyAsync(b.p, v.data(), bytes, hipMemcpyHostToDevice, stream));
+                sync();
             }
-            sync();  // the host vector / staging buffer may be reused
         }
         return b;
     }
@@ -216,11 +251,18 @@ struct Ctx {
         std::vector<T> v(n);
         if (n) {
             const size_t bytes = n * sizeof(T);
-            void *stage = bytes <= (1u << 20) ? pinned_stage().get(bytes) : nullptr;
+            PinnedStage &ps = pinned_stage();
+            void *stage = ps.bump(bytes);
+            if (!stage) {
+                sync();
+                ps.ensure(bytes);
+                stage = ps.bump(bytes);
+            }
             if (stage) {
                 OVM_THROW_IF(hipMemcpyAsync(stage, d, bytes, hipMemcpyDeviceToHost, stream));
-                sync();
+                OVM_THROW_IF(hipStreamSynchronize(stream));
                 memcpy(v.data(), stage, bytes);
+                ps.rewind();
             } else {
                 OVM_THROW_IF(hipMemcpyAsync(v.data(), d, bytes, hipMemcpyDeviceToHost, stream));
                 sync();
@@ -571,7 +613,8 @@ struct Prover {
                 Fp norm = fp(uint64_t(1) << (tv[t].log_lifted - tv[t].log_height)).inv();
                 OVM_THROW_IF(gkr_eval_leaves(pd.dev(), d_lc.p, tv[t].cols.p, tv[t].log_height, d_lb.p, d_ll.p, norm,
                                              tree.at(n_leaves), cx.stream));
-                cx.sync();
+                // no synchronisation: the temporaries go back to the block cache and are only ever reused
+                // by later work on this same stream
             }
             delete ps_leaves;
             {
@@ -713,11 +756,37 @@ struct Prover {
         };
         std::vector<TraceProgs> tp(T);
         std::vector<std::vector<EF>> sp0(3 * T);
-        DevBuf<EF> partials((size_t)RED_BLOCKS * MAX_COSETS * 2 * N + 64);
+        // Phase A enqueues every trace's work (eq table, coset LDE, zerocheck and logup evaluation)
+        // without waiting; each reduction gets its own partial-sum buffer and mailbox slots. Phase B
+        // waits ONCE and does the host algebra. With tens of AIRs per proof a wait per AIR per
+        // reduction was most of this stage's time.
+        struct Round0Job {
+            unsigned cdeg = 0, zc_cosets = 0, lg_cosets = 0;
+            size_t zc_slot = 0, lg_slot = 0;
+            DevBuf<EF> d_eq, zc_partials, lg_partials;
+            DevBuf<Fp> lde;
+            DevBuf<uint32_t> d_used;
+            DevBuf<Fp> d_sp;
+        };
+        std::vector<Round0Job> jobs(T);
+        size_t next_slot = 0;
+        // shift^i / N per coset (the iDFT scale is folded in): the same for every trace
+        std::vector<Fp> shift_pows(MAX_COSETS * N);
+        for (unsigned k = 0; k < MAX_COSETS; k++) {
+            Fp sh = g.pow(k + 1), cur = fp((uint64_t)N).inv();
+            for (size_t i = 0; i < N; i++) {
+                shift_pows[k * N + i] = cur;
+                cur *= sh;
+            }
+        }
+        auto d_sp_all = cx.upload(shift_pows);
+        auto d_xi = cx.upload(xi);
         for (size_t t = 0; t < T; t++) {
             const AirKey &a = air(t);
             TraceView &v = tv[t];
+            Round0Job &job = jobs[t];
             unsigned cdeg = a.max_constraint_degree;
+            job.cdeg = cdeg;
             // eq(xi_3, b) per interaction
             for (size_t k = 0; k < a.interactions.size(); k++) {
                 const Slice &s = ilayout.cols[ilayout.mat_starts[t] + k].slice;
@@ -755,102 +824,110 @@ struct Prover {
                 if (v.n_lift > 0)
                     tp[t].lg_g = make_grouped(compile_grouped(a, v.cm, traces[t].public_values, roots, (uint32_t)wts.size(), MLE_GROUPS));
             }
-            // eq(xi[l_skip..l_skip+n_lift], x)
-            DevBuf<EF> d_eq(size_t(1) << v.n_lift);
-            {
-                std::vector<EF> pt(xi.begin() + l_skip, xi.begin() + l_skip + v.n_lift);
-                auto d_pt = cx.upload(pt);
-                OVM_THROW_IF(eq_table(d_pt.p, v.n_lift, d_eq.p, cx.stream));
-                cx.sync();
-            }
-            unsigned zc_cosets = cdeg ? cdeg - 1 : 0, lg_cosets = tp[t].lg ? cdeg : 0;
-            unsigned n_cosets = std::max(zc_cosets, lg_cosets);
+            job.zc_cosets = cdeg ? cdeg - 1 : 0;
+            job.lg_cosets = tp[t].lg ? cdeg : 0;
+            const unsigned n_cosets = std::max(job.zc_cosets, job.lg_cosets);
             if (n_cosets > MAX_COSETS) throw OvmFail(801, "constraint degree too large");
-            if (n_cosets) {
-                std::vector<char> usedm(v.cm.total, 0);
-                for (auto c : tp[t].zc->prog.used_cols) usedm[c] = 1;
-                if (tp[t].lg)
-                    for (auto c : tp[t].lg->prog.used_cols) usedm[c] = 1;
-                std::vector<uint32_t> used;
-                for (size_t c = 0; c < usedm.size(); c++)
-                    if (usedm[c]) used.push_back((uint32_t)c);
-                std::vector<Fp> shift_pows(n_cosets * N);
-                for (unsigned k = 0; k < n_cosets; k++) {
-                    Fp sh = g.pow(k + 1), cur = fp((uint64_t)N).inv();  // shift^i / N: iDFT scale folded in
-                    for (size_t i = 0; i < N; i++) {
-                        shift_pows[k * N + i] = cur;
-                        cur *= sh;
-                    }
-                }
-                auto d_used = cx.upload(used);
-                auto d_sp = cx.upload(shift_pows);
-                DevBuf<Fp> lde((size_t)n_cosets * v.cm.total << v.log_lifted);
-                {
+            if (!n_cosets) continue;
+            // eq(xi[l_skip..l_skip+n_lift], x)
+            job.d_eq.alloc(size_t(1) << v.n_lift);
+            OVM_THROW_IF(eq_table(d_xi.p + l_skip, v.n_lift, job.d_eq.p, cx.stream));
+            std::vector<char> usedm(v.cm.total, 0);
+            for (auto c : tp[t].zc->prog.used_cols) usedm[c] = 1;
+            if (tp[t].lg)
+                for (auto c : tp[t].lg->prog.used_cols) usedm[c] = 1;
+            std::vector<uint32_t> used;
+            for (size_t c = 0; c < usedm.size(); c++)
+                if (usedm[c]) used.push_back((uint32_t)c);
+            job.d_used = cx.upload(used);
+            job.lde.alloc((size_t)n_cosets * v.cm.total << v.log_lifted);
+            {
                 OVM_PROF("round0.coset_lde", cx.stream);
-                OVM_THROW_IF(coset_lde(v.cols.p, d_used.p, (uint32_t)used.size(), (uint32_t)v.cm.total, v.log_lifted, l_skip,
-                                       n_cosets, d_sp.p, lde.p, cx.stream));
+                OVM_THROW_IF(coset_lde(v.cols.p, job.d_used.p, (uint32_t)used.size(), (uint32_t)v.cm.total, v.log_lifted, l_skip,
+                                       n_cosets, d_sp_all.p, job.lde.p, cx.stream));
+            }
+            const size_t red_blocks = std::min<size_t>(RED_BLOCKS, ((size_t(1) << v.log_lifted) + RED_THREADS - 1) / RED_THREADS);
+            if (job.zc_cosets) {
+                OVM_PROF("round0.zerocheck", cx.stream);
+                job.zc_partials.alloc(red_blocks * job.zc_cosets * N + 64);
+                job.zc_slot = next_slot;
+                next_slot += (job.zc_cosets * N + 63) & ~size_t(63);
+                OVM_THROW_IF(round0_eval(tp[t].zc->dev(), job.lde.p, (uint32_t)v.cm.total, v.log_lifted, l_skip, job.zc_cosets, 1,
+                                         job.d_eq.p, EF::zero(), mb.arm(job.zc_partials.p, job.zc_slot), cx.stream));
+            }
+            if (job.lg_cosets) {
+                OVM_PROF("round0.logup", cx.stream);
+                job.lg_partials.alloc(red_blocks * job.lg_cosets * 2 * N + 64);
+                job.lg_slot = next_slot;
+                next_slot += (job.lg_cosets * 2 * N + 63) & ~size_t(63);
+                OVM_THROW_IF(round0_eval(tp[t].lg->dev(), job.lde.p, (uint32_t)v.cm.total, v.log_lifted, l_skip, job.lg_cosets, 2,
+                                         job.d_eq.p, tp[t].lg_const, mb.arm(job.lg_partials.p, job.lg_slot), cx.stream));
+            }
+            if (next_slot + 4 * MAX_COSETS * N + 128 > Mailbox::SLOTS) throw OvmFail(801, "too many traces for the round-0 mailbox");
+        }
+        if (next_slot) mb.wait(cx.stream);
+        for (size_t t = 0; t < T; t++) {
+            Round0Job &job = jobs[t];
+            TraceView &v = tv[t];
+            const unsigned cdeg = job.cdeg;
+            if (job.zc_cosets) {
+                auto ev = mb.read(job.zc_slot, (size_t)job.zc_cosets * N);
+                std::vector<std::vector<EF>> ce(job.zc_cosets, std::vector<EF>(N));
+                for (unsigned k = 0; k < job.zc_cosets; k++) {
+                    Fp zinv = (g.pow(k + 1).exp_power_of_2(l_skip) - Fp::one()).inv();
+                    for (size_t z = 0; z < N; z++) ce[k][z] = ev[k * N + z] * zinv;
                 }
-                if (zc_cosets) {
-                    OVM_PROF("round0.zerocheck", cx.stream);
-                    OVM_THROW_IF(round0_eval(tp[t].zc->dev(), lde.p, (uint32_t)v.cm.total, v.log_lifted, l_skip, zc_cosets, 1,
-                                             d_eq.p, EF::zero(), mb.arm(partials.p), cx.stream));
-                    auto ev = mb.take((size_t)zc_cosets * N, cx.stream);
-                    std::vector<std::vector<EF>> ce(zc_cosets, std::vector<EF>(N));
-                    for (unsigned k = 0; k < zc_cosets; k++) {
-                        Fp zinv = (g.pow(k + 1).exp_power_of_2(l_skip) - Fp::one()).inv();
-                        for (size_t z = 0; z < N; z++) ce[k][z] = ev[k * N + z] * zinv;
-                    }
-                    std::vector<EF> q = from_coset_evals(ce, l_skip);
-                    unsigned deg = cdeg * (unsigned)(N - 1);
-                    std::vector<EF> coeffs(deg + 1);
-                    for (size_t i = 0; i <= deg; i++) {
-                        EF c = i < q.size() ? -q[i] : EF::zero();
-                        if (i >= N && i - N < q.size()) c += q[i - N];
-                        coeffs[i] = c;
-                    }
-                    sp0[2 * T + t] = std::move(coeffs);
+                std::vector<EF> q = from_coset_evals(ce, l_skip);
+                unsigned deg = cdeg * (unsigned)(N - 1);
+                std::vector<EF> coeffs(deg + 1);
+                for (size_t i = 0; i <= deg; i++) {
+                    EF c = i < q.size() ? -q[i] : EF::zero();
+                    if (i >= N && i - N < q.size()) c += q[i - N];
+                    coeffs[i] = c;
                 }
-                if (lg_cosets) {
-                    OVM_PROF("round0.logup", cx.stream);
-                    OVM_THROW_IF(round0_eval(tp[t].lg->dev(), lde.p, (uint32_t)v.cm.total, v.log_lifted, l_skip, lg_cosets, 2,
-                                             d_eq.p, tp[t].lg_const, mb.arm(partials.p), cx.stream));
-                    auto ev = mb.take((size_t)lg_cosets * 2 * N, cx.stream);
-                    std::vector<std::vector<EF>> cn(lg_cosets, std::vector<EF>(N)), cden(lg_cosets, std::vector<EF>(N));
-                    for (unsigned k = 0; k < lg_cosets; k++)
-                        for (size_t z = 0; z < N; z++) {
-                            cn[k][z] = ev[(k * 2 + 0) * N + z];
-                            cden[k][z] = ev[(k * 2 + 1) * N + z];
-                        }
-                    Fp norm = fp(uint64_t(1) << (v.log_lifted - v.log_height)).inv();
-                    std::vector<EF> pn = from_coset_evals(cn, l_skip), pd = from_coset_evals(cden, l_skip);
-                    for (auto &x : pn) x = x * norm;
-                    sp0[2 * t] = std::move(pn);
-                    sp0[2 * t + 1] = std::move(pd);
-                }
-                cx.sync();
-            } else if (cdeg != 0) {
+                sp0[2 * T + t] = std::move(coeffs);
+            } else if (cdeg != 0 && !job.lg_cosets) {
                 sp0[2 * T + t] = std::vector<EF>(cdeg * (N - 1) + 1, EF::zero());
             }
+            if (job.lg_cosets) {
+                auto ev = mb.read(job.lg_slot, (size_t)job.lg_cosets * 2 * N);
+                std::vector<std::vector<EF>> cn(job.lg_cosets, std::vector<EF>(N)), cden(job.lg_cosets, std::vector<EF>(N));
+                for (unsigned k = 0; k < job.lg_cosets; k++)
+                    for (size_t z = 0; z < N; z++) {
+                        cn[k][z] = ev[(k * 2 + 0) * N + z];
+                        cden[k][z] = ev[(k * 2 + 1) * N + z];
+                    }
+                Fp norm = fp(uint64_t(1) << (v.log_lifted - v.log_height)).inv();
+                std::vector<EF> pn = from_coset_evals(cn, l_skip), pd = from_coset_evals(cden, l_skip);
+                for (auto &x : pn) x = x * norm;
+                sp0[2 * t] = std::move(pn);
+                sp0[2 * t + 1] = std::move(pd);
+            }
+            job = Round0Job();  // release the LDE and scratch buffers
         }
 
         wt.mark("rap.round0");
         // ---- s_0 assembly (host; a few dozen extension-field elements) ----
         const unsigned sp0_deg = cdeg_global * (unsigned)(N - 1), s_deg = cdeg_global + 1, s0_deg = s_deg * (unsigned)(N - 1);
         const size_t large = size_t(1) << log2_ceil(s0_deg + 1);
-        auto mul_by = [&](std::vector<EF> a, const std::vector<EF> &eqev) {
-            a.resize(large, EF::zero());
-            a = small_dft(a, false);
-            for (size_t i = 0; i < large; i++) a[i] = a[i] * eqev[i];
-            return small_dft(a, true);
+        // product with the degree-(N-1) eq polynomial. The reference multiplies on a domain of size
+        // `large` (no wrap-around: deg <= s0_deg < large), i.e. a plain polynomial product; with tens of
+        // AIRs the N-term schoolbook product is much cheaper on the host than two size-`large` DFTs.
+        auto mul_by = [&](const std::vector<EF> &a, const std::vector<EF> &eq_coeffs) {
+            std::vector<EF> out(large, EF::zero());
+            for (size_t j = 0; j < eq_coeffs.size(); j++) {
+                if (is_zero(eq_coeffs[j])) continue;
+                const EF::Pre e = eq_coeffs[j].pre();
+                for (size_t i = 0; i < a.size() && i + j < large; i++) out[i + j] += a[i] * e;
+            }
+            return out;
         };
         std::vector<std::vector<EF>> s0_logup(2 * T);
         {
             std::vector<EF> eqc = small_dft(eq_hypercube(std::vector<EF>(xi.begin(), xi.begin() + l_skip)), true);
-            eqc.resize(large, EF::zero());
-            std::vector<EF> eqev = small_dft(eqc, false);
             for (size_t i = 0; i < 2 * T; i++) {
                 std::vector<EF> c(sp0[i].begin(), sp0[i].begin() + std::min(sp0[i].size(), (size_t)sp0_deg + 1));
-                s0_logup[i] = mul_by(std::move(c), eqev);
+                s0_logup[i] = mul_by(c, eqc);
             }
         }
         std::vector<EF> numer_terms, denom_terms;
@@ -879,13 +956,11 @@ struct Prover {
             }
             std::reverse(eqc.begin(), eqc.end());
             eqc[0] = ef(n_inv);
-            eqc.resize(large, EF::zero());
-            std::vector<EF> eqev = small_dft(eqc, false);
-            std::vector<EF> c(large, EF::zero());
+            std::vector<EF> c(sp0_deg + 1, EF::zero());
             for (size_t j = 0; j <= sp0_deg; j++)
                 for (size_t t = 0; t < T; t++)
                     if (j < sp0[2 * T + t].size()) c[j] += mu_pows[2 * T + t] * sp0[2 * T + t][j];
-            s0_zc = mul_by(std::move(c), eqev);
+            s0_zc = mul_by(c, eqc);
         }
         std::vector<EF> s0(s0_deg + 1);
         for (size_t j = 0; j <= s0_deg; j++) {
@@ -934,12 +1009,53 @@ struct Prover {
         std::vector<EF> zc_tilde(T, EF::zero());
         std::vector<std::array<EF, 2>> lg_tilde(T, {EF::zero(), EF::zero()});
         std::vector<std::vector<EF>> round_polys;
-        DevBuf<EF> d_eqr(size_t(1) << std::max(n_max, 1u)), d_pt(std::max(n_max, 1u));
-        DevBuf<EF> mle_partials((size_t)RED_BLOCKS * MLE_GROUPS * 8 + 64);
+        // one eq table per distinct trace height and round (shared by all traces of that height);
+        // per trace and program its own partial-sum scratch and 8 mailbox slots
+        std::vector<DevBuf<EF>> d_eqr_by_nlift(n_max + 1);
+        std::vector<DevBuf<EF>> mle_partials(2 * T);
+        for (size_t t = 0; t < T; t++) {
+            if (tv[t].n_lift == 0) continue;
+            if (!d_eqr_by_nlift[tv[t].n_lift].p) d_eqr_by_nlift[tv[t].n_lift].alloc(size_t(1) << tv[t].n_lift);
+            const size_t rec = std::min<size_t>(RED_BLOCKS, ((size_t(1) << (tv[t].n_lift - 1)) + RED_THREADS - 1) / RED_THREADS) * MLE_GROUPS * 8 + 64;
+            mle_partials[2 * t].alloc(rec);
+            if (!air(t).interactions.empty()) mle_partials[2 * t + 1].alloc(rec);
+        }
+        if (16 * T + 64 > Mailbox::SLOTS) throw OvmFail(801, "too many traces for the MLE-round mailbox");
         OVM_PROF("constraints.mle_rounds", cx.stream);
         for (unsigned round = 1; round <= n_max; round++) {
             EF r_prev = r[round - 1];
             std::vector<std::vector<EF>> sp(3 * T);
+            // phase A: enqueue the round sums of every trace that still has rows to fold
+            std::vector<char> eq_done(n_max + 1, 0);
+            bool any_launch = false;
+            for (size_t t = 0; t < T; t++) {
+                TraceView &v = tv[t];
+                if (round > v.n_lift) continue;
+                const bool has_int = !air(t).interactions.empty();
+                const unsigned log_num_y = v.n_lift - round;
+                DevBuf<EF> &d_eqr = d_eqr_by_nlift[v.n_lift];
+                if (!eq_done[v.n_lift]) {
+                    // eq over xi[l_skip + round .. l_skip + n_lift]
+                    OVM_THROW_IF(eq_table(d_xi.p + l_skip + round, log_num_y, d_eqr.p, cx.stream));
+                    eq_done[v.n_lift] = 1;
+                }
+                const EF *mats = v.mats_in_a ? v.mats_a.p : v.mats_b.p;
+                {
+                    const GroupedDev &gd = *tp[t].zc_g;
+                    OVM_THROW_IF(mle_round_eval_grouped(gd.code.p, gd.off.p, (uint32_t)gd.gp.off.size() - 1, gd.gp.max_slots,
+                                                        tp[t].zc->weights.p, mats, v.cur_log_h, cdeg_global, 1, d_eqr.p,
+                                                        EF::zero(), mb.arm(mle_partials[2 * t].p, 16 * t), cx.stream));
+                }
+                if (has_int) {
+                    const GroupedDev &gd = *tp[t].lg_g;
+                    OVM_THROW_IF(mle_round_eval_grouped(gd.code.p, gd.off.p, (uint32_t)gd.gp.off.size() - 1, gd.gp.max_slots,
+                                                        tp[t].lg->weights.p, mats, v.cur_log_h, cdeg_global, 2, d_eqr.p,
+                                                        tp[t].lg_const, mb.arm(mle_partials[2 * t + 1].p, 16 * t + 8), cx.stream));
+                }
+                any_launch = true;
+            }
+            if (any_launch) mb.wait(cx.stream);
+            // phase B: host
             for (size_t t = 0; t < T; t++) {
                 TraceView &v = tv[t];
                 const AirKey &a = air(t);
@@ -963,29 +1079,11 @@ struct Prover {
                     sp[2 * t] = has_int ? std::vector<EF>{lg_tilde[t][0]} : std::vector<EF>(cdeg_global, EF::zero());
                     sp[2 * t + 1] = has_int ? std::vector<EF>{lg_tilde[t][1]} : std::vector<EF>(cdeg_global, EF::zero());
                 } else {
-                    unsigned log_num_y = v.n_lift - round;
-                    // eq over xi[l_skip + round .. l_skip + n_lift]
-                    if (log_num_y) OVM_THROW_IF(hipMemcpyAsync(d_pt.p, xi.data() + l_skip + round, log_num_y * sizeof(EF), hipMemcpyHostToDevice, cx.stream));
-                    OVM_THROW_IF(eq_table(d_pt.p, log_num_y, d_eqr.p, cx.stream));
-                    const EF *mats = v.mats_in_a ? v.mats_a.p : v.mats_b.p;
-                    {
-                        const GroupedDev &gd = *tp[t].zc_g;
-                        OVM_THROW_IF(mle_round_eval_grouped(gd.code.p, gd.off.p, (uint32_t)gd.gp.off.size() - 1, gd.gp.max_slots,
-                                                            tp[t].zc->weights.p, mats, v.cur_log_h, cdeg_global, 1, d_eqr.p,
-                                                            EF::zero(), mb.arm(mle_partials.p), cx.stream));
-                    }
-                    auto ev = mb.take(8, cx.stream);
+                    auto ev = mb.read(16 * t, 8);
                     sp[2 * T + t].resize(cdeg_global);
                     for (unsigned i = 0; i < cdeg_global; i++) sp[2 * T + t][i] = ev[2 * i];
                     if (has_int) {
-                        {
-                            const GroupedDev &gd = *tp[t].lg_g;
-                            OVM_THROW_IF(mle_round_eval_grouped(gd.code.p, gd.off.p, (uint32_t)gd.gp.off.size() - 1,
-                                                                gd.gp.max_slots, tp[t].lg->weights.p, mats, v.cur_log_h,
-                                                                cdeg_global, 2, d_eqr.p, tp[t].lg_const,
-                                                                mb.arm(mle_partials.p), cx.stream));
-                        }
-                        auto e2 = mb.take(8, cx.stream);
+                        auto e2 = mb.read(16 * t + 8, 8);
                         sp[2 * t].resize(cdeg_global);
                         sp[2 * t + 1].resize(cdeg_global);
                         for (unsigned i = 0; i < cdeg_global; i++) {

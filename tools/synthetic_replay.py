@@ -30,6 +30,7 @@ def main():
     ap.add_argument("--max-log-height", type=int, default=22)
     ap.add_argument("--verify", action="store_true", help="check every proof with the oracle's verifier restatement")
     ap.add_argument("--out", default=None)
+    ap.add_argument("--segment", type=int, default=None, help="replay only this segment index, with the stage profile")
     args = ap.parse_args()
 
     import torch
@@ -45,7 +46,7 @@ def main():
     segs = airs.load_reth_shapes()
     params = airs.app_params(args.max_log_height)
     params["max_constraint_degree"] = 4
-    picked = list(range(0, len(segs), args.every))
+    picked = list(range(0, len(segs), args.every)) if args.segment is None else [args.segment]
     results, total_ms, total_cells = [], 0.0, 0
     for n, si in enumerate(picked):
         air_list, shapes = airs.synthetic_segment(segs[si], args.max_log_height)
@@ -56,10 +57,18 @@ def main():
         if n == 0:
             dev.prove(pk, traces)  # warm-up: allocator, twiddles
         torch.cuda.synchronize()
+        if args.segment is not None:
+            pkg.profile_enable(True)
         t0 = time.perf_counter()
         proof, _ = dev.prove(pk, traces)
         torch.cuda.synchronize()
         ms = (time.perf_counter() - t0) * 1e3
+        if args.segment is not None:
+            prof = pkg.profile_report()
+            pkg.profile_enable(False)
+            for k, v in sorted(prof.items(), key=lambda kv: -kv[1][1])[:25]:
+                print(f"   {k:32s} calls {v[0]:5d}  {v[1]:9.3f} ms", file=sys.stderr)
+            print(f"   sum of profiled device time: {sum(v[1] for v in prof.values()):.1f} ms", file=sys.stderr)
         if orc is not None:
             orc.verify(blob, proof)
         total_ms += ms
