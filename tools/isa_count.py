@@ -21,7 +21,7 @@ def main():
         subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-S",
                                "--cuda-device-only", "-I", os.path.join(ROOT, "include"), "-o", out, src],
                               stderr=subprocess.DEVNULL)
-        cur, cnt, meta = None, collections.defaultdict(collections.Counter), collections.defaultdict(dict)
+        cur, cnt, meta, entries = None, collections.defaultdict(collections.Counter), {}, []
         for line in open(out):
             m = re.match(r"^(_Z\w+):", line)
             if m:
@@ -29,12 +29,16 @@ def main():
                 continue
             if cur and re.match(r"^\s+(v_|s_|global_|ds_|buffer_|flat_|scratch_)", line):
                 cnt[cur][line.split()[0]] += 1
-            m = re.match(r"^\s+\.(vgpr_count|sgpr_count|private_segment_fixed_size|group_segment_fixed_size):\s+(\d+)", line)
-            if m:
-                meta.setdefault("_pending", {})[m.group(1)] = int(m.group(2))
-            m = re.match(r"^\s+\.name:\s+(\S+)", line)
-            if m and "_pending" in meta:
-                meta[m.group(1)] = meta.pop("_pending")
+            # amdhsa.kernels metadata: one YAML list item per kernel, keys in alphabetical order
+            if re.match(r"^\s+- \.", line):
+                entry = {}
+                entries.append(entry)
+            m = re.match(r"^\s+(?:- )?\.(name|vgpr_count|sgpr_count|private_segment_fixed_size|group_segment_fixed_size):\s+(\S+)", line)
+            if m and entries:
+                entries[-1][m.group(1)] = m.group(2)
+        for e in entries:
+            if "name" in e:
+                meta[e["name"]] = {k: int(v) for k, v in e.items() if k != "name"}
         for k, v in cnt.items():
             if pat not in k:
                 continue
