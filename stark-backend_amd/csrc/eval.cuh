@@ -1,0 +1,110 @@
+// Constraint-evaluation kernel bodies, parameterised by the program that evaluates one row:
+// the register-program interpreter (stages.hip) or straight-line code generated per AIR and
+// compiled at run time (jit.cpp). Device code only; embedded into the hiprtc translation unit.
+#pragma once
+#include "device_common.h"
+
+namespace ovm {
+
+// ---- extension-field memory access (16-byte vectors) ----------------------------------------
+__device__ __forceinline__ EF ld_ef(const EF *p) {
+    uint4 v = *reinterpret_cast<const uint4 *>(p);
+    EF r;
+    r.c[0] = Fp::raw(v.x);
+    r.c[1] = Fp::raw(v.y);
+    r.c[2] = Fp::raw(v.z);
+    r.c[3] = Fp::raw(v.w);
+    return r;
+}
+__device__ __forceinline__ void st_ef(EF *p, const EF &x) {
+    *reinterpret_cast<uint4 *>(p) = make_uint4(x.c[0].v, x.c[1].v, x.c[2].v, x.c[3].v);
+}
+__device__ __forceinline__ void stp(uint32_t *b, uint64_t st, uint64_t i, const EF &x) {
+#pragma unroll
+    for (int k = 0; k < 4; k++) b[k * st + i] = x.c[k].v;
+}
+
+// ---- round 0: program values on the coset LDEs, weighted by eq and summed per (coset, z) ------
+// Prog::operator()(const Fp *lde_k, uint32_t log_lifted, uint64_t p, EF (&out)[2]) adds the
+// program's accumulators at row p of coset k (lde_k = column 0 of that coset) into out.
+//   partials[((block * n_cosets + k) * n_out + o) * N + z]
+template <class Prog>
+__device__ __forceinline__ void round0_eval_body(const Prog &prog, const Fp *lde, uint32_t n_cols_total,
+                                                 uint32_t log_lifted, uint32_t l_skip, uint32_t n_cosets,
+                                                 uint32_t n_out, const EF *eq_xi, EF add_const, EF *partials) {
+    __shared__ EF sh[RED_THREADS];
+    const uint32_t N = 1u << l_skip;
+    const uint64_t total = 1ull << log_lifted;
+    const uint64_t stride = (uint64_t)gridDim.x * RED_THREADS;  // multiple of N (N <= RED_THREADS)
+    EF sums[MAX_COSETS * 2];
+#pragma unroll
+    for (int i = 0; i < (int)(MAX_COSETS * 2); i++) sums[i] = EF::zero();
+    for (uint64_t p = (uint64_t)blockIdx.x * RED_THREADS + threadIdx.x; p < total; p += stride) {
+        const EF::Pre eq = ld_ef(eq_xi + (p >> l_skip)).pre();
+#pragma unroll
+        for (uint32_t k = 0; k < MAX_COSETS; k++) {  // static indices keep `sums` in registers
+            if (k < n_cosets) {
+                EF out[2] = {EF::zero(), add_const};
+                prog(lde + (((uint64_t)k * n_cols_total) << log_lifted), log_lifted, p, out);
+                sums[2 * k] = sums[2 * k] + out[0] * eq;
+                if (n_out > 1) sums[2 * k + 1] = sums[2 * k + 1] + out[1] * eq;
+            }
+        }
+    }
+    // reduce over lanes with equal z = tid mod N
+#pragma unroll
+    for (uint32_t k = 0; k < MAX_COSETS; k++)
+#pragma unroll
+        for (uint32_t o = 0; o < 2; o++) {
+            if (k >= n_cosets || o >= n_out) continue;  // uniform
+            sh[threadIdx.x] = sums[2 * k + o];
+            __syncthreads();
+            if (threadIdx.x < N) {
+                EF acc = sh[threadIdx.x];
+                for (uint32_t j = threadIdx.x + N; j < RED_THREADS; j += N) acc = acc + sh[j];
+                st_ef(partials + ((size_t)blockIdx.x * n_cosets * n_out + k * n_out + o) * N + threadIdx.x, acc);
+            }
+            __syncthreads();
+        }
+}
+
+// ---- LogUp-GKR leaves ---------------------------------------------------------------------------
+struct BaseFetch {
+    const ColDesc *cols;
+    uint64_t row;
+    __device__ __forceinline__ Fp operator()(uint32_t col) const {
+        const ColDesc cd = cols[col];
+        return cd.ptr[(row + cd.rot) & ((1ull << cd.log_height) - 1)];
+    }
+};
+struct LeafEmit {
+    FracPlanes leaves;
+    const uint64_t *leaf_base;
+    const uint32_t *leaf_log_len;
+    uint32_t log_height;
+    uint64_t row;
+    Fp norm;
+    __device__ __forceinline__ void operator()(uint32_t k, Fp numer, const EF &den) const {
+        const Fp p = numer * norm;  // base-field numerator: limbs 1..3 stay zero
+        uint64_t len = 1ull << leaf_log_len[k];
+        for (uint64_t off = 0; off < len; off += 1ull << log_height) {
+            const uint64_t i = leaf_base[k] + off + row;
+            leaves.P()[i] = p.v;  // limbs 1..3 are zero: written by the fill, or never read (p_base)
+            stp(leaves.Q(), leaves.stride, i, den);
+        }
+    }
+};
+// Prog::operator()(const BaseFetch &fetch, const LeafEmit &emit) evaluates every interaction of the
+// AIR at fetch.row and emits (count, denominator) per interaction.
+template <class Prog>
+__device__ __forceinline__ void gkr_leaves_body(const Prog &prog, const ColDesc *cols, uint32_t log_height,
+                                                const uint64_t *leaf_base, const uint32_t *leaf_log_len, Fp norm,
+                                                FracPlanes leaves) {
+    uint64_t row = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= (1ull << log_height)) return;
+    BaseFetch fetch{cols, row};
+    LeafEmit emit{leaves, leaf_base, leaf_log_len, log_height, row, norm};
+    prog(fetch, emit);
+}
+
+}  // namespace ovm

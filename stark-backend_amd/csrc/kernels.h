@@ -1,32 +1,11 @@
 // Internal launch API of the sumcheck-stage kernels (stages.hip). All pointers are device
 // pointers unless noted; extension-field buffers are 16-byte aligned arrays of [u32;4].
 #pragma once
+#include "device_common.h"
 #include "device_ctx.h"
 #include "program.h"
 
 namespace ovm {
-
-// A column of a trace view: value(p) = ptr[(p + rot) & (2^log_height - 1)]  (cyclic lift).
-struct ColDesc {
-    const Fp *ptr;
-    uint32_t log_height;
-    uint32_t rot;
-};
-
-// Limb-planar arrays (GKR data): limb k of element i is p[k * stride + i]; stride is a multiple
-// of 4 and p is 16-byte aligned so 2/4 consecutive elements are one vector access per plane.
-struct EFPlanes {
-    uint32_t *p;
-    uint64_t stride;
-};
-// Fractions: numerator limbs in planes 0..3, denominator limbs in planes 4..7.
-struct FracPlanes {
-    uint32_t *p;
-    uint64_t stride;
-    BB_HD uint32_t *P() const { return p; }
-    BB_HD uint32_t *Q() const { return p + 4 * stride; }
-    BB_HD FracPlanes at(uint64_t first) const { return FracPlanes{p + first, stride}; }
-};
 
 struct DevProgram {
     const Instr *code;
@@ -34,21 +13,6 @@ struct DevProgram {
     uint32_t num_slots;
     const EF *weights;
 };
-
-// Destination of a reduction (stages.hip "last workgroup finishes"): per-workgroup partial
-// records, a self-resetting arrival counter, and a host-mapped mailbox (out + flag) that the host
-// spins on -- one launch per sumcheck round, no D2H copy, no stream synchronisation.
-struct RedOut {
-    EF *partials;       // device scratch, >= (number of workgroups) * K
-    uint32_t *counter;  // device, zero before the launch; the last workgroup resets it
-    EF *out;            // device-visible address of the K results (host-mapped)
-    uint32_t *flag;     // device-visible address of the completion flag (host-mapped), may be null
-    uint32_t seq;       // value stored to *flag once out[] is visible to the host
-};
-
-static constexpr unsigned MAX_COSETS = 4;
-static constexpr unsigned RED_BLOCKS = 2048;  // grid cap of the partial-sum kernels (8 workgroups per CU)
-static constexpr unsigned RED_THREADS = 256;
 
 // ro.out[k] = sum_b ro.partials[b * K + k], then the flag (for reductions with many outputs)
 int sum_partials(const RedOut &ro, uint32_t n_blocks, uint32_t K, hipStream_t s);

@@ -20,7 +20,7 @@
 namespace ovm {
 
 enum Op : uint8_t { OP_ADD = 0, OP_SUB, OP_MUL, OP_NEG, OP_ACC, OP_DEN, OP_LEAF };
-enum OperandKind : uint8_t { K_SLOT = 0, K_COL, K_CONST };
+enum OperandKind : uint8_t { K_SLOT = 0, K_COL, K_CONST, K_PUBLIC /* only in programs compiled for the JIT */ };
 
 struct Instr {
     uint8_t op, ak, bk, acc;
@@ -75,10 +75,58 @@ struct Root {
     uint32_t weight; // weight index (ACC, DEN) or leaf index (LEAF)
 };
 
+inline ColumnMap column_map_of(const AirKey &air) {
+    ColumnMap cm;
+    cm.need_rot = air.need_rot;
+    cm.pre_width = air.preprocessed_width;
+    cm.part_width = air.cached_widths;
+    cm.part_width.push_back(air.common_main_width);
+    cm.finish();
+    return cm;
+}
+
+// Roots of the three programs of an AIR. The weight indices they carry are positions in arrays
+// the prover fills per proof (lambda powers; eq_3b * beta powers; beta powers), so the program
+// STRUCTURE depends on the AIR only.
+inline std::vector<Root> roots_zerocheck(const AirKey &a) {
+    std::vector<Root> roots;
+    for (size_t i = 0; i < a.constraint_idx.size(); i++) roots.push_back({a.constraint_idx[i], OP_ACC, 0, (uint32_t)i});
+    return roots;
+}
+// logup round sums: accumulator 1 += w * message field, accumulator 0 += w * count; weights in emission order
+inline std::vector<Root> roots_logup(const AirKey &a, uint32_t *num_weights = nullptr) {
+    std::vector<Root> roots;
+    uint32_t w = 0;
+    for (auto &it : a.interactions) {
+        for (size_t j = 0; j < it.message.size(); j++) roots.push_back({it.message[j], OP_ACC, 1, w++});
+        roots.push_back({it.count, OP_ACC, 0, w++});
+    }
+    if (num_weights) *num_weights = w;
+    return roots;
+}
+// GKR leaves: per interaction the message fields feed the denominator (weight = beta^j), the count closes leaf k
+inline std::vector<Root> roots_leaves(const AirKey &a) {
+    std::vector<Root> roots;
+    for (size_t k = 0; k < a.interactions.size(); k++) {
+        const Interaction &it = a.interactions[k];
+        for (size_t j = 0; j < it.message.size(); j++) roots.push_back({it.message[j], OP_DEN, 0, (uint32_t)j});
+        roots.push_back({it.count, OP_LEAF, 0, (uint32_t)k});
+    }
+    return roots;
+}
+
 // Compiles the nodes needed by `roots` (emitted in the given order, each right after its node is
 // available). Public values are folded to constants.
+// `public_values == nullptr`: keep public values symbolic (K_PUBLIC operands, payload = index) -- the
+// program then depends on the AIR only and can be turned into code once per proving key (jit.cpp).
+inline Program compile_program_impl(const AirKey &air, const ColumnMap &cm, const std::vector<Fp> *public_values_p,
+                                    const std::vector<Root> &roots, uint32_t num_weights);
 inline Program compile_program(const AirKey &air, const ColumnMap &cm, const std::vector<Fp> &public_values,
                                const std::vector<Root> &roots, uint32_t num_weights) {
+    return compile_program_impl(air, cm, &public_values, roots, num_weights);
+}
+inline Program compile_program_impl(const AirKey &air, const ColumnMap &cm, const std::vector<Fp> *public_values_p,
+                                    const std::vector<Root> &roots, uint32_t num_weights) {
     const size_t n = air.nodes.size();
     std::vector<char> need(n, 0);
     for (auto &r : roots) need[r.node] = 1;
@@ -127,8 +175,14 @@ inline Program compile_program(const AirKey &air, const ColumnMap &cm, const std
         switch (nd.kind) {
             case N_VAR:
                 if (nd.entry == E_PUBLIC) {
-                    kind = K_CONST;
-                    payload = public_values.at(nd.index).v;
+                    if (public_values_p) {
+                        kind = K_CONST;
+                        payload = public_values_p->at(nd.index).v;
+                    } else {
+                        if (nd.index >= air.num_public_values) throw OvmFail(1, "public value out of range");
+                        kind = K_PUBLIC;
+                        payload = nd.index;
+                    }
                 } else if (nd.entry == E_MAIN) {
                     if (nd.part_index >= cm.part_width.size() || nd.index >= cm.part_width[nd.part_index] ||
                         (nd.offset && !cm.need_rot))

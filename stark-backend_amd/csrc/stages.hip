@@ -12,22 +12,9 @@
 // them through wave shuffles and LDS, and writes one record per workgroup; `sum_partials`
 // finishes. Field addition is exact, so the result does not depend on the schedule.
 #include "kernels.h"
+#include "eval.cuh"
 
 namespace ovm {
-
-// ---- extension-field memory access (16-byte vectors) ----------------------------------------
-__device__ __forceinline__ EF ld_ef(const EF *p) {
-    uint4 v = *reinterpret_cast<const uint4 *>(p);
-    EF r;
-    r.c[0] = Fp::raw(v.x);
-    r.c[1] = Fp::raw(v.y);
-    r.c[2] = Fp::raw(v.z);
-    r.c[3] = Fp::raw(v.w);
-    return r;
-}
-__device__ __forceinline__ void st_ef(EF *p, const EF &x) {
-    *reinterpret_cast<uint4 *>(p) = make_uint4(x.c[0].v, x.c[1].v, x.c[2].v, x.c[3].v);
-}
 
 __device__ __forceinline__ EF wave_sum(EF v) {
 #pragma unroll
@@ -408,41 +395,22 @@ struct LdeFetch {
 };
 
 template <int NS>
+struct InterpRound0 {
+    DevProgram prog;
+    __device__ __forceinline__ void operator()(const Fp *lde_k, uint32_t log_lifted, uint64_t p, EF (&out)[2]) const {
+        Fp slots[NS];
+        LdeFetch fetch{lde_k, log_lifted, p};
+        run_program_acc<Fp>(prog.code, prog.n_instr, prog.weights, slots, fetch, out);
+    }
+};
+template <int NS>
 __global__ __launch_bounds__(RED_THREADS) void round0_eval_kernel(DevProgram prog, const Fp *lde,
                                                                   uint32_t n_cols_total, uint32_t log_lifted,
                                                                   uint32_t l_skip, uint32_t n_cosets,
                                                                   uint32_t n_out, const EF *eq_xi, EF add_const,
                                                                   EF *partials) {
-    __shared__ EF sh[RED_THREADS];
-    const uint32_t N = 1u << l_skip;
-    const uint64_t total = 1ull << log_lifted;
-    const uint64_t stride = (uint64_t)gridDim.x * RED_THREADS;  // multiple of N (N <= RED_THREADS)
-    EF sums[MAX_COSETS * 2];
-#pragma unroll
-    for (int i = 0; i < (int)(MAX_COSETS * 2); i++) sums[i] = EF::zero();
-    Fp slots[NS];
-    for (uint64_t p = (uint64_t)blockIdx.x * RED_THREADS + threadIdx.x; p < total; p += stride) {
-        EF eq = ld_ef(eq_xi + (p >> l_skip));
-        for (uint32_t k = 0; k < n_cosets; k++) {
-            LdeFetch fetch{lde + (((uint64_t)k * n_cols_total) << log_lifted), log_lifted, p};
-            EF out[2] = {EF::zero(), add_const};
-            run_program_acc<Fp>(prog.code, prog.n_instr, prog.weights, slots, fetch, out);
-            sums[2 * k] = sums[2 * k] + eq * out[0];
-            if (n_out > 1) sums[2 * k + 1] = sums[2 * k + 1] + eq * out[1];
-        }
-    }
-    // reduce over lanes with equal z = tid mod N
-    for (uint32_t k = 0; k < n_cosets; k++)
-        for (uint32_t o = 0; o < n_out; o++) {
-            sh[threadIdx.x] = sums[2 * k + o];
-            __syncthreads();
-            if (threadIdx.x < N) {
-                EF acc = sh[threadIdx.x];
-                for (uint32_t j = threadIdx.x + N; j < RED_THREADS; j += N) acc = acc + sh[j];
-                st_ef(partials + ((size_t)blockIdx.x * n_cosets * n_out + k * n_out + o) * N + threadIdx.x, acc);
-            }
-            __syncthreads();
-        }
+    round0_eval_body(InterpRound0<NS>{prog}, lde, n_cols_total, log_lifted, l_skip, n_cosets, n_out, eq_xi, add_const,
+                     partials);
 }
 
 #define DISPATCH_SLOTS(NSLOTS, CALL)                      \
@@ -622,10 +590,6 @@ __device__ __forceinline__ EF ldp(const uint32_t *b, uint64_t st, uint64_t i) {
     for (int k = 0; k < 4; k++) r.c[k] = Fp::raw(b[k * st + i]);
     return r;
 }
-__device__ __forceinline__ void stp(uint32_t *b, uint64_t st, uint64_t i, const EF &x) {
-#pragma unroll
-    for (int k = 0; k < 4; k++) b[k * st + i] = x.c[k].v;
-}
 __device__ __forceinline__ void ldp2(const uint32_t *b, uint64_t st, uint64_t i, EF &e0, EF &e1) {
 #pragma unroll
     for (int k = 0; k < 4; k++) {
@@ -685,42 +649,20 @@ int gkr_fill_leaves(FracPlanes leaves, uint64_t n, EF alpha, bool p_base, hipStr
     return 0;
 }
 
-struct BaseFetch {
-    const ColDesc *cols;
-    uint64_t row;
-    __device__ Fp operator()(uint32_t col) const {
-        const ColDesc cd = cols[col];
-        return cd.ptr[(row + cd.rot) & ((1ull << cd.log_height) - 1)];
+template <int NS>
+struct InterpLeaves {
+    DevProgram prog;
+    const EF *leaf_const;
+    __device__ __forceinline__ void operator()(const BaseFetch &fetch, const LeafEmit &emit) const {
+        Fp slots[NS];
+        run_program_leaves<Fp>(prog.code, prog.n_instr, prog.weights, leaf_const, slots, fetch, emit);
     }
 };
-struct LeafEmit {
-    FracPlanes leaves;
-    const uint64_t *leaf_base;
-    const uint32_t *leaf_log_len;
-    uint32_t log_height;
-    uint64_t row;
-    Fp norm;
-    __device__ void operator()(uint32_t k, Fp numer, const EF &den) const {
-        const Fp p = numer * norm;  // base-field numerator: limbs 1..3 stay zero
-        uint64_t len = 1ull << leaf_log_len[k];
-        for (uint64_t off = 0; off < len; off += 1ull << log_height) {
-            const uint64_t i = leaf_base[k] + off + row;
-            leaves.P()[i] = p.v;  // limbs 1..3 are zero: written by the fill, or never read (p_base)
-            stp(leaves.Q(), leaves.stride, i, den);
-        }
-    }
-};
-
 template <int NS>
 __global__ void gkr_leaves_kernel(DevProgram prog, const EF *leaf_const, const ColDesc *cols, uint32_t log_height,
                                   const uint64_t *leaf_base, const uint32_t *leaf_log_len, Fp norm,
                                   FracPlanes leaves) {
-    uint64_t row = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (row >= (1ull << log_height)) return;
-    Fp slots[NS];
-    BaseFetch fetch{cols, row};
-    LeafEmit emit{leaves, leaf_base, leaf_log_len, log_height, row, norm};
-    run_program_leaves<Fp>(prog.code, prog.n_instr, prog.weights, leaf_const, slots, fetch, emit);
+    gkr_leaves_body(InterpLeaves<NS>{prog, leaf_const}, cols, log_height, leaf_base, leaf_log_len, norm, leaves);
 }
 int gkr_eval_leaves(const DevProgram &prog, const EF *d_leaf_const, const ColDesc *d_cols, uint32_t log_height,
                     const uint64_t *d_leaf_base, const uint32_t *d_leaf_log_len, Fp norm, FracPlanes leaves,
