@@ -89,6 +89,7 @@ SIGNATURES = {
     "ovm_hip_pk_load": (c_int, [c_void_p, c_uint64, POINTER(c_void_p), c_void_p]),
     "ovm_hip_pk_free": (None, [c_void_p]),
     "ovm_hip_pk_preprocessed_commitment": (c_int, [c_void_p, c_uint32, c_void_p]),
+    "ovm_hip_jit_compile_check": (c_int, [c_void_p, c_uint64, POINTER(ctypes.c_double), c_char_p, c_uint64]),
     "ovm_hip_last_error": (c_char_p, []),
     "ovm_hip_trim": (c_int, []),
     "ovm_hip_commit": (c_int, [c_void_p, c_uint32, c_void_p, c_void_p, POINTER(c_void_p), c_void_p]),
@@ -398,6 +399,15 @@ Device.commit_matrix = _commit_matrix
 Device.commit_traces = _commit_traces
 Device.prove_rap_constraints = _prove_rap_constraints
 Device.prove_openings = _prove_openings
+
+
+def jit_compile_check(blob) -> tuple:
+    """(ok, seconds, message): generates and hiprtc-compiles the key's constraint kernels; no GPU needed."""
+    b = np.ascontiguousarray(blob, dtype=np.uint32)
+    secs = ctypes.c_double(0)
+    msg = ctypes.create_string_buffer(4096)
+    rc = _lib().ovm_hip_jit_compile_check(b.ctypes.data, b.size, ctypes.byref(secs), msg, len(msg))
+    return rc == 0, secs.value, msg.value.decode(errors="replace")
 
 
 def profile_enable(on: bool) -> None:

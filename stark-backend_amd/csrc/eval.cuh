@@ -41,22 +41,17 @@ __device__ __forceinline__ void round0_eval_body(const Prog &prog, const Fp *lde
     for (int i = 0; i < (int)(MAX_COSETS * 2); i++) sums[i] = EF::zero();
     for (uint64_t p = (uint64_t)blockIdx.x * RED_THREADS + threadIdx.x; p < total; p += stride) {
         const EF::Pre eq = ld_ef(eq_xi + (p >> l_skip)).pre();
-#pragma unroll
-        for (uint32_t k = 0; k < MAX_COSETS; k++) {  // static indices keep `sums` in registers
-            if (k < n_cosets) {
-                EF out[2] = {EF::zero(), add_const};
-                prog(lde + (((uint64_t)k * n_cols_total) << log_lifted), log_lifted, p, out);
-                sums[2 * k] = sums[2 * k] + out[0] * eq;
-                if (n_out > 1) sums[2 * k + 1] = sums[2 * k + 1] + out[1] * eq;
-            }
+        // (a runtime loop on purpose: unrolling it would replicate the whole row program per coset)
+        for (uint32_t k = 0; k < n_cosets; k++) {
+            EF out[2] = {EF::zero(), add_const};
+            prog(lde + (((uint64_t)k * n_cols_total) << log_lifted), log_lifted, p, out);
+            sums[2 * k] = sums[2 * k] + out[0] * eq;
+            if (n_out > 1) sums[2 * k + 1] = sums[2 * k + 1] + out[1] * eq;
         }
     }
     // reduce over lanes with equal z = tid mod N
-#pragma unroll
-    for (uint32_t k = 0; k < MAX_COSETS; k++)
-#pragma unroll
-        for (uint32_t o = 0; o < 2; o++) {
-            if (k >= n_cosets || o >= n_out) continue;  // uniform
+    for (uint32_t k = 0; k < n_cosets; k++)
+        for (uint32_t o = 0; o < n_out; o++) {
             sh[threadIdx.x] = sums[2 * k + o];
             __syncthreads();
             if (threadIdx.x < N) {

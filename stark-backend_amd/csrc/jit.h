@@ -32,7 +32,12 @@ struct JitModule {
 
 // Generates and compiles the kernels of every AIR of the key. Returns null (and a message) when
 // hiprtc is unavailable or the compilation fails; the caller then keeps interpreting.
-std::shared_ptr<JitModule> jit_build(const ProvingKey &pk, std::string &message);
+// load = false: generate and compile only (no device needed), for tests and timing.
+std::shared_ptr<JitModule> jit_build(const ProvingKey &pk, std::string &message, bool load = true);
+
+// Number of program instructions jit_build would turn into code (compile time grows with it:
+// roughly 5-10 ms each, in one basic block per kernel).
+size_t jit_program_size(const ProvingKey &pk);
 
 // Source text of the translation unit jit_build compiles (for inspection and tests).
 std::string jit_source(const ProvingKey &pk);

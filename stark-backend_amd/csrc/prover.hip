@@ -14,7 +14,9 @@
 #include <chrono>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 
+#include "jit.h"
 #include "kernels.h"
 
 namespace ovm {
@@ -357,6 +359,11 @@ struct WallTrace {
 struct DeviceKey {
     ProvingKey pk;
     std::vector<std::unique_ptr<PcsData>> pre;
+    // run-time compiled constraint kernels (jit.h), built on first use
+    mutable std::mutex jit_mu;
+    mutable std::shared_ptr<JitModule> jit;
+    mutable bool jit_tried = false;
+    mutable std::string jit_message;
 };
 
 struct Prover {
@@ -379,6 +386,38 @@ struct Prover {
 
     const Params &P() const { return pk.params; }
     const AirKey &air(size_t t) const { return pk.airs[traces[t].air_idx]; }
+    // Compiled constraint kernels: OVM_JIT=0 never, OVM_JIT=1 always, unset: for proofs of at least
+    // 2^24 trace cells under keys whose programs are small enough to compile in a few seconds
+    // (hiprtc spends 5-10 ms per program instruction; a 40-AIR key can take minutes, once).
+    std::shared_ptr<JitModule> jit;
+    void select_jit() {
+        const char *e = std::getenv("OVM_JIT");
+        bool want;
+        if (e && *e) {
+            want = e[0] != '0';
+        } else {
+            size_t cells = 0;
+            for (size_t t = 0; t < traces.size(); t++) cells += traces[t].height * air(t).common_main_width;
+            want = cells >= (size_t(1) << 24);
+        }
+        if (!want) return;
+        std::lock_guard<std::mutex> lk(dk.jit_mu);
+        if (!dk.jit_tried && !(e && *e) && jit_program_size(pk) > 1500) {
+            dk.jit_tried = true;
+            dk.jit_message = "not compiled: key too large for the automatic policy (set OVM_JIT=1)";
+        }
+        if (!dk.jit_tried) {
+            dk.jit_tried = true;
+            dk.jit = jit_build(pk, dk.jit_message);
+            if (std::getenv("OVM_TRACE"))
+                fprintf(stderr, "[ovm] jit: %s (%.2f s)\n", dk.jit_message.c_str(), dk.jit ? dk.jit->compile_seconds : 0.0);
+        }
+        jit = dk.jit;
+    }
+    const JitKernels *jit_of(size_t t) const {
+        if (!jit) return nullptr;
+        return &jit->per_air[traces[t].air_idx];
+    }
     const PcsData *pre_of(size_t t) const {
         const uint32_t a = traces[t].air_idx;
         return a < dk.pre.size() ? dk.pre[a].get() : nullptr;
@@ -497,6 +536,21 @@ struct Prover {
         return d;
     }
 
+    // Round-0 evaluation through the compiled kernel of the AIR when there is one, else the interpreter.
+    int launch_round0(hipFunction_t fn, const DevProgram &prog, const Fp *lde, uint32_t n_cols_total, uint32_t log_lifted,
+                      uint32_t l_skip, uint32_t n_cosets, uint32_t n_out, const EF *d_eq, EF add_const, const RedOut &ro,
+                      const Fp *d_pvals, uint32_t grid) {
+        if (!fn)
+            return round0_eval(prog, lde, n_cols_total, log_lifted, l_skip, n_cosets, n_out, d_eq, add_const, ro, cx.stream);
+        if (n_cosets == 0) return 0;
+        EF *partials = ro.partials;
+        const EF *W = prog.weights;
+        void *args[] = {&lde, &n_cols_total, &log_lifted, &l_skip, &n_cosets, &n_out, &d_eq, &add_const, &partials, &W, &d_pvals};
+        hipError_t e = hipModuleLaunchKernel(fn, grid, 1, 1, RED_THREADS, 1, 1, 0, cx.stream, args, nullptr);
+        if (e != hipSuccess) return (int)e;
+        return sum_partials(ro, grid, n_cosets * n_out << l_skip, cx.stream);
+    }
+
     // host evaluation of a program on one row (tail rounds)
     static void host_eval(const Program &p, const std::vector<EF> &weights, const std::vector<EF> &row, EF add_const,
                           EF out[2]) {
@@ -513,6 +567,15 @@ struct Prover {
     std::vector<EF> prove_rap_constraints() {
         const unsigned l_skip = P().l_skip;
         const size_t N = size_t(1) << l_skip, T = traces.size();
+        select_jit();
+        // public values of each trace on the device (operands of the compiled kernels)
+        std::vector<DevBuf<Fp>> d_pv(T);
+        if (jit)
+            for (size_t t = 0; t < T; t++) {
+                std::vector<Fp> pv = traces[t].public_values;
+                if (pv.empty()) pv.push_back(Fp::zero());
+                d_pv[t] = cx.upload(pv);
+            }
         const unsigned cdeg_global = P().max_constraint_degree;
         std::vector<TraceView> tv(T);
         uint64_t total_interactions = 0;
@@ -593,26 +656,38 @@ struct Prover {
             for (size_t t = 0; t < T; t++) {
                 const AirKey &a = air(t);
                 if (a.interactions.empty()) continue;
-                std::vector<Root> roots;
+                std::vector<Root> roots = roots_leaves(a);
                 std::vector<EF> leaf_const;
                 std::vector<uint64_t> leaf_base;
                 std::vector<uint32_t> leaf_log_len;
                 for (size_t k = 0; k < a.interactions.size(); k++) {
                     const Interaction &it = a.interactions[k];
-                    for (size_t j = 0; j < it.message.size(); j++) roots.push_back({it.message[j], OP_DEN, 0, (uint32_t)j});
-                    roots.push_back({it.count, OP_LEAF, 0, (uint32_t)k});
                     leaf_const.push_back(beta_pows[it.message.size()] * fp((uint64_t)it.bus_index + 1) + alpha);
                     const Slice &s = ilayout.cols[ilayout.mat_starts[t] + k].slice;
                     leaf_base.push_back(s.row_idx);
                     leaf_log_len.push_back(s.log_height);
                 }
-                ProgDev pd = make_prog(compile_program(a, tv[t].cm, traces[t].public_values, roots, (uint32_t)beta_pows.size()), beta_pows);
                 auto d_lc = cx.upload(leaf_const);
                 auto d_lb = cx.upload(leaf_base);
                 auto d_ll = cx.upload(leaf_log_len);
                 Fp norm = fp(uint64_t(1) << (tv[t].log_lifted - tv[t].log_height)).inv();
-                OVM_THROW_IF(gkr_eval_leaves(pd.dev(), d_lc.p, tv[t].cols.p, tv[t].log_height, d_lb.p, d_ll.p, norm,
-                                             tree.at(n_leaves), cx.stream));
+                const JitKernels *jk = jit_of(t);
+                if (jk && jk->leaves) {
+                    auto d_bp = cx.upload(beta_pows);
+                    const ColDesc *cols = tv[t].cols.p;
+                    uint32_t lh = tv[t].log_height;
+                    const uint64_t *lb = d_lb.p;
+                    const uint32_t *ll = d_ll.p;
+                    FracPlanes lv = tree.at(n_leaves);
+                    const EF *W = d_bp.p, *LC = d_lc.p;
+                    const Fp *PV = d_pv[t].p;
+                    void *args[] = {&cols, &lh, &lb, &ll, &norm, &lv, &W, &LC, &PV};
+                    OVM_THROW_IF(hipModuleLaunchKernel(jk->leaves, ceil_div(1ull << lh, 256), 1, 1, 256, 1, 1, 0, cx.stream, args, nullptr));
+                } else {
+                    ProgDev pd = make_prog(compile_program(a, tv[t].cm, traces[t].public_values, roots, (uint32_t)beta_pows.size()), beta_pows);
+                    OVM_THROW_IF(gkr_eval_leaves(pd.dev(), d_lc.p, tv[t].cols.p, tv[t].log_height, d_lb.p, d_ll.p, norm,
+                                                 tree.at(n_leaves), cx.stream));
+                }
                 // no synchronisation: the temporaries go back to the block cache and are only ever reused
                 // by later work on this same stream
             }
@@ -799,23 +874,18 @@ struct Prover {
                 tp[t].eq3b.push_back(e);
             }
             {
-                std::vector<Root> roots;
-                for (size_t i = 0; i < a.constraint_idx.size(); i++) roots.push_back({a.constraint_idx[i], OP_ACC, 0, (uint32_t)i});
+                std::vector<Root> roots = roots_zerocheck(a);
                 tp[t].zc_w = lambda_pows;
                 tp[t].zc = std::make_unique<ProgDev>(make_prog(compile_program(a, v.cm, traces[t].public_values, roots, (uint32_t)lambda_pows.size()), lambda_pows));
                 if (v.n_lift > 0)
                     tp[t].zc_g = make_grouped(compile_grouped(a, v.cm, traces[t].public_values, roots, (uint32_t)lambda_pows.size(), MLE_GROUPS));
             }
             if (!a.interactions.empty()) {
-                std::vector<Root> roots;
-                std::vector<EF> wts;
+                std::vector<Root> roots = roots_logup(a);
+                std::vector<EF> wts;  // in the order roots_logup numbers them
                 for (size_t k = 0; k < a.interactions.size(); k++) {
                     const Interaction &it = a.interactions[k];
-                    for (size_t j = 0; j < it.message.size(); j++) {
-                        roots.push_back({it.message[j], OP_ACC, 1, (uint32_t)wts.size()});
-                        wts.push_back(tp[t].eq3b[k] * beta_pows[j]);
-                    }
-                    roots.push_back({it.count, OP_ACC, 0, (uint32_t)wts.size()});
+                    for (size_t j = 0; j < it.message.size(); j++) wts.push_back(tp[t].eq3b[k] * beta_pows[j]);
                     wts.push_back(tp[t].eq3b[k]);
                     tp[t].lg_const += tp[t].eq3b[k] * (beta_pows[it.message.size()] * fp((uint64_t)it.bus_index + 1));
                 }
@@ -852,16 +922,18 @@ struct Prover {
                 job.zc_partials.alloc(red_blocks * job.zc_cosets * N + 64);
                 job.zc_slot = next_slot;
                 next_slot += (job.zc_cosets * N + 63) & ~size_t(63);
-                OVM_THROW_IF(round0_eval(tp[t].zc->dev(), job.lde.p, (uint32_t)v.cm.total, v.log_lifted, l_skip, job.zc_cosets, 1,
-                                         job.d_eq.p, EF::zero(), mb.arm(job.zc_partials.p, job.zc_slot), cx.stream));
+                OVM_THROW_IF(launch_round0(jit_of(t) ? jit_of(t)->r0_zerocheck : nullptr, tp[t].zc->dev(), job.lde.p,
+                                           (uint32_t)v.cm.total, v.log_lifted, l_skip, job.zc_cosets, 1, job.d_eq.p, EF::zero(),
+                                           mb.arm(job.zc_partials.p, job.zc_slot), d_pv[t].p, (uint32_t)red_blocks));
             }
             if (job.lg_cosets) {
                 OVM_PROF("round0.logup", cx.stream);
                 job.lg_partials.alloc(red_blocks * job.lg_cosets * 2 * N + 64);
                 job.lg_slot = next_slot;
                 next_slot += (job.lg_cosets * 2 * N + 63) & ~size_t(63);
-                OVM_THROW_IF(round0_eval(tp[t].lg->dev(), job.lde.p, (uint32_t)v.cm.total, v.log_lifted, l_skip, job.lg_cosets, 2,
-                                         job.d_eq.p, tp[t].lg_const, mb.arm(job.lg_partials.p, job.lg_slot), cx.stream));
+                OVM_THROW_IF(launch_round0(jit_of(t) ? jit_of(t)->r0_logup : nullptr, tp[t].lg->dev(), job.lde.p,
+                                           (uint32_t)v.cm.total, v.log_lifted, l_skip, job.lg_cosets, 2, job.d_eq.p, tp[t].lg_const,
+                                           mb.arm(job.lg_partials.p, job.lg_slot), d_pv[t].p, (uint32_t)red_blocks));
             }
             if (next_slot + 4 * MAX_COSETS * N + 128 > Mailbox::SLOTS) throw OvmFail(801, "too many traces for the round-0 mailbox");
         }
@@ -1882,6 +1954,24 @@ int ovm_hip_pk_preprocessed_commitment(const ovm_pk_t *pk_, uint32_t air_idx, ui
     if (air_idx >= dk.pre.size() || !dk.pre[air_idx]) return (int)hipErrorInvalidValue;
     for (int i = 0; i < 8; i++) commitment_out[i] = dk.pre[air_idx]->root.d[i].v;
     return 0;
+}
+
+int ovm_hip_jit_compile_check(const uint32_t *blob, uint64_t words, double *seconds, char *message, uint64_t message_cap) {
+    if (!blob) return (int)hipErrorInvalidValue;
+    try {
+        ProvingKey pk = parse_pk_blob(blob, words);
+        std::string msg;
+        auto jm = jit_build(pk, msg, false);
+        if (seconds) *seconds = jm ? jm->compile_seconds : 0.0;
+        if (message && message_cap) {
+            strncpy(message, msg.c_str(), message_cap - 1);
+            message[message_cap - 1] = 0;
+        }
+        return jm ? 0 : (int)hipErrorUnknown;
+    } catch (const std::exception &e) {
+        g_last_error = e.what();
+        return (int)hipErrorInvalidValue;
+    }
 }
 
 int ovm_hip_trim(void) {

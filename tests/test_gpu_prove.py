@@ -279,3 +279,49 @@ def test_config_e_full_size_verifies(dev, pkg, orc):
     orc.verify(blob, proof)
     del trace
     pkg._lib().ovm_hip_trim()
+
+
+# ---- run-time compiled constraint kernels (csrc/jit.cpp) vs the interpreter vs the oracle ----------
+def test_jit_fibonacci_and_interactions(dev, pkg, orc, monkeypatch):
+    monkeypatch.setenv("OVM_JIT", "1")
+    params = airs.test_params(l_skip=2, n_stack=6, k_whir=2)
+    tr, pvs = airs.fibonacci_trace(0, 1, 64)
+    run_case(dev, pkg, orc, params, [airs.fibonacci_air()], [(0, tr, 64, pvs)])  # public-value operands
+    s = np.array([[0, 1], [7, 4], [3, 5], [546, 889]], dtype=np.uint32)
+    r = np.array([[1, 5], [3, 4], [4, 4], [2, 5], [0, 123], [545, 889], [1, 889], [0, 456]], dtype=np.uint32)
+    traces = [(0, np.ascontiguousarray(s.T).reshape(-1), 4, []), (1, np.ascontiguousarray(r.T).reshape(-1), 8, [])]
+    run_case(dev, pkg, orc, params, [airs.dummy_interaction_air(1, True, 0), airs.dummy_interaction_air(1, False, 0)], traces)
+
+
+@pytest.mark.parametrize("cols,log_h,l_skip,n_stack,k_whir", [(8, 5, 2, 6, 2), (100, 10, 4, 12, 4)])
+def test_jit_benchmark_air(dev, pkg, orc, monkeypatch, cols, log_h, l_skip, n_stack, k_whir):
+    monkeypatch.setenv("OVM_JIT", "1")
+    params = airs.test_params(l_skip=l_skip, n_stack=n_stack, k_whir=k_whir)
+    h = 1 << log_h
+    tr = airs.splitmix64_bits(0xD15EA5E, cols * h)
+    run_case(dev, pkg, orc, params, [airs.uniform_runner_air(cols)], [(0, tr, h, [])])
+
+
+def test_jit_partitioned_and_mixed(dev, pkg, orc, monkeypatch):
+    monkeypatch.setenv("OVM_JIT", "1")
+    sels = [i % 2 == 0 for i in range(16)]
+    common, cached = airs.preprocessed_cached_traces(sels, 3)
+    pre = {0: (np.array([int(s) for s in sels], np.uint32), len(sels))}
+    run_partitioned(dev, pkg, orc, airs.test_params(), [airs.preprocessed_cached_air(3)],
+                    [(0, common, len(sels), [], cached)], pre)
+    params = airs.test_params(l_skip=2, n_stack=6, k_whir=2)
+    bench = airs.uniform_runner_air(8)
+    t1, pv = airs.fibonacci_trace(0, 1, 16)
+    run_case(dev, pkg, orc, params, [airs.fibonacci_air(), bench, bench],
+             [(0, t1, 16, pv), (1, airs.splitmix64_bits(1, 8 * 64), 64, []), (2, airs.splitmix64_bits(2, 8 * 2), 2, [])])
+
+
+def test_jit_and_interpreter_agree_at_full_size(dev, pkg, orc, monkeypatch):
+    """Config D: the proof with compiled kernels equals the proof with the interpreter, byte for byte."""
+    blob, pk, trace, h = _config_d(pkg, dev, 22, 100, 24)
+    monkeypatch.setenv("OVM_JIT", "0")
+    a, _ = dev.prove(pk, [(0, trace, h, [])])
+    monkeypatch.setenv("OVM_JIT", "1")
+    b, _ = dev.prove(pk, [(0, trace, h, [])])
+    assert a == b
+    orc.verify(blob, b)
