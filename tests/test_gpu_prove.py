@@ -325,3 +325,47 @@ def test_jit_and_interpreter_agree_at_full_size(dev, pkg, orc, monkeypatch):
     b, _ = dev.prove(pk, [(0, trace, h, [])])
     assert a == b
     orc.verify(blob, b)
+
+
+# ---- error behaviour through the C ABI: invalid inputs give error codes and messages, never crashes ----
+def test_error_paths(dev, pkg, orc):
+    import torch
+    params = airs.test_params(l_skip=2, n_stack=5, k_whir=2)
+    air_list = [airs.dummy_interaction_air(1, True, 0), airs.dummy_interaction_air(1, False, 0)]
+    pk = pkg.ProvingKey(airs.pk_blob(params, air_list))
+    up = lambda a: dev.upload(pkg.to_mont(np.asarray(a, dtype=np.uint32)))
+    s = np.array([[0, 1], [7, 4], [3, 5], [546, 889]], dtype=np.uint32).T.reshape(-1)
+    # 1. interactions that do not balance (a sender without its receiver): LogUp root sum is non-zero
+    with pytest.raises(pkg.OvmError, match="non-zero root sum"):
+        dev.prove(pk, [(0, up(s), 4, [])])
+    # 2. AIR index out of range
+    with pytest.raises(pkg.OvmError, match="air index"):
+        dev.prove(pk, [(7, up(s), 4, [])])
+    # 3. height not a power of two
+    with pytest.raises(pkg.OvmError):
+        dev.prove(pk, [(0, up(np.zeros(6, np.uint32)), 3, [])])
+    # 4. wrong number of public values
+    pkf = pkg.ProvingKey(airs.pk_blob(params, [airs.fibonacci_air()]))
+    tr, pvs = airs.fibonacci_trace(0, 1, 16)
+    with pytest.raises(pkg.OvmError, match="public values"):
+        dev.prove(pkf, [(0, up(tr), 16, pvs[:2])])
+    # 5. a cached partition is declared by the AIR but not supplied
+    c_airs, c_traces = airs.cached_fixture_11()
+    pkc = pkg.ProvingKey(airs.pk_blob(airs.test_params(), c_airs))
+    with pytest.raises(pkg.OvmError, match="cached"):
+        dev.prove(pkc, [(a, up(c), h, p) for a, c, h, p, _ in c_traces])
+    # 6. malformed key blobs
+    blob = airs.pk_blob(params, air_list)
+    with pytest.raises(pkg.OvmError):
+        pkg.ProvingKey(blob[:-3])
+    bad = blob.copy()
+    bad[0] ^= 1
+    with pytest.raises(pkg.OvmError):
+        pkg.ProvingKey(bad)
+    # 7. proof buffer too small: error code, and the required length is reported by a retry
+    r = np.array([[1, 5], [3, 4], [4, 4], [2, 5], [0, 123], [545, 889], [1, 889], [0, 456]], dtype=np.uint32).T.reshape(-1)
+    good = [(0, up(s), 4, []), (1, up(r), 8, [])]
+    with pytest.raises(pkg.OvmError):
+        dev.prove(pk, good, proof_cap=64)
+    proof, _ = dev.prove(pk, good)  # the library is still usable after every failure above
+    orc.verify(airs.pk_blob(params, air_list), proof)
