@@ -20,7 +20,7 @@ from ctypes import (POINTER, Structure, c_char_p, c_int, c_size_t, c_uint32, c_u
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libopenvm_hip.so")
+LIB_PATH = os.environ.get("OVM_HIP_LIB") or os.path.join(_HERE, "libopenvm_hip.so")
 INCLUDE_DIR = os.path.join(os.path.dirname(_HERE), "include")
 
 P = 2013265921  # 15 * 2^27 + 1

@@ -25,13 +25,15 @@ __device__ __forceinline__ void stp(uint32_t *b, uint64_t st, uint64_t i, const 
 }
 
 // ---- round 0: program values on the coset LDEs, weighted by eq and summed per (coset, z) ------
-// Prog::operator()(const Fp *lde_k, uint32_t log_lifted, uint64_t p, EF (&out)[2]) adds the
-// program's accumulators at row p of coset k (lde_k = column 0 of that coset) into out.
+// A lane evaluates Prog::ROWS rows per step (rows p, p + stride, ...: same z = p mod N).
+// Prog::operator()(const Fp *lde_k, uint32_t log_lifted, const uint64_t (&p)[ROWS], EF (&out)[ROWS][2])
+// adds the program's accumulators at those rows of coset k (lde_k = column 0 of that coset).
 //   partials[((block * n_cosets + k) * n_out + o) * N + z]
 template <class Prog>
 __device__ __forceinline__ void round0_eval_body(const Prog &prog, const Fp *lde, uint32_t n_cols_total,
                                                  uint32_t log_lifted, uint32_t l_skip, uint32_t n_cosets,
                                                  uint32_t n_out, const EF *eq_xi, EF add_const, EF *partials) {
+    constexpr int R = Prog::ROWS;
     __shared__ EF sh[RED_THREADS];
     const uint32_t N = 1u << l_skip;
     const uint64_t total = 1ull << log_lifted;
@@ -39,14 +41,30 @@ __device__ __forceinline__ void round0_eval_body(const Prog &prog, const Fp *lde
     EF sums[MAX_COSETS * 2];
 #pragma unroll
     for (int i = 0; i < (int)(MAX_COSETS * 2); i++) sums[i] = EF::zero();
-    for (uint64_t p = (uint64_t)blockIdx.x * RED_THREADS + threadIdx.x; p < total; p += stride) {
-        const EF::Pre eq = ld_ef(eq_xi + (p >> l_skip)).pre();
+    for (uint64_t p0 = (uint64_t)blockIdx.x * RED_THREADS + threadIdx.x; p0 < total; p0 += stride * R) {
+        uint64_t p[R];
+        EF::Pre eq[R];
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const uint64_t q = p0 + (uint64_t)r * stride;
+            const bool live = q < total;  // a row past the end is evaluated at p0 with weight zero
+            p[r] = live ? q : p0;
+            eq[r] = (live ? ld_ef(eq_xi + (q >> l_skip)) : EF::zero()).pre();
+        }
         // (a runtime loop on purpose: unrolling it would replicate the whole row program per coset)
         for (uint32_t k = 0; k < n_cosets; k++) {
-            EF out[2] = {EF::zero(), add_const};
+            EF out[R][2];
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                out[r][0] = EF::zero();
+                out[r][1] = add_const;
+            }
             prog(lde + (((uint64_t)k * n_cols_total) << log_lifted), log_lifted, p, out);
-            sums[2 * k] = sums[2 * k] + out[0] * eq;
-            if (n_out > 1) sums[2 * k + 1] = sums[2 * k + 1] + out[1] * eq;
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                sums[2 * k] = sums[2 * k] + out[r][0] * eq[r];
+                if (n_out > 1) sums[2 * k + 1] = sums[2 * k + 1] + out[r][1] * eq[r];
+            }
         }
     }
     // reduce over lanes with equal z = tid mod N

@@ -317,6 +317,64 @@ BB_HD void run_program_acc(const Instr *code, uint32_t n_instr, const FpExt *wei
     }
 }
 
+// The same for R rows per lane at once (base-field programs): one instruction decode -- the
+// interpreter's dominant cost, ~30 scalar instructions -- is amortised over R field operations.
+// slots[s][r], out[r][acc]; fetch(col, r) reads column `col` at the lane's r-th row.
+template <int R, class Fetch>
+BB_HD void load_operand_rows(uint8_t kind, uint32_t payload, const Fp (*slots)[R], Fetch &fetch, Fp (&v)[R]) {
+    if (kind == K_SLOT) {
+#pragma unroll
+        for (int r = 0; r < R; r++) v[r] = slots[payload][r];
+    } else if (kind == K_COL) {
+#pragma unroll
+        for (int r = 0; r < R; r++) v[r] = fetch(payload, r);
+    } else {
+#pragma unroll
+        for (int r = 0; r < R; r++) v[r] = Fp::raw(payload);
+    }
+}
+template <int R, class Fetch>
+BB_HD void run_program_acc_rows(const Instr *code, uint32_t n_instr, const FpExt *weights, Fp (*slots)[R], Fetch &fetch,
+                                FpExt (*out)[2]) {
+    for (uint32_t pc = 0; pc < n_instr; pc++) {
+        const Instr in = code[pc];
+        Fp a[R], b[R];
+        load_operand_rows<R>(in.ak, in.a, slots, fetch, a);
+        switch (in.op) {
+            case OP_ADD:
+                load_operand_rows<R>(in.bk, in.b, slots, fetch, b);
+#pragma unroll
+                for (int r = 0; r < R; r++) slots[in.dst][r] = a[r] + b[r];
+                break;
+            case OP_SUB:
+                load_operand_rows<R>(in.bk, in.b, slots, fetch, b);
+#pragma unroll
+                for (int r = 0; r < R; r++) slots[in.dst][r] = a[r] - b[r];
+                break;
+            case OP_MUL:
+                load_operand_rows<R>(in.bk, in.b, slots, fetch, b);
+#pragma unroll
+                for (int r = 0; r < R; r++) slots[in.dst][r] = a[r] * b[r];
+                break;
+            case OP_NEG:
+#pragma unroll
+                for (int r = 0; r < R; r++) slots[in.dst][r] = -a[r];
+                break;
+            default: {  // OP_ACC
+                const FpExt w = weights[in.b];
+                if (in.acc) {  // (static indices: a runtime index would push `out` into scratch memory)
+#pragma unroll
+                    for (int r = 0; r < R; r++) out[r][1] += w * a[r];
+                } else {
+#pragma unroll
+                    for (int r = 0; r < R; r++) out[r][0] += w * a[r];
+                }
+                break;
+            }
+        }
+    }
+}
+
 // Leaf mode: `emit(k, numer, denom)` is called per interaction.
 template <class T, class Fetch, class Emit>
 BB_HD void run_program_leaves(const Instr *code, uint32_t n_instr, const FpExt *weights, const FpExt *leaf_const,

@@ -394,13 +394,26 @@ struct LdeFetch {
     __device__ Fp operator()(uint32_t col) const { return base[((uint64_t)col << log_lifted) + p]; }
 };
 
+// The interpreter can evaluate R0_ROWS rows per lane per pass over the program (one instruction
+// decode amortised over R0_ROWS field operations). Measured on MI355X (A/B in one session, config D
+// and the 21-segment reth replay): 2 rows = no difference within +-2 % noise, 4 rows = slower
+// (196 VGPRs, 2 waves per SIMD). So: 1.
+static constexpr int R0_ROWS = 1;
+struct LdeFetchRows {
+    const Fp *base;
+    uint32_t log_lifted;
+    const uint64_t *p;
+    __device__ __forceinline__ Fp operator()(uint32_t col, int r) const { return base[((uint64_t)col << log_lifted) + p[r]]; }
+};
 template <int NS>
 struct InterpRound0 {
+    static constexpr int ROWS = R0_ROWS;
     DevProgram prog;
-    __device__ __forceinline__ void operator()(const Fp *lde_k, uint32_t log_lifted, uint64_t p, EF (&out)[2]) const {
-        Fp slots[NS];
-        LdeFetch fetch{lde_k, log_lifted, p};
-        run_program_acc<Fp>(prog.code, prog.n_instr, prog.weights, slots, fetch, out);
+    __device__ __forceinline__ void operator()(const Fp *lde_k, uint32_t log_lifted, const uint64_t (&p)[ROWS],
+                                               EF (&out)[ROWS][2]) const {
+        Fp slots[NS][ROWS];
+        LdeFetchRows fetch{lde_k, log_lifted, p};
+        run_program_acc_rows<ROWS>(prog.code, prog.n_instr, prog.weights, slots, fetch, out);
     }
 };
 template <int NS>
@@ -427,7 +440,10 @@ int round0_eval(const DevProgram &prog, const Fp *lde, uint32_t n_cols_total, ui
                 hipStream_t s) {
     if (n_cosets == 0) return 0;
     if (n_cosets > MAX_COSETS || n_out > 2 || (1u << l_skip) > RED_THREADS) return (int)hipErrorInvalidValue;
-    uint32_t grid = red_grid(1ull << log_lifted);
+    // every lane gets R0_ROWS live rows whenever the trace is tall enough
+    uint64_t lanes = (1ull << log_lifted) / R0_ROWS;
+    if (lanes < RED_THREADS) lanes = RED_THREADS;
+    uint32_t grid = red_grid(lanes);
 #define CALL(NS)                                                                                              \
     hipLaunchKernelGGL(round0_eval_kernel<NS>, dim3(grid), dim3(RED_THREADS), 0, s, prog, lde, n_cols_total, \
                        log_lifted, l_skip, n_cosets, n_out, d_eq_xi, add_const, ro.partials)
