@@ -258,6 +258,19 @@ struct Transcript {
     // minimum witness (device search), then absorbed like check_witness does
     Fp grind(unsigned bits) {
         if (bits == 0) return Fp::zero();
+        if (bits <= 6) {
+            // ~2^bits candidates: a host search (about 1.5 us per candidate) beats a device launch plus
+            // two copies and a synchronisation (~85 us); same minimum witness
+            for (uint32_t w = 0; w < bb::P; w++) {
+                p2::Sponge t = s;
+                t.observe(Fp::from_canonical(w));
+                if (t.sample_bits(bits) == 0) {
+                    s = t;
+                    return Fp::from_canonical(w);
+                }
+            }
+            throw OvmFail(1, "grind: no witness");
+        }
         ovm_sponge_t st;
         for (int i = 0; i < 16; i++) st.state[i] = s.state[i].v;
         st.absorb_idx = s.absorb_idx;
