@@ -462,9 +462,33 @@ __global__ void fold_ple_kernel(const ColDesc *cols, uint32_t log_lifted, uint32
     const ColDesc cd = cols[blockIdx.y];
     const uint64_t hmask = (1ull << cd.log_height) - 1;
     EF acc = EF::zero();
-    for (uint32_t z = 0; z < (1u << l_skip); z++) {
-        Fp v = cd.ptr[((x << l_skip) + z + cd.rot) & hmask];
-        acc = acc + ld_ef(weights + z) * v;
+    if (l_skip == 4 && cd.log_height >= 4) {
+        // 16-row chunks: the lane's chunk is 64 contiguous bytes -> four 16-byte loads (a rotated
+        // view needs the first row of the next chunk as well)
+        const uint64_t base = (x << 4) & hmask;
+        const uint4 *src = reinterpret_cast<const uint4 *>(cd.ptr + base);
+        uint32_t r[17];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            uint4 t = src[q];
+            r[4 * q] = t.x;
+            r[4 * q + 1] = t.y;
+            r[4 * q + 2] = t.z;
+            r[4 * q + 3] = t.w;
+        }
+        r[16] = cd.rot ? cd.ptr[(base + 16) & hmask].v : 0;
+        if (cd.rot > 1) {  // (views only ever rotate by 0 or 1; keep the general path exact)
+            for (uint32_t z = 0; z < 16; z++) r[z] = cd.ptr[((x << 4) + z + cd.rot) & hmask].v;
+            r[16] = 0;
+        }
+        const uint32_t sh = cd.rot == 1 ? 1 : 0;
+#pragma unroll
+        for (int z = 0; z < 16; z++) acc = acc + ld_ef(weights + z) * Fp::raw(sh ? r[z + 1] : r[z]);
+    } else {
+        for (uint32_t z = 0; z < (1u << l_skip); z++) {
+            Fp v = cd.ptr[((x << l_skip) + z + cd.rot) & hmask];
+            acc = acc + ld_ef(weights + z) * v;
+        }
     }
     st_ef(out + (uint64_t)blockIdx.y * nx + x, acc);
 }
