@@ -1371,7 +1371,9 @@ struct Prover {
             auto d_lrot = cx.upload(lrot);
             unsigned log_len = std::max(wd.log_height, l_skip);
             const Fp *base = commits[tvs[w0].com]->stacked_view + tvs[w0].s.col_idx * H + tvs[w0].s.row_idx;
-            OVM_THROW_IF(stacked_round0(base, (uint32_t)(w1 - w0), log_len, l_skip, d_leq.p, d_lrot.p, wd.eq_cube.p,
+            bool any_rot = false;
+            for (auto &x : lrot) any_rot |= !is_zero(x);
+            OVM_THROW_IF(stacked_round0(base, (uint32_t)(w1 - w0), log_len, l_skip, d_leq.p, any_rot ? d_lrot.p : nullptr, wd.eq_cube.p,
                                         mb.arm(partials.p), cx.stream));
             auto R = mb.take(3 * N, cx.stream);
             // host: chunk-aggregated vectors -> coset evaluations with the univariate factors

@@ -956,10 +956,14 @@ __global__ __launch_bounds__(RED_THREADS) void stacked_round0_kernel(const Fp *b
     EF sums[3] = {EF::zero(), EF::zero(), EF::zero()};
     for (uint64_t p = (uint64_t)blockIdx.x * RED_THREADS + threadIdx.x; p < total; p += stride) {
         EF qe = EF::zero(), qr = EF::zero();
-        for (uint32_t i = 0; i < n_slices; i++) {
-            Fp v = base[((uint64_t)i << log_len) + p];
-            qe = qe + ld_ef(lam_eq + i) * v;
-            qr = qr + ld_ef(lam_rot + i) * v;
+        if (lam_rot) {
+            for (uint32_t i = 0; i < n_slices; i++) {
+                Fp v = base[((uint64_t)i << log_len) + p];
+                qe = qe + ld_ef(lam_eq + i) * v;
+                qr = qr + ld_ef(lam_rot + i) * v;
+            }
+        } else {  // no slice of this window has a rotated opening: its weights are all zero
+            for (uint32_t i = 0; i < n_slices; i++) qe = qe + ld_ef(lam_eq + i) * base[((uint64_t)i << log_len) + p];
         }
         uint64_t x = p >> l_skip, xp = x == 0 ? nx - 1 : x - 1;
         EF ec = ld_ef(eq_cube + x), ecp = ld_ef(eq_cube + xp);
