@@ -471,3 +471,51 @@ def synthetic_segment(seg, max_log_height):
         air_list.append(air)
         shapes.append((i, max(min(rec[0], max_log_height), 1), width))
     return air_list, shapes
+
+
+# ---- randomised AIRs for differential testing (not from the reference) ---------------------------
+def random_air(rng, width, n_constraints, n_pairs, max_degree=3, use_next=True, num_public_values=0):
+    """A random AIR: constraints are random expression trees over local / next cells, constants and
+    public values (degree <= max_degree); every interaction is sent and received with the same
+    fields and count, so LogUp balances on ANY trace. Constraints are NOT satisfied by random traces:
+    both provers still emit a proof (no prover-side validity check), and their bytes must agree."""
+    a = Air("RandomAir", width, num_public_values=num_public_values)
+
+    def leaf():
+        k = int(rng.integers(0, 10))
+        if k < 6 or not use_next:
+            return a.local(int(rng.integers(0, width)))
+        if k < 8:
+            return a.next(int(rng.integers(0, width)))
+        if k < 9 and num_public_values:
+            return a.public(int(rng.integers(0, num_public_values)))
+        return Expr.lift(int(rng.integers(0, P)))
+
+    def tree(depth, deg_budget):
+        if depth == 0 or deg_budget <= 1 and rng.integers(0, 2):
+            return leaf()
+        op = int(rng.integers(0, 4))
+        if op == 0 and deg_budget >= 2:
+            d1 = int(rng.integers(1, deg_budget))
+            return tree(depth - 1, d1) * tree(depth - 1, deg_budget - d1)
+        if op == 1:
+            return tree(depth - 1, deg_budget) + tree(depth - 1, deg_budget)
+        if op == 2:
+            return tree(depth - 1, deg_budget) - tree(depth - 1, deg_budget)
+        return -tree(depth - 1, deg_budget)
+
+    for _ in range(n_constraints):
+        e = tree(3, max_degree)
+        sel = int(rng.integers(0, 5))
+        when = [None, IS_FIRST(), IS_LAST(), IS_TRANSITION(), None][sel]
+        if when is not None and e.deg + 1 > max_degree:
+            when = None
+        a.assert_zero(e, when=when)
+    for i in range(n_pairs):
+        n_fields = int(rng.integers(1, 4))
+        fields = [tree(1, 1) for _ in range(n_fields)]
+        count = a.local(int(rng.integers(0, width)))
+        bus = int(rng.integers(0, 3))
+        a.push_interaction(bus, fields, count)
+        a.push_interaction(bus, fields, NEG_ONE() * count)
+    return a.finish()

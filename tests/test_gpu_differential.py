@@ -1,0 +1,69 @@
+"""Differential testing on randomised AIRs and random (constraint-violating) traces: the HIP proof
+must equal the oracle's byte for byte. Neither prover checks validity, so every intermediate value
+-- constraint evaluations on cosets, LogUp numerators/denominators, sumcheck polynomials -- takes
+generic field values instead of the zeros a satisfied AIR produces."""
+import numpy as np
+import pytest
+
+import airs
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def _no_oracle_debug_asserts(monkeypatch):
+    # the oracle mirrors a reference debug_assert on the zerocheck sum; traces here violate constraints
+    monkeypatch.setenv("ORC_SKIP_DEBUG_ASSERTS", "1")
+
+
+def _run(dev, pkg, orc, params, air_list, traces):
+    blob = airs.pk_blob(params, air_list)
+    want = orc.prove(blob, traces)["proof"]
+    pk = pkg.ProvingKey(blob)
+    dtr = [(a, dev.upload(pkg.to_mont(np.asarray(tr, dtype=np.uint32))), h, pv) for a, tr, h, pv in traces]
+    got, secs = dev.prove(pk, dtr)
+    if got != want:
+        n = min(len(got), len(want))
+        first = next((i for i in range(n) if got[i] != want[i]), n)
+        pytest.fail(f"proof differs at byte {first} of {len(want)} (section ends {secs})")
+
+
+@pytest.mark.parametrize("seed", range(20))
+def test_random_single_air(dev, pkg, orc, seed):
+    rng = np.random.default_rng(1000 + seed)
+    l_skip = int(rng.integers(1, 5))
+    log_h = int(rng.integers(0, 8))
+    n_stack = max(int(rng.integers(3, 8)), log_h + 1 - l_skip if log_h + 1 > l_skip else 3)
+    params = airs.test_params(l_skip=l_skip, n_stack=n_stack, k_whir=int(rng.integers(1, 4)))
+    width = int(rng.integers(2, 10))
+    npv = int(rng.integers(0, 3))
+    air = airs.random_air(rng, width, int(rng.integers(1, 12)), int(rng.integers(0, 4)), num_public_values=npv)
+    h = 1 << log_h
+    tr = rng.integers(0, airs.P, size=width * h, dtype=np.uint64).astype(np.uint32)
+    pvs = [int(x) for x in rng.integers(0, airs.P, size=npv)]
+    _run(dev, pkg, orc, params, [air], [(0, tr, h, pvs)])
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_random_multi_air(dev, pkg, orc, seed, monkeypatch):
+    rng = np.random.default_rng(2000 + seed)
+    if seed % 2:
+        monkeypatch.setenv("OVM_JIT", "1")  # the compiled kernels on generic values as well
+    params = airs.test_params(l_skip=int(rng.integers(2, 4)), n_stack=7, k_whir=2)
+    air_list, traces = [], []
+    for i in range(int(rng.integers(2, 5))):
+        width = int(rng.integers(2, 8))
+        air_list.append(airs.random_air(rng, width, int(rng.integers(0, 8)), int(rng.integers(0, 3))))
+        h = 1 << int(rng.integers(0, 7))
+        traces.append((i, rng.integers(0, airs.P, size=width * h, dtype=np.uint64).astype(np.uint32), h, []))
+    _run(dev, pkg, orc, params, air_list, traces)
+
+
+def test_internal_like_parameters(dev, pkg, orc):
+    """l_skip 2, log_blowup 3 (the reference's internal-aggregation shape, config/mod.rs:170-199), k_whir 4."""
+    params = airs.make_params(2, 9, 3, 4, 3, 5, 2, 2, 2, 2, 3, 512)
+    rng = np.random.default_rng(7)
+    air = airs.random_air(rng, 6, 8, 2)
+    h = 1 << 7
+    tr = rng.integers(0, airs.P, size=6 * h, dtype=np.uint64).astype(np.uint32)
+    _run(dev, pkg, orc, params, [air], [(0, tr, h, [])])
