@@ -23,14 +23,22 @@ struct JitKernels {
     hipFunction_t leaves = nullptr;
 };
 
-struct JitModule {
+// The loaded code object of one AIR (shared by every key that contains an identical AIR).
+struct JitAirModule {
     hipModule_t mod = nullptr;
-    std::vector<JitKernels> per_air;
-    double compile_seconds = 0;
-    ~JitModule();
+    JitKernels k;
+    ~JitAirModule();
 };
 
-// Generates and compiles the kernels of every AIR of the key. Returns null (and a message) when
+struct JitModule {
+    std::vector<JitKernels> per_air;
+    std::vector<std::shared_ptr<JitAirModule>> modules;  // keep-alive
+    double compile_seconds = 0;
+};
+
+// Generates and compiles the kernels of every AIR of the key: one translation unit per AIR,
+// distinct ones compiled in parallel (OVM_JIT_THREADS, default all cores), compiled code and
+// loaded modules cached process-wide by source text. Returns null (and a message) when
 // hiprtc is unavailable or the compilation fails; the caller then keeps interpreting.
 // load = false: generate and compile only (no device needed), for tests and timing.
 std::shared_ptr<JitModule> jit_build(const ProvingKey &pk, std::string &message, bool load = true);
