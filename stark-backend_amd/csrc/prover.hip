@@ -1943,6 +1943,14 @@ int ovm_hip_pk_load(const uint32_t *blob, uint64_t words, ovm_pk_t **pk_out, ovm
             pcs->own_mat = std::move(dev);
             dk->pre[a] = std::move(pcs);
         }
+        // OVM_JIT=1: compile the constraint kernels now, as part of loading the key (the reference's
+        // keygen-time work), instead of inside the first proof that uses it
+        if (const char *e = std::getenv("OVM_JIT"))
+            if (e[0] == '1') {
+                std::lock_guard<std::mutex> lk(dk->jit_mu);
+                dk->jit_tried = true;
+                dk->jit = jit_build(dk->pk, dk->jit_message);
+            }
         *pk_out = reinterpret_cast<ovm_pk_t *>(dk.release());
         return 0;
     });
