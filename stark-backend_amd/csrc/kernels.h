@@ -36,12 +36,9 @@ int round0_eval(const DevProgram &prog, const Fp *lde, uint32_t n_cols_total, ui
 int fold_ple(const ColDesc *d_cols, uint32_t n_cols, uint32_t log_lifted, uint32_t l_skip, const EF *d_weights,
              EF *out, hipStream_t s);
 
-// MLE round on folded EF matrices (n_cols x 2^log_h, column-major):
-//   out[(X-1) * n_out + o] = sum_y eq[y] * program_o(row interpolated at X from rows 2y, 2y+1)
-int mle_round_eval(const DevProgram &prog, const EF *mats, uint32_t n_cols, uint32_t log_h, uint32_t degree,
-                   uint32_t n_out, const EF *d_eq, EF add_const, const RedOut &ro, hipStream_t s);
-
-// Same sums from a grouped program: grid = (y blocks, X = 1..degree, group); out[2*(X-1)+o].
+// MLE round on folded EF matrices (n_cols x 2^log_h, column-major), node-grouped program:
+//   out[2*(X-1)+o] = sum_y eq[y] * program_o(row interpolated at X from rows 2y, 2y+1);
+//   grid = (y blocks, X = 1..degree, group).
 int mle_round_eval_grouped(const Instr *d_code, const uint32_t *d_off, uint32_t n_groups, uint32_t max_slots,
                            const EF *d_weights, const EF *mats, uint32_t log_h, uint32_t degree, uint32_t n_out,
                            const EF *d_eq, EF add_const, const RedOut &ro, hipStream_t s);
@@ -50,7 +47,6 @@ int mle_round_eval_grouped(const Instr *d_code, const uint32_t *d_off, uint32_t 
 int fold_mle(const EF *in, EF *out, uint32_t n_cols, uint32_t log_h, EF r, hipStream_t s);
 
 // ---- LogUp GKR ----  (layer format: record x = fractions 2x, 2x+1 = (p0,q0),(p1,q1))
-int eq_table_planes(const EF *d_point, uint32_t n, EFPlanes out, hipStream_t s);
 // heap[2^k + y] = eq(point[n-k .. n), y) for k = 0 .. n-1 (2^n entries, node 1 = 1): the weights of
 // sub-round n-1-k of a layer sumcheck whose eq factor is split off (stages.hip)
 int eq_heap(const EF *d_point, uint32_t n, EFPlanes heap, hipStream_t s);

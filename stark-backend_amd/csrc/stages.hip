@@ -152,27 +152,12 @@ int build_selectors(Fp *sels, uint32_t log_lifted, uint32_t log_height, hipStrea
     return 0;
 }
 
-// Output policies: 16-byte AoS elements, or limb planes (used by the GKR kernels).
+// Output policy: 16-byte AoS elements (the GKR phase builds its own limb-planar eq heap).
 struct EqOutAos {
     EF *p;
     __device__ EF ld(uint64_t i) const { return ld_ef(p + i); }
     __device__ void st(uint64_t i, const EF &x) const { st_ef(p + i, x); }
 };
-struct EqOutPlanes {
-    uint32_t *p;
-    uint64_t stride;
-    __device__ EF ld(uint64_t i) const {
-        EF r;
-#pragma unroll
-        for (int k = 0; k < 4; k++) r.c[k] = Fp::raw(p[k * stride + i]);
-        return r;
-    }
-    __device__ void st(uint64_t i, const EF &x) const {
-#pragma unroll
-        for (int k = 0; k < 4; k++) p[k * stride + i] = x.c[k].v;
-    }
-};
-
 template <bool MOBIUS, class Out>
 __global__ void eq_table_kernel(const EF *point, uint32_t n, Out out) {
     uint64_t y = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -220,9 +205,6 @@ static int eq_table_impl(const EF *d_point, uint32_t n, Out out, hipStream_t s) 
 }
 int eq_table(const EF *d_point, uint32_t n, EF *out, hipStream_t s) {
     return eq_table_impl<false>(d_point, n, EqOutAos{out}, s);
-}
-int eq_table_planes(const EF *d_point, uint32_t n, EFPlanes out, hipStream_t s) {
-    return eq_table_impl<false>(d_point, n, EqOutPlanes{out.p, out.stride}, s);
 }
 int mobius_eq_table(const EF *d_point, uint32_t n, EF *out, hipStream_t s) {
     return eq_table_impl<true>(d_point, n, EqOutAos{out}, s);
@@ -514,43 +496,6 @@ struct MleFetch {
         return t0 + (t1 - t0) * x;
     }
 };
-
-template <int NS>
-__global__ __launch_bounds__(RED_THREADS) void mle_round_kernel(DevProgram prog, const EF *mats, uint32_t log_h,
-                                                                uint32_t degree, uint32_t n_out, const EF *eq,
-                                                                EF add_const, RedOut ro) {
-    const uint64_t n_y = 1ull << (log_h - 1);
-    const uint64_t stride = (uint64_t)gridDim.x * RED_THREADS;
-    EF sums[8];
-#pragma unroll
-    for (int i = 0; i < 8; i++) sums[i] = EF::zero();
-    EF slots[NS];
-    for (uint64_t y = (uint64_t)blockIdx.x * RED_THREADS + threadIdx.x; y < n_y; y += stride) {
-        EF e = ld_ef(eq + y);
-        for (uint32_t xi = 1; xi <= degree; xi++) {
-            MleFetch fetch{mats, log_h, y, Fp::from_canonical(xi)};
-            EF out[2] = {EF::zero(), add_const};
-            run_program_acc<EF>(prog.code, prog.n_instr, prog.weights, slots, fetch, out);
-            sums[2 * (xi - 1)] = sums[2 * (xi - 1)] + e * out[0];
-            if (n_out > 1) sums[2 * (xi - 1) + 1] = sums[2 * (xi - 1) + 1] + e * out[1];
-        }
-    }
-    block_sum_store<8>(sums, ro.partials + (size_t)blockIdx.x * 8, ro.counter != nullptr);
-    finish_reduction<8>(ro, gridDim.x, 8);
-}
-
-int mle_round_eval(const DevProgram &prog, const EF *mats, uint32_t n_cols, uint32_t log_h, uint32_t degree,
-                   uint32_t n_out, const EF *d_eq, EF add_const, const RedOut &ro, hipStream_t s) {
-    if (degree > 4 || n_out > 2 || log_h == 0) return (int)hipErrorInvalidValue;
-    uint32_t grid = red_grid(1ull << (log_h - 1));
-#define CALL(NS)                                                                                          \
-    hipLaunchKernelGGL(mle_round_kernel<NS>, dim3(grid), dim3(RED_THREADS), 0, s, prog, mats, log_h, degree, \
-                       n_out, d_eq, add_const, red_inline(ro, grid))
-    DISPATCH_SLOTS(prog.num_slots, CALL);
-#undef CALL
-    OVM_CHECK_LAUNCH();
-    return red_finish(ro, grid, grid, 8, s);  // out[2*(X-1)+o]
-}
 
 template <int NS>
 __global__ __launch_bounds__(RED_THREADS) void mle_round_grouped_kernel(const Instr *code, const uint32_t *off,
