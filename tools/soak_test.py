@@ -1,0 +1,24 @@
+"""Soak test (GPU): 300 identical proofs must be byte-identical and must not grow device memory; 50 keys with a
+preprocessed trace are created and freed. Run: python tools/soak_test.py"""
+import sys, os, numpy as np, torch, time
+sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
+import __graft_entry__ as ge, airs
+pkg = ge._load_pkg(); dev = pkg.Device(0)
+params = airs.test_params(l_skip=4, n_stack=10, k_whir=4)
+pk = pkg.ProvingKey(airs.pk_blob(params, [airs.uniform_runner_air(20)]))
+h = 1 << 12
+tr = dev.upload(pkg.to_mont(airs.splitmix64_bits(1, 20 * h)))
+first = None
+for i in range(300):
+    proof, _ = dev.prove(pk, [(0, tr, h, [])])
+    if first is None: first = proof
+    assert proof == first
+    if i % 100 == 0:
+        free, total = torch.cuda.mem_get_info(); print(i, "used GB", round((total - free) / 2**30, 3), flush=True)
+free, total = torch.cuda.mem_get_info(); print("end used GB", round((total - free) / 2**30, 3))
+# many keys in a row (key lifetime: preprocessed commit + free)
+sels=[i%2==0 for i in range(16)]
+for i in range(50):
+    pre={0:(np.array([int(s) for s in sels],np.uint32),16)}
+    k = pkg.ProvingKey(airs.pk_blob(airs.test_params(), [airs.fibonacci_selector_air()], preprocessed=pre)); del k
+free, total = torch.cuda.mem_get_info(); print("after 50 keys used GB", round((total - free) / 2**30, 3))
