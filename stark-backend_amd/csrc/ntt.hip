@@ -15,6 +15,8 @@
 // A pass handles `r` consecutive DIF stages on tiles of 2^r x 2^c elements (2^c consecutive rows
 // so that every global access is a run of >= 2^c * 4 bytes) staged through LDS. Zero padding of
 // the message is virtual: rows >= 2^log_n_in read as zero in the first pass.
+#include <mutex>
+
 #include "device_ctx.h"
 #include "openvm_hip.h"
 
@@ -37,6 +39,8 @@ TwState g_tw[16];
 const Twiddles *twiddles() {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+    static std::mutex mu;  // engines on several host threads may initialise the same device at once
+    std::lock_guard<std::mutex> lk(mu);
     TwState &st = g_tw[dev];
     if (st.ready) return &st.dev;
     const size_t nlo = size_t(1) << TW_LO_BITS, nhi = size_t(1) << TW_HI_BITS;

@@ -369,3 +369,38 @@ def test_error_paths(dev, pkg, orc):
         dev.prove(pk, good, proof_cap=64)
     proof, _ = dev.prove(pk, good)  # the library is still usable after every failure above
     orc.verify(airs.pk_blob(params, air_list), proof)
+
+
+def test_two_host_threads_prove_concurrently(dev, pkg, orc):
+    """One stream per OS thread, one shared proving key (the reference's supported concurrency:
+    cuda-backend/examples/keccakf.rs:88-131): both threads must reproduce the single-threaded bytes."""
+    import threading
+    import torch
+    params = airs.test_params(l_skip=4, n_stack=9, k_whir=4)
+    air = airs.uniform_runner_air(20)
+    blob = airs.pk_blob(params, [air])
+    pk = pkg.ProvingKey(blob)
+    h = 1 << 11
+    tr = dev.upload(pkg.to_mont(airs.splitmix64_bits(5, 20 * h)))
+    ref, _ = dev.prove(pk, [(0, tr, h, [])])
+    orc.verify(blob, ref)
+    torch.cuda.synchronize()
+    errors = []
+
+    def worker():
+        try:
+            with torch.cuda.stream(torch.cuda.Stream()):
+                d = pkg.Device(0)
+                for _ in range(6):
+                    got, _ = d.prove(pk, [(0, tr, h, [])])
+                    if got != ref:
+                        errors.append("proof differs")
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+
+    ts = [threading.Thread(target=worker) for _ in range(2)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errors, errors
