@@ -652,7 +652,15 @@ struct Prover {
             ProfScope *ps_leaves = new ProfScope("gkr.leaves", cx.stream);
             // big trees: only limb 0 of the leaf numerators exists (small ones are read through generic paths)
             const bool p_base = TR >= 12;
-            OVM_THROW_IF(gkr_fill_leaves(tree.at(n_leaves), n_leaves, alpha, p_base, cx.stream));
+            // The interaction slices are packed from row 0 with no gaps (descending powers of two), and the
+            // leaf kernels write every row of every slice: only the padding tail needs the default (0, alpha).
+            uint64_t used_leaves = 0;
+            for (auto &sc : ilayout.cols) used_leaves = std::max<uint64_t>(used_leaves, sc.slice.row_idx + (uint64_t(1) << sc.slice.log_height));
+            if (used_leaves > n_leaves) throw OvmFail(1, "internal: interaction layout exceeds the tree");
+            // (small trees keep the full fill: there the leaf kernels rely on it for numerator limbs 1..3)
+            if (!p_base) used_leaves = 0;
+            if (used_leaves < n_leaves)
+                OVM_THROW_IF(gkr_fill_leaves(tree.at(n_leaves + used_leaves), n_leaves - used_leaves, alpha, p_base, cx.stream));
             for (size_t t = 0; t < T; t++) {
                 const AirKey &a = air(t);
                 if (a.interactions.empty()) continue;
