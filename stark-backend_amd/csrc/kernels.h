@@ -84,6 +84,9 @@ int whir_mu_batch(const Fp *msg, uint32_t width, uint32_t log_h, const EF *d_mu_
 // in-place subset-zeta (dir=+1: coeffs->evals) or Moebius (dir=-1: evals->coeffs) over all bits
 int zeta_transform(EF *v, uint32_t log_n, int dir, hipStream_t s);
 int whir_round(const EF *f, const EF *w, uint64_t n_pairs, const RedOut &ro, hipStream_t s);
+// fold the previous round with alpha and return the NEXT round's sums over the n_pairs folded pairs
+int whir_fold_round(const EF *f_in, const EF *w_in, EF *f_out, EF *w_out, uint64_t n_pairs, EF alpha, const RedOut &ro,
+                    hipStream_t s);
 int whir_fold(const EF *f_in, const EF *w_in, EF *f_out, EF *w_out, uint64_t n_out, EF alpha, hipStream_t s);
 // out = sum_i coeffs[i] * z^i
 int horner_eval(const EF *coeffs, uint64_t n, EF z, const RedOut &ro, hipStream_t s);

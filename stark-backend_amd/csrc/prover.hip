@@ -1623,17 +1623,29 @@ struct Prover {
         for (size_t wr = 0; wr < n_rounds; wr++) {
             const bool is_last = wr + 1 == n_rounds;
             ProfScope *ps_ws = new ProfScope("whir.sumcheck_fold", cx.stream);
+            EF al = EF::zero();
             for (unsigned rd = 0; rd < k_whir; rd++) {
                 const EF *f = fw_in_a ? f_a.p : f_b.p, *wv = fw_in_a ? w_a.p : w_b.p;
                 uint64_t half = 1ull << (m - rd - 1);
-                OVM_THROW_IF(whir_round(f, wv, half, mb.arm(d_red.p), cx.stream));
+                if (rd == 0) {
+                    OVM_THROW_IF(whir_round(f, wv, half, mb.arm(d_red.p), cx.stream));
+                } else {
+                    // fold round rd-1 with its alpha and get this round's sums in the same pass
+                    OVM_THROW_IF(whir_fold_round(f, wv, fw_in_a ? f_b.p : f_a.p, fw_in_a ? w_b.p : w_a.p, half, al,
+                                                 mb.arm(d_red.p), cx.stream));
+                    fw_in_a = !fw_in_a;
+                }
                 auto sv = mb.take(2, cx.stream);
                 ts.observe_ext(sv[0]);
                 ts.observe_ext(sv[1]);
                 whir_polys.push_back({sv[0], sv[1]});
                 folding_pows.push_back(ts.grind(P().folding_pow_bits));
-                EF al = ts.sample_ext();
-                OVM_THROW_IF(whir_fold(f, wv, fw_in_a ? f_b.p : f_a.p, fw_in_a ? w_b.p : w_a.p, half, al, cx.stream));
+                al = ts.sample_ext();
+            }
+            {
+                // the last fold of this WHIR round
+                const EF *f = fw_in_a ? f_a.p : f_b.p, *wv = fw_in_a ? w_a.p : w_b.p;
+                OVM_THROW_IF(whir_fold(f, wv, fw_in_a ? f_b.p : f_a.p, fw_in_a ? w_b.p : w_a.p, 1ull << (m - k_whir), al, cx.stream));
                 fw_in_a = !fw_in_a;
             }
             delete ps_ws;

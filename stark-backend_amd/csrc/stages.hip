@@ -1067,6 +1067,38 @@ int whir_round(const EF *f, const EF *w, uint64_t n_pairs, const RedOut &ro, hip
     return red_finish(ro, grid, grid, 2, s);
 }
 
+// Fused "fold by alpha, then the next round's sums" (as in the GKR phase): output pair y is built
+// from f[4y..4y+3], w[4y..4y+3]; one pass over the data per sumcheck round instead of two.
+__global__ __launch_bounds__(RED_THREADS) void whir_fold_round_kernel(const EF *f_in, const EF *w_in, EF *f_out,
+                                                                      EF *w_out, uint64_t n_pairs, EF alpha_in,
+                                                                      RedOut ro) {
+    const uint64_t stride = (uint64_t)gridDim.x * RED_THREADS;
+    const EF::Pre alpha = alpha_in.pre();
+    EF sums[2] = {EF::zero(), EF::zero()};
+    for (uint64_t y = (uint64_t)blockIdx.x * RED_THREADS + threadIdx.x; y < n_pairs; y += stride) {
+        EF a0 = ld_ef(f_in + 4 * y), a1 = ld_ef(f_in + 4 * y + 1), a2 = ld_ef(f_in + 4 * y + 2), a3 = ld_ef(f_in + 4 * y + 3);
+        EF b0 = ld_ef(w_in + 4 * y), b1 = ld_ef(w_in + 4 * y + 1), b2 = ld_ef(w_in + 4 * y + 2), b3 = ld_ef(w_in + 4 * y + 3);
+        const EF f0 = a0 + (a1 - a0) * alpha, f1 = a2 + (a3 - a2) * alpha;
+        const EF w0 = b0 + (b1 - b0) * alpha, w1 = b2 + (b3 - b2) * alpha;
+        st_ef(f_out + 2 * y, f0);
+        st_ef(f_out + 2 * y + 1, f1);
+        st_ef(w_out + 2 * y, w0);
+        st_ef(w_out + 2 * y + 1, w1);
+        sums[0] = sums[0] + f1 * w1;
+        sums[1] = sums[1] + (f1.dbl() - f0) * (w1.dbl() - w0);
+    }
+    block_sum_store<2>(sums, ro.partials + (size_t)blockIdx.x * 2, ro.counter != nullptr);
+    finish_reduction<2>(ro, gridDim.x, 2);
+}
+int whir_fold_round(const EF *f_in, const EF *w_in, EF *f_out, EF *w_out, uint64_t n_pairs, EF alpha, const RedOut &ro,
+                    hipStream_t s) {
+    uint32_t grid = red_grid(n_pairs);
+    hipLaunchKernelGGL(whir_fold_round_kernel, dim3(grid), dim3(RED_THREADS), 0, s, f_in, w_in, f_out, w_out, n_pairs, alpha,
+                       red_inline(ro, grid));
+    OVM_CHECK_LAUNCH();
+    return red_finish(ro, grid, grid, 2, s);
+}
+
 __global__ void whir_fold_kernel(const EF *f_in, const EF *w_in, EF *f_out, EF *w_out, uint64_t n_out, EF alpha_in) {
     uint64_t y = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (y >= n_out) return;
