@@ -730,10 +730,10 @@ struct Prover {
                 DevBuf<uint32_t> rec_a(8 * wcap), rec_b(8 * wcap), eq_buf(4 * wcap);
                 const FracPlanes recs[2] = {{rec_a.p, wcap}, {rec_b.p, wcap}};
                 const EFPlanes heap{eq_buf.p, wcap};
-                DevBuf<EF> partials(RED_BLOCKS * 4), d_point(TR);
+                DevBuf<EF> partials(RED_BLOCKS * 4);
                 for (unsigned round = 1; round < TR; round++) {
                     EF lambda = ts.sample_ext();
-                    OVM_THROW_IF(hipMemcpyAsync(d_point.p, xi_prev.data(), round * sizeof(EF), hipMemcpyHostToDevice, cx.stream));
+                    auto d_point = cx.upload(xi_prev);  // (through the pinned arena: a pageable source would block the host)
                     OVM_THROW_IF(eq_heap(d_point.p, round, heap, cx.stream));
                     FracPlanes rec = tree.at(size_t(2) << round);
                     std::vector<std::array<EF, 3>> polys;
@@ -1482,7 +1482,6 @@ struct Prover {
         delete ps_stf;
         ProfScope *ps_str = new ProfScope("stacked.mle_rounds", cx.stream);
         std::vector<std::array<EF, 2>> st_polys;
-        DevBuf<uint64_t> d_gidx(2 * tvs.size() + 2);
         DevBuf<EF> d_gout(2 * tvs.size() + 2);
         for (unsigned round = 1; round <= n_stack; round++) {
             std::array<EF, 2> batch{EF::zero(), EF::zero()};
@@ -1501,8 +1500,8 @@ struct Prover {
                     }
             std::vector<EF> gv;
             if (!gidx.empty()) {
-                OVM_THROW_IF(hipMemcpyAsync(d_gidx.p, gidx.data(), gidx.size() * 8, hipMemcpyHostToDevice, cx.stream));
-                OVM_THROW_IF(gather_ef(q_cur, d_gidx.p, gidx.size(), d_gout.p, cx.stream));
+                auto d_gi = cx.upload(gidx);
+                OVM_THROW_IF(gather_ef(q_cur, d_gi.p, gidx.size(), d_gout.p, cx.stream));
                 gv = cx.download(d_gout.p, gidx.size());
             }
             size_t gi = 0;
