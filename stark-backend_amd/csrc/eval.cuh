@@ -43,13 +43,12 @@ __device__ __forceinline__ void round0_eval_body(const Prog &prog, const Fp *lde
     for (int i = 0; i < (int)(MAX_COSETS * 2); i++) sums[i] = EF::zero();
     for (uint64_t p0 = (uint64_t)blockIdx.x * RED_THREADS + threadIdx.x; p0 < total; p0 += stride * R) {
         uint64_t p[R];
-        EF::Pre eq[R];
+        bool live[R];
 #pragma unroll
         for (int r = 0; r < R; r++) {
             const uint64_t q = p0 + (uint64_t)r * stride;
-            const bool live = q < total;  // a row past the end is evaluated at p0 with weight zero
-            p[r] = live ? q : p0;
-            eq[r] = (live ? ld_ef(eq_xi + (q >> l_skip)) : EF::zero()).pre();
+            live[r] = q < total;  // a row past the end is evaluated at p0 with weight zero
+            p[r] = live[r] ? q : p0;
         }
         // (a runtime loop on purpose: unrolling it would replicate the whole row program per coset)
         for (uint32_t k = 0; k < n_cosets; k++) {
@@ -62,8 +61,10 @@ __device__ __forceinline__ void round0_eval_body(const Prog &prog, const Fp *lde
             prog(lde + (((uint64_t)k * n_cols_total) << log_lifted), log_lifted, p, out);
 #pragma unroll
             for (int r = 0; r < R; r++) {
-                sums[2 * k] = sums[2 * k] + out[r][0] * eq[r];
-                if (n_out > 1) sums[2 * k + 1] = sums[2 * k + 1] + out[r][1] * eq[r];
+                // (loaded here, not held across the program: 7 registers per row)
+                const EF::Pre eq = (live[r] ? ld_ef(eq_xi + (p[r] >> l_skip)) : EF::zero()).pre();
+                sums[2 * k] = sums[2 * k] + out[r][0] * eq;
+                if (n_out > 1) sums[2 * k + 1] = sums[2 * k + 1] + out[r][1] * eq;
             }
         }
     }

@@ -14,6 +14,24 @@ struct DevProgram {
     const EF *weights;
 };
 
+// Staged round-0 program (program.h: stage_program), device arrays.
+struct DevStaged {
+    const StagedBlock *blocks = nullptr;
+    const uint32_t *loads = nullptr;
+    const StagedInstr *code = nullptr;
+    const StagedAcc *accs = nullptr;
+    uint32_t n_blocks = 0;
+    uint32_t num_rows = 0;
+    uint32_t rows = 0;  // trace rows per lane the offsets were scaled for
+    uint32_t stage_rows = 0;  // rows of one staging buffer
+};
+// Rows per lane and LDS layout for staging a program of `num_slots` slots on a trace of 2^log_lifted
+// rows; rows == 0: its LDS image does not fit (use the plain interpreter).
+struct StagedPlan {
+    uint32_t rows = 0, stage_rows = 0, acc_rows = 0;
+};
+StagedPlan round0_staged_plan(uint32_t log_lifted, uint32_t n_out, uint32_t num_slots);
+
 // ro.out[k] = sum_b ro.partials[b * K + k], then the flag (for reductions with many outputs)
 int sum_partials(const RedOut &ro, uint32_t n_blocks, uint32_t K, hipStream_t s);
 
@@ -29,7 +47,8 @@ int coset_lde(const ColDesc *d_cols, const uint32_t *d_used, uint32_t n_used, ui
               hipStream_t s);
 
 // Round 0: out[((k * n_out) + o) * N + z] = sum_x eq_xi[x] * program_o(lde_k row (x<<l)+z) (+ add_const for o==1)
-int round0_eval(const DevProgram &prog, const Fp *lde, uint32_t n_cols_total, uint32_t log_lifted, uint32_t l_skip,
+// `staged` (optional, blocks != nullptr): the same program in staged form; used when its LDS image fits.
+int round0_eval(const DevProgram &prog, const DevStaged &staged, const Fp *lde, uint32_t n_cols_total, uint32_t log_lifted, uint32_t l_skip,
                 uint32_t n_cosets, uint32_t n_out, const EF *d_eq_xi, EF add_const, const RedOut &ro, hipStream_t s);
 
 // out[col * (lifted >> l) + x] = sum_z w[z] * col(( x << l) + z)

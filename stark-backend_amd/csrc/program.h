@@ -252,6 +252,197 @@ inline Program compile_program_impl(const AirKey &air, const ColumnMap &cm, cons
     return prog;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Staged form of an ACC program for the round-0 kernel (stages.hip, StagedRound0).
+//
+// The plain interpreter above decodes operand kinds per instruction and loads trace cells where
+// they are used; on gfx950 that is bound by scalar/branch issue and by the serial
+// decode -> load -> use chain, not by arithmetic. The staged form moves the decisions to the host:
+//   * the program is cut into blocks; a block first brings the (distinct) columns it reads into
+//     LDS staging rows -- asynchronous loads straight into LDS, all in flight together -- then
+//     runs its arithmetic instructions, then its accumulations (a second, branch-free loop);
+//   * every operand is an LDS row or, for `b` only, an immediate constant: constants in `a` are
+//     swapped / folded / materialised here;
+//   * an accumulation `out[o] += W[w] * x` becomes an entry (row of x, w) of the block's list; x is
+//     made to live in a row nothing overwrites before the block ends (a staging row, or an
+//     accumulation row the producing instruction writes directly).
+// LDS rows: two staging buffers of stage_rows rows (block b's columns are requested while block
+// b - 1 runs), acc_rows accumulation operands, then the program's slots. Row r is the words lds[r * 256 + lane] of the workgroup.
+// ---------------------------------------------------------------------------------------------
+// (one bit per operation: the kernel tests them in order of frequency; an enum would be compiled
+// into a balanced compare tree that reaches the multiply last)
+enum StagedOp : uint32_t {
+    S_MUL = 1, S_ADD = 2, S_SUB = 4, S_RSUB = 8 /* b - a */, S_NEG = 16, S_MOV = 32 /* dst = a */, S_MOVC = 64 /* dst = b */
+};
+struct StagedLayout {
+    uint32_t stage_rows = 8, acc_rows = 8;
+    // two staging buffers: block b's columns land in rows [(b & 1) * stage_rows, ...) while block b - 1 runs
+    uint32_t acc_row0() const { return 2 * stage_rows; }
+    uint32_t slot_row0() const { return 2 * stage_rows + acc_rows; }
+};
+static constexpr uint32_t S_B_CONST = 0x100;
+
+
+struct StagedInstr {
+    uint32_t op;   // StagedOp | S_B_CONST
+    uint32_t dst;  // LDS row
+    uint32_t a;    // LDS row
+    uint32_t b;    // LDS row / Montgomery constant
+};
+struct StagedAcc {  // 32 bytes: one scalar load brings the weight and the row
+    uint32_t w[4];  // the extension-field weight W[w], inlined (the staged form is built per proof)
+    uint32_t row, pad[3];
+};
+
+struct StagedBlock {
+    uint32_t load_off, n_loads, instr_off, n_instr;
+    uint32_t acc_off, n_acc0, n_acc1, pad;  // entries of output 0 first, then output 1
+};
+struct StagedProgram {
+    std::vector<StagedBlock> blocks;
+    std::vector<uint32_t> loads;  // flat column of staging row j of its block
+    std::vector<StagedInstr> code;
+    std::vector<StagedAcc> accs;
+    uint32_t num_rows = 0;  // SLOT_ROW0 + slots
+    // operand rows -> word offsets for `rows_per_lane` trace rows per lane
+    void scale_rows(uint32_t rows_per_lane) {
+        const uint32_t k = rows_per_lane * 256;
+        for (auto &in : code) {
+            in.dst *= k;
+            in.a *= k;
+            if (!(in.op & S_B_CONST)) in.b *= k;
+        }
+        for (auto &e : accs) e.row *= k;
+    }
+};
+
+inline StagedProgram stage_program(const Program &p, const std::vector<FpExt> &weights,
+                                   const StagedLayout &layout = StagedLayout()) {
+    const uint32_t STAGE_ROWS = layout.stage_rows, ACC_ROWS = layout.acc_rows, SLOT_ROW0 = layout.slot_row0();
+    StagedProgram sp;
+    sp.num_rows = SLOT_ROW0 + p.num_slots;
+    // dead_after[i]: the slot instruction i reads as `a` is not read again before it is rewritten
+    std::vector<char> dead_after(p.code.size(), 0);
+    {
+        std::vector<char> read_later(p.num_slots + 1, 0);
+        for (size_t i = p.code.size(); i-- > 0;) {
+            const Instr &in = p.code[i];
+            const bool binary = in.op == OP_ADD || in.op == OP_SUB || in.op == OP_MUL;
+            if (in.op != OP_ACC) read_later[in.dst] = 0;  // (reads of this instruction are marked below)
+            if (in.ak == K_SLOT) {
+                dead_after[i] = !read_later[in.a];
+                read_later[in.a] = 1;
+            }
+            if (binary && in.bk == K_SLOT) read_later[in.b] = 1;
+        }
+    }
+    std::vector<uint32_t> cur_cols;  // columns staged by the open block
+    std::vector<StagedAcc> acc0, acc1;
+    StagedBlock blk{};
+    size_t blk_first_instr = 0;
+    auto flush = [&] {
+        if (blk.n_instr == 0 && cur_cols.empty() && acc0.empty() && acc1.empty()) return;
+        blk.n_loads = (uint32_t)cur_cols.size();
+        sp.loads.insert(sp.loads.end(), cur_cols.begin(), cur_cols.end());
+        blk.acc_off = (uint32_t)sp.accs.size();
+        blk.n_acc0 = (uint32_t)acc0.size();
+        blk.n_acc1 = (uint32_t)acc1.size();
+        sp.accs.insert(sp.accs.end(), acc0.begin(), acc0.end());
+        sp.accs.insert(sp.accs.end(), acc1.begin(), acc1.end());
+        sp.blocks.push_back(blk);
+        cur_cols.clear();
+        acc0.clear();
+        acc1.clear();
+        blk = StagedBlock{};
+        blk.load_off = (uint32_t)sp.loads.size();
+        blk.instr_off = (uint32_t)sp.code.size();
+        blk_first_instr = sp.code.size();
+    };
+    auto staged_row = [&](uint32_t col) -> int {
+        for (size_t j = 0; j < cur_cols.size(); j++)
+            if (cur_cols[j] == col) return (int)(j + (sp.blocks.size() & 1) * STAGE_ROWS);
+        return -1;
+    };
+    auto emit = [&](uint32_t op, uint32_t dst, uint32_t a, uint32_t b) {
+        sp.code.push_back(StagedInstr{op, dst, a, b});
+        blk.n_instr++;
+    };
+    for (size_t idx = 0; idx < p.code.size(); idx++) {
+        const Instr &in = p.code[idx];
+        const bool binary = in.op == OP_ADD || in.op == OP_SUB || in.op == OP_MUL;
+        if (in.op > OP_ACC) throw OvmFail(1, "stage_program: not an ACC program");
+        // columns this instruction needs that the open block has not staged yet
+        auto needs = [&](uint32_t (&need)[2]) {
+            int n = 0;
+            if (in.ak == K_COL && staged_row(in.a) < 0) need[n++] = in.a;
+            if (binary && in.bk == K_COL && staged_row(in.b) < 0 && !(n && need[0] == in.b)) need[n++] = in.b;
+            return n;
+        };
+        uint32_t need[2];
+        int n_need = needs(need);
+        if (cur_cols.size() + n_need > STAGE_ROWS || (in.op == OP_ACC && acc0.size() + acc1.size() == ACC_ROWS)) {
+            flush();
+            n_need = needs(need);
+        }
+        for (int i = 0; i < n_need; i++) cur_cols.push_back(need[i]);
+        struct Opnd {
+            bool is_const;
+            uint32_t v;
+        };
+        auto acc_entry = [&](uint32_t row, uint32_t w) {
+            if (w >= weights.size()) throw OvmFail(1, "stage_program: weight index out of range");
+            StagedAcc e{};
+            for (int k = 0; k < 4; k++) e.w[k] = weights[w].c[k].v;
+            e.row = row;
+            return e;
+        };
+        auto opnd = [&](uint8_t kind, uint32_t payload) -> Opnd {
+            if (kind == K_SLOT) return {false, SLOT_ROW0 + payload};
+            if (kind == K_COL) return {false, (uint32_t)staged_row(payload)};
+            if (kind == K_CONST) return {true, payload};
+            throw OvmFail(1, "stage_program: symbolic public values are for the JIT only");
+        };
+        const Opnd a = opnd(in.ak, in.a);
+        const uint32_t dst = SLOT_ROW0 + in.dst;
+        if (in.op == OP_ACC) {
+            std::vector<StagedAcc> &list = in.acc ? acc1 : acc0;
+            const uint32_t acc_row = layout.acc_row0() + (uint32_t)(acc0.size() + acc1.size());
+            if (in.ak == K_COL) {
+                list.push_back(acc_entry(a.v, in.b));  // a staging row stays put until the block ends
+            } else if (a.is_const) {
+                emit(S_MOVC | S_B_CONST, acc_row, 0, a.v);
+                list.push_back(acc_entry(acc_row, in.b));
+            } else if (dead_after[idx] && sp.code.size() > blk_first_instr && sp.code.back().dst == a.v) {
+                sp.code.back().dst = acc_row;  // the producer writes the accumulation row directly
+                list.push_back(acc_entry(acc_row, in.b));
+            } else {
+                emit(S_MOV | S_B_CONST, acc_row, a.v, 0);
+                list.push_back(acc_entry(acc_row, in.b));
+            }
+        } else if (in.op == OP_NEG) {
+            if (a.is_const) emit(S_MOVC | S_B_CONST, dst, 0, (-Fp::raw(a.v)).v);
+            else emit(S_NEG | S_B_CONST, dst, a.v, 0);
+        } else {
+            const Opnd b = opnd(in.bk, in.b);
+            if (a.is_const && b.is_const) {
+                const Fp x = Fp::raw(a.v), y = Fp::raw(b.v);
+                const Fp r = in.op == OP_ADD ? x + y : in.op == OP_SUB ? x - y : x * y;
+                emit(S_MOVC | S_B_CONST, dst, 0, r.v);
+            } else if (a.is_const) {  // constant on the left: commute, or b - a reversed
+                emit((in.op == OP_ADD ? S_ADD : in.op == OP_MUL ? S_MUL : S_RSUB) | S_B_CONST, dst, b.v, a.v);
+            } else {
+                emit((in.op == OP_ADD ? S_ADD : in.op == OP_MUL ? S_MUL : S_SUB) | (b.is_const ? S_B_CONST : 0), dst, a.v,
+                     b.v);
+            }
+        }
+    }
+    flush();
+    // the kernel prefetches one instruction / one entry past the block it runs
+    sp.code.push_back(StagedInstr{S_MOV | S_B_CONST, 0, 0, 0});
+    sp.accs.push_back(StagedAcc{});
+    return sp;
+}
+
 // The same roots split into `n_groups` independent sub-programs (consecutive runs of roots). All
 // root ops here are additive (ACC), so the groups' outputs simply add; shared DAG nodes are
 // recomputed per group. Used by the multilinear rounds, where the number of evaluation points

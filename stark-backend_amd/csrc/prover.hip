@@ -526,22 +526,48 @@ struct Prover {
         Program prog;
         DevBuf<Instr> code;
         DevBuf<EF> weights;
+        // round-0 programs also carry their staged form (program.h: stage_program)
+        DevBuf<StagedBlock> st_blocks;
+        DevBuf<uint32_t> st_loads;
+        DevBuf<StagedInstr> st_code;
+        DevBuf<StagedAcc> st_accs;
+        DevStaged staged;
         DevProgram dev() const { return DevProgram{code.p, (uint32_t)prog.code.size(), prog.num_slots, weights.p}; }
     };
-    ProgDev make_prog(Program p, const std::vector<EF> &weights) {
+    // staged_rows_for: (log_lifted, n_out) of the round-0 launch when the staged form is wanted
+    ProgDev make_prog(Program p, const std::vector<EF> &weights, bool staged = false, uint32_t log_lifted = 0,
+                      uint32_t n_out = 1) {
         ProgDev d;
         d.code = cx.upload(p.code);
         d.weights = cx.upload(weights);
+        if (staged) {
+            const StagedPlan plan = round0_staged_plan(log_lifted, n_out, p.num_slots);
+            if (plan.rows == 0) {
+                d.prog = std::move(p);
+                return d;
+            }
+            StagedLayout layout;
+            layout.stage_rows = plan.stage_rows;
+            layout.acc_rows = plan.acc_rows;
+            StagedProgram sp = stage_program(p, weights, layout);
+            const uint32_t rows = plan.rows;
+            sp.scale_rows(rows);
+            d.st_blocks = cx.upload(sp.blocks);
+            d.st_loads = cx.upload(sp.loads);
+            d.st_code = cx.upload(sp.code);
+            d.st_accs = cx.upload(sp.accs);
+            d.staged = DevStaged{d.st_blocks.p, d.st_loads.p, d.st_code.p, d.st_accs.p, (uint32_t)sp.blocks.size(), sp.num_rows, rows, layout.stage_rows};
+        }
         d.prog = std::move(p);
         return d;
     }
 
     // Round-0 evaluation through the compiled kernel of the AIR when there is one, else the interpreter.
-    int launch_round0(hipFunction_t fn, const DevProgram &prog, const Fp *lde, uint32_t n_cols_total, uint32_t log_lifted,
+    int launch_round0(hipFunction_t fn, const DevProgram &prog, const DevStaged &staged, const Fp *lde, uint32_t n_cols_total, uint32_t log_lifted,
                       uint32_t l_skip, uint32_t n_cosets, uint32_t n_out, const EF *d_eq, EF add_const, const RedOut &ro,
                       const Fp *d_pvals, uint32_t grid) {
         if (!fn)
-            return round0_eval(prog, lde, n_cols_total, log_lifted, l_skip, n_cosets, n_out, d_eq, add_const, ro, cx.stream);
+            return round0_eval(prog, staged, lde, n_cols_total, log_lifted, l_skip, n_cosets, n_out, d_eq, add_const, ro, cx.stream);
         if (n_cosets == 0) return 0;
         EF *partials = ro.partials;
         const EF *W = prog.weights;
@@ -884,7 +910,7 @@ struct Prover {
             {
                 std::vector<Root> roots = roots_zerocheck(a);
                 tp[t].zc_w = lambda_pows;
-                tp[t].zc = std::make_unique<ProgDev>(make_prog(compile_program(a, v.cm, traces[t].public_values, roots, (uint32_t)lambda_pows.size()), lambda_pows));
+                tp[t].zc = std::make_unique<ProgDev>(make_prog(compile_program(a, v.cm, traces[t].public_values, roots, (uint32_t)lambda_pows.size()), lambda_pows, !(jit_of(t) && jit_of(t)->r0_zerocheck), v.log_lifted, 1));
                 if (v.n_lift > 0)
                     tp[t].zc_g = make_grouped(compile_grouped(a, v.cm, traces[t].public_values, roots, (uint32_t)lambda_pows.size(), MLE_GROUPS));
             }
@@ -898,7 +924,7 @@ struct Prover {
                     tp[t].lg_const += tp[t].eq3b[k] * (beta_pows[it.message.size()] * fp((uint64_t)it.bus_index + 1));
                 }
                 tp[t].lg_w = wts;
-                tp[t].lg = std::make_unique<ProgDev>(make_prog(compile_program(a, v.cm, traces[t].public_values, roots, (uint32_t)wts.size()), wts));
+                tp[t].lg = std::make_unique<ProgDev>(make_prog(compile_program(a, v.cm, traces[t].public_values, roots, (uint32_t)wts.size()), wts, !(jit_of(t) && jit_of(t)->r0_logup), v.log_lifted, 2));
                 if (v.n_lift > 0)
                     tp[t].lg_g = make_grouped(compile_grouped(a, v.cm, traces[t].public_values, roots, (uint32_t)wts.size(), MLE_GROUPS));
             }
@@ -930,7 +956,7 @@ struct Prover {
                 job.zc_partials.alloc(red_blocks * job.zc_cosets * N + 64);
                 job.zc_slot = next_slot;
                 next_slot += (job.zc_cosets * N + 63) & ~size_t(63);
-                OVM_THROW_IF(launch_round0(jit_of(t) ? jit_of(t)->r0_zerocheck : nullptr, tp[t].zc->dev(), job.lde.p,
+                OVM_THROW_IF(launch_round0(jit_of(t) ? jit_of(t)->r0_zerocheck : nullptr, tp[t].zc->dev(), tp[t].zc->staged, job.lde.p,
                                            (uint32_t)v.cm.total, v.log_lifted, l_skip, job.zc_cosets, 1, job.d_eq.p, EF::zero(),
                                            mb.arm(job.zc_partials.p, job.zc_slot), d_pv[t].p, (uint32_t)red_blocks));
             }
@@ -939,7 +965,7 @@ struct Prover {
                 job.lg_partials.alloc(red_blocks * job.lg_cosets * 2 * N + 64);
                 job.lg_slot = next_slot;
                 next_slot += (job.lg_cosets * 2 * N + 63) & ~size_t(63);
-                OVM_THROW_IF(launch_round0(jit_of(t) ? jit_of(t)->r0_logup : nullptr, tp[t].lg->dev(), job.lde.p,
+                OVM_THROW_IF(launch_round0(jit_of(t) ? jit_of(t)->r0_logup : nullptr, tp[t].lg->dev(), tp[t].lg->staged, job.lde.p,
                                            (uint32_t)v.cm.total, v.log_lifted, l_skip, job.lg_cosets, 2, job.d_eq.p, tp[t].lg_const,
                                            mb.arm(job.lg_partials.p, job.lg_slot), d_pv[t].p, (uint32_t)red_blocks));
             }

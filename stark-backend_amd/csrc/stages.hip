@@ -376,36 +376,309 @@ struct LdeFetch {
     __device__ Fp operator()(uint32_t col) const { return base[((uint64_t)col << log_lifted) + p]; }
 };
 
-// The interpreter can evaluate R0_ROWS rows per lane per pass over the program (one instruction
-// decode amortised over R0_ROWS field operations). Measured on MI355X (A/B in one session, config D
-// and the 21-segment reth replay): 2 rows = no difference within +-2 % noise, 4 rows = slower
-// (196 VGPRs, 2 waves per SIMD). So: 1.
-static constexpr int R0_ROWS = 1;
-struct LdeFetchRows {
-    const Fp *base;
-    uint32_t log_lifted;
-    const uint64_t *p;
-    __device__ __forceinline__ Fp operator()(uint32_t col, int r) const { return base[((uint64_t)col << log_lifted) + p[r]]; }
-};
-template <int NS>
-struct InterpRound0 {
-    static constexpr int ROWS = R0_ROWS;
-    DevProgram prog;
-    __device__ __forceinline__ void operator()(const Fp *lde_k, uint32_t log_lifted, const uint64_t (&p)[ROWS],
-                                               EF (&out)[ROWS][2]) const {
-        Fp slots[NS][ROWS];
-        LdeFetchRows fetch{lde_k, log_lifted, p};
-        run_program_acc_rows<ROWS>(prog.code, prog.n_instr, prog.weights, slots, fetch, out);
+// The interpreter evaluates ROWS rows per lane per pass over the program: decode, branches and
+// scalar work (the larger part of the issue slots, see below) are paid once per ROWS field
+// operations. round0_eval picks ROWS from the trace height so the grid still fills the chip.
+// What bounds the interpreter (SQ counters on the Keccak-shaped 9.5K-instruction program, 2^20 rows):
+// not memory -- pointing every column operand at 8 cached columns changes nothing -- but issue slots:
+// ~37 scalar and ~30 vector instructions per interpreted instruction, plus 8-way LDS bank conflicts
+// where the compiler had placed the per-lane slot array. Hence:
+//  * one 16-byte scalar load per instruction and shift/mask decoding (no per-field loads);
+//  * blocks of R0_PREFETCH instructions: all column operands of a block are requested, then it runs
+//    (the loads are otherwise serially dependent: decode -> load -> use, one at a time);
+//  * slots in LDS as [slot][row][lane] words (conflict-free) while they fit, else private memory;
+//  * ACC adds raw 62-bit products into 96-bit accumulators (v_mad_u64_u32 + carry) and reduces
+//    once per row instead of four Montgomery reductions and four modular adds per ACC.
+struct Acc96 {
+    uint64_t lo[4];
+    uint32_t hi[4];
+    __device__ __forceinline__ void clear() {
+#pragma unroll
+        for (int k = 0; k < 4; k++) lo[k] = 0, hi[k] = 0;
+    }
+    __device__ __forceinline__ void add(const EF &w, Fp a) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const uint64_t prod = (uint64_t)a.v * w.c[k].v;
+            lo[k] += prod;
+            hi[k] += lo[k] < prod;
+        }
+    }
+    // (hi * 2^64 + lo) * 2^-32 mod P per limb
+    __device__ __forceinline__ EF finish() const {
+        EF r;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            uint32_t xh = (uint32_t)(lo[k] >> 32);
+            xh = bb::umin32(xh, xh - bb::P);  // < 2^32 < 3P: two steps bring it below P
+            xh = bb::umin32(xh, xh - bb::P);
+            const Fp low = Fp::raw(bb::mont_reduce(((uint64_t)xh << 32) | (uint32_t)lo[k]));
+            r.c[k] = low + Fp::raw(hi[k]) * Fp::raw(bb::R2);  // hi < n_instr < P
+        }
+        return r;
     }
 };
-template <int NS>
+
+template <int NS, int R, int NOUT>
+struct InterpRound0 {
+    static constexpr int ROWS = R;
+    static constexpr int PREFETCH = 8 / ROWS;
+    static constexpr bool LDS_SLOTS = NS * ROWS <= 32;  // <= 32 KiB per workgroup
+    DevProgram prog;
+
+    struct Slots {
+        uint32_t *lds;
+        uint32_t priv[LDS_SLOTS ? 1 : NS * ROWS];
+        __device__ __forceinline__ Fp get(uint32_t s, int r) const {
+            if constexpr (LDS_SLOTS) return Fp::raw(lds[(s * ROWS + r) * RED_THREADS]);
+            else return Fp::raw(priv[s * ROWS + r]);
+        }
+        __device__ __forceinline__ void set(uint32_t s, int r, Fp v) {
+            if constexpr (LDS_SLOTS) lds[(s * ROWS + r) * RED_THREADS] = v.v;
+            else priv[s * ROWS + r] = v.v;
+        }
+    };
+    struct Decoded {
+        uint32_t op, ak, bk, acc, dst, a, b;
+        __device__ __forceinline__ explicit Decoded(const uint4 raw)
+            : op(raw.x & 0xff), ak((raw.x >> 8) & 0xff), bk((raw.x >> 16) & 0xff), acc(raw.x >> 24),
+              dst(raw.y & 0xffff), a(raw.z), b(raw.w) {}
+    };
+    static __device__ __forceinline__ Fp operand(uint32_t kind, uint32_t payload, const Slots &slots, int r, Fp col) {
+        return kind == K_COL ? col : kind == K_SLOT ? slots.get(payload, r) : Fp::raw(payload);
+    }
+    static __device__ __forceinline__ void exec(const Decoded &in, const EF *weights, Slots &slots, const Fp (&ca)[ROWS],
+                                                const Fp (&cb)[ROWS], Acc96 (&acc)[ROWS][NOUT]) {
+        Fp a[ROWS];
+#pragma unroll
+        for (int r = 0; r < ROWS; r++) a[r] = operand(in.ak, in.a, slots, r, ca[r]);
+        switch (in.op) {
+            case OP_ADD:
+#pragma unroll
+                for (int r = 0; r < ROWS; r++) slots.set(in.dst, r, a[r] + operand(in.bk, in.b, slots, r, cb[r]));
+                break;
+            case OP_SUB:
+#pragma unroll
+                for (int r = 0; r < ROWS; r++) slots.set(in.dst, r, a[r] - operand(in.bk, in.b, slots, r, cb[r]));
+                break;
+            case OP_MUL:
+#pragma unroll
+                for (int r = 0; r < ROWS; r++) slots.set(in.dst, r, a[r] * operand(in.bk, in.b, slots, r, cb[r]));
+                break;
+            case OP_NEG:
+#pragma unroll
+                for (int r = 0; r < ROWS; r++) slots.set(in.dst, r, -a[r]);
+                break;
+            default: {  // OP_ACC
+                const EF w = weights[in.b];
+                if (NOUT > 1 && in.acc) {
+#pragma unroll
+                    for (int r = 0; r < ROWS; r++) acc[r][NOUT - 1].add(w, a[r]);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < ROWS; r++) acc[r][0].add(w, a[r]);
+                }
+                break;
+            }
+        }
+    }
+    __device__ __forceinline__ void operator()(const Fp *lde_k, uint32_t log_lifted, const uint64_t (&p)[ROWS],
+                                               EF (&out)[ROWS][2]) const {
+        __shared__ uint32_t lds_slots[LDS_SLOTS ? NS * ROWS * RED_THREADS : 1];
+        Slots slots;
+        slots.lds = lds_slots + threadIdx.x;
+        Acc96 acc[ROWS][NOUT];
+#pragma unroll
+        for (int r = 0; r < ROWS; r++)
+#pragma unroll
+            for (int o = 0; o < NOUT; o++) acc[r][o].clear();
+        const uint4 *code = reinterpret_cast<const uint4 *>(prog.code);
+        const uint32_t n_blocked = prog.n_instr - prog.n_instr % PREFETCH;
+        for (uint32_t pc = 0; pc < n_blocked; pc += PREFETCH) {
+            uint4 raw[PREFETCH];
+            Fp ca[PREFETCH][ROWS], cb[PREFETCH][ROWS];
+#pragma unroll
+            for (int d = 0; d < PREFETCH; d++) {
+                raw[d] = code[pc + d];
+                const Decoded in(raw[d]);
+                if (in.ak == K_COL) {
+#pragma unroll
+                    for (int r = 0; r < ROWS; r++) ca[d][r] = lde_k[((uint64_t)in.a << log_lifted) + p[r]];
+                }
+                if (in.bk == K_COL && in.op <= OP_MUL) {
+#pragma unroll
+                    for (int r = 0; r < ROWS; r++) cb[d][r] = lde_k[((uint64_t)in.b << log_lifted) + p[r]];
+                }
+            }
+#pragma unroll
+            for (int d = 0; d < PREFETCH; d++) exec(Decoded(raw[d]), prog.weights, slots, ca[d], cb[d], acc);
+        }
+        for (uint32_t pc = n_blocked; pc < prog.n_instr; pc++) {
+            const Decoded in(code[pc]);
+            Fp ca[ROWS], cb[ROWS];
+#pragma unroll
+            for (int r = 0; r < ROWS; r++) {
+                ca[r] = in.ak == K_COL ? lde_k[((uint64_t)in.a << log_lifted) + p[r]] : Fp::zero();
+                cb[r] = in.bk == K_COL && in.op <= OP_MUL ? lde_k[((uint64_t)in.b << log_lifted) + p[r]] : Fp::zero();
+            }
+            exec(in, prog.weights, slots, ca, cb, acc);
+        }
+#pragma unroll
+        for (int r = 0; r < ROWS; r++) {
+#pragma unroll
+            for (int o = 0; o < NOUT; o++) out[r][o] = out[r][o] + acc[r][o].finish();
+        }
+    }
+};
+template <int NS, int R, int NOUT>
 __global__ __launch_bounds__(RED_THREADS) void round0_eval_kernel(DevProgram prog, const Fp *lde,
                                                                   uint32_t n_cols_total, uint32_t log_lifted,
                                                                   uint32_t l_skip, uint32_t n_cosets,
                                                                   uint32_t n_out, const EF *eq_xi, EF add_const,
                                                                   EF *partials) {
-    round0_eval_body(InterpRound0<NS>{prog}, lde, n_cols_total, log_lifted, l_skip, n_cosets, n_out, eq_xi, add_const,
-                     partials);
+    round0_eval_body(InterpRound0<NS, R, NOUT>{prog}, lde, n_cols_total, log_lifted, l_skip, n_cosets, n_out, eq_xi,
+                     add_const, partials);
+}
+
+// ---- staged round-0 interpreter (program.h: stage_program) -----------------------------------
+// Per block: [bring the block's columns into LDS rows 0..n_loads: LDS-DMA, all in flight together,
+// no VGPR staging] [arithmetic loop: operands are LDS rows, `b` may be an immediate; no
+// accumulators live in this loop's control flow] [accumulation loop: branch-free 96-bit MACs].
+// LDS image of the workgroup: word (row * R + r) * 256 + lane. The program arrays are read through
+// the constant address space so that they stay scalar loads next to the LDS-DMA writes.
+#define OVM_CONST_AS __attribute__((address_space(4)))
+template <int R, int NOUT>
+struct StagedRound0 {
+    static constexpr int ROWS = R;
+    DevStaged prog;
+    const EF *weights;
+
+    // acc += a * w as a 96-bit integer (v_mad_u64_u32 with carry-out, then the carry into the top word)
+    static __device__ __forceinline__ void mac96(uint64_t &lo, uint32_t &hi, uint32_t a, uint32_t w) {
+        asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32_e32 %1, vcc, 0, %1, vcc"
+            : "+v"(lo), "+v"(hi)
+            : "v"(a), "s"(w)
+            : "vcc");
+    }
+    // entries are two 16-byte words: weight, then {row offset, -, -, -}
+    static __device__ __forceinline__ void run_accs(const OVM_CONST_AS uint4 *list, uint32_t n, const uint32_t *mine,
+                                                    Acc96 (&acc)[R]) {
+#if defined(__HIP_DEVICE_COMPILE__)  // (address-space-qualified loads do not parse in the host pass)
+        uint4 w = list[0], e = list[1];  // (the list is padded: reading one entry past the end is fine)
+        for (uint32_t i = n; i != 0; --i) {
+            list += 2;
+            const uint4 w_next = list[0], e_next = list[1];
+            const uint32_t *row = mine + e.x;
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                const uint32_t a = row[r * RED_THREADS];
+                mac96(acc[r].lo[0], acc[r].hi[0], a, w.x);
+                mac96(acc[r].lo[1], acc[r].hi[1], a, w.y);
+                mac96(acc[r].lo[2], acc[r].hi[2], a, w.z);
+                mac96(acc[r].lo[3], acc[r].hi[3], a, w.w);
+            }
+            w = w_next;
+            e = e_next;
+        }
+#endif
+    }
+    static __device__ __forceinline__ void exec(const uint4 in, uint32_t *mine) {
+        const uint32_t op = in.x;  // op | flags, dst, a, b: operand fields are word offsets of LDS rows
+        const uint32_t *arow = mine + in.z;
+        uint32_t *drow = mine + in.y;
+        Fp a[R], b[R];
+#pragma unroll
+        for (int r = 0; r < R; r++) a[r] = Fp::raw(arow[r * RED_THREADS]);
+        if (op & S_B_CONST) {
+#pragma unroll
+            for (int r = 0; r < R; r++) b[r] = Fp::raw(in.w);
+        } else {
+            const uint32_t *brow = mine + in.w;
+#pragma unroll
+            for (int r = 0; r < R; r++) b[r] = Fp::raw(brow[r * RED_THREADS]);
+        }
+#define OVM_STORE(EXPR)                                                                  \
+    {                                                                                    \
+        _Pragma("unroll") for (int r = 0; r < R; r++) drow[r * RED_THREADS] = (EXPR).v; \
+        return;                                                                          \
+    }
+        if (op & S_MUL) OVM_STORE(a[r] * b[r])
+        if (op & S_ADD) OVM_STORE(a[r] + b[r])
+        if (op & S_SUB) OVM_STORE(a[r] - b[r])
+        if (op & S_RSUB) OVM_STORE(b[r] - a[r])
+        if (op & S_NEG) OVM_STORE(-a[r])
+        if (op & S_MOV) OVM_STORE(a[r])
+        OVM_STORE(b[r])  // S_MOVC
+#undef OVM_STORE
+    }
+    __device__ __forceinline__ void operator()(const Fp *lde_k, uint32_t log_lifted, const uint64_t (&p)[R],
+                                               EF (&out)[R][2]) const {
+#if defined(__HIP_DEVICE_COMPILE__)
+        extern __shared__ uint32_t lds_image[];
+        uint32_t *mine = lds_image + threadIdx.x;  // this lane's word of row 0
+        // LDS-DMA destination: wave-uniform base, the hardware adds lane * 4
+        uint32_t *wave_row = lds_image + (__builtin_amdgcn_readfirstlane(threadIdx.x) & ~63u);
+        const OVM_CONST_AS uint4 *blocks = (const OVM_CONST_AS uint4 *)prog.blocks;
+        const OVM_CONST_AS uint32_t *loads = (const OVM_CONST_AS uint32_t *)prog.loads;
+        const OVM_CONST_AS uint4 *code = (const OVM_CONST_AS uint4 *)prog.code;
+        const OVM_CONST_AS uint4 *accs = (const OVM_CONST_AS uint4 *)prog.accs;
+        Acc96 acc0[R], acc1[R];
+#pragma unroll
+        for (int r = 0; r < R; r++) acc0[r].clear(), acc1[r].clear();
+        // LDS-DMA through inline asm: the compiler would otherwise drain every outstanding DMA before
+        // the next LDS read (it cannot tell the two staging buffers apart); the waits are placed by hand.
+        const uint32_t lds_base = (uint32_t)(size_t)(__attribute__((address_space(3))) uint32_t *)lds_image +
+                                  (__builtin_amdgcn_readfirstlane(threadIdx.x) & ~63u) * 4;
+        auto request = [&](uint32_t blk) {
+            const uint4 hd = blocks[2 * blk];
+            uint32_t dst = lds_base + (blk & 1) * prog.stage_rows * (R * RED_THREADS * 4);
+            for (uint32_t j = 0; j < hd.y; j++) {
+                const uint64_t col = loads[hd.x + j];
+#pragma unroll
+                for (int r = 0; r < R; r++) {
+                    const Fp *src = lde_k + (col << log_lifted) + p[r];
+                    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, off"
+                                 :
+                                 : "s"(dst), "v"(src)
+                                 : "memory", "m0");
+                    dst += RED_THREADS * 4;
+                }
+            }
+        };
+        request(0);
+        for (uint32_t blk = 0; blk < prog.n_blocks; blk++) {
+            const uint4 hd = blocks[2 * blk];       // load_off, n_loads, instr_off, n_instr
+            const uint4 hd2 = blocks[2 * blk + 1];  // acc_off, n_acc0, n_acc1
+            __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this block's columns have landed
+            asm volatile("" ::: "memory");
+            if (blk + 1 < prog.n_blocks) request(blk + 1);  // in flight while this block runs
+            // the next instruction is requested before this one runs
+            const OVM_CONST_AS uint4 *ip = code + hd.z;
+            uint4 cur = ip[0];
+            for (uint32_t i = hd.w; i != 0; --i) {
+                ++ip;
+                const uint4 next = *ip;
+                exec(cur, mine);
+                cur = next;
+            }
+            run_accs(accs + 2 * hd2.x, hd2.y, mine, acc0);
+            if (NOUT > 1) run_accs(accs + 2 * (hd2.x + hd2.y), hd2.z, mine, acc1);
+        }
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            out[r][0] = out[r][0] + acc0[r].finish();
+            if (NOUT > 1) out[r][1] = out[r][1] + acc1[r].finish();
+        }
+#endif
+    }
+};
+template <int R, int NOUT>
+__global__ __launch_bounds__(RED_THREADS) void round0_staged_kernel(DevStaged prog, const EF *weights, const Fp *lde,
+                                                                    uint32_t n_cols_total, uint32_t log_lifted,
+                                                                    uint32_t l_skip, uint32_t n_cosets, uint32_t n_out,
+                                                                    const EF *eq_xi, EF add_const, EF *partials) {
+    round0_eval_body(StagedRound0<R, NOUT>{prog, weights}, lde, n_cols_total, log_lifted, l_skip, n_cosets, n_out,
+                     eq_xi, add_const, partials);
 }
 
 #define DISPATCH_SLOTS(NSLOTS, CALL)                      \
@@ -417,20 +690,97 @@ __global__ __launch_bounds__(RED_THREADS) void round0_eval_kernel(DevProgram pro
         else return (int)hipErrorNotSupported;            \
     } while (0)
 
-int round0_eval(const DevProgram &prog, const Fp *lde, uint32_t n_cols_total, uint32_t log_lifted, uint32_t l_skip,
-                uint32_t n_cosets, uint32_t n_out, const EF *d_eq_xi, EF add_const, const RedOut &ro,
-                hipStream_t s) {
+// Rows per lane: as many as leave >= 2^18 lanes (4 waves per SIMD), at most 4 accumulator sets per lane.
+// OVM_R0_ROWS=1|2|4 overrides the choice (parity tests run every variant on small traces).
+static int round0_rows(uint32_t log_lifted, uint32_t n_out) {
+    int rows = log_lifted >= 20 ? 4 : log_lifted == 19 ? 2 : 1;
+    if (const char *e = getenv("OVM_R0_ROWS")) {
+        const int v = atoi(e);
+        if (v == 1 || v == 2 || v == 4) rows = v;
+    }
+    while (rows > 1 && (rows * n_out > 4 || (1ull << log_lifted) / rows < RED_THREADS)) rows >>= 1;
+    return rows;
+}
+
+// Layout policy of the staged interpreter. What it trades: rows per lane R (halves / quarters the
+// scalar work per field operation) against LDS per workgroup (R KiB per LDS row), i.e. resident
+// waves. Measured on the Keccak-shaped program: 4 workgroups per CU (<= 36 KiB of image) with R = 2
+// and the rest of the budget split between the two staging buffers and the accumulation rows.
+StagedPlan round0_staged_plan(uint32_t log_lifted, uint32_t n_out, uint32_t num_slots) {
+    StagedPlan plan;
+    const char *es = getenv("OVM_STAGE_ROWS"), *ea = getenv("OVM_ACC_ROWS");  // (tuning / parity-test overrides)
+    for (int rows = round0_rows(log_lifted, n_out); rows >= 1; rows >>= 1) {
+        const uint32_t first_budget = getenv("OVM_STAGE_KIB") ? (uint32_t)atoi(getenv("OVM_STAGE_KIB")) : 36u;
+        for (uint32_t budget_kib : {first_budget, 60u}) {
+            if (budget_kib > first_budget && rows > 1) continue;  // a larger image only as the last resort
+            const uint32_t budget_rows = budget_kib / (uint32_t)rows;
+            if (budget_rows < num_slots + 6) continue;
+            uint32_t each = (budget_rows - num_slots) / 3;  // 2 staging buffers + accumulation rows
+            if (each > 8) each = 8;
+            plan.rows = (uint32_t)rows;
+            plan.stage_rows = es ? (uint32_t)std::max(2, atoi(es)) : each;
+            plan.acc_rows = ea ? (uint32_t)std::max(1, atoi(ea)) : each;
+            return plan;
+        }
+    }
+    return plan;  // rows == 0: does not fit, use the plain interpreter
+}
+
+int round0_eval(const DevProgram &prog, const DevStaged &staged, const Fp *lde, uint32_t n_cols_total,
+                uint32_t log_lifted, uint32_t l_skip, uint32_t n_cosets, uint32_t n_out, const EF *d_eq_xi,
+                EF add_const, const RedOut &ro, hipStream_t s) {
     if (n_cosets == 0) return 0;
-    if (n_cosets > MAX_COSETS || n_out > 2 || (1u << l_skip) > RED_THREADS) return (int)hipErrorInvalidValue;
-    // every lane gets R0_ROWS live rows whenever the trace is tall enough
-    uint64_t lanes = (1ull << log_lifted) / R0_ROWS;
+    if (n_cosets > MAX_COSETS || n_out < 1 || n_out > 2 || (1u << l_skip) > RED_THREADS)
+        return (int)hipErrorInvalidValue;
+    int rows = round0_rows(log_lifted, n_out);
+    if (staged.blocks) {
+        rows = (int)staged.rows;  // fixed when the program was staged (round0_staged_rows)
+        const size_t lds_bytes = (size_t)staged.num_rows * rows * RED_THREADS * 4;
+        {
+            uint64_t lanes = (1ull << log_lifted) / rows;
+            if (lanes < RED_THREADS) lanes = RED_THREADS;
+            // as many workgroups as are resident at once (LDS-bound), and every lane the same number of passes
+            const uint32_t resident = 256u * (uint32_t)std::max<size_t>(1, std::min<size_t>(8, (160u << 10) / (lds_bytes + (5u << 10))));
+            const uint32_t needed = (uint32_t)((lanes + RED_THREADS - 1) / RED_THREADS);
+            const uint32_t passes = (needed + resident - 1) / resident;
+            const uint32_t grid = (needed + passes - 1) / passes;
+#define LAUNCH(R, NOUT)                                                                                             \
+    hipLaunchKernelGGL((round0_staged_kernel<R, NOUT>), dim3(grid), dim3(RED_THREADS), lds_bytes, s, staged,       \
+                       prog.weights, lde, n_cols_total, log_lifted, l_skip, n_cosets, n_out, d_eq_xi, add_const,  \
+                       ro.partials)
+            if (n_out == 1) {
+                if (rows == 4) LAUNCH(4, 1);
+                else if (rows == 2) LAUNCH(2, 1);
+                else LAUNCH(1, 1);
+            } else {
+                if (rows == 2) LAUNCH(2, 2);
+                else LAUNCH(1, 2);
+            }
+#undef LAUNCH
+            OVM_CHECK_LAUNCH();
+            return sum_partials(ro, grid, n_cosets * n_out << l_skip, s);
+        }
+    }
+    uint64_t lanes = (1ull << log_lifted) / rows;
     if (lanes < RED_THREADS) lanes = RED_THREADS;
     uint32_t grid = red_grid(lanes);
-#define CALL(NS)                                                                                              \
-    hipLaunchKernelGGL(round0_eval_kernel<NS>, dim3(grid), dim3(RED_THREADS), 0, s, prog, lde, n_cols_total, \
-                       log_lifted, l_skip, n_cosets, n_out, d_eq_xi, add_const, ro.partials)
+#define LAUNCH(NS, R, NOUT)                                                                                      \
+    hipLaunchKernelGGL((round0_eval_kernel<NS, R, NOUT>), dim3(grid), dim3(RED_THREADS), 0, s, prog, lde,       \
+                       n_cols_total, log_lifted, l_skip, n_cosets, n_out, d_eq_xi, add_const, ro.partials)
+#define CALL(NS)                                           \
+    do {                                                   \
+        if (n_out == 1) {                                  \
+            if (rows == 4) LAUNCH(NS, 4, 1);               \
+            else if (rows == 2) LAUNCH(NS, 2, 1);          \
+            else LAUNCH(NS, 1, 1);                         \
+        } else {                                           \
+            if (rows == 2) LAUNCH(NS, 2, 2);               \
+            else LAUNCH(NS, 1, 2);                         \
+        }                                                  \
+    } while (0)
     DISPATCH_SLOTS(prog.num_slots, CALL);
 #undef CALL
+#undef LAUNCH
     OVM_CHECK_LAUNCH();
     return sum_partials(ro, grid, n_cosets * n_out << l_skip, s);
 }

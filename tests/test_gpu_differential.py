@@ -67,3 +67,26 @@ def test_internal_like_parameters(dev, pkg, orc):
     h = 1 << 7
     tr = rng.integers(0, airs.P, size=6 * h, dtype=np.uint64).astype(np.uint32)
     _run(dev, pkg, orc, params, [air], [(0, tr, h, [])])
+
+
+@pytest.mark.parametrize("stage,acc,rows", [(2, 1, 1), (2, 1, 4), (3, 2, 2), (4, 8, 1), (8, 3, 2), (5, 5, 4)])
+@pytest.mark.parametrize("seed", range(4))
+def test_staged_interpreter_layouts(dev, pkg, orc, monkeypatch, stage, acc, rows, seed):
+    """The round-0 staged interpreter (program.h stage_program, stages.hip StagedRound0) under forced
+    layouts: tiny staging buffers and accumulation lists (a block boundary every instruction or two),
+    1 / 2 / 4 trace rows per lane. Wider AIRs with more constraints than the cases above so that
+    programs span many blocks."""
+    monkeypatch.setenv("OVM_JIT", "0")
+    monkeypatch.setenv("OVM_STAGE_ROWS", str(stage))
+    monkeypatch.setenv("OVM_ACC_ROWS", str(acc))
+    monkeypatch.setenv("OVM_R0_ROWS", str(rows))
+    rng = np.random.default_rng(3000 + seed)
+    l_skip = int(rng.integers(2, 5))
+    log_h = int(rng.integers(l_skip, 11))
+    params = airs.test_params(l_skip=l_skip, n_stack=max(8, log_h + 1 - l_skip), k_whir=2)
+    width = int(rng.integers(6, 24))
+    air = airs.random_air(rng, width, int(rng.integers(10, 40)), int(rng.integers(1, 4)), num_public_values=2)
+    h = 1 << log_h
+    tr = rng.integers(0, airs.P, size=width * h, dtype=np.uint64).astype(np.uint32)
+    pvs = [int(x) for x in rng.integers(0, airs.P, size=2)]
+    _run(dev, pkg, orc, params, [air], [(0, tr, h, pvs)])
