@@ -71,7 +71,8 @@ int fold_mle(const EF *in, EF *out, uint32_t n_cols, uint32_t log_h, EF r, hipSt
 int eq_heap(const EF *d_point, uint32_t n, EFPlanes heap, hipStream_t s);
 // p_base: leaf numerators are base-field, only limb plane 0 of P is written / read (stages.hip)
 int gkr_fill_leaves(FracPlanes leaves, uint64_t n, EF alpha, bool p_base, hipStream_t s);
-int gkr_eval_leaves(const DevProgram &prog, const EF *d_leaf_const, const ColDesc *d_cols, uint32_t log_height,
+// `staged` (optional): the DEN/LEAF program in staged form, laid out for one row per lane
+int gkr_eval_leaves(const DevProgram &prog, const DevStaged &staged, const EF *d_leaf_const, const ColDesc *d_cols, uint32_t log_height,
                     const uint64_t *d_leaf_base, const uint32_t *d_leaf_log_len, Fp norm, FracPlanes leaves,
                     hipStream_t s);
 int gkr_build_layer(FracPlanes child, FracPlanes parent, uint64_t n_parent, bool child_p_base, hipStream_t s);

@@ -296,7 +296,10 @@ struct StagedAcc {  // 32 bytes: one scalar load brings the weight and the row
 
 struct StagedBlock {
     uint32_t load_off, n_loads, instr_off, n_instr;
-    uint32_t acc_off, n_acc0, n_acc1, pad;  // entries of output 0 first, then output 1
+    // ACC programs: entries of output 0 first, then output 1; leaf = 0.
+    // DEN/LEAF programs (LogUp-GKR leaves): n_acc1 = row of the leaf's numerator, leaf = interaction
+    // index + 1 when the block ends with that interaction's LEAF (at most one per block).
+    uint32_t acc_off, n_acc0, n_acc1, leaf;
 };
 struct StagedProgram {
     std::vector<StagedBlock> blocks;
@@ -313,6 +316,8 @@ struct StagedProgram {
             if (!(in.op & S_B_CONST)) in.b *= k;
         }
         for (auto &e : accs) e.row *= k;
+        for (auto &b : blocks)
+            if (b.leaf) b.n_acc1 *= k;
     }
 };
 
@@ -328,7 +333,7 @@ inline StagedProgram stage_program(const Program &p, const std::vector<FpExt> &w
         for (size_t i = p.code.size(); i-- > 0;) {
             const Instr &in = p.code[i];
             const bool binary = in.op == OP_ADD || in.op == OP_SUB || in.op == OP_MUL;
-            if (in.op != OP_ACC) read_later[in.dst] = 0;  // (reads of this instruction are marked below)
+            if (in.op < OP_ACC) read_later[in.dst] = 0;  // (reads of this instruction are marked below)
             if (in.ak == K_SLOT) {
                 dead_after[i] = !read_later[in.a];
                 read_later[in.a] = 1;
@@ -341,12 +346,12 @@ inline StagedProgram stage_program(const Program &p, const std::vector<FpExt> &w
     StagedBlock blk{};
     size_t blk_first_instr = 0;
     auto flush = [&] {
-        if (blk.n_instr == 0 && cur_cols.empty() && acc0.empty() && acc1.empty()) return;
+        if (blk.n_instr == 0 && cur_cols.empty() && acc0.empty() && acc1.empty() && !blk.leaf) return;
         blk.n_loads = (uint32_t)cur_cols.size();
         sp.loads.insert(sp.loads.end(), cur_cols.begin(), cur_cols.end());
         blk.acc_off = (uint32_t)sp.accs.size();
         blk.n_acc0 = (uint32_t)acc0.size();
-        blk.n_acc1 = (uint32_t)acc1.size();
+        if (!blk.leaf) blk.n_acc1 = (uint32_t)acc1.size();  // (a leaf block keeps its numerator row there)
         sp.accs.insert(sp.accs.end(), acc0.begin(), acc0.end());
         sp.accs.insert(sp.accs.end(), acc1.begin(), acc1.end());
         sp.blocks.push_back(blk);
@@ -370,7 +375,7 @@ inline StagedProgram stage_program(const Program &p, const std::vector<FpExt> &w
     for (size_t idx = 0; idx < p.code.size(); idx++) {
         const Instr &in = p.code[idx];
         const bool binary = in.op == OP_ADD || in.op == OP_SUB || in.op == OP_MUL;
-        if (in.op > OP_ACC) throw OvmFail(1, "stage_program: not an ACC program");
+        const bool accumulates = in.op == OP_ACC || in.op == OP_DEN || in.op == OP_LEAF;
         // columns this instruction needs that the open block has not staged yet
         auto needs = [&](uint32_t (&need)[2]) {
             int n = 0;
@@ -380,7 +385,7 @@ inline StagedProgram stage_program(const Program &p, const std::vector<FpExt> &w
         };
         uint32_t need[2];
         int n_need = needs(need);
-        if (cur_cols.size() + n_need > STAGE_ROWS || (in.op == OP_ACC && acc0.size() + acc1.size() == ACC_ROWS)) {
+        if (cur_cols.size() + n_need > STAGE_ROWS || (accumulates && acc0.size() + acc1.size() == ACC_ROWS)) {
             flush();
             n_need = needs(need);
         }
@@ -404,8 +409,17 @@ inline StagedProgram stage_program(const Program &p, const std::vector<FpExt> &w
         };
         const Opnd a = opnd(in.ak, in.a);
         const uint32_t dst = SLOT_ROW0 + in.dst;
-        if (in.op == OP_ACC) {
-            std::vector<StagedAcc> &list = in.acc ? acc1 : acc0;
+        if (in.op == OP_LEAF) {  // numerator = a; closes the interaction's denominator sum
+            uint32_t row = a.v;
+            if (a.is_const) {
+                row = layout.acc_row0() + (uint32_t)acc0.size();
+                emit(S_MOVC | S_B_CONST, row, 0, a.v);
+            }
+            blk.n_acc1 = row;
+            blk.leaf = in.b + 1;
+            flush();
+        } else if (accumulates) {
+            std::vector<StagedAcc> &list = (in.op == OP_ACC && in.acc) ? acc1 : acc0;
             const uint32_t acc_row = layout.acc_row0() + (uint32_t)(acc0.size() + acc1.size());
             if (in.ak == K_COL) {
                 list.push_back(acc_entry(a.v, in.b));  // a staging row stays put until the block ends

@@ -720,8 +720,9 @@ struct Prover {
                     void *args[] = {&cols, &lh, &lb, &ll, &norm, &lv, &W, &LC, &PV};
                     OVM_THROW_IF(hipModuleLaunchKernel(jk->leaves, ceil_div(1ull << lh, 256), 1, 1, 256, 1, 1, 0, cx.stream, args, nullptr));
                 } else {
-                    ProgDev pd = make_prog(compile_program(a, tv[t].cm, traces[t].public_values, roots, (uint32_t)beta_pows.size()), beta_pows);
-                    OVM_THROW_IF(gkr_eval_leaves(pd.dev(), d_lc.p, tv[t].cols.p, tv[t].log_height, d_lb.p, d_ll.p, norm,
+                    // staged for one row per lane (log_lifted 0 selects that plan)
+                    ProgDev pd = make_prog(compile_program(a, tv[t].cm, traces[t].public_values, roots, (uint32_t)beta_pows.size()), beta_pows, true, 0, 1);
+                    OVM_THROW_IF(gkr_eval_leaves(pd.dev(), pd.staged, d_lc.p, tv[t].cols.p, tv[t].log_height, d_lb.p, d_ll.p, norm,
                                                  tree.at(n_leaves), cx.stream));
                 }
                 // no synchronisation: the temporaries go back to the block cache and are only ever reused

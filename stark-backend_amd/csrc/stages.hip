@@ -547,11 +547,8 @@ __global__ __launch_bounds__(RED_THREADS) void round0_eval_kernel(DevProgram pro
 // LDS image of the workgroup: word (row * R + r) * 256 + lane. The program arrays are read through
 // the constant address space so that they stay scalar loads next to the LDS-DMA writes.
 #define OVM_CONST_AS __attribute__((address_space(4)))
-template <int R, int NOUT>
-struct StagedRound0 {
-    static constexpr int ROWS = R;
-    DevStaged prog;
-    const EF *weights;
+template <int R>
+struct StagedVM {
 
     // acc += a * w as a 96-bit integer (v_mad_u64_u32 with carry-out, then the carry into the top word)
     static __device__ __forceinline__ void mac96(uint64_t &lo, uint32_t &hi, uint32_t a, uint32_t w) {
@@ -611,35 +608,31 @@ struct StagedRound0 {
         OVM_STORE(b[r])  // S_MOVC
 #undef OVM_STORE
     }
-    __device__ __forceinline__ void operator()(const Fp *lde_k, uint32_t log_lifted, const uint64_t (&p)[R],
-                                               EF (&out)[R][2]) const {
+    // Runs every block. src(col, r) = address of the lane's r-th cell of column `col`;
+    // after(blk, acc_off, n_acc0, n_acc1 / tag) runs once the block's arithmetic is done.
+    template <class Src, class After>
+    static __device__ __forceinline__ void run(const DevStaged &prog, uint32_t *lds_image, const Src &src, After &&after) {
 #if defined(__HIP_DEVICE_COMPILE__)
-        extern __shared__ uint32_t lds_image[];
         uint32_t *mine = lds_image + threadIdx.x;  // this lane's word of row 0
-        // LDS-DMA destination: wave-uniform base, the hardware adds lane * 4
-        uint32_t *wave_row = lds_image + (__builtin_amdgcn_readfirstlane(threadIdx.x) & ~63u);
         const OVM_CONST_AS uint4 *blocks = (const OVM_CONST_AS uint4 *)prog.blocks;
         const OVM_CONST_AS uint32_t *loads = (const OVM_CONST_AS uint32_t *)prog.loads;
         const OVM_CONST_AS uint4 *code = (const OVM_CONST_AS uint4 *)prog.code;
-        const OVM_CONST_AS uint4 *accs = (const OVM_CONST_AS uint4 *)prog.accs;
-        Acc96 acc0[R], acc1[R];
-#pragma unroll
-        for (int r = 0; r < R; r++) acc0[r].clear(), acc1[r].clear();
         // LDS-DMA through inline asm: the compiler would otherwise drain every outstanding DMA before
         // the next LDS read (it cannot tell the two staging buffers apart); the waits are placed by hand.
+        // Destination: wave-uniform base in M0, the hardware adds lane * 4.
         const uint32_t lds_base = (uint32_t)(size_t)(__attribute__((address_space(3))) uint32_t *)lds_image +
                                   (__builtin_amdgcn_readfirstlane(threadIdx.x) & ~63u) * 4;
         auto request = [&](uint32_t blk) {
             const uint4 hd = blocks[2 * blk];
             uint32_t dst = lds_base + (blk & 1) * prog.stage_rows * (R * RED_THREADS * 4);
             for (uint32_t j = 0; j < hd.y; j++) {
-                const uint64_t col = loads[hd.x + j];
+                const uint32_t col = loads[hd.x + j];
 #pragma unroll
                 for (int r = 0; r < R; r++) {
-                    const Fp *src = lde_k + (col << log_lifted) + p[r];
+                    const Fp *cell = src(col, r);
                     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, off"
                                  :
-                                 : "s"(dst), "v"(src)
+                                 : "s"(dst), "v"(cell)
                                  : "memory", "m0");
                     dst += RED_THREADS * 4;
                 }
@@ -648,7 +641,7 @@ struct StagedRound0 {
         request(0);
         for (uint32_t blk = 0; blk < prog.n_blocks; blk++) {
             const uint4 hd = blocks[2 * blk];       // load_off, n_loads, instr_off, n_instr
-            const uint4 hd2 = blocks[2 * blk + 1];  // acc_off, n_acc0, n_acc1
+            const uint4 hd2 = blocks[2 * blk + 1];  // acc_off, n_acc0, n_acc1, tag
             __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this block's columns have landed
             asm volatile("" ::: "memory");
             if (blk + 1 < prog.n_blocks) request(blk + 1);  // in flight while this block runs
@@ -661,9 +654,31 @@ struct StagedRound0 {
                 exec(cur, mine);
                 cur = next;
             }
-            run_accs(accs + 2 * hd2.x, hd2.y, mine, acc0);
-            if (NOUT > 1) run_accs(accs + 2 * (hd2.x + hd2.y), hd2.z, mine, acc1);
+            after(hd2);
         }
+#endif
+    }
+};
+
+template <int R, int NOUT>
+struct StagedRound0 {
+    static constexpr int ROWS = R;
+    DevStaged prog;
+    __device__ __forceinline__ void operator()(const Fp *lde_k, uint32_t log_lifted, const uint64_t (&p)[R],
+                                               EF (&out)[R][2]) const {
+#if defined(__HIP_DEVICE_COMPILE__)
+        extern __shared__ uint32_t lds_image[];
+        const uint32_t *mine = lds_image + threadIdx.x;
+        const OVM_CONST_AS uint4 *accs = (const OVM_CONST_AS uint4 *)prog.accs;
+        Acc96 acc0[R], acc1[R];
+#pragma unroll
+        for (int r = 0; r < R; r++) acc0[r].clear(), acc1[r].clear();
+        StagedVM<R>::run(
+            prog, lds_image, [&](uint32_t col, int r) { return lde_k + ((uint64_t)col << log_lifted) + p[r]; },
+            [&](const uint4 hd2) {
+                StagedVM<R>::run_accs(accs + 2 * hd2.x, hd2.y, mine, acc0);
+                if (NOUT > 1) StagedVM<R>::run_accs(accs + 2 * (hd2.x + hd2.y), hd2.z, mine, acc1);
+            });
 #pragma unroll
         for (int r = 0; r < R; r++) {
             out[r][0] = out[r][0] + acc0[r].finish();
@@ -677,7 +692,7 @@ __global__ __launch_bounds__(RED_THREADS) void round0_staged_kernel(DevStaged pr
                                                                     uint32_t n_cols_total, uint32_t log_lifted,
                                                                     uint32_t l_skip, uint32_t n_cosets, uint32_t n_out,
                                                                     const EF *eq_xi, EF add_const, EF *partials) {
-    round0_eval_body(StagedRound0<R, NOUT>{prog, weights}, lde, n_cols_total, log_lifted, l_skip, n_cosets, n_out,
+    round0_eval_body(StagedRound0<R, NOUT>{prog}, lde, n_cols_total, log_lifted, l_skip, n_cosets, n_out,
                      eq_xi, add_const, partials);
 }
 
@@ -999,10 +1014,55 @@ __global__ void gkr_leaves_kernel(DevProgram prog, const EF *leaf_const, const C
                                   FracPlanes leaves) {
     gkr_leaves_body(InterpLeaves<NS>{prog, leaf_const}, cols, log_height, leaf_base, leaf_log_len, norm, leaves);
 }
-int gkr_eval_leaves(const DevProgram &prog, const EF *d_leaf_const, const ColDesc *d_cols, uint32_t log_height,
-                    const uint64_t *d_leaf_base, const uint32_t *d_leaf_log_len, Fp norm, FracPlanes leaves,
-                    hipStream_t s) {
+// Staged form (program.h: stage_program on the DEN/LEAF program): a block's DENs are its
+// accumulation list; a block that ends an interaction carries the LEAF (numerator row, index).
+__global__ __launch_bounds__(256) void gkr_leaves_staged_kernel(DevStaged prog, const EF *leaf_const,
+                                                                const ColDesc *cols, uint32_t log_height,
+                                                                const uint64_t *leaf_base, const uint32_t *leaf_log_len,
+                                                                Fp norm, FracPlanes leaves) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    extern __shared__ uint32_t lds_image[];
+    const uint64_t row = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = row < (1ull << log_height);
+    const uint64_t at = live ? row : 0;  // (dead lanes of a short trace still feed the wave's LDS-DMA)
+    const uint32_t *mine = lds_image + threadIdx.x;
+    const OVM_CONST_AS uint4 *accs = (const OVM_CONST_AS uint4 *)prog.accs;
+    const OVM_CONST_AS uint4 *descs = (const OVM_CONST_AS uint4 *)cols;  // {ptr lo, ptr hi, log_height, rot}
+    static_assert(sizeof(ColDesc) == 16, "ColDesc is read as one 16-byte scalar load");
+    const LeafEmit emit{leaves, leaf_base, leaf_log_len, log_height, row, norm};
+    Acc96 acc[1];
+    acc[0].clear();
+    StagedVM<1>::run(
+        prog, lds_image,
+        [&](uint32_t col, int) {
+            const uint4 d = descs[col];
+            const Fp *ptr = (const Fp *)(((uint64_t)d.y << 32) | d.x);
+            return ptr + ((at + d.w) & ((1ull << d.z) - 1));
+        },
+        [&](const uint4 hd2) {
+            StagedVM<1>::run_accs(accs + 2 * hd2.x, hd2.y, mine, acc);
+            if (hd2.w) {
+                const uint32_t k = hd2.w - 1;
+                const EF den = acc[0].finish() + ld_ef(leaf_const + k);
+                const Fp numer = Fp::raw(mine[hd2.z]);
+                if (live) emit(k, numer, den);
+                acc[0].clear();
+            }
+        });
+#endif
+}
+
+int gkr_eval_leaves(const DevProgram &prog, const DevStaged &staged, const EF *d_leaf_const, const ColDesc *d_cols,
+                    uint32_t log_height, const uint64_t *d_leaf_base, const uint32_t *d_leaf_log_len, Fp norm,
+                    FracPlanes leaves, hipStream_t s) {
     uint32_t grid = ceil_div(1ull << log_height, 256);
+    if (staged.blocks) {
+        const size_t lds_bytes = (size_t)staged.num_rows * RED_THREADS * 4;
+        hipLaunchKernelGGL(gkr_leaves_staged_kernel, dim3(grid), dim3(256), lds_bytes, s, staged, d_leaf_const, d_cols,
+                           log_height, d_leaf_base, d_leaf_log_len, norm, leaves);
+        OVM_CHECK_LAUNCH();
+        return 0;
+    }
 #define CALL(NS)                                                                                           \
     hipLaunchKernelGGL(gkr_leaves_kernel<NS>, dim3(grid), dim3(256), 0, s, prog, d_leaf_const, d_cols, log_height, \
                        d_leaf_base, d_leaf_log_len, norm, leaves)
