@@ -526,38 +526,42 @@ struct Prover {
         Program prog;
         DevBuf<Instr> code;
         DevBuf<EF> weights;
-        // round-0 programs also carry their staged form (program.h: stage_program)
-        DevBuf<StagedBlock> st_blocks;
-        DevBuf<uint32_t> st_loads;
-        DevBuf<StagedInstr> st_code;
-        DevBuf<StagedAcc> st_accs;
+        // round-0 and leaf programs also carry their staged form (program.h: stage_program), one
+        // device buffer: [blocks | accs | code | loads]
+        DevBuf<uint32_t> st_words;
         DevStaged staged;
         DevProgram dev() const { return DevProgram{code.p, (uint32_t)prog.code.size(), prog.num_slots, weights.p}; }
     };
-    // staged_rows_for: (log_lifted, n_out) of the round-0 launch when the staged form is wanted
+    // staged: also build the staged form, laid out for the round-0 launch on 2^log_lifted rows with
+    // n_out outputs (log_lifted 0: one row per lane, the leaves kernel). The plain code is then only
+    // uploaded if staging does not fit.
     ProgDev make_prog(Program p, const std::vector<EF> &weights, bool staged = false, uint32_t log_lifted = 0,
                       uint32_t n_out = 1) {
         ProgDev d;
-        d.code = cx.upload(p.code);
         d.weights = cx.upload(weights);
-        if (staged) {
-            const StagedPlan plan = round0_staged_plan(log_lifted, n_out, p.num_slots);
-            if (plan.rows == 0) {
-                d.prog = std::move(p);
-                return d;
-            }
-            StagedLayout layout;
-            layout.stage_rows = plan.stage_rows;
-            layout.acc_rows = plan.acc_rows;
-            StagedProgram sp = stage_program(p, weights, layout);
-            const uint32_t rows = plan.rows;
-            sp.scale_rows(rows);
-            d.st_blocks = cx.upload(sp.blocks);
-            d.st_loads = cx.upload(sp.loads);
-            d.st_code = cx.upload(sp.code);
-            d.st_accs = cx.upload(sp.accs);
-            d.staged = DevStaged{d.st_blocks.p, d.st_loads.p, d.st_code.p, d.st_accs.p, (uint32_t)sp.blocks.size(), sp.num_rows, rows, layout.stage_rows};
+        const StagedPlan plan = staged ? round0_staged_plan(log_lifted, n_out, p.num_slots) : StagedPlan();
+        if (plan.rows == 0) {
+            d.code = cx.upload(p.code);
+            d.prog = std::move(p);
+            return d;
         }
+        StagedLayout layout;
+        layout.stage_rows = plan.stage_rows;
+        layout.acc_rows = plan.acc_rows;
+        StagedProgram sp = stage_program(p, weights, layout);
+        sp.scale_rows(plan.rows);
+        static_assert(sizeof(StagedBlock) == 32 && sizeof(StagedAcc) == 32 && sizeof(StagedInstr) == 16, "staged layout");
+        const size_t w_blocks = sp.blocks.size() * 8, w_accs = sp.accs.size() * 8, w_code = sp.code.size() * 4;
+        std::vector<uint32_t> words(w_blocks + w_accs + w_code + sp.loads.size());
+        memcpy(words.data(), sp.blocks.data(), w_blocks * 4);
+        memcpy(words.data() + w_blocks, sp.accs.data(), w_accs * 4);
+        memcpy(words.data() + w_blocks + w_accs, sp.code.data(), w_code * 4);
+        memcpy(words.data() + w_blocks + w_accs + w_code, sp.loads.data(), sp.loads.size() * 4);
+        d.st_words = cx.upload(words);
+        const uint32_t *base = d.st_words.p;
+        d.staged = DevStaged{(const StagedBlock *)base, base + w_blocks + w_accs + w_code,
+                             (const StagedInstr *)(base + w_blocks + w_accs), (const StagedAcc *)(base + w_blocks),
+                             (uint32_t)sp.blocks.size(), sp.num_rows, plan.rows, layout.stage_rows};
         d.prog = std::move(p);
         return d;
     }
