@@ -62,8 +62,38 @@ int mle_round_eval_grouped(const Instr *d_code, const uint32_t *d_off, uint32_t 
                            const EF *d_weights, const EF *mats, uint32_t log_h, uint32_t degree, uint32_t n_out,
                            const EF *d_eq, EF add_const, const RedOut &ro, hipStream_t s);
 
+// The same for many (trace, program) jobs in ONE launch: the late rounds of a many-AIR proof are
+// dozens of launches of a handful of workgroups each, serialised by the stream; batched they run
+// side by side. blockIdx.z enumerates (job, group); job j's last workgroup sums its records into
+// job.out (a mailbox slot), the last job to finish raises ro.flag. d_counters: n_jobs + 1 words,
+// zero on entry, zero again on exit.
+struct MleJob {
+    const Instr *code;
+    const uint32_t *off;
+    const EF *weights;
+    const EF *mats;
+    const EF *eq;
+    EF *partials;
+    EF *out;
+    EF add_const;
+    uint32_t log_h, n_out, n_groups, gx;
+    uint32_t z0, max_slots, pad[2];
+};
+int mle_round_eval_batched(const MleJob *d_jobs, const MleJob *h_jobs, uint32_t n_jobs, uint32_t degree,
+                           uint32_t *d_counters, const RedOut &ro, hipStream_t s);
+// workgroups along y that mle_round_eval_grouped / _batched use for 2^(log_h-1) pairs and this many groups
+uint32_t mle_round_gx(uint32_t log_h, uint32_t degree, uint32_t n_groups);
+
 // out[c * h/2 + y] = in[c*h + 2y] + r * (in[c*h + 2y + 1] - in[c*h + 2y])
 int fold_mle(const EF *in, EF *out, uint32_t n_cols, uint32_t log_h, EF r, hipStream_t s);
+
+// fold_mle for many small matrices in one launch (blockIdx.y enumerates (job, column))
+struct FoldJob {
+    const EF *in;
+    EF *out;
+    uint32_t n_cols, log_h, y0, pad;
+};
+int fold_mle_batched(const FoldJob *d_jobs, const FoldJob *h_jobs, uint32_t n_jobs, EF r, hipStream_t s);
 
 // ---- LogUp GKR ----  (layer format: record x = fractions 2x, 2x+1 = (p0,q0),(p1,q1))
 // heap[2^k + y] = eq(point[n-k .. n), y) for k = 0 .. n-1 (2^n entries, node 1 = 1): the weights of

@@ -182,6 +182,11 @@ struct Mailbox {
         ++seq;
         return RedOut{partials, d_counter, d->data + slot, &d->flag, seq};
     }
+    // device address of result slot `slot` (for kernels that finish several reductions, see mle_round_eval_batched)
+    EF *slot_ptr(size_t slot) const {
+        if (slot + 64 > SLOTS) throw OvmFail((int)hipErrorInvalidValue, "mailbox: slot out of range");
+        return d->data + slot;
+    }
     // Wait for the reduction armed last and copy out its first n results.
     std::vector<EF> take(size_t n, hipStream_t s) {
         wait(s);
@@ -855,6 +860,8 @@ struct Prover {
             DevBuf<Instr> code;
             DevBuf<uint32_t> off;
         };
+        // (splitting the roots of the short rounds four times finer -- 64 groups -- was measured slower:
+        // batched kernel 174 -> 210 ms over the 21-segment replay sample; per-workgroup overhead dominates)
         static constexpr uint32_t MLE_GROUPS = 16;
         auto make_grouped = [&](GroupedProgram gp) {
             auto g = std::make_unique<GroupedDev>();
@@ -1134,6 +1141,11 @@ struct Prover {
             if (!air(t).interactions.empty()) mle_partials[2 * t + 1].alloc(rec);
         }
         if (16 * T + 64 > Mailbox::SLOTS) throw OvmFail(801, "too many traces for the MLE-round mailbox");
+        // Jobs of at most MLE_BATCH_MAX_WGS workgroups go into one launch per round (the late rounds
+        // of a many-AIR proof are otherwise dozens of tiny launches serialised by the stream).
+        static constexpr uint32_t MLE_BATCH_MAX_WGS = 256;
+        DevBuf<uint32_t> mle_counters(2 * T + 1);
+        OVM_THROW_IF(hipMemsetAsync(mle_counters.p, 0, (2 * T + 1) * sizeof(uint32_t), cx.stream));
         OVM_PROF("constraints.mle_rounds", cx.stream);
         for (unsigned round = 1; round <= n_max; round++) {
             EF r_prev = r[round - 1];
@@ -1141,6 +1153,24 @@ struct Prover {
             // phase A: enqueue the round sums of every trace that still has rows to fold
             std::vector<char> eq_done(n_max + 1, 0);
             bool any_launch = false;
+            std::vector<MleJob> jobs;
+            auto enqueue = [&](const GroupedDev &gd, const EF *weights, const EF *mats, unsigned log_h, uint32_t n_out,
+                               const EF *eq, EF add_const, EF *partials, size_t slot) {
+                const uint32_t n_groups = (uint32_t)gd.gp.off.size() - 1;
+                const uint32_t gx = mle_round_gx(log_h, cdeg_global, n_groups);
+                if (gx * cdeg_global * n_groups <= MLE_BATCH_MAX_WGS) {
+                    MleJob j{};
+                    j.code = gd.code.p, j.off = gd.off.p, j.weights = weights, j.mats = mats, j.eq = eq;
+                    j.partials = partials, j.out = mb.slot_ptr(slot), j.add_const = add_const;
+                    j.log_h = log_h, j.n_out = n_out, j.n_groups = n_groups, j.gx = gx;
+                    j.z0 = jobs.empty() ? 0 : jobs.back().z0 + jobs.back().n_groups;
+                    j.max_slots = gd.gp.max_slots;
+                    jobs.push_back(j);
+                } else {
+                    OVM_THROW_IF(mle_round_eval_grouped(gd.code.p, gd.off.p, n_groups, gd.gp.max_slots, weights, mats, log_h,
+                                                        cdeg_global, n_out, eq, add_const, mb.arm(partials, slot), cx.stream));
+                }
+            };
             for (size_t t = 0; t < T; t++) {
                 TraceView &v = tv[t];
                 if (round > v.n_lift) continue;
@@ -1153,19 +1183,16 @@ struct Prover {
                     eq_done[v.n_lift] = 1;
                 }
                 const EF *mats = v.mats_in_a ? v.mats_a.p : v.mats_b.p;
-                {
-                    const GroupedDev &gd = *tp[t].zc_g;
-                    OVM_THROW_IF(mle_round_eval_grouped(gd.code.p, gd.off.p, (uint32_t)gd.gp.off.size() - 1, gd.gp.max_slots,
-                                                        tp[t].zc->weights.p, mats, v.cur_log_h, cdeg_global, 1, d_eqr.p,
-                                                        EF::zero(), mb.arm(mle_partials[2 * t].p, 16 * t), cx.stream));
-                }
-                if (has_int) {
-                    const GroupedDev &gd = *tp[t].lg_g;
-                    OVM_THROW_IF(mle_round_eval_grouped(gd.code.p, gd.off.p, (uint32_t)gd.gp.off.size() - 1, gd.gp.max_slots,
-                                                        tp[t].lg->weights.p, mats, v.cur_log_h, cdeg_global, 2, d_eqr.p,
-                                                        tp[t].lg_const, mb.arm(mle_partials[2 * t + 1].p, 16 * t + 8), cx.stream));
-                }
+                enqueue(*tp[t].zc_g, tp[t].zc->weights.p, mats, v.cur_log_h, 1, d_eqr.p, EF::zero(), mle_partials[2 * t].p, 16 * t);
+                if (has_int)
+                    enqueue(*tp[t].lg_g, tp[t].lg->weights.p, mats, v.cur_log_h, 2, d_eqr.p, tp[t].lg_const,
+                            mle_partials[2 * t + 1].p, 16 * t + 8);
                 any_launch = true;
+            }
+            if (!jobs.empty()) {  // armed last: its flag means every reduction of the round is done
+                auto d_jobs = cx.upload(jobs);
+                OVM_THROW_IF(mle_round_eval_batched(d_jobs.p, jobs.data(), (uint32_t)jobs.size(), cdeg_global, mle_counters.p,
+                                                    mb.arm(nullptr, 0), cx.stream));
             }
             if (any_launch) mb.wait(cx.stream);
             // phase B: host
@@ -1249,15 +1276,36 @@ struct Prover {
             EF rr = ts.sample_ext();
             r.push_back(rr);
             prev_s = horner(coeffs, rr);
-            for (size_t t = 0; t < T; t++) {
-                TraceView &v = tv[t];
-                if (v.cur_log_h == 0) continue;
-                const EF *in = v.mats_in_a ? v.mats_a.p : v.mats_b.p;
-                EF *o = v.mats_in_a ? v.mats_b.p : v.mats_a.p;
-                OVM_THROW_IF(fold_mle(in, o, (uint32_t)v.cm.total, v.cur_log_h, rr, cx.stream));
-                v.mats_in_a = !v.mats_in_a;
-                v.cur_log_h--;
-                if (v.cur_log_h == 0) v.final_row = cx.download(o, v.cm.total);
+            {
+                // matrices of at most 2^11 rows fold in one launch per round (as many as fit its grid)
+                std::vector<FoldJob> fj;
+                auto flush_folds = [&] {
+                    if (fj.empty()) return;
+                    auto d_fj = cx.upload(fj);
+                    OVM_THROW_IF(fold_mle_batched(d_fj.p, fj.data(), (uint32_t)fj.size(), rr, cx.stream));
+                    fj.clear();
+                };
+                for (size_t t = 0; t < T; t++) {
+                    TraceView &v = tv[t];
+                    if (v.cur_log_h == 0 || v.cm.total == 0) continue;
+                    const EF *in = v.mats_in_a ? v.mats_a.p : v.mats_b.p;
+                    EF *o = v.mats_in_a ? v.mats_b.p : v.mats_a.p;
+                    if (v.cur_log_h <= 11 && v.cm.total <= 32768) {
+                        const uint32_t y0 = fj.empty() ? 0 : fj.back().y0 + fj.back().n_cols;
+                        if (y0 + v.cm.total > 65535) flush_folds();
+                        fj.push_back(FoldJob{in, o, (uint32_t)v.cm.total, v.cur_log_h, fj.empty() ? 0 : fj.back().y0 + fj.back().n_cols, 0});
+                    } else {
+                        OVM_THROW_IF(fold_mle(in, o, (uint32_t)v.cm.total, v.cur_log_h, rr, cx.stream));
+                    }
+                }
+                flush_folds();
+                for (size_t t = 0; t < T; t++) {
+                    TraceView &v = tv[t];
+                    if (v.cur_log_h == 0) continue;
+                    v.mats_in_a = !v.mats_in_a;
+                    v.cur_log_h--;
+                    if (v.cur_log_h == 0) v.final_row = cx.download(v.mats_in_a ? v.mats_a.p : v.mats_b.p, v.cm.total);
+                }
             }
             EF eqr = eq1(xi_cur, rr);
             eq_ns.push_back(eq_ns[round - 1] * eqr);

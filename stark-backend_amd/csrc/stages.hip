@@ -886,15 +886,91 @@ __global__ __launch_bounds__(RED_THREADS) void mle_round_grouped_kernel(const In
     finish_reduction<8>(ro, gridDim.x * gridDim.z, K);
 }
 
-int mle_round_eval_grouped(const Instr *d_code, const uint32_t *d_off, uint32_t n_groups, uint32_t max_slots,
-                           const EF *d_weights, const EF *mats, uint32_t log_h, uint32_t degree, uint32_t n_out,
-                           const EF *d_eq, EF add_const, const RedOut &ro, hipStream_t s) {
-    if (degree == 0 || degree > 4 || n_out > 2 || log_h == 0 || n_groups == 0) return (int)hipErrorInvalidValue;
+uint32_t mle_round_gx(uint32_t log_h, uint32_t degree, uint32_t n_groups) {
     uint32_t gx = red_grid(1ull << (log_h - 1));
     // keep the total grid near RED_BLOCKS workgroups
     uint32_t cap = RED_BLOCKS / (degree * n_groups);
     if (cap < 1) cap = 1;
-    if (gx > cap) gx = cap;
+    return gx > cap ? cap : gx;
+}
+
+template <int NS>
+__global__ __launch_bounds__(RED_THREADS) void mle_round_batched_kernel(const MleJob *jobs, uint32_t n_jobs,
+                                                                        uint32_t *counters, RedOut ro) {
+    uint32_t j = 0;
+    while (j + 1 < n_jobs && blockIdx.z >= jobs[j].z0 + jobs[j].n_groups) j++;
+    const MleJob job = jobs[j];
+    if (blockIdx.x >= job.gx) return;
+    const uint64_t n_y = 1ull << (job.log_h - 1);
+    const uint64_t stride = (uint64_t)job.gx * RED_THREADS;
+    const uint32_t xi = blockIdx.y + 1, grp = blockIdx.z - job.z0, K = 2 * gridDim.y;
+    const Instr *gcode = job.code + job.off[grp];
+    const uint32_t n_instr = job.off[grp + 1] - job.off[grp];
+    EF sums[2] = {EF::zero(), EF::zero()};
+    EF slots[NS];
+    for (uint64_t y = (uint64_t)blockIdx.x * RED_THREADS + threadIdx.x; y < n_y; y += stride) {
+        EF e = ld_ef(job.eq + y);
+        MleFetch fetch{job.mats, job.log_h, y, Fp::from_canonical(xi)};
+        EF out[2] = {EF::zero(), grp == 0 ? job.add_const : EF::zero()};
+        run_program_acc<EF>(gcode, n_instr, job.weights, slots, fetch, out);
+        sums[0] = sums[0] + e * out[0];
+        if (job.n_out > 1) sums[1] = sums[1] + e * out[1];
+    }
+    block_sum_store<2>(sums, job.partials + ((size_t)(blockIdx.x * job.n_groups + grp)) * K + 2 * blockIdx.y, true);
+    // the job's last workgroup sums the job; the last job raises the flag
+    __shared__ uint32_t s_last;
+    if (threadIdx.x == 0) {
+        const uint32_t total = job.gx * gridDim.y * job.n_groups;
+        s_last = atomicAdd(counters + 1 + j, 1u) == total - 1;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();
+    EF acc[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) acc[k] = EF::zero();
+    const uint32_t n_records = job.gx * job.n_groups;
+    for (uint32_t b = threadIdx.x; b < n_records; b += RED_THREADS) {
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+            if ((uint32_t)k < K) acc[k] = acc[k] + ld_ef(job.partials + (size_t)b * K + k);
+    }
+    block_sum_store<8, true>(acc, job.out);  // (system-scope fence after the stores)
+    if (threadIdx.x == 0) {
+        counters[1 + j] = 0;
+        if (atomicAdd(counters, 1u) == n_jobs - 1) {
+            counters[0] = 0;
+            publish(ro);
+        }
+    }
+}
+
+int mle_round_eval_batched(const MleJob *d_jobs, const MleJob *h_jobs, uint32_t n_jobs, uint32_t degree,
+                           uint32_t *d_counters, const RedOut &ro, hipStream_t s) {
+    if (n_jobs == 0) return 0;
+    if (degree == 0 || degree > 4) return (int)hipErrorInvalidValue;
+    uint32_t gx = 1, gz = 0, max_slots = 1;
+    for (uint32_t j = 0; j < n_jobs; j++) {
+        if (h_jobs[j].log_h == 0 || h_jobs[j].n_groups == 0 || h_jobs[j].n_out > 2 || h_jobs[j].z0 != gz)
+            return (int)hipErrorInvalidValue;
+        gx = std::max(gx, h_jobs[j].gx);
+        gz += h_jobs[j].n_groups;
+        max_slots = std::max(max_slots, h_jobs[j].max_slots);
+    }
+    dim3 grid(gx, degree, gz);
+#define CALL(NS) \
+    hipLaunchKernelGGL(mle_round_batched_kernel<NS>, grid, dim3(RED_THREADS), 0, s, d_jobs, n_jobs, d_counters, ro)
+    DISPATCH_SLOTS(max_slots, CALL);
+#undef CALL
+    OVM_CHECK_LAUNCH();
+    return 0;
+}
+
+int mle_round_eval_grouped(const Instr *d_code, const uint32_t *d_off, uint32_t n_groups, uint32_t max_slots,
+                           const EF *d_weights, const EF *mats, uint32_t log_h, uint32_t degree, uint32_t n_out,
+                           const EF *d_eq, EF add_const, const RedOut &ro, hipStream_t s) {
+    if (degree == 0 || degree > 4 || n_out > 2 || log_h == 0 || n_groups == 0) return (int)hipErrorInvalidValue;
+    const uint32_t gx = mle_round_gx(log_h, degree, n_groups);
     dim3 grid(gx, degree, n_groups);
 #define CALL(NS)                                                                                               \
     hipLaunchKernelGGL(mle_round_grouped_kernel<NS>, grid, dim3(RED_THREADS), 0, s, d_code, d_off, d_weights, mats, \
@@ -919,6 +995,33 @@ int fold_mle(const EF *in, EF *out, uint32_t n_cols, uint32_t log_h, EF r, hipSt
     if (n_cols == 0 || log_h == 0) return 0;
     hipLaunchKernelGGL(fold_mle_kernel, dim3(ceil_div(1ull << (log_h - 1), 256), n_cols), dim3(256), 0, s, in, out,
                        log_h, r);
+    OVM_CHECK_LAUNCH();
+    return 0;
+}
+
+__global__ void fold_mle_batched_kernel(const FoldJob *jobs, uint32_t n_jobs, EF r_in) {
+    uint32_t j = 0;
+    while (j + 1 < n_jobs && blockIdx.y >= jobs[j].y0 + jobs[j].n_cols) j++;
+    const FoldJob job = jobs[j];
+    const EF::Pre r = r_in.pre();
+    const uint64_t h2 = 1ull << (job.log_h - 1);
+    const uint64_t y = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (y >= h2) return;
+    const uint32_t col = blockIdx.y - job.y0;
+    const EF *p = job.in + ((uint64_t)col << job.log_h) + 2 * y;
+    EF t0 = ld_ef(p), t1 = ld_ef(p + 1);
+    st_ef(job.out + (uint64_t)col * h2 + y, t0 + (t1 - t0) * r);
+}
+int fold_mle_batched(const FoldJob *d_jobs, const FoldJob *h_jobs, uint32_t n_jobs, EF r, hipStream_t s) {
+    if (n_jobs == 0) return 0;
+    uint64_t gx = 1, gy = 0;
+    for (uint32_t j = 0; j < n_jobs; j++) {
+        if (h_jobs[j].log_h == 0 || h_jobs[j].n_cols == 0 || h_jobs[j].y0 != gy) return (int)hipErrorInvalidValue;
+        gx = std::max<uint64_t>(gx, ceil_div(1ull << (h_jobs[j].log_h - 1), 256));
+        gy += h_jobs[j].n_cols;
+    }
+    if (gy > 65535) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(fold_mle_batched_kernel, dim3((uint32_t)gx, (uint32_t)gy), dim3(256), 0, s, d_jobs, n_jobs, r);
     OVM_CHECK_LAUNCH();
     return 0;
 }
