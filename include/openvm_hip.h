@@ -262,7 +262,9 @@ int ovm_hip_prove_openings(const ovm_pk_t *pk, uint32_t n_traces, const ovm_trac
  *   sponge: transcript state, updated in place (NULL = fresh transcript).
  *   section_offsets5 (optional): byte offsets of the ends of header / GKR / batch-constraint /
  *   stacking / WHIR sections.
- * PoW witnesses are the minimum valid ones. Synchronises the stream. */
+ * PoW witnesses are the minimum valid ones. Synchronises the stream.
+ * If proof_cap is too small: returns hipErrorInvalidValue (1) with *proof_len = the size needed and
+ * the sponge untouched, so the call can simply be repeated with a larger buffer. */
 int ovm_hip_prove(const ovm_pk_t *pk, uint32_t n_traces, const ovm_trace_t *traces, ovm_sponge_t *sponge,
                   uint8_t *proof_out, uint64_t proof_cap, uint64_t *proof_len, uint64_t *section_offsets5,
                   ovm_stream_t stream);

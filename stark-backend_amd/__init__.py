@@ -331,6 +331,8 @@ def _prove(self, pk: ProvingKey, traces, sponge: SpongeState | None = None, proo
     secs = (c_uint64 * 5)()
     rc = _lib().ovm_hip_prove(pk.handle, len(traces), arr, ctypes.byref(sponge) if sponge is not None else None,
                               out.ctypes.data, proof_cap, ctypes.byref(plen), secs, self.stream)
+    if rc != 0 and plen.value > proof_cap:  # buffer too small: the size needed came back, the sponge is untouched
+        return _prove(self, pk, traces, sponge, int(plen.value))
     if rc != 0:
         _fail(rc, "ovm_hip_prove")
     return out[:plen.value].tobytes(), [int(x) for x in secs]

@@ -2103,8 +2103,9 @@ int ovm_hip_prove(const ovm_pk_t *pk_, uint32_t n_traces, const ovm_trace_t *tra
         *proof_len = pr.out.buf.size();
         if (section_offsets5)
             for (size_t i = 0; i < 5 && i < pr.section_offsets.size(); i++) section_offsets5[i] = pr.section_offsets[i];
+        if (pr.out.buf.size() > proof_cap || !proof_out)  // *proof_len holds the size needed; the sponge is untouched
+            throw OvmFail((int)hipErrorInvalidValue, "proof buffer too small: " + std::to_string(pr.out.buf.size()) + " bytes needed");
         sponge_out(pr, sponge);
-        if (pr.out.buf.size() > proof_cap || !proof_out) return (int)hipErrorInvalidValue;
         memcpy(proof_out, pr.out.buf.data(), pr.out.buf.size());
         return 0;
     });

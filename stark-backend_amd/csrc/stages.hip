@@ -645,15 +645,18 @@ struct StagedVM {
             __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this block's columns have landed
             asm volatile("" ::: "memory");
             if (blk + 1 < prog.n_blocks) request(blk + 1);  // in flight while this block runs
-            // the next instruction is requested before this one runs
+            // four instructions per scalar load where the block has them (one SMEM latency per four:
+            // an outstanding scalar load would be waited for by every LDS wait, the counter is shared)
             const OVM_CONST_AS uint4 *ip = code + hd.z;
-            uint4 cur = ip[0];
-            for (uint32_t i = hd.w; i != 0; --i) {
-                ++ip;
-                const uint4 next = *ip;
-                exec(cur, mine);
-                cur = next;
+            uint32_t i = hd.w;
+            for (; i >= 4; i -= 4, ip += 4) {
+                const uint4 g0 = ip[0], g1 = ip[1], g2 = ip[2], g3 = ip[3];
+                exec(g0, mine);
+                exec(g1, mine);
+                exec(g2, mine);
+                exec(g3, mine);
             }
+            for (; i != 0; --i, ++ip) exec(*ip, mine);
             after(hd2);
         }
 #endif

@@ -22,3 +22,19 @@ for i in range(50):
     pre={0:(np.array([int(s) for s in sels],np.uint32),16)}
     k = pkg.ProvingKey(airs.pk_blob(airs.test_params(), [airs.fibonacci_selector_air()], preprocessed=pre)); del k
 free, total = torch.cuda.mem_get_info(); print("after 50 keys used GB", round((total - free) / 2**30, 3))
+# many-AIR proofs (batched MLE rounds, staged VM, per-job reduction counters): the captured segment with the
+# most AIRs at heights clamped to 2^13, 60 times; identical bytes every time, no memory growth
+segs = airs.load_reth_shapes()
+si = max(range(len(segs)), key=lambda i: len(segs[i]["airs"]))
+air_list, shapes = airs.synthetic_segment(segs[si], 13)
+params2 = airs.app_params(22)
+params2["max_constraint_degree"] = 4
+pk2 = pkg.ProvingKey(airs.pk_blob(params2, air_list))
+traces = [(i, torch.zeros(w << lh, dtype=torch.int32, device="cuda:0"), 1 << lh, []) for i, lh, w in shapes]
+first = None
+t0 = time.time()
+for i in range(60):
+    proof, _ = dev.prove(pk2, traces)
+    if first is None: first = proof
+    assert proof == first, f"many-AIR proof {i} differs"
+free, total = torch.cuda.mem_get_info(); print(f"{len(air_list)} AIRs x 60 proofs identical, {time.time() - t0:.1f} s, used GB", round((total - free) / 2**30, 3))
