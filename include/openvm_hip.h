@@ -191,6 +191,12 @@ int ovm_hip_pk_preprocessed_commitment(const ovm_pk_t *pk, uint32_t air_idx, uin
  * (environment: OVM_JIT=0 never, OVM_JIT=1 always, unset: proofs of >= 2^24 trace cells). */
 int ovm_hip_jit_compile_check(const uint32_t *blob, uint64_t words, double *seconds, char *message,
                               uint64_t message_cap);
+/* Host-only self-test of the staged constraint-program form (csrc/program.h stage_program: what the
+ * round-0 and GKR-leaf kernels execute): every program of every AIR of the key is staged with
+ * `stage_rows` staging rows per buffer and `acc_rows` accumulation rows and run on one random row next
+ * to the plain interpreter. Needs no device. 0 = all equal; `blocks_out` (optional) = blocks staged. */
+int ovm_hip_staged_selftest(const uint32_t *blob, uint64_t words, uint32_t stage_rows, uint32_t acc_rows,
+                            uint64_t seed, uint64_t *blocks_out);
 /* Returns the calling thread's cached device blocks to the driver (the prover recycles its
  * buffers between proofs; reference: VPMM pool, crates/cuda-common/src/memory_manager/). */
 int ovm_hip_trim(void);

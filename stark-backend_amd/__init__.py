@@ -90,6 +90,7 @@ SIGNATURES = {
     "ovm_hip_pk_free": (None, [c_void_p]),
     "ovm_hip_pk_preprocessed_commitment": (c_int, [c_void_p, c_uint32, c_void_p]),
     "ovm_hip_jit_compile_check": (c_int, [c_void_p, c_uint64, POINTER(ctypes.c_double), c_char_p, c_uint64]),
+    "ovm_hip_staged_selftest": (c_int, [c_void_p, c_uint64, c_uint32, c_uint32, c_uint64, _u64p]),
     "ovm_hip_last_error": (c_char_p, []),
     "ovm_hip_trim": (c_int, []),
     "ovm_hip_commit": (c_int, [c_void_p, c_uint32, c_void_p, c_void_p, POINTER(c_void_p), c_void_p]),
@@ -410,6 +411,18 @@ def jit_compile_check(blob) -> tuple:
     msg = ctypes.create_string_buffer(4096)
     rc = _lib().ovm_hip_jit_compile_check(b.ctypes.data, b.size, ctypes.byref(secs), msg, len(msg))
     return rc == 0, secs.value, msg.value.decode(errors="replace")
+
+
+def staged_selftest(blob, stage_rows: int, acc_rows: int, seed: int = 1) -> int:
+    """Stages every constraint program of the key (csrc/program.h stage_program) with the given layout
+    and runs it on a random row next to the plain interpreter, on the host; no GPU needed. Returns the
+    number of blocks staged; raises OvmError on a mismatch."""
+    b = np.ascontiguousarray(blob, dtype=np.uint32)
+    blocks = c_uint64(0)
+    rc = _lib().ovm_hip_staged_selftest(b.ctypes.data, b.size, stage_rows, acc_rows, seed, ctypes.byref(blocks))
+    if rc != 0:
+        _fail(rc, "ovm_hip_staged_selftest")
+    return int(blocks.value)
 
 
 def profile_enable(on: bool) -> None:

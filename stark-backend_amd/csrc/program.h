@@ -307,6 +307,7 @@ struct StagedProgram {
     std::vector<StagedInstr> code;
     std::vector<StagedAcc> accs;
     uint32_t num_rows = 0;  // SLOT_ROW0 + slots
+    uint32_t stage_rows = 0;  // rows of one staging buffer
     // operand rows -> word offsets for `rows_per_lane` trace rows per lane
     void scale_rows(uint32_t rows_per_lane) {
         const uint32_t k = rows_per_lane * 256;
@@ -326,6 +327,7 @@ inline StagedProgram stage_program(const Program &p, const std::vector<FpExt> &w
     const uint32_t STAGE_ROWS = layout.stage_rows, ACC_ROWS = layout.acc_rows, SLOT_ROW0 = layout.slot_row0();
     StagedProgram sp;
     sp.num_rows = SLOT_ROW0 + p.num_slots;
+    sp.stage_rows = STAGE_ROWS;
     // dead_after[i]: the slot instruction i reads as `a` is not read again before it is rewritten
     std::vector<char> dead_after(p.code.size(), 0);
     {
@@ -455,6 +457,55 @@ inline StagedProgram stage_program(const Program &p, const std::vector<FpExt> &w
     sp.code.push_back(StagedInstr{S_MOV | S_B_CONST, 0, 0, 0});
     sp.accs.push_back(StagedAcc{});
     return sp;
+}
+
+// Host execution of a staged program on one row (self-test of stage_program, no device): `row[col]`
+// are the trace cells; ACC programs add into out[0], out[1]; DEN/LEAF programs call
+// leaf(k, numerator, denominator sum). Mirrors stages.hip StagedVM block for block (rows not
+// scaled: call before scale_rows).
+template <class Leaf>
+inline void staged_host_eval(const StagedProgram &sp, const std::vector<Fp> &row, FpExt out[2], Leaf &&leaf) {
+    std::vector<Fp> lds(sp.num_rows, Fp::zero());
+    FpExt den = FpExt::zero();
+    const uint32_t stage_rows = sp.stage_rows;
+    for (size_t b = 0; b < sp.blocks.size(); b++) {
+        const StagedBlock &blk = sp.blocks[b];
+        for (uint32_t j = 0; j < blk.n_loads; j++) lds.at((b & 1) * stage_rows + j) = row.at(sp.loads[blk.load_off + j]);
+        for (uint32_t i = 0; i < blk.n_instr; i++) {
+            const StagedInstr &in = sp.code[blk.instr_off + i];
+            const Fp a = lds.at(in.a);
+            const Fp bv = (in.op & S_B_CONST) ? Fp::raw(in.b) : lds.at(in.b);
+            Fp r;
+            if (in.op & S_MUL) r = a * bv;
+            else if (in.op & S_ADD) r = a + bv;
+            else if (in.op & S_SUB) r = a - bv;
+            else if (in.op & S_RSUB) r = bv - a;
+            else if (in.op & S_NEG) r = -a;
+            else if (in.op & S_MOV) r = a;
+            else r = bv;
+            lds.at(in.dst) = r;
+        }
+        auto weight = [&](const StagedAcc &e) {
+            FpExt w;
+            for (int k = 0; k < 4; k++) w.c[k] = Fp::raw(e.w[k]);
+            return w;
+        };
+        // accumulator 0 lives across blocks (the kernel's Acc96): a LEAF block emits and clears it
+        for (uint32_t i = 0; i < blk.n_acc0; i++) {
+            const StagedAcc &e = sp.accs[blk.acc_off + i];
+            den += weight(e) * lds.at(e.row);
+        }
+        if (blk.leaf) {
+            leaf(blk.leaf - 1, lds.at(blk.n_acc1), den);
+            den = FpExt::zero();
+        } else {
+            for (uint32_t i = 0; i < blk.n_acc1; i++) {
+                const StagedAcc &e = sp.accs[blk.acc_off + blk.n_acc0 + i];
+                out[1] += weight(e) * lds.at(e.row);
+            }
+        }
+    }
+    out[0] += den;
 }
 
 // The same roots split into `n_groups` independent sub-programs (consecutive runs of roots). All

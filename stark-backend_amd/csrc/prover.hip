@@ -2005,9 +2005,9 @@ void sponge_out(const Prover &pr, ovm_sponge_t *sponge) {
     sponge->sample_idx = pr.ts.s.sample_idx;
 }
 template <class F>
-int guarded(F &&f) {
+int guarded(F &&f, bool needs_device = true) {
     try {
-        if (!twiddles()) return (int)hipErrorInitializationError;
+        if (needs_device && !twiddles()) return (int)hipErrorInitializationError;
         return f();
     } catch (const OvmFail &e) {
         g_last_error = e.what();
@@ -2087,6 +2087,79 @@ int ovm_hip_jit_compile_check(const uint32_t *blob, uint64_t words, double *seco
 int ovm_hip_trim(void) {
     block_cache().trim();
     return 0;
+}
+
+// Host-only self-test of the staged program form (program.h: stage_program / staged_host_eval): for
+// every AIR of the key, the zerocheck, LogUp and GKR-leaf programs are staged with the given layout
+// and run on one random row (random public values and weights) next to the plain interpreter.
+int ovm_hip_staged_selftest(const uint32_t *blob, uint64_t words, uint32_t stage_rows, uint32_t acc_rows, uint64_t seed,
+                            uint64_t *blocks_out) {
+    if (!blob || stage_rows < 2 || acc_rows < 1) return (int)hipErrorInvalidValue;
+    return guarded([&]() -> int {
+        const ProvingKey pk = parse_pk_blob(blob, words);
+        uint64_t st = seed * 0x9E3779B97F4A7C15ull + 1, n_blocks = 0;
+        auto rnd = [&]() {
+            st += 0x9E3779B97F4A7C15ull;
+            uint64_t z = st;
+            z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+            z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+            return Fp::from_canonical((uint32_t)((z ^ (z >> 31)) % bb::P));
+        };
+        auto rnd_ef = [&]() {
+            EF e;
+            for (int k = 0; k < 4; k++) e.c[k] = rnd();
+            return e;
+        };
+        StagedLayout layout;
+        layout.stage_rows = stage_rows;
+        layout.acc_rows = acc_rows;
+        for (size_t a = 0; a < pk.airs.size(); a++) {
+            const AirKey &air = pk.airs[a];
+            const ColumnMap cm = column_map_of(air);
+            std::vector<Fp> row(cm.total), pv(air.num_public_values);
+            for (auto &x : row) x = rnd();
+            for (auto &x : pv) x = rnd();
+            auto fetch = [&](uint32_t col) { return row[col]; };
+            auto fail = [&](const char *what) {
+                throw OvmFail(1, "staged self-test: AIR " + std::to_string(a) + " " + what + " program differs");
+            };
+            for (int kind = 0; kind < 2; kind++) {  // ACC programs: zerocheck, LogUp
+                if (kind == 1 && air.interactions.empty()) continue;
+                uint32_t nw = (uint32_t)air.constraint_idx.size();
+                std::vector<Root> roots = kind == 0 ? roots_zerocheck(air) : roots_logup(air, &nw);
+                std::vector<EF> w(std::max<uint32_t>(nw, 1));
+                for (auto &x : w) x = rnd_ef();
+                const Program p = compile_program(air, cm, pv, roots, nw);
+                EF want[2] = {EF::zero(), EF::zero()}, got[2] = {EF::zero(), EF::zero()};
+                std::vector<Fp> slots(p.num_slots);
+                run_program_acc<Fp>(p.code.data(), (uint32_t)p.code.size(), w.data(), slots.data(), fetch, want);
+                const StagedProgram sp = stage_program(p, w, layout);
+                n_blocks += sp.blocks.size();
+                staged_host_eval(sp, row, got, [&](uint32_t, Fp, const EF &) { fail("ACC (unexpected LEAF)"); });
+                if (!(got[0] == want[0]) || !(got[1] == want[1])) fail(kind == 0 ? "zerocheck" : "LogUp");
+            }
+            if (!air.interactions.empty()) {  // DEN/LEAF program
+                size_t max_len = 0;
+                for (auto &it : air.interactions) max_len = std::max(max_len, it.message.size());
+                std::vector<EF> w(max_len + 1), lc(air.interactions.size());
+                for (auto &x : w) x = rnd_ef();
+                for (auto &x : lc) x = rnd_ef();
+                const Program p = compile_program(air, cm, pv, roots_leaves(air), (uint32_t)w.size());
+                std::vector<std::pair<Fp, EF>> want(air.interactions.size()), got(air.interactions.size());
+                std::vector<Fp> slots(p.num_slots);
+                auto emit_want = [&](uint32_t k, Fp numer, const EF &den) { want.at(k) = {numer, den}; };
+                run_program_leaves<Fp>(p.code.data(), (uint32_t)p.code.size(), w.data(), lc.data(), slots.data(), fetch, emit_want);
+                const StagedProgram sp = stage_program(p, w, layout);
+                n_blocks += sp.blocks.size();
+                EF unused[2] = {EF::zero(), EF::zero()};
+                staged_host_eval(sp, row, unused, [&](uint32_t k, Fp numer, const EF &den) { got.at(k) = {numer, den + lc.at(k)}; });
+                for (size_t k = 0; k < want.size(); k++)
+                    if (!(got[k].first.v == want[k].first.v) || !(got[k].second == want[k].second)) fail("GKR-leaf");
+            }
+        }
+        if (blocks_out) *blocks_out = n_blocks;
+        return 0;
+    }, false);
 }
 
 const char *ovm_hip_last_error(void) { return g_last_error.c_str(); }

@@ -1,0 +1,49 @@
+"""Host-side check of the staged constraint-program form (csrc/program.h: stage_program -- what the
+round-0 and GKR-leaf kernels of the HIP path execute). `ovm_hip_staged_selftest` stages the
+zerocheck, LogUp and GKR-leaf programs of every AIR of a key with a given LDS layout and runs them on
+a random row next to the plain register-program interpreter, entirely on the host: block cutting,
+double-buffered staging rows, operand normalisation (constants on the left, folding, RSUB/MOVC),
+deferred accumulation lists, producer redirection and one-LEAF-per-block are all exercised without a
+GPU. (The GPU parity tests then pin the kernels that execute this form.)"""
+import numpy as np
+import pytest
+
+import airs
+
+
+def _random_key(seed, n_airs=4):
+    rng = np.random.default_rng(seed)
+    air_list = []
+    for _ in range(n_airs):
+        width = int(rng.integers(2, 40))
+        air_list.append(airs.random_air(rng, width, int(rng.integers(1, 60)), int(rng.integers(0, 5)),
+                                        num_public_values=int(rng.integers(0, 3))))
+    return airs.pk_blob(airs.test_params(), air_list)
+
+
+@pytest.mark.parametrize("stage_rows,acc_rows", [(2, 1), (2, 3), (3, 2), (4, 4), (8, 8), (16, 16), (64, 64)])
+def test_staged_form_equals_plain_program_on_random_airs(pkg, stage_rows, acc_rows):
+    total = 0
+    for seed in range(6):
+        total += pkg.staged_selftest(_random_key(100 + seed), stage_rows, acc_rows, seed=seed + 1)
+    assert total > 0
+    if stage_rows <= 4:
+        assert total > 200  # tiny layouts: programs span many blocks
+
+
+def test_staged_form_on_fixture_airs(pkg):
+    """The reference-derived fixture AIRs (Fibonacci, interactions, selectors/preprocessed, cached,
+    BenchmarkAir) and the Keccak-shaped synthetic AIR of the captured reth workload."""
+    air_list = [airs.fibonacci_air(), airs.dummy_interaction_air(2, True, 0), airs.dummy_interaction_air(3, False, 0),
+                airs.uniform_runner_air(20), airs.fibonacci_selector_air()]
+    pre = {4: (np.array([i % 2 == 0 for i in range(16)], np.uint32), 16)}
+    blob = airs.pk_blob(airs.test_params(), air_list, preprocessed=pre)
+    for layout in [(2, 1), (4, 4), (8, 8)]:
+        assert pkg.staged_selftest(blob, *layout) > 0
+    segs = airs.load_reth_shapes()
+    rec = next(r for s in segs for r in s["airs"] if r[1] == 2634)
+    air, _ = airs.synthetic_air(rec)
+    params = airs.app_params(22)
+    params["max_constraint_degree"] = 4
+    blocks = pkg.staged_selftest(airs.pk_blob(params, [air]), 8, 8)
+    assert blocks > 400  # 3 183 accumulations, at most 8 per block
