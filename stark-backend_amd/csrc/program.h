@@ -127,15 +127,25 @@ inline Program compile_program(const AirKey &air, const ColumnMap &cm, const std
 }
 inline Program compile_program_impl(const AirKey &air, const ColumnMap &cm, const std::vector<Fp> *public_values_p,
                                     const std::vector<Root> &roots, uint32_t num_weights) {
-    const size_t n = air.nodes.size();
+    // Only the index range [lo, n) of the DAG that the roots reach is visited (children precede their
+    // parents): a group of consecutive constraints touches a small window of a big DAG, and this runs
+    // once per AIR, group and proof.
+    size_t n = 0;
+    for (auto &r : roots) n = std::max(n, (size_t)r.node + 1);
+    if (n > air.nodes.size()) throw OvmFail(1, "program compiler: root out of range");
     std::vector<char> need(n, 0);
-    for (auto &r : roots) need[r.node] = 1;
-    for (size_t i = n; i-- > 0;) {
+    size_t pending = 0, lo = n;
+    for (auto &r : roots)
+        if (!need[r.node]) need[r.node] = 1, pending++;
+    for (size_t i = n; i-- > 0 && pending > 0;) {
         if (!need[i]) continue;
+        pending--;
+        lo = i;
         const Node &nd = air.nodes[i];
         if (nd.kind >= N_ADD) {
-            need[nd.left] = 1;
-            if (nd.kind != N_NEG) need[nd.right] = 1;
+            if (nd.left >= i || (nd.kind != N_NEG && nd.right >= i)) throw OvmFail(1, "program compiler: DAG not topological");
+            if (!need[nd.left]) need[nd.left] = 1, pending++;
+            if (nd.kind != N_NEG && !need[nd.right]) need[nd.right] = 1, pending++;
         }
     }
     // Roots fire strictly in sequence (a LEAF closes the DENs before it): root r fires at time
@@ -150,7 +160,7 @@ inline Program compile_program_impl(const AirKey &air, const ColumnMap &cm, cons
         }
     }
     std::vector<size_t> last_use(n, 0);
-    for (size_t i = 0; i < n; i++) {
+    for (size_t i = lo; i < n; i++) {
         if (!need[i]) continue;
         const Node &nd = air.nodes[i];
         last_use[i] = std::max(last_use[i], i);
@@ -161,9 +171,14 @@ inline Program compile_program_impl(const AirKey &air, const ColumnMap &cm, cons
     }
     for (size_t r = 0; r < roots.size(); r++)
         last_use[roots[r].node] = std::max(last_use[roots[r].node], fire[r]);
-    std::vector<std::vector<uint32_t>> release_at(n);
-    for (size_t i = 0; i < n; i++)
-        if (need[i] && air.nodes[i].kind >= N_ADD) release_at[last_use[i]].push_back((uint32_t)i);
+    // release lists per time step as intrusive singly linked lists (no per-node allocation: this runs
+    // once per AIR, group and proof)
+    std::vector<int32_t> release_head(n, -1), release_next(n, -1);
+    for (size_t i = n; i-- > lo;)
+        if (need[i] && air.nodes[i].kind >= N_ADD) {
+            release_next[i] = release_head[last_use[i]];
+            release_head[last_use[i]] = (int32_t)i;
+        }
 
     Program prog;
     prog.num_weights = num_weights;
@@ -211,7 +226,7 @@ inline Program compile_program_impl(const AirKey &air, const ColumnMap &cm, cons
         }
     };
     size_t next_root = 0;
-    for (size_t i = 0; i < n; i++) {
+    for (size_t i = lo; i < n; i++) {
         if (need[i] && air.nodes[i].kind >= N_ADD) {
             const Node &nd = air.nodes[i];
             Instr in{};
@@ -240,7 +255,7 @@ inline Program compile_program_impl(const AirKey &air, const ColumnMap &cm, cons
             prog.code.push_back(in);
             next_root++;
         }
-        for (uint32_t node : release_at[i]) {
+        for (int32_t node = release_head[i]; node >= 0; node = release_next[node]) {
             free_slots.push_back((uint32_t)slot_of[node]);
             slot_of[node] = -2;
         }

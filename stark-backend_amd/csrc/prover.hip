@@ -14,6 +14,7 @@
 #include <chrono>
 #include <cstdlib>
 #include <cstring>
+#include <future>
 #include <mutex>
 
 #include "jit.h"
@@ -598,10 +599,44 @@ struct Prover {
         run_program_acc<EF>(p.code.data(), (uint32_t)p.code.size(), weights.data(), slots.data(), fetch, out);
     }
 
+    // The register programs of every trace (they depend on the key and the public values only, not on
+    // any challenge): in the one-call prove they are compiled on a helper thread while the device
+    // commits the traces -- ~7 ms of host work for a 46-AIR segment that the device used to wait for.
+    // (splitting the roots of the short rounds four times finer -- 64 groups -- was measured slower:
+    // batched kernel 174 -> 210 ms over the 21-segment replay sample; per-workgroup overhead dominates)
+    static constexpr uint32_t MLE_GROUPS = 16;
+    struct TracePrograms {
+        Program zc, lg, leaves;
+        GroupedProgram zc_g, lg_g;
+    };
+    std::future<std::vector<TracePrograms>> programs_future;
+    std::vector<TracePrograms> compile_all_programs() const {
+        std::vector<TracePrograms> out(traces.size());
+        for (size_t t = 0; t < traces.size(); t++) {
+            const AirKey &a = air(t);
+            const ColumnMap cm = column_map_of(a);
+            const std::vector<Fp> &pv = traces[t].public_values;
+            const bool tall = traces[t].height > (size_t(1) << P().l_skip);  // has multilinear rounds
+            {
+                const std::vector<Root> roots = roots_zerocheck(a);
+                out[t].zc = compile_program(a, cm, pv, roots, 0);
+                if (tall) out[t].zc_g = compile_grouped(a, cm, pv, roots, 0, MLE_GROUPS);
+            }
+            if (!a.interactions.empty()) {
+                const std::vector<Root> roots = roots_logup(a);
+                out[t].lg = compile_program(a, cm, pv, roots, 0);
+                if (tall) out[t].lg_g = compile_grouped(a, cm, pv, roots, 0, MLE_GROUPS);
+                out[t].leaves = compile_program(a, cm, pv, roots_leaves(a), 0);
+            }
+        }
+        return out;
+    }
+
     // -----------------------------------------------------------------------------------------
     // Stage 2: zerocheck + LogUp (MultiRapProver::prove_rap_constraints)
     // -----------------------------------------------------------------------------------------
     std::vector<EF> prove_rap_constraints() {
+        std::vector<TracePrograms> progs = programs_future.valid() ? programs_future.get() : compile_all_programs();
         const unsigned l_skip = P().l_skip;
         const size_t N = size_t(1) << l_skip, T = traces.size();
         select_jit();
@@ -730,7 +765,7 @@ struct Prover {
                     OVM_THROW_IF(hipModuleLaunchKernel(jk->leaves, ceil_div(1ull << lh, 256), 1, 1, 256, 1, 1, 0, cx.stream, args, nullptr));
                 } else {
                     // staged for one row per lane (log_lifted 0 selects that plan)
-                    ProgDev pd = make_prog(compile_program(a, tv[t].cm, traces[t].public_values, roots, (uint32_t)beta_pows.size()), beta_pows, true, 0, 1);
+                    ProgDev pd = make_prog(std::move(progs[t].leaves), beta_pows, true, 0, 1);
                     OVM_THROW_IF(gkr_eval_leaves(pd.dev(), pd.staged, d_lc.p, tv[t].cols.p, tv[t].log_height, d_lb.p, d_ll.p, norm,
                                                  tree.at(n_leaves), cx.stream));
                 }
@@ -860,9 +895,6 @@ struct Prover {
             DevBuf<Instr> code;
             DevBuf<uint32_t> off;
         };
-        // (splitting the roots of the short rounds four times finer -- 64 groups -- was measured slower:
-        // batched kernel 174 -> 210 ms over the 21-segment replay sample; per-workgroup overhead dominates)
-        static constexpr uint32_t MLE_GROUPS = 16;
         auto make_grouped = [&](GroupedProgram gp) {
             auto g = std::make_unique<GroupedDev>();
             g->code = cx.upload(gp.code);
@@ -924,9 +956,9 @@ struct Prover {
             {
                 std::vector<Root> roots = roots_zerocheck(a);
                 tp[t].zc_w = lambda_pows;
-                tp[t].zc = std::make_unique<ProgDev>(make_prog(compile_program(a, v.cm, traces[t].public_values, roots, (uint32_t)lambda_pows.size()), lambda_pows, true, v.log_lifted, 1));
+                tp[t].zc = std::make_unique<ProgDev>(make_prog(std::move(progs[t].zc), lambda_pows, true, v.log_lifted, 1));
                 if (v.n_lift > 0)
-                    tp[t].zc_g = make_grouped(compile_grouped(a, v.cm, traces[t].public_values, roots, (uint32_t)lambda_pows.size(), MLE_GROUPS));
+                    tp[t].zc_g = make_grouped(std::move(progs[t].zc_g));
             }
             if (!a.interactions.empty()) {
                 std::vector<Root> roots = roots_logup(a);
@@ -938,9 +970,9 @@ struct Prover {
                     tp[t].lg_const += tp[t].eq3b[k] * (beta_pows[it.message.size()] * fp((uint64_t)it.bus_index + 1));
                 }
                 tp[t].lg_w = wts;
-                tp[t].lg = std::make_unique<ProgDev>(make_prog(compile_program(a, v.cm, traces[t].public_values, roots, (uint32_t)wts.size()), wts, true, v.log_lifted, 2));
+                tp[t].lg = std::make_unique<ProgDev>(make_prog(std::move(progs[t].lg), wts, true, v.log_lifted, 2));
                 if (v.n_lift > 0)
-                    tp[t].lg_g = make_grouped(compile_grouped(a, v.cm, traces[t].public_values, roots, (uint32_t)wts.size(), MLE_GROUPS));
+                    tp[t].lg_g = make_grouped(std::move(progs[t].lg_g));
             }
             job.zc_cosets = cdeg ? cdeg - 1 : 0;
             job.lg_cosets = tp[t].lg ? cdeg : 0;
@@ -1519,7 +1551,8 @@ struct Prover {
             cx.sync();
         }
         // per-window tables and combined vectors
-        std::vector<EF> eq_ub(tvs.size(), EF::one());
+        std::vector<EF> tail_d(tvs.size(), EF::zero());  // D_i of the finished slices (see the round loop)
+        std::vector<char> tail_ready(tvs.size(), 0);
         {
             EF eq_u0r0 = eq_uni(l_skip, u0, r0), eq_u0r0_rot = eq_uni(l_skip, u0, r0 * omega_skip), eq_u01 = eq_uni_at_one(l_skip, u0);
             for (size_t wi = 0; wi < W; wi++) {
@@ -1595,16 +1628,25 @@ struct Prover {
                     batch[0] += sv[0];
                     batch[1] += sv[1];
                 } else {
+                    // A finished slice contributes q(X) * eq1b(X, b) * D_i with
+                    //   D_i = eq_ub_i * (lambda_eq * eq_fin + lambda_rot * krot_fin)   (constant in X),
+                    //   q(1) = t1, q(2) = 2 t1 - t0,  eq1b(1, b) = b,  eq1b(2, b) = b ? 2 : -1
+                    // -- two extension-field multiplies per slice and round (this loop runs over every
+                    // stacked column of a many-AIR proof, with the device idle).
                     for (size_t i = win[wi]; i < win[wi + 1]; i++, gi++) {
-                        EF t0 = gv[2 * gi], t1 = gv[2 * gi + 1];
-                        size_t b = (tvs[i].s.row_idx >> (l_skip + round - 1)) & 1;
-                        for (unsigned X = 1; X <= 2; X++) {
-                            EF x = ef_u64(X);
-                            EF q = t0 + (t1 - t0) * x;
-                            EF ub = eq_ub[i] * eq1b(x, b);
-                            EF acc = lam[tvs[i].leq] * q * (wd.eq_fin * ub);
-                            if (tvs[i].lrot >= 0) acc += lam[(size_t)tvs[i].lrot] * q * (wd.krot_fin * ub);
-                            batch[X - 1] += acc;
+                        const EF t0 = gv[2 * gi], t1 = gv[2 * gi + 1];
+                        const size_t b = (tvs[i].s.row_idx >> (l_skip + round - 1)) & 1;
+                        if (!tail_ready[i]) {
+                            tail_d[i] = lam[tvs[i].leq] * wd.eq_fin;
+                            if (tvs[i].lrot >= 0) tail_d[i] += lam[(size_t)tvs[i].lrot] * wd.krot_fin;
+                            tail_ready[i] = 1;
+                        }
+                        const EF v2 = (t1 + t1 - t0) * tail_d[i];
+                        if (b) {
+                            batch[0] += t1 * tail_d[i];
+                            batch[1] += v2 + v2;
+                        } else {
+                            batch[1] -= v2;
                         }
                     }
                 }
@@ -1635,7 +1677,7 @@ struct Prover {
             }
             for (size_t i = 0; i < tvs.size(); i++) {
                 unsigned n_lift = tvs[i].s.log_height > l_skip ? tvs[i].s.log_height - l_skip : 0;
-                if (round > n_lift) eq_ub[i] = eq_ub[i] * eq1b(ur, (tvs[i].s.row_idx >> (l_skip + round - 1)) & 1);
+                if (round > n_lift && tail_ready[i]) tail_d[i] = tail_d[i] * eq1b(ur, (tvs[i].s.row_idx >> (l_skip + round - 1)) & 1);
             }
         }
         delete ps_str;
@@ -1912,6 +1954,7 @@ struct Prover {
     void prove(std::vector<TraceIn> in) {
         set_traces(std::move(in));
         ts.observe_digest(pk.vk_pre_hash);
+        programs_future = std::async(std::launch::async, [this] { return compile_all_programs(); });
         wt.mark("setup");
         PcsData pcs = commit();
         wt.mark("commit");
