@@ -729,7 +729,7 @@ StagedPlan round0_staged_plan(uint32_t log_lifted, uint32_t n_out, uint32_t num_
     const char *es = getenv("OVM_STAGE_ROWS"), *ea = getenv("OVM_ACC_ROWS");  // (tuning / parity-test overrides)
     for (int rows = round0_rows(log_lifted, n_out); rows >= 1; rows >>= 1) {
         const uint32_t first_budget = getenv("OVM_STAGE_KIB") ? (uint32_t)atoi(getenv("OVM_STAGE_KIB")) : 36u;
-        for (uint32_t budget_kib : {first_budget, 60u}) {
+        for (uint32_t budget_kib : {first_budget, 56u}) {
             if (budget_kib > first_budget && rows > 1) continue;  // a larger image only as the last resort
             const uint32_t budget_rows = budget_kib / (uint32_t)rows;
             if (budget_rows < num_slots + 6) continue;

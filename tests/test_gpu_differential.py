@@ -90,3 +90,31 @@ def test_staged_interpreter_layouts(dev, pkg, orc, monkeypatch, stage, acc, rows
     tr = rng.integers(0, airs.P, size=width * h, dtype=np.uint64).astype(np.uint32)
     pvs = [int(x) for x in rng.integers(0, airs.P, size=2)]
     _run(dev, pkg, orc, params, [air], [(0, tr, h, pvs)])
+
+
+@pytest.mark.parametrize("live", [20, 40, 70, 200])
+def test_many_live_slots(dev, pkg, orc, monkeypatch, live):
+    """Programs with many simultaneously live intermediates: `live` products are created by the first
+    constraint and consumed by the second, so the register program needs that many slots. 20 fits
+    the staged VM's default LDS image, 40 its last-resort 56 KiB image, 70 and 200 fall back to the plain
+    interpreter (slots in private memory, NS 128 / 512)."""
+    monkeypatch.setenv("OVM_JIT", "0")
+    rng = np.random.default_rng(4000 + live)
+    width = 8
+    a = airs.Air("ManyLiveSlots", width)
+    prods = [a.local(i % width) * a.local((i + 3) % width) + airs.Expr.lift(i + 1) for i in range(live)]
+    s1 = prods[0]
+    for p in prods[1:]:
+        s1 = s1 + p
+    a.assert_zero(s1)
+    s2 = prods[0] * a.next(0)
+    for i, p in enumerate(prods[1:], 1):
+        s2 = s2 + p * a.next(i % width)
+    a.assert_zero(s2)
+    a.push_interaction(0, [prods[1], a.local(2)], a.local(0))
+    a.push_interaction(0, [prods[1], a.local(2)], airs.NEG_ONE() * a.local(0))
+    air = a.finish()
+    params = airs.test_params(l_skip=3, n_stack=8, k_whir=2)
+    h = 1 << 9
+    tr = rng.integers(0, airs.P, size=width * h, dtype=np.uint64).astype(np.uint32)
+    _run(dev, pkg, orc, params, [air], [(0, tr, h, [])])
