@@ -255,6 +255,16 @@ __global__ __launch_bounds__(NTT_THREADS) void dif_pass_kernel(const T *in, T *o
 static constexpr uint32_t W16[8] = {W16C(0), W16C(1), W16C(2), W16C(3), W16C(4), W16C(5), W16C(6), W16C(7)};
 #undef W16C
 
+// (a - b) * w with the difference left unreduced in (0, 2P): the Montgomery product only needs its
+// operands' product below 2^32 * P, so the canonicalising min of the subtraction is dropped.
+__device__ __forceinline__ Fp mul_diff(Fp a, Fp b, Fp w) { return Fp::raw(bb::mont_mul(a.v - b.v + bb::P, w.v)); }
+__device__ __forceinline__ FpExt mul_diff(const FpExt &a, const FpExt &b, Fp w) {
+    FpExt r;
+#pragma unroll
+    for (int k = 0; k < 4; k++) r.c[k] = mul_diff(a.c[k], b.c[k], w);
+    return r;
+}
+
 // NB stages on the low NB bits of the register index (upper bits = independent groups).
 template <class T, int NB, bool HAS_W>
 __device__ __forceinline__ void radix_dif(T (&x)[16], Fp w0) {
@@ -271,8 +281,7 @@ __device__ __forceinline__ void radix_dif(T (&x)[16], Fp w0) {
                 const int v = g + j;
                 T a = x[v], b = x[v + half];
                 x[v] = a + b;
-                T d = a - b;
-                x[v + half] = (!HAS_W && j == 0) ? d : d * tw;
+                x[v + half] = (!HAS_W && j == 0) ? a - b : mul_diff(a, b, tw);
             }
         }
         if (HAS_W) wk = wk.square();
@@ -324,10 +333,32 @@ __global__ __launch_bounds__(1 << (TL - 4)) void dif16_pass_kernel(const T *in, 
         const bool is_last_partial = (last_nb != 0) && (wdx == n_full);
         bl = is_last_partial ? 0 : top - 4 * (wdx + 1);
         if (wdx == 0) {
+            // Position of register v: a uniform part (pos_base + v * vstep, folded into a scalar base
+            // address) + a lane part that fits 32 bits -- one VGPR offset for all 16 loads instead of
+            // ~11 vector instructions of 64-bit index arithmetic (and a branch) per load.
+            const uint32_t l0 = l_of(0);
+            const uint32_t lane_off = c > 0 ? (uint32_t)((((uint64_t)(l0 >> c)) << beta) | (l0 & c_mask)) : l0;
+            const uint64_t vstep = c > 0 ? 1ull << (bl - c + beta) : 1ull << bl;
+            const T *src0 = in_col + pos_base;
+            if (log_n_in >= L) {  // every position holds an input element
 #pragma unroll
-            for (int v = 0; v < 16; v++) {
-                uint64_t p = pos_of(l_of(v));
-                x[v] = p < n_in ? in_col[p] : T::zero();
+                for (int v = 0; v < 16; v++) x[v] = (src0 + (uint64_t)v * vstep)[lane_off];
+            } else if (c > 0) {
+                // zero-padded input, strided pass: window 0 is the top of the tile, so lane_off < vstep and
+                // register v is in range for all lanes or for none when n_in is a multiple of vstep
+#pragma unroll
+                for (int v = 0; v < 16; v++) {
+                    const uint64_t ub = pos_base + (uint64_t)v * vstep;
+                    if (ub + vstep <= n_in) x[v] = (src0 + (uint64_t)v * vstep)[lane_off];
+                    else if (ub >= n_in) x[v] = T::zero();
+                    else x[v] = ub + lane_off < n_in ? (src0 + (uint64_t)v * vstep)[lane_off] : T::zero();
+                }
+            } else {
+#pragma unroll
+                for (int v = 0; v < 16; v++) {
+                    uint64_t p = pos_of(l_of(v));
+                    x[v] = p < n_in ? in_col[p] : T::zero();
+                }
             }
         } else {
 #pragma unroll
@@ -366,6 +397,17 @@ __global__ __launch_bounds__(1 << (TL - 4)) void dif16_pass_kernel(const T *in, 
             out_col[pos_base | l] = tile[pad(l)];
         }
         return;
+    }
+    {  // (strided pass) same split as the loads: scalar base per register, one lane offset
+        const uint32_t l0 = l_of(0);
+        const uint32_t lane_off = c > 0 ? (uint32_t)((((uint64_t)(l0 >> c)) << beta) | (l0 & c_mask)) : l0;
+        const uint64_t vstep = c > 0 && bl >= c ? 1ull << (bl - c + beta) : 0;
+        if (vstep) {
+            T *dst0 = out_col + pos_base;
+#pragma unroll
+            for (int v = 0; v < 16; v++) (dst0 + (uint64_t)v * vstep)[lane_off] = x[v];
+            return;
+        }
     }
 #pragma unroll
     for (int v = 0; v < 16; v++) out_col[pos_of(l_of(v))] = x[v];

@@ -605,6 +605,7 @@ struct Prover {
     // (splitting the roots of the short rounds four times finer -- 64 groups -- was measured slower:
     // batched kernel 174 -> 210 ms over the 21-segment replay sample; per-workgroup overhead dominates)
     static constexpr uint32_t MLE_GROUPS = 16;
+    static constexpr uint64_t PLANE_SKEW = 1088;  // words: 4 KiB + 256 B
     struct TracePrograms {
         Program zc, lg, leaves;
         GroupedProgram zc_g, lg_g;
@@ -718,7 +719,9 @@ struct Prover {
         if (!ilayout.cols.empty()) {
             const size_t n_leaves = size_t(1) << TR;
             // heap-ordered fraction tree (node 1 = root, layer j at [2^j, 2^(j+1))), 8 limb planes
-            const uint64_t tree_stride = std::max<uint64_t>(2 * n_leaves, 4);
+            // (+ PLANE_SKEW words: limb planes a power of two apart put the 8-20 streams of a wave on the same
+            // HBM channels)
+            const uint64_t tree_stride = std::max<uint64_t>(2 * n_leaves, 4) + PLANE_SKEW;
             DevBuf<uint32_t> tree_buf(8 * tree_stride);
             const FracPlanes tree{tree_buf.p, tree_stride};
             ProfScope *ps_leaves = new ProfScope("gkr.leaves", cx.stream);
@@ -799,7 +802,7 @@ struct Prover {
             std::vector<EF> xi_prev{ts.sample_ext()};
             if (TR > 1) {
                 // fold buffers in layer format (8 limb planes) and the eq heap (4 limb planes)
-                const uint64_t wcap = std::max<uint64_t>(uint64_t(1) << (TR - 1), 4);
+                const uint64_t wcap = std::max<uint64_t>(uint64_t(1) << (TR - 1), 4) + PLANE_SKEW;
                 DevBuf<uint32_t> rec_a(8 * wcap), rec_b(8 * wcap), eq_buf(4 * wcap);
                 const FracPlanes recs[2] = {{rec_a.p, wcap}, {rec_b.p, wcap}};
                 const EFPlanes heap{eq_buf.p, wcap};

@@ -1338,30 +1338,30 @@ __global__ __launch_bounds__(RED_THREADS) void gkr_fold_round_kernel(FracPlanes 
 #pragma unroll
     for (int i = 0; i < NP; i++) sums[i] = EF::zero();
     for (uint64_t y = (uint64_t)blockIdx.x * RED_THREADS + threadIdx.x; y < n_pairs; y += stride) {
+        // all loads of the pair first (P, Q and the weight are three independent latencies otherwise:
+        // the stores to `out` in between keep the compiler from hoisting them)
         EF fp[4], fq[4];
-        {
-            EF u[4], v[4];
-            if (PBASE) {
-                ldp4_base(in.P(), 8 * y, u);
-                ldp4_base(in.P(), 8 * y + 4, v);
-            } else {
-                ldp4(in.P(), in.stride, 8 * y, u);      // records 4y, 4y+1
-                ldp4(in.P(), in.stride, 8 * y + 4, v);  // records 4y+2, 4y+3
-            }
-            fp[0] = u[0] + (u[2] - u[0]) * r;
-            fp[1] = u[1] + (u[3] - u[1]) * r;
-            fp[2] = v[0] + (v[2] - v[0]) * r;
-            fp[3] = v[1] + (v[3] - v[1]) * r;
-            stp4(out.P(), out.stride, 4 * y, fp);
-            ldp4(in.Q(), in.stride, 8 * y, u);
-            ldp4(in.Q(), in.stride, 8 * y + 4, v);
-            fq[0] = u[0] + (u[2] - u[0]) * r;
-            fq[1] = u[1] + (u[3] - u[1]) * r;
-            fq[2] = v[0] + (v[2] - v[0]) * r;
-            fq[3] = v[1] + (v[3] - v[1]) * r;
-            stp4(out.Q(), out.stride, 4 * y, fq);
+        EF up[4], vp[4], uq[4], vq[4];
+        if (PBASE) {
+            ldp4_base(in.P(), 8 * y, up);
+            ldp4_base(in.P(), 8 * y + 4, vp);
+        } else {
+            ldp4(in.P(), in.stride, 8 * y, up);      // records 4y, 4y+1
+            ldp4(in.P(), in.stride, 8 * y + 4, vp);  // records 4y+2, 4y+3
         }
+        ldp4(in.Q(), in.stride, 8 * y, uq);
+        ldp4(in.Q(), in.stride, 8 * y + 4, vq);
         const EF e = ldp(eq.p, eq.stride, y);
+        fp[0] = up[0] + (up[2] - up[0]) * r;
+        fp[1] = up[1] + (up[3] - up[1]) * r;
+        fp[2] = vp[0] + (vp[2] - vp[0]) * r;
+        fp[3] = vp[1] + (vp[3] - vp[1]) * r;
+        stp4(out.P(), out.stride, 4 * y, fp);
+        fq[0] = uq[0] + (uq[2] - uq[0]) * r;
+        fq[1] = uq[1] + (uq[3] - uq[1]) * r;
+        fq[2] = vq[0] + (vq[2] - vq[0]) * r;
+        fq[3] = vq[1] + (vq[3] - vq[1]) * r;
+        stp4(out.Q(), out.stride, 4 * y, fq);
         EF a[4] = {fp[0], fq[0], fp[1], fq[1]};
         const EF b[4] = {fp[2], fq[2], fp[3], fq[3]};
         gkr_pair_sums<NP>(a, b, e, lambda, sums);
