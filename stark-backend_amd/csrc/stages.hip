@@ -419,6 +419,27 @@ struct Acc96 {
     }
 };
 
+// acc += w * a for a wave-uniform extension-field weight (in SGPRs) and a base-field value: four
+// 96-bit multiply-adds (v_mad_u64_u32 with carry-out + v_addc) instead of four Montgomery products
+// and four modular additions; one reduction when the sum is finished (Acc96::finish). Used wherever
+// a kernel sums weight_i * cell_i over many cells.
+__device__ __forceinline__ void mac96(uint64_t &lo, uint32_t &hi, uint32_t a, uint32_t w) {
+    asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32_e32 %1, vcc, 0, %1, vcc"
+        : "+v"(lo), "+v"(hi)
+        : "v"(a), "s"(w)
+        : "vcc");
+}
+#define OVM_CONST_AS __attribute__((address_space(4)))
+__device__ __forceinline__ void mac_weight(Acc96 &acc, const EF *weights, uint32_t idx, uint32_t a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const uint4 w = ((const OVM_CONST_AS uint4 *)weights)[idx];  // scalar load: the weight table is read-only here
+    mac96(acc.lo[0], acc.hi[0], a, w.x);
+    mac96(acc.lo[1], acc.hi[1], a, w.y);
+    mac96(acc.lo[2], acc.hi[2], a, w.z);
+    mac96(acc.lo[3], acc.hi[3], a, w.w);
+#endif
+}
+
 template <int NS, int R, int NOUT>
 struct InterpRound0 {
     static constexpr int ROWS = R;
@@ -546,17 +567,9 @@ __global__ __launch_bounds__(RED_THREADS) void round0_eval_kernel(DevProgram pro
 // accumulators live in this loop's control flow] [accumulation loop: branch-free 96-bit MACs].
 // LDS image of the workgroup: word (row * R + r) * 256 + lane. The program arrays are read through
 // the constant address space so that they stay scalar loads next to the LDS-DMA writes.
-#define OVM_CONST_AS __attribute__((address_space(4)))
 template <int R>
 struct StagedVM {
 
-    // acc += a * w as a 96-bit integer (v_mad_u64_u32 with carry-out, then the carry into the top word)
-    static __device__ __forceinline__ void mac96(uint64_t &lo, uint32_t &hi, uint32_t a, uint32_t w) {
-        asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32_e32 %1, vcc, 0, %1, vcc"
-            : "+v"(lo), "+v"(hi)
-            : "v"(a), "s"(w)
-            : "vcc");
-    }
     // entries are two 16-byte words: weight, then {row offset, -, -, -}
     static __device__ __forceinline__ void run_accs(const OVM_CONST_AS uint4 *list, uint32_t n, const uint32_t *mine,
                                                     Acc96 (&acc)[R]) {
@@ -832,8 +845,11 @@ __global__ void fold_ple_kernel(const ColDesc *cols, uint32_t log_lifted, uint32
             r[16] = 0;
         }
         const uint32_t sh = cd.rot == 1 ? 1 : 0;
+        Acc96 lazy;
+        lazy.clear();
 #pragma unroll
-        for (int z = 0; z < 16; z++) acc = acc + ld_ef(weights + z) * Fp::raw(sh ? r[z + 1] : r[z]);
+        for (int z = 0; z < 16; z++) mac_weight(lazy, weights, z, sh ? r[z + 1] : r[z]);
+        acc = lazy.finish();
     } else {
         for (uint32_t z = 0; z < (1u << l_skip); z++) {
             Fp v = cd.ptr[((x << l_skip) + z + cd.rot) & hmask];
@@ -1416,16 +1432,19 @@ __global__ __launch_bounds__(RED_THREADS) void stacked_round0_kernel(const Fp *b
     const uint64_t nx = total >> l_skip;
     EF sums[3] = {EF::zero(), EF::zero(), EF::zero()};
     for (uint64_t p = (uint64_t)blockIdx.x * RED_THREADS + threadIdx.x; p < total; p += stride) {
-        EF qe = EF::zero(), qr = EF::zero();
+        Acc96 le, lr;
+        le.clear();
+        lr.clear();
         if (lam_rot) {
             for (uint32_t i = 0; i < n_slices; i++) {
-                Fp v = base[((uint64_t)i << log_len) + p];
-                qe = qe + ld_ef(lam_eq + i) * v;
-                qr = qr + ld_ef(lam_rot + i) * v;
+                const uint32_t v = base[((uint64_t)i << log_len) + p].v;
+                mac_weight(le, lam_eq, i, v);
+                mac_weight(lr, lam_rot, i, v);
             }
         } else {  // no slice of this window has a rotated opening: its weights are all zero
-            for (uint32_t i = 0; i < n_slices; i++) qe = qe + ld_ef(lam_eq + i) * base[((uint64_t)i << log_len) + p];
+            for (uint32_t i = 0; i < n_slices; i++) mac_weight(le, lam_eq, i, base[((uint64_t)i << log_len) + p].v);
         }
+        const EF qe = le.finish(), qr = lr.finish();
         uint64_t x = p >> l_skip, xp = x == 0 ? nx - 1 : x - 1;
         EF ec = ld_ef(eq_cube + x), ecp = ld_ef(eq_cube + xp);
         sums[0] = sums[0] + ec * qe;
@@ -1502,9 +1521,11 @@ __global__ void whir_mu_batch_kernel(const Fp *msg, uint32_t width, uint32_t log
                                      uint32_t mu_offset, EF *f, int accumulate) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (1ull << log_h)) return;
-    EF acc = accumulate ? ld_ef(f + i) : EF::zero();
-    for (uint32_t j = 0; j < width; j++) acc = acc + ld_ef(mu_pows + mu_offset + j) * msg[((uint64_t)j << log_h) + i];
-    st_ef(f + i, acc);
+    Acc96 lazy;
+    lazy.clear();
+    for (uint32_t j = 0; j < width; j++) mac_weight(lazy, mu_pows, mu_offset + j, msg[((uint64_t)j << log_h) + i].v);
+    const EF sum = lazy.finish();
+    st_ef(f + i, accumulate ? ld_ef(f + i) + sum : sum);
 }
 int whir_mu_batch(const Fp *msg, uint32_t width, uint32_t log_h, const EF *d_mu_pows, uint32_t mu_offset, EF *f,
                   int accumulate, hipStream_t s) {
