@@ -82,7 +82,7 @@ struct MleJob {
 int mle_round_eval_batched(const MleJob *d_jobs, const MleJob *h_jobs, uint32_t n_jobs, uint32_t degree,
                            uint32_t *d_counters, const RedOut &ro, hipStream_t s);
 // workgroups along y that mle_round_eval_grouped / _batched use for 2^(log_h-1) pairs and this many groups
-uint32_t mle_round_gx(uint32_t log_h, uint32_t degree, uint32_t n_groups);
+uint32_t mle_round_gx(uint32_t log_h, uint32_t degree, uint32_t n_groups, bool points_in_lane = false);
 
 // out[c * h/2 + y] = in[c*h + 2y] + r * (in[c*h + 2y + 1] - in[c*h + 2y])
 int fold_mle(const EF *in, EF *out, uint32_t n_cols, uint32_t log_h, EF r, hipStream_t s);

@@ -905,10 +905,118 @@ __global__ __launch_bounds__(RED_THREADS) void mle_round_grouped_kernel(const In
     finish_reduction<8>(ro, gridDim.x * gridDim.z, K);
 }
 
-uint32_t mle_round_gx(uint32_t log_h, uint32_t degree, uint32_t n_groups) {
+// ---- the same rounds with all D evaluation points in one lane ----------------------------------
+// A lane owns one pair y and evaluates the program at X = 1..D together: one instruction decode and
+// ONE fetch of the pair (t0, t1) per column operand serve all points -- the values at X = 1, 2, ...
+// are t1, t1 + d, t1 + 2d with d = t1 - t0, i.e. additions only, where the per-X kernels multiply.
+template <int NS, int D>
+__device__ __forceinline__ void mle_eval_points(const Instr *code, uint32_t n_instr, const EF *weights, const EF *mats,
+                                                uint32_t log_h, uint64_t y, EF (&out)[D][2]) {
+    EF slots[NS][D];
+    auto operand = [&](uint8_t kind, uint32_t payload, EF (&v)[D]) {
+        if (kind == K_SLOT) {
+#pragma unroll
+            for (int x = 0; x < D; x++) v[x] = slots[payload][x];
+        } else if (kind == K_COL) {
+            const EF *p = mats + ((uint64_t)payload << log_h) + 2 * y;
+            const EF t0 = ld_ef(p), t1 = ld_ef(p + 1);
+            const EF d = t1 - t0;
+            v[0] = t1;
+#pragma unroll
+            for (int x = 1; x < D; x++) v[x] = v[x - 1] + d;
+        } else {
+            const EF cst = EF::from_base(Fp::raw(payload));
+#pragma unroll
+            for (int x = 0; x < D; x++) v[x] = cst;
+        }
+    };
+    for (uint32_t pc = 0; pc < n_instr; pc++) {
+        const Instr in = code[pc];
+        EF a[D], b[D];
+        operand(in.ak, in.a, a);
+        switch (in.op) {
+            case OP_ADD:
+                operand(in.bk, in.b, b);
+#pragma unroll
+                for (int x = 0; x < D; x++) slots[in.dst][x] = a[x] + b[x];
+                break;
+            case OP_SUB:
+                operand(in.bk, in.b, b);
+#pragma unroll
+                for (int x = 0; x < D; x++) slots[in.dst][x] = a[x] - b[x];
+                break;
+            case OP_MUL:
+                operand(in.bk, in.b, b);
+#pragma unroll
+                for (int x = 0; x < D; x++) slots[in.dst][x] = a[x] * b[x];
+                break;
+            case OP_NEG:
+#pragma unroll
+                for (int x = 0; x < D; x++) slots[in.dst][x] = -a[x];
+                break;
+            default: {  // OP_ACC
+                const EF::Pre w = ld_ef(weights + in.b).pre();
+                if (in.acc) {
+#pragma unroll
+                    for (int x = 0; x < D; x++) out[x][1] = out[x][1] + a[x] * w;
+                } else {
+#pragma unroll
+                    for (int x = 0; x < D; x++) out[x][0] = out[x][0] + a[x] * w;
+                }
+                break;
+            }
+        }
+    }
+}
+
+template <int NS, int D>
+__device__ __forceinline__ void mle_round_points_body(const Instr *gcode, uint32_t n_instr, const EF *weights,
+                                                      const EF *mats, uint32_t log_h, uint32_t n_out, const EF *eq,
+                                                      EF add_const, uint32_t gx, EF (&sums)[2 * D]) {
+    const uint64_t n_y = 1ull << (log_h - 1);
+    const uint64_t stride = (uint64_t)gx * RED_THREADS;
+#pragma unroll
+    for (int k = 0; k < 2 * D; k++) sums[k] = EF::zero();
+    for (uint64_t y = (uint64_t)blockIdx.x * RED_THREADS + threadIdx.x; y < n_y; y += stride) {
+        const EF::Pre e = ld_ef(eq + y).pre();
+        EF out[D][2];
+#pragma unroll
+        for (int x = 0; x < D; x++) {
+            out[x][0] = EF::zero();
+            out[x][1] = add_const;
+        }
+        mle_eval_points<NS, D>(gcode, n_instr, weights, mats, log_h, y, out);
+#pragma unroll
+        for (int x = 0; x < D; x++) {
+            sums[2 * x] = sums[2 * x] + out[x][0] * e;
+            if (n_out > 1) sums[2 * x + 1] = sums[2 * x + 1] + out[x][1] * e;
+        }
+    }
+}
+
+template <int NS, int D>
+__global__ __launch_bounds__(RED_THREADS) void mle_round_points_kernel(const Instr *code, const uint32_t *off,
+                                                                       const EF *weights, const EF *mats,
+                                                                       uint32_t log_h, uint32_t n_out, const EF *eq,
+                                                                       EF add_const, RedOut ro) {
+    const uint32_t grp = blockIdx.z;
+    EF sums[2 * D];
+    mle_round_points_body<NS, D>(code + off[grp], off[grp + 1] - off[grp], weights, mats, log_h, n_out, eq,
+                                 grp == 0 ? add_const : EF::zero(), gridDim.x, sums);
+    block_sum_store<2 * D>(sums, ro.partials + ((size_t)(blockIdx.x * gridDim.z + grp)) * (2 * D), ro.counter != nullptr);
+    finish_reduction<8>(ro, gridDim.x * gridDim.z, 2 * D);
+}
+
+// OVM_MLE_POINTS=0 selects the one-point-per-lane kernel for the large rounds too (A/B and parity tests)
+static bool mle_points_in_lane() {
+    const char *e = getenv("OVM_MLE_POINTS");
+    return !(e && e[0] == '0');
+}
+
+uint32_t mle_round_gx(uint32_t log_h, uint32_t degree, uint32_t n_groups, bool points_in_lane) {
     uint32_t gx = red_grid(1ull << (log_h - 1));
     // keep the total grid near RED_BLOCKS workgroups
-    uint32_t cap = RED_BLOCKS / (degree * n_groups);
+    uint32_t cap = RED_BLOCKS / ((points_in_lane ? 1 : degree) * n_groups);
     if (cap < 1) cap = 1;
     return gx > cap ? cap : gx;
 }
@@ -976,6 +1084,8 @@ int mle_round_eval_batched(const MleJob *d_jobs, const MleJob *h_jobs, uint32_t 
         gz += h_jobs[j].n_groups;
         max_slots = std::max(max_slots, h_jobs[j].max_slots);
     }
+    // (the short rounds stay one point per lane: with all points in a lane the batched kernel was
+    // measured slower, 4.8 -> 6.8 ms on the config B shape -- a lane's serial walk is its latency)
     dim3 grid(gx, degree, gz);
 #define CALL(NS) \
     hipLaunchKernelGGL(mle_round_batched_kernel<NS>, grid, dim3(RED_THREADS), 0, s, d_jobs, n_jobs, d_counters, ro)
@@ -989,7 +1099,25 @@ int mle_round_eval_grouped(const Instr *d_code, const uint32_t *d_off, uint32_t 
                            const EF *d_weights, const EF *mats, uint32_t log_h, uint32_t degree, uint32_t n_out,
                            const EF *d_eq, EF add_const, const RedOut &ro, hipStream_t s) {
     if (degree == 0 || degree > 4 || n_out > 2 || log_h == 0 || n_groups == 0) return (int)hipErrorInvalidValue;
-    const uint32_t gx = mle_round_gx(log_h, degree, n_groups);
+    const uint32_t gx = mle_round_gx(log_h, degree, n_groups, mle_points_in_lane());
+    if (mle_points_in_lane()) {
+        dim3 grid(gx, 1, n_groups);
+#define CALLD(NS, DD)                                                                                                  \
+    hipLaunchKernelGGL((mle_round_points_kernel<NS, DD>), grid, dim3(RED_THREADS), 0, s, d_code, d_off, d_weights, mats, \
+                       log_h, n_out, d_eq, add_const, red_inline(ro, gx * n_groups))
+#define CALL(NS)                                  \
+    do {                                          \
+        if (degree == 1) CALLD(NS, 1);            \
+        else if (degree == 2) CALLD(NS, 2);       \
+        else if (degree == 3) CALLD(NS, 3);       \
+        else CALLD(NS, 4);                        \
+    } while (0)
+        DISPATCH_SLOTS(max_slots, CALL);
+#undef CALL
+#undef CALLD
+        OVM_CHECK_LAUNCH();
+        return red_finish(ro, gx * n_groups, gx * n_groups, 2 * degree, s);
+    }
     dim3 grid(gx, degree, n_groups);
 #define CALL(NS)                                                                                               \
     hipLaunchKernelGGL(mle_round_grouped_kernel<NS>, grid, dim3(RED_THREADS), 0, s, d_code, d_off, d_weights, mats, \

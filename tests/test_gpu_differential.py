@@ -118,3 +118,26 @@ def test_many_live_slots(dev, pkg, orc, monkeypatch, live):
     h = 1 << 9
     tr = rng.integers(0, airs.P, size=width * h, dtype=np.uint64).astype(np.uint32)
     _run(dev, pkg, orc, params, [air], [(0, tr, h, [])])
+
+
+@pytest.mark.parametrize("points", ["1", "0"])
+@pytest.mark.parametrize("seed", range(4))
+def test_unbatched_mle_round_kernels(dev, pkg, orc, monkeypatch, points, seed):
+    """The kernels of the LARGE multilinear rounds on small traces: with OVM_MLE_BATCH=0 every
+    (trace, program) job is its own launch, through the all-points-in-one-lane kernel (default) or the
+    one-point-per-lane kernel (OVM_MLE_POINTS=0). Degree-3 and degree-4 keys."""
+    monkeypatch.setenv("OVM_MLE_BATCH", "0")
+    monkeypatch.setenv("OVM_MLE_POINTS", points)
+    rng = np.random.default_rng(5000 + seed)
+    l_skip = int(rng.integers(2, 4))
+    params = airs.test_params(l_skip=l_skip, n_stack=9, k_whir=2)
+    if seed % 2:
+        params["max_constraint_degree"] = 4
+    air_list, traces = [], []
+    for i in range(3):
+        width = int(rng.integers(3, 12))
+        air_list.append(airs.random_air(rng, width, int(rng.integers(4, 30)), int(rng.integers(0, 3)),
+                                        max_degree=params["max_constraint_degree"]))
+        h = 1 << int(rng.integers(l_skip + 1, 11))
+        traces.append((i, rng.integers(0, airs.P, size=width * h, dtype=np.uint64).astype(np.uint32), h, []))
+    _run(dev, pkg, orc, params, air_list, traces)
