@@ -1416,14 +1416,41 @@ __global__ void eq_heap_level_kernel(const EF *point, uint32_t n, uint32_t k, EF
     EF hi = lo * ld_ef(point + (n - 1 - k));
     stp2(heap.p, heap.stride, 2 * i, lo - hi, hi);
 }
+// Up to three levels per launch: a lane takes node i of level k and writes its 2 + 4 + 8 descendants
+// (consecutive lanes write consecutive runs in every limb plane). A layer of 2^24 weights is 5 launches
+// instead of 14.
+__global__ void eq_heap_levels_kernel(const EF *point, uint32_t n, uint32_t k, uint32_t levels, EFPlanes heap) {
+    const uint64_t i = (1ull << k) + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (2ull << k)) return;
+    EF cur[8];
+    cur[0] = ldp(heap.p, heap.stride, i);
+#pragma unroll
+    for (int l = 0; l < 3; l++) {
+        if ((uint32_t)l >= levels) break;
+        const EF::Pre x = ld_ef(point + (n - 1 - (k + l))).pre();
+        const int cnt = 1 << l;  // nodes of this lane at level k + l: (i << l) .. + cnt
+#pragma unroll
+        for (int t = cnt - 1; t >= 0; t--) {  // expand in place from the back
+            const EF lo = cur[t], hi = lo * x;
+            cur[2 * t] = lo - hi;
+            cur[2 * t + 1] = hi;
+        }
+        const uint64_t base = i << (l + 1);
+#pragma unroll
+        for (int t = 0; t < cnt; t++) stp2(heap.p, heap.stride, base + 2 * t, cur[2 * t], cur[2 * t + 1]);
+    }
+}
 int eq_heap(const EF *d_point, uint32_t n, EFPlanes heap, hipStream_t s) {
     if (n == 0) return (int)hipErrorInvalidValue;
     const uint32_t top = n - 1 < EQ_HEAP_DIRECT_DEPTH ? n - 1 : EQ_HEAP_DIRECT_DEPTH;
     hipLaunchKernelGGL(eq_heap_top_kernel, dim3(ceil_div(2ull << top, 256)), dim3(256), 0, s, d_point, n, top, heap);
     OVM_CHECK_LAUNCH();
-    for (uint32_t k = top; k + 1 < n; k++) {
-        hipLaunchKernelGGL(eq_heap_level_kernel, dim3(ceil_div(1ull << k, 256)), dim3(256), 0, s, d_point, n, k, heap);
+    for (uint32_t k = top; k + 1 < n;) {
+        const uint32_t levels = n - 1 - k < 3 ? n - 1 - k : 3;
+        hipLaunchKernelGGL(eq_heap_levels_kernel, dim3(ceil_div(1ull << k, 256)), dim3(256), 0, s, d_point, n, k, levels,
+                           heap);
         OVM_CHECK_LAUNCH();
+        k += levels;
     }
     return 0;
 }
