@@ -185,10 +185,10 @@ void ovm_hip_pk_free(ovm_pk_t *pk);
  * AIR has none. */
 int ovm_hip_pk_preprocessed_commitment(const ovm_pk_t *pk, uint32_t air_idx, uint32_t commitment_out[8]);
 /* Generates the per-AIR constraint kernels of a key (csrc/jit.cpp: straight-line code per AIR for the
- * round-0 evaluations and the LogUp-GKR leaves) and compiles them with hiprtc for gfx950 WITHOUT
- * loading them: needs no device. 0 on success; `seconds` = compile time; `message` = status or the
- * compiler log. ovm_hip_prove compiles (and loads) the same code on first use for large proofs
- * (environment: OVM_JIT=0 never, OVM_JIT=1 always, unset: proofs of >= 2^24 trace cells). */
+ * LogUp-GKR leaves) and compiles them with hiprtc for gfx950 WITHOUT loading them: needs no device.
+ * 0 on success; `seconds` = compile time; `message` = status or the compiler log. ovm_hip_prove
+ * compiles (and loads) the same code on first use only when OVM_JIT=1 is set in the environment
+ * (opt-in: the built-in staged interpreter is as fast). */
 int ovm_hip_jit_compile_check(const uint32_t *blob, uint64_t words, double *seconds, char *message,
                               uint64_t message_cap);
 /* Host-only self-test of the staged constraint-program form (csrc/program.h stage_program: what the

@@ -389,56 +389,7 @@ struct LdeFetch {
 //  * slots in LDS as [slot][row][lane] words (conflict-free) while they fit, else private memory;
 //  * ACC adds raw 62-bit products into 96-bit accumulators (v_mad_u64_u32 + carry) and reduces
 //    once per row instead of four Montgomery reductions and four modular adds per ACC.
-struct Acc96 {
-    uint64_t lo[4];
-    uint32_t hi[4];
-    __device__ __forceinline__ void clear() {
-#pragma unroll
-        for (int k = 0; k < 4; k++) lo[k] = 0, hi[k] = 0;
-    }
-    __device__ __forceinline__ void add(const EF &w, Fp a) {
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const uint64_t prod = (uint64_t)a.v * w.c[k].v;
-            lo[k] += prod;
-            hi[k] += lo[k] < prod;
-        }
-    }
-    // (hi * 2^64 + lo) * 2^-32 mod P per limb
-    __device__ __forceinline__ EF finish() const {
-        EF r;
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            uint32_t xh = (uint32_t)(lo[k] >> 32);
-            xh = bb::umin32(xh, xh - bb::P);  // < 2^32 < 3P: two steps bring it below P
-            xh = bb::umin32(xh, xh - bb::P);
-            const Fp low = Fp::raw(bb::mont_reduce(((uint64_t)xh << 32) | (uint32_t)lo[k]));
-            r.c[k] = low + Fp::raw(hi[k]) * Fp::raw(bb::R2);  // hi < n_instr < P
-        }
-        return r;
-    }
-};
-
-// acc += w * a for a wave-uniform extension-field weight (in SGPRs) and a base-field value: four
-// 96-bit multiply-adds (v_mad_u64_u32 with carry-out + v_addc) instead of four Montgomery products
-// and four modular additions; one reduction when the sum is finished (Acc96::finish). Used wherever
-// a kernel sums weight_i * cell_i over many cells.
-__device__ __forceinline__ void mac96(uint64_t &lo, uint32_t &hi, uint32_t a, uint32_t w) {
-    asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32_e32 %1, vcc, 0, %1, vcc"
-        : "+v"(lo), "+v"(hi)
-        : "v"(a), "s"(w)
-        : "vcc");
-}
-#define OVM_CONST_AS __attribute__((address_space(4)))
-__device__ __forceinline__ void mac_weight(Acc96 &acc, const EF *weights, uint32_t idx, uint32_t a) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    const uint4 w = ((const OVM_CONST_AS uint4 *)weights)[idx];  // scalar load: the weight table is read-only here
-    mac96(acc.lo[0], acc.hi[0], a, w.x);
-    mac96(acc.lo[1], acc.hi[1], a, w.y);
-    mac96(acc.lo[2], acc.hi[2], a, w.z);
-    mac96(acc.lo[3], acc.hi[3], a, w.w);
-#endif
-}
+// (Acc96 / mac96 / mac_weight: eval.cuh -- shared with the run-time compiled kernels)
 
 template <int NS, int R, int NOUT>
 struct InterpRound0 {
