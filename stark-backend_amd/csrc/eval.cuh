@@ -85,16 +85,20 @@ __device__ __forceinline__ void mac_weight(Acc96 &acc, const EF *weights, uint32
 template <class Prog>
 __device__ __forceinline__ void round0_eval_body(const Prog &prog, const Fp *lde, uint32_t n_cols_total,
                                                  uint32_t log_lifted, uint32_t l_skip, uint32_t n_cosets,
-                                                 uint32_t n_out, const EF *eq_xi, EF add_const, EF *partials) {
+                                                 uint32_t n_out, const EF *eq_xi, EF add_const, EF *partials,
+                                                 uint32_t bx = blockIdx.x, uint32_t gx = gridDim.x,
+                                                 bool fence = false) {
+    // (bx, gx: this workgroup's index and the number of workgroups of ITS job -- a batched launch runs
+    // several jobs side by side; fence: device-scope release of the partial records for an in-kernel finish)
     constexpr int R = Prog::ROWS;
     __shared__ EF sh[RED_THREADS];
     const uint32_t N = 1u << l_skip;
     const uint64_t total = 1ull << log_lifted;
-    const uint64_t stride = (uint64_t)gridDim.x * RED_THREADS;  // multiple of N (N <= RED_THREADS)
+    const uint64_t stride = (uint64_t)gx * RED_THREADS;  // multiple of N (N <= RED_THREADS)
     EF sums[MAX_COSETS * 2];
 #pragma unroll
     for (int i = 0; i < (int)(MAX_COSETS * 2); i++) sums[i] = EF::zero();
-    for (uint64_t p0 = (uint64_t)blockIdx.x * RED_THREADS + threadIdx.x; p0 < total; p0 += stride * R) {
+    for (uint64_t p0 = (uint64_t)bx * RED_THREADS + threadIdx.x; p0 < total; p0 += stride * R) {
         uint64_t p[R];
         bool live[R];
 #pragma unroll
@@ -129,7 +133,8 @@ __device__ __forceinline__ void round0_eval_body(const Prog &prog, const Fp *lde
             if (threadIdx.x < N) {
                 EF acc = sh[threadIdx.x];
                 for (uint32_t j = threadIdx.x + N; j < RED_THREADS; j += N) acc = acc + sh[j];
-                st_ef(partials + ((size_t)blockIdx.x * n_cosets * n_out + k * n_out + o) * N + threadIdx.x, acc);
+                st_ef(partials + ((size_t)bx * n_cosets * n_out + k * n_out + o) * N + threadIdx.x, acc);
+                if (fence) __threadfence();
             }
             __syncthreads();
         }

@@ -47,6 +47,26 @@ int coset_lde(const ColDesc *d_cols, const uint32_t *d_used, uint32_t n_used, ui
               hipStream_t s);
 
 // Round 0: out[((k * n_out) + o) * N + z] = sum_x eq_xi[x] * program_o(lde_k row (x<<l)+z) (+ add_const for o==1)
+// Round 0 of many traces in ONE launch (staged programs of equal rows-per-lane and output count): the
+// small traces of a many-AIR proof are otherwise dozens of launches of a few workgroups each. Job j
+// owns workgroups [wg0, wg0 + gx); its last workgroup sums the job's records into job.out (K =
+// n_cosets * n_out << l_skip mailbox slots), the last job raises ro.flag. d_counters: n_jobs + 1
+// words, zero on entry and on exit.
+struct R0Job {
+    DevStaged prog;
+    const Fp *lde;
+    const EF *eq_xi;
+    EF *partials;
+    EF *out;
+    EF add_const;
+    uint32_t n_cols_total, log_lifted, n_cosets, gx;
+    uint32_t wg0, pad[3];
+};
+// workgroups round0_eval gives a staged program on a trace of 2^log_lifted rows
+uint32_t round0_staged_grid(const DevStaged &staged, uint32_t log_lifted);
+int round0_eval_batched(const R0Job *d_jobs, const R0Job *h_jobs, uint32_t n_jobs, uint32_t rows, uint32_t n_out,
+                        uint32_t l_skip, uint32_t *d_counters, const RedOut &ro, hipStream_t s);
+
 // `staged` (optional, blocks != nullptr): the same program in staged form; used when its LDS image fits.
 int round0_eval(const DevProgram &prog, const DevStaged &staged, const Fp *lde, uint32_t n_cols_total, uint32_t log_lifted, uint32_t l_skip,
                 uint32_t n_cosets, uint32_t n_out, const EF *d_eq_xi, EF add_const, const RedOut &ro, hipStream_t s);

@@ -916,6 +916,23 @@ struct Prover {
             DevBuf<Fp> d_sp;
         };
         std::vector<Round0Job> jobs(T);
+        // Staged round-0 evaluations of traces of fewer than 2^R0_BATCH_MAX_LOG rows are collected per
+        // (rows per lane, outputs) and run in one launch each after the loop: a many-AIR proof has dozens of
+        // them, each a few workgroups (OVM_R0_BATCH=0: every trace its own launch).
+        static constexpr uint32_t R0_BATCH_MAX_LOG = 20;
+        const char *r0_batch_env = getenv("OVM_R0_BATCH");
+        const bool r0_batch = !(r0_batch_env && r0_batch_env[0] == '0');
+        std::vector<R0Job> r0_groups[3][2];  // [log2 rows][n_out - 1]
+        auto r0_enqueue = [&](const DevStaged &staged, const Fp *lde, uint32_t n_cols_total, uint32_t log_lifted,
+                              uint32_t n_cosets, uint32_t n_out, const EF *eq_xi, EF add_const, EF *partials, size_t slot) {
+            if (!r0_batch || !staged.blocks || log_lifted >= R0_BATCH_MAX_LOG) return false;
+            R0Job j{};
+            j.prog = staged, j.lde = lde, j.eq_xi = eq_xi, j.partials = partials, j.out = mb.slot_ptr(slot);
+            j.add_const = add_const, j.n_cols_total = n_cols_total, j.log_lifted = log_lifted, j.n_cosets = n_cosets;
+            j.gx = round0_staged_grid(staged, log_lifted);
+            r0_groups[staged.rows == 4 ? 2 : staged.rows == 2 ? 1 : 0][n_out - 1].push_back(j);
+            return true;
+        };
         size_t next_slot = 0;
         // shift^i / N per coset (the iDFT scale is folded in): the same for every trace
         std::vector<Fp> shift_pows(MAX_COSETS * N);
@@ -994,20 +1011,49 @@ struct Prover {
                 job.zc_partials.alloc(red_blocks * job.zc_cosets * N + 64);
                 job.zc_slot = next_slot;
                 next_slot += (job.zc_cosets * N + 63) & ~size_t(63);
-                OVM_THROW_IF(launch_round0(jit_of(t) ? jit_of(t)->r0_zerocheck : nullptr, tp[t].zc->dev(), tp[t].zc->staged, job.lde.p,
-                                           (uint32_t)v.cm.total, v.log_lifted, l_skip, job.zc_cosets, 1, job.d_eq.p, EF::zero(),
-                                           mb.arm(job.zc_partials.p, job.zc_slot), d_pv[t].p, (uint32_t)red_blocks));
+                if (!r0_enqueue(tp[t].zc->staged, job.lde.p, (uint32_t)v.cm.total, v.log_lifted, job.zc_cosets, 1, job.d_eq.p,
+                                EF::zero(), job.zc_partials.p, job.zc_slot))
+                    OVM_THROW_IF(launch_round0(jit_of(t) ? jit_of(t)->r0_zerocheck : nullptr, tp[t].zc->dev(), tp[t].zc->staged, job.lde.p,
+                                               (uint32_t)v.cm.total, v.log_lifted, l_skip, job.zc_cosets, 1, job.d_eq.p, EF::zero(),
+                                               mb.arm(job.zc_partials.p, job.zc_slot), d_pv[t].p, (uint32_t)red_blocks));
             }
             if (job.lg_cosets) {
                 OVM_PROF("round0.logup", cx.stream);
                 job.lg_partials.alloc(red_blocks * job.lg_cosets * 2 * N + 64);
                 job.lg_slot = next_slot;
                 next_slot += (job.lg_cosets * 2 * N + 63) & ~size_t(63);
-                OVM_THROW_IF(launch_round0(jit_of(t) ? jit_of(t)->r0_logup : nullptr, tp[t].lg->dev(), tp[t].lg->staged, job.lde.p,
-                                           (uint32_t)v.cm.total, v.log_lifted, l_skip, job.lg_cosets, 2, job.d_eq.p, tp[t].lg_const,
-                                           mb.arm(job.lg_partials.p, job.lg_slot), d_pv[t].p, (uint32_t)red_blocks));
+                if (!r0_enqueue(tp[t].lg->staged, job.lde.p, (uint32_t)v.cm.total, v.log_lifted, job.lg_cosets, 2, job.d_eq.p,
+                                tp[t].lg_const, job.lg_partials.p, job.lg_slot))
+                    OVM_THROW_IF(launch_round0(jit_of(t) ? jit_of(t)->r0_logup : nullptr, tp[t].lg->dev(), tp[t].lg->staged, job.lde.p,
+                                               (uint32_t)v.cm.total, v.log_lifted, l_skip, job.lg_cosets, 2, job.d_eq.p, tp[t].lg_const,
+                                               mb.arm(job.lg_partials.p, job.lg_slot), d_pv[t].p, (uint32_t)red_blocks));
             }
             if (next_slot + 4 * MAX_COSETS * N + 128 > Mailbox::SLOTS) throw OvmFail(801, "too many traces for the round-0 mailbox");
+        }
+        DevBuf<uint32_t> r0_counters(2 * T + 8);
+        {
+            size_t n_batched = 0;
+            for (auto &byrows : r0_groups)
+                for (auto &g : byrows) n_batched += g.size();
+            if (n_batched) {
+                OVM_PROF("round0.batched", cx.stream);
+                OVM_THROW_IF(hipMemsetAsync(r0_counters.p, 0, (2 * T + 8) * sizeof(uint32_t), cx.stream));
+                size_t counter_off = 0;
+                for (int lr = 0; lr < 3; lr++)
+                    for (int no = 0; no < 2; no++) {
+                        std::vector<R0Job> &g = r0_groups[lr][no];
+                        if (g.empty()) continue;
+                        uint32_t wg = 0;
+                        for (auto &j : g) {
+                            j.wg0 = wg;
+                            wg += j.gx;
+                        }
+                        auto d_jobs = cx.upload(g);
+                        OVM_THROW_IF(round0_eval_batched(d_jobs.p, g.data(), (uint32_t)g.size(), 1u << lr, (uint32_t)no + 1, l_skip,
+                                                         r0_counters.p + counter_off, mb.arm(nullptr, 0), cx.stream));
+                        counter_off += g.size() + 1;
+                    }
+            }
         }
         if (next_slot) mb.wait(cx.stream);
         for (size_t t = 0; t < T; t++) {

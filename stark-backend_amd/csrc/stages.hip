@@ -573,7 +573,8 @@ struct StagedVM {
 #undef OVM_STORE
     }
     // Runs every block. src(col, r) = address of the lane's r-th cell of column `col`;
-    // after(blk, acc_off, n_acc0, n_acc1 / tag) runs once the block's arithmetic is done.
+    // after(second header word: acc_off, n_acc0, n_acc1 | numerator row, leaf) runs once the block's
+    // arithmetic is done.
     template <class Src, class After>
     static __device__ __forceinline__ void run(const DevStaged &prog, uint32_t *lds_image, const Src &src, After &&after) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -655,7 +656,7 @@ struct StagedRound0 {
     }
 };
 template <int R, int NOUT>
-__global__ __launch_bounds__(RED_THREADS) void round0_staged_kernel(DevStaged prog, const EF *weights, const Fp *lde,
+__global__ __launch_bounds__(RED_THREADS) void round0_staged_kernel(DevStaged prog, const Fp *lde,
                                                                     uint32_t n_cols_total, uint32_t log_lifted,
                                                                     uint32_t l_skip, uint32_t n_cosets, uint32_t n_out,
                                                                     const EF *eq_xi, EF add_const, EF *partials) {
@@ -708,6 +709,83 @@ StagedPlan round0_staged_plan(uint32_t log_lifted, uint32_t n_out, uint32_t num_
     return plan;  // rows == 0: does not fit, use the plain interpreter
 }
 
+uint32_t round0_staged_grid(const DevStaged &staged, uint32_t log_lifted) {
+    const size_t lds_bytes = (size_t)staged.num_rows * staged.rows * RED_THREADS * 4;
+    uint64_t lanes = (1ull << log_lifted) / staged.rows;
+    if (lanes < RED_THREADS) lanes = RED_THREADS;
+    // as many workgroups as are resident at once (LDS-bound), and every lane the same number of passes
+    const uint32_t resident = 256u * (uint32_t)std::max<size_t>(1, std::min<size_t>(8, (160u << 10) / (lds_bytes + (5u << 10))));
+    const uint32_t needed = (uint32_t)((lanes + RED_THREADS - 1) / RED_THREADS);
+    const uint32_t passes = (needed + resident - 1) / resident;
+    return (needed + passes - 1) / passes;
+}
+
+template <int R, int NOUT>
+__global__ __launch_bounds__(RED_THREADS) void round0_staged_batched_kernel(const R0Job *jobs, uint32_t n_jobs,
+                                                                            uint32_t l_skip, uint32_t *counters,
+                                                                            RedOut ro) {
+    uint32_t j = 0;
+    while (j + 1 < n_jobs && blockIdx.x >= jobs[j].wg0 + jobs[j].gx) j++;
+    const R0Job job = jobs[j];
+    const uint32_t bx = blockIdx.x - job.wg0;
+    round0_eval_body(StagedRound0<R, NOUT>{job.prog}, job.lde, job.n_cols_total, job.log_lifted, l_skip, job.n_cosets,
+                     NOUT, job.eq_xi, job.add_const, job.partials, bx, job.gx, true);
+    // the job's last workgroup sums the job's records; the last job raises the flag
+    __shared__ uint32_t s_last;
+    __syncthreads();
+    if (threadIdx.x == 0) s_last = atomicAdd(counters + 1 + j, 1u) == job.gx - 1;
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();
+    const uint32_t K = (job.n_cosets * NOUT) << l_skip;
+    for (uint32_t k = threadIdx.x; k < K; k += RED_THREADS) {
+        EF acc = EF::zero();
+        for (uint32_t b = 0; b < job.gx; b++) acc = acc + ld_ef(job.partials + (size_t)b * K + k);
+        st_ef(job.out + k, acc);
+    }
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        counters[1 + j] = 0;
+        if (atomicAdd(counters, 1u) == n_jobs - 1) {
+            counters[0] = 0;
+            publish(ro);
+        }
+    }
+}
+
+int round0_eval_batched(const R0Job *d_jobs, const R0Job *h_jobs, uint32_t n_jobs, uint32_t rows, uint32_t n_out,
+                        uint32_t l_skip, uint32_t *d_counters, const RedOut &ro, hipStream_t s) {
+    if (n_jobs == 0) return 0;
+    if (n_out < 1 || n_out > 2 || (1u << l_skip) > RED_THREADS) return (int)hipErrorInvalidValue;
+    uint32_t grid = 0;
+    size_t lds_bytes = 0;
+    for (uint32_t j = 0; j < n_jobs; j++) {
+        const R0Job &job = h_jobs[j];
+        if (!job.prog.blocks || job.prog.rows != rows || job.wg0 != grid || job.gx == 0 || job.n_cosets == 0 ||
+            job.n_cosets > MAX_COSETS)
+            return (int)hipErrorInvalidValue;
+        grid += job.gx;
+        lds_bytes = std::max(lds_bytes, (size_t)job.prog.num_rows * rows * RED_THREADS * 4);
+    }
+#define LAUNCH(R, NOUT)                                                                                                 \
+    hipLaunchKernelGGL((round0_staged_batched_kernel<R, NOUT>), dim3(grid), dim3(RED_THREADS), lds_bytes, s, d_jobs, n_jobs, \
+                       l_skip, d_counters, ro)
+    if (n_out == 1) {
+        if (rows == 4) LAUNCH(4, 1);
+        else if (rows == 2) LAUNCH(2, 1);
+        else if (rows == 1) LAUNCH(1, 1);
+        else return (int)hipErrorInvalidValue;
+    } else {
+        if (rows == 2) LAUNCH(2, 2);
+        else if (rows == 1) LAUNCH(1, 2);
+        else return (int)hipErrorInvalidValue;
+    }
+#undef LAUNCH
+    OVM_CHECK_LAUNCH();
+    return 0;
+}
+
 int round0_eval(const DevProgram &prog, const DevStaged &staged, const Fp *lde, uint32_t n_cols_total,
                 uint32_t log_lifted, uint32_t l_skip, uint32_t n_cosets, uint32_t n_out, const EF *d_eq_xi,
                 EF add_const, const RedOut &ro, hipStream_t s) {
@@ -719,17 +797,10 @@ int round0_eval(const DevProgram &prog, const DevStaged &staged, const Fp *lde, 
         rows = (int)staged.rows;  // fixed when the program was staged (round0_staged_rows)
         const size_t lds_bytes = (size_t)staged.num_rows * rows * RED_THREADS * 4;
         {
-            uint64_t lanes = (1ull << log_lifted) / rows;
-            if (lanes < RED_THREADS) lanes = RED_THREADS;
-            // as many workgroups as are resident at once (LDS-bound), and every lane the same number of passes
-            const uint32_t resident = 256u * (uint32_t)std::max<size_t>(1, std::min<size_t>(8, (160u << 10) / (lds_bytes + (5u << 10))));
-            const uint32_t needed = (uint32_t)((lanes + RED_THREADS - 1) / RED_THREADS);
-            const uint32_t passes = (needed + resident - 1) / resident;
-            const uint32_t grid = (needed + passes - 1) / passes;
+            const uint32_t grid = round0_staged_grid(staged, log_lifted);
 #define LAUNCH(R, NOUT)                                                                                             \
-    hipLaunchKernelGGL((round0_staged_kernel<R, NOUT>), dim3(grid), dim3(RED_THREADS), lds_bytes, s, staged,       \
-                       prog.weights, lde, n_cols_total, log_lifted, l_skip, n_cosets, n_out, d_eq_xi, add_const,  \
-                       ro.partials)
+    hipLaunchKernelGGL((round0_staged_kernel<R, NOUT>), dim3(grid), dim3(RED_THREADS), lds_bytes, s, staged, lde, \
+                       n_cols_total, log_lifted, l_skip, n_cosets, n_out, d_eq_xi, add_const, ro.partials)
             if (n_out == 1) {
                 if (rows == 4) LAUNCH(4, 1);
                 else if (rows == 2) LAUNCH(2, 1);
