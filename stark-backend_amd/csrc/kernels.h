@@ -121,6 +121,19 @@ int fold_mle_batched(const FoldJob *d_jobs, const FoldJob *h_jobs, uint32_t n_jo
 int eq_heap(const EF *d_point, uint32_t n, EFPlanes heap, hipStream_t s);
 // p_base: leaf numerators are base-field, only limb plane 0 of P is written / read (stages.hip)
 int gkr_fill_leaves(FracPlanes leaves, uint64_t n, EF alpha, bool p_base, hipStream_t s);
+// The leaf kernels of many traces in one launch (staged programs, one row per lane): job j owns
+// workgroups [wg0, wg0 + gx).
+struct LeavesJob {
+    DevStaged prog;
+    const EF *leaf_const;
+    const ColDesc *cols;
+    const uint64_t *leaf_base;
+    const uint32_t *leaf_log_len;
+    Fp norm;
+    uint32_t log_height, gx, wg0;
+};
+int gkr_eval_leaves_batched(const LeavesJob *d_jobs, const LeavesJob *h_jobs, uint32_t n_jobs, FracPlanes leaves,
+                            hipStream_t s);
 // `staged` (optional): the DEN/LEAF program in staged form, laid out for one row per lane
 int gkr_eval_leaves(const DevProgram &prog, const DevStaged &staged, const EF *d_leaf_const, const ColDesc *d_cols, uint32_t log_height,
                     const uint64_t *d_leaf_base, const uint32_t *d_leaf_log_len, Fp norm, FracPlanes leaves,

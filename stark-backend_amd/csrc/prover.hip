@@ -725,6 +725,14 @@ struct Prover {
             if (!p_base) used_leaves = 0;
             if (used_leaves < n_leaves)
                 OVM_THROW_IF(gkr_fill_leaves(tree.at(n_leaves + used_leaves), n_leaves - used_leaves, alpha, p_base, cx.stream));
+            struct LeafKeep {
+                ProgDev pd;
+                DevBuf<EF> lc;
+                DevBuf<uint64_t> lb;
+                DevBuf<uint32_t> ll;
+            };
+            std::vector<LeafKeep> leaf_keep;
+            std::vector<LeavesJob> leaf_jobs;
             for (size_t t = 0; t < T; t++) {
                 const AirKey &a = air(t);
                 if (a.interactions.empty()) continue;
@@ -758,12 +766,29 @@ struct Prover {
                 } else {
                     // staged for one row per lane (log_lifted 0 selects that plan)
                     ProgDev pd = make_prog(std::move(progs[t].leaves), beta_pows, true, 0, 1);
-                    OVM_THROW_IF(gkr_eval_leaves(pd.dev(), pd.staged, d_lc.p, tv[t].cols.p, tv[t].log_height, d_lb.p, d_ll.p, norm,
-                                                 tree.at(n_leaves), cx.stream));
+                    if (pd.staged.blocks && tv[t].log_height < 20) {
+                        // small traces: one launch for all of them after the loop (the buffers stay alive till then)
+                        LeavesJob j{};
+                        j.prog = pd.staged, j.leaf_const = d_lc.p, j.cols = tv[t].cols.p, j.leaf_base = d_lb.p;
+                        j.leaf_log_len = d_ll.p, j.norm = norm, j.log_height = tv[t].log_height;
+                        j.gx = (uint32_t)ceil_div(1ull << tv[t].log_height, 256);
+                        j.wg0 = leaf_jobs.empty() ? 0 : leaf_jobs.back().wg0 + leaf_jobs.back().gx;
+                        leaf_jobs.push_back(j);
+                        leaf_keep.push_back(LeafKeep{std::move(pd), std::move(d_lc), std::move(d_lb), std::move(d_ll)});
+                    } else {
+                        OVM_THROW_IF(gkr_eval_leaves(pd.dev(), pd.staged, d_lc.p, tv[t].cols.p, tv[t].log_height, d_lb.p, d_ll.p,
+                                                     norm, tree.at(n_leaves), cx.stream));
+                    }
                 }
                 // no synchronisation: the temporaries go back to the block cache and are only ever reused
                 // by later work on this same stream
             }
+            if (!leaf_jobs.empty()) {
+                auto d_jobs = cx.upload(leaf_jobs);
+                OVM_THROW_IF(gkr_eval_leaves_batched(d_jobs.p, leaf_jobs.data(), (uint32_t)leaf_jobs.size(), tree.at(n_leaves),
+                                                     cx.stream));
+            }
+            leaf_keep.clear();
             delete ps_leaves;
             {
             OVM_PROF("gkr.build_tree", cx.stream);

@@ -1288,13 +1288,13 @@ __global__ void gkr_leaves_kernel(DevProgram prog, const EF *leaf_const, const C
 }
 // Staged form (program.h: stage_program on the DEN/LEAF program): a block's DENs are its
 // accumulation list; a block that ends an interaction carries the LEAF (numerator row, index).
-__global__ __launch_bounds__(256) void gkr_leaves_staged_kernel(DevStaged prog, const EF *leaf_const,
-                                                                const ColDesc *cols, uint32_t log_height,
-                                                                const uint64_t *leaf_base, const uint32_t *leaf_log_len,
-                                                                Fp norm, FracPlanes leaves) {
+__device__ __forceinline__ void gkr_leaves_staged_body(const DevStaged &prog, const EF *leaf_const, const ColDesc *cols,
+                                                       uint32_t log_height, const uint64_t *leaf_base,
+                                                       const uint32_t *leaf_log_len, Fp norm, FracPlanes leaves,
+                                                       uint32_t bx) {
 #if defined(__HIP_DEVICE_COMPILE__)
     extern __shared__ uint32_t lds_image[];
-    const uint64_t row = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t row = (uint64_t)bx * blockDim.x + threadIdx.x;
     const bool live = row < (1ull << log_height);
     const uint64_t at = live ? row : 0;  // (dead lanes of a short trace still feed the wave's LDS-DMA)
     const uint32_t *mine = lds_image + threadIdx.x;
@@ -1322,6 +1322,35 @@ __global__ __launch_bounds__(256) void gkr_leaves_staged_kernel(DevStaged prog, 
             }
         });
 #endif
+}
+__global__ __launch_bounds__(256) void gkr_leaves_staged_kernel(DevStaged prog, const EF *leaf_const,
+                                                                const ColDesc *cols, uint32_t log_height,
+                                                                const uint64_t *leaf_base, const uint32_t *leaf_log_len,
+                                                                Fp norm, FracPlanes leaves) {
+    gkr_leaves_staged_body(prog, leaf_const, cols, log_height, leaf_base, leaf_log_len, norm, leaves, blockIdx.x);
+}
+__global__ __launch_bounds__(256) void gkr_leaves_staged_batched_kernel(const LeavesJob *jobs, uint32_t n_jobs,
+                                                                        FracPlanes leaves) {
+    uint32_t j = 0;
+    while (j + 1 < n_jobs && blockIdx.x >= jobs[j].wg0 + jobs[j].gx) j++;
+    const LeavesJob job = jobs[j];
+    gkr_leaves_staged_body(job.prog, job.leaf_const, job.cols, job.log_height, job.leaf_base, job.leaf_log_len, job.norm,
+                           leaves, blockIdx.x - job.wg0);
+}
+int gkr_eval_leaves_batched(const LeavesJob *d_jobs, const LeavesJob *h_jobs, uint32_t n_jobs, FracPlanes leaves,
+                            hipStream_t s) {
+    if (n_jobs == 0) return 0;
+    uint32_t grid = 0;
+    size_t lds_bytes = 0;
+    for (uint32_t j = 0; j < n_jobs; j++) {
+        if (!h_jobs[j].prog.blocks || h_jobs[j].prog.rows != 1 || h_jobs[j].wg0 != grid || h_jobs[j].gx == 0)
+            return (int)hipErrorInvalidValue;
+        grid += h_jobs[j].gx;
+        lds_bytes = std::max(lds_bytes, (size_t)h_jobs[j].prog.num_rows * RED_THREADS * 4);
+    }
+    hipLaunchKernelGGL(gkr_leaves_staged_batched_kernel, dim3(grid), dim3(256), lds_bytes, s, d_jobs, n_jobs, leaves);
+    OVM_CHECK_LAUNCH();
+    return 0;
 }
 
 int gkr_eval_leaves(const DevProgram &prog, const DevStaged &staged, const EF *d_leaf_const, const ColDesc *d_cols,
