@@ -97,11 +97,14 @@ struct MleJob {
     EF *out;
     EF add_const;
     uint32_t log_h, n_out, n_groups, gx;
-    uint32_t z0, max_slots, pad[2];
+    uint32_t z0, max_slots;
+    uint32_t partials_cap, pad;  // capacity of `partials` in EF (checked by the launcher)
 };
 int mle_round_eval_batched(const MleJob *d_jobs, const MleJob *h_jobs, uint32_t n_jobs, uint32_t degree,
                            uint32_t *d_counters, const RedOut &ro, hipStream_t s);
-// workgroups along y that mle_round_eval_grouped / _batched use for 2^(log_h-1) pairs and this many groups
+// workgroups per (job, group) of the batched kernel (lanes enumerate (pair, point))
+uint32_t mle_round_batched_gx(uint32_t log_h, uint32_t degree, uint32_t n_groups);
+// workgroups along y that mle_round_eval_grouped uses for 2^(log_h-1) pairs and this many groups
 uint32_t mle_round_gx(uint32_t log_h, uint32_t degree, uint32_t n_groups, bool points_in_lane = false);
 
 // out[c * h/2 + y] = in[c*h + 2y] + r * (in[c*h + 2y + 1] - in[c*h + 2y])

@@ -1231,7 +1231,9 @@ struct Prover {
         for (size_t t = 0; t < T; t++) {
             if (tv[t].n_lift == 0) continue;
             if (!d_eqr_by_nlift[tv[t].n_lift].p) d_eqr_by_nlift[tv[t].n_lift].alloc(size_t(1) << tv[t].n_lift);
-            const size_t rec = std::min<size_t>(RED_BLOCKS, ((size_t(1) << (tv[t].n_lift - 1)) + RED_THREADS - 1) / RED_THREADS) * MLE_GROUPS * 8 + 64;
+            // records of 8 sums per (workgroup, group); the batched kernel's lanes enumerate (pair, point), so it can
+            // run up to `degree` times the workgroups of the per-pair kernels
+            const size_t rec = std::min<size_t>(RED_BLOCKS, (((size_t)cdeg_global << (tv[t].n_lift - 1)) + RED_THREADS - 1) / RED_THREADS) * MLE_GROUPS * 8 + 64;
             mle_partials[2 * t].alloc(rec);
             if (!air(t).interactions.empty()) mle_partials[2 * t + 1].alloc(rec);
         }
@@ -1252,16 +1254,17 @@ struct Prover {
             bool any_launch = false;
             std::vector<MleJob> jobs;
             auto enqueue = [&](const GroupedDev &gd, const EF *weights, const EF *mats, unsigned log_h, uint32_t n_out,
-                               const EF *eq, EF add_const, EF *partials, size_t slot) {
+                               const EF *eq, EF add_const, EF *partials, size_t partials_cap, size_t slot) {
                 const uint32_t n_groups = (uint32_t)gd.gp.off.size() - 1;
-                const uint32_t gx = mle_round_gx(log_h, cdeg_global, n_groups);
-                if (gx * cdeg_global * n_groups <= MLE_BATCH_MAX_WGS) {
+                const uint32_t gx = mle_round_batched_gx(log_h, cdeg_global, n_groups);
+                if (gx * n_groups <= MLE_BATCH_MAX_WGS) {
                     MleJob j{};
                     j.code = gd.code.p, j.off = gd.off.p, j.weights = weights, j.mats = mats, j.eq = eq;
                     j.partials = partials, j.out = mb.slot_ptr(slot), j.add_const = add_const;
                     j.log_h = log_h, j.n_out = n_out, j.n_groups = n_groups, j.gx = gx;
                     j.z0 = jobs.empty() ? 0 : jobs.back().z0 + jobs.back().n_groups;
                     j.max_slots = gd.gp.max_slots;
+                    j.partials_cap = (uint32_t)partials_cap;
                     jobs.push_back(j);
                 } else {
                     OVM_THROW_IF(mle_round_eval_grouped(gd.code.p, gd.off.p, n_groups, gd.gp.max_slots, weights, mats, log_h,
@@ -1280,10 +1283,10 @@ struct Prover {
                     eq_done[v.n_lift] = 1;
                 }
                 const EF *mats = v.mats_in_a ? v.mats_a.p : v.mats_b.p;
-                enqueue(*tp[t].zc_g, tp[t].zc->weights.p, mats, v.cur_log_h, 1, d_eqr.p, EF::zero(), mle_partials[2 * t].p, 16 * t);
+                enqueue(*tp[t].zc_g, tp[t].zc->weights.p, mats, v.cur_log_h, 1, d_eqr.p, EF::zero(), mle_partials[2 * t].p, mle_partials[2 * t].n, 16 * t);
                 if (has_int)
                     enqueue(*tp[t].lg_g, tp[t].lg->weights.p, mats, v.cur_log_h, 2, d_eqr.p, tp[t].lg_const,
-                            mle_partials[2 * t + 1].p, 16 * t + 8);
+                            mle_partials[2 * t + 1].p, mle_partials[2 * t + 1].n, 16 * t + 8);
                 any_launch = true;
             }
             if (!jobs.empty()) {  // armed last: its flag means every reduction of the round is done

@@ -1043,35 +1043,45 @@ uint32_t mle_round_gx(uint32_t log_h, uint32_t degree, uint32_t n_groups, bool p
     return gx > cap ? cap : gx;
 }
 
-template <int NS>
+// Batched short rounds: lanes enumerate (pair y, point X) of a (job, group), so a round of 8 pairs and
+// 4 points fills 32 lanes of ONE wave instead of 8 lanes of four (the short rounds are bound by the
+// number of mostly-empty waves the machine has to run, not by latency: prefetching operands or
+// splitting the groups finer both made them slower).
+template <int NS, int D>
 __global__ __launch_bounds__(RED_THREADS) void mle_round_batched_kernel(const MleJob *jobs, uint32_t n_jobs,
                                                                         uint32_t *counters, RedOut ro) {
     uint32_t j = 0;
     while (j + 1 < n_jobs && blockIdx.z >= jobs[j].z0 + jobs[j].n_groups) j++;
     const MleJob job = jobs[j];
     if (blockIdx.x >= job.gx) return;
-    const uint64_t n_y = 1ull << (job.log_h - 1);
+    const uint64_t n_items = (uint64_t)D << (job.log_h - 1);  // (y, X) pairs
     const uint64_t stride = (uint64_t)job.gx * RED_THREADS;
-    const uint32_t xi = blockIdx.y + 1, grp = blockIdx.z - job.z0, K = 2 * gridDim.y;
+    const uint32_t grp = blockIdx.z - job.z0, K = 2 * D;
     const Instr *gcode = job.code + job.off[grp];
     const uint32_t n_instr = job.off[grp + 1] - job.off[grp];
-    EF sums[2] = {EF::zero(), EF::zero()};
+    EF sums[2 * D];
+#pragma unroll
+    for (int k = 0; k < 2 * D; k++) sums[k] = EF::zero();
     EF slots[NS];
-    for (uint64_t y = (uint64_t)blockIdx.x * RED_THREADS + threadIdx.x; y < n_y; y += stride) {
+    for (uint64_t item = (uint64_t)blockIdx.x * RED_THREADS + threadIdx.x; item < n_items; item += stride) {
+        const uint64_t y = item / D;
+        const uint32_t xi = (uint32_t)(item % D);  // point X = xi + 1
         EF e = ld_ef(job.eq + y);
-        MleFetch fetch{job.mats, job.log_h, y, Fp::from_canonical(xi)};
+        MleFetch fetch{job.mats, job.log_h, y, Fp::from_canonical(xi + 1)};
         EF out[2] = {EF::zero(), grp == 0 ? job.add_const : EF::zero()};
         run_program_acc<EF>(gcode, n_instr, job.weights, slots, fetch, out);
-        sums[0] = sums[0] + e * out[0];
-        if (job.n_out > 1) sums[1] = sums[1] + e * out[1];
+        const EF s0 = e * out[0], s1 = job.n_out > 1 ? e * out[1] : EF::zero();
+#pragma unroll
+        for (int x = 0; x < D; x++)
+            if (xi == (uint32_t)x) {
+                sums[2 * x] = sums[2 * x] + s0;
+                sums[2 * x + 1] = sums[2 * x + 1] + s1;
+            }
     }
-    block_sum_store<2>(sums, job.partials + ((size_t)(blockIdx.x * job.n_groups + grp)) * K + 2 * blockIdx.y, true);
+    block_sum_store<2 * D>(sums, job.partials + ((size_t)(blockIdx.x * job.n_groups + grp)) * K, true);
     // the job's last workgroup sums the job; the last job raises the flag
     __shared__ uint32_t s_last;
-    if (threadIdx.x == 0) {
-        const uint32_t total = job.gx * gridDim.y * job.n_groups;
-        s_last = atomicAdd(counters + 1 + j, 1u) == total - 1;
-    }
+    if (threadIdx.x == 0) s_last = atomicAdd(counters + 1 + j, 1u) == job.gx * job.n_groups - 1;
     __syncthreads();
     if (!s_last) return;
     __threadfence();
@@ -1094,25 +1104,42 @@ __global__ __launch_bounds__(RED_THREADS) void mle_round_batched_kernel(const Ml
     }
 }
 
+// workgroups per (job, group) of the batched kernel
+uint32_t mle_round_batched_gx(uint32_t log_h, uint32_t degree, uint32_t n_groups) {
+    uint32_t gx = red_grid((uint64_t)degree << (log_h - 1));
+    uint32_t cap = RED_BLOCKS / n_groups;
+    if (cap < 1) cap = 1;
+    return gx > cap ? cap : gx;
+}
+
 int mle_round_eval_batched(const MleJob *d_jobs, const MleJob *h_jobs, uint32_t n_jobs, uint32_t degree,
                            uint32_t *d_counters, const RedOut &ro, hipStream_t s) {
     if (n_jobs == 0) return 0;
     if (degree == 0 || degree > 4) return (int)hipErrorInvalidValue;
     uint32_t gx = 1, gz = 0, max_slots = 1;
     for (uint32_t j = 0; j < n_jobs; j++) {
-        if (h_jobs[j].log_h == 0 || h_jobs[j].n_groups == 0 || h_jobs[j].n_out > 2 || h_jobs[j].z0 != gz)
+        if (h_jobs[j].log_h == 0 || h_jobs[j].n_groups == 0 || h_jobs[j].n_out > 2 || h_jobs[j].z0 != gz ||
+            (uint64_t)h_jobs[j].gx * h_jobs[j].n_groups * 2 * degree > h_jobs[j].partials_cap)
             return (int)hipErrorInvalidValue;
         gx = std::max(gx, h_jobs[j].gx);
         gz += h_jobs[j].n_groups;
         max_slots = std::max(max_slots, h_jobs[j].max_slots);
     }
-    // (the short rounds stay one point per lane: with all points in a lane the batched kernel was
-    // measured slower, 4.8 -> 6.8 ms on the config B shape -- a lane's serial walk is its latency)
-    dim3 grid(gx, degree, gz);
-#define CALL(NS) \
-    hipLaunchKernelGGL(mle_round_batched_kernel<NS>, grid, dim3(RED_THREADS), 0, s, d_jobs, n_jobs, d_counters, ro)
+    // (all points of a pair in ONE lane, as the large rounds do, was measured slower here: 4.8 -> 6.8 ms on
+    // the config B shape)
+    dim3 grid(gx, 1, gz);
+#define CALLD(NS, DD) \
+    hipLaunchKernelGGL((mle_round_batched_kernel<NS, DD>), grid, dim3(RED_THREADS), 0, s, d_jobs, n_jobs, d_counters, ro)
+#define CALL(NS)                                  \
+    do {                                          \
+        if (degree == 1) CALLD(NS, 1);            \
+        else if (degree == 2) CALLD(NS, 2);       \
+        else if (degree == 3) CALLD(NS, 3);       \
+        else CALLD(NS, 4);                        \
+    } while (0)
     DISPATCH_SLOTS(max_slots, CALL);
 #undef CALL
+#undef CALLD
     OVM_CHECK_LAUNCH();
     return 0;
 }
