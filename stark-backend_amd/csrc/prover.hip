@@ -1647,8 +1647,18 @@ struct Prover {
                     cr.push_back(tvs[i].lrot >= 0 ? lam[(size_t)tvs[i].lrot] : EF::zero());
                 }
                 auto d_off = cx.upload(off);
-                auto d_ce = cx.upload(ce);
-                auto d_cr = cx.upload(cr);
+                auto coef_pre = [](const std::vector<EF> &cs) {
+                    const Fp eleven = fp(11);
+                    std::vector<uint32_t> w(8 * cs.size());
+                    for (size_t i = 0; i < cs.size(); i++)
+                        for (int k = 0; k < 4; k++) {
+                            w[8 * i + k] = cs[i].c[k].v;
+                            w[8 * i + 4 + k] = k ? (cs[i].c[k] * eleven).v : 0;
+                        }
+                    return w;
+                };
+                auto d_ce = cx.upload(coef_pre(ce));
+                auto d_cr = cx.upload(coef_pre(cr));
                 OVM_THROW_IF(stacked_combine(q_a.p, d_off.p, (uint32_t)(w1 - w0), wd.n_lift, d_ce.p, d_cr.p, wd.vec_a.p,
                                              wd.vec_a.p + hw, cx.stream));
                 cx.sync();

@@ -1707,23 +1707,44 @@ int stacked_round0(const Fp *base, uint32_t n_slices, uint32_t log_len, uint32_t
     return sum_partials(ro, grid, 3u << l_skip, s);
 }
 
+// out_eq[x] = sum_i coef_eq[i] * q_i[x], out_rot likewise: extension-field products with wave-uniform
+// left factors, accumulated lazily -- limb k of c * v is sum_j v_j * m[k][j] with m[k][j] = c[k-j] for
+// j <= k and 11 * c[k-j+4] otherwise; the seven distinct factors (c0..c3, 11 c1..11 c3) come from the
+// host, and the 16 products of a multiplication go straight into the 96-bit accumulators.
+struct CoefPre {
+    uint32_t c[4];
+    uint32_t w[4];  // w[k] = 11 * c[k] (w[0] unused)
+};
+__device__ __forceinline__ void mac_ef_ef(Acc96 &acc, const CoefPre *coefs, uint32_t idx, const EF &v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const uint4 c = ((const OVM_CONST_AS uint4 *)coefs)[2 * idx], w = ((const OVM_CONST_AS uint4 *)coefs)[2 * idx + 1];
+    const uint32_t cc[4] = {c.x, c.y, c.z, c.w}, ww[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) mac96(acc.lo[k], acc.hi[k], v.c[j].v, j <= k ? cc[k - j] : ww[k - j + 4]);
+#endif
+}
 __global__ void stacked_combine_kernel(const EF *q, const uint64_t *slice_off, uint32_t n_slices, uint32_t log_len,
-                                       const EF *coef_eq, const EF *coef_rot, EF *out_eq, EF *out_rot) {
+                                       const CoefPre *coef_eq, const CoefPre *coef_rot, EF *out_eq, EF *out_rot) {
     uint64_t x = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (x >= (1ull << log_len)) return;
-    EF ae = EF::zero(), ar = EF::zero();
+    Acc96 ae, ar;
+    ae.clear();
+    ar.clear();
     for (uint32_t i = 0; i < n_slices; i++) {
-        EF v = ld_ef(q + slice_off[i] + x);
-        ae = ae + ld_ef(coef_eq + i) * v;
-        ar = ar + ld_ef(coef_rot + i) * v;
+        const EF v = ld_ef(q + slice_off[i] + x);
+        mac_ef_ef(ae, coef_eq, i, v);
+        mac_ef_ef(ar, coef_rot, i, v);
     }
-    st_ef(out_eq + x, ae);
-    st_ef(out_rot + x, ar);
+    st_ef(out_eq + x, ae.finish());
+    st_ef(out_rot + x, ar.finish());
 }
 int stacked_combine(const EF *q, const uint64_t *d_slice_off, uint32_t n_slices, uint32_t log_len,
-                    const EF *d_coef_eq, const EF *d_coef_rot, EF *out_eq, EF *out_rot, hipStream_t s) {
+                    const uint32_t *d_coef_eq_pre, const uint32_t *d_coef_rot_pre, EF *out_eq, EF *out_rot, hipStream_t s) {
+    if (4ull * n_slices >= bb::P) return (int)hipErrorInvalidValue;  // (carry words stay below P)
     hipLaunchKernelGGL(stacked_combine_kernel, dim3(ceil_div(1ull << log_len, 256)), dim3(256), 0, s, q, d_slice_off,
-                       n_slices, log_len, d_coef_eq, d_coef_rot, out_eq, out_rot);
+                       n_slices, log_len, (const CoefPre *)d_coef_eq_pre, (const CoefPre *)d_coef_rot_pre, out_eq, out_rot);
     OVM_CHECK_LAUNCH();
     return 0;
 }
