@@ -103,6 +103,9 @@ __global__ __launch_bounds__(HASH_THREADS) void grind_kernel(p2::Sponge sponge, 
     uint32_t i = blockIdx.x * HASH_THREADS + threadIdx.x;
     if (i >= count) return;
     uint32_t w = base + i;
+    // a smaller witness has been found already: nothing this lane could add (workgroups start roughly in
+    // ascending order, so the windows after the first hit cost next to nothing)
+    if (*(volatile uint32_t *)result < w) return;
     p2::Sponge s = sponge;
     s.observe(Fp::from_canonical(w));
     if (s.sample_bits(bits) == 0) atomicMin(result, w);
@@ -240,9 +243,10 @@ int ovm_hip_sponge_grind(const ovm_sponge_t *sponge, uint32_t bits, uint32_t *wi
     OVM_PROF("grind", stream);
     static thread_local uint32_t *d_result = nullptr;
     if (!d_result) OVM_CHECK(hipMalloc(&d_result, sizeof(uint32_t)));
-    // Expected 2^bits candidates per hit: scan in batches of that size, ascending, so the first
-    // batch with a hit yields the global minimum witness.
-    uint64_t batch = 1ull << (bits < 16 ? 16 : bits);
+    // Expected 2^bits candidates per hit: scan ascending in batches of four times that (a batch holds a
+    // hit with probability 1 - e^-4; the candidates above the first hit exit early), so the first batch
+    // with a hit yields the global minimum witness.
+    uint64_t batch = 4ull << (bits < 16 ? 16 : bits);
     if (batch > (1ull << 24)) batch = 1ull << 24;
     for (uint64_t base = 0; base < bb::P; base += batch) {
         uint32_t init = 0xffffffffu;
