@@ -72,8 +72,9 @@ int round0_eval(const DevProgram &prog, const DevStaged &staged, const Fp *lde, 
                 uint32_t n_cosets, uint32_t n_out, const EF *d_eq_xi, EF add_const, const RedOut &ro, hipStream_t s);
 
 // out[col * (lifted >> l) + x] = sum_z w[z] * col(( x << l) + z)
-int fold_ple(const ColDesc *d_cols, uint32_t n_cols, uint32_t log_lifted, uint32_t l_skip, const EF *d_weights,
-             EF *out, hipStream_t s);
+// d_twins (optional, n_cols entries): see fold_ple_kernel -- a column and its rotated view computed from one read
+int fold_ple(const ColDesc *d_cols, const int32_t *d_twins, uint32_t n_cols, uint32_t log_lifted, uint32_t l_skip,
+             const EF *d_weights, EF *out, hipStream_t s);
 
 // MLE round on folded EF matrices (n_cols x 2^log_h, column-major), node-grouped program:
 //   out[2*(X-1)+o] = sum_y eq[y] * program_o(row interpolated at X from rows 2y, 2y+1);

@@ -510,6 +510,7 @@ struct Prover {
         int n = 0;
         DevBuf<Fp> sels;
         DevBuf<ColDesc> cols;
+        DevBuf<int32_t> twins;  // per flat column: index of its rotated view / -2 for the views / -1 (fold_ple)
         // folded matrices (EF, column-major, all flat columns), ping-pong
         DevBuf<EF> mats_a, mats_b;
         bool mats_in_a = true;
@@ -660,12 +661,17 @@ struct Prover {
             v.sels.alloc(size_t(3) << v.log_lifted);
             OVM_THROW_IF(build_selectors(v.sels.p, v.log_lifted, v.log_height, cx.stream));
             std::vector<ColDesc> cd(v.cm.total);
+            std::vector<int32_t> twin(v.cm.total, -1);
             for (int sidx = 0; sidx < 3; sidx++) cd[sidx] = ColDesc{v.sels.p + ((size_t)sidx << v.log_lifted), v.log_lifted, 0};
             const size_t h = traces[t].height;
             auto put_mat = [&](const Fp *ptr, size_t w, uint32_t base) {
                 for (size_t c = 0; c < w; c++) {
                     cd[base + c] = ColDesc{ptr + c * h, v.log_height, 0};
-                    if (v.cm.need_rot) cd[base + w + c] = ColDesc{ptr + c * h, v.log_height, 1};
+                    if (v.cm.need_rot) {
+                        cd[base + w + c] = ColDesc{ptr + c * h, v.log_height, 1};
+                        // (a chunk and its rotated view share cells only when the trace has whole 16-row chunks)
+                        if (v.log_height >= 4) twin[base + c] = (int32_t)(base + w + c), twin[base + w + c] = -2;
+                    }
                 }
             };
             if (v.cm.pre_width) {
@@ -684,6 +690,7 @@ struct Prover {
             }
             put_mat(traces[t].d_trace, air(t).common_main_width, v.cm.col((uint32_t)n_cached, 0, 0));
             v.cols = cx.upload(cd);
+            v.twins = cx.upload(twin);
         }
         const unsigned n_max = tv[0].n_lift;
         unsigned n_logup = 0;
@@ -1204,7 +1211,7 @@ struct Prover {
                 size_t h = size_t(1) << v.n_lift;
                 v.mats_a.alloc(v.cm.total * h);
                 v.mats_b.alloc(v.cm.total * std::max<size_t>(h / 2, 1));
-                OVM_THROW_IF(fold_ple(v.cols.p, (uint32_t)v.cm.total, v.log_lifted, l_skip, d_w.p, v.mats_a.p, cx.stream));
+                OVM_THROW_IF(fold_ple(v.cols.p, v.twins.p, (uint32_t)v.cm.total, v.log_lifted, l_skip, d_w.p, v.mats_a.p, cx.stream));
                 v.cur_log_h = v.n_lift;
                 v.mats_in_a = true;
                 if (v.n_lift == 0) v.final_row = cx.download(v.mats_a.p, v.cm.total);
@@ -1615,7 +1622,7 @@ struct Prover {
                 for (size_t c = 0; c < commits[com]->layout.width; c++)
                     cd[coff[com] + c] = ColDesc{commits[com]->stacked_view + c * H, l_skip + n_stack, 0};
             auto d_cd = cx.upload(cd);
-            OVM_THROW_IF(fold_ple(d_cd.p, (uint32_t)width, l_skip + n_stack, l_skip, d_w.p, q_a.p, cx.stream));
+            OVM_THROW_IF(fold_ple(d_cd.p, nullptr, (uint32_t)width, l_skip + n_stack, l_skip, d_w.p, q_a.p, cx.stream));
             cx.sync();
         }
         // per-window tables and combined vectors

@@ -839,11 +839,16 @@ int round0_eval(const DevProgram &prog, const DevStaged &staged, const Fp *lde, 
 }
 
 // ---- fold_ple: evaluate each chunk's interpolant at r via barycentric weights ---------------
-__global__ void fold_ple_kernel(const ColDesc *cols, uint32_t log_lifted, uint32_t l_skip, const EF *weights,
-                                EF *out) {
+// twins (optional): twins[j] = column index of the rotated view of column j when this lane should
+// produce it as well (same 17 cells, weights shifted by one row), -2 = column j is such a rotated view
+// and is skipped here, -1 = neither.
+__global__ void fold_ple_kernel(const ColDesc *cols, const int32_t *twins, uint32_t log_lifted, uint32_t l_skip,
+                                const EF *weights, EF *out) {
     const uint64_t nx = 1ull << (log_lifted - l_skip);
     uint64_t x = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (x >= nx) return;
+    const int32_t twin = twins ? twins[blockIdx.y] : -1;
+    if (twin == -2) return;
     const ColDesc cd = cols[blockIdx.y];
     const uint64_t hmask = (1ull << cd.log_height) - 1;
     EF acc = EF::zero();
@@ -861,7 +866,7 @@ __global__ void fold_ple_kernel(const ColDesc *cols, uint32_t log_lifted, uint32
             r[4 * q + 2] = t.z;
             r[4 * q + 3] = t.w;
         }
-        r[16] = cd.rot ? cd.ptr[(base + 16) & hmask].v : 0;
+        r[16] = (cd.rot || twin >= 0) ? cd.ptr[(base + 16) & hmask].v : 0;
         if (cd.rot > 1) {  // (views only ever rotate by 0 or 1; keep the general path exact)
             for (uint32_t z = 0; z < 16; z++) r[z] = cd.ptr[((x << 4) + z + cd.rot) & hmask].v;
             r[16] = 0;
@@ -872,6 +877,13 @@ __global__ void fold_ple_kernel(const ColDesc *cols, uint32_t log_lifted, uint32
 #pragma unroll
         for (int z = 0; z < 16; z++) mac_weight(lazy, weights, z, sh ? r[z + 1] : r[z]);
         acc = lazy.finish();
+        if (twin >= 0 && cd.rot == 0) {  // the rotated view of the same cells
+            Acc96 lazy1;
+            lazy1.clear();
+#pragma unroll
+            for (int z = 0; z < 16; z++) mac_weight(lazy1, weights, z, r[z + 1]);
+            st_ef(out + (uint64_t)twin * nx + x, lazy1.finish());
+        }
     } else {
         for (uint32_t z = 0; z < (1u << l_skip); z++) {
             Fp v = cd.ptr[((x << l_skip) + z + cd.rot) & hmask];
@@ -880,11 +892,12 @@ __global__ void fold_ple_kernel(const ColDesc *cols, uint32_t log_lifted, uint32
     }
     st_ef(out + (uint64_t)blockIdx.y * nx + x, acc);
 }
-int fold_ple(const ColDesc *d_cols, uint32_t n_cols, uint32_t log_lifted, uint32_t l_skip, const EF *d_weights,
-             EF *out, hipStream_t s) {
+int fold_ple(const ColDesc *d_cols, const int32_t *d_twins, uint32_t n_cols, uint32_t log_lifted, uint32_t l_skip,
+             const EF *d_weights, EF *out, hipStream_t s) {
     if (n_cols == 0) return 0;
+    if (d_twins && l_skip != 4) d_twins = nullptr;  // (only the 16-row chunk path shares the cells)
     uint64_t nx = 1ull << (log_lifted - l_skip);
-    hipLaunchKernelGGL(fold_ple_kernel, dim3(ceil_div(nx, 256), n_cols), dim3(256), 0, s, d_cols, log_lifted, l_skip,
+    hipLaunchKernelGGL(fold_ple_kernel, dim3(ceil_div(nx, 256), n_cols), dim3(256), 0, s, d_cols, d_twins, log_lifted, l_skip,
                        d_weights, out);
     OVM_CHECK_LAUNCH();
     return 0;
