@@ -197,6 +197,10 @@ int ovm_hip_jit_compile_check(const uint32_t *blob, uint64_t words, double *seco
  * to the plain interpreter. Needs no device. 0 = all equal; `blocks_out` (optional) = blocks staged. */
 int ovm_hip_staged_selftest(const uint32_t *blob, uint64_t words, uint32_t stage_rows, uint32_t acc_rows,
                             uint64_t seed, uint64_t *blocks_out);
+/* Host-only self-test of the transcript's permutation: the run-time selected host implementation
+ * (AVX2 where the CPU has it, csrc/host_poseidon2.cpp) against the scalar one on n pseudo-random
+ * states. 1 = equal on all of them. */
+int ovm_hip_host_permute_selftest(uint32_t n, uint64_t seed);
 /* Returns the calling thread's cached device blocks to the driver (the prover recycles its
  * buffers between proofs; reference: VPMM pool, crates/cuda-common/src/memory_manager/). */
 int ovm_hip_trim(void);

@@ -91,6 +91,7 @@ SIGNATURES = {
     "ovm_hip_pk_preprocessed_commitment": (c_int, [c_void_p, c_uint32, c_void_p]),
     "ovm_hip_jit_compile_check": (c_int, [c_void_p, c_uint64, POINTER(ctypes.c_double), c_char_p, c_uint64]),
     "ovm_hip_staged_selftest": (c_int, [c_void_p, c_uint64, c_uint32, c_uint32, c_uint64, _u64p]),
+    "ovm_hip_host_permute_selftest": (c_int, [c_uint32, c_uint64]),
     "ovm_hip_last_error": (c_char_p, []),
     "ovm_hip_trim": (c_int, []),
     "ovm_hip_commit": (c_int, [c_void_p, c_uint32, c_void_p, c_void_p, POINTER(c_void_p), c_void_p]),

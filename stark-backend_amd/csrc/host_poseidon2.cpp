@@ -1,0 +1,137 @@
+// Host-side Poseidon2-BabyBear permutation for the Fiat-Shamir transcript: AVX2, the 16-word state in
+// two 256-bit registers of Montgomery words. Bit-identical to p2::permute (poseidon2.h); selected at
+// run time (__builtin_cpu_supports), so the library stays portable to hosts without AVX2.
+//
+// External layers: both halves through the S-box at once (x^7 = x^4 * x^3, four 8-lane Montgomery
+// products), M4 on the four lanes of each 128-bit quarter by lane rotations (y_i = S + x_i + 2 x_{i+1},
+// S = the quarter's sum), then the sum over the four quarters. Internal layers: the S-box of word 0 in
+// scalar code, the sum of all 16 words by three rotate-and-add steps, the diagonal as one 8-lane
+// product per half.
+#if !defined(__HIP_DEVICE_COMPILE__) && defined(__x86_64__)
+#ifndef OVM_HOST_FAST_PERMUTE
+#define OVM_HOST_FAST_PERMUTE 1
+#endif
+#include "poseidon2.h"
+
+#include <immintrin.h>
+
+#include <cstring>
+
+namespace p2 {
+namespace {
+
+#define OVM_AVX2 __attribute__((target("avx2"))) inline
+
+struct Tables {
+    alignas(32) uint32_t diag[16];
+    alignas(32) uint32_t rc_initial[64], rc_terminal[64];
+    Tables() {
+        // V = [-2, 1, 2, 1/2, 3, 4, -1/2, -3, -4, 1/2^8, 1/4, 1/8, 1/2^27, -1/2^8, -1/16, -1/2^27]
+        auto inv2k = [](int k) {
+            Fp x = Fp::one();
+            for (int i = 0; i < k; i++) x = x.halve();
+            return x;
+        };
+        const Fp one = Fp::one(), two = one + one, three = two + one, four = two + two;
+        const Fp v[16] = {-two,        one,       two,       inv2k(1),  three,      four,       -inv2k(1),  -three,
+                          -four,       inv2k(8),  inv2k(2),  inv2k(3),  inv2k(27),  -inv2k(8),  -inv2k(4),  -inv2k(27)};
+        for (int i = 0; i < 16; i++) diag[i] = v[i].v;
+        memcpy(rc_initial, RC_INITIAL, sizeof(rc_initial));
+        memcpy(rc_terminal, RC_TERMINAL, sizeof(rc_terminal));
+    }
+};
+const Tables &tables() {
+    static const Tables t;
+    return t;
+}
+
+OVM_AVX2 __m256i add_p(__m256i a, __m256i b) {
+    const __m256i P8 = _mm256_set1_epi32((int)bb::P);
+    const __m256i t = _mm256_add_epi32(a, b);
+    return _mm256_min_epu32(t, _mm256_sub_epi32(t, P8));
+}
+// 8 Montgomery products: even and odd lanes as 64-bit products; x - (x * M mod 2^32) * P has a zero low
+// word, its high word is xh - uh in (-P, P), corrected by min(r, r + P) as in bb::mont_mul
+OVM_AVX2 __m256i mont_mul(__m256i a, __m256i b) {
+    const __m256i P8 = _mm256_set1_epi32((int)bb::P), M8 = _mm256_set1_epi32((int)bb::MONTY_M);
+    const __m256i a_odd = _mm256_srli_epi64(a, 32), b_odd = _mm256_srli_epi64(b, 32);
+    const __m256i pe = _mm256_mul_epu32(a, b), po = _mm256_mul_epu32(a_odd, b_odd);
+    const __m256i ue = _mm256_mul_epu32(_mm256_mul_epu32(pe, M8), P8), uo = _mm256_mul_epu32(_mm256_mul_epu32(po, M8), P8);
+    const __m256i de = _mm256_sub_epi64(pe, ue), dodd = _mm256_sub_epi64(po, uo);
+    const __m256i r = _mm256_blend_epi32(_mm256_srli_epi64(de, 32), dodd, 0xAA);
+    return _mm256_min_epu32(r, _mm256_add_epi32(r, P8));
+}
+OVM_AVX2 __m256i sbox(__m256i x, __m256i rc) {
+    const __m256i s = add_p(x, rc);
+    const __m256i s2 = mont_mul(s, s), s3 = mont_mul(s2, s), s4 = mont_mul(s2, s2);
+    return mont_mul(s4, s3);
+}
+OVM_AVX2 __m256i m4(__m256i x) {
+    const __m256i r1 = _mm256_shuffle_epi32(x, 0x39), r2 = _mm256_shuffle_epi32(x, 0x4E), r3 = _mm256_shuffle_epi32(x, 0x93);
+    const __m256i sum = add_p(add_p(x, r1), add_p(r2, r3));
+    return add_p(add_p(sum, x), add_p(r1, r1));  // 2 x_i + 3 x_{i+1} + x_{i+2} + x_{i+3}
+}
+OVM_AVX2 void external_linear(__m256i &v0, __m256i &v1) {
+    v0 = m4(v0);
+    v1 = m4(v1);
+    const __m256i t = add_p(v0, v1);
+    const __m256i u = add_p(t, _mm256_permute2x128_si256(t, t, 0x01));
+    v0 = add_p(v0, u);
+    v1 = add_p(v1, u);
+}
+__attribute__((target("avx2"))) void permute_avx2(Fp *s) {
+    const Tables &t = tables();
+    __m256i v0 = _mm256_loadu_si256((const __m256i *)s), v1 = _mm256_loadu_si256((const __m256i *)(s + 8));
+    const __m256i d0 = _mm256_load_si256((const __m256i *)t.diag), d1 = _mm256_load_si256((const __m256i *)(t.diag + 8));
+    external_linear(v0, v1);
+    for (int r = 0; r < 4; r++) {
+        v0 = sbox(v0, _mm256_load_si256((const __m256i *)(t.rc_initial + 16 * r)));
+        v1 = sbox(v1, _mm256_load_si256((const __m256i *)(t.rc_initial + 16 * r + 8)));
+        external_linear(v0, v1);
+    }
+    for (int r = 0; r < 13; r++) {
+        const Fp x0 = sbox7_add(Fp::raw((uint32_t)_mm256_cvtsi256_si32(v0)), RC_INTERNAL[r]);
+        v0 = _mm256_blend_epi32(v0, _mm256_castsi128_si256(_mm_cvtsi32_si128((int)x0.v)), 0x01);
+        __m256i sum = add_p(v0, v1);
+        sum = add_p(sum, _mm256_permute2x128_si256(sum, sum, 0x01));
+        sum = add_p(sum, _mm256_shuffle_epi32(sum, 0x4E));
+        sum = add_p(sum, _mm256_shuffle_epi32(sum, 0xB1));  // every lane: the sum of all 16 words
+        v0 = add_p(mont_mul(v0, d0), sum);
+        v1 = add_p(mont_mul(v1, d1), sum);
+    }
+    for (int r = 0; r < 4; r++) {
+        v0 = sbox(v0, _mm256_load_si256((const __m256i *)(t.rc_terminal + 16 * r)));
+        v1 = sbox(v1, _mm256_load_si256((const __m256i *)(t.rc_terminal + 16 * r + 8)));
+        external_linear(v0, v1);
+    }
+    _mm256_storeu_si256((__m256i *)s, v0);
+    _mm256_storeu_si256((__m256i *)(s + 8), v1);
+}
+
+}  // namespace
+
+void host_permute(Fp *s) {
+    static const bool avx2 = __builtin_cpu_supports("avx2");
+    if (avx2) permute_avx2(s);
+    else permute(s);
+}
+
+}  // namespace p2
+
+// Self-test hook (tests/test_abi.py): 1 if the dispatcher and the scalar permutation agree on n states
+extern "C" int ovm_hip_host_permute_selftest(uint32_t n, uint64_t seed) {
+    uint64_t st = seed * 0x9E3779B97F4A7C15ull + 1;
+    for (uint32_t it = 0; it < n; it++) {
+        p2::Fp a[16], b[16];
+        for (int i = 0; i < 16; i++) {
+            st = st * 6364136223846793005ull + 1442695040888963407ull;
+            a[i] = b[i] = p2::Fp::from_canonical((uint32_t)((st >> 33) % bb::P));
+        }
+        p2::permute(a);
+        p2::host_permute(b);
+        for (int i = 0; i < 16; i++)
+            if (a[i].v != b[i].v) return 0;
+    }
+    return 1;
+}
+#endif

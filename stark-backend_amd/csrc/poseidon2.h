@@ -143,6 +143,21 @@ BB_HD void permute(Fp *s) {
     }
 }
 
+// The transcript's permutations run on the host, one after the other (a duplex sponge is sequential:
+// ~900 per config D proof, ~20 000 when a many-AIR proof absorbs its column openings). On x86 hosts
+// with AVX2 they go through an 8-lane implementation (csrc/host_poseidon2.cpp, 2.2x the scalar code);
+// the dispatcher falls back to permute() elsewhere.
+#if !defined(__HIP_DEVICE_COMPILE__) && !defined(__HIPCC_RTC__) && defined(__x86_64__) && defined(OVM_HOST_FAST_PERMUTE)
+void host_permute(Fp *s);
+#endif
+BB_HD void permute_any(Fp *s) {
+#if !defined(__HIP_DEVICE_COMPILE__) && !defined(__HIPCC_RTC__) && defined(__x86_64__) && defined(OVM_HOST_FAST_PERMUTE)
+    host_permute(s);
+#else
+    permute(s);
+#endif
+}
+
 struct Digest {
     Fp d[8];
 };
@@ -175,14 +190,14 @@ struct Sponge {
     BB_HD void observe(Fp x) {
         state[absorb_idx++] = x;
         if (absorb_idx == RATE) {
-            permute(state);
+            permute_any(state);
             absorb_idx = 0;
             sample_idx = RATE;
         }
     }
     BB_HD Fp sample() {
         if (absorb_idx != 0 || sample_idx == 0) {
-            permute(state);
+            permute_any(state);
             absorb_idx = 0;
             sample_idx = RATE;
         }

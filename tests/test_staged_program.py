@@ -47,3 +47,9 @@ def test_staged_form_on_fixture_airs(pkg):
     params["max_constraint_degree"] = 4
     blocks = pkg.staged_selftest(airs.pk_blob(params, [air]), 8, 8)
     assert blocks > 400  # 3 183 accumulations, at most 8 per block
+
+
+def test_host_transcript_permutation_matches_scalar(pkg):
+    """The Fiat-Shamir transcript's host permutation is dispatched at run time (AVX2 where available,
+    csrc/host_poseidon2.cpp); it must equal the scalar Poseidon2 on every state."""
+    assert pkg._lib().ovm_hip_host_permute_selftest(20000, 7) == 1
