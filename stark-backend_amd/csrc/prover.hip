@@ -1216,7 +1216,6 @@ struct Prover {
                 v.mats_in_a = true;
                 if (v.n_lift == 0) v.final_row = cx.download(v.mats_a.p, v.cm.total);
             }
-            cx.sync();
         }
         std::vector<EF> eq_ns{eq_uni(l_skip, xi[0], r0)};
         EF eq_sharp0 = EF::zero();
@@ -1546,6 +1545,10 @@ struct Prover {
         const unsigned s0_deg = 2 * (unsigned)(N - 1);
         std::vector<EF> s0(s0_deg + 1, EF::zero());
         ProfScope *ps_st0 = new ProfScope("stacked.round0", cx.stream);
+        // phase A: the round-0 sums of every window are enqueued (own partial records, own mailbox slots);
+        // phase B: one wait, then the host algebra per window
+        if (64 * W + 64 > Mailbox::SLOTS) throw OvmFail(801, "too many stacking windows for the mailbox");
+        std::vector<DevBuf<EF>> r0_partials(W);
         for (size_t wi = 0; wi < W; wi++) {
             Window &wd = ws[wi];
             size_t w0 = win[wi], w1 = win[wi + 1];
@@ -1569,9 +1572,15 @@ struct Prover {
             const Fp *base = commits[tvs[w0].com]->stacked_view + tvs[w0].s.col_idx * H + tvs[w0].s.row_idx;
             bool any_rot = false;
             for (auto &x : lrot) any_rot |= !is_zero(x);
+            r0_partials[wi].alloc(std::min<size_t>(RED_BLOCKS, ((size_t(1) << log_len) + RED_THREADS - 1) / RED_THREADS) * 3 * N + 64);
             OVM_THROW_IF(stacked_round0(base, (uint32_t)(w1 - w0), log_len, l_skip, d_leq.p, any_rot ? d_lrot.p : nullptr, wd.eq_cube.p,
-                                        mb.arm(partials.p), cx.stream));
-            auto R = mb.take(3 * N, cx.stream);
+                                        mb.arm(r0_partials[wi].p, 64 * wi), cx.stream));
+        }
+        if (W) mb.wait(cx.stream);
+        r0_partials.clear();
+        for (size_t wi = 0; wi < W; wi++) {
+            Window &wd = ws[wi];
+            auto R = mb.read(64 * wi, 3 * N);
             // host: chunk-aggregated vectors -> coset evaluations with the univariate factors
             std::vector<std::vector<EF>> coef(3);
             for (int v = 0; v < 3; v++) coef[v] = small_dft(std::vector<EF>(R.begin() + v * N, R.begin() + (v + 1) * N), true);
@@ -1623,7 +1632,8 @@ struct Prover {
                     cd[coff[com] + c] = ColDesc{commits[com]->stacked_view + c * H, l_skip + n_stack, 0};
             auto d_cd = cx.upload(cd);
             OVM_THROW_IF(fold_ple(d_cd.p, nullptr, (uint32_t)width, l_skip + n_stack, l_skip, d_w.p, q_a.p, cx.stream));
-            cx.sync();
+            // (no synchronisation: the temporaries go back to the block cache and are only ever reused by later
+            // work on this same stream)
         }
         // per-window tables and combined vectors
         std::vector<EF> tail_d(tvs.size(), EF::zero());  // D_i of the finished slices (see the round loop)
@@ -1668,7 +1678,7 @@ struct Prover {
                 auto d_cr = cx.upload(coef_pre(cr));
                 OVM_THROW_IF(stacked_combine(q_a.p, d_off.p, (uint32_t)(w1 - w0), wd.n_lift, d_ce.p, d_cr.p, wd.vec_a.p,
                                              wd.vec_a.p + hw, cx.stream));
-                cx.sync();
+                // (no synchronisation per window: the host prepares the next window while this one runs)
                 wd.cur_log_h = wd.n_lift;
                 wd.in_a = true;
                 if (wd.n_lift == 0) {
