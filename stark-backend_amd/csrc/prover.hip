@@ -1610,6 +1610,7 @@ struct Prover {
             for (size_t i = 0; i <= s0_deg; i++) s0[i] += p0[i] + p1[i];
         }
         delete ps_st0;
+        wt.mark("openings.stacked.round0");
         for (auto &c : s0) ts.observe_ext(c);
         std::vector<EF> u;
         EF u0 = ts.sample_ext();
@@ -1689,12 +1690,26 @@ struct Prover {
             }
         }
         delete ps_stf;
+        wt.mark("openings.stacked.setup");
         ProfScope *ps_str = new ProfScope("stacked.mle_rounds", cx.stream);
         std::vector<std::array<EF, 2>> st_polys;
         DevBuf<EF> d_gout(2 * tvs.size() + 2);
+        // per window its own partial records and 8 mailbox slots: the sums of all live windows of a round are
+        // enqueued together and waited for once
+        std::vector<DevBuf<EF>> round_partials(W);
+        for (size_t wi = 0; wi < W; wi++)
+            if (ws[wi].n_lift) round_partials[wi].alloc(std::min<size_t>(RED_BLOCKS, ((size_t(1) << (ws[wi].n_lift - 1)) + RED_THREADS - 1) / RED_THREADS) * 2 + 64);
         for (unsigned round = 1; round <= n_stack; round++) {
             std::array<EF, 2> batch{EF::zero(), EF::zero()};
             const EF *q_cur = q_in_a ? q_a.p : q_b.p;
+            bool any_window_launch = false;
+            for (size_t wi = 0; wi < W; wi++) {
+                Window &wd = ws[wi];
+                if (round > wd.n_lift) continue;
+                const EF *vec = wd.in_a ? wd.vec_a.p : wd.vec_b.p;
+                OVM_THROW_IF(stacked_round(vec, wd.cur_log_h, mb.arm(round_partials[wi].p, 8 * wi), cx.stream));
+                any_window_launch = true;
+            }
             // tail slices: gather their two entries
             std::vector<uint64_t> gidx;
             std::vector<size_t> gslice;
@@ -1713,13 +1728,12 @@ struct Prover {
                 OVM_THROW_IF(gather_ef(q_cur, d_gi.p, gidx.size(), d_gout.p, cx.stream));
                 gv = cx.download(d_gout.p, gidx.size());
             }
+            if (any_window_launch) mb.wait(cx.stream);
             size_t gi = 0;
             for (size_t wi = 0; wi < W; wi++) {
                 Window &wd = ws[wi];
                 if (round <= wd.n_lift) {
-                    const EF *vec = wd.in_a ? wd.vec_a.p : wd.vec_b.p;
-                    OVM_THROW_IF(stacked_round(vec, wd.cur_log_h, mb.arm(partials.p), cx.stream));
-                    auto sv = mb.take(2, cx.stream);
+                    auto sv = mb.read(8 * wi, 2);
                     batch[0] += sv[0];
                     batch[1] += sv[1];
                 } else {
@@ -1776,6 +1790,7 @@ struct Prover {
             }
         }
         delete ps_str;
+        wt.mark("openings.stacked.rounds");
         std::vector<EF> stacking_openings = cx.download(q_in_a ? q_a.p : q_b.p, width);
         for (auto &c : stacking_openings) ts.observe_ext(c);
         q_a.release();
