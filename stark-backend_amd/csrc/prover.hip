@@ -1770,18 +1770,34 @@ struct Prover {
                 q_in_a = !q_in_a;
                 q_log_h--;
             }
-            for (size_t wi = 0; wi < W; wi++) {
-                Window &wd = ws[wi];
-                if (wd.cur_log_h == 0) continue;
-                const EF *in = wd.in_a ? wd.vec_a.p : wd.vec_b.p;
-                EF *o = wd.in_a ? wd.vec_b.p : wd.vec_a.p;
-                OVM_THROW_IF(fold_mle(in, o, 4, wd.cur_log_h, ur, cx.stream));
-                wd.in_a = !wd.in_a;
-                wd.cur_log_h--;
-                if (wd.cur_log_h == 0) {
-                    auto fin = cx.download(o, 4);
-                    wd.eq_fin = fin[2];
-                    wd.krot_fin = fin[3];
+            {
+                // the four vectors of every live window fold in one launch (big windows on their own)
+                std::vector<FoldJob> fj;
+                for (size_t wi = 0; wi < W; wi++) {
+                    Window &wd = ws[wi];
+                    if (wd.cur_log_h == 0) continue;
+                    const EF *in = wd.in_a ? wd.vec_a.p : wd.vec_b.p;
+                    EF *o = wd.in_a ? wd.vec_b.p : wd.vec_a.p;
+                    if (wd.cur_log_h <= 11)
+                        fj.push_back(FoldJob{in, o, 4, wd.cur_log_h, fj.empty() ? 0 : fj.back().y0 + fj.back().n_cols, 0});
+                    else
+                        OVM_THROW_IF(fold_mle(in, o, 4, wd.cur_log_h, ur, cx.stream));
+                }
+                if (!fj.empty()) {
+                    auto d_fj = cx.upload(fj);
+                    OVM_THROW_IF(fold_mle_batched(d_fj.p, fj.data(), (uint32_t)fj.size(), ur, cx.stream));
+                }
+                for (size_t wi = 0; wi < W; wi++) {
+                    Window &wd = ws[wi];
+                    if (wd.cur_log_h == 0) continue;
+                    EF *o = wd.in_a ? wd.vec_b.p : wd.vec_a.p;
+                    wd.in_a = !wd.in_a;
+                    wd.cur_log_h--;
+                    if (wd.cur_log_h == 0) {
+                        auto fin = cx.download(o, 4);
+                        wd.eq_fin = fin[2];
+                        wd.krot_fin = fin[3];
+                    }
                 }
             }
             for (size_t i = 0; i < tvs.size(); i++) {
