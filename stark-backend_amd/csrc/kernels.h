@@ -161,8 +161,12 @@ int stacked_round0(const Fp *base, uint32_t n_slices, uint32_t log_len, uint32_t
                    const EF *d_lam_rot, const EF *d_eq_cube, const RedOut &ro, hipStream_t s);
 // Q[v][x] = sum_i coef_v[i] * q[(col_i * h + row_i + x)] for v in {eq, rot}
 // d_coef_*_pre: 8 words per slice = {c0, c1, c2, c3, 0, 11 c1, 11 c2, 11 c3} (Montgomery words; host: coef_pre)
+// chunks > 1: the slices are split over `chunks` workgroup rows whose partial sums go through d_scratch
+// (chunks * 2 << log_len EF) -- for short windows of thousands of slices (stacked_round0_chunks)
+uint32_t stacked_round0_chunks(uint32_t n_slices, uint32_t log_len);
 int stacked_combine(const EF *q, const uint64_t *d_slice_off, uint32_t n_slices, uint32_t log_len,
-                    const uint32_t *d_coef_eq_pre, const uint32_t *d_coef_rot_pre, EF *out_eq, EF *out_rot, hipStream_t s);
+                    const uint32_t *d_coef_eq_pre, const uint32_t *d_coef_rot_pre, EF *out_eq, EF *out_rot, EF *d_scratch,
+                    uint32_t chunks, hipStream_t s);
 // s[X-1] = sum_y Qeq(X,y) eq(X,y) + Qrot(X,y) krot(X,y), X = 1,2 ; vec = 4 columns of 2^log_h
 int stacked_round(const EF *vec4, uint32_t log_h, const RedOut &ro, hipStream_t s);
 

@@ -1572,7 +1572,7 @@ struct Prover {
             const Fp *base = commits[tvs[w0].com]->stacked_view + tvs[w0].s.col_idx * H + tvs[w0].s.row_idx;
             bool any_rot = false;
             for (auto &x : lrot) any_rot |= !is_zero(x);
-            r0_partials[wi].alloc(std::min<size_t>(RED_BLOCKS, ((size_t(1) << log_len) + RED_THREADS - 1) / RED_THREADS) * 3 * N + 64);
+            r0_partials[wi].alloc((size_t)RED_BLOCKS * 3 * N + 64);  // (grid * slice chunks <= RED_BLOCKS records)
             OVM_THROW_IF(stacked_round0(base, (uint32_t)(w1 - w0), log_len, l_skip, d_leq.p, any_rot ? d_lrot.p : nullptr, wd.eq_cube.p,
                                         mb.arm(r0_partials[wi].p, 64 * wi), cx.stream));
         }
@@ -1677,8 +1677,10 @@ struct Prover {
                 };
                 auto d_ce = cx.upload(coef_pre(ce));
                 auto d_cr = cx.upload(coef_pre(cr));
+                const uint32_t chunks = stacked_round0_chunks((uint32_t)(w1 - w0), wd.n_lift);
+                DevBuf<EF> scratch(chunks > 1 ? (size_t)chunks * 2 * hw : 0);
                 OVM_THROW_IF(stacked_combine(q_a.p, d_off.p, (uint32_t)(w1 - w0), wd.n_lift, d_ce.p, d_cr.p, wd.vec_a.p,
-                                             wd.vec_a.p + hw, cx.stream));
+                                             wd.vec_a.p + hw, scratch.p, chunks, cx.stream));
                 // (no synchronisation per window: the host prepares the next window while this one runs)
                 wd.cur_log_h = wd.n_lift;
                 wd.in_a = true;

@@ -1677,20 +1677,24 @@ __global__ __launch_bounds__(RED_THREADS) void stacked_round0_kernel(const Fp *b
     const uint64_t total = 1ull << log_len, stride = (uint64_t)gridDim.x * RED_THREADS;
     const uint64_t nx = total >> l_skip;
     EF sums[3] = {EF::zero(), EF::zero(), EF::zero()};
+    // blockIdx.y takes a chunk of the slices (the sums are linear in them): a short window with thousands of
+    // slices is otherwise a handful of lanes walking all of them one after the other
+    const uint32_t per = (n_slices + gridDim.y - 1) / gridDim.y;
+    const uint32_t i0 = blockIdx.y * per, i1 = i0 + per < n_slices ? i0 + per : n_slices;
     for (uint64_t p = (uint64_t)blockIdx.x * RED_THREADS + threadIdx.x; p < total; p += stride) {
         Acc96 le, lr;
         le.clear();
         lr.clear();
         if (lam_rot) {
 #pragma unroll 8
-            for (uint32_t i = 0; i < n_slices; i++) {
+            for (uint32_t i = i0; i < i1; i++) {
                 const uint32_t v = base[((uint64_t)i << log_len) + p].v;
                 mac_weight(le, lam_eq, i, v);
                 mac_weight(lr, lam_rot, i, v);
             }
         } else {  // no slice of this window has a rotated opening: its weights are all zero
 #pragma unroll 8
-            for (uint32_t i = 0; i < n_slices; i++) mac_weight(le, lam_eq, i, base[((uint64_t)i << log_len) + p].v);
+            for (uint32_t i = i0; i < i1; i++) mac_weight(le, lam_eq, i, base[((uint64_t)i << log_len) + p].v);
         }
         const EF qe = le.finish(), qr = lr.finish();
         uint64_t x = p >> l_skip, xp = x == 0 ? nx - 1 : x - 1;
@@ -1705,19 +1709,28 @@ __global__ __launch_bounds__(RED_THREADS) void stacked_round0_kernel(const Fp *b
         if (threadIdx.x < N) {
             EF acc = sh[threadIdx.x];
             for (uint32_t j = threadIdx.x + N; j < RED_THREADS; j += N) acc = acc + sh[j];
-            st_ef(partials + ((size_t)blockIdx.x * 3 + v) * N + threadIdx.x, acc);
+            st_ef(partials + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 3 + v) * N + threadIdx.x, acc);
         }
         __syncthreads();
     }
+}
+// slice chunks of stacked_round0 / stacked_combine for a window of 2^log_len rows: enough workgroups to
+// occupy the machine (records: grid * chunks <= RED_BLOCKS), at least 16 slices each
+uint32_t stacked_round0_chunks(uint32_t n_slices, uint32_t log_len) {
+    const uint32_t grid = red_grid(1ull << log_len);
+    uint32_t chunks = RED_BLOCKS / 2 / grid;
+    if (chunks > n_slices / 16) chunks = n_slices / 16;
+    return chunks < 1 ? 1 : chunks;
 }
 int stacked_round0(const Fp *base, uint32_t n_slices, uint32_t log_len, uint32_t l_skip, const EF *d_lam_eq,
                    const EF *d_lam_rot, const EF *d_eq_cube, const RedOut &ro, hipStream_t s) {
     if ((1u << l_skip) > RED_THREADS) return (int)hipErrorInvalidValue;
     uint32_t grid = red_grid(1ull << log_len);
-    hipLaunchKernelGGL(stacked_round0_kernel, dim3(grid), dim3(RED_THREADS), 0, s, base, n_slices, log_len, l_skip,
+    const uint32_t chunks = stacked_round0_chunks(n_slices, log_len);
+    hipLaunchKernelGGL(stacked_round0_kernel, dim3(grid, chunks), dim3(RED_THREADS), 0, s, base, n_slices, log_len, l_skip,
                        d_lam_eq, d_lam_rot, d_eq_cube, ro.partials);
     OVM_CHECK_LAUNCH();
-    return sum_partials(ro, grid, 3u << l_skip, s);
+    return sum_partials(ro, grid * chunks, 3u << l_skip, s);
 }
 
 // out_eq[x] = sum_i coef_eq[i] * q_i[x], out_rot likewise: extension-field products with wave-uniform
@@ -1739,25 +1752,52 @@ __device__ __forceinline__ void mac_ef_ef(Acc96 &acc, const CoefPre *coefs, uint
 #endif
 }
 __global__ void stacked_combine_kernel(const EF *q, const uint64_t *slice_off, uint32_t n_slices, uint32_t log_len,
-                                       const CoefPre *coef_eq, const CoefPre *coef_rot, EF *out_eq, EF *out_rot) {
+                                       const CoefPre *coef_eq, const CoefPre *coef_rot, EF *out_eq, EF *out_rot,
+                                       EF *scratch) {
     uint64_t x = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (x >= (1ull << log_len)) return;
+    // blockIdx.y takes a chunk of the slices; with more than one chunk the partial sums go to
+    // scratch[(chunk * 2 + {eq, rot}) << log_len | x] and stacked_combine_reduce_kernel adds them up
+    const uint32_t per = (n_slices + gridDim.y - 1) / gridDim.y;
+    const uint32_t i0 = blockIdx.y * per, i1 = i0 + per < n_slices ? i0 + per : n_slices;
     Acc96 ae, ar;
     ae.clear();
     ar.clear();
-    for (uint32_t i = 0; i < n_slices; i++) {
+    for (uint32_t i = i0; i < i1; i++) {
         const EF v = ld_ef(q + slice_off[i] + x);
         mac_ef_ef(ae, coef_eq, i, v);
         mac_ef_ef(ar, coef_rot, i, v);
     }
-    st_ef(out_eq + x, ae.finish());
-    st_ef(out_rot + x, ar.finish());
+    if (gridDim.y == 1) {
+        st_ef(out_eq + x, ae.finish());
+        st_ef(out_rot + x, ar.finish());
+    } else {
+        st_ef(scratch + (((uint64_t)blockIdx.y * 2) << log_len) + x, ae.finish());
+        st_ef(scratch + (((uint64_t)blockIdx.y * 2 + 1) << log_len) + x, ar.finish());
+    }
+}
+__global__ void stacked_combine_reduce_kernel(const EF *scratch, uint32_t chunks, uint32_t log_len, EF *out_eq,
+                                              EF *out_rot) {
+    uint64_t x = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (x >= (1ull << log_len)) return;
+    EF ae = EF::zero(), ar = EF::zero();
+    for (uint32_t c = 0; c < chunks; c++) {
+        ae = ae + ld_ef(scratch + (((uint64_t)c * 2) << log_len) + x);
+        ar = ar + ld_ef(scratch + (((uint64_t)c * 2 + 1) << log_len) + x);
+    }
+    st_ef(out_eq + x, ae);
+    st_ef(out_rot + x, ar);
 }
 int stacked_combine(const EF *q, const uint64_t *d_slice_off, uint32_t n_slices, uint32_t log_len,
-                    const uint32_t *d_coef_eq_pre, const uint32_t *d_coef_rot_pre, EF *out_eq, EF *out_rot, hipStream_t s) {
-    if (4ull * n_slices >= bb::P) return (int)hipErrorInvalidValue;  // (carry words stay below P)
-    hipLaunchKernelGGL(stacked_combine_kernel, dim3(ceil_div(1ull << log_len, 256)), dim3(256), 0, s, q, d_slice_off,
-                       n_slices, log_len, (const CoefPre *)d_coef_eq_pre, (const CoefPre *)d_coef_rot_pre, out_eq, out_rot);
+                    const uint32_t *d_coef_eq_pre, const uint32_t *d_coef_rot_pre, EF *out_eq, EF *out_rot, EF *d_scratch,
+                    uint32_t chunks, hipStream_t s) {
+    if (4ull * n_slices >= bb::P || chunks < 1 || (chunks > 1 && !d_scratch)) return (int)hipErrorInvalidValue;
+    const uint32_t gx = (uint32_t)ceil_div(1ull << log_len, 256);
+    hipLaunchKernelGGL(stacked_combine_kernel, dim3(gx, chunks), dim3(256), 0, s, q, d_slice_off, n_slices, log_len,
+                       (const CoefPre *)d_coef_eq_pre, (const CoefPre *)d_coef_rot_pre, out_eq, out_rot, d_scratch);
+    if (chunks > 1)
+        hipLaunchKernelGGL(stacked_combine_reduce_kernel, dim3(gx), dim3(256), 0, s, d_scratch, chunks, log_len, out_eq,
+                           out_rot);
     OVM_CHECK_LAUNCH();
     return 0;
 }
