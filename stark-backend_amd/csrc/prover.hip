@@ -595,6 +595,13 @@ struct Prover {
     // (splitting the roots of the short rounds four times finer -- 64 groups -- was measured slower:
     // batched kernel 174 -> 210 ms over the 21-segment replay sample; per-workgroup overhead dominates)
     static constexpr uint32_t MLE_GROUPS = 16;
+    // long programs are split finer: a lane's walk through its group is what a short round takes, and a
+    // 10 K-instruction program in 16 groups is 600 instructions per lane (OVM_MLE_GROUPS_MAX caps it)
+    static constexpr uint32_t MLE_GROUP_INSTRS = 128, MLE_GROUPS_MAX = 128;
+    static uint32_t mle_groups_for(size_t n_instr) {
+        static const uint32_t cap = getenv("OVM_MLE_GROUPS_MAX") ? (uint32_t)std::max(1, atoi(getenv("OVM_MLE_GROUPS_MAX"))) : MLE_GROUPS_MAX;
+        return (uint32_t)std::min<size_t>(std::max<size_t>(MLE_GROUPS, n_instr / MLE_GROUP_INSTRS), std::max(cap, MLE_GROUPS));
+    }
     static constexpr uint64_t PLANE_SKEW = 1088;  // words: 4 KiB + 256 B
     struct TracePrograms {
         Program zc, lg, leaves;
@@ -611,12 +618,12 @@ struct Prover {
             {
                 const std::vector<Root> roots = roots_zerocheck(a);
                 out[t].zc = compile_program(a, cm, pv, roots, 0);
-                if (tall) out[t].zc_g = compile_grouped(a, cm, pv, roots, 0, MLE_GROUPS);
+                if (tall) out[t].zc_g = compile_grouped(a, cm, pv, roots, 0, mle_groups_for(out[t].zc.code.size()));
             }
             if (!a.interactions.empty()) {
                 const std::vector<Root> roots = roots_logup(a);
                 out[t].lg = compile_program(a, cm, pv, roots, 0);
-                if (tall) out[t].lg_g = compile_grouped(a, cm, pv, roots, 0, MLE_GROUPS);
+                if (tall) out[t].lg_g = compile_grouped(a, cm, pv, roots, 0, mle_groups_for(out[t].lg.code.size()));
                 out[t].leaves = compile_program(a, cm, pv, roots_leaves(a), 0);
             }
         }
@@ -1239,9 +1246,11 @@ struct Prover {
             if (!d_eqr_by_nlift[tv[t].n_lift].p) d_eqr_by_nlift[tv[t].n_lift].alloc(size_t(1) << tv[t].n_lift);
             // records of 8 sums per (workgroup, group); the batched kernel's lanes enumerate (pair, point), so it can
             // run up to `degree` times the workgroups of the per-pair kernels
-            const size_t rec = std::min<size_t>(RED_BLOCKS, (((size_t)cdeg_global << (tv[t].n_lift - 1)) + RED_THREADS - 1) / RED_THREADS) * MLE_GROUPS * 8 + 64;
-            mle_partials[2 * t].alloc(rec);
-            if (!air(t).interactions.empty()) mle_partials[2 * t + 1].alloc(rec);
+            const size_t wgs = std::min<size_t>(RED_BLOCKS, (((size_t)cdeg_global << (tv[t].n_lift - 1)) + RED_THREADS - 1) / RED_THREADS);
+            // (every launcher keeps workgroups x groups within RED_BLOCKS records, or one workgroup per group)
+            auto records = [&](size_t groups) { return std::min(wgs * groups, std::max<size_t>(RED_BLOCKS, groups)); };
+            mle_partials[2 * t].alloc(records(tp[t].zc_g->gp.off.size() - 1) * 8 + 64);
+            if (!air(t).interactions.empty()) mle_partials[2 * t + 1].alloc(records(tp[t].lg_g->gp.off.size() - 1) * 8 + 64);
         }
         if (16 * T + 64 > Mailbox::SLOTS) throw OvmFail(801, "too many traces for the MLE-round mailbox");
         // Jobs of at most MLE_BATCH_MAX_WGS workgroups go into one launch per round (the late rounds
