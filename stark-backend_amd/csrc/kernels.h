@@ -60,7 +60,12 @@ struct R0Job {
     EF *out;
     EF add_const;
     uint32_t n_cols_total, log_lifted, n_cosets, gx;
-    uint32_t wg0, pad[3];
+    uint32_t wg0;
+    // a long program on a short trace is split into n_groups sub-programs (disjoint sets of accumulation
+    // roots, the sums add): workgroup bx of the job runs group bx / gx_group; progs = device array of their
+    // staged forms (n_groups == 1: `prog` alone). lds_rows = the largest num_rows among them.
+    uint32_t n_groups, gx_group, lds_rows;
+    const DevStaged *progs;
 };
 // workgroups round0_eval gives a staged program on a trace of 2^log_lifted rows
 uint32_t round0_staged_grid(const DevStaged &staged, uint32_t log_lifted);

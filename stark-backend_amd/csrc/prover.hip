@@ -562,6 +562,61 @@ struct Prover {
         return d;
     }
 
+    // A grouped program (disjoint sets of accumulation roots, the same groups the multilinear rounds use)
+    // with every group staged on its own: round 0 of a LONG program on a SHORT trace runs the groups as
+    // extra workgroups of one job instead of walking thousands of instructions in a few lanes.
+    struct StagedGroups {
+        DevBuf<uint32_t> words;
+        DevBuf<DevStaged> descs;
+        std::vector<DevStaged> host;
+        uint32_t rows = 0, max_num_rows = 0;
+    };
+    // want_groups <= the program's groups: consecutive groups are merged (their codes are self-contained, so
+    // running one after the other in a lane is the sum of their accumulations)
+    std::unique_ptr<StagedGroups> make_staged_groups(const GroupedProgram &gp, const std::vector<EF> &weights,
+                                                     uint32_t log_lifted, uint32_t n_out, size_t want_groups) {
+        const StagedPlan plan = round0_staged_plan(log_lifted, n_out, gp.max_slots);
+        const size_t src_groups = gp.off.size() - 1;
+        const size_t n_groups = std::min(src_groups, want_groups);
+        if (plan.rows == 0 || n_groups < 2) return nullptr;
+        StagedLayout layout;
+        layout.stage_rows = plan.stage_rows;
+        layout.acc_rows = plan.acc_rows;
+        auto sg = std::make_unique<StagedGroups>();
+        sg->rows = plan.rows;
+        std::vector<uint32_t> words;
+        struct Off {
+            size_t blocks, accs, code, loads, n_blocks, num_rows;
+        };
+        std::vector<Off> offs;
+        for (size_t k = 0; k < n_groups; k++) {
+            Program pg;
+            pg.code.assign(gp.code.begin() + gp.off[src_groups * k / n_groups], gp.code.begin() + gp.off[src_groups * (k + 1) / n_groups]);
+            pg.num_slots = gp.max_slots;
+            StagedProgram sp = stage_program(pg, weights, layout);
+            sp.scale_rows(plan.rows);
+            while (words.size() % 8) words.push_back(0);  // 32-byte alignment of the block / entry arrays
+            const size_t w_blocks = sp.blocks.size() * 8, w_accs = sp.accs.size() * 8, w_code = sp.code.size() * 4;
+            const size_t base = words.size();
+            words.resize(base + w_blocks + w_accs + w_code + sp.loads.size());
+            memcpy(words.data() + base, sp.blocks.data(), w_blocks * 4);
+            memcpy(words.data() + base + w_blocks, sp.accs.data(), w_accs * 4);
+            memcpy(words.data() + base + w_blocks + w_accs, sp.code.data(), w_code * 4);
+            memcpy(words.data() + base + w_blocks + w_accs + w_code, sp.loads.data(), sp.loads.size() * 4);
+            offs.push_back({base, base + w_blocks, base + w_blocks + w_accs, base + w_blocks + w_accs + w_code, sp.blocks.size(),
+                            sp.num_rows});
+            sg->max_num_rows = std::max(sg->max_num_rows, sp.num_rows);
+        }
+        sg->words = cx.upload(words);
+        const uint32_t *b = sg->words.p;
+        for (auto &o : offs)
+            sg->host.push_back(DevStaged{(const StagedBlock *)(b + o.blocks), b + o.loads, (const StagedInstr *)(b + o.code),
+                                         (const StagedAcc *)(b + o.accs), (uint32_t)o.n_blocks, (uint32_t)o.num_rows, plan.rows,
+                                         layout.stage_rows});
+        sg->descs = cx.upload(sg->host);
+        return sg;
+    }
+
     // Round-0 evaluation through the compiled kernel of the AIR when there is one, else the interpreter.
     int launch_round0(hipFunction_t fn, const DevProgram &prog, const DevStaged &staged, const Fp *lde, uint32_t n_cols_total, uint32_t log_lifted,
                       uint32_t l_skip, uint32_t n_cosets, uint32_t n_out, const EF *d_eq, EF add_const, const RedOut &ro,
@@ -936,6 +991,7 @@ struct Prover {
         struct TraceProgs {
             std::unique_ptr<ProgDev> zc, lg;
             std::unique_ptr<GroupedDev> zc_g, lg_g;
+            std::unique_ptr<StagedGroups> zc_sg, lg_sg;  // round 0 of long programs on short traces
             std::vector<EF> zc_w, lg_w;
             EF lg_const = EF::zero();
             std::vector<EF> eq3b;
@@ -959,17 +1015,39 @@ struct Prover {
         // (rows per lane, outputs) and run in one launch each after the loop: a many-AIR proof has dozens of
         // them, each a few workgroups (OVM_R0_BATCH=0: every trace its own launch).
         static constexpr uint32_t R0_BATCH_MAX_LOG = 20;
+        // (as many groups as keep the job within this many workgroups: on taller traces the lanes are there
+        // already, and the job's last workgroup sums workgroups x groups records)
+        static constexpr uint32_t R0_GROUP_JOB_WGS = 512;
         const char *r0_batch_env = getenv("OVM_R0_BATCH");
         const bool r0_batch = !(r0_batch_env && r0_batch_env[0] == '0');
         std::vector<R0Job> r0_groups[3][2];  // [log2 rows][n_out - 1]
-        auto r0_enqueue = [&](const DevStaged &staged, const Fp *lde, uint32_t n_cols_total, uint32_t log_lifted,
-                              uint32_t n_cosets, uint32_t n_out, const EF *eq_xi, EF add_const, EF *partials, size_t slot) {
-            if (!r0_batch || !staged.blocks || log_lifted >= R0_BATCH_MAX_LOG) return false;
+        // long programs (more groups than the OVM_R0_GROUPS_MIN threshold, default: more than MLE_GROUPS, i.e.
+        // > ~2 K instructions) run their groups as extra workgroups of the job
+        const uint32_t r0_groups_min = getenv("OVM_R0_GROUPS_MIN") ? (uint32_t)atoi(getenv("OVM_R0_GROUPS_MIN")) : MLE_GROUPS + 1;
+        auto r0_batchable = [&](const DevStaged &staged, uint32_t log_lifted) {
+            return r0_batch && staged.blocks && log_lifted < R0_BATCH_MAX_LOG;
+        };
+        // workgroups (= partial records) the job will use
+        auto r0_job_grid = [&](const DevStaged &staged, const StagedGroups *sg, uint32_t log_lifted) -> uint32_t {
+            if (!sg) return round0_staged_grid(staged, log_lifted);
+            DevStaged widest = sg->host[0];
+            widest.num_rows = sg->max_num_rows;
+            return round0_staged_grid(widest, log_lifted) * (uint32_t)sg->host.size();
+        };
+        auto r0_enqueue = [&](const DevStaged &staged, const StagedGroups *sg, const Fp *lde, uint32_t n_cols_total,
+                              uint32_t log_lifted, uint32_t n_cosets, uint32_t n_out, const EF *eq_xi, EF add_const,
+                              EF *partials, size_t slot) {
+            if (!r0_batchable(staged, log_lifted)) return false;
             R0Job j{};
-            j.prog = staged, j.lde = lde, j.eq_xi = eq_xi, j.partials = partials, j.out = mb.slot_ptr(slot);
+            j.prog = sg ? sg->host[0] : staged;
+            j.lde = lde, j.eq_xi = eq_xi, j.partials = partials, j.out = mb.slot_ptr(slot);
             j.add_const = add_const, j.n_cols_total = n_cols_total, j.log_lifted = log_lifted, j.n_cosets = n_cosets;
-            j.gx = round0_staged_grid(staged, log_lifted);
-            r0_groups[staged.rows == 4 ? 2 : staged.rows == 2 ? 1 : 0][n_out - 1].push_back(j);
+            j.gx = r0_job_grid(staged, sg, log_lifted);
+            j.n_groups = sg ? (uint32_t)sg->host.size() : 1;
+            j.gx_group = j.gx / j.n_groups;
+            j.lds_rows = sg ? sg->max_num_rows : staged.num_rows;
+            j.progs = sg ? sg->descs.p : nullptr;
+            r0_groups[j.prog.rows == 4 ? 2 : j.prog.rows == 2 ? 1 : 0][n_out - 1].push_back(j);
             return true;
         };
         size_t next_slot = 0;
@@ -1047,22 +1125,34 @@ struct Prover {
             const size_t red_blocks = std::min<size_t>(RED_BLOCKS, ((size_t(1) << v.log_lifted) + RED_THREADS - 1) / RED_THREADS);
             if (job.zc_cosets) {
                 OVM_PROF("round0.zerocheck", cx.stream);
-                job.zc_partials.alloc(red_blocks * job.zc_cosets * N + 64);
+                if (r0_batchable(tp[t].zc->staged, v.log_lifted) && tp[t].zc_g && tp[t].zc_g->gp.off.size() - 1 >= r0_groups_min)
+                    tp[t].zc_sg = make_staged_groups(tp[t].zc_g->gp, tp[t].zc_w, v.log_lifted, 1,
+                                                     R0_GROUP_JOB_WGS / round0_staged_grid(tp[t].zc->staged, v.log_lifted));
+                const size_t zc_records = std::max<size_t>(red_blocks, r0_batchable(tp[t].zc->staged, v.log_lifted)
+                                                                           ? r0_job_grid(tp[t].zc->staged, tp[t].zc_sg.get(), v.log_lifted)
+                                                                           : 0);
+                job.zc_partials.alloc(zc_records * job.zc_cosets * N + 64);
                 job.zc_slot = next_slot;
                 next_slot += (job.zc_cosets * N + 63) & ~size_t(63);
-                if (!r0_enqueue(tp[t].zc->staged, job.lde.p, (uint32_t)v.cm.total, v.log_lifted, job.zc_cosets, 1, job.d_eq.p,
-                                EF::zero(), job.zc_partials.p, job.zc_slot))
+                if (!r0_enqueue(tp[t].zc->staged, tp[t].zc_sg.get(), job.lde.p, (uint32_t)v.cm.total, v.log_lifted, job.zc_cosets, 1,
+                                job.d_eq.p, EF::zero(), job.zc_partials.p, job.zc_slot))
                     OVM_THROW_IF(launch_round0(jit_of(t) ? jit_of(t)->r0_zerocheck : nullptr, tp[t].zc->dev(), tp[t].zc->staged, job.lde.p,
                                                (uint32_t)v.cm.total, v.log_lifted, l_skip, job.zc_cosets, 1, job.d_eq.p, EF::zero(),
                                                mb.arm(job.zc_partials.p, job.zc_slot), d_pv[t].p, (uint32_t)red_blocks));
             }
             if (job.lg_cosets) {
                 OVM_PROF("round0.logup", cx.stream);
-                job.lg_partials.alloc(red_blocks * job.lg_cosets * 2 * N + 64);
+                if (r0_batchable(tp[t].lg->staged, v.log_lifted) && tp[t].lg_g && tp[t].lg_g->gp.off.size() - 1 >= r0_groups_min)
+                    tp[t].lg_sg = make_staged_groups(tp[t].lg_g->gp, tp[t].lg_w, v.log_lifted, 2,
+                                                     R0_GROUP_JOB_WGS / round0_staged_grid(tp[t].lg->staged, v.log_lifted));
+                const size_t lg_records = std::max<size_t>(red_blocks, r0_batchable(tp[t].lg->staged, v.log_lifted)
+                                                                           ? r0_job_grid(tp[t].lg->staged, tp[t].lg_sg.get(), v.log_lifted)
+                                                                           : 0);
+                job.lg_partials.alloc(lg_records * job.lg_cosets * 2 * N + 64);
                 job.lg_slot = next_slot;
                 next_slot += (job.lg_cosets * 2 * N + 63) & ~size_t(63);
-                if (!r0_enqueue(tp[t].lg->staged, job.lde.p, (uint32_t)v.cm.total, v.log_lifted, job.lg_cosets, 2, job.d_eq.p,
-                                tp[t].lg_const, job.lg_partials.p, job.lg_slot))
+                if (!r0_enqueue(tp[t].lg->staged, tp[t].lg_sg.get(), job.lde.p, (uint32_t)v.cm.total, v.log_lifted, job.lg_cosets, 2,
+                                job.d_eq.p, tp[t].lg_const, job.lg_partials.p, job.lg_slot))
                     OVM_THROW_IF(launch_round0(jit_of(t) ? jit_of(t)->r0_logup : nullptr, tp[t].lg->dev(), tp[t].lg->staged, job.lde.p,
                                                (uint32_t)v.cm.total, v.log_lifted, l_skip, job.lg_cosets, 2, job.d_eq.p, tp[t].lg_const,
                                                mb.arm(job.lg_partials.p, job.lg_slot), d_pv[t].p, (uint32_t)red_blocks));

@@ -597,7 +597,7 @@ struct StagedVM {
                     const Fp *cell = src(col, r);
                     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, off"
                                  :
-                                 : "s"(dst), "v"(cell)
+                                 : "s"(__builtin_amdgcn_readfirstlane(dst)), "v"(cell)
                                  : "memory", "m0");
                     dst += RED_THREADS * 4;
                 }
@@ -728,8 +728,21 @@ __global__ __launch_bounds__(RED_THREADS) void round0_staged_batched_kernel(cons
     while (j + 1 < n_jobs && blockIdx.x >= jobs[j].wg0 + jobs[j].gx) j++;
     const R0Job job = jobs[j];
     const uint32_t bx = blockIdx.x - job.wg0;
-    round0_eval_body(StagedRound0<R, NOUT>{job.prog}, job.lde, job.n_cols_total, job.log_lifted, l_skip, job.n_cosets,
-                     NOUT, job.eq_xi, job.add_const, job.partials, bx, job.gx, true);
+    const uint32_t K = (job.n_cosets * NOUT) << l_skip;
+    if (job.n_groups > 1) {
+        const uint32_t grp = bx / job.gx_group;
+#if defined(__HIP_DEVICE_COMPILE__)  // (scalar load of the group's descriptor: it feeds scalar operands of the VM)
+        const DevStaged gprog = ((const OVM_CONST_AS DevStaged *)job.progs)[grp];
+#else
+        const DevStaged gprog = job.progs[grp];
+#endif
+        round0_eval_body(StagedRound0<R, NOUT>{gprog}, job.lde, job.n_cols_total, job.log_lifted, l_skip,
+                         job.n_cosets, NOUT, job.eq_xi, grp == 0 ? job.add_const : EF::zero(),
+                         job.partials + (size_t)grp * job.gx_group * K, bx - grp * job.gx_group, job.gx_group, true);
+    } else {
+        round0_eval_body(StagedRound0<R, NOUT>{job.prog}, job.lde, job.n_cols_total, job.log_lifted, l_skip, job.n_cosets,
+                         NOUT, job.eq_xi, job.add_const, job.partials, bx, job.gx, true);
+    }
     // the job's last workgroup sums the job's records; the last job raises the flag
     __shared__ uint32_t s_last;
     __syncthreads();
@@ -737,7 +750,6 @@ __global__ __launch_bounds__(RED_THREADS) void round0_staged_batched_kernel(cons
     __syncthreads();
     if (!s_last) return;
     __threadfence();
-    const uint32_t K = (job.n_cosets * NOUT) << l_skip;
     for (uint32_t k = threadIdx.x; k < K; k += RED_THREADS) {
         EF acc = EF::zero();
         for (uint32_t b = 0; b < job.gx; b++) acc = acc + ld_ef(job.partials + (size_t)b * K + k);
@@ -763,10 +775,11 @@ int round0_eval_batched(const R0Job *d_jobs, const R0Job *h_jobs, uint32_t n_job
     for (uint32_t j = 0; j < n_jobs; j++) {
         const R0Job &job = h_jobs[j];
         if (!job.prog.blocks || job.prog.rows != rows || job.wg0 != grid || job.gx == 0 || job.n_cosets == 0 ||
-            job.n_cosets > MAX_COSETS)
+            job.n_cosets > MAX_COSETS || job.n_groups < 1 || (job.n_groups > 1 && (!job.progs || job.gx != job.gx_group * job.n_groups)) ||
+            job.lds_rows < job.prog.num_rows)
             return (int)hipErrorInvalidValue;
         grid += job.gx;
-        lds_bytes = std::max(lds_bytes, (size_t)job.prog.num_rows * rows * RED_THREADS * 4);
+        lds_bytes = std::max(lds_bytes, (size_t)job.lds_rows * rows * RED_THREADS * 4);
     }
 #define LAUNCH(R, NOUT)                                                                                                 \
     hipLaunchKernelGGL((round0_staged_batched_kernel<R, NOUT>), dim3(grid), dim3(RED_THREADS), lds_bytes, s, d_jobs, n_jobs, \

@@ -141,3 +141,27 @@ def test_unbatched_mle_round_kernels(dev, pkg, orc, monkeypatch, points, seed):
         h = 1 << int(rng.integers(l_skip + 1, 11))
         traces.append((i, rng.integers(0, airs.P, size=width * h, dtype=np.uint64).astype(np.uint32), h, []))
     _run(dev, pkg, orc, params, air_list, traces)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_round0_program_groups(dev, pkg, orc, monkeypatch, seed):
+    """Round 0 with the program split into root groups that run as extra workgroups of the batched job
+    (the path long programs take on short traces), forced here for every program with at least two
+    groups; also with two rows per lane and tiny staging buffers."""
+    monkeypatch.setenv("OVM_JIT", "0")
+    monkeypatch.setenv("OVM_R0_GROUPS_MIN", "2")
+    if seed % 2:
+        monkeypatch.setenv("OVM_R0_ROWS", "2")
+        monkeypatch.setenv("OVM_STAGE_ROWS", "3")
+        monkeypatch.setenv("OVM_ACC_ROWS", "2")
+    rng = np.random.default_rng(6000 + seed)
+    l_skip = int(rng.integers(2, 5))
+    params = airs.test_params(l_skip=l_skip, n_stack=9, k_whir=2)
+    air_list, traces = [], []
+    for i in range(3):
+        width = int(rng.integers(4, 16))
+        air_list.append(airs.random_air(rng, width, int(rng.integers(8, 50)), int(rng.integers(1, 4)), num_public_values=1))
+        h = 1 << int(rng.integers(l_skip + 1, 11))
+        traces.append((i, rng.integers(0, airs.P, size=width * h, dtype=np.uint64).astype(np.uint32), h,
+                       [int(rng.integers(0, airs.P))]))
+    _run(dev, pkg, orc, params, air_list, traces)
