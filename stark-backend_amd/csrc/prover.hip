@@ -1347,7 +1347,7 @@ struct Prover {
         // of a many-AIR proof are otherwise dozens of tiny launches serialised by the stream).
         // (OVM_MLE_BATCH=0 launches every job on its own: parity tests of the unbatched kernels on small traces)
         const char *mle_batch_env = getenv("OVM_MLE_BATCH");
-        const uint32_t MLE_BATCH_MAX_WGS = mle_batch_env && mle_batch_env[0] == '0' ? 0 : 256;
+        const uint32_t MLE_BATCH_MAX_WGS = mle_batch_env ? (uint32_t)atoi(mle_batch_env) : 256;  // (0: no batching)
         DevBuf<uint32_t> mle_counters(2 * T + 1);
         OVM_THROW_IF(hipMemsetAsync(mle_counters.p, 0, (2 * T + 1) * sizeof(uint32_t), cx.stream));
         OVM_PROF("constraints.mle_rounds", cx.stream);
