@@ -1,0 +1,68 @@
+#!/usr/bin/env python3
+"""Parity fuzzing on the GPU (test infrastructure, not collected by pytest): random multi-AIR keys and traces, random settings of the executor
+knobs (rows per lane, staging layout, batching, program groups), HIP proof bytes vs the oracle's.
+
+    python tests/fuzz_parity.py --cases 10 --seed 1      (~30 s per case: the oracle proves on the CPU)
+"""
+import argparse
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--cases", type=int, default=10)
+    ap.add_argument("--seed", type=int, default=1)
+    args = ap.parse_args()
+    os.environ["ORC_SKIP_DEBUG_ASSERTS"] = "1"
+    import importlib
+    import airs
+    import oracle_lib
+    pkg = importlib.import_module("stark-backend_amd")
+    orc = oracle_lib.load()
+    dev = pkg.Device(0)
+    rng = np.random.default_rng(args.seed)
+    knobs = {"OVM_R0_ROWS": ["", "1", "2", "4"], "OVM_STAGE_ROWS": ["", "2", "3", "8"], "OVM_ACC_ROWS": ["", "1", "4"],
+             "OVM_R0_BATCH": ["", "0"], "OVM_MLE_BATCH": ["", "0", "64"], "OVM_MLE_POINTS": ["", "0"],
+             "OVM_R0_GROUPS_MIN": ["", "2", "4"], "OVM_MLE_GROUPS_MAX": ["", "16", "32"], "OVM_JIT": ["0"]}
+    bad = 0
+    for case in range(args.cases):
+        env = {k: str(rng.choice(v)) for k, v in knobs.items()}
+        for k, v in env.items():
+            if v:
+                os.environ[k] = v
+            else:
+                os.environ.pop(k, None)
+        l_skip = int(rng.integers(1, 5))
+        deg = int(rng.choice([3, 4]))
+        params = airs.test_params(l_skip=l_skip, n_stack=int(rng.integers(8, 11)), k_whir=int(rng.integers(1, 4)))
+        params["max_constraint_degree"] = deg
+        air_list, traces = [], []
+        for i in range(int(rng.integers(1, 6))):
+            width = int(rng.integers(2, 20))
+            npv = int(rng.integers(0, 3))
+            air_list.append(airs.random_air(rng, width, int(rng.integers(0, 60)), int(rng.integers(0, 4)), max_degree=deg,
+                                            num_public_values=npv))
+            h = 1 << int(rng.integers(0, 11))
+            traces.append((i, rng.integers(0, airs.P, size=width * h, dtype=np.uint64).astype(np.uint32), h,
+                           [int(x) for x in rng.integers(0, airs.P, size=npv)]))
+        blob = airs.pk_blob(params, air_list)
+        want = orc.prove(blob, traces)["proof"]
+        pk = pkg.ProvingKey(blob)
+        dtr = [(a, dev.upload(pkg.to_mont(np.asarray(tr, dtype=np.uint32))), h, pv) for a, tr, h, pv in traces]
+        got, _ = dev.prove(pk, dtr)
+        ok = got == want
+        bad += not ok
+        print(f"case {case}: {'ok' if ok else 'MISMATCH'} airs={len(air_list)} l_skip={l_skip} deg={deg} env={ {k: v for k, v in env.items() if v} }", flush=True)
+    print(f"{args.cases - bad}/{args.cases} identical")
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()

@@ -24,14 +24,15 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
-def main():
+def main(argv=None, verify=None):
+    """verify(blob, proof): optional checker called on every proof (tests/replay_verified.py passes the oracle's
+    verifier restatement; this tool itself never touches oracle/)."""
     ap = argparse.ArgumentParser()
     ap.add_argument("--every", type=int, default=10)
     ap.add_argument("--max-log-height", type=int, default=22)
-    ap.add_argument("--verify", action="store_true", help="check every proof with the oracle's verifier restatement")
     ap.add_argument("--out", default=None)
     ap.add_argument("--segment", type=int, default=None, help="replay only this segment index, with the stage profile")
-    args = ap.parse_args()
+    args = ap.parse_args(argv)
 
     import torch
     import __graft_entry__ as ge
@@ -39,10 +40,6 @@ def main():
 
     pkg = ge._load_pkg()
     dev = pkg.Device(0)
-    orc = None
-    if args.verify:
-        import oracle_lib
-        orc = oracle_lib.load()
     segs = airs.load_reth_shapes()
     params = airs.app_params(args.max_log_height)
     params["max_constraint_degree"] = 4
@@ -69,8 +66,8 @@ def main():
             for k, v in sorted(prof.items(), key=lambda kv: -kv[1][1])[:25]:
                 print(f"   {k:32s} calls {v[0]:5d}  {v[1]:9.3f} ms", file=sys.stderr)
             print(f"   sum of profiled device time: {sum(v[1] for v in prof.values()):.1f} ms", file=sys.stderr)
-        if orc is not None:
-            orc.verify(blob, proof)
+        if verify is not None:
+            verify(blob, proof)
         total_ms += ms
         total_cells += cells
         results.append({"segment_idx": segs[si]["idx"], "num_airs": len(air_list), "main_cells": cells,
@@ -81,7 +78,7 @@ def main():
     card = {"workload": "reth-block-23992138 synthetic replay", "every": args.every,
             "max_log_height": args.max_log_height, "sampled_segments": len(picked), "total_segments": len(segs),
             "total_prove_ms": round(total_ms, 1), "total_main_cells": total_cells,
-            "cells_per_sec": round(total_cells / (total_ms / 1e3), 1), "verified": bool(args.verify),
+            "cells_per_sec": round(total_cells / (total_ms / 1e3), 1), "verified": verify is not None,
             "device": torch.cuda.get_device_name(0), "segments": results}
     text = json.dumps(card)
     if args.out:
