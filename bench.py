@@ -39,7 +39,40 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--zero-trace", action="store_true",
                     help="all-zero trace (what the reference's uniform_runner proves) instead of seeded random bits")
+    ap.add_argument("--launch-check", action="store_true",
+                    help="only start the ranks, rendezvous (gloo when there is no GPU) and print n_gpus: the launcher's CPU test")
     args = ap.parse_args()
+
+    # `python bench.py --gpus N` starts the N ranks itself: one child `torch.distributed.run` with one rank
+    # per GPU, started BEFORE this process imports torch or touches a GPU (children are fresh processes,
+    # nothing that initialised the GPU is ever re-executed); this process only waits and passes the exit
+    # code on. Under the driver's own torchrun launch RANK / WORLD_SIZE are set and must agree with --gpus.
+    if "RANK" not in os.environ and args.gpus > 1:
+        import socket
+        import subprocess
+        with socket.socket() as sock:
+            sock.bind(("127.0.0.1", 0))
+            port = sock.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        sys.exit(subprocess.run(cmd, env=env).returncode)
+    if int(os.environ.get("WORLD_SIZE", "1")) != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={os.environ.get('WORLD_SIZE', '1')}", file=sys.stderr)
+        sys.exit(2)
+    if args.launch_check:
+        import torch
+        import torch.distributed as dist
+        world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+        if world > 1:
+            dist.init_process_group("nccl" if torch.cuda.is_available() else "gloo")
+            t = torch.ones(1, device="cuda" if torch.cuda.is_available() else "cpu")
+            dist.all_reduce(t)
+            assert int(t.item()) == world
+            dist.destroy_process_group()
+        if rank == 0:
+            print(json.dumps({"launch_check": True, "n_gpus": world}), flush=True)
+        return
 
     import torch
     import __graft_entry__ as ge

@@ -184,13 +184,6 @@ void ovm_hip_pk_free(ovm_pk_t *pk);
  * must equal `vk.preprocessed_data.commit` (keygen/types.rs:99-107). hipErrorInvalidValue if the
  * AIR has none. */
 int ovm_hip_pk_preprocessed_commitment(const ovm_pk_t *pk, uint32_t air_idx, uint32_t commitment_out[8]);
-/* Generates the per-AIR constraint kernels of a key (csrc/jit.cpp: straight-line code per AIR for the
- * LogUp-GKR leaves) and compiles them with hiprtc for gfx950 WITHOUT loading them: needs no device.
- * 0 on success; `seconds` = compile time; `message` = status or the compiler log. ovm_hip_prove
- * compiles (and loads) the same code on first use only when OVM_JIT=1 is set in the environment
- * (opt-in: the built-in staged interpreter is as fast). */
-int ovm_hip_jit_compile_check(const uint32_t *blob, uint64_t words, double *seconds, char *message,
-                              uint64_t message_cap);
 /* Host-only self-test of the staged constraint-program form (csrc/program.h stage_program: what the
  * round-0 and GKR-leaf kernels execute): every program of every AIR of the key is staged with
  * `stage_rows` staging rows per buffer and `acc_rows` accumulation rows and run on one random row next
@@ -242,6 +235,26 @@ int ovm_hip_commit(const ovm_pk_t *pk, uint32_t n_traces, const ovm_trace_t *tra
  * as long as the handle. */
 int ovm_hip_commit_matrix(const ovm_pk_t *pk, const uint32_t *d_matrix, uint64_t width, uint64_t height,
                           uint32_t commitment_out[8], ovm_pcs_t **pcs_out, ovm_stream_t stream);
+/* TraceCommitter::commit exactly as the trait has it (hal.rs:84-87: `commit(&self, &[&Matrix])`, no key,
+ * no AIR indices; CUDA peer: `stacked_commit(l_skip, n_stack, log_blowup, k_whir, traces, ..)`,
+ * crates/cuda-backend/src/stacked_pcs.rs:50-88): stacks the n matrices, which MUST be sorted by height
+ * descending (stacked_pcs.rs:294), eval->coeff, RS encode, Merkle tree. The handle points into the
+ * matrices when one of them fills the stacked matrix exactly: keep them alive as long as the handle. */
+typedef struct ovm_pcs_params {
+    uint32_t l_skip, n_stack, log_blowup, k_whir;
+} ovm_pcs_params_t;
+typedef struct ovm_matrix {
+    const uint32_t *d_ptr; /* device, column-major Montgomery words */
+    uint64_t width, height; /* height a power of two */
+} ovm_matrix_t;
+int ovm_hip_commit_matrices(const ovm_pcs_params_t *params, uint32_t n, const ovm_matrix_t *mats, uint32_t commitment_out[8],
+                            ovm_pcs_t **pcs_out, ovm_stream_t stream);
+/* Exact size of the proof `ovm_hip_prove` writes for traces of these shapes (only air_idx and height of
+ * each entry are read): byte offsets of the ends of the header / GKR / batch-constraint / stacking / WHIR
+ * sections; section_ends5[4] is the proof length. The encoding has no data-dependent lengths, so buffers
+ * can be sized once and no call ever has to be repeated (reference: the buffer-size queries of
+ * crates/cuda-backend/src/cuda/logup_zerocheck.rs:152,344-352). Needs no device. */
+int ovm_hip_proof_size(const ovm_pk_t *pk, uint32_t n_traces, const ovm_trace_t *traces, uint64_t section_ends5[5]);
 void ovm_hip_pcs_free(ovm_pcs_t *pcs);
 
 /* MultiRapProver::prove_rap_constraints (hal.rs:94-112; CUDA backend: crates/cuda-backend/src/
@@ -249,7 +262,9 @@ void ovm_hip_pcs_free(ovm_pcs_t *pcs);
  * out = GkrProof bytes (gkr_len) followed by BatchConstraintProof bytes, each in the encoding of
  * proof.rs:226-421 (`GkrProof::decode` / `BatchConstraintProof::decode` read them).
  * r_out = the sumcheck point (the trait's `Artifacts = Vec<EF>`), 4 Montgomery words per element,
- * r_len elements. Synchronises the stream. */
+ * r_len elements. Synchronises the stream. If out_cap or r_cap is too small: hipErrorInvalidValue with
+ * *total_len / *r_len = the sizes needed and the sponge untouched (sizes beforehand: ovm_hip_proof_size;
+ * r_len = l_skip-independent: 1 + max over traces of max(log_height - l_skip, 0)). */
 int ovm_hip_prove_rap_constraints(const ovm_pk_t *pk, uint32_t n_traces, const ovm_trace_t *traces,
                                   ovm_sponge_t *sponge, uint8_t *out, uint64_t out_cap, uint64_t *gkr_len,
                                   uint64_t *total_len, uint32_t *r_out, uint32_t r_cap, uint32_t *r_len,
@@ -259,7 +274,8 @@ int ovm_hip_prove_rap_constraints(const ovm_pk_t *pk, uint32_t n_traces, const o
  * stacked opening reduction and WHIR over all commitments -- the common main, then per trace its
  * preprocessed commitment (from the key) and its cached mains (cpu-backend/src/device.rs:147-172).
  * out = StackingProof bytes (stacking_len) followed by WhirProof bytes. d_common_main and
- * public_values of `traces` are not read. Synchronises the stream. */
+ * public_values of `traces` are not read. Synchronises the stream. Too small an `out`: as above (sponge
+ * untouched, *total_len = the size needed). */
 int ovm_hip_prove_openings(const ovm_pk_t *pk, uint32_t n_traces, const ovm_trace_t *traces, ovm_pcs_t *common_main,
                            const uint32_t *r, uint32_t r_len, ovm_sponge_t *sponge, uint8_t *out, uint64_t out_cap,
                            uint64_t *stacking_len, uint64_t *total_len, ovm_stream_t stream);
@@ -273,8 +289,9 @@ int ovm_hip_prove_openings(const ovm_pk_t *pk, uint32_t n_traces, const ovm_trac
  *   section_offsets5 (optional): byte offsets of the ends of header / GKR / batch-constraint /
  *   stacking / WHIR sections.
  * PoW witnesses are the minimum valid ones. Synchronises the stream.
- * If proof_cap is too small: returns hipErrorInvalidValue (1) with *proof_len = the size needed and
- * the sponge untouched, so the call can simply be repeated with a larger buffer. */
+ * If proof_cap is too small: returns hipErrorInvalidValue (1) with *proof_len = the size needed, BEFORE
+ * doing any work (the proof length depends on the shapes only, see ovm_hip_proof_size); the sponge is
+ * untouched. */
 int ovm_hip_prove(const ovm_pk_t *pk, uint32_t n_traces, const ovm_trace_t *traces, ovm_sponge_t *sponge,
                   uint8_t *proof_out, uint64_t proof_cap, uint64_t *proof_len, uint64_t *section_offsets5,
                   ovm_stream_t stream);

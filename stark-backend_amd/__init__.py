@@ -44,6 +44,18 @@ class TraceStruct(Structure):
                 ("cached", c_void_p)]
 
 
+class PcsParams(Structure):
+    """``ovm_pcs_params_t``: the parameters a commitment depends on (config.rs:51-65)."""
+
+    _fields_ = [("l_skip", c_uint32), ("n_stack", c_uint32), ("log_blowup", c_uint32), ("k_whir", c_uint32)]
+
+
+class MatrixStruct(Structure):
+    """``ovm_matrix_t``: one column-major device matrix."""
+
+    _fields_ = [("d_ptr", c_void_p), ("width", c_uint64), ("height", c_uint64)]
+
+
 class SpongeState(Structure):
     """``ovm_sponge_t`` (reference: crates/cuda-backend/src/sponge.rs:39-48)."""
 
@@ -89,13 +101,14 @@ SIGNATURES = {
     "ovm_hip_pk_load": (c_int, [c_void_p, c_uint64, POINTER(c_void_p), c_void_p]),
     "ovm_hip_pk_free": (None, [c_void_p]),
     "ovm_hip_pk_preprocessed_commitment": (c_int, [c_void_p, c_uint32, c_void_p]),
-    "ovm_hip_jit_compile_check": (c_int, [c_void_p, c_uint64, POINTER(ctypes.c_double), c_char_p, c_uint64]),
     "ovm_hip_staged_selftest": (c_int, [c_void_p, c_uint64, c_uint32, c_uint32, c_uint64, _u64p]),
     "ovm_hip_host_permute_selftest": (c_int, [c_uint32, c_uint64]),
     "ovm_hip_last_error": (c_char_p, []),
     "ovm_hip_trim": (c_int, []),
     "ovm_hip_commit": (c_int, [c_void_p, c_uint32, c_void_p, c_void_p, POINTER(c_void_p), c_void_p]),
     "ovm_hip_commit_matrix": (c_int, [c_void_p, c_void_p, c_uint64, c_uint64, c_void_p, POINTER(c_void_p), c_void_p]),
+    "ovm_hip_commit_matrices": (c_int, [POINTER(PcsParams), c_uint32, c_void_p, c_void_p, POINTER(c_void_p), c_void_p]),
+    "ovm_hip_proof_size": (c_int, [c_void_p, c_uint32, c_void_p, _u64p]),
     "ovm_hip_pcs_free": (None, [c_void_p]),
     "ovm_hip_prove_rap_constraints": (c_int, [c_void_p, c_uint32, c_void_p, POINTER(SpongeState), c_void_p, c_uint64,
                                               _u64p, _u64p, c_void_p, c_uint32, _u32p, c_void_p]),
@@ -325,16 +338,30 @@ def _fail(rc, what):
     raise OvmError(rc, f"{what} [{msg.decode() if msg else ''}]")
 
 
-def _prove(self, pk: ProvingKey, traces, sponge: SpongeState | None = None, proof_cap: int = 1 << 26):
-    """Coordinator::prove on resident traces. Returns (proof bytes, section end offsets)."""
+def proof_size(pk: ProvingKey, shapes) -> list:
+    """Section end offsets (header, GKR, batch constraints, stacking, WHIR) of the proof for traces of the
+    given (air_idx, height) shapes; the last one is the proof length. Host only."""
+    arr = (TraceStruct * len(shapes))()
+    for i, (air_idx, height) in enumerate(shapes):
+        arr[i].air_idx, arr[i].height = air_idx, height
+    ends = (c_uint64 * 5)()
+    rc = _lib().ovm_hip_proof_size(pk.handle, len(shapes), arr, ends)
+    if rc != 0:
+        _fail(rc, "ovm_hip_proof_size")
+    return [int(x) for x in ends]
+
+
+def _prove(self, pk: ProvingKey, traces, sponge: SpongeState | None = None, proof_cap: int | None = None):
+    """Coordinator::prove on resident traces. Returns (proof bytes, section end offsets). The buffer is
+    sized by ovm_hip_proof_size unless `proof_cap` is given."""
     arr, keep = _trace_structs(traces)
+    if proof_cap is None:
+        proof_cap = proof_size(pk, [(t[0], t[2]) for t in traces])[4]
     out = np.zeros(proof_cap, dtype=np.uint8)
     plen = c_uint64(0)
     secs = (c_uint64 * 5)()
     rc = _lib().ovm_hip_prove(pk.handle, len(traces), arr, ctypes.byref(sponge) if sponge is not None else None,
                               out.ctypes.data, proof_cap, ctypes.byref(plen), secs, self.stream)
-    if rc != 0 and plen.value > proof_cap:  # buffer too small: the size needed came back, the sponge is untouched
-        return _prove(self, pk, traces, sponge, int(plen.value))
     if rc != 0:
         _fail(rc, "ovm_hip_prove")
     return out[:plen.value].tobytes(), [int(x) for x in secs]
@@ -364,6 +391,21 @@ def _commit_matrix(self, pk: ProvingKey, tensor, width: int, height: int) -> Pcs
     if rc != 0:
         _fail(rc, "ovm_hip_commit_matrix")
     return PcsData(h, root, keep=tensor)
+
+
+def _commit_matrices(self, params: dict, mats) -> PcsData:
+    """TraceCommitter::commit(&[&Matrix]) (hal.rs:84-87): `mats` = [(tensor, width, height)], sorted by
+    height descending; `params` needs l_skip, n_stack, log_blowup, k_whir."""
+    pp = PcsParams(params["l_skip"], params["n_stack"], params["log_blowup"], params["k_whir"])
+    arr = (MatrixStruct * len(mats))()
+    for i, (t, w, h) in enumerate(mats):
+        arr[i].d_ptr, arr[i].width, arr[i].height = t.data_ptr(), w, h
+    root = np.zeros(8, dtype=np.uint32)
+    h = c_void_p(0)
+    rc = _lib().ovm_hip_commit_matrices(ctypes.byref(pp), len(mats), arr, root.ctypes.data, ctypes.byref(h), self.stream)
+    if rc != 0:
+        _fail(rc, "ovm_hip_commit_matrices")
+    return PcsData(h, root, keep=[m[0] for m in mats])
 
 
 def _prove_rap_constraints(self, pk: ProvingKey, traces, sponge: SpongeState, cap: int = 1 << 24):
@@ -400,18 +442,10 @@ def _prove_openings(self, pk: ProvingKey, traces, pcs: PcsData, r: np.ndarray, s
 
 
 Device.commit_matrix = _commit_matrix
+Device.commit_matrices = _commit_matrices
 Device.commit_traces = _commit_traces
 Device.prove_rap_constraints = _prove_rap_constraints
 Device.prove_openings = _prove_openings
-
-
-def jit_compile_check(blob) -> tuple:
-    """(ok, seconds, message): generates and hiprtc-compiles the key's constraint kernels; no GPU needed."""
-    b = np.ascontiguousarray(blob, dtype=np.uint32)
-    secs = ctypes.c_double(0)
-    msg = ctypes.create_string_buffer(4096)
-    rc = _lib().ovm_hip_jit_compile_check(b.ctypes.data, b.size, ctypes.byref(secs), msg, len(msg))
-    return rc == 0, secs.value, msg.value.decode(errors="replace")
 
 
 def staged_selftest(blob, stage_rows: int, acc_rows: int, seed: int = 1) -> int:

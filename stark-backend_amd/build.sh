@@ -8,19 +8,6 @@ obj="$here/build"
 mkdir -p "$obj"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 FLAGS=(--offload-arch=gfx950 -O3 -std=c++17 -fPIC -DOVM_HOST_FAST_PERMUTE=1 -I"$here/../include" -I"$src" -Wall -Wno-unused-function -Wno-unused-variable -Wno-unused-result)
-# headers the run-time compiler (csrc/jit.cpp, hiprtc) needs, embedded as raw string literals
-emb="$src/embedded_headers.inc"
-tmp="$emb.tmp"
-{
-  echo "// generated by build.sh -- do not edit"
-  for h in bb31.h device_common.h eval.cuh; do
-    sym="SRC_$(echo "$h" | tr '.' '_')"
-    printf 'static const char %s[] = R"OVMSRC(' "$sym"
-    cat "$src/$h"
-    printf ')OVMSRC";\n'
-  done
-} > "$tmp"
-if ! cmp -s "$tmp" "$emb" 2>/dev/null; then mv "$tmp" "$emb"; else rm -f "$tmp"; fi
 pids=()
 objs=()
 for f in "$src"/*.hip "$src"/*.cpp; do
@@ -33,5 +20,5 @@ for f in "$src"/*.hip "$src"/*.cpp; do
   fi
 done
 for p in "${pids[@]:-}"; do [ -n "$p" ] && wait "$p"; done
-"$HIPCC" --offload-arch=gfx950 -shared -fPIC -o "$out" "${objs[@]}" -ldl
+"$HIPCC" --offload-arch=gfx950 -shared -fPIC -o "$out" "${objs[@]}"
 echo "built $out"

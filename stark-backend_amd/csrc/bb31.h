@@ -11,22 +11,10 @@
 // 4 multiplies (a*b lo/hi, lo*M, hi(t*P)) + subtract + a 2-instruction branch-free correction
 // `min(r, r + P)`. No 64-bit compares, no vcc, no shift-add tricks (they are not cheaper here).
 #pragma once
-#if !defined(__HIPCC_RTC__)
 #include <stdint.h>
-#else  // hiprtc has no libc headers
-typedef unsigned char uint8_t;
-typedef unsigned short uint16_t;
-typedef unsigned int uint32_t;
-typedef unsigned long uint64_t;
-typedef int int32_t;
-typedef long int64_t;
-typedef __SIZE_TYPE__ size_t;
-#endif
 
 #if defined(__HIPCC__)
-#if !defined(__HIPCC_RTC__)  // hiprtc (csrc/jit.cpp) pre-includes its own runtime declarations
 #include <hip/hip_runtime.h>
-#endif
 #define BB_HD __host__ __device__ __forceinline__
 #else
 #define BB_HD inline

@@ -1,6 +1,4 @@
-// Device-side types shared by the compiled kernels (stages.hip) and the runtime-compiled
-// constraint kernels (jit.cpp embeds this header and eval.cuh into the hiprtc translation unit).
-// Nothing host-only (no std:: containers) may appear here.
+// Device-side types of the stage kernels (stages.hip). Nothing host-only (no std:: containers) here.
 #pragma once
 #include "bb31.h"
 

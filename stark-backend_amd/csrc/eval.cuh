@@ -1,6 +1,5 @@
 // Constraint-evaluation kernel bodies, parameterised by the program that evaluates one row:
-// the register-program interpreter (stages.hip) or straight-line code generated per AIR and
-// compiled at run time (jit.cpp). Device code only; embedded into the hiprtc translation unit.
+// the register-program interpreter and the staged VM (stages.hip). Device code only.
 #pragma once
 #include "device_common.h"
 

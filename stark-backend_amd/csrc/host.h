@@ -91,6 +91,14 @@ struct ProvingKey {
     std::vector<AirKey> airs;
 };
 
+// Ranges the kernels and the index arithmetic are built for (two-adicity 27 bounds every domain).
+inline void check_pcs_params(const Params &p) {
+    if (p.l_skip == 0 || p.l_skip > 10) throw OvmFail(1, "l_skip out of range (1..10)");
+    if (p.l_skip + p.n_stack + p.log_blowup > 27) throw OvmFail(1, "l_skip + n_stack + log_blowup exceeds the two-adicity 27");
+    if (p.k_whir == 0 || p.k_whir > 8 || p.k_whir > p.l_skip + p.n_stack) throw OvmFail(1, "k_whir out of range");
+    if (p.log_blowup == 0 || p.log_blowup > 8) throw OvmFail(1, "log_blowup out of range (1..8)");
+}
+
 // Flat u32 proving-key blob, see include/openvm_hip.h. Field constants are canonical.
 inline ProvingKey parse_pk_blob(const uint32_t *w, size_t n) {
     size_t i = 0;
@@ -112,7 +120,13 @@ inline ProvingKey parse_pk_blob(const uint32_t *w, size_t n) {
     p.logup_pow_bits = next();
     p.max_constraint_degree = next();
     uint32_t rounds = next();
+    if (rounds > 64) throw OvmFail(1, "pk blob: too many WHIR rounds");
     for (uint32_t r = 0; r < rounds; r++) p.whir_num_queries.push_back(next());
+    check_pcs_params(p);
+    if ((uint64_t)rounds * p.k_whir > p.l_skip + p.n_stack) throw OvmFail(1, "pk blob: WHIR rounds exceed the stacked height");
+    if (p.mu_pow_bits > 30 || p.query_phase_pow_bits > 30 || p.folding_pow_bits > 30 || p.logup_pow_bits > 30)
+        throw OvmFail(1, "pk blob: proof-of-work bits out of range");
+    if (p.max_constraint_degree > 8) throw OvmFail(1, "pk blob: max_constraint_degree out of range");
     for (int k = 0; k < 8; k++) pk.vk_pre_hash.d[k] = fp(next());
     uint32_t num_airs = next();
     for (uint32_t a = 0; a < num_airs; a++) {
@@ -168,6 +182,9 @@ inline ProvingKey parse_pk_blob(const uint32_t *w, size_t n) {
             a.preprocessed_height = next();
             if (a.preprocessed_height == 0 || (a.preprocessed_height & (a.preprocessed_height - 1)))
                 throw OvmFail(1, "preprocessed trace height");
+            if (a.preprocessed_height > (size_t(1) << (p.l_skip + p.n_stack)) ||
+                a.preprocessed_width > (n - i) / a.preprocessed_height)  // (also rules out width * height overflowing)
+                throw OvmFail(1, "pk blob: preprocessed trace larger than the blob");
             a.preprocessed_vals.resize(a.preprocessed_width * a.preprocessed_height);
             for (auto &v : a.preprocessed_vals) v = fp(next());
         }

@@ -241,7 +241,18 @@ int ovm_hip_sponge_grind(const ovm_sponge_t *sponge, uint32_t bits, uint32_t *wi
     s.sample_idx = sponge->sample_idx;
     if (s.absorb_idx >= 8 || s.sample_idx > 8) return (int)hipErrorInvalidValue;
     OVM_PROF("grind", stream);
-    static thread_local uint32_t *d_result = nullptr;
+    // one result word per (thread, device), released when the thread exits
+    struct GrindScratch {
+        uint32_t *p[16] = {};
+        ~GrindScratch() {
+            for (uint32_t *q : p)
+                if (q) (void)hipFree(q);
+        }
+    };
+    static thread_local GrindScratch scratch;
+    int dev = 0;
+    OVM_CHECK(hipGetDevice(&dev));
+    uint32_t *&d_result = scratch.p[dev & 15];
     if (!d_result) OVM_CHECK(hipMalloc(&d_result, sizeof(uint32_t)));
     // Expected 2^bits candidates per hit: scan ascending in batches of four times that (a batch holds a
     // hit with probability 1 - e^-4; the candidates above the first hit exit early), so the first batch

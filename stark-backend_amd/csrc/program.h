@@ -20,7 +20,7 @@
 namespace ovm {
 
 enum Op : uint8_t { OP_ADD = 0, OP_SUB, OP_MUL, OP_NEG, OP_ACC, OP_DEN, OP_LEAF };
-enum OperandKind : uint8_t { K_SLOT = 0, K_COL, K_CONST, K_PUBLIC /* only in programs compiled for the JIT */ };
+enum OperandKind : uint8_t { K_SLOT = 0, K_COL, K_CONST };
 
 struct Instr {
     uint8_t op, ak, bk, acc;
@@ -117,16 +117,8 @@ inline std::vector<Root> roots_leaves(const AirKey &a) {
 
 // Compiles the nodes needed by `roots` (emitted in the given order, each right after its node is
 // available). Public values are folded to constants.
-// `public_values == nullptr`: keep public values symbolic (K_PUBLIC operands, payload = index) -- the
-// program then depends on the AIR only and can be turned into code once per proving key (jit.cpp).
-inline Program compile_program_impl(const AirKey &air, const ColumnMap &cm, const std::vector<Fp> *public_values_p,
-                                    const std::vector<Root> &roots, uint32_t num_weights);
 inline Program compile_program(const AirKey &air, const ColumnMap &cm, const std::vector<Fp> &public_values,
                                const std::vector<Root> &roots, uint32_t num_weights) {
-    return compile_program_impl(air, cm, &public_values, roots, num_weights);
-}
-inline Program compile_program_impl(const AirKey &air, const ColumnMap &cm, const std::vector<Fp> *public_values_p,
-                                    const std::vector<Root> &roots, uint32_t num_weights) {
     // Only the index range [lo, n) of the DAG that the roots reach is visited (children precede their
     // parents): a group of consecutive constraints touches a small window of a big DAG, and this runs
     // once per AIR, group and proof.
@@ -190,14 +182,8 @@ inline Program compile_program_impl(const AirKey &air, const ColumnMap &cm, cons
         switch (nd.kind) {
             case N_VAR:
                 if (nd.entry == E_PUBLIC) {
-                    if (public_values_p) {
-                        kind = K_CONST;
-                        payload = public_values_p->at(nd.index).v;
-                    } else {
-                        if (nd.index >= air.num_public_values) throw OvmFail(1, "public value out of range");
-                        kind = K_PUBLIC;
-                        payload = nd.index;
-                    }
+                    kind = K_CONST;
+                    payload = public_values.at(nd.index).v;
                 } else if (nd.entry == E_MAIN) {
                     if (nd.part_index >= cm.part_width.size() || nd.index >= cm.part_width[nd.part_index] ||
                         (nd.offset && !cm.need_rot))
@@ -422,7 +408,7 @@ inline StagedProgram stage_program(const Program &p, const std::vector<FpExt> &w
             if (kind == K_SLOT) return {false, SLOT_ROW0 + payload};
             if (kind == K_COL) return {false, (uint32_t)staged_row(payload)};
             if (kind == K_CONST) return {true, payload};
-            throw OvmFail(1, "stage_program: symbolic public values are for the JIT only");
+            throw OvmFail(1, "stage_program: bad operand kind");
         };
         const Opnd a = opnd(in.ak, in.a);
         const uint32_t dst = SLOT_ROW0 + in.dst;

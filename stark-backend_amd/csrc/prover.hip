@@ -16,8 +16,8 @@
 #include <cstring>
 #include <future>
 #include <mutex>
+#include <unordered_map>
 
-#include "jit.h"
 #include "kernels.h"
 
 namespace ovm {
@@ -25,48 +25,78 @@ namespace ovm {
 // ---------------------------------------------------------------------------------------------
 // Device memory helpers
 // ---------------------------------------------------------------------------------------------
-// Caching device allocator: freed blocks go to a per-device free list instead of back to the
-// driver and are handed out again (best fit) by later requests. A proof requests the same sizes
-// every time, so after the first proof no hipMalloc / hipFree happens at all (those cost hundreds
-// of milliseconds for multi-GB buffers and synchronise the device). All work of a prover runs on
-// one stream, so reuse is stream-ordered by construction. This is the role the reference gives its
-// VPMM pool (crates/cuda-common/src/memory_manager/); `ovm_hip_trim` returns the cache to the driver.
+// Caching device allocator: freed blocks go to a free list instead of back to the driver and are
+// handed out again (best fit) by later requests. A proof requests the same sizes every time, so after
+// the first proof no hipMalloc / hipFree happens at all (those cost hundreds of milliseconds for
+// multi-GB buffers and synchronise the device). This is the role the reference gives its VPMM pool
+// (crates/cuda-common/src/memory_manager/); `ovm_hip_trim` returns the cache to the driver.
+//
+// Free lists are per (thread, device): all work of a prover runs on one stream, so a block is reused
+// in stream order by construction. WHO owns a live block and how big it is lives in one process-wide
+// registry, so a block freed on another thread than the one that allocated it (a key or PCS handle
+// dropped elsewhere) is recognised, released to the driver with its true size forgotten nowhere, and
+// never enters a free list under a stale size. A thread's cached blocks go back to the driver when
+// the thread exits.
+struct BlockCache;
+struct BlockRegistry {
+    std::mutex mu;
+    std::unordered_map<void *, std::pair<size_t, const BlockCache *>> live;
+    static BlockRegistry &get() {
+        static BlockRegistry *r = new BlockRegistry();  // (leaked on purpose: thread-exit destructors may run late)
+        return *r;
+    }
+};
 struct BlockCache {
     std::multimap<size_t, void *> free_blocks;  // size -> ptr
-    std::map<void *, size_t> live;
     size_t cached_bytes = 0;
+    // upper bound on the bytes this cache may hold in free blocks (0 = unbounded); see ovm_hip_set_cache_limit
+    size_t limit_bytes = 0;
+    ~BlockCache() { trim(); }
     void *get(size_t bytes) {
         bytes = (bytes + 255) & ~size_t(255);
         auto it = free_blocks.lower_bound(bytes);
+        void *p = nullptr;
+        size_t sz = bytes;
         if (it != free_blocks.end() && it->first <= bytes + bytes / 8 + 4096) {
-            void *p = it->second;
-            size_t sz = it->first;
+            p = it->second;
+            sz = it->first;
             free_blocks.erase(it);
             cached_bytes -= sz;
-            live[p] = sz;
-            return p;
+        } else {
+            hipError_t e = hipMalloc(&p, bytes);
+            if (e != hipSuccess) {
+                trim();
+                e = hipMalloc(&p, bytes);
+            }
+            if (e != hipSuccess) throw OvmFail((int)e, "hipMalloc");
         }
-        void *p = nullptr;
-        hipError_t e = hipMalloc(&p, bytes);
-        if (e != hipSuccess) {
-            trim();
-            e = hipMalloc(&p, bytes);
-        }
-        if (e != hipSuccess) throw OvmFail((int)e, "hipMalloc");
-        live[p] = bytes;
+        BlockRegistry &reg = BlockRegistry::get();
+        std::lock_guard<std::mutex> lk(reg.mu);
+        reg.live[p] = {sz, this};
         return p;
     }
     void put(void *p) {
-        auto it = live.find(p);
-        if (it == live.end()) {
-            (void)hipFree(p);  // allocated through another thread's cache (a key freed off-thread)
+        size_t sz = 0;
+        const BlockCache *owner = nullptr;
+        {
+            BlockRegistry &reg = BlockRegistry::get();
+            std::lock_guard<std::mutex> lk(reg.mu);
+            auto it = reg.live.find(p);
+            if (it != reg.live.end()) {
+                sz = it->second.first;
+                owner = it->second.second;
+                reg.live.erase(it);
+            }
+        }
+        if (owner != this || (limit_bytes && cached_bytes + sz > limit_bytes)) {
+            (void)hipFree(p);  // another thread's block (hipFree waits for the device), or over the cache limit
             return;
         }
-        free_blocks.emplace(it->second, p);
-        cached_bytes += it->second;
-        live.erase(it);
+        free_blocks.emplace(sz, p);
+        cached_bytes += sz;
     }
     void trim() {
+        if (free_blocks.empty()) return;
         (void)hipDeviceSynchronize();
         for (auto &b : free_blocks) (void)hipFree(b.second);
         free_blocks.clear();
@@ -119,6 +149,10 @@ struct DevBuf {
 struct PinnedStage {
     char *p = nullptr;
     size_t bytes = 0, used = 0;
+    uint64_t bumps = 0;  // allocations ever made: Mailbox::wait rewinds only if none came after its arm()
+    ~PinnedStage() {
+        if (p) (void)hipHostFree(p);
+    }
     void ensure(size_t need) {
         if (need <= bytes) return;
         if (p) (void)hipHostFree(p);
@@ -138,6 +172,7 @@ struct PinnedStage {
         if (!p || used + need > bytes) return nullptr;
         void *r = p + used;
         used += need;
+        bumps++;
         return r;
     }
     void rewind() { used = 0; }
@@ -160,6 +195,11 @@ struct Mailbox {
     Page *h = nullptr, *d = nullptr;
     uint32_t *d_counter = nullptr;
     uint32_t seq = 0;
+    uint64_t bumps_at_arm = 0;  // pinned-stage allocations at the time of the last arm()
+    ~Mailbox() {
+        if (h) (void)hipHostFree(h);
+        if (d_counter) (void)hipFree(d_counter);
+    }
     void init() {
         if (h) return;
         void *hp = nullptr, *dp = nullptr;
@@ -181,6 +221,7 @@ struct Mailbox {
     RedOut arm(EF *partials, size_t slot = 0) {
         if (slot + 64 > SLOTS) throw OvmFail((int)hipErrorInvalidValue, "mailbox: slot out of range");
         ++seq;
+        bumps_at_arm = pinned_stage().bumps;
         return RedOut{partials, d_counter, d->data + slot, &d->flag, seq};
     }
     // device address of result slot `slot` (for kernels that finish several reductions, see mle_round_eval_batched)
@@ -214,7 +255,9 @@ struct Mailbox {
             }
         }
         std::atomic_thread_fence(std::memory_order_acquire);
-        pinned_stage().rewind();  // every copy issued before that reduction has completed
+        // Every copy issued before the reduction armed last has completed. A copy staged AFTER that arm() may
+        // still be queued behind the kernel: then the arena is left alone (the next synchronisation rewinds it).
+        if (pinned_stage().bumps == bumps_at_arm) pinned_stage().rewind();
     }
 };
 inline Mailbox &mailbox() {
@@ -365,11 +408,6 @@ struct WallTrace {
 struct DeviceKey {
     ProvingKey pk;
     std::vector<std::unique_ptr<PcsData>> pre;
-    // run-time compiled constraint kernels (jit.h), built on first use
-    mutable std::mutex jit_mu;
-    mutable std::shared_ptr<JitModule> jit;
-    mutable bool jit_tried = false;
-    mutable std::string jit_message;
 };
 
 struct Prover {
@@ -392,27 +430,6 @@ struct Prover {
 
     const Params &P() const { return pk.params; }
     const AirKey &air(size_t t) const { return pk.airs[traces[t].air_idx]; }
-    // Compiled constraint kernels of this key, if requested (select_jit)
-    std::shared_ptr<JitModule> jit;
-    // Run-time compiled kernels are opt-in (OVM_JIT=1): since the staged VM took over round 0 and
-    // matches the compiled GKR-leaf kernel (config D: 0.84 vs 0.78-0.81 ms, both at the HBM bound),
-    // compiling buys nothing by default and costs seconds on the first proof of a key.
-    void select_jit() {
-        const char *e = std::getenv("OVM_JIT");
-        if (!(e && *e && e[0] != '0')) return;
-        std::lock_guard<std::mutex> lk(dk.jit_mu);
-        if (!dk.jit_tried) {
-            dk.jit_tried = true;
-            dk.jit = jit_build(pk, dk.jit_message);
-            if (std::getenv("OVM_TRACE"))
-                fprintf(stderr, "[ovm] jit: %s (%.2f s)\n", dk.jit_message.c_str(), dk.jit ? dk.jit->compile_seconds : 0.0);
-        }
-        jit = dk.jit;
-    }
-    const JitKernels *jit_of(size_t t) const {
-        if (!jit) return nullptr;
-        return &jit->per_air[traces[t].air_idx];
-    }
     const PcsData *pre_of(size_t t) const {
         const uint32_t a = traces[t].air_idx;
         return a < dk.pre.size() ? dk.pre[a].get() : nullptr;
@@ -617,23 +634,6 @@ struct Prover {
         return sg;
     }
 
-    // Round-0 evaluation through the compiled kernel of the AIR when there is one, else the interpreter.
-    int launch_round0(hipFunction_t fn, const DevProgram &prog, const DevStaged &staged, const Fp *lde, uint32_t n_cols_total, uint32_t log_lifted,
-                      uint32_t l_skip, uint32_t n_cosets, uint32_t n_out, const EF *d_eq, EF add_const, const RedOut &ro,
-                      const Fp *d_pvals, uint32_t grid) {
-        // (the staged interpreter outruns the per-AIR compiled kernel wherever its LDS image fits:
-        // config D round 0 zerocheck 1.00 -> 0.50 ms, logup 0.47 -> 0.39 ms)
-        if (!fn || staged.blocks)
-            return round0_eval(prog, staged, lde, n_cols_total, log_lifted, l_skip, n_cosets, n_out, d_eq, add_const, ro, cx.stream);
-        if (n_cosets == 0) return 0;
-        EF *partials = ro.partials;
-        const EF *W = prog.weights;
-        void *args[] = {&lde, &n_cols_total, &log_lifted, &l_skip, &n_cosets, &n_out, &d_eq, &add_const, &partials, &W, &d_pvals};
-        hipError_t e = hipModuleLaunchKernel(fn, grid, 1, 1, RED_THREADS, 1, 1, 0, cx.stream, args, nullptr);
-        if (e != hipSuccess) return (int)e;
-        return sum_partials(ro, grid, n_cosets * n_out << l_skip, cx.stream);
-    }
-
     // host evaluation of a program on one row (tail rounds)
     static void host_eval(const Program &p, const std::vector<EF> &weights, const std::vector<EF> &row, EF add_const,
                           EF out[2]) {
@@ -692,15 +692,6 @@ struct Prover {
         std::vector<TracePrograms> progs = programs_future.valid() ? programs_future.get() : compile_all_programs();
         const unsigned l_skip = P().l_skip;
         const size_t N = size_t(1) << l_skip, T = traces.size();
-        select_jit();
-        // public values of each trace on the device (operands of the compiled kernels)
-        std::vector<DevBuf<Fp>> d_pv(T);
-        if (jit)
-            for (size_t t = 0; t < T; t++) {
-                std::vector<Fp> pv = traces[t].public_values;
-                if (pv.empty()) pv.push_back(Fp::zero());
-                d_pv[t] = cx.upload(pv);
-            }
         const unsigned cdeg_global = P().max_constraint_degree;
         std::vector<TraceView> tv(T);
         uint64_t total_interactions = 0;
@@ -820,19 +811,7 @@ struct Prover {
                 auto d_lb = cx.upload(leaf_base);
                 auto d_ll = cx.upload(leaf_log_len);
                 Fp norm = fp(uint64_t(1) << (tv[t].log_lifted - tv[t].log_height)).inv();
-                const JitKernels *jk = jit_of(t);
-                if (jk && jk->leaves) {
-                    auto d_bp = cx.upload(beta_pows);
-                    const ColDesc *cols = tv[t].cols.p;
-                    uint32_t lh = tv[t].log_height;
-                    const uint64_t *lb = d_lb.p;
-                    const uint32_t *ll = d_ll.p;
-                    FracPlanes lv = tree.at(n_leaves);
-                    const EF *W = d_bp.p, *LC = d_lc.p;
-                    const Fp *PV = d_pv[t].p;
-                    void *args[] = {&cols, &lh, &lb, &ll, &norm, &lv, &W, &LC, &PV};
-                    OVM_THROW_IF(hipModuleLaunchKernel(jk->leaves, ceil_div(1ull << lh, 256), 1, 1, 256, 1, 1, 0, cx.stream, args, nullptr));
-                } else {
+                {
                     // staged for one row per lane (log_lifted 0 selects that plan)
                     ProgDev pd = make_prog(std::move(progs[t].leaves), beta_pows, true, 0, 1);
                     if (pd.staged.blocks && tv[t].log_height < 20) {
@@ -1136,9 +1115,8 @@ struct Prover {
                 next_slot += (job.zc_cosets * N + 63) & ~size_t(63);
                 if (!r0_enqueue(tp[t].zc->staged, tp[t].zc_sg.get(), job.lde.p, (uint32_t)v.cm.total, v.log_lifted, job.zc_cosets, 1,
                                 job.d_eq.p, EF::zero(), job.zc_partials.p, job.zc_slot))
-                    OVM_THROW_IF(launch_round0(jit_of(t) ? jit_of(t)->r0_zerocheck : nullptr, tp[t].zc->dev(), tp[t].zc->staged, job.lde.p,
-                                               (uint32_t)v.cm.total, v.log_lifted, l_skip, job.zc_cosets, 1, job.d_eq.p, EF::zero(),
-                                               mb.arm(job.zc_partials.p, job.zc_slot), d_pv[t].p, (uint32_t)red_blocks));
+                    OVM_THROW_IF(round0_eval(tp[t].zc->dev(), tp[t].zc->staged, job.lde.p, (uint32_t)v.cm.total, v.log_lifted, l_skip,
+                                             job.zc_cosets, 1, job.d_eq.p, EF::zero(), mb.arm(job.zc_partials.p, job.zc_slot), cx.stream));
             }
             if (job.lg_cosets) {
                 OVM_PROF("round0.logup", cx.stream);
@@ -1153,9 +1131,8 @@ struct Prover {
                 next_slot += (job.lg_cosets * 2 * N + 63) & ~size_t(63);
                 if (!r0_enqueue(tp[t].lg->staged, tp[t].lg_sg.get(), job.lde.p, (uint32_t)v.cm.total, v.log_lifted, job.lg_cosets, 2,
                                 job.d_eq.p, tp[t].lg_const, job.lg_partials.p, job.lg_slot))
-                    OVM_THROW_IF(launch_round0(jit_of(t) ? jit_of(t)->r0_logup : nullptr, tp[t].lg->dev(), tp[t].lg->staged, job.lde.p,
-                                               (uint32_t)v.cm.total, v.log_lifted, l_skip, job.lg_cosets, 2, job.d_eq.p, tp[t].lg_const,
-                                               mb.arm(job.lg_partials.p, job.lg_slot), d_pv[t].p, (uint32_t)red_blocks));
+                    OVM_THROW_IF(round0_eval(tp[t].lg->dev(), tp[t].lg->staged, job.lde.p, (uint32_t)v.cm.total, v.log_lifted, l_skip,
+                                             job.lg_cosets, 2, job.d_eq.p, tp[t].lg_const, mb.arm(job.lg_partials.p, job.lg_slot), cx.stream));
             }
             if (next_slot + 4 * MAX_COSETS * N + 128 > Mailbox::SLOTS) throw OvmFail(801, "too many traces for the round-0 mailbox");
         }
@@ -2237,6 +2214,100 @@ struct Prover {
     }
 };
 
+
+// Byte offsets of the ends of the five proof sections (header, GKR, batch constraints, stacking, WHIR)
+// for traces of the given shapes: the encoding (proof.rs:226-421) has no data-dependent lengths, so the
+// size of a proof is a function of the key and the trace heights alone. `ovm_hip_proof_size` exposes it
+// so that callers size their buffers once (reference: the buffer-size queries of
+// crates/cuda-backend/src/cuda/logup_zerocheck.rs:152,344-352).
+struct ShapeIn {
+    uint32_t air_idx;
+    size_t height;
+};
+inline std::array<uint64_t, 5> proof_section_ends(const ProvingKey &pk, std::vector<ShapeIn> tr) {
+    const Params &P = pk.params;
+    std::stable_sort(tr.begin(), tr.end(), [](const ShapeIn &a, const ShapeIn &b) {
+        if (a.height != b.height) return a.height > b.height;
+        return a.air_idx < b.air_idx;
+    });
+    const unsigned l_skip = P.l_skip, n_stack = P.n_stack, k = P.k_whir;
+    const uint64_t N = uint64_t(1) << l_skip;
+    const size_t num_airs = pk.airs.size(), T = tr.size();
+    std::vector<char> present(num_airs, 0);
+    for (auto &t : tr) {
+        if (t.air_idx >= num_airs) throw OvmFail(1, "air index out of range");
+        if (present[t.air_idx]) throw OvmFail(1, "duplicate air index");
+        if (t.height == 0 || (t.height & (t.height - 1))) throw OvmFail(1, "trace height");
+        present[t.air_idx] = 1;
+    }
+    std::array<uint64_t, 5> ends{};
+    uint64_t sz = 4 + 32 + 4 + (num_airs + 7) / 8;
+    for (auto &t : tr) sz += 8 + 32 * pk.airs[t.air_idx].cached_widths.size();
+    sz += 4;
+    for (size_t a = 0; a < num_airs; a++) sz += 4 + (present[a] ? 4 * (uint64_t)pk.airs[a].num_public_values : 0);
+    ends[0] = sz;
+    // GKR
+    uint64_t total_interactions = 0;
+    unsigned n_max = 0;
+    for (auto &t : tr) {
+        const unsigned lh = log2_strict(t.height), lifted = std::max(lh, l_skip);
+        total_interactions += (uint64_t)pk.airs[t.air_idx].interactions.size() << lifted;
+        n_max = std::max(n_max, lifted - l_skip);
+    }
+    sz += 4 + 16 + 4;
+    if (total_interactions) {
+        const unsigned TR = 64 - (unsigned)__builtin_clzll(total_interactions);  // l_skip + n_logup
+        sz += 64ull * TR;
+        for (unsigned round = 1; round < TR; round++) sz += 48ull * round;
+    }
+    ends[1] = sz;
+    // batch constraints
+    const uint64_t cdeg = P.max_constraint_degree, s_deg = cdeg + 1, s0_deg = s_deg * (N - 1);
+    sz += 4 + 16 * T + 16 * T + 4 + 16 * (s0_deg + 1) + 4;
+    if (n_max) sz += 4 + 16ull * n_max * s_deg;
+    for (auto &t : tr) {
+        const AirKey &a = pk.airs[t.air_idx];
+        const uint64_t rot = a.need_rot ? 2 : 1;
+        sz += 4 + 4 + 16 * rot * a.common_main_width;
+        if (a.preprocessed_width) sz += 4 + 16 * rot * a.preprocessed_width;
+        for (size_t w : a.cached_widths) sz += 4 + 16 * rot * w;
+    }
+    ends[2] = sz;
+    // stacking: commitments = common main, then per trace preprocessed + cached mains
+    std::vector<uint64_t> widths;
+    {
+        std::vector<std::pair<size_t, unsigned>> meta;
+        for (auto &t : tr) meta.push_back({pk.airs[t.air_idx].common_main_width, log2_strict(t.height)});
+        widths.push_back(Layout(l_skip, l_skip + n_stack, meta).width);
+        for (auto &t : tr) {
+            const AirKey &a = pk.airs[t.air_idx];
+            const unsigned lh = log2_strict(t.height);
+            if (a.preprocessed_width) widths.push_back(Layout(l_skip, l_skip + n_stack, {{a.preprocessed_width, lh}}).width);
+            for (size_t w : a.cached_widths) widths.push_back(Layout(l_skip, l_skip + n_stack, {{w, lh}}).width);
+        }
+    }
+    sz += 4 + 16 * (2 * (N - 1) + 1) + 4 + 32ull * n_stack + 4;
+    for (uint64_t w : widths) sz += 4 + 16 * w;
+    ends[3] = sz;
+    // WHIR
+    const size_t n_rounds = P.whir_num_queries.size();
+    unsigned m = l_skip + n_stack, log_rs = m + P.log_blowup;
+    sz += 4 + 4 + 32ull * n_rounds * k + 4;
+    if (n_rounds) sz += 48ull * (n_rounds - 1);  // codeword commitments + out-of-domain values
+    sz += 4ull * n_rounds * k + 4ull * n_rounds + 4 + 4;
+    const uint64_t nq0 = n_rounds ? P.whir_num_queries[0] : 0;
+    if (nq0) {
+        sz += 4 + 4 * widths.size();
+        for (uint64_t w : widths) sz += ((nq0 << k) * w) * 4 + nq0 * (log_rs - k) * 32;
+    }
+    for (size_t wr = 1; wr < n_rounds; wr++) sz += 4 + (P.whir_num_queries[wr] << k) * 16 + P.whir_num_queries[wr] * (log_rs - wr - k) * 32;
+    sz += 4;
+    if (m < n_rounds * k) throw OvmFail(1, "WHIR rounds exceed the stacked height");
+    sz += 4 + (16ull << (m - n_rounds * k));
+    ends[4] = sz;
+    return ends;
+}
+
 }  // namespace ovm
 
 using namespace ovm;
@@ -2244,16 +2315,29 @@ using namespace ovm;
 static thread_local std::string g_last_error;
 
 namespace {
-std::vector<TraceIn> traces_from_abi(uint32_t n_traces, const ovm_trace_t *tr) {
+// Validation at the C boundary: every violated precondition is an error code plus a message
+// (ovm_hip_last_error), never a fault.
+inline Fp checked_word(uint32_t w, const char *what) {
+    if (w >= bb::P) throw OvmFail((int)hipErrorInvalidValue, std::string(what) + ": Montgomery word >= P");
+    return Fp::raw(w);
+}
+std::vector<TraceIn> traces_from_abi(const ProvingKey &pk, uint32_t n_traces, const ovm_trace_t *tr, bool need_data = true) {
     if (!tr) throw OvmFail((int)hipErrorInvalidValue, "traces");
     std::vector<TraceIn> in;
+    std::vector<char> seen(pk.airs.size(), 0);
     for (uint32_t t = 0; t < n_traces; t++) {
         TraceIn ti;
         ti.air_idx = tr[t].air_idx;
+        if (ti.air_idx >= pk.airs.size()) throw OvmFail((int)hipErrorInvalidValue, "air index out of range");
+        if (seen[ti.air_idx]) throw OvmFail((int)hipErrorInvalidValue, "duplicate air index");
+        seen[ti.air_idx] = 1;
+        const AirKey &air = pk.airs[ti.air_idx];
         ti.d_trace = (const Fp *)tr[t].d_common_main;
         ti.height = tr[t].height;
         if (ti.height == 0 || (ti.height & (ti.height - 1))) throw OvmFail((int)hipErrorInvalidValue, "trace height");
-        for (uint32_t i = 0; i < tr[t].num_public_values; i++) ti.public_values.push_back(Fp::raw(tr[t].public_values[i]));
+        if (need_data && !ti.d_trace && air.common_main_width) throw OvmFail((int)hipErrorInvalidValue, "d_common_main is null");
+        if (tr[t].num_public_values && !tr[t].public_values) throw OvmFail((int)hipErrorInvalidValue, "public_values is null");
+        for (uint32_t i = 0; i < tr[t].num_public_values; i++) ti.public_values.push_back(checked_word(tr[t].public_values[i], "public value"));
         for (uint32_t i = 0; i < tr[t].num_cached; i++) {
             if (!tr[t].cached || !tr[t].cached[i]) throw OvmFail((int)hipErrorInvalidValue, "cached main handle");
             ti.cached.push_back(reinterpret_cast<const PcsData *>(tr[t].cached[i]));
@@ -2264,7 +2348,8 @@ std::vector<TraceIn> traces_from_abi(uint32_t n_traces, const ovm_trace_t *tr) {
 }
 void sponge_in(Prover &pr, const ovm_sponge_t *sponge) {
     if (!sponge) return;
-    for (int i = 0; i < 16; i++) pr.ts.s.state[i] = Fp::raw(sponge->state[i]);
+    if (sponge->absorb_idx >= 8 || sponge->sample_idx > 8) throw OvmFail((int)hipErrorInvalidValue, "sponge indices");
+    for (int i = 0; i < 16; i++) pr.ts.s.state[i] = checked_word(sponge->state[i], "sponge state");
     pr.ts.s.absorb_idx = sponge->absorb_idx;
     pr.ts.s.sample_idx = sponge->sample_idx;
 }
@@ -2298,6 +2383,11 @@ int ovm_hip_pk_load(const uint32_t *blob, uint64_t words, ovm_pk_t **pk_out, ovm
         auto dk = std::make_unique<DeviceKey>();
         dk->pk = parse_pk_blob(blob, words);
         dk->pre.resize(dk->pk.airs.size());
+        // (a key without preprocessed traces is host data only: it loads without a device, which is what
+        // ovm_hip_proof_size and the host-side self-tests need)
+        bool any_pre = false;
+        for (auto &a : dk->pk.airs) any_pre |= a.preprocessed_width != 0;
+        if (any_pre && !twiddles()) return (int)hipErrorInitializationError;
         // keygen's part of the device work: upload and commit every preprocessed trace on its own
         // (keygen/mod.rs:283-300; DeviceDataTransporter::transport_pk_to_device, hal.rs:141-150)
         for (size_t a = 0; a < dk->pk.airs.size(); a++) {
@@ -2313,17 +2403,9 @@ int ovm_hip_pk_load(const uint32_t *blob, uint64_t words, ovm_pk_t **pk_out, ovm
             pcs->own_mat = std::move(dev);
             dk->pre[a] = std::move(pcs);
         }
-        // OVM_JIT=1: compile the constraint kernels now, as part of loading the key (the reference's
-        // keygen-time work), instead of inside the first proof that uses it
-        if (const char *e = std::getenv("OVM_JIT"))
-            if (e[0] == '1') {
-                std::lock_guard<std::mutex> lk(dk->jit_mu);
-                dk->jit_tried = true;
-                dk->jit = jit_build(dk->pk, dk->jit_message);
-            }
         *pk_out = reinterpret_cast<ovm_pk_t *>(dk.release());
         return 0;
-    });
+    }, false);
 }
 
 void ovm_hip_pk_free(ovm_pk_t *pk) { delete reinterpret_cast<DeviceKey *>(pk); }
@@ -2334,24 +2416,6 @@ int ovm_hip_pk_preprocessed_commitment(const ovm_pk_t *pk_, uint32_t air_idx, ui
     if (air_idx >= dk.pre.size() || !dk.pre[air_idx]) return (int)hipErrorInvalidValue;
     for (int i = 0; i < 8; i++) commitment_out[i] = dk.pre[air_idx]->root.d[i].v;
     return 0;
-}
-
-int ovm_hip_jit_compile_check(const uint32_t *blob, uint64_t words, double *seconds, char *message, uint64_t message_cap) {
-    if (!blob) return (int)hipErrorInvalidValue;
-    try {
-        ProvingKey pk = parse_pk_blob(blob, words);
-        std::string msg;
-        auto jm = jit_build(pk, msg, false);
-        if (seconds) *seconds = jm ? jm->compile_seconds : 0.0;
-        if (message && message_cap) {
-            strncpy(message, msg.c_str(), message_cap - 1);
-            message[message_cap - 1] = 0;
-        }
-        return jm ? 0 : (int)hipErrorUnknown;
-    } catch (const std::exception &e) {
-        g_last_error = e.what();
-        return (int)hipErrorInvalidValue;
-    }
 }
 
 int ovm_hip_trim(void) {
@@ -2440,14 +2504,21 @@ int ovm_hip_prove(const ovm_pk_t *pk_, uint32_t n_traces, const ovm_trace_t *tra
     if (!pk_ || !proof_len || n_traces == 0 || !traces) return (int)hipErrorInvalidValue;
     const DeviceKey &dk = *reinterpret_cast<const DeviceKey *>(pk_);
     return guarded([&]() -> int {
+        // the proof length is a function of the shapes: a buffer that is too small is refused BEFORE any work
+        {
+            std::vector<ShapeIn> sh;
+            for (uint32_t t = 0; t < n_traces; t++) sh.push_back({traces[t].air_idx, (size_t)traces[t].height});
+            const uint64_t need = proof_section_ends(dk.pk, sh)[4];
+            *proof_len = need;
+            if (need > proof_cap || !proof_out)
+                throw OvmFail((int)hipErrorInvalidValue, "proof buffer too small: " + std::to_string(need) + " bytes needed");
+        }
         Prover pr(dk, (hipStream_t)stream);
         sponge_in(pr, sponge);
-        pr.prove(traces_from_abi(n_traces, traces));
-        *proof_len = pr.out.buf.size();
+        pr.prove(traces_from_abi(dk.pk, n_traces, traces));
+        if (pr.out.buf.size() != *proof_len) throw OvmFail((int)hipErrorUnknown, "internal: proof length differs from ovm_hip_proof_size");
         if (section_offsets5)
             for (size_t i = 0; i < 5 && i < pr.section_offsets.size(); i++) section_offsets5[i] = pr.section_offsets[i];
-        if (pr.out.buf.size() > proof_cap || !proof_out)  // *proof_len holds the size needed; the sponge is untouched
-            throw OvmFail((int)hipErrorInvalidValue, "proof buffer too small: " + std::to_string(pr.out.buf.size()) + " bytes needed");
         sponge_out(pr, sponge);
         memcpy(proof_out, pr.out.buf.data(), pr.out.buf.size());
         return 0;
@@ -2460,7 +2531,7 @@ int ovm_hip_commit(const ovm_pk_t *pk_, uint32_t n_traces, const ovm_trace_t *tr
     const DeviceKey &dk = *reinterpret_cast<const DeviceKey *>(pk_);
     return guarded([&]() -> int {
         Prover pr(dk, (hipStream_t)stream);
-        pr.set_traces(traces_from_abi(n_traces, traces), false);
+        pr.set_traces(traces_from_abi(dk.pk, n_traces, traces), false);
         auto *pcs = new PcsData(pr.commit());
         pr.cx.sync();
         for (int i = 0; i < 8; i++) commitment_out[i] = pcs->root.d[i].v;
@@ -2484,6 +2555,46 @@ int ovm_hip_commit_matrix(const ovm_pk_t *pk_, const uint32_t *d_matrix, uint64_
     });
 }
 
+int ovm_hip_commit_matrices(const ovm_pcs_params_t *params, uint32_t n, const ovm_matrix_t *mats, uint32_t commitment_out[8],
+                            ovm_pcs_t **pcs_out, ovm_stream_t stream) {
+    if (!params || !mats || n == 0 || !commitment_out || !pcs_out) return (int)hipErrorInvalidValue;
+    return guarded([&]() -> int {
+        DeviceKey dk;  // only the PCS parameters of a key matter to a commitment
+        dk.pk.params.l_skip = params->l_skip;
+        dk.pk.params.n_stack = params->n_stack;
+        dk.pk.params.log_blowup = params->log_blowup;
+        dk.pk.params.k_whir = params->k_whir;
+        check_pcs_params(dk.pk.params);
+        std::vector<Prover::MatIn> in;
+        for (uint32_t i = 0; i < n; i++) {
+            const ovm_matrix_t &m = mats[i];
+            if (m.height == 0 || (m.height & (m.height - 1))) throw OvmFail((int)hipErrorInvalidValue, "matrix height");
+            if (m.width && !m.d_ptr) throw OvmFail((int)hipErrorInvalidValue, "matrix pointer is null");
+            if (i && m.height > mats[i - 1].height)  // (stacked_pcs.rs:294: "must already be in height-sorted order")
+                throw OvmFail((int)hipErrorInvalidValue, "matrices must be sorted by height, descending");
+            in.push_back({(const Fp *)m.d_ptr, (size_t)m.width, (size_t)m.height});
+        }
+        Prover pr(dk, (hipStream_t)stream);
+        auto *pcs = new PcsData(pr.commit_mats(in));
+        pr.cx.sync();
+        for (int i = 0; i < 8; i++) commitment_out[i] = pcs->root.d[i].v;
+        *pcs_out = reinterpret_cast<ovm_pcs_t *>(pcs);
+        return 0;
+    });
+}
+
+int ovm_hip_proof_size(const ovm_pk_t *pk_, uint32_t n_traces, const ovm_trace_t *traces, uint64_t section_ends5[5]) {
+    if (!pk_ || !traces || n_traces == 0 || !section_ends5) return (int)hipErrorInvalidValue;
+    const DeviceKey &dk = *reinterpret_cast<const DeviceKey *>(pk_);
+    return guarded([&]() -> int {
+        std::vector<ShapeIn> sh;
+        for (uint32_t t = 0; t < n_traces; t++) sh.push_back({traces[t].air_idx, (size_t)traces[t].height});
+        const auto ends = proof_section_ends(dk.pk, sh);
+        for (int i = 0; i < 5; i++) section_ends5[i] = ends[i];
+        return 0;
+    }, false);
+}
+
 void ovm_hip_pcs_free(ovm_pcs_t *pcs) { delete reinterpret_cast<PcsData *>(pcs); }
 
 int ovm_hip_prove_rap_constraints(const ovm_pk_t *pk_, uint32_t n_traces, const ovm_trace_t *traces,
@@ -2495,14 +2606,17 @@ int ovm_hip_prove_rap_constraints(const ovm_pk_t *pk_, uint32_t n_traces, const 
     return guarded([&]() -> int {
         Prover pr(dk, (hipStream_t)stream);
         sponge_in(pr, sponge);
-        pr.set_traces(traces_from_abi(n_traces, traces));
+        pr.set_traces(traces_from_abi(dk.pk, n_traces, traces));
         std::vector<EF> r = pr.prove_rap_constraints();
         pr.cx.sync();
-        sponge_out(pr, sponge);
         if (gkr_len) *gkr_len = pr.section_offsets.empty() ? 0 : pr.section_offsets[0];
         *total_len = pr.out.buf.size();
         *r_len = (uint32_t)r.size();
-        if (pr.out.buf.size() > out_cap || !out || r.size() > r_cap || !r_out) return (int)hipErrorInvalidValue;
+        // too small: the sizes needed are in *total_len / *r_len and the caller's sponge is untouched, so the
+        // call can be repeated (ovm_hip_proof_size gives the sizes beforehand)
+        if (pr.out.buf.size() > out_cap || !out || r.size() > r_cap || !r_out)
+            throw OvmFail((int)hipErrorInvalidValue, "output buffer too small");
+        sponge_out(pr, sponge);
         memcpy(out, pr.out.buf.data(), pr.out.buf.size());
         for (size_t i = 0; i < r.size(); i++)
             for (int k = 0; k < 4; k++) r_out[4 * i + k] = r[i].c[k].v;
@@ -2518,16 +2632,16 @@ int ovm_hip_prove_openings(const ovm_pk_t *pk_, uint32_t n_traces, const ovm_tra
     return guarded([&]() -> int {
         Prover pr(dk, (hipStream_t)stream);
         sponge_in(pr, sponge);
-        pr.set_traces(traces_from_abi(n_traces, traces), false);
+        pr.set_traces(traces_from_abi(dk.pk, n_traces, traces, false), false);
         std::vector<EF> rv(r_len);
         for (uint32_t i = 0; i < r_len; i++)
-            for (int k = 0; k < 4; k++) rv[i].c[k] = Fp::raw(r[4 * i + k]);
+            for (int k = 0; k < 4; k++) rv[i].c[k] = checked_word(r[4 * i + k], "r");
         pr.prove_openings(*reinterpret_cast<const PcsData *>(common_main), rv);
         pr.cx.sync();
-        sponge_out(pr, sponge);
         if (stacking_len) *stacking_len = pr.section_offsets.empty() ? 0 : pr.section_offsets[0];
         *total_len = pr.out.buf.size();
-        if (pr.out.buf.size() > out_cap || !out) return (int)hipErrorInvalidValue;
+        if (pr.out.buf.size() > out_cap || !out) throw OvmFail((int)hipErrorInvalidValue, "output buffer too small");
+        sponge_out(pr, sponge);
         memcpy(out, pr.out.buf.data(), pr.out.buf.size());
         return 0;
     });

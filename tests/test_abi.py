@@ -38,12 +38,3 @@ def test_missing_library_fails_loudly(pkg, monkeypatch):
     monkeypatch.setattr(pkg, "LIB_PATH", "/nonexistent/libopenvm_hip.so")
     with pytest.raises(ImportError):
         pkg.lib()
-
-
-def test_jit_code_generation_compiles_without_a_device(pkg):
-    """csrc/jit.cpp: the per-AIR constraint kernels generated for a key compile with hiprtc for
-    gfx950 (no GPU involved: nothing is loaded or launched)."""
-    import airs
-    blob = airs.pk_blob(airs.test_params(), [airs.fibonacci_air(), airs.dummy_interaction_air(2, True, 0)])
-    ok, seconds, message = pkg.jit_compile_check(blob)
-    assert ok, message

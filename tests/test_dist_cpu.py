@@ -43,3 +43,21 @@ def test_max_over_ranks_world2():
 
 def test_max_over_ranks_single_process(pkg):
     assert pkg.max_over_ranks(3.5) == 3.5
+
+
+def test_bench_launcher_starts_n_ranks():
+    """`python bench.py --gpus 2` itself starts two ranks (gloo here): n_gpus comes from real ranks, and a
+    --gpus that disagrees with WORLD_SIZE is refused."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--launch-check"], env=env,
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    assert json.loads(line) == {"launch_check": True, "n_gpus": 2}
+    bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "3", "--launch-check"],
+                         env=dict(env, RANK="0", WORLD_SIZE="2"), capture_output=True, text=True, timeout=120)
+    assert bad.returncode == 2 and "WORLD_SIZE" in bad.stderr

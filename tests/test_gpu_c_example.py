@@ -26,7 +26,7 @@ def test_plain_c_caller(dev, pkg, orc, tmp_path):
     tr = airs.splitmix64_bits(0xD15EA5E, 20 * h).astype(np.uint32)
     blob.astype("<u4").tofile(tmp_path / "key.u32")
     tr.astype("<u4").tofile(tmp_path / "trace.u32")
-    env = dict(os.environ, OVM_JIT="0")
+    env = dict(os.environ)
     out = subprocess.run([str(exe), str(tmp_path / "key.u32"), str(tmp_path / "trace.u32"), "0", str(h),
                           str(tmp_path / "proof.bin")], capture_output=True, text=True, env=env, timeout=120)
     assert out.returncode == 0, out.stderr

@@ -47,8 +47,6 @@ def test_random_single_air(dev, pkg, orc, seed):
 @pytest.mark.parametrize("seed", range(10))
 def test_random_multi_air(dev, pkg, orc, seed, monkeypatch):
     rng = np.random.default_rng(2000 + seed)
-    if seed % 2:
-        monkeypatch.setenv("OVM_JIT", "1")  # the compiled kernels on generic values as well
     params = airs.test_params(l_skip=int(rng.integers(2, 4)), n_stack=7, k_whir=2)
     air_list, traces = [], []
     for i in range(int(rng.integers(2, 5))):
@@ -76,7 +74,6 @@ def test_staged_interpreter_layouts(dev, pkg, orc, monkeypatch, stage, acc, rows
     layouts: tiny staging buffers and accumulation lists (a block boundary every instruction or two),
     1 / 2 / 4 trace rows per lane. Wider AIRs with more constraints than the cases above so that
     programs span many blocks."""
-    monkeypatch.setenv("OVM_JIT", "0")
     monkeypatch.setenv("OVM_STAGE_ROWS", str(stage))
     monkeypatch.setenv("OVM_ACC_ROWS", str(acc))
     monkeypatch.setenv("OVM_R0_ROWS", str(rows))
@@ -98,7 +95,6 @@ def test_many_live_slots(dev, pkg, orc, monkeypatch, live):
     constraint and consumed by the second, so the register program needs that many slots. 20 fits
     the staged VM's default LDS image, 40 its last-resort 56 KiB image, 70 and 200 fall back to the plain
     interpreter (slots in private memory, NS 128 / 512)."""
-    monkeypatch.setenv("OVM_JIT", "0")
     rng = np.random.default_rng(4000 + live)
     width = 8
     a = airs.Air("ManyLiveSlots", width)
@@ -148,7 +144,6 @@ def test_round0_program_groups(dev, pkg, orc, monkeypatch, seed):
     """Round 0 with the program split into root groups that run as extra workgroups of the batched job
     (the path long programs take on short traces), forced here for every program with at least two
     groups; also with two rows per lane and tiny staging buffers."""
-    monkeypatch.setenv("OVM_JIT", "0")
     monkeypatch.setenv("OVM_R0_GROUPS_MIN", "2")
     if seed % 2:
         monkeypatch.setenv("OVM_R0_ROWS", "2")

@@ -1,0 +1,103 @@
+"""Byte / element parity against the CPU oracle AT THE BASELINE SIZES (the paths only the big
+shapes reach -- two strided radix-16 NTT passes, the width-25 row hash on 2^25 rows, the unbatched
+multilinear-round kernels, the plane-0-only GKR leaf layer -- had only property checks).
+The oracle runs on the GPU box's host cores; sizes are chosen so the whole file stays within minutes."""
+import os
+import time
+
+import numpy as np
+import pytest
+
+import airs
+
+pytestmark = pytest.mark.gpu
+P = 2013265921
+
+
+def _bits_trace(pkg, dev, n, seed=0xD15EA5E):
+    """Seeded boolean cells on the device (Montgomery words) and the same cells, canonical, on the host."""
+    import torch
+    gen = torch.Generator(device="cuda:0")
+    gen.manual_seed(seed)
+    bits = torch.randint(0, 2, (n,), dtype=torch.int32, device="cuda:0", generator=gen)
+    host = bits.cpu().numpy().astype(np.uint32)
+    return bits * int(pkg.to_mont(np.array([1], dtype=np.uint32))[0]), host
+
+
+@pytest.mark.parametrize("log_n,log_n_in", [(22, 22), (25, 24)])
+def test_ntt_dif_large_vs_oracle(dev, pkg, orc, log_n, log_n_in):
+    """ovm_hip_ntt_dif at L = 22 (full input) and L = 25 with a zero-padded 2^24 input (the RS encode of
+    config D: three radix-16 passes, two of them strided) against the oracle's DFT, element for element."""
+    rng = np.random.default_rng(100 + log_n)
+    n, n_in = 1 << log_n, 1 << log_n_in
+    a = rng.integers(0, P, size=n_in, dtype=np.uint64).astype(np.uint32)
+    d = dev.upload(pkg.to_mont(a))
+    out = dev.empty(n)
+    dev.ntt_dif(d, out, 1, log_n, log_n_in=log_n_in)
+    got = pkg.from_mont(dev.download(out))
+    padded = np.concatenate([a, np.zeros(n - n_in, np.uint32)])
+    want = orc.dft(padded)
+    perm = pkg.bitrev(np.arange(n), log_n).astype(np.int64)
+    assert np.array_equal(got, want[perm])
+
+
+def test_config_d_commit_root_vs_oracle(dev, pkg, orc):
+    """The config D commitment itself (2^22 x 100 = stacked 2^24 x 25, blowup 2, k_whir 4): root of
+    ovm_hip_commit == root of the oracle's rs_code_matrix + merkle_tree over the same cells."""
+    params = airs.app_params(24)
+    pk = pkg.ProvingKey(airs.pk_blob(params, [airs.uniform_runner_air(100)]))
+    h = 1 << 22
+    trace, host = _bits_trace(pkg, dev, 100 * h)
+    pcs = dev.commit_traces(pk, [(0, trace, h, [])])
+    got = pkg.from_mont(pcs.root)
+    pcs.free()
+    t0 = time.time()
+    # 100 columns of 2^22 rows, column-major, ARE the 25 stacked columns of 2^24 rows
+    code = orc.rs_code_matrix(4, 1, host, 25, 1 << 24)
+    layers = orc.merkle_tree(code, 25, 1 << 25, 16)
+    print(f"oracle commit of 2^24 x 25: {time.time() - t0:.1f} s")
+    assert np.array_equal(got, layers[-1][0])
+    pkg._lib().ovm_hip_trim()
+
+
+def _prove_both(dev, pkg, orc, log_rows, cols, log_stacked):
+    params = airs.app_params(log_stacked)
+    blob = airs.pk_blob(params, [airs.uniform_runner_air(cols)])
+    pk = pkg.ProvingKey(blob)
+    h = 1 << log_rows
+    trace, host = _bits_trace(pkg, dev, cols * h)
+    got, _ = dev.prove(pk, [(0, trace, h, [])])
+    t0 = time.time()
+    want = orc.prove(blob, [(0, host, h, [])])["proof"]
+    dt = time.time() - t0
+    orc.verify(blob, got)
+    return got, want, dt
+
+
+def test_benchmark_air_2_20_x_100_byte_identical(dev, pkg, orc):
+    """uniform_runner BenchmarkAir, 2^20 rows x 100 columns, app parameters with log_stacked_height 22:
+    the HIP proof equals the oracle's proof byte for byte (2^25-leaf GKR tree with the plane-0-only leaf
+    layer, unbatched multilinear rounds, two-pass NTT)."""
+    got, want, dt = _prove_both(dev, pkg, orc, 20, 100, 22)
+    print(f"oracle prove of 2^20 x 100: {dt:.1f} s")
+    assert got == want
+
+
+@pytest.mark.skipif(not os.environ.get("OVM_FULL_PARITY"), reason="minutes of host time: set OVM_FULL_PARITY=1")
+def test_config_d_full_byte_identical(dev, pkg, orc):
+    """The headline configuration itself, byte for byte (result of the last run: profiles/r02/)."""
+    got, want, dt = _prove_both(dev, pkg, orc, 22, 100, 24)
+    print(f"oracle prove of 2^22 x 100: {dt:.1f} s; proof {len(got)} bytes; identical: {got == want}")
+    assert got == want
+
+
+def test_fibonacci_2_12_config_a(dev, pkg, orc):
+    """BASELINE config A at its stated size: Fibonacci AIR, 2^12 rows, app parameters (log_stacked_height 12)."""
+    params = airs.app_params(12)
+    blob = airs.pk_blob(params, [airs.fibonacci_air()])
+    tr, pvs = airs.fibonacci_trace(0, 1, 1 << 12)
+    want = orc.prove(blob, [(0, tr, 1 << 12, pvs)])["proof"]
+    pk = pkg.ProvingKey(blob)
+    got, _ = dev.prove(pk, [(0, dev.upload(pkg.to_mont(np.asarray(tr, dtype=np.uint32))), 1 << 12, pvs)])
+    assert got == want
+    orc.verify(blob, got)

@@ -122,6 +122,13 @@ def test_gkr_three_point_fallback(dev, pkg, orc, monkeypatch):
     run_case(dev, pkg, orc, params, [airs.uniform_runner_air(20)], [(0, tr, h, [])])
 
 
+def sponge_before_openings(pkg, orc, raw):
+    import ctypes
+    s = pkg.SpongeState()
+    ctypes.memmove(ctypes.byref(s), raw, len(raw))
+    return s
+
+
 def test_stage_level_entries_match_monolithic(dev, pkg, orc):
     """commit / prove_rap_constraints / prove_openings (the three hal.rs traits) driven by a
     coordinator on the caller's side -- here prover/mod.rs:110-175 restated on the oracle's
@@ -139,6 +146,7 @@ def test_stage_level_entries_match_monolithic(dev, pkg, orc):
     orc.verify(blob, mono)
 
     pcs = dev.commit_traces(pk, dtr)
+    root_words = pcs.root.copy()
     root = pkg.from_mont(pcs.root)
     assert root.astype("<u4").tobytes() == mono[4:36]
     ts = orc.transcript()
@@ -162,12 +170,23 @@ def test_stage_level_entries_match_monolithic(dev, pkg, orc):
     sponge.absorb_idx, sponge.sample_idx = ai, si
 
     gkr, batch, r = dev.prove_rap_constraints(pk, dtr, sponge)
+    ts_state = bytes(sponge)
     assert gkr == mono[secs[0]:secs[1]]
     assert batch == mono[secs[1]:secs[2]]
     stacking, whir = dev.prove_openings(pk, dtr, pcs, r, sponge)
     assert stacking == mono[secs[2]:secs[3]]
     assert whir == mono[secs[3]:secs[4]]
     pcs.free()
+    # TraceCommitter::commit(&[&Matrix]) as the trait has it: matrices (height-sorted), parameters, no key
+    by_h = sorted(range(3), key=lambda i: (-traces[i][2], traces[i][0]))
+    mats = [(dtr[i][1], air_list[traces[i][0]]["common_main_width"], traces[i][2]) for i in by_h]
+    pcs2 = dev.commit_matrices(params, mats)
+    assert (pcs2.root == root_words).all()
+    stacking2, whir2 = dev.prove_openings(pk, dtr, pcs2, r, sponge_before_openings(pkg, orc, ts_state))
+    assert stacking2 == stacking and whir2 == whir
+    with pytest.raises(pkg.OvmError, match="sorted"):
+        dev.commit_matrices(params, mats[::-1])
+    pcs2.free()
     del final
 
 
@@ -281,52 +300,6 @@ def test_config_e_full_size_verifies(dev, pkg, orc):
     pkg._lib().ovm_hip_trim()
 
 
-# ---- run-time compiled constraint kernels (csrc/jit.cpp) vs the interpreter vs the oracle ----------
-def test_jit_fibonacci_and_interactions(dev, pkg, orc, monkeypatch):
-    monkeypatch.setenv("OVM_JIT", "1")
-    params = airs.test_params(l_skip=2, n_stack=6, k_whir=2)
-    tr, pvs = airs.fibonacci_trace(0, 1, 64)
-    run_case(dev, pkg, orc, params, [airs.fibonacci_air()], [(0, tr, 64, pvs)])  # public-value operands
-    s = np.array([[0, 1], [7, 4], [3, 5], [546, 889]], dtype=np.uint32)
-    r = np.array([[1, 5], [3, 4], [4, 4], [2, 5], [0, 123], [545, 889], [1, 889], [0, 456]], dtype=np.uint32)
-    traces = [(0, np.ascontiguousarray(s.T).reshape(-1), 4, []), (1, np.ascontiguousarray(r.T).reshape(-1), 8, [])]
-    run_case(dev, pkg, orc, params, [airs.dummy_interaction_air(1, True, 0), airs.dummy_interaction_air(1, False, 0)], traces)
-
-
-@pytest.mark.parametrize("cols,log_h,l_skip,n_stack,k_whir", [(8, 5, 2, 6, 2), (100, 10, 4, 12, 4)])
-def test_jit_benchmark_air(dev, pkg, orc, monkeypatch, cols, log_h, l_skip, n_stack, k_whir):
-    monkeypatch.setenv("OVM_JIT", "1")
-    params = airs.test_params(l_skip=l_skip, n_stack=n_stack, k_whir=k_whir)
-    h = 1 << log_h
-    tr = airs.splitmix64_bits(0xD15EA5E, cols * h)
-    run_case(dev, pkg, orc, params, [airs.uniform_runner_air(cols)], [(0, tr, h, [])])
-
-
-def test_jit_partitioned_and_mixed(dev, pkg, orc, monkeypatch):
-    monkeypatch.setenv("OVM_JIT", "1")
-    sels = [i % 2 == 0 for i in range(16)]
-    common, cached = airs.preprocessed_cached_traces(sels, 3)
-    pre = {0: (np.array([int(s) for s in sels], np.uint32), len(sels))}
-    run_partitioned(dev, pkg, orc, airs.test_params(), [airs.preprocessed_cached_air(3)],
-                    [(0, common, len(sels), [], cached)], pre)
-    params = airs.test_params(l_skip=2, n_stack=6, k_whir=2)
-    bench = airs.uniform_runner_air(8)
-    t1, pv = airs.fibonacci_trace(0, 1, 16)
-    run_case(dev, pkg, orc, params, [airs.fibonacci_air(), bench, bench],
-             [(0, t1, 16, pv), (1, airs.splitmix64_bits(1, 8 * 64), 64, []), (2, airs.splitmix64_bits(2, 8 * 2), 2, [])])
-
-
-def test_jit_and_interpreter_agree_at_full_size(dev, pkg, orc, monkeypatch):
-    """Config D: the proof with compiled kernels equals the proof with the interpreter, byte for byte."""
-    blob, pk, trace, h = _config_d(pkg, dev, 22, 100, 24)
-    monkeypatch.setenv("OVM_JIT", "0")
-    a, _ = dev.prove(pk, [(0, trace, h, [])])
-    monkeypatch.setenv("OVM_JIT", "1")
-    b, _ = dev.prove(pk, [(0, trace, h, [])])
-    assert a == b
-    orc.verify(blob, b)
-
-
 # ---- error behaviour through the C ABI: invalid inputs give error codes and messages, never crashes ----
 def test_error_paths(dev, pkg, orc):
     import torch
@@ -362,7 +335,7 @@ def test_error_paths(dev, pkg, orc):
     bad[0] ^= 1
     with pytest.raises(pkg.OvmError):
         pkg.ProvingKey(bad)
-    # 7. proof buffer too small: error code, and the required length is reported by a retry
+    # 7. proof buffer too small: refused before any work, with the required length (= ovm_hip_proof_size)
     r = np.array([[1, 5], [3, 4], [4, 4], [2, 5], [0, 123], [545, 889], [1, 889], [0, 456]], dtype=np.uint32).T.reshape(-1)
     good = [(0, up(s), 4, []), (1, up(r), 8, [])]
     import ctypes
@@ -375,9 +348,19 @@ def test_error_paths(dev, pkg, orc):
                                   ctypes.byref(plen), None, dev.stream)
     assert rc == 1 and plen.value > 64 and bytes(sponge) == before  # size reported, transcript untouched
     assert b"too small" in pkg._lib().ovm_hip_last_error()
-    small, _ = dev.prove(pk, good, proof_cap=64)  # the binding repeats the call with the reported size
-    proof, _ = dev.prove(pk, good)  # the library is still usable after every failure above
-    assert small == proof and len(proof) == plen.value
+    assert pkg.proof_size(pk, [(0, 4), (1, 8)])[4] == plen.value
+    proof, secs = dev.prove(pk, good)  # the library is still usable after every failure above
+    assert len(proof) == plen.value and secs == pkg.proof_size(pk, [(0, 4), (1, 8)])
+    # 8. null trace pointer, duplicate AIR index, a word >= P among the public values: error codes, no faults
+    with pytest.raises(pkg.OvmError, match="null"):
+        dev.prove(pk, [(0, None, 4, []), (1, up(r), 8, [])])
+    with pytest.raises(pkg.OvmError, match="duplicate"):
+        dev.prove(pk, [(0, up(s), 4, []), (0, up(s), 4, [])])
+    arrf, keepf = pkg._trace_structs([(0, up(tr), 16, pvs)])
+    keepf[0][0] = 0x78000001  # = P: not a reduced Montgomery word
+    outf = np.zeros(1 << 20, dtype=np.uint8)
+    rc = pkg._lib().ovm_hip_prove(pkf.handle, 1, arrf, None, outf.ctypes.data, outf.size, ctypes.byref(plen), None, dev.stream)
+    assert rc == 1 and b">= P" in pkg._lib().ovm_hip_last_error()
     orc.verify(airs.pk_blob(params, air_list), proof)
 
 

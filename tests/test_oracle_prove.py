@@ -79,3 +79,17 @@ def test_multi_air_mixed_heights(orc):
     blob = airs.pk_blob(params, [fib, bench, bench])
     out = orc.prove(blob, [(0, t1, 16, pv), (1, t2, 64, []), (2, t3, 2, [])])
     orc.verify(blob, out["proof"])
+
+
+def test_fibonacci_2_12_config_a(orc):
+    """BASELINE config A: Fibonacci AIR at 2^12 rows under app parameters, CPU only (plumbing): the
+    oracle's proof is accepted by the verifier restatement and a tampered public value is rejected."""
+    params = airs.app_params(12)
+    blob = airs.pk_blob(params, [airs.fibonacci_air()])
+    tr, pvs = airs.fibonacci_trace(0, 1, 1 << 12)
+    proof = orc.prove(blob, [(0, tr, 1 << 12, pvs)])["proof"]
+    orc.verify(blob, proof)
+    bad = bytearray(proof)
+    bad[-5] ^= 1
+    with pytest.raises(RuntimeError):
+        orc.verify(blob, bytes(bad))

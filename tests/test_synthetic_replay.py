@@ -67,24 +67,6 @@ def test_gpu_full_size_segments_verify(dev, pkg, orc, seg_i):
 
 
 @pytest.mark.gpu
-def test_gpu_jit_matches_oracle_on_synthetic_airs(dev, pkg, orc, monkeypatch):
-    """Six AIR shapes of segment 0 with compiled kernels (hiprtc spends seconds per AIR, so not a
-    whole segment): byte-identical to the oracle."""
-    import torch
-    monkeypatch.setenv("OVM_JIT", "1")
-    params = airs.test_params(l_skip=2, n_stack=8, k_whir=3, max_constraint_degree=4)
-    air_list, shapes = airs.synthetic_segment(SEGS[0], 5)
-    air_list, shapes = air_list[1:7], [(i - 1, lh, w) for i, lh, w in shapes[1:7]]
-    blob = airs.pk_blob(params, air_list)
-    traces = [(i, np.zeros(w << lh, np.uint32), 1 << lh, []) for i, lh, w in shapes]
-    want = orc.prove(blob, traces)["proof"]
-    pk = pkg.ProvingKey(blob)
-    dtr = [(i, torch.zeros(w << lh, dtype=torch.int32, device="cuda:0"), 1 << lh, []) for i, lh, w in shapes]
-    got, _ = dev.prove(pk, dtr)
-    assert got == want
-
-
-@pytest.mark.gpu
 def test_gpu_config_b_shape_verifies(dev, pkg, orc):
     """BASELINE config B shape: one AIR with KeccakfPermAir's captured shape (2 634 columns, 3 183
     degree-3 constraints, two 102-field interactions) at 2^20 rows -- 2.76e9 cells, codeword 22 GB --
