@@ -296,6 +296,60 @@ int ovm_hip_prove(const ovm_pk_t *pk, uint32_t n_traces, const ovm_trace_t *trac
                   uint8_t *proof_out, uint64_t proof_cap, uint64_t *proof_len, uint64_t *section_offsets5,
                   ovm_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------
+ * Sharded proving: ONE joint proof over the ranks of one node, one AIR (trace) per GPU
+ * (BASELINE config D/E in their 8 x MI355X form). DESIGN.md §6 has the protocol.
+ * ------------------------------------------------------------------------------------- */
+
+/* The communicator of a sharded call. Two exchanges exist:
+ *   allgather_host   small host buffers, hundreds of times per proof (per-round partial sums of the
+ *                    sumchecks, roots, openings): all[r*bytes ..] = rank r's `mine`; every rank calls
+ *                    it in the same order with the same `bytes`. Built in: ovm_hip_shm_allgather.
+ *   allgather_device device buffers, once per proof: the mu-batched WHIR vector of each rank
+ *                    (reference: the batching step of prover/whir.rs:95-132), d_all[r*bytes ..] = rank
+ *                    r's d_mine. The host language supplies it on top of RCCL over xGMI
+ *                    (torch.distributed in this repository's Python host, an rccl binding in Rust); it
+ *                    must be ordered after the work already enqueued on `stream` and complete, from
+ *                    the point of view of later work on `stream`, when it returns.
+ * Both return 0 or a hipError_t value. */
+typedef struct ovm_shard {
+    uint32_t rank, world;
+    void *ctx;
+    int (*allgather_host)(void *ctx, const void *mine, void *all, uint64_t bytes);
+    int (*allgather_device)(void *ctx, const void *d_mine, void *d_all, uint64_t bytes, ovm_stream_t stream);
+} ovm_shard_t;
+
+/* Built-in small exchange for the ranks of one node: a POSIX shared-memory segment `name` (a unique
+ * name per job, e.g. "/ovm-<port>-<pid>"; every rank passes the same one) with two slots of
+ * slot_bytes per rank; a rank stores its contribution and a sequence number, the others spin on it
+ * (about a microsecond per exchange). create() returns when every rank has attached, and removes
+ * the name. Set ovm_shard_t.allgather_host = ovm_hip_shm_allgather and .ctx = the communicator
+ * (or call it from a wrapper if ctx is needed for the device exchange as well). */
+typedef struct ovm_shm_comm ovm_shm_comm_t;
+int ovm_hip_shm_comm_create(const char *name, uint32_t rank, uint32_t world, uint64_t slot_bytes, ovm_shm_comm_t **out);
+/* The same over memory the ranks already share (threads of one process): `base` = zero-filled buffer of
+ * ovm_hip_shm_segment_bytes(world, slot_bytes) bytes. */
+uint64_t ovm_hip_shm_segment_bytes(uint32_t world, uint64_t slot_bytes);
+int ovm_hip_shm_comm_attach(void *base, uint32_t rank, uint32_t world, uint64_t slot_bytes, ovm_shm_comm_t **out);
+void ovm_hip_shm_comm_destroy(ovm_shm_comm_t *comm);
+int ovm_hip_shm_allgather(void *comm, const void *mine, void *all, uint64_t bytes);
+
+/* `Coordinator::prove` (prover/mod.rs:104-197) as ONE joint proof computed by shard->world ranks.
+ * `traces` lists ALL traces of the proof on every rank (air_idx and height always valid);
+ * owner[t] = the rank that holds trace t: only there are d_common_main, public_values and the cached
+ * handles read (elsewhere they may be null / zero). Owners must be assigned to the traces in
+ * blocks: sorted as the prover sorts them (height descending, air index ascending), owner must be
+ * non-decreasing. Every rank calls this with the same key and trace list.
+ * Work split: per-trace work (cached-main commitments supplied by the caller, LogUp leaves and the
+ * sub-tree over them, round 0, multilinear rounds, its columns of the stacked reduction and of the
+ * mu-batch) on the owner; the common-main commitment and WHIR after the batching on rank 0; the
+ * transcript replicated on every rank from the all-gathered round values.
+ * The proof (identical to ovm_hip_prove's on one device, byte for byte) is written on rank 0 only;
+ * other ranks return 0 with *proof_len = 0. */
+int ovm_hip_prove_sharded(const ovm_pk_t *pk, const ovm_shard_t *shard, uint32_t n_traces, const ovm_trace_t *traces,
+                          const uint32_t *owner, ovm_sponge_t *sponge, uint8_t *proof_out, uint64_t proof_cap,
+                          uint64_t *proof_len, uint64_t *section_offsets5, ovm_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
