@@ -334,6 +334,20 @@ int ovm_hip_shm_comm_attach(void *base, uint32_t rank, uint32_t world, uint64_t 
 void ovm_hip_shm_comm_destroy(ovm_shm_comm_t *comm);
 int ovm_hip_shm_allgather(void *comm, const void *mine, void *all, uint64_t bytes);
 
+/* Host-only self-test of the sharded LogUp-GKR bookkeeping (csrc/gkr_shard.h): `world` simulated ranks
+ * (threads over the shared-memory exchange) own the leaf runs [0, ends[0]), [ends[0], ends[1]), ... of a
+ * random fraction tree of 2^TR leaves, the rest is padding; every rank's transcript must equal that of the
+ * unsharded run with the padding written out, and the windowed eq-heap plans are replayed on the host.
+ * Needs no device. 0 = equal; message of a failure: ovm_hip_selftest_error(). */
+int ovm_hip_gkr_shard_selftest(uint32_t world, uint32_t TR, const uint64_t *ends, uint64_t seed, int three_points);
+const char *ovm_hip_selftest_error(void);
+/* Host-only self-test of a communicator: `rounds` small exchanges of round- and rank-dependent sizes (some
+ * larger than one shared-memory slot) through allgather_host, and -- if world > 1 and n > 0 -- one bulk
+ * exchange of n extension-field elements through allgather_device, called with HOST pointers and a null
+ * stream, whose blocks are then added up with the field's addition and compared with the expected sum.
+ * This is how the CPU tests exercise the callback a host language supplies (tests/test_shard_cpu.py: gloo). */
+int ovm_hip_shard_exchange_selftest(const ovm_shard_t *shard, uint64_t n, uint32_t rounds, uint64_t seed);
+
 /* `Coordinator::prove` (prover/mod.rs:104-197) as ONE joint proof computed by shard->world ranks.
  * `traces` lists ALL traces of the proof on every rank (air_idx and height always valid);
  * owner[t] = the rank that holds trace t: only there are d_common_main, public_values and the cached

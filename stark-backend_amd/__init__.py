@@ -116,6 +116,16 @@ SIGNATURES = {
                                        POINTER(SpongeState), c_void_p, c_uint64, _u64p, _u64p, c_void_p]),
     "ovm_hip_prove": (c_int, [c_void_p, c_uint32, c_void_p, POINTER(SpongeState), c_void_p, c_uint64, _u64p, _u64p,
                               c_void_p]),
+    "ovm_hip_shm_comm_create": (c_int, [c_char_p, c_uint32, c_uint32, c_uint64, POINTER(c_void_p)]),
+    "ovm_hip_shm_segment_bytes": (c_uint64, [c_uint32, c_uint64]),
+    "ovm_hip_shm_comm_attach": (c_int, [c_void_p, c_uint32, c_uint32, c_uint64, POINTER(c_void_p)]),
+    "ovm_hip_shm_comm_destroy": (None, [c_void_p]),
+    "ovm_hip_shm_allgather": (c_int, [c_void_p, c_void_p, c_void_p, c_uint64]),
+    "ovm_hip_gkr_shard_selftest": (c_int, [c_uint32, c_uint32, _u64p, c_uint64, c_int]),
+    "ovm_hip_selftest_error": (c_char_p, []),
+    "ovm_hip_shard_exchange_selftest": (c_int, [c_void_p, c_uint64, c_uint32, c_uint64]),
+    "ovm_hip_prove_sharded": (c_int, [c_void_p, c_void_p, c_uint32, c_void_p, _u32p, POINTER(SpongeState), c_void_p, c_uint64,
+                                      _u64p, _u64p, c_void_p]),
 }
 
 
@@ -408,6 +418,111 @@ def _commit_matrices(self, params: dict, mats) -> PcsData:
     return PcsData(h, root, keep=[m[0] for m in mats])
 
 
+# ---- sharded proving: one joint proof over the ranks of one node (include/openvm_hip.h) ----
+class ShardStruct(Structure):
+    """``ovm_shard_t``."""
+
+    _fields_ = [("rank", c_uint32), ("world", c_uint32), ("ctx", c_void_p), ("allgather_host", c_void_p),
+                ("allgather_device", c_void_p)]
+
+
+_AG_DEVICE = ctypes.CFUNCTYPE(c_int, c_void_p, c_void_p, c_void_p, c_uint64, c_void_p)
+
+
+class _DevPtr:
+    """A raw device range as a ``__cuda_array_interface__`` object (so torch can view it without a copy)."""
+
+    def __init__(self, ptr, nbytes):
+        self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 2}
+
+
+class Shard:
+    """This rank's communicator for ``Device.prove_sharded``: the library's shared-memory exchange for the
+    small per-round values, and ``torch.distributed`` (RCCL over xGMI with the nccl backend; host-staged with
+    gloo, which is what the CPU tests and several ranks sharing ONE GPU use) for the one bulk all-gather.
+    ``name``: the same unique shared-memory name on every rank (e.g. from rank 0 via broadcast_object_list)."""
+
+    def __init__(self, rank: int, world: int, name: str, slot_bytes: int = 1 << 20, group=None, host_buffers: bool = False):
+        import torch
+        import torch.distributed as dist
+
+        self.rank, self.world, self.group = rank, world, group
+        self.host_buffers = host_buffers  # the bulk exchange is handed HOST pointers (CPU tests of the callback)
+        h = c_void_p(0)
+        check(_lib().ovm_hip_shm_comm_create(name.encode(), rank, world, slot_bytes, ctypes.byref(h)), "ovm_hip_shm_comm_create")
+        self.comm = h
+        self._torch, self._dist = torch, dist
+        self._cb = _AG_DEVICE(self._allgather_device)
+        self.abi = ShardStruct(rank, world, h, ctypes.cast(_lib().ovm_hip_shm_allgather, c_void_p),
+                               ctypes.cast(self._cb, c_void_p))
+        self.bulk_bytes = 0
+
+    def _allgather_device(self, ctx, d_mine, d_all, nbytes, stream):
+        try:
+            torch, dist = self._torch, self._dist
+            if self.host_buffers:
+                send = torch.frombuffer((ctypes.c_uint8 * nbytes).from_address(d_mine), dtype=torch.uint8)
+                parts = [torch.empty(nbytes, dtype=torch.uint8) for _ in range(self.world)]
+                dist.all_gather(parts, send, group=self.group)
+                for r, part in enumerate(parts):
+                    ctypes.memmove(d_all + r * nbytes, part.data_ptr(), nbytes)
+                self.bulk_bytes += int(nbytes) * self.world
+                return 0
+            torch.cuda.current_stream().synchronize()  # what the prover enqueued before the exchange
+            self.bulk_bytes += int(nbytes) * self.world
+            if dist.get_backend(self.group) == "nccl":
+                dev = torch.device("cuda", torch.cuda.current_device())
+                send = torch.as_tensor(_DevPtr(d_mine, nbytes), device=dev)
+                recv = torch.as_tensor(_DevPtr(d_all, nbytes * self.world), device=dev)
+                dist.all_gather_into_tensor(recv, send, group=self.group)
+            else:  # host-staged (gloo): the same call sequence without a device collective
+                send = torch.empty(nbytes, dtype=torch.uint8)
+                check(_lib().ovm_hip_memcpy_d2h(send.data_ptr(), d_mine, nbytes, stream), "ovm_hip_memcpy_d2h")
+                check(_lib().ovm_hip_stream_synchronize(stream), "ovm_hip_stream_synchronize")
+                parts = [torch.empty(nbytes, dtype=torch.uint8) for _ in range(self.world)]
+                dist.all_gather(parts, send, group=self.group)
+                for r, part in enumerate(parts):
+                    check(_lib().ovm_hip_memcpy_h2d(d_all + r * nbytes, part.data_ptr(), nbytes, stream), "ovm_hip_memcpy_h2d")
+                check(_lib().ovm_hip_stream_synchronize(stream), "ovm_hip_stream_synchronize")
+            torch.cuda.current_stream().synchronize()
+            return 0
+        except Exception as e:  # never let an exception cross the C boundary
+            import sys
+            print(f"[ovm] allgather_device failed on rank {self.rank}: {e!r}", file=sys.stderr, flush=True)
+            return 999
+
+    def close(self):
+        if self.comm:
+            _lib().ovm_hip_shm_comm_destroy(self.comm)
+            self.comm = None
+
+
+def shard_exchange_selftest(shard: Shard, n: int, rounds: int, seed: int = 1) -> None:
+    rc = _lib().ovm_hip_shard_exchange_selftest(ctypes.byref(shard.abi), n, rounds, seed)
+    if rc != 0:
+        raise OvmError(rc, f"ovm_hip_shard_exchange_selftest [{_lib().ovm_hip_selftest_error().decode()}]")
+
+
+def _prove_sharded(self, pk: ProvingKey, shard: Shard, traces, owners, sponge: SpongeState | None = None):
+    """ONE joint proof over ``shard.world`` ranks. ``traces`` lists every trace of the proof as in ``prove``;
+    entries owned by another rank may carry ``None`` for the tensor and the cached list. Returns
+    (proof bytes, section ends) on rank 0 and (b"", []) elsewhere."""
+    arr, keep = _trace_structs(traces)
+    own = (c_uint32 * len(traces))(*[int(o) for o in owners])
+    cap = proof_size(pk, [(t[0], t[2]) for t in traces])[4] if shard.rank == 0 else 0
+    out = np.zeros(max(cap, 1), dtype=np.uint8)
+    plen = c_uint64(0)
+    secs = (c_uint64 * 5)()
+    rc = _lib().ovm_hip_prove_sharded(pk.handle, ctypes.byref(shard.abi), len(traces), arr, own,
+                                      ctypes.byref(sponge) if sponge is not None else None, out.ctypes.data, cap,
+                                      ctypes.byref(plen), secs, self.stream)
+    if rc != 0:
+        _fail(rc, "ovm_hip_prove_sharded")
+    if shard.rank != 0:
+        return b"", []
+    return out[:plen.value].tobytes(), [int(x) for x in secs]
+
+
 def _prove_rap_constraints(self, pk: ProvingKey, traces, sponge: SpongeState, cap: int = 1 << 24):
     """MultiRapProver::prove_rap_constraints. Returns (GkrProof bytes, BatchConstraintProof bytes,
     r as an (n, 4) array of Montgomery words); ``sponge`` is updated in place."""
@@ -441,11 +556,21 @@ def _prove_openings(self, pk: ProvingKey, traces, pcs: PcsData, r: np.ndarray, s
     return b[:st_len.value], b[st_len.value:]
 
 
+Device.prove_sharded = _prove_sharded
 Device.commit_matrix = _commit_matrix
 Device.commit_matrices = _commit_matrices
 Device.commit_traces = _commit_traces
 Device.prove_rap_constraints = _prove_rap_constraints
 Device.prove_openings = _prove_openings
+
+
+def gkr_shard_selftest(world: int, TR: int, ends, seed: int = 1, three_points: bool = False) -> None:
+    """Host-only: the sharded LogUp-GKR driver with `world` simulated ranks owning the leaf runs that end at
+    `ends`, against the unsharded run (csrc/selftest.cpp). Raises on a mismatch."""
+    e = (c_uint64 * world)(*[int(x) for x in ends])
+    rc = _lib().ovm_hip_gkr_shard_selftest(world, TR, e, seed, 1 if three_points else 0)
+    if rc != 0:
+        raise OvmError(rc, f"ovm_hip_gkr_shard_selftest [{_lib().ovm_hip_selftest_error().decode()}]")
 
 
 def staged_selftest(blob, stage_rows: int, acc_rows: int, seed: int = 1) -> int:

@@ -5,6 +5,9 @@
 #include "device_ctx.h"
 #include "program.h"
 
+#include <utility>
+#include <vector>
+
 namespace ovm {
 
 struct DevProgram {
@@ -128,6 +131,30 @@ int fold_mle_batched(const FoldJob *d_jobs, const FoldJob *h_jobs, uint32_t n_jo
 // heap[2^k + y] = eq(point[n-k .. n), y) for k = 0 .. n-1 (2^n entries, node 1 = 1): the weights of
 // sub-round n-1-k of a layer sumcheck whose eq factor is split off (stages.hip)
 int eq_heap(const EF *d_point, uint32_t n, EFPlanes heap, hipStream_t s);
+// Windowed form for a rank that owns an index window of the layer's table (sharded GKR, gkr_shard.h):
+// need[d] = [lo, hi) = the entries of depth d the sub-round sums read. Depths <= top are full tables at
+// heap index 2^d + y; a deeper depth d stores entries [lo[d], lo[d] + cnt[d]) at heap index off[d] + (y - lo[d]).
+// With need[d] = [0, 2^d) this is exactly the heap eq_heap builds. total = heap elements needed.
+struct EqHeapPlan {
+    uint32_t n = 0, top = 0;
+    bool empty = true;
+    uint64_t total = 0;
+    std::vector<uint64_t> off, lo, cnt;
+    struct Launch {
+        uint32_t k, levels;
+        uint64_t src_first, count;
+    };
+    std::vector<Launch> launches;
+    // heap index of entry y of depth d
+    uint64_t at(uint32_t d, uint64_t y) const { return off[d] + (y - lo[d]); }
+};
+EqHeapPlan eq_heap_plan(uint32_t n, const std::vector<std::pair<uint64_t, uint64_t>> &need);
+int eq_heap_run(const EF *d_point, const EqHeapPlan &plan, EFPlanes heap, hipStream_t s);
+// fractions at arbitrary plane positions, for the host (n <= 32)
+int gkr_read_list(FracPlanes t, const uint64_t *d_pos, const uint32_t *d_pbase, uint32_t n, const RedOut &ro, hipStream_t s);
+// up to two table records for the host, read (fold = false: two fractions at `at`) or folded by r (four fractions)
+int gkr_edge_records(FracPlanes src, uint64_t at0, uint64_t at1, uint32_t n, bool p_base, bool fold, EF r, const RedOut &ro,
+                     hipStream_t s);
 // p_base: leaf numerators are base-field, only limb plane 0 of P is written / read (stages.hip)
 int gkr_fill_leaves(FracPlanes leaves, uint64_t n, EF alpha, bool p_base, hipStream_t s);
 // The leaf kernels of many traces in one launch (staged programs, one row per lane): job j owns
@@ -190,6 +217,8 @@ int horner_eval(const EF *coeffs, uint64_t n, EF z, const RedOut &ro, hipStream_
 // w[x] += sum_q gamma_q * eq(x, pow(z_q)) using split tables lo/hi (n_q x 2^half each)
 int whir_w_accumulate(EF *w, uint32_t log_n, const EF *d_tab_lo, const EF *d_tab_hi, uint32_t log_lo,
                       uint32_t n_q, hipStream_t s);
+// out[i] = sum_b in[b * n + i]
+int ef_sum_blocks(const EF *in, uint32_t n_blocks, uint64_t n, EF *out, hipStream_t s);
 int gather_ef(const EF *src, const uint64_t *d_idx, uint64_t n, EF *out, hipStream_t s);
 
 }  // namespace ovm

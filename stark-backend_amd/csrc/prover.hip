@@ -18,7 +18,9 @@
 #include <mutex>
 #include <unordered_map>
 
+#include "gkr_shard.h"
 #include "kernels.h"
+#include "shard.h"
 
 namespace ovm {
 
@@ -360,7 +362,9 @@ struct TraceIn {
     const Fp *d_trace;  // common main, column-major, width from the key
     size_t height;
     std::vector<Fp> public_values;
-    std::vector<const PcsData *> cached;  // committed cached main partitions, in partition order
+    std::vector<const PcsData *> cached;  // committed cached main partitions, in partition order (owner only)
+    std::vector<p2::Digest> cached_roots;  // their commitments (every rank, after the exchange of a sharded proof)
+    uint32_t owner = 0;
 };
 
 struct PcsData {
@@ -420,6 +424,11 @@ struct Prover {
     const bool force_three_points = std::getenv("OVM_GKR_THREE_POINTS") != nullptr;
     Transcript ts;
     std::vector<TraceIn> traces;  // sorted
+    // Sharded proving: owner[t] = the rank holding sorted trace t. Per-trace device work
+    // runs on the owner only; its few results are all-gathered so that every rank runs the same transcript.
+    ShardComm sh;
+    std::vector<uint32_t> owner;
+    bool mine(size_t t) const { return owner[t] == sh.rank; }
     ByteWriter out;
     std::vector<size_t> section_offsets;
 
@@ -657,7 +666,6 @@ struct Prover {
         static const uint32_t cap = getenv("OVM_MLE_GROUPS_MAX") ? (uint32_t)std::max(1, atoi(getenv("OVM_MLE_GROUPS_MAX"))) : MLE_GROUPS_MAX;
         return (uint32_t)std::min<size_t>(std::max<size_t>(MLE_GROUPS, n_instr / MLE_GROUP_INSTRS), std::max(cap, MLE_GROUPS));
     }
-    static constexpr uint64_t PLANE_SKEW = 1088;  // words: 4 KiB + 256 B
     struct TracePrograms {
         Program zc, lg, leaves;
         GroupedProgram zc_g, lg_g;
@@ -666,6 +674,7 @@ struct Prover {
     std::vector<TracePrograms> compile_all_programs() const {
         std::vector<TracePrograms> out(traces.size());
         for (size_t t = 0; t < traces.size(); t++) {
+            if (!mine(t)) continue;
             const AirKey &a = air(t);
             const ColumnMap cm = column_map_of(a);
             const std::vector<Fp> &pv = traces[t].public_values;
@@ -684,6 +693,188 @@ struct Prover {
         }
         return out;
     }
+
+    // Sharded proving: vecs[i] was computed by rank owner_of(i) only; afterwards every rank holds all of them.
+    template <class OwnerOf>
+    void share_vectors(std::vector<std::vector<EF>> &vecs, OwnerOf owner_of) {
+        if (sh.single()) return;
+        Packer pk_;
+        for (size_t i = 0; i < vecs.size(); i++)
+            if (owner_of(i) == sh.rank) {
+                pk_.put<uint64_t>(i);
+                pk_.put_vec(vecs[i]);
+            }
+        const auto all = sh.allgatherv(pk_.buf);
+        for (uint32_t r = 0; r < sh.world; r++) {
+            if (r == sh.rank) continue;
+            Unpacker u(all[r]);
+            while (!u.done()) {
+                const uint64_t i = u.get<uint64_t>();
+                if (i >= vecs.size() || owner_of(i) != r) throw OvmFail(1, "shard exchange: unexpected vector");
+                vecs[i] = u.get_vec<EF>();
+            }
+        }
+    }
+
+    // -----------------------------------------------------------------------------------------
+    // The device side of the LogUp-GKR driver (gkr_shard.h): this rank's window of every tree layer,
+    // of the folded tables and of the eq heap. With one rank and no padding the windows are the
+    // whole arrays and the launches are the ones a single-device prover makes.
+    // -----------------------------------------------------------------------------------------
+    static constexpr uint64_t PLANE_SKEW = 1088;  // words: 4 KiB + 256 B
+    struct GkrDevice : GkrDeviceOps {
+        Prover &pr;
+        const GkrPlan &plan;
+        const uint32_t me;
+        const unsigned TR;
+        const bool p_base;  // big trees: only limb 0 of the leaf numerators exists
+        std::vector<uint64_t> toff, fb;  // per layer: plane offset of my window, global index of its element 0
+        uint64_t tree_stride = 0, wcap = 0;
+        DevBuf<uint32_t> tree_buf, rec_a, rec_b, eq_buf;
+        DevBuf<EF> partials, d_point;
+        EqHeapPlan hp;
+        uint64_t eq_stride = 0;
+        std::vector<uint64_t> rbase;  // rbase[sr]: global record index of element 0 of table(sr)'s buffer (sr >= 1)
+        std::vector<URange> Rchain;   // Rchain[s] = my records of table(s) of the current layer
+
+        static uint64_t up64(uint64_t x) { return (x + 63) & ~uint64_t(63); }
+        GkrDevice(Prover &pr_, const GkrPlan &pl, bool p_base_)
+            : pr(pr_), plan(pl), me(pr_.sh.rank), TR(pl.TR), p_base(p_base_), toff(pl.TR + 1, 0), fb(pl.TR + 1, 0) {
+            uint64_t cur = 0;
+            for (unsigned j = 0; j <= TR; j++) {
+                const URange &r = plan.F[j][me];
+                toff[j] = cur;
+                if (r.empty()) continue;
+                fb[j] = r.lo & ~uint64_t(63);
+                cur += up64(r.hi - fb[j]);
+            }
+            // (+ PLANE_SKEW words: limb planes a power of two apart put the 8-20 streams of a wave on the same
+            // HBM channels)
+            tree_stride = std::max<uint64_t>(cur, 64) + PLANE_SKEW;
+            tree_buf.alloc(8 * tree_stride);
+            // folded tables: table(1) holds at most half of the layer's records (+ alignment slack), 2 fractions each
+            wcap = up64(plan.F[TR][me].size() / 2 + 128) + PLANE_SKEW;
+            rec_a.alloc(8 * wcap);
+            rec_b.alloc(8 * wcap);
+            uint64_t eq_total = 64;
+            for (unsigned round = 1; round < TR; round++) eq_total = std::max(eq_total, heap_plan_for(round).total);
+            eq_stride = up64(eq_total) + PLANE_SKEW;
+            eq_buf.alloc(4 * eq_stride);
+            partials.alloc(RED_BLOCKS * 4);
+        }
+        FracPlanes tree() const { return FracPlanes{tree_buf.p, tree_stride}; }
+        // planes positioned at global fraction i of layer j (i inside my window)
+        FracPlanes layer_at(unsigned j, uint64_t i) const { return tree().at(toff[j] + (i - fb[j])); }
+        FracPlanes leaves() const { return tree().at(toff[TR]); }  // element 0 = global leaf fb[TR]
+        uint64_t leaf_origin() const { return fb[TR]; }
+        FracPlanes recs(unsigned sr) const { return FracPlanes{(sr & 1) ? rec_b.p : rec_a.p, wcap}; }
+
+        // my record ranges of a layer's tables: chain[0] = records of the layer, chain[s + 1] = up(chain[s])
+        std::vector<URange> chain_for(unsigned round) const {
+            std::vector<URange> c(round + 2);
+            c[0] = up(plan.F[round + 1][me]);
+            for (unsigned s2 = 0; s2 <= round; s2++) c[s2 + 1] = up(c[s2]);
+            return c;
+        }
+        EqHeapPlan heap_plan_for(unsigned round) const {
+            const std::vector<URange> c = chain_for(round);
+            std::vector<std::pair<uint64_t, uint64_t>> need(round);
+            for (unsigned d = 0; d < round; d++) need[d] = {c[round - d].lo, c[round - d].hi};  // pairs of sub-round round-1-d
+            return eq_heap_plan(round, need);
+        }
+
+        // limb planes 1..3 of my leaf numerators (small trees only: big ones never read them)
+        void clear_leaf_numerators() {
+            const URange &r = plan.F[TR][me];
+            if (p_base || r.empty()) return;
+            for (int k = 1; k < 4; k++)
+                OVM_THROW_IF(hipMemsetAsync(leaves().p + k * tree_stride + (r.lo - fb[TR]), 0, r.size() * sizeof(uint32_t), pr.cx.stream));
+        }
+        void build() {
+            for (unsigned j = TR; j-- > 0;) {
+                const URange &r = plan.F[j][me];
+                if (r.empty()) continue;
+                OVM_THROW_IF(gkr_build_layer(layer_at(j + 1, 2 * r.lo), layer_at(j, r.lo), r.size(), p_base && j + 1 == TR, pr.cx.stream));
+            }
+        }
+        void read_layer_edges(std::vector<std::array<Frac, 2>> &out) override {
+            std::vector<uint64_t> pos;
+            std::vector<uint32_t> pb;
+            std::vector<std::pair<unsigned, int>> where;
+            for (unsigned j = 0; j <= TR; j++) {
+                const URange &r = plan.F[j][me];
+                if (r.empty()) continue;
+                for (int e = 0; e < 2; e++) {
+                    pos.push_back(toff[j] + ((e ? r.hi - 1 : r.lo) - fb[j]));
+                    pb.push_back(p_base && j == TR ? 1 : 0);
+                    where.push_back({j, e});
+                }
+            }
+            for (size_t at = 0; at < pos.size(); at += 32) {
+                const uint32_t n = (uint32_t)std::min<size_t>(32, pos.size() - at);
+                auto d_pos = pr.cx.upload(std::vector<uint64_t>(pos.begin() + at, pos.begin() + at + n));
+                auto d_pb = pr.cx.upload(std::vector<uint32_t>(pb.begin() + at, pb.begin() + at + n));
+                OVM_THROW_IF(gkr_read_list(tree(), d_pos.p, d_pb.p, n, pr.mb.arm(nullptr), pr.cx.stream));
+                auto v = pr.mb.take(2 * n, pr.cx.stream);
+                for (uint32_t i = 0; i < n; i++) out[where[at + i].first][where[at + i].second] = Frac{v[2 * i], v[2 * i + 1]};
+            }
+        }
+        void begin_layer(unsigned round, const std::vector<EF> &point) override {
+            Rchain = chain_for(round);
+            hp = heap_plan_for(round);
+            rbase.assign(round + 1, 0);
+            for (unsigned sr = 1; sr <= round; sr++) rbase[sr] = (2 * Rchain[sr + 1].lo) & ~uint64_t(31);
+            if (hp.empty) return;
+            d_point = pr.cx.upload(point);  // (through the pinned arena: a pageable source would block the host)
+            OVM_THROW_IF(eq_heap_run(d_point.p, hp, EFPlanes{eq_buf.p, eq_stride}, pr.cx.stream));
+        }
+        // planes positioned at record y of table(sr) (sr == 0: the tree layer)
+        FracPlanes table_at(unsigned round, unsigned sr, uint64_t y) const {
+            if (sr == 0) return layer_at(round + 1, 2 * y);
+            return recs(sr).at(2 * (y - rbase[sr]));
+        }
+        void subround(unsigned round, unsigned sr, URange pairs, const uint64_t *edge_idx, unsigned n_edges, EF r_prev, EF lambda,
+                      unsigned n_points, EF *S, GkrRec *edges) override {
+            hipStream_t st = pr.cx.stream;
+            const bool leaf_layer = p_base && round + 1 == TR;
+            const bool have_pairs = !pairs.empty();
+            if (n_edges) {
+                // (first: when a sums kernel follows, it is the one that raises the flag)
+                RedOut ro = pr.mb.arm(nullptr, 8);
+                if (have_pairs) ro.flag = nullptr;
+                // record e of table(sr): two fractions of the layer (sr == 0), or the fold by r_prev of records
+                // 2e, 2e+1 of table(sr-1) = four fractions of the layer (sr == 1) / of the previous buffer
+                uint64_t at[2] = {0, 0};
+                const unsigned L = round + 1;
+                const FracPlanes base = sr <= 1 ? tree().at(toff[L]) : recs(sr - 1);
+                for (unsigned k = 0; k < n_edges; k++)
+                    at[k] = sr == 0 ? 2 * edge_idx[k] - fb[L] : sr == 1 ? 4 * edge_idx[k] - fb[L] : 2 * (2 * edge_idx[k] - rbase[sr - 1]);
+                OVM_THROW_IF(gkr_edge_records(base, at[0], at[1], n_edges, leaf_layer && sr <= 1, sr != 0, r_prev, ro, st));
+            }
+            if (have_pairs) {
+                const uint64_t y0 = pairs.lo, n_pairs = pairs.size();
+                const unsigned d = round - 1 - sr;
+                const EFPlanes eq{eq_buf.p + hp.at(d, y0), eq_stride};
+                if (sr == 0) {
+                    OVM_THROW_IF(gkr_round(table_at(round, 0, 2 * y0), leaf_layer, eq, n_pairs, lambda, n_points, pr.mb.arm(partials.p), st));
+                } else {
+                    // fold sub-round sr-1 with r_prev and get this sub-round's sums in one pass
+                    OVM_THROW_IF(gkr_fold_round(table_at(round, sr - 1, 4 * y0), leaf_layer && sr == 1, eq, table_at(round, sr, 2 * y0), n_pairs,
+                                                r_prev, lambda, n_points, pr.mb.arm(partials.p), st));
+                }
+            }
+            pr.mb.wait(st);
+            if (have_pairs) {
+                auto v = pr.mb.read(0, n_points);
+                for (unsigned k = 0; k < n_points; k++) S[k] = v[k];
+            }
+            if (n_edges) {
+                auto v = pr.mb.read(8, 4 * n_edges);
+                for (unsigned k = 0; k < n_edges; k++)
+                    for (int c = 0; c < 4; c++) edges[k].v[c] = v[4 * k + c];
+            }
+        }
+    };
 
     // -----------------------------------------------------------------------------------------
     // Stage 2: zerocheck + LogUp (MultiRapProver::prove_rap_constraints)
@@ -710,6 +901,7 @@ struct Prover {
             size_t ni = air(t).interactions.size();
             total_interactions += (uint64_t)ni << v.log_lifted;
             imeta.push_back({ni, v.log_lifted});
+            if (!mine(t)) continue;
             // device view: selectors + columns
             v.sels.alloc(size_t(3) << v.log_lifted);
             OVM_THROW_IF(build_selectors(v.sels.p, v.log_lifted, v.log_height, cx.stream));
@@ -759,32 +951,34 @@ struct Prover {
         for (auto &a : pk.airs) max_constraints = std::max(max_constraints, a.constraint_idx.size());
         std::vector<EF> beta_pows = powers_of(beta, max_msg + 1);
 
-        // ---- GKR ----
+        // ---- GKR ---- (gkr_shard.h drives it: this rank's leaf run on the device, padding in closed form)
         std::vector<EF> xi;
         EF q0_claim = EF::one();
         std::vector<std::array<EF, 4>> claims;               // p0,p1,q0,q1 per layer
         std::vector<std::vector<std::array<EF, 3>>> gkr_polys;
         const unsigned TR = l_skip + n_logup;
         if (!ilayout.cols.empty()) {
-            const size_t n_leaves = size_t(1) << TR;
-            // heap-ordered fraction tree (node 1 = root, layer j at [2^j, 2^(j+1))), 8 limb planes
-            // (+ PLANE_SKEW words: limb planes a power of two apart put the 8-20 streams of a wave on the same
-            // HBM channels)
-            const uint64_t tree_stride = std::max<uint64_t>(2 * n_leaves, 4) + PLANE_SKEW;
-            DevBuf<uint32_t> tree_buf(8 * tree_stride);
-            const FracPlanes tree{tree_buf.p, tree_stride};
-            ProfScope *ps_leaves = new ProfScope("gkr.leaves", cx.stream);
+            const uint64_t n_leaves = uint64_t(1) << TR;
+            // The interaction slices are packed from row 0 with no gaps (descending powers of two) in sorted
+            // trace order, so the leaves of a rank (a block of consecutive traces) are one run; what is left
+            // above the last slice is padding.
+            uint64_t used_leaves = 0;
+            std::vector<URange> rank_leaves(sh.world);
+            for (size_t t = 0; t < T; t++)
+                for (size_t k = 0; k < air(t).interactions.size(); k++) {
+                    const Slice &sl = ilayout.cols[ilayout.mat_starts[t] + k].slice;
+                    const uint64_t lo = sl.row_idx, hi = sl.row_idx + (uint64_t(1) << sl.log_height);
+                    used_leaves = std::max(used_leaves, hi);
+                    URange &r = rank_leaves[owner[t]];
+                    r = r.empty() ? URange{lo, hi} : URange{std::min(r.lo, lo), std::max(r.hi, hi)};
+                }
+            if (used_leaves > n_leaves) throw OvmFail(1, "internal: interaction layout exceeds the tree");
+            const GkrPlan plan(TR, rank_leaves, used_leaves);
             // big trees: only limb 0 of the leaf numerators exists (small ones are read through generic paths)
             const bool p_base = TR >= 12;
-            // The interaction slices are packed from row 0 with no gaps (descending powers of two), and the
-            // leaf kernels write every row of every slice: only the padding tail needs the default (0, alpha).
-            uint64_t used_leaves = 0;
-            for (auto &sc : ilayout.cols) used_leaves = std::max<uint64_t>(used_leaves, sc.slice.row_idx + (uint64_t(1) << sc.slice.log_height));
-            if (used_leaves > n_leaves) throw OvmFail(1, "internal: interaction layout exceeds the tree");
-            // (small trees keep the full fill: there the leaf kernels rely on it for numerator limbs 1..3)
-            if (!p_base) used_leaves = 0;
-            if (used_leaves < n_leaves)
-                OVM_THROW_IF(gkr_fill_leaves(tree.at(n_leaves + used_leaves), n_leaves - used_leaves, alpha, p_base, cx.stream));
+            GkrDevice gd(*this, plan, p_base);
+            ProfScope *ps_leaves = new ProfScope("gkr.leaves", cx.stream);
+            gd.clear_leaf_numerators();
             struct LeafKeep {
                 ProgDev pd;
                 DevBuf<EF> lc;
@@ -795,8 +989,7 @@ struct Prover {
             std::vector<LeavesJob> leaf_jobs;
             for (size_t t = 0; t < T; t++) {
                 const AirKey &a = air(t);
-                if (a.interactions.empty()) continue;
-                std::vector<Root> roots = roots_leaves(a);
+                if (a.interactions.empty() || !mine(t)) continue;
                 std::vector<EF> leaf_const;
                 std::vector<uint64_t> leaf_base;
                 std::vector<uint32_t> leaf_log_len;
@@ -804,135 +997,53 @@ struct Prover {
                     const Interaction &it = a.interactions[k];
                     leaf_const.push_back(beta_pows[it.message.size()] * fp((uint64_t)it.bus_index + 1) + alpha);
                     const Slice &s = ilayout.cols[ilayout.mat_starts[t] + k].slice;
-                    leaf_base.push_back(s.row_idx);
+                    leaf_base.push_back(s.row_idx - gd.leaf_origin());  // (relative to this rank's leaf window)
                     leaf_log_len.push_back(s.log_height);
                 }
                 auto d_lc = cx.upload(leaf_const);
                 auto d_lb = cx.upload(leaf_base);
                 auto d_ll = cx.upload(leaf_log_len);
                 Fp norm = fp(uint64_t(1) << (tv[t].log_lifted - tv[t].log_height)).inv();
-                {
-                    // staged for one row per lane (log_lifted 0 selects that plan)
-                    ProgDev pd = make_prog(std::move(progs[t].leaves), beta_pows, true, 0, 1);
-                    if (pd.staged.blocks && tv[t].log_height < 20) {
-                        // small traces: one launch for all of them after the loop (the buffers stay alive till then)
-                        LeavesJob j{};
-                        j.prog = pd.staged, j.leaf_const = d_lc.p, j.cols = tv[t].cols.p, j.leaf_base = d_lb.p;
-                        j.leaf_log_len = d_ll.p, j.norm = norm, j.log_height = tv[t].log_height;
-                        j.gx = (uint32_t)ceil_div(1ull << tv[t].log_height, 256);
-                        j.wg0 = leaf_jobs.empty() ? 0 : leaf_jobs.back().wg0 + leaf_jobs.back().gx;
-                        leaf_jobs.push_back(j);
-                        leaf_keep.push_back(LeafKeep{std::move(pd), std::move(d_lc), std::move(d_lb), std::move(d_ll)});
-                    } else {
-                        OVM_THROW_IF(gkr_eval_leaves(pd.dev(), pd.staged, d_lc.p, tv[t].cols.p, tv[t].log_height, d_lb.p, d_ll.p,
-                                                     norm, tree.at(n_leaves), cx.stream));
-                    }
+                // staged for one row per lane (log_lifted 0 selects that plan)
+                ProgDev pd = make_prog(std::move(progs[t].leaves), beta_pows, true, 0, 1);
+                if (pd.staged.blocks && tv[t].log_height < 20) {
+                    // small traces: one launch for all of them after the loop (the buffers stay alive till then)
+                    LeavesJob j{};
+                    j.prog = pd.staged, j.leaf_const = d_lc.p, j.cols = tv[t].cols.p, j.leaf_base = d_lb.p;
+                    j.leaf_log_len = d_ll.p, j.norm = norm, j.log_height = tv[t].log_height;
+                    j.gx = (uint32_t)ceil_div(1ull << tv[t].log_height, 256);
+                    j.wg0 = leaf_jobs.empty() ? 0 : leaf_jobs.back().wg0 + leaf_jobs.back().gx;
+                    leaf_jobs.push_back(j);
+                    leaf_keep.push_back(LeafKeep{std::move(pd), std::move(d_lc), std::move(d_lb), std::move(d_ll)});
+                } else {
+                    OVM_THROW_IF(gkr_eval_leaves(pd.dev(), pd.staged, d_lc.p, tv[t].cols.p, tv[t].log_height, d_lb.p, d_ll.p,
+                                                 norm, gd.leaves(), cx.stream));
                 }
                 // no synchronisation: the temporaries go back to the block cache and are only ever reused
                 // by later work on this same stream
             }
             if (!leaf_jobs.empty()) {
                 auto d_jobs = cx.upload(leaf_jobs);
-                OVM_THROW_IF(gkr_eval_leaves_batched(d_jobs.p, leaf_jobs.data(), (uint32_t)leaf_jobs.size(), tree.at(n_leaves),
-                                                     cx.stream));
+                OVM_THROW_IF(gkr_eval_leaves_batched(d_jobs.p, leaf_jobs.data(), (uint32_t)leaf_jobs.size(), gd.leaves(), cx.stream));
             }
             leaf_keep.clear();
             delete ps_leaves;
             {
-            OVM_PROF("gkr.build_tree", cx.stream);
-            wt.mark("rap.gkr.leaves");
-            for (unsigned j = TR; j-- > 0;)
-                OVM_THROW_IF(gkr_build_layer(tree.at(size_t(2) << j), tree.at(size_t(1) << j), size_t(1) << j, p_base && j + 1 == TR, cx.stream));
+                OVM_PROF("gkr.build_tree", cx.stream);
+                wt.mark("rap.gkr.leaves");
+                gd.build();
             }
             wt.mark("rap.gkr.build");
             OVM_PROF("gkr.layer_sumchecks", cx.stream);
-            {
-                OVM_THROW_IF(gkr_read_fracs(tree, 1, 3, mb.arm(nullptr), cx.stream));
-                auto top = mb.take(6, cx.stream);  // (p, q) of nodes 1, 2, 3
-                if (!is_zero(top[0])) throw OvmFail(1, "LogUp: non-zero root sum (interactions do not balance)");
-                q0_claim = top[1];
-                ts.observe_ext(q0_claim);
-                claims.push_back({top[2], top[4], top[3], top[5]});
-            }
-            auto observe_claims = [&](const std::array<EF, 4> &c) {
-                ts.observe_ext(c[0]);
-                ts.observe_ext(c[2]);
-                ts.observe_ext(c[1]);
-                ts.observe_ext(c[3]);
-            };
-            observe_claims(claims[0]);
-            std::vector<EF> xi_prev{ts.sample_ext()};
-            if (TR > 1) {
-                // fold buffers in layer format (8 limb planes) and the eq heap (4 limb planes)
-                const uint64_t wcap = std::max<uint64_t>(uint64_t(1) << (TR - 1), 4) + PLANE_SKEW;
-                DevBuf<uint32_t> rec_a(8 * wcap), rec_b(8 * wcap), eq_buf(4 * wcap);
-                const FracPlanes recs[2] = {{rec_a.p, wcap}, {rec_b.p, wcap}};
-                const EFPlanes heap{eq_buf.p, wcap};
-                DevBuf<EF> partials(RED_BLOCKS * 4);
-                for (unsigned round = 1; round < TR; round++) {
-                    EF lambda = ts.sample_ext();
-                    auto d_point = cx.upload(xi_prev);  // (through the pinned arena: a pageable source would block the host)
-                    OVM_THROW_IF(eq_heap(d_point.p, round, heap, cx.stream));
-                    FracPlanes rec = tree.at(size_t(2) << round);
-                    std::vector<std::array<EF, 3>> polys;
-                    std::vector<EF> rho;
-                    EF r_prev = EF::zero();
-                    EF c_bound = EF::one();  // prod_{i < sr} eq1(xi_i, r_i)
-                    // the layer's sumcheck claim: previous claims interpolated at mu = xi_prev[0], batched with lambda
-                    const auto &pc = claims.back();  // p0, p1, q0, q1
-                    EF claim = (pc[0] + (pc[1] - pc[0]) * xi_prev[0]) + lambda * (pc[2] + (pc[3] - pc[2]) * xi_prev[0]);
-                    const EF inv2 = EF::from_base(fp(2).inv());
-                    for (unsigned sr = 0; sr < round; sr++) {
-                        const uint64_t n_pairs = 1ull << (round - sr - 1);
-                        const EFPlanes eq{heap.p + n_pairs, heap.stride};  // depth round-1-sr of the heap
-                        // s(X) = c_bound * eq1(a, X) * S(X), a = xi_sr, S quadratic. The device returns S(1), S(2);
-                        // S(0) follows from the claim s(0) + s(1) unless c_bound * (1 - a) = 0 (then: three points).
-                        const EF a = xi_prev[sr];
-                        const EF w0 = c_bound * (EF::one() - a);
-                        const unsigned n_points = (is_zero(w0) || force_three_points) ? 3 : 2;
-                        if (sr == 0) {
-                            OVM_THROW_IF(gkr_round(rec, p_base && round + 1 == TR, eq, n_pairs, lambda, n_points,
-                                                   mb.arm(partials.p), cx.stream));
-                        } else {
-                            // fold sub-round sr-1 with r_prev and get this sub-round's sums in one pass
-                            OVM_THROW_IF(gkr_fold_round(rec, p_base && round + 1 == TR && sr == 1, eq, recs[sr & 1], n_pairs,
-                                                        r_prev, lambda, n_points, mb.arm(partials.p), cx.stream));
-                            rec = recs[sr & 1];
-                        }
-                        auto S = mb.take(n_points, cx.stream);  // S(1), S(2)[, S(3)]
-                        // eq1(a, X) = a X + (1-a)(1-X) = a, 3a-1, 5a-2 at X = 1, 2, 3
-                        const EF a2 = a.dbl(), a3 = a2 + a, a5 = a3 + a2;
-                        const EF w[3] = {c_bound * a, c_bound * (a3 - EF::one()), c_bound * (a5 - EF::one().dbl())};
-                        EF S0;
-                        if (n_points == 2) {
-                            S0 = (claim - w[0] * S[0]) * w0.inv();
-                            S.push_back(S0 - (S[0].dbl() + S[0]) + (S[1].dbl() + S[1]));  // S(3): third difference = 0
-                        } else {
-                            S0 = (S[0].dbl() + S[0]) - (S[1].dbl() + S[1]) + S[2];
-                        }
-                        std::array<EF, 3> sv = {S[0] * w[0], S[1] * w[1], S[2] * w[2]};
-                        for (auto &e : sv) ts.observe_ext(e);
-                        polys.push_back(sv);
-                        r_prev = ts.sample_ext();
-                        rho.push_back(r_prev);
-                        c_bound = c_bound * (a * r_prev + (EF::one() - a) * (EF::one() - r_prev));
-                        // next claim s(r) = c_bound' * S(r), S through (0, S0), (1, S1), (2, S2)
-                        const EF rm1 = r_prev - EF::one(), rm2 = rm1 - EF::one();
-                        claim = c_bound * (S0 * (rm1 * rm2) * inv2 - S[0] * (r_prev * rm2) + S[1] * (r_prev * rm1) * inv2);
-                    }
-                    // last fold: one record (the layer claims)
-                    OVM_THROW_IF(gkr_fold_final(rec, r_prev, mb.arm(nullptr), cx.stream));
-                    auto fin = mb.take(4, cx.stream);
-                    claims.push_back({fin[0], fin[2], fin[1], fin[3]});
-                    observe_claims(claims.back());
-                    EF mu = ts.sample_ext();
-                    xi_prev.clear();
-                    xi_prev.push_back(mu);
-                    xi_prev.insert(xi_prev.end(), rho.begin(), rho.end());
-                    gkr_polys.push_back(std::move(polys));
-                }
-            }
-            xi = xi_prev;
+            GkrSharded drv(plan, sh, gd, alpha);
+            drv.force_three_points = force_three_points;
+            drv.observe = [this](const EF &e) { ts.observe_ext(e); };
+            drv.sample = [this]() { return ts.sample_ext(); };
+            GkrOutput go = drv.run();
+            q0_claim = go.q0_claim;
+            claims = std::move(go.claims);
+            gkr_polys = std::move(go.polys);
+            xi = std::move(go.xi);
         }
         wt.mark("rap.gkr");
         const unsigned n_global = std::max(n_max, n_logup);
@@ -1042,6 +1153,7 @@ struct Prover {
         auto d_sp_all = cx.upload(shift_pows);
         auto d_xi = cx.upload(xi);
         for (size_t t = 0; t < T; t++) {
+            if (!mine(t)) continue;
             const AirKey &a = air(t);
             TraceView &v = tv[t];
             Round0Job &job = jobs[t];
@@ -1163,6 +1275,7 @@ struct Prover {
         }
         if (next_slot) mb.wait(cx.stream);
         for (size_t t = 0; t < T; t++) {
+            if (!mine(t)) continue;
             Round0Job &job = jobs[t];
             TraceView &v = tv[t];
             const unsigned cdeg = job.cdeg;
@@ -1202,6 +1315,8 @@ struct Prover {
             job = Round0Job();  // release the LDE and scratch buffers
         }
 
+        // (sharded: the coefficient vectors of a trace come from its owner)
+        share_vectors(sp0, [&](size_t i) { return owner[i < 2 * T ? i / 2 : i - 2 * T]; });
         wt.mark("rap.round0");
         // ---- s_0 assembly (host; a few dozen extension-field elements) ----
         const unsigned sp0_deg = cdeg_global * (unsigned)(N - 1), s_deg = cdeg_global + 1, s0_deg = s_deg * (unsigned)(N - 1);
@@ -1281,6 +1396,7 @@ struct Prover {
             auto d_w = cx.upload(wts);
             OVM_PROF("constraints.fold_ple", cx.stream);
             for (size_t t = 0; t < T; t++) {
+                if (!mine(t)) continue;
                 TraceView &v = tv[t];
                 size_t h = size_t(1) << v.n_lift;
                 v.mats_a.alloc(v.cm.total * h);
@@ -1309,7 +1425,7 @@ struct Prover {
         std::vector<DevBuf<EF>> d_eqr_by_nlift(n_max + 1);
         std::vector<DevBuf<EF>> mle_partials(2 * T);
         for (size_t t = 0; t < T; t++) {
-            if (tv[t].n_lift == 0) continue;
+            if (tv[t].n_lift == 0 || !mine(t)) continue;
             if (!d_eqr_by_nlift[tv[t].n_lift].p) d_eqr_by_nlift[tv[t].n_lift].alloc(size_t(1) << tv[t].n_lift);
             // records of 8 sums per (workgroup, group); the batched kernel's lanes enumerate (pair, point), so it can
             // run up to `degree` times the workgroups of the per-pair kernels
@@ -1355,7 +1471,7 @@ struct Prover {
             };
             for (size_t t = 0; t < T; t++) {
                 TraceView &v = tv[t];
-                if (round > v.n_lift) continue;
+                if (round > v.n_lift || !mine(t)) continue;
                 const bool has_int = !air(t).interactions.empty();
                 const unsigned log_num_y = v.n_lift - round;
                 DevBuf<EF> &d_eqr = d_eqr_by_nlift[v.n_lift];
@@ -1377,8 +1493,9 @@ struct Prover {
                                                     mb.arm(nullptr, 0), cx.stream));
             }
             if (any_launch) mb.wait(cx.stream);
-            // phase B: host
+            // phase B: host (the owner of a trace evaluates its round polynomials; sharded: then all-gathered)
             for (size_t t = 0; t < T; t++) {
+                if (!mine(t)) continue;
                 TraceView &v = tv[t];
                 const AirKey &a = air(t);
                 bool has_int = !a.interactions.empty();
@@ -1418,6 +1535,7 @@ struct Prover {
                     }
                 }
             }
+            share_vectors(sp, [&](size_t i) { return owner[i < 2 * T ? i / 2 : i - 2 * T]; });
             size_t tail_start = T;
             for (size_t t = 0; t < T; t++)
                 if ((int)round > tv[t].n) {
@@ -1497,6 +1615,16 @@ struct Prover {
         wt.mark("rap.mle_rounds");
         // ---- openings ---- (cpu.rs:644-694, mod.rs:408-424): per trace the parts [common main,
         // preprocessed?, cached_0, ...], each as (claim, rotated claim) pairs when the AIR needs rotation
+        if (!sh.single()) {
+            std::vector<std::vector<EF>> rows(T);
+            for (size_t t = 0; t < T; t++)
+                if (mine(t)) rows[t] = tv[t].final_row;
+            share_vectors(rows, [&](size_t t) { return owner[t]; });
+            for (size_t t = 0; t < T; t++) {
+                if (rows[t].size() != tv[t].cm.total) throw OvmFail(1, "shard exchange: column openings of the wrong length");
+                tv[t].final_row = std::move(rows[t]);
+            }
+        }
         std::vector<std::vector<std::vector<EF>>> openings(T);
         for (size_t t = 0; t < T; t++) {
             TraceView &v = tv[t];
@@ -1545,37 +1673,112 @@ struct Prover {
     // -----------------------------------------------------------------------------------------
     // Stage 3: stacked opening reduction + WHIR (OpeningProver::prove_openings)
     // -----------------------------------------------------------------------------------------
-    // `commits`: the common-main commitment first, then per trace (sorted order) its preprocessed
-    // commitment (if any) and its cached mains (cpu-backend/src/device.rs:147-172).
-    std::vector<const PcsData *> gather_commits(const PcsData &common, std::vector<std::vector<bool>> &need_rot) const {
-        std::vector<const PcsData *> commits{&common};
-        need_rot.clear();
-        need_rot.emplace_back();
-        for (size_t t = 0; t < traces.size(); t++) need_rot[0].push_back(air(t).need_rot);
+    // The commitments of a proof: the common main first, then per trace (sorted order) its preprocessed
+    // commitment (if any) and its cached mains (cpu-backend/src/device.rs:147-172). Layout, root and owner
+    // are known on every rank; the data (`pcs`) only on the owner -- rank 0 for the common main, the owner
+    // of the trace for the others.
+    struct CommitRef {
+        const PcsData *pcs = nullptr;
+        Layout layout;
+        p2::Digest root;
+        uint32_t owner = 0;
+        std::vector<bool> need_rot;  // per stacked matrix
+    };
+    Layout common_main_layout() const {
+        std::vector<std::pair<size_t, unsigned>> meta;
+        for (size_t t = 0; t < traces.size(); t++) meta.push_back({air(t).common_main_width, log2_strict(traces[t].height)});
+        return Layout(P().l_skip, P().l_skip + P().n_stack, meta);
+    }
+    std::vector<CommitRef> gather_commits(const PcsData *common, const p2::Digest &common_root) const {
+        const unsigned l_skip = P().l_skip, lh = l_skip + P().n_stack;
+        std::vector<CommitRef> commits(1);
+        commits[0].pcs = common;
+        commits[0].layout = common_main_layout();
+        commits[0].root = common_root;
+        commits[0].owner = 0;
+        for (size_t t = 0; t < traces.size(); t++) commits[0].need_rot.push_back(air(t).need_rot);
         for (size_t t = 0; t < traces.size(); t++) {
+            const unsigned log_h = log2_strict(traces[t].height);
             if (air(t).preprocessed_width) {
                 if (!pre_of(t)) throw OvmFail(1, "preprocessed commitment missing");
-                commits.push_back(pre_of(t));
-                need_rot.push_back({air(t).need_rot});
+                CommitRef c;
+                c.pcs = mine(t) ? pre_of(t) : nullptr;
+                c.layout = Layout(l_skip, lh, {{air(t).preprocessed_width, log_h}});
+                c.root = pre_of(t)->root;
+                c.owner = owner[t];
+                c.need_rot = {air(t).need_rot};
+                commits.push_back(std::move(c));
             }
-            for (auto *c : traces[t].cached) {
-                commits.push_back(c);
-                need_rot.push_back({air(t).need_rot});
+            if (traces[t].cached_roots.size() != air(t).cached_widths.size()) throw OvmFail(1, "cached main partitions: wrong count");
+            for (size_t k = 0; k < air(t).cached_widths.size(); k++) {
+                CommitRef c;
+                c.pcs = mine(t) ? traces[t].cached[k] : nullptr;
+                c.layout = Layout(l_skip, lh, {{air(t).cached_widths[k], log_h}});
+                c.root = traces[t].cached_roots[k];
+                c.owner = owner[t];
+                c.need_rot = {air(t).need_rot};
+                commits.push_back(std::move(c));
             }
         }
+        for (auto &c : commits)
+            if (c.owner == sh.rank && (!c.pcs || c.pcs->log_height != lh || c.pcs->layout.width != c.layout.width))
+                throw OvmFail(1, "commitment missing or of a different stacked shape");
         return commits;
     }
+    // v += the same vector of every other rank (sharded proving; identity on one rank)
+    void share_sum(std::vector<EF> &v) {
+        if (sh.single() || v.empty()) return;
+        std::vector<EF> all(v.size() * sh.world);
+        sh.allgather(v.data(), all.data(), v.size() * sizeof(EF));
+        for (size_t i = 0; i < v.size(); i++) {
+            EF acc = EF::zero();
+            for (uint32_t r = 0; r < sh.world; r++) acc += all[r * v.size() + i];
+            v[i] = acc;
+        }
+    }
 
-    void prove_openings(const PcsData &common_main, const std::vector<EF> &r) {
+    // Opened rows and Merkle paths of one initial commitment at WHIR round-0 query indices (whir.rs: the rows
+    // {i + t * query_stride} of query i and the siblings along its path; physical order, see merkle.hip):
+    // vals[(q * 2^k + t) * width + c], digs[q * lq + j].
+    void open_initial_rows(const PcsData &pcs, const std::vector<uint64_t> &qidx, unsigned lq, std::vector<Fp> &vals,
+                           std::vector<p2::Digest> &digs) {
+        const unsigned k_whir = P().k_whir;
+        const uint64_t qs = 1ull << lq;
+        std::vector<uint64_t> rows, didx;
+        for (uint64_t i : qidx) {
+            uint64_t grp = bitrev64(i, lq);
+            for (uint64_t t = 0; t < (1ull << k_whir); t++) rows.push_back((grp << k_whir) + bitrev64(t, k_whir));
+            for (unsigned j = 0; j < lq; j++) didx.push_back(layer_entry(qs, lq, j, (i >> j) ^ 1));
+        }
+        const size_t cw = pcs.layout.width;
+        auto d_rows = cx.upload(rows);
+        auto d_didx = cx.upload(didx);
+        DevBuf<p2::Digest> d_dig(std::max<size_t>(didx.size(), 1));
+        DevBuf<Fp> d_vals(std::max<size_t>(rows.size() * cw, 1));
+        OVM_THROW_IF(ovm_hip_gather_rows((const uint32_t *)pcs.codeword.p, cw, 1ull << pcs.log_rows, 1, d_rows.p, rows.size(),
+                                         (uint32_t *)d_vals.p, cx.stream));
+        OVM_THROW_IF(ovm_hip_gather_digests((const uint32_t *)pcs.layers.p, d_didx.p, didx.size(), (uint32_t *)d_dig.p, cx.stream));
+        vals = cx.download(d_vals.p, rows.size() * cw);
+        digs = cx.download(d_dig.p, didx.size());
+    }
+
+    // `common_main`: the common-main PCS data (sharded: on rank 0 only, null elsewhere); its root is known everywhere.
+    void prove_openings(const PcsData *common_main, const p2::Digest &common_root, const std::vector<EF> &r) {
         const unsigned l_skip = P().l_skip, n_stack = P().n_stack;
         const size_t N = size_t(1) << l_skip, H = size_t(1) << (l_skip + n_stack);
-        std::vector<std::vector<bool>> need_rot_per_commit;
-        const std::vector<const PcsData *> commits = gather_commits(common_main, need_rot_per_commit);
-        // the stacked matrices of all commitments side by side: commitment c owns columns [coff[c], coff[c+1])
-        std::vector<size_t> coff{0};
-        for (auto *c : commits) {
-            if (c->log_height != l_skip + n_stack) throw OvmFail(1, "commitment with a different stacked height");
-            coff.push_back(coff.back() + c->layout.width);
+        const std::vector<CommitRef> commits = gather_commits(common_main, common_root);
+        const bool root_rank = sh.rank == 0;
+        auto own = [&](size_t com) { return commits[com].owner == sh.rank; };
+        // the stacked matrices of all commitments side by side: commitment c owns columns [coff[c], coff[c+1]);
+        // this rank holds the columns of ITS commitments, side by side, at [loff[c], loff[c] + width_c)
+        std::vector<size_t> coff{0}, loff(commits.size(), 0);
+        size_t lwidth = 0;
+        for (size_t com = 0; com < commits.size(); com++) {
+            coff.push_back(coff.back() + commits[com].layout.width);
+            if (own(com)) {
+                loff[com] = lwidth;
+                lwidth += commits[com].layout.width;
+            }
         }
         const size_t width = coff.back();
         ByteWriter &w = out;
@@ -1592,10 +1795,10 @@ struct Prover {
         std::vector<TV> tvs;
         size_t li = 0;
         for (size_t com = 0; com < commits.size(); com++)
-            for (auto &sc : commits[com]->layout.cols) {
+            for (auto &sc : commits[com].layout.cols) {
                 TV t{com, sc.slice, li, -1};
                 li++;
-                if (need_rot_per_commit[com][sc.mat_idx]) t.lrot = (long)li;
+                if (commits[com].need_rot[sc.mat_idx]) t.lrot = (long)li;
                 li++;
                 tvs.push_back(t);
             }
@@ -1613,7 +1816,7 @@ struct Prover {
             unsigned log_height, n_lift, cur_log_h;
             int n;
             DevBuf<EF> eq_cube, vec_a, vec_b;
-            bool in_a = true;
+            bool in_a = true, own = false;
             EF eq_fin = EF::zero(), krot_fin = EF::zero();
         };
         std::vector<Window> ws(W);
@@ -1625,12 +1828,16 @@ struct Prover {
         // phase B: one wait, then the host algebra per window
         if (64 * W + 64 > Mailbox::SLOTS) throw OvmFail(801, "too many stacking windows for the mailbox");
         std::vector<DevBuf<EF>> r0_partials(W);
+        bool any_own_window = false;
         for (size_t wi = 0; wi < W; wi++) {
             Window &wd = ws[wi];
             size_t w0 = win[wi], w1 = win[wi + 1];
             wd.log_height = tvs[w0].s.log_height;
             wd.n = (int)wd.log_height - (int)l_skip;
             wd.n_lift = (unsigned)std::max(wd.n, 0);
+            wd.own = own(tvs[w0].com);
+            if (!wd.own) continue;
+            any_own_window = true;
             wd.eq_cube.alloc(size_t(1) << wd.n_lift);
             {
                 std::vector<EF> pt(r.begin() + 1, r.begin() + 1 + wd.n_lift);
@@ -1645,17 +1852,18 @@ struct Prover {
             auto d_leq = cx.upload(leq);
             auto d_lrot = cx.upload(lrot);
             unsigned log_len = std::max(wd.log_height, l_skip);
-            const Fp *base = commits[tvs[w0].com]->stacked_view + tvs[w0].s.col_idx * H + tvs[w0].s.row_idx;
+            const Fp *base = commits[tvs[w0].com].pcs->stacked_view + tvs[w0].s.col_idx * H + tvs[w0].s.row_idx;
             bool any_rot = false;
             for (auto &x : lrot) any_rot |= !is_zero(x);
             r0_partials[wi].alloc((size_t)RED_BLOCKS * 3 * N + 64);  // (grid * slice chunks <= RED_BLOCKS records)
             OVM_THROW_IF(stacked_round0(base, (uint32_t)(w1 - w0), log_len, l_skip, d_leq.p, any_rot ? d_lrot.p : nullptr, wd.eq_cube.p,
                                         mb.arm(r0_partials[wi].p, 64 * wi), cx.stream));
         }
-        if (W) mb.wait(cx.stream);
+        if (any_own_window) mb.wait(cx.stream);
         r0_partials.clear();
         for (size_t wi = 0; wi < W; wi++) {
             Window &wd = ws[wi];
+            if (!wd.own) continue;
             auto R = mb.read(64 * wi, 3 * N);
             // host: chunk-aggregated vectors -> coset evaluations with the univariate factors
             std::vector<std::vector<EF>> coef(3);
@@ -1685,6 +1893,7 @@ struct Prover {
             std::vector<EF> p0 = from_coset_evals(e0, l_skip), p1 = from_coset_evals(e1, l_skip);
             for (size_t i = 0; i <= s0_deg; i++) s0[i] += p0[i] + p1[i];
         }
+        share_sum(s0);  // (sharded: every rank has summed its own windows)
         delete ps_st0;
         wt.mark("openings.stacked.round0");
         for (auto &c : s0) ts.observe_ext(c);
@@ -1693,7 +1902,7 @@ struct Prover {
         u.push_back(u0);
 
         // fold the stacked matrix at u_0
-        DevBuf<EF> q_a(width << n_stack), q_b(width << (n_stack ? n_stack - 1 : 0));
+        DevBuf<EF> q_a(std::max<size_t>(lwidth, 1) << n_stack), q_b(std::max<size_t>(lwidth, 1) << (n_stack ? n_stack - 1 : 0));
         bool q_in_a = true;
         unsigned q_log_h = n_stack;
         ProfScope *ps_stf = new ProfScope("stacked.fold_ple", cx.stream);
@@ -1703,12 +1912,13 @@ struct Prover {
             std::vector<EF> wts(N);
             for (size_t z = 0; z < N; z++) wts[z] = un * (u0 - omega_pows[z]).inv() * (omega_pows[z] * ninv);
             auto d_w = cx.upload(wts);
-            std::vector<ColDesc> cd(width);
+            std::vector<ColDesc> cd(lwidth);
             for (size_t com = 0; com < commits.size(); com++)
-                for (size_t c = 0; c < commits[com]->layout.width; c++)
-                    cd[coff[com] + c] = ColDesc{commits[com]->stacked_view + c * H, l_skip + n_stack, 0};
+                for (size_t c = 0; own(com) && c < commits[com].layout.width; c++)
+                    cd[loff[com] + c] = ColDesc{commits[com].pcs->stacked_view + c * H, l_skip + n_stack, 0};
             auto d_cd = cx.upload(cd);
-            OVM_THROW_IF(fold_ple(d_cd.p, nullptr, (uint32_t)width, l_skip + n_stack, l_skip, d_w.p, q_a.p, cx.stream));
+            if (lwidth)
+                OVM_THROW_IF(fold_ple(d_cd.p, nullptr, (uint32_t)lwidth, l_skip + n_stack, l_skip, d_w.p, q_a.p, cx.stream));
             // (no synchronisation: the temporaries go back to the block cache and are only ever reused by later
             // work on this same stream)
         }
@@ -1719,6 +1929,7 @@ struct Prover {
             EF eq_u0r0 = eq_uni(l_skip, u0, r0), eq_u0r0_rot = eq_uni(l_skip, u0, r0 * omega_skip), eq_u01 = eq_uni_at_one(l_skip, u0);
             for (size_t wi = 0; wi < W; wi++) {
                 Window &wd = ws[wi];
+                if (!wd.own) continue;
                 size_t w0 = win[wi], w1 = win[wi + 1], hw = size_t(1) << wd.n_lift;
                 EF ind = in_uni(l_skip, wd.n, u0), equ = eq_u0r0, equ_rot = eq_u0r0_rot;
                 if (wd.n < 0) {
@@ -1736,7 +1947,7 @@ struct Prover {
                 std::vector<uint64_t> off;
                 std::vector<EF> ce, cr;
                 for (size_t i = w0; i < w1; i++) {
-                    off.push_back(((uint64_t)(coff[tvs[i].com] + tvs[i].s.col_idx) << n_stack) + (tvs[i].s.row_idx >> l_skip));
+                    off.push_back(((uint64_t)(loff[tvs[i].com] + tvs[i].s.col_idx) << n_stack) + (tvs[i].s.row_idx >> l_skip));
                     ce.push_back(lam[tvs[i].leq]);
                     cr.push_back(tvs[i].lrot >= 0 ? lam[(size_t)tvs[i].lrot] : EF::zero());
                 }
@@ -1776,14 +1987,14 @@ struct Prover {
         // enqueued together and waited for once
         std::vector<DevBuf<EF>> round_partials(W);
         for (size_t wi = 0; wi < W; wi++)
-            if (ws[wi].n_lift) round_partials[wi].alloc(std::min<size_t>(RED_BLOCKS, ((size_t(1) << (ws[wi].n_lift - 1)) + RED_THREADS - 1) / RED_THREADS) * 2 + 64);
+            if (ws[wi].n_lift && ws[wi].own) round_partials[wi].alloc(std::min<size_t>(RED_BLOCKS, ((size_t(1) << (ws[wi].n_lift - 1)) + RED_THREADS - 1) / RED_THREADS) * 2 + 64);
         for (unsigned round = 1; round <= n_stack; round++) {
             std::array<EF, 2> batch{EF::zero(), EF::zero()};
             const EF *q_cur = q_in_a ? q_a.p : q_b.p;
             bool any_window_launch = false;
             for (size_t wi = 0; wi < W; wi++) {
                 Window &wd = ws[wi];
-                if (round > wd.n_lift) continue;
+                if (round > wd.n_lift || !wd.own) continue;
                 const EF *vec = wd.in_a ? wd.vec_a.p : wd.vec_b.p;
                 OVM_THROW_IF(stacked_round(vec, wd.cur_log_h, mb.arm(round_partials[wi].p, 8 * wi), cx.stream));
                 any_window_launch = true;
@@ -1792,10 +2003,10 @@ struct Prover {
             std::vector<uint64_t> gidx;
             std::vector<size_t> gslice;
             for (size_t wi = 0; wi < W; wi++)
-                if (round > ws[wi].n_lift)
+                if (round > ws[wi].n_lift && ws[wi].own)
                     for (size_t i = win[wi]; i < win[wi + 1]; i++) {
                         uint64_t row_start = (tvs[i].s.row_idx >> (l_skip + round)) << 1;
-                        const uint64_t gcol = coff[tvs[i].com] + tvs[i].s.col_idx;
+                        const uint64_t gcol = loff[tvs[i].com] + tvs[i].s.col_idx;
                         gidx.push_back((gcol << q_log_h) + row_start);
                         gidx.push_back((gcol << q_log_h) + row_start + 1);
                         gslice.push_back(i);
@@ -1810,6 +2021,7 @@ struct Prover {
             size_t gi = 0;
             for (size_t wi = 0; wi < W; wi++) {
                 Window &wd = ws[wi];
+                if (!wd.own) continue;
                 if (round <= wd.n_lift) {
                     auto sv = mb.read(8 * wi, 2);
                     batch[0] += sv[0];
@@ -1838,13 +2050,18 @@ struct Prover {
                     }
                 }
             }
+            if (!sh.single()) {  // every rank has summed its own windows and finished slices
+                std::vector<EF> bv{batch[0], batch[1]};
+                share_sum(bv);
+                batch = {bv[0], bv[1]};
+            }
             for (auto &e : batch) ts.observe_ext(e);
             st_polys.push_back(batch);
             EF ur = ts.sample_ext();
             u.push_back(ur);
             {
                 EF *qo = q_in_a ? q_b.p : q_a.p;
-                OVM_THROW_IF(fold_mle(q_cur, qo, (uint32_t)width, q_log_h, ur, cx.stream));
+                if (lwidth) OVM_THROW_IF(fold_mle(q_cur, qo, (uint32_t)lwidth, q_log_h, ur, cx.stream));
                 q_in_a = !q_in_a;
                 q_log_h--;
             }
@@ -1853,7 +2070,7 @@ struct Prover {
                 std::vector<FoldJob> fj;
                 for (size_t wi = 0; wi < W; wi++) {
                     Window &wd = ws[wi];
-                    if (wd.cur_log_h == 0) continue;
+                    if (wd.cur_log_h == 0 || !wd.own) continue;
                     const EF *in = wd.in_a ? wd.vec_a.p : wd.vec_b.p;
                     EF *o = wd.in_a ? wd.vec_b.p : wd.vec_a.p;
                     if (wd.cur_log_h <= 11)
@@ -1867,7 +2084,7 @@ struct Prover {
                 }
                 for (size_t wi = 0; wi < W; wi++) {
                     Window &wd = ws[wi];
-                    if (wd.cur_log_h == 0) continue;
+                    if (wd.cur_log_h == 0 || !wd.own) continue;
                     EF *o = wd.in_a ? wd.vec_b.p : wd.vec_a.p;
                     wd.in_a = !wd.in_a;
                     wd.cur_log_h--;
@@ -1885,7 +2102,18 @@ struct Prover {
         }
         delete ps_str;
         wt.mark("openings.stacked.rounds");
-        std::vector<EF> stacking_openings = cx.download(q_in_a ? q_a.p : q_b.p, width);
+        std::vector<EF> stacking_openings(width, EF::zero());
+        {
+            std::vector<EF> local = cx.download(q_in_a ? q_a.p : q_b.p, lwidth);
+            std::vector<std::vector<EF>> per_commit(commits.size());
+            for (size_t com = 0; com < commits.size(); com++)
+                if (own(com)) per_commit[com].assign(local.begin() + loff[com], local.begin() + loff[com] + commits[com].layout.width);
+            share_vectors(per_commit, [&](size_t com) { return commits[com].owner; });
+            for (size_t com = 0; com < commits.size(); com++) {
+                if (per_commit[com].size() != commits[com].layout.width) throw OvmFail(1, "shard exchange: stacking openings of the wrong length");
+                std::copy(per_commit[com].begin(), per_commit[com].end(), stacking_openings.begin() + coff[com]);
+            }
+        }
         for (auto &c : stacking_openings) ts.observe_ext(c);
         q_a.release();
         q_b.release();
@@ -1920,14 +2148,54 @@ struct Prover {
         Fp mu_pow_witness = ts.grind(P().mu_pow_bits);
         EF mu = ts.sample_ext();
         unsigned m = l_skip + n_stack;
-        DevBuf<EF> f_a(size_t(1) << m), f_b(size_t(1) << (m - 1)), w_a(size_t(1) << m), w_b(size_t(1) << (m - 1));
+        DevBuf<EF> f_a(size_t(1) << m), f_b(size_t(1) << (m - 1)), w_a, w_b;
         {
-            OVM_PROF("whir.mu_batch", cx.stream);
+            ProfScope ps_mu("whir.mu_batch", cx.stream);
             std::vector<EF> mu_pows = powers_of(mu, width);
             auto d_mu = cx.upload(mu_pows);
-            for (size_t com = 0; com < commits.size(); com++)
-                OVM_THROW_IF(whir_mu_batch(commits[com]->msg.p, (uint32_t)commits[com]->layout.width, m, d_mu.p,
-                                           (uint32_t)coff[com], f_a.p, com ? 1 : 0, cx.stream));
+            bool first = true;
+            for (size_t com = 0; com < commits.size(); com++) {
+                if (!own(com)) continue;
+                OVM_THROW_IF(whir_mu_batch(commits[com].pcs->msg.p, (uint32_t)commits[com].layout.width, m, d_mu.p,
+                                           (uint32_t)coff[com], f_a.p, first ? 0 : 1, cx.stream));
+                first = false;
+            }
+            if (first) OVM_THROW_IF(hipMemsetAsync(f_a.p, 0, sizeof(EF) << m, cx.stream));  // (a rank without commitments)
+        }
+        if (!sh.single()) {
+            // THE bulk exchange of a sharded proof (north_star: "RCCL allgather only at the FRI batch-opening
+            // step"; prover/whir.rs:95-132 batches all commitments into one vector): every rank holds the
+            // mu-weighted sum of ITS columns; all-gather the vectors and add them up. Modular addition is not
+            // an RCCL reduction, hence gather + local add; only rank 0 goes on with the sum.
+            OVM_PROF("whir.mu_allgather", cx.stream);
+            DevBuf<EF> gathered((size_t)sh.world << m);
+            sh.allgather_device(f_a.p, gathered.p, sizeof(EF) << m, (ovm_stream_t)cx.stream);
+            if (root_rank) OVM_THROW_IF(ef_sum_blocks(gathered.p, sh.world, uint64_t(1) << m, f_a.p, cx.stream));
+        }
+        if (!root_rank) {
+            // This rank's remaining part: the rows and Merkle paths of ITS commitments that the first WHIR round
+            // opens, at the query indices rank 0 samples (nothing later in the transcript depends on them).
+            const unsigned lq0 = m + P().log_blowup - P().k_whir;
+            Unpacker uq(sh.bcast(0, {}));
+            const std::vector<uint64_t> qidx0 = uq.get_vec<uint64_t>();
+            Packer pk_;
+            for (size_t com = 0; com < commits.size(); com++) {
+                if (!own(com)) continue;
+                std::vector<Fp> vals;
+                std::vector<p2::Digest> digs;
+                open_initial_rows(*commits[com].pcs, qidx0, lq0, vals, digs);
+                pk_.put<uint64_t>(com);
+                pk_.put_vec(vals);
+                pk_.put_vec(digs);
+            }
+            sh.allgatherv(pk_.buf);
+            section_offsets.push_back(w.buf.size());
+            return;
+        }
+        w_a.alloc(size_t(1) << m);
+        w_b.alloc(size_t(1) << (m - 1));
+        {
+            OVM_PROF("whir.mu_batch", cx.stream);
             OVM_THROW_IF(zeta_transform(f_a.p, m, +1, cx.stream));
             auto d_u = cx.upload(u_cube);
             OVM_THROW_IF(mobius_eq_table(d_u.p, m, w_a.p, cx.stream));
@@ -2024,15 +2292,32 @@ struct Prover {
                 auto d_didx = cx.upload(didx);
                 DevBuf<p2::Digest> d_dig(std::max<size_t>(didx.size(), 1));
                 if (wr == 0) {
+                    // sharded: the other ranks open the rows of their own commitments at these indices
+                    std::vector<std::vector<uint8_t>> remote;
+                    if (!sh.single()) {
+                        Packer pq;
+                        pq.put_vec(qidx);
+                        sh.bcast(0, pq.buf);
+                        remote = sh.allgatherv({});
+                    }
+                    std::vector<std::vector<Fp>> vals_of(commits.size());
+                    std::vector<std::vector<p2::Digest>> digs_of(commits.size());
+                    for (size_t com = 0; com < commits.size(); com++)
+                        if (own(com)) open_initial_rows(*commits[com].pcs, qidx, lq, vals_of[com], digs_of[com]);
+                    for (uint32_t rk = 1; rk < sh.world; rk++) {
+                        Unpacker u(remote[rk]);
+                        while (!u.done()) {
+                            const uint64_t com = u.get<uint64_t>();
+                            if (com >= commits.size() || commits[com].owner != rk) throw OvmFail(1, "shard exchange: unexpected opened rows");
+                            vals_of[com] = u.get_vec<Fp>();
+                            digs_of[com] = u.get_vec<p2::Digest>();
+                        }
+                    }
                     for (size_t com = 0; com < commits.size(); com++) {
-                        const PcsData &pcs = *commits[com];
-                        const size_t cw = pcs.layout.width;
-                        DevBuf<Fp> d_vals(std::max<size_t>(rows.size() * cw, 1));
-                        OVM_THROW_IF(ovm_hip_gather_rows((const uint32_t *)pcs.codeword.p, cw, 1ull << pcs.log_rows, 1, d_rows.p,
-                                                         rows.size(), (uint32_t *)d_vals.p, cx.stream));
-                        OVM_THROW_IF(ovm_hip_gather_digests((const uint32_t *)pcs.layers.p, d_didx.p, didx.size(), (uint32_t *)d_dig.p, cx.stream));
-                        auto vals = cx.download(d_vals.p, rows.size() * cw);
-                        auto digs = cx.download(d_dig.p, didx.size());
+                        const size_t cw = commits[com].layout.width;
+                        const auto &vals = vals_of[com];
+                        const auto &digs = digs_of[com];
+                        if (vals.size() != rows.size() * cw || digs.size() != didx.size()) throw OvmFail(1, "opened rows of the wrong size");
                         for (size_t q = 0; q < nq; q++) {
                             std::vector<std::vector<Fp>> qr;
                             for (size_t t = 0; t < (size_t(1) << k_whir); t++) {
@@ -2113,7 +2398,7 @@ struct Prover {
         w.usize(init_rows[0].size());
         if (!init_rows[0].empty()) {
             w.usize(init_proofs[0][0].size());
-            for (auto *c : commits) w.usize(c->layout.width);
+            for (auto &c : commits) w.usize(c.layout.width);
             for (auto &cr : init_rows)
                 for (auto &qr : cr)
                     for (auto &row : qr)
@@ -2148,11 +2433,82 @@ struct Prover {
             if (a.height != b.height) return a.height > b.height;
             return a.air_idx < b.air_idx;
         });
+        owner.clear();
         for (auto &t : traces) {
             if (t.air_idx >= pk.airs.size()) throw OvmFail(1, "air index out of range");
-            if (need_public_values && t.public_values.size() != pk.airs[t.air_idx].num_public_values)
+            if (t.owner >= sh.world) throw OvmFail(1, "trace owner out of range");
+            if (!owner.empty() && t.owner < owner.back())
+                throw OvmFail(1, "sharded proving: owners must be non-decreasing over the traces sorted by (height desc, air index)");
+            owner.push_back(t.owner);
+            if (need_public_values && t.owner == sh.rank && t.public_values.size() != pk.airs[t.air_idx].num_public_values)
                 throw OvmFail(1, "public values length");
+            if (t.owner == sh.rank) {
+                t.cached_roots.clear();
+                for (auto *c : t.cached) t.cached_roots.push_back(c->root);
+            }
         }
+    }
+
+    // Sharded: the common mains of all traces are needed where the common-main commitment is built (rank 0).
+    // Every rank contributes the common mains of ITS traces (concatenated in sorted order) to one device
+    // all-gather; rank 0 stacks and commits from the gathered buffer. (The per-AIR bulk -- the cached mains --
+    // never moves: SURVEY §8(e) "committing each AIR's trace as its own commitment".)
+    DevBuf<Fp> common_gathered;
+    void commit_common_sharded(PcsData &pcs, p2::Digest &root) {
+        std::vector<uint64_t> words_of_rank(sh.world, 0), off_in_rank(traces.size(), 0);
+        for (size_t t = 0; t < traces.size(); t++) {
+            off_in_rank[t] = words_of_rank[owner[t]];
+            words_of_rank[owner[t]] += (uint64_t)air(t).common_main_width * traces[t].height;
+        }
+        uint64_t max_words = 0;
+        for (uint64_t wds : words_of_rank) max_words = std::max(max_words, wds);
+        if (max_words) {
+            DevBuf<Fp> send(max_words);
+            for (size_t t = 0; t < traces.size(); t++) {
+                const uint64_t n = (uint64_t)air(t).common_main_width * traces[t].height;
+                if (mine(t) && n)
+                    OVM_THROW_IF(hipMemcpyAsync(send.p + off_in_rank[t], traces[t].d_trace, n * sizeof(Fp), hipMemcpyDeviceToDevice, cx.stream));
+            }
+            common_gathered.alloc(max_words * sh.world);
+            sh.allgather_device(send.p, common_gathered.p, max_words * sizeof(Fp), (ovm_stream_t)cx.stream);
+            cx.sync();  // (`send` goes back to the cache: the exchange may have run on another stream)
+        }
+        if (sh.rank == 0) {
+            std::vector<MatIn> mats;
+            for (size_t t = 0; t < traces.size(); t++)
+                mats.push_back({common_gathered.p + owner[t] * max_words + off_in_rank[t], air(t).common_main_width, traces[t].height});
+            pcs = commit_mats(mats);
+            root = pcs.root;
+        }
+        std::vector<uint8_t> rb(sizeof(p2::Digest));
+        memcpy(rb.data(), &root, sizeof(p2::Digest));
+        rb = sh.bcast(0, rb);
+        if (rb.size() != sizeof(p2::Digest)) throw OvmFail(1, "shard exchange: common-main root");
+        memcpy(&root, rb.data(), sizeof(p2::Digest));
+    }
+    // Sharded: public values and cached-main commitments of every trace, from its owner.
+    void exchange_trace_meta() {
+        Packer pk_;
+        for (size_t t = 0; t < traces.size(); t++)
+            if (mine(t)) {
+                pk_.put<uint64_t>(t);
+                pk_.put_vec(traces[t].public_values);
+                pk_.put_vec(traces[t].cached_roots);
+            }
+        const auto all = sh.allgatherv(pk_.buf);
+        for (uint32_t r = 0; r < sh.world; r++) {
+            if (r == sh.rank) continue;
+            Unpacker u(all[r]);
+            while (!u.done()) {
+                const uint64_t t = u.get<uint64_t>();
+                if (t >= traces.size() || owner[t] != r) throw OvmFail(1, "shard exchange: unexpected trace record");
+                traces[t].public_values = u.get_vec<Fp>();
+                traces[t].cached_roots = u.get_vec<p2::Digest>();
+            }
+        }
+        for (size_t t = 0; t < traces.size(); t++)
+            if (traces[t].public_values.size() != air(t).num_public_values || traces[t].cached_roots.size() != air(t).cached_widths.size())
+                throw OvmFail(1, "shard exchange: public values / cached commitments of a trace are missing");
     }
 
     void prove(std::vector<TraceIn> in) {
@@ -2160,12 +2516,20 @@ struct Prover {
         ts.observe_digest(pk.vk_pre_hash);
         programs_future = std::async(std::launch::async, [this] { return compile_all_programs(); });
         wt.mark("setup");
-        PcsData pcs = commit();
+        PcsData pcs;
+        p2::Digest common_root;
+        if (sh.single()) {
+            pcs = commit();
+            common_root = pcs.root;
+        } else {
+            commit_common_sharded(pcs, common_root);
+            exchange_trace_meta();
+        }
         wt.mark("commit");
         const size_t num_airs = pk.airs.size();
         std::vector<int> present(num_airs, -1);
         for (size_t t = 0; t < traces.size(); t++) present[traces[t].air_idx] = (int)t;
-        ts.observe_digest(pcs.root);
+        ts.observe_digest(common_root);
         for (size_t a = 0; a < num_airs; a++) {
             if (!pk.airs[a].is_required) ts.observe(present[a] >= 0 ? Fp::one() : Fp::zero());
             if (present[a] >= 0) {
@@ -2177,13 +2541,13 @@ struct Prover {
                 } else {
                     ts.observe(fp(log2_strict(traces[t].height)));
                 }
-                for (auto *c : traces[t].cached) ts.observe_digest(c->root);
+                for (auto &c : traces[t].cached_roots) ts.observe_digest(c);
                 for (auto &pv : traces[t].public_values) ts.observe(pv);
             }
         }
         // proof header
         out.u32(3);  // CODEC_VERSION
-        out.digest(pcs.root);
+        out.digest(common_root);
         out.usize(num_airs);
         for (size_t a = 0; a < num_airs; a += 8) {
             uint8_t b = 0;
@@ -2194,8 +2558,8 @@ struct Prover {
         for (size_t a = 0; a < num_airs; a++)
             if (present[a] >= 0) {
                 out.usize(log2_strict(traces[present[a]].height));
-                out.usize(traces[present[a]].cached.size());
-                for (auto *c : traces[present[a]].cached) out.digest(c->root);
+                out.usize(traces[present[a]].cached_roots.size());
+                for (auto &c : traces[present[a]].cached_roots) out.digest(c);
             }
         out.usize(num_airs);
         for (size_t a = 0; a < num_airs; a++) {
@@ -2209,7 +2573,7 @@ struct Prover {
         section_offsets.push_back(out.buf.size());
         std::vector<EF> r = prove_rap_constraints();
         wt.mark("rap_constraints.rest");
-        prove_openings(pcs, r);
+        prove_openings(sh.rank == 0 ? &pcs : nullptr, common_root, r);
         wt.mark("openings.whir");
     }
 };
@@ -2321,7 +2685,9 @@ inline Fp checked_word(uint32_t w, const char *what) {
     if (w >= bb::P) throw OvmFail((int)hipErrorInvalidValue, std::string(what) + ": Montgomery word >= P");
     return Fp::raw(w);
 }
-std::vector<TraceIn> traces_from_abi(const ProvingKey &pk, uint32_t n_traces, const ovm_trace_t *tr, bool need_data = true) {
+// owner / rank (sharded proving): entries of traces held by another rank carry shape only
+std::vector<TraceIn> traces_from_abi(const ProvingKey &pk, uint32_t n_traces, const ovm_trace_t *tr, bool need_data = true,
+                                     const uint32_t *owner = nullptr, uint32_t rank = 0) {
     if (!tr) throw OvmFail((int)hipErrorInvalidValue, "traces");
     std::vector<TraceIn> in;
     std::vector<char> seen(pk.airs.size(), 0);
@@ -2332,9 +2698,14 @@ std::vector<TraceIn> traces_from_abi(const ProvingKey &pk, uint32_t n_traces, co
         if (seen[ti.air_idx]) throw OvmFail((int)hipErrorInvalidValue, "duplicate air index");
         seen[ti.air_idx] = 1;
         const AirKey &air = pk.airs[ti.air_idx];
-        ti.d_trace = (const Fp *)tr[t].d_common_main;
         ti.height = tr[t].height;
         if (ti.height == 0 || (ti.height & (ti.height - 1))) throw OvmFail((int)hipErrorInvalidValue, "trace height");
+        ti.owner = owner ? owner[t] : 0;
+        if (ti.owner != rank) {
+            in.push_back(std::move(ti));
+            continue;
+        }
+        ti.d_trace = (const Fp *)tr[t].d_common_main;
         if (need_data && !ti.d_trace && air.common_main_width) throw OvmFail((int)hipErrorInvalidValue, "d_common_main is null");
         if (tr[t].num_public_values && !tr[t].public_values) throw OvmFail((int)hipErrorInvalidValue, "public_values is null");
         for (uint32_t i = 0; i < tr[t].num_public_values; i++) ti.public_values.push_back(checked_word(tr[t].public_values[i], "public value"));
@@ -2525,6 +2896,37 @@ int ovm_hip_prove(const ovm_pk_t *pk_, uint32_t n_traces, const ovm_trace_t *tra
     });
 }
 
+int ovm_hip_prove_sharded(const ovm_pk_t *pk_, const ovm_shard_t *shard, uint32_t n_traces, const ovm_trace_t *traces,
+                          const uint32_t *owner, ovm_sponge_t *sponge, uint8_t *proof_out, uint64_t proof_cap,
+                          uint64_t *proof_len, uint64_t *section_offsets5, ovm_stream_t stream) {
+    if (!pk_ || !proof_len || n_traces == 0 || !traces || !shard || !owner || shard->world == 0 || shard->rank >= shard->world)
+        return (int)hipErrorInvalidValue;
+    const DeviceKey &dk = *reinterpret_cast<const DeviceKey *>(pk_);
+    return guarded([&]() -> int {
+        const bool root = shard->rank == 0;
+        std::vector<ShapeIn> sh;
+        for (uint32_t t = 0; t < n_traces; t++) sh.push_back({traces[t].air_idx, (size_t)traces[t].height});
+        const uint64_t need = proof_section_ends(dk.pk, sh)[4];
+        *proof_len = root ? need : 0;
+        // (a refusal must be unanimous or the other ranks would wait for this one: only rank 0's buffer matters,
+        // and a rank-0 buffer that is too small fails here on every rank's own copy of the same test)
+        if (root && (need > proof_cap || !proof_out))
+            throw OvmFail((int)hipErrorInvalidValue, "proof buffer too small: " + std::to_string(need) + " bytes needed");
+        Prover pr(dk, (hipStream_t)stream);
+        pr.sh = ShardComm(shard);
+        sponge_in(pr, sponge);
+        pr.prove(traces_from_abi(dk.pk, n_traces, traces, true, owner, shard->rank));
+        if (root) {
+            if (pr.out.buf.size() != need) throw OvmFail((int)hipErrorUnknown, "internal: proof length differs from ovm_hip_proof_size");
+            if (section_offsets5)
+                for (size_t i = 0; i < 5 && i < pr.section_offsets.size(); i++) section_offsets5[i] = pr.section_offsets[i];
+            sponge_out(pr, sponge);
+            memcpy(proof_out, pr.out.buf.data(), pr.out.buf.size());
+        }
+        return 0;
+    });
+}
+
 int ovm_hip_commit(const ovm_pk_t *pk_, uint32_t n_traces, const ovm_trace_t *traces, uint32_t commitment_out[8],
                    ovm_pcs_t **pcs_out, ovm_stream_t stream) {
     if (!pk_ || !pcs_out || !commitment_out || n_traces == 0 || !traces) return (int)hipErrorInvalidValue;
@@ -2636,7 +3038,8 @@ int ovm_hip_prove_openings(const ovm_pk_t *pk_, uint32_t n_traces, const ovm_tra
         std::vector<EF> rv(r_len);
         for (uint32_t i = 0; i < r_len; i++)
             for (int k = 0; k < 4; k++) rv[i].c[k] = checked_word(r[4 * i + k], "r");
-        pr.prove_openings(*reinterpret_cast<const PcsData *>(common_main), rv);
+        const PcsData *cm = reinterpret_cast<const PcsData *>(common_main);
+        pr.prove_openings(cm, cm->root, rv);
         pr.cx.sync();
         if (stacking_len) *stacking_len = pr.section_offsets.empty() ? 0 : pr.section_offsets[0];
         *total_len = pr.out.buf.size();

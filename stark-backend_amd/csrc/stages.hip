@@ -1559,6 +1559,170 @@ int eq_heap(const EF *d_point, uint32_t n, EFPlanes heap, hipStream_t s) {
     return 0;
 }
 
+// ---- windowed eq heap (sharded GKR) ----------------------------------------------------------
+// A rank that owns the index window [lo, hi) of a layer's table needs, at depth d of the heap, only
+// the entries of its window at that depth (and the parents they are expanded from). Depths up to
+// `top` are full tables at heap index 2^d + y as above; deeper depths are stored as windows:
+// entry y of depth d lives at heap index off[d] + (y - lo[d]).
+EqHeapPlan eq_heap_plan(uint32_t n, const std::vector<std::pair<uint64_t, uint64_t>> &need) {
+    EqHeapPlan pl;
+    pl.n = n;
+    pl.off.assign(n, 0);
+    pl.lo.assign(n, 0);
+    pl.cnt.assign(n, 0);
+    pl.top = n == 0 ? 0 : (n - 1 < EQ_HEAP_DIRECT_DEPTH ? n - 1 : EQ_HEAP_DIRECT_DEPTH);
+    if (n == 0) return pl;
+    // E[d]: entries depth d must hold = its own window and the parents of everything deeper
+    std::vector<std::pair<uint64_t, uint64_t>> E(n, {0, 0});
+    bool any = false;
+    for (uint32_t d = n; d-- > 0;) {
+        uint64_t lo = need[d].first, hi = need[d].second;
+        bool has = lo < hi;
+        if (d + 1 < n && E[d + 1].first < E[d + 1].second) {
+            const uint64_t plo = E[d + 1].first >> 1, phi = ((E[d + 1].second - 1) >> 1) + 1;
+            lo = has ? std::min(lo, plo) : plo;
+            hi = has ? std::max(hi, phi) : phi;
+            has = true;
+        }
+        E[d] = has ? std::make_pair(lo, hi) : std::make_pair<uint64_t, uint64_t>(0, 0);
+        any |= has;
+    }
+    for (uint32_t d = 0; d <= pl.top; d++) {
+        pl.off[d] = uint64_t(1) << d;
+        pl.lo[d] = 0;
+        pl.cnt[d] = uint64_t(1) << d;
+    }
+    pl.total = uint64_t(2) << pl.top;
+    pl.empty = !any;
+    if (!any) return pl;
+    for (uint32_t k = pl.top; k + 1 < n;) {
+        const uint32_t levels = n - 1 - k < 3 ? n - 1 - k : 3;
+        // source lanes: the parents (levels up) of what the deepest level of this launch must hold
+        uint64_t lo = E[k + levels].first >> levels, hi = ((E[k + levels].second - 1) >> levels) + 1;
+        for (uint32_t l = 1; l < levels; l++) {  // (the intermediate depths' own windows are inside by construction)
+            lo = std::min(lo, E[k + l].first >> l);
+            hi = std::max(hi, ((E[k + l].second - 1) >> l) + 1);
+        }
+        lo &= ~uint64_t(7);
+        hi = std::min<uint64_t>((hi + 7) & ~uint64_t(7), uint64_t(1) << k);
+        EqHeapPlan::Launch ln{k, levels, lo, hi - lo};
+        for (uint32_t l = 1; l <= levels; l++) {
+            pl.off[k + l] = pl.total;
+            pl.lo[k + l] = lo << l;
+            pl.cnt[k + l] = (hi - lo) << l;
+            pl.total += (pl.cnt[k + l] + 7) & ~uint64_t(7);
+        }
+        pl.launches.push_back(ln);
+        k += levels;
+    }
+    return pl;
+}
+// lane t expands entry src_lo + t of depth k into its descendants of depths k+1 .. k+levels
+__global__ void eq_heap_levels_win_kernel(const EF *point, uint32_t n, uint32_t k, uint32_t levels, EFPlanes heap,
+                                          uint64_t src_off, uint64_t src_lo, uint64_t src_first, uint64_t count,
+                                          uint64_t off1, uint64_t off2, uint64_t off3, uint64_t dst_lo) {
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= count) return;
+    const uint64_t i = src_first + t;  // entry index at depth k
+    EF cur[8];
+    cur[0] = ldp(heap.p, heap.stride, src_off + (i - src_lo));
+    const uint64_t offs[3] = {off1, off2, off3};
+#pragma unroll
+    for (int l = 0; l < 3; l++) {
+        if ((uint32_t)l >= levels) break;
+        const EF::Pre x = ld_ef(point + (n - 1 - (k + l))).pre();
+        const int cnt = 1 << l;
+#pragma unroll
+        for (int u = cnt - 1; u >= 0; u--) {
+            const EF lo = cur[u], hi = lo * x;
+            cur[2 * u] = lo - hi;
+            cur[2 * u + 1] = hi;
+        }
+        const uint64_t base = offs[l] + ((i << (l + 1)) - (dst_lo << (l + 1)));
+#pragma unroll
+        for (int u = 0; u < cnt; u++) stp2(heap.p, heap.stride, base + 2 * u, cur[2 * u], cur[2 * u + 1]);
+    }
+}
+int eq_heap_run(const EF *d_point, const EqHeapPlan &pl, EFPlanes heap, hipStream_t s) {
+    if (pl.n == 0) return (int)hipErrorInvalidValue;
+    if (pl.empty) return 0;
+    hipLaunchKernelGGL(eq_heap_top_kernel, dim3(ceil_div(2ull << pl.top, 256)), dim3(256), 0, s, d_point, pl.n, pl.top, heap);
+    OVM_CHECK_LAUNCH();
+    for (auto &ln : pl.launches) {
+        const uint32_t k = ln.k;
+        hipLaunchKernelGGL(eq_heap_levels_win_kernel, dim3(ceil_div(ln.count, 256)), dim3(256), 0, s, d_point, pl.n, k, ln.levels,
+                           heap, pl.off[k], pl.lo[k], ln.src_first, ln.count, pl.off[k + 1], ln.levels > 1 ? pl.off[k + 2] : 0,
+                           ln.levels > 2 ? pl.off[k + 3] : 0, ln.src_first);
+        OVM_CHECK_LAUNCH();
+    }
+    return 0;
+}
+
+// out[2i], out[2i+1] = (p, q) of the fractions at plane positions pos[i] (n <= 32); pbase[i] != 0: only
+// limb plane 0 of that numerator exists. No flag unless ro.flag.
+__global__ void gkr_read_list_kernel(FracPlanes t, const uint64_t *pos, const uint32_t *pbase, uint32_t n, RedOut ro) {
+    const uint32_t i = threadIdx.x;
+    if (i < n) {
+        const uint64_t at = pos[i];
+        EF p = pbase[i] ? EF::from_base(Fp::raw(t.P()[at])) : ldp(t.P(), t.stride, at);
+        st_ef(ro.out + 2 * i, p);
+        st_ef(ro.out + 2 * i + 1, ldp(t.Q(), t.stride, at));
+        __threadfence_system();
+    }
+    __syncthreads();
+    if (i == 0) publish(ro);
+}
+int gkr_read_list(FracPlanes t, const uint64_t *d_pos, const uint32_t *d_pbase, uint32_t n, const RedOut &ro, hipStream_t s) {
+    if (n > 64) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(gkr_read_list_kernel, dim3(1), dim3(64), 0, s, t, d_pos, d_pbase, n, ro);
+    OVM_CHECK_LAUNCH();
+    return 0;
+}
+
+// Up to two table records for the host: out[4k..4k+4) = (p0, q0, p1, q1). fold == 0: record k is the two
+// fractions at src[k] (planes offset by at[k]); fold != 0: it is the fold by r of the two records = four
+// fractions there (the gkr_fold_final of round 1, at any index).
+__global__ void gkr_edge_kernel(FracPlanes src, uint64_t at0, uint64_t at1, uint32_t n, int p_base, int fold, EF r, RedOut ro) {
+    const uint32_t k = threadIdx.x;
+    if (k < n) {
+        const uint64_t at = k == 0 ? at0 : at1;
+        EF *out = ro.out + 4 * k;
+        if (fold) {
+            EF p[4], q[4];
+            if (p_base)
+                ldp4_base(src.P(), at, p);
+            else
+                ldp4(src.P(), src.stride, at, p);
+            ldp4(src.Q(), src.stride, at, q);
+            st_ef(out + 0, p[0] + (p[2] - p[0]) * r);
+            st_ef(out + 1, q[0] + (q[2] - q[0]) * r);
+            st_ef(out + 2, p[1] + (p[3] - p[1]) * r);
+            st_ef(out + 3, q[1] + (q[3] - q[1]) * r);
+        } else {
+            EF p0, p1, q0, q1;
+            if (p_base)
+                ldp2_base(src.P(), at, p0, p1);
+            else
+                ldp2(src.P(), src.stride, at, p0, p1);
+            ldp2(src.Q(), src.stride, at, q0, q1);
+            st_ef(out + 0, p0);
+            st_ef(out + 1, q0);
+            st_ef(out + 2, p1);
+            st_ef(out + 3, q1);
+        }
+        __threadfence_system();
+    }
+    __syncthreads();
+    if (k == 0) publish(ro);
+}
+int gkr_edge_records(FracPlanes src, uint64_t at0, uint64_t at1, uint32_t n, bool p_base, bool fold, EF r, const RedOut &ro,
+                     hipStream_t s) {
+    if (n == 0 || n > 2) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(gkr_edge_kernel, dim3(1), dim3(64), 0, s, src, at0, at1, n, p_base ? 1 : 0, fold ? 1 : 0, r, ro);
+    OVM_CHECK_LAUNCH();
+    return 0;
+}
+
 template <bool PBASE, int NP>
 __global__ __launch_bounds__(RED_THREADS) void gkr_round_kernel(FracPlanes rec, EFPlanes eq, uint64_t n_pairs,
                                                                 EF lambda_in, RedOut ro) {
@@ -2025,6 +2189,22 @@ __global__ void gather_ef_kernel(const EF *src, const uint64_t *idx, uint64_t n,
 int gather_ef(const EF *src, const uint64_t *d_idx, uint64_t n, EF *out, hipStream_t s) {
     if (n == 0) return 0;
     hipLaunchKernelGGL(gather_ef_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, s, src, d_idx, n, out);
+    OVM_CHECK_LAUNCH();
+    return 0;
+}
+
+// out[i] = sum over the n_blocks vectors in[b * n + i] (the per-rank mu-batched WHIR vectors of a sharded proof,
+// all-gathered; `out` may be one of the blocks' source buffers but not inside `in`)
+__global__ void ef_sum_blocks_kernel(const EF *in, uint32_t n_blocks, uint64_t n, EF *out) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    EF acc = ld_ef(in + i);
+    for (uint32_t b = 1; b < n_blocks; b++) acc = acc + ld_ef(in + (uint64_t)b * n + i);
+    st_ef(out + i, acc);
+}
+int ef_sum_blocks(const EF *in, uint32_t n_blocks, uint64_t n, EF *out, hipStream_t s) {
+    if (n_blocks == 0) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(ef_sum_blocks_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, s, in, n_blocks, n, out);
     OVM_CHECK_LAUNCH();
     return 0;
 }

@@ -242,6 +242,26 @@ def benchmark_air(num_columns, total_constraints, total_interaction_pairs):
     return a.finish()
 
 
+def benchmark_air_partitioned(num_columns, total_constraints, total_interaction_pairs):
+    """BenchmarkAir with its columns declared as ONE cached-main partition plus a 1-column common main
+    (the per-AIR-commitment form of the multi-GPU layout; pattern of
+    test_utils/dummy_airs/preprocessed_cached_air/air.rs:22-30). Same constraints and interactions on
+    the cached columns; the common column carries one boolean constraint."""
+    a = Air("BenchmarkAirPartitioned", 1, cached_main_widths=[num_columns])
+    for i in range(total_constraints):
+        a.assert_bool(a.cached(0, i % num_columns))
+    a.assert_bool(a.local(0))
+    for i in range(total_interaction_pairs):
+        a.push_interaction(0, [a.cached(0, i % num_columns)], ONE())
+        a.push_interaction(0, [a.cached(0, i % num_columns)], NEG_ONE())
+    return a.finish()
+
+
+def uniform_runner_air_partitioned(cols, constraints_per_col=2.0, interactions_per_col=0.25):
+    rnd = lambda x: int(math.floor(x + 0.5))
+    return benchmark_air_partitioned(cols, rnd(constraints_per_col * cols), rnd(interactions_per_col * cols / 2.0))
+
+
 def uniform_runner_air(cols, constraints_per_col=2.0, interactions_per_col=0.25):
     """uniform_runner.rs:196-199"""
     rnd = lambda x: int(math.floor(x + 0.5))  # f64::round (half away from zero)

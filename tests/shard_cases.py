@@ -1,0 +1,55 @@
+"""Multi-AIR proving contexts for the sharded prover's tests: (params, airs, traces, owners) with
+traces = (air_idx, common main [canonical, column-major], height, public values, cached mains or None)
+and owners[i] = the rank that holds traces[i]. Test infrastructure."""
+import numpy as np
+
+import airs
+
+
+def _bench_partitioned(n_airs, cols, log_heights, params, seed=0):
+    air = airs.uniform_runner_air_partitioned(cols)
+    traces = []
+    for i in range(n_airs):
+        h = 1 << log_heights[i]
+        traces.append((i, airs.splitmix64_bits(seed + 1000 + i, h), h, [], airs.splitmix64_bits(seed + 2000 + i, cols * h)))
+    return params, [air] * n_airs, traces
+
+
+def _owners_blocks(traces, world):
+    """Owners assigned in blocks over the traces in the prover's sorted order (height desc, air index)."""
+    order = sorted(range(len(traces)), key=lambda i: (-traces[i][2], traces[i][0]))
+    owners = [0] * len(traces)
+    for pos, i in enumerate(order):
+        owners[i] = pos * world // len(traces)
+    return owners
+
+
+def make(name, world):
+    if name == "bench8":  # one partitioned BenchmarkAir per rank, equal heights (config D's multi-GPU form, small)
+        p, a, t = _bench_partitioned(world, 8, [5] * world, airs.test_params(l_skip=2, n_stack=6, k_whir=2))
+    elif name == "bench_mixed_heights":  # twice as many AIRs as ranks, heights incl. one below 2^l_skip
+        lh = [6, 5, 5, 4, 3, 3, 1, 0][:2 * world]
+        p, a, t = _bench_partitioned(len(lh), 6, lh, airs.test_params(l_skip=2, n_stack=7, k_whir=2), seed=7)
+    elif name == "bench_app":  # app-like parameters (l_skip 4, k_whir 4), 2^10 rows x 20 columns per AIR
+        p, a, t = _bench_partitioned(world, 20, [10] * world, airs.test_params(l_skip=4, n_stack=8, k_whir=4), seed=3)
+    elif name == "mixture":  # Fibonacci (common main only, public values) + partitioned sender/receiver + plain benchmark AIR
+        c_airs, c_traces = airs.cached_fixture_11()
+        ftr, fpv = airs.fibonacci_trace(0, 1, 16)
+        bench = airs.uniform_runner_air(5)
+        a = [airs.fibonacci_air()] + c_airs + [bench]
+        t = [(0, ftr, 16, fpv, None)] + [(x + 1, c, h, pv, k) for x, c, h, pv, k in c_traces] + \
+            [(3, airs.splitmix64_bits(9, 5 * 32), 32, [], None)]
+        p = airs.test_params()
+    elif name == "no_interactions_on_one_rank":  # the last rank's AIR has no interactions: its leaf run is empty
+        p = airs.test_params(l_skip=2, n_stack=6, k_whir=2)
+        air = airs.uniform_runner_air_partitioned(8)
+        ftr, fpv = airs.fibonacci_trace(0, 1, 4)
+        a = [air] * (world - 1) + [airs.fibonacci_air()]
+        t = [(i, airs.splitmix64_bits(40 + i, 32), 32, [], airs.splitmix64_bits(50 + i, 8 * 32)) for i in range(world - 1)]
+        t.append((world - 1, ftr, 4, fpv, None))
+    else:
+        raise KeyError(name)
+    return p, a, t, _owners_blocks(t, world)
+
+
+CASES = ["bench8", "bench_mixed_heights", "bench_app", "mixture", "no_interactions_on_one_rank"]

@@ -1,0 +1,63 @@
+"""One rank of a sharded proof (tests/test_gpu_shard.py starts `world` of these on ONE GPU: logical shards
+with their own streams and caches, gloo + host staging standing in for RCCL; bench.py runs the same code
+path with one GPU per rank and the nccl backend). Rank 0 writes the joint proof to --out."""
+import argparse
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--rank", type=int, required=True)
+    ap.add_argument("--world", type=int, required=True)
+    ap.add_argument("--port", type=int, required=True)
+    ap.add_argument("--case", required=True)
+    ap.add_argument("--shm", required=True)
+    ap.add_argument("--out", required=True)
+    ap.add_argument("--repeat", type=int, default=1)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from conftest import load_pkg
+    import airs
+    import shard_cases
+
+    pkg = load_pkg()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(args.port))
+    dist.init_process_group("gloo", rank=args.rank, world_size=args.world)
+    dev = pkg.Device(0)
+    params, air_list, traces, owners = shard_cases.make(args.case, args.world)
+    pk = pkg.ProvingKey(airs.pk_blob(params, air_list))
+    shard = pkg.Shard(args.rank, args.world, args.shm)
+    up = lambda a: dev.upload(pkg.to_mont(np.asarray(a, dtype=np.uint32)))
+    dtr = []
+    for (a, common, h, pvs, cached), o in zip(traces, owners):
+        if o != args.rank:
+            dtr.append((a, None, h, [], None))
+            continue
+        handles = []
+        if cached is not None:
+            off = 0
+            for w in air_list[a]["cached_main_widths"]:
+                handles.append(dev.commit_matrix(pk, up(cached[off:off + w * h]), w, h))
+                off += w * h
+        dtr.append((a, up(common), h, pvs, handles))
+    proof = b""
+    for _ in range(args.repeat):
+        proof, secs = dev.prove_sharded(pk, shard, dtr, owners)
+    if args.rank == 0:
+        with open(args.out, "wb") as f:
+            f.write(proof)
+    dist.barrier()
+    shard.close()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,85 @@
+"""CPU tests of the sharded prover's host side (no GPU):
+  * the LogUp-GKR driver with 1..8 simulated ranks against the unsharded run (csrc/selftest.cpp);
+  * the exchange protocol between two REAL processes: the library's shared-memory all-gather for the
+    per-round values, and the bulk all-gather callback supplied by the Python host over torch.distributed
+    with the gloo backend (world size 2, 127.0.0.1) followed by the modular add of the gathered blocks."""
+import os
+import socket
+import uuid
+
+import numpy as np
+import pytest
+import torch.multiprocessing as mp
+
+
+def test_gkr_driver_one_rank_with_and_without_padding(pkg):
+    pkg.gkr_shard_selftest(1, 6, [64])
+    pkg.gkr_shard_selftest(1, 6, [52])       # config D's shape in small: 26 of 32 slices used
+    pkg.gkr_shard_selftest(1, 6, [52], three_points=True)
+    pkg.gkr_shard_selftest(1, 1, [2])
+    pkg.gkr_shard_selftest(1, 3, [1])
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_gkr_driver_config_d_layout(pkg, world):
+    """world AIRs of 26 interaction slices each (13 send/receive pairs), slices of 2^3 leaves."""
+    slices = 26 * world
+    TR = (slices * 8 - 1).bit_length()
+    pkg.gkr_shard_selftest(world, TR, [26 * 8 * (r + 1) for r in range(world)], seed=world)
+
+
+def test_gkr_driver_random_ranges(pkg):
+    """Arbitrary (also odd, also empty) leaf runs per rank, random padding, both point counts."""
+    rng = np.random.default_rng(11)
+    for it in range(60):
+        TR = int(rng.integers(2, 11))
+        world = int(rng.integers(1, 9))
+        used = int(rng.integers(1, (1 << TR) + 1))
+        ends = sorted(int(x) for x in rng.integers(0, used + 1, size=world - 1)) + [used]
+        pkg.gkr_shard_selftest(world, TR, ends, seed=it, three_points=it % 4 == 0)
+
+
+def test_gkr_driver_rejects_bad_input(pkg):
+    with pytest.raises(pkg.OvmError):
+        pkg.gkr_shard_selftest(2, 4, [9, 5])  # ends not monotone
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, shm, q):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import torch.distributed as dist
+    from conftest import load_pkg
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    pkg = load_pkg()
+    try:
+        shard = pkg.Shard(rank, world, shm, slot_bytes=1 << 16, host_buffers=True)
+        pkg.shard_exchange_selftest(shard, n=5000, rounds=200, seed=5)
+        q.put((rank, "ok", shard.bulk_bytes))
+        shard.close()
+    except Exception as e:  # noqa: BLE001
+        q.put((rank, repr(e), 0))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_exchange_protocol_world2_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port, shm = _free_port(), f"/ovm-test-{uuid.uuid4().hex[:12]}"
+    ps = [ctx.Process(target=_worker, args=(r, 2, port, shm, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in range(2))
+    for p in ps:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert [r[1] for r in res] == ["ok", "ok"], res
+    assert all(r[2] == 2 * 5000 * 16 for r in res)          # one bulk exchange of n EF elements per rank
+    assert not os.path.exists("/dev/shm" + shm)              # the segment's name is gone after the handshake
