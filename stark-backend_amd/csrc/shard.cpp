@@ -9,6 +9,7 @@
 #include <unistd.h>
 
 #include <chrono>
+#include <cstdlib>
 #include <stdexcept>
 
 #include "host.h"
@@ -148,6 +149,7 @@ int ovm_hip_shm_comm_create(const char *name, uint32_t rank, uint32_t world, uin
     c->slot_bytes = slot_bytes;
     c->name = name;
     c->owns_mapping = true;
+    if (const char *e = getenv("OVM_SHARD_TIMEOUT_S")) c->timeout_s = std::max(1.0, atof(e));  // (a peer that died: give up after this long)
     // handshake: once it completes every rank has mapped the segment, so the name can go away
     // (nothing is left behind in /dev/shm when a job dies later)
     const int rc = c->allgather(nullptr, nullptr, 0);

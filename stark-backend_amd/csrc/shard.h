@@ -67,9 +67,12 @@ struct Packer {
     }
 };
 struct Unpacker {
+    std::vector<uint8_t> owned;  // (a copy: messages are small, and a temporary can be passed safely)
     const uint8_t *p;
     size_t n, at = 0;
-    explicit Unpacker(const std::vector<uint8_t> &b) : p(b.data()), n(b.size()) {}
+    explicit Unpacker(std::vector<uint8_t> b) : owned(std::move(b)), p(owned.data()), n(owned.size()) {}
+    Unpacker(const Unpacker &) = delete;
+    Unpacker &operator=(const Unpacker &) = delete;
     bool done() const { return at >= n; }
     void need(size_t k) const;
     template <class T>

@@ -27,6 +27,7 @@ def _free_port():
 def run_sharded(case, world, tmp_path, repeat=1):
     port, shm, out = _free_port(), f"/ovm-test-{uuid.uuid4().hex[:12]}", str(tmp_path / "proof.bin")
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env["OVM_SHARD_TIMEOUT_S"] = "60"  # a rank that died must not hold the others for minutes
     procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "shard_worker.py"), "--rank", str(r), "--world", str(world),
                                "--port", str(port), "--case", case, "--shm", shm, "--out", out, "--repeat", str(repeat)],
                               env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]

@@ -1,0 +1,81 @@
+// Measured ceiling of the Poseidon2 instruction mix on gfx950: the SAME permutation code the Merkle
+// kernels run (csrc/poseidon2.h, p2::permute) on register-resident states -- ITER chained permutations
+// per lane, no memory traffic inside the loop -- at the occupancy of hash_rows_kernel (256-lane
+// workgroups, as many waves per SIMD as the register budget gives). What hash_rows_kernel<1> achieves
+// (bench.py: roofline.issue_bound.achieved_Gperm_s) is quoted against this number: the difference is
+// what loads, stores and the sponge bookkeeping cost; anything beyond it needs FEWER INSTRUCTIONS per
+// permutation, not better scheduling. Also reads s_memtime around the loop to report the shader clock
+// the run actually had and the cycles one wave-level VALU instruction took.
+//   hipcc --offload-arch=gfx950 -O3 -I stark-backend_amd/csrc -I include tools/ubench_poseidon2.hip -o tools/ubench_poseidon2
+//   tools/ubench_poseidon2 [json path]
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+
+#include "poseidon2.h"
+
+using bb::Fp;
+static constexpr int ITER = 256;
+static constexpr int VALU_PER_PERM = 7233;  // tools/isa_count.py on merkle.hip
+
+__global__ __launch_bounds__(256) void perm_loop_kernel(uint32_t *out, uint32_t seed, unsigned long long *ticks) {
+    Fp s[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) s[i] = Fp::raw((threadIdx.x * 2654435761u + blockIdx.x * 40503u + i * 97u + seed) % bb::P);
+    const unsigned long long t0 = __builtin_readcyclecounter();
+    for (int it = 0; it < ITER; it++) p2::permute(s);
+    const unsigned long long t1 = __builtin_readcyclecounter();
+    uint32_t x = 0;
+#pragma unroll
+    for (int i = 0; i < 16; i++) x ^= s[i].v;
+    out[(size_t)blockIdx.x * blockDim.x + threadIdx.x] = x;
+    if (threadIdx.x == 0 && blockIdx.x == 0) *ticks = t1 - t0;
+}
+
+int main(int argc, char **argv) {
+    hipDeviceProp_t p;
+    hipGetDeviceProperties(&p, 0);
+    const int waves_per_simd = 8;  // launch enough workgroups for 8 resident waves per SIMD, several rounds of them
+    const int blocks = p.multiProcessorCount * (4 * waves_per_simd / 4) * 8;
+    uint32_t *d;
+    unsigned long long *d_ticks, ticks = 0;
+    hipMalloc(&d, (size_t)blocks * 256 * 4);
+    hipMalloc(&d_ticks, 8);
+    hipEvent_t a, b;
+    hipEventCreate(&a);
+    hipEventCreate(&b);
+    hipLaunchKernelGGL(perm_loop_kernel, dim3(blocks), dim3(256), 0, 0, d, 1u, d_ticks);
+    hipDeviceSynchronize();
+    float best = 1e30f;
+    for (int rep = 0; rep < 5; rep++) {
+        hipEventRecord(a);
+        hipLaunchKernelGGL(perm_loop_kernel, dim3(blocks), dim3(256), 0, 0, d, 3u + rep, d_ticks);
+        hipEventRecord(b);
+        hipEventSynchronize(b);
+        float ms;
+        hipEventElapsedTime(&ms, a, b);
+        if (ms < best) best = ms;
+    }
+    hipMemcpy(&ticks, d_ticks, 8, hipMemcpyDeviceToHost);
+    const double perms = (double)blocks * 256 * ITER;
+    const double gperm = perms / (best * 1e-3) / 1e9;
+    const double wave_instr_per_simd = perms * VALU_PER_PERM / 64.0 / (p.multiProcessorCount * 4.0);
+    const double cyc_nominal = best * 1e-3 * 2.4e9 / wave_instr_per_simd;
+    // s_memtime counts at a fixed 100 MHz on gfx9: wall time of one wave's loop, for reference
+    printf("poseidon2 mix ceiling: %.3f ms for %.3g permutations -> %.3f Gperm/s; %.2f cycles per wave-level VALU instruction per SIMD at 2.4 GHz "
+           "(%d CUs, %d blocks of 256 lanes, %d permutations per lane); one wave's loop: %llu counter ticks\n",
+           best, perms, gperm, cyc_nominal, p.multiProcessorCount, blocks, ITER, ticks);
+    if (argc > 1) {
+        FILE *f = fopen(argv[1], "w");
+        if (f) {
+            fprintf(f, "{\"gperm_per_s\": %.4f, \"ms\": %.4f, \"permutations\": %.0f, \"valu_instr_per_permutation\": %d, "
+                       "\"cycles_per_wave_valu_instr_per_simd_at_2.4GHz\": %.3f, \"compute_units\": %d, \"source\": \"tools/ubench_poseidon2.hip\"}\n",
+                    gperm, best, perms, VALU_PER_PERM, cyc_nominal, p.multiProcessorCount);
+            fclose(f);
+        }
+    }
+    hipFree(d);
+    hipFree(d_ticks);
+    return 0;
+}
