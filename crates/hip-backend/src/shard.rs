@@ -1,0 +1,124 @@
+//! Sharded proving: ONE joint proof over the GPUs of a node, one AIR (trace) per GPU, one process
+//! per GPU (DESIGN.md §6 of the HIP backend). Each rank owns the traces it generated
+//! and the cached-main commitments of those traces; the per-round sumcheck values travel through the
+//! library's shared-memory exchange, and the one bulk exchange -- the mu-batched WHIR vector -- goes
+//! through the `allgather_device` callback, which a deployment implements with RCCL
+//! (`ncclAllGather` on the rank's stream). The reference has no peer for this file.
+use std::{
+    ffi::{c_void, CString},
+    os::raw::c_int,
+    ptr,
+};
+
+use openvm_stark_backend::prover::{DeviceMultiStarkProvingKey, ProvingContext};
+
+use crate::{
+    device::abi_traces,
+    error::HipError,
+    ffi,
+    transcript::DuplexSpongeHip,
+    HipBackend, HipDevice,
+};
+
+/// The device all-gather a deployment supplies (RCCL over xGMI): `d_all[r * bytes ..] = rank r's d_mine`,
+/// ordered after the work already enqueued on `stream` and complete for later work on it on return.
+pub trait BulkExchange: Send {
+    fn allgather_device(&mut self, d_mine: *const c_void, d_all: *mut c_void, bytes: u64, stream: ffi::OvmStream) -> i32;
+}
+
+/// One rank's communicator: the shared-memory segment for the small exchanges + the bulk callback.
+pub struct ShardComm {
+    shm: *mut ffi::OvmShmComm,
+    bulk: Box<dyn BulkExchange>,
+    pub rank: u32,
+    pub world: u32,
+}
+
+unsafe extern "C" fn host_trampoline(ctx: *mut c_void, mine: *const c_void, all: *mut c_void, bytes: u64) -> c_int {
+    let comm = &*(ctx as *const ShardComm);
+    ffi::ovm_hip_shm_allgather(comm.shm as *mut c_void, mine, all, bytes)
+}
+unsafe extern "C" fn device_trampoline(
+    ctx: *mut c_void,
+    d_mine: *const c_void,
+    d_all: *mut c_void,
+    bytes: u64,
+    stream: ffi::OvmStream,
+) -> c_int {
+    let comm = &mut *(ctx as *mut ShardComm);
+    comm.bulk.allgather_device(d_mine, d_all, bytes, stream)
+}
+
+impl ShardComm {
+    /// `name`: the same unique shared-memory name on every rank of the job (e.g. "/ovm-<port>-<pid>").
+    pub fn new(name: &str, rank: u32, world: u32, bulk: Box<dyn BulkExchange>) -> Result<Box<Self>, HipError> {
+        let cname = CString::new(name).expect("shared-memory name with a NUL byte");
+        let mut shm: *mut ffi::OvmShmComm = ptr::null_mut();
+        // SAFETY: valid out-pointer; returns when every rank has attached.
+        HipError::from_result("ovm_hip_shm_comm_create", unsafe {
+            ffi::ovm_hip_shm_comm_create(cname.as_ptr(), rank, world, 1 << 20, &mut shm)
+        })?;
+        Ok(Box::new(Self { shm, bulk, rank, world }))
+    }
+    fn abi(self: &mut Box<Self>) -> ffi::OvmShard {
+        ffi::OvmShard {
+            rank: self.rank,
+            world: self.world,
+            ctx: (&mut **self) as *mut ShardComm as *mut c_void,
+            allgather_host: Some(host_trampoline),
+            allgather_device: Some(device_trampoline),
+        }
+    }
+}
+impl Drop for ShardComm {
+    fn drop(&mut self) {
+        // SAFETY: created by ovm_hip_shm_comm_create, destroyed once.
+        unsafe { ffi::ovm_hip_shm_comm_destroy(self.shm) };
+    }
+}
+
+impl HipDevice {
+    /// `Coordinator::prove` as one joint proof over `comm.world` ranks. `ctx` holds this rank's traces
+    /// (device data) -- and, for the traces of other ranks, entries with the right AIR index and height
+    /// whose matrices are empty; `owners[i]` = rank of `ctx.per_trace[i]`, non-decreasing in sorted
+    /// order. Returns the encoded proof on rank 0 (`Proof::decode_from_bytes` reads it), `None` elsewhere.
+    pub fn prove_sharded(
+        &self,
+        comm: &mut Box<ShardComm>,
+        transcript: &mut DuplexSpongeHip,
+        mpk: &DeviceMultiStarkProvingKey<HipBackend>,
+        ctx: &ProvingContext<HipBackend>,
+        owners: &[u32],
+    ) -> Result<Option<Vec<u8>>, HipError> {
+        assert_eq!(owners.len(), ctx.per_trace.len());
+        let abi = abi_traces(ctx);
+        let key = mpk.per_air.first().expect("proving key without AIRs").other_data.key.0;
+        let mut ends = [0u64; 5];
+        HipError::from_result("ovm_hip_proof_size", unsafe {
+            ffi::ovm_hip_proof_size(key, abi.traces.len() as u32, abi.traces.as_ptr(), ends.as_mut_ptr())
+        })?;
+        let mut out = vec![0u8; if comm.rank == 0 { ends[4] as usize } else { 0 }];
+        let mut len = 0u64;
+        let shard = comm.abi();
+        // SAFETY: all pointers are valid for the call; `comm` outlives it.
+        HipError::from_result("ovm_hip_prove_sharded", unsafe {
+            ffi::ovm_hip_prove_sharded(
+                key,
+                &shard,
+                abi.traces.len() as u32,
+                abi.traces.as_ptr(),
+                owners.as_ptr(),
+                transcript.state_mut(),
+                out.as_mut_ptr(),
+                out.len() as u64,
+                &mut len,
+                ptr::null_mut(),
+                self.stream(),
+            )
+        })?;
+        Ok((comm.rank == 0).then(|| {
+            out.truncate(len as usize);
+            out
+        }))
+    }
+}

@@ -51,8 +51,12 @@ def oracle_proof(orc, case, world):
     return blob, want
 
 
-@pytest.mark.parametrize("world", [2, 4])
-@pytest.mark.parametrize("case", shard_cases.CASES)
+# (every context with 2 shards; with 4 shards the three that differ in structure: one AIR per rank, mixed
+# heights with two AIRs per rank, and the mixture of plain / cached / public-value AIRs)
+RUNS = [(c, 2) for c in shard_cases.CASES] + [(c, 4) for c in ("bench8", "bench_mixed_heights", "mixture")]
+
+
+@pytest.mark.parametrize("case,world", RUNS)
 def test_logical_shards_match_oracle(orc, tmp_path, case, world):
     blob, want = oracle_proof(orc, case, world)
     got = run_sharded(case, world, tmp_path)
