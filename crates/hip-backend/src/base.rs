@@ -137,4 +137,5 @@ impl Drop for PkHandle {
 #[derive(Clone)]
 pub struct AirDataHip {
     pub(crate) key: Arc<PkHandle>,
+    pub(crate) air_idx: u32,
 }

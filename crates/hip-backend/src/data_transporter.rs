@@ -54,7 +54,7 @@ impl DeviceDataTransporter<SC, HipBackend> for HipDevice {
                     air_name: pk.air_name.clone(),
                     vk: pk.vk.clone(),
                     preprocessed_data,
-                    other_data: AirDataHip { key: key.clone() },
+                    other_data: AirDataHip { key: key.clone(), air_idx: air_idx as u32 },
                 }
             })
             .collect();

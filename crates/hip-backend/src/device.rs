@@ -34,12 +34,12 @@ impl ProverBackend for HipBackend {
     type PcsData = StackedPcsDataHip;
     type OtherAirData = AirDataHip;
 
-    /// hal.rs:57-62. The staged constraint VM keeps its intermediates in LDS (at most 36 KiB per
-    /// workgroup) and the plain interpreter at most 512 slots per lane in private
-    /// memory: no per-row HBM buffer exists, so round 0 needs no temporary memory that scales with the
-    /// trace and metering can use the default.
-    fn constraint_eval_buffer_size(_pk: &DeviceStarkProvingKey<Self>) -> usize {
-        0
+    /// hal.rs:57-62: bytes of round-0 scratch per trace row of this AIR -- the coset LDE of its view
+    /// columns (the constraint VM itself keeps its intermediates in LDS). With
+    /// `zerocheck_save_memory` the library multiplies it by the slab, not by the trace height.
+    fn constraint_eval_buffer_size(pk: &DeviceStarkProvingKey<Self>) -> usize {
+        // SAFETY: the key handle is valid for the life of the proving key; host-only query.
+        unsafe { ffi::ovm_hip_constraint_eval_buffer_size(pk.other_data.key.0, pk.other_data.air_idx) as usize }
     }
 }
 

@@ -65,6 +65,17 @@ pub struct OvmMatrix {
     pub height: u64,
 }
 
+/// `ovm_prover_config_t` (reference: GpuProverConfig, cuda-backend/src/device.rs:25-30)
+#[repr(C)]
+#[derive(Clone, Copy, Debug)]
+pub struct OvmProverConfig {
+    pub cache_rs_code_matrix: u32,
+    pub zerocheck_save_memory: u32,
+    pub round0_slab_log_rows: u32,
+    pub _pad: u32,
+    pub cache_limit_bytes: u64,
+}
+
 /// `ovm_shard_t`: the communicator of a sharded proof
 #[repr(C)]
 #[derive(Clone, Copy)]
@@ -203,6 +214,14 @@ extern "C" {
         blocks_out: *mut u64,
     ) -> c_int;
     pub fn ovm_hip_host_permute_selftest(n: u32, seed: u64) -> c_int;
+    pub fn ovm_hip_set_prover_config(cfg: *const OvmProverConfig) -> c_int;
+    pub fn ovm_hip_memory_stats(
+        live_bytes: *mut u64,
+        peak_live_bytes: *mut u64,
+        cached_bytes: *mut u64,
+        reset_peak: c_int,
+    ) -> c_int;
+    pub fn ovm_hip_constraint_eval_buffer_size(pk: *const OvmPk, air_idx: u32) -> u64;
     pub fn ovm_hip_trim() -> c_int;
     pub fn ovm_hip_last_error() -> *const c_char;
     pub fn ovm_hip_commit(

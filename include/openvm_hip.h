@@ -194,6 +194,34 @@ int ovm_hip_staged_selftest(const uint32_t *blob, uint64_t words, uint32_t stage
  * (AVX2 where the CPU has it, csrc/host_poseidon2.cpp) against the scalar one on n pseudo-random
  * states. 1 = equal on all of them. */
 int ovm_hip_host_permute_selftest(uint32_t n, uint64_t seed);
+/* Memory-bounded modes of the calling thread's provers (reference: GpuProverConfig{cache_stacked_matrix,
+ * cache_rs_code_matrix, zerocheck_save_memory}, crates/cuda-backend/src/device.rs:25-30). Defaults: everything
+ * resident (all fields zero except cache_rs_code_matrix = 1).
+ *   cache_rs_code_matrix = 0   a commitment made from now on drops its codeword once the Merkle tree is built
+ *                              and re-encodes it when WHIR opens rows of it (reference: whir.rs:404-416): -3.4 GB
+ *                              per 2^22 x 100 commitment at blowup 2, one extra NTT at opening time.
+ *   zerocheck_save_memory = 1  round 0 extends and evaluates a tall trace in slabs of 2^round0_slab_log_rows rows
+ *                              (0 = default 20): the coset-LDE buffer shrinks from
+ *                              ovm_hip_constraint_eval_buffer_size(pk, air) x height to that x the slab.
+ *   cache_limit_bytes          upper bound on the device memory the thread's caching allocator keeps in free
+ *                              blocks (0 = unbounded); blocks beyond it go back to the driver.
+ * Proofs are identical in every mode. The stacked matrix is never copied when one trace fills it
+ * (cache_stacked_matrix has no counterpart here). */
+typedef struct ovm_prover_config {
+    uint32_t cache_rs_code_matrix;
+    uint32_t zerocheck_save_memory;
+    uint32_t round0_slab_log_rows;
+    uint32_t _pad;
+    uint64_t cache_limit_bytes;
+} ovm_prover_config_t;
+int ovm_hip_set_prover_config(const ovm_prover_config_t *cfg);
+/* Device memory handed out by the library's allocator, process-wide: now, at its peak (reset_peak != 0 restarts
+ * the peak from the current value), and the calling thread's cached free blocks. Any pointer may be null. */
+int ovm_hip_memory_stats(uint64_t *live_bytes, uint64_t *peak_live_bytes, uint64_t *cached_bytes, int reset_peak);
+/* ProverBackend::constraint_eval_buffer_size (hal.rs:57-62): bytes of round-0 scratch per trace ROW of this AIR
+ * (the coset LDE of every view column on max(degree - 1, degree if it has interactions) cosets); what memory
+ * metering multiplies by the trace height -- or by the slab with zerocheck_save_memory. 0 for a bad index. */
+uint64_t ovm_hip_constraint_eval_buffer_size(const ovm_pk_t *pk, uint32_t air_idx);
 /* Returns the calling thread's cached device blocks to the driver (the prover recycles its
  * buffers between proofs; reference: VPMM pool, crates/cuda-common/src/memory_manager/). */
 int ovm_hip_trim(void);

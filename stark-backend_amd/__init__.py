@@ -56,6 +56,13 @@ class MatrixStruct(Structure):
     _fields_ = [("d_ptr", c_void_p), ("width", c_uint64), ("height", c_uint64)]
 
 
+class ProverConfigStruct(Structure):
+    """``ovm_prover_config_t`` (reference: GpuProverConfig, crates/cuda-backend/src/device.rs:25-30)."""
+
+    _fields_ = [("cache_rs_code_matrix", c_uint32), ("zerocheck_save_memory", c_uint32), ("round0_slab_log_rows", c_uint32),
+                ("_pad", c_uint32), ("cache_limit_bytes", c_uint64)]
+
+
 class SpongeState(Structure):
     """``ovm_sponge_t`` (reference: crates/cuda-backend/src/sponge.rs:39-48)."""
 
@@ -105,6 +112,9 @@ SIGNATURES = {
     "ovm_hip_host_permute_selftest": (c_int, [c_uint32, c_uint64]),
     "ovm_hip_last_error": (c_char_p, []),
     "ovm_hip_trim": (c_int, []),
+    "ovm_hip_set_prover_config": (c_int, [POINTER(ProverConfigStruct)]),
+    "ovm_hip_memory_stats": (c_int, [_u64p, _u64p, _u64p, c_int]),
+    "ovm_hip_constraint_eval_buffer_size": (c_uint64, [c_void_p, c_uint32]),
     "ovm_hip_commit": (c_int, [c_void_p, c_uint32, c_void_p, c_void_p, POINTER(c_void_p), c_void_p]),
     "ovm_hip_commit_matrix": (c_int, [c_void_p, c_void_p, c_uint64, c_uint64, c_void_p, POINTER(c_void_p), c_void_p]),
     "ovm_hip_commit_matrices": (c_int, [POINTER(PcsParams), c_uint32, c_void_p, c_void_p, POINTER(c_void_p), c_void_p]),
@@ -583,6 +593,24 @@ def staged_selftest(blob, stage_rows: int, acc_rows: int, seed: int = 1) -> int:
     if rc != 0:
         _fail(rc, "ovm_hip_staged_selftest")
     return int(blocks.value)
+
+
+def set_prover_config(cache_rs_code_matrix: bool = True, zerocheck_save_memory: bool = False,
+                      round0_slab_log_rows: int = 0, cache_limit_bytes: int = 0) -> None:
+    """Memory-bounded modes of the calling thread's provers (include/openvm_hip.h: ovm_prover_config_t)."""
+    cfg = ProverConfigStruct(int(cache_rs_code_matrix), int(zerocheck_save_memory), round0_slab_log_rows, 0, cache_limit_bytes)
+    check(_lib().ovm_hip_set_prover_config(ctypes.byref(cfg)), "ovm_hip_set_prover_config")
+
+
+def memory_stats(reset_peak: bool = False) -> dict:
+    """Device bytes handed out by the library's allocator (live / peak, process-wide) and cached by this thread."""
+    live, peak, cached = c_uint64(0), c_uint64(0), c_uint64(0)
+    _lib().ovm_hip_memory_stats(ctypes.byref(live), ctypes.byref(peak), ctypes.byref(cached), 1 if reset_peak else 0)
+    return {"live": live.value, "peak": peak.value, "cached": cached.value}
+
+
+def constraint_eval_buffer_size(pk: ProvingKey, air_idx: int) -> int:
+    return int(_lib().ovm_hip_constraint_eval_buffer_size(pk.handle, air_idx))
 
 
 def profile_enable(on: bool) -> None:

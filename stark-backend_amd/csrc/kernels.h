@@ -45,9 +45,11 @@ int mobius_eq_table(const EF *d_point, uint32_t n, EF *out, hipStream_t s);
 // Coset low-degree extension of the used columns of one trace view.
 //   lde[(k * n_cols_total + col) << log_lifted | p] for k < n_cosets, col in used_cols
 //   d_shift_pows[k * 2^l_skip + i] = shift_k^i / 2^l_skip
+// row0 != 0: the slab of rows [row0, row0 + 2^log_lifted) of the columns (a multiple of 2^l_skip) is extended
+// into an lde buffer laid out for 2^log_lifted rows -- round 0 in slabs (zerocheck_save_memory)
 int coset_lde(const ColDesc *d_cols, const uint32_t *d_used, uint32_t n_used, uint32_t n_cols_total,
               uint32_t log_lifted, uint32_t l_skip, uint32_t n_cosets, const Fp *d_shift_pows, Fp *lde,
-              hipStream_t s);
+              hipStream_t s, uint64_t row0 = 0);
 
 // Round 0: out[((k * n_out) + o) * N + z] = sum_x eq_xi[x] * program_o(lde_k row (x<<l)+z) (+ add_const for o==1)
 // Round 0 of many traces in ONE launch (staged programs of equal rows-per-lane and output count): the

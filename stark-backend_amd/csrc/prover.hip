@@ -43,6 +43,7 @@ struct BlockCache;
 struct BlockRegistry {
     std::mutex mu;
     std::unordered_map<void *, std::pair<size_t, const BlockCache *>> live;
+    size_t live_bytes = 0, peak_live_bytes = 0;  // blocks handed out (process-wide): ovm_hip_memory_stats
     static BlockRegistry &get() {
         static BlockRegistry *r = new BlockRegistry();  // (leaked on purpose: thread-exit destructors may run late)
         return *r;
@@ -75,6 +76,8 @@ struct BlockCache {
         BlockRegistry &reg = BlockRegistry::get();
         std::lock_guard<std::mutex> lk(reg.mu);
         reg.live[p] = {sz, this};
+        reg.live_bytes += sz;
+        reg.peak_live_bytes = std::max(reg.peak_live_bytes, reg.live_bytes);
         return p;
     }
     void put(void *p) {
@@ -88,6 +91,7 @@ struct BlockCache {
                 sz = it->second.first;
                 owner = it->second.second;
                 reg.live.erase(it);
+                reg.live_bytes -= sz;
             }
         }
         if (owner != this || (limit_bytes && cached_bytes + sz > limit_bytes)) {
@@ -105,6 +109,19 @@ struct BlockCache {
         cached_bytes = 0;
     }
 };
+// Memory-bounded modes (reference: GpuProverConfig, cuda-backend/src/device.rs:25-30), per
+// prover thread (one engine per thread). Defaults keep everything resident: 288 GB of HBM is the normal case.
+struct ProverConfig {
+    bool cache_rs_code_matrix = true;    // false: a commitment's codeword is dropped once its Merkle tree is built
+                                         // and re-encoded when WHIR opens rows of it (cuda-backend/src/whir.rs:404-416)
+    bool zerocheck_save_memory = false;  // true: round 0 extends and evaluates a tall trace in slabs of rows
+    unsigned round0_slab_log_rows = 20;  // slab size in that mode
+};
+inline ProverConfig &prover_config() {
+    static thread_local ProverConfig cfg;
+    return cfg;
+}
+
 inline BlockCache &block_cache() {
     static thread_local BlockCache caches[16];
     int dev = 0;
@@ -514,6 +531,7 @@ struct Prover {
         d.codeword.alloc(width << d.log_rows);
         OVM_THROW_IF(ovm_hip_ntt_dif((const uint32_t *)d.msg.p, (uint32_t *)d.codeword.p, width, d.log_rows, lh, cx.stream));
         build_tree(d, (const uint32_t *)d.codeword.p, width, false);
+        if (!prover_config().cache_rs_code_matrix) d.codeword.release();  // re-encoded from `msg` when rows are opened
         return d;
     }
 
@@ -1094,7 +1112,8 @@ struct Prover {
         // reduction was most of this stage's time.
         struct Round0Job {
             unsigned cdeg = 0, zc_cosets = 0, lg_cosets = 0;
-            size_t zc_slot = 0, lg_slot = 0;
+            size_t zc_slot = 0, lg_slot = 0, zc_stride = 0, lg_stride = 0;
+            uint32_t n_slabs = 1;
             DevBuf<EF> d_eq, zc_partials, lg_partials;
             DevBuf<Fp> lde;
             DevBuf<uint32_t> d_used;
@@ -1207,44 +1226,62 @@ struct Prover {
             for (size_t c = 0; c < usedm.size(); c++)
                 if (usedm[c]) used.push_back((uint32_t)c);
             job.d_used = cx.upload(used);
-            job.lde.alloc((size_t)n_cosets * v.cm.total << v.log_lifted);
-            {
-                OVM_PROF("round0.coset_lde", cx.stream);
-                OVM_THROW_IF(coset_lde(v.cols.p, job.d_used.p, (uint32_t)used.size(), (uint32_t)v.cm.total, v.log_lifted, l_skip,
-                                       n_cosets, d_sp_all.p, job.lde.p, cx.stream));
-            }
-            const size_t red_blocks = std::min<size_t>(RED_BLOCKS, ((size_t(1) << v.log_lifted) + RED_THREADS - 1) / RED_THREADS);
+            // zerocheck_save_memory: a tall trace is extended and evaluated in slabs of 2^slab rows -- the LDE buffer
+            // (n_cosets x columns x rows words: 3.5 GB at config D, 14 GB at config E) shrinks to one slab; the slab
+            // sums are linear and are added up on the host. (The chunks of 2^l_skip rows are independent.)
+            const ProverConfig &pcfg = prover_config();
+            const unsigned slab_log = (pcfg.zerocheck_save_memory && v.log_lifted > std::max(pcfg.round0_slab_log_rows, l_skip))
+                                          ? std::max(pcfg.round0_slab_log_rows, l_skip) : v.log_lifted;
+            job.n_slabs = 1u << (v.log_lifted - slab_log);
+            job.lde.alloc((size_t)n_cosets * v.cm.total << slab_log);
+            const size_t red_blocks = std::min<size_t>(RED_BLOCKS, ((size_t(1) << slab_log) + RED_THREADS - 1) / RED_THREADS);
+            const bool batch_zc = job.zc_cosets && job.n_slabs == 1 && r0_batchable(tp[t].zc->staged, v.log_lifted);
+            const bool batch_lg = job.lg_cosets && job.n_slabs == 1 && r0_batchable(tp[t].lg->staged, v.log_lifted);
             if (job.zc_cosets) {
-                OVM_PROF("round0.zerocheck", cx.stream);
-                if (r0_batchable(tp[t].zc->staged, v.log_lifted) && tp[t].zc_g && tp[t].zc_g->gp.off.size() - 1 >= r0_groups_min)
+                if (batch_zc && tp[t].zc_g && tp[t].zc_g->gp.off.size() - 1 >= r0_groups_min)
                     tp[t].zc_sg = make_staged_groups(tp[t].zc_g->gp, tp[t].zc_w, v.log_lifted, 1,
                                                      R0_GROUP_JOB_WGS / round0_staged_grid(tp[t].zc->staged, v.log_lifted));
-                const size_t zc_records = std::max<size_t>(red_blocks, r0_batchable(tp[t].zc->staged, v.log_lifted)
-                                                                           ? r0_job_grid(tp[t].zc->staged, tp[t].zc_sg.get(), v.log_lifted)
-                                                                           : 0);
+                const size_t zc_records = std::max<size_t>(red_blocks, batch_zc ? r0_job_grid(tp[t].zc->staged, tp[t].zc_sg.get(), v.log_lifted) : 0);
                 job.zc_partials.alloc(zc_records * job.zc_cosets * N + 64);
                 job.zc_slot = next_slot;
-                next_slot += (job.zc_cosets * N + 63) & ~size_t(63);
-                if (!r0_enqueue(tp[t].zc->staged, tp[t].zc_sg.get(), job.lde.p, (uint32_t)v.cm.total, v.log_lifted, job.zc_cosets, 1,
-                                job.d_eq.p, EF::zero(), job.zc_partials.p, job.zc_slot))
-                    OVM_THROW_IF(round0_eval(tp[t].zc->dev(), tp[t].zc->staged, job.lde.p, (uint32_t)v.cm.total, v.log_lifted, l_skip,
-                                             job.zc_cosets, 1, job.d_eq.p, EF::zero(), mb.arm(job.zc_partials.p, job.zc_slot), cx.stream));
+                job.zc_stride = (job.zc_cosets * N + 63) & ~size_t(63);
+                next_slot += job.zc_stride * job.n_slabs;
             }
             if (job.lg_cosets) {
-                OVM_PROF("round0.logup", cx.stream);
-                if (r0_batchable(tp[t].lg->staged, v.log_lifted) && tp[t].lg_g && tp[t].lg_g->gp.off.size() - 1 >= r0_groups_min)
+                if (batch_lg && tp[t].lg_g && tp[t].lg_g->gp.off.size() - 1 >= r0_groups_min)
                     tp[t].lg_sg = make_staged_groups(tp[t].lg_g->gp, tp[t].lg_w, v.log_lifted, 2,
                                                      R0_GROUP_JOB_WGS / round0_staged_grid(tp[t].lg->staged, v.log_lifted));
-                const size_t lg_records = std::max<size_t>(red_blocks, r0_batchable(tp[t].lg->staged, v.log_lifted)
-                                                                           ? r0_job_grid(tp[t].lg->staged, tp[t].lg_sg.get(), v.log_lifted)
-                                                                           : 0);
+                const size_t lg_records = std::max<size_t>(red_blocks, batch_lg ? r0_job_grid(tp[t].lg->staged, tp[t].lg_sg.get(), v.log_lifted) : 0);
                 job.lg_partials.alloc(lg_records * job.lg_cosets * 2 * N + 64);
                 job.lg_slot = next_slot;
-                next_slot += (job.lg_cosets * 2 * N + 63) & ~size_t(63);
-                if (!r0_enqueue(tp[t].lg->staged, tp[t].lg_sg.get(), job.lde.p, (uint32_t)v.cm.total, v.log_lifted, job.lg_cosets, 2,
-                                job.d_eq.p, tp[t].lg_const, job.lg_partials.p, job.lg_slot))
-                    OVM_THROW_IF(round0_eval(tp[t].lg->dev(), tp[t].lg->staged, job.lde.p, (uint32_t)v.cm.total, v.log_lifted, l_skip,
-                                             job.lg_cosets, 2, job.d_eq.p, tp[t].lg_const, mb.arm(job.lg_partials.p, job.lg_slot), cx.stream));
+                job.lg_stride = (job.lg_cosets * 2 * N + 63) & ~size_t(63);
+                next_slot += job.lg_stride * job.n_slabs;
+            }
+            if (next_slot + 4 * MAX_COSETS * N + 128 > Mailbox::SLOTS) throw OvmFail(801, "too many traces for the round-0 mailbox");
+            for (uint32_t sb = 0; sb < job.n_slabs; sb++) {
+                const uint64_t row0 = (uint64_t)sb << slab_log;
+                const EF *eq_slab = job.d_eq.p + (row0 >> l_skip);
+                {
+                    OVM_PROF("round0.coset_lde", cx.stream);
+                    OVM_THROW_IF(coset_lde(v.cols.p, job.d_used.p, (uint32_t)used.size(), (uint32_t)v.cm.total, slab_log, l_skip,
+                                           n_cosets, d_sp_all.p, job.lde.p, cx.stream, row0));
+                }
+                if (job.zc_cosets) {
+                    OVM_PROF("round0.zerocheck", cx.stream);
+                    const size_t slot = job.zc_slot + sb * job.zc_stride;
+                    if (!(batch_zc && r0_enqueue(tp[t].zc->staged, tp[t].zc_sg.get(), job.lde.p, (uint32_t)v.cm.total, v.log_lifted, job.zc_cosets, 1,
+                                                 job.d_eq.p, EF::zero(), job.zc_partials.p, slot)))
+                        OVM_THROW_IF(round0_eval(tp[t].zc->dev(), tp[t].zc->staged, job.lde.p, (uint32_t)v.cm.total, slab_log, l_skip,
+                                                 job.zc_cosets, 1, eq_slab, EF::zero(), mb.arm(job.zc_partials.p, slot), cx.stream));
+                }
+                if (job.lg_cosets) {
+                    OVM_PROF("round0.logup", cx.stream);
+                    const size_t slot = job.lg_slot + sb * job.lg_stride;
+                    if (!(batch_lg && r0_enqueue(tp[t].lg->staged, tp[t].lg_sg.get(), job.lde.p, (uint32_t)v.cm.total, v.log_lifted, job.lg_cosets, 2,
+                                                 job.d_eq.p, tp[t].lg_const, job.lg_partials.p, slot)))
+                        OVM_THROW_IF(round0_eval(tp[t].lg->dev(), tp[t].lg->staged, job.lde.p, (uint32_t)v.cm.total, slab_log, l_skip,
+                                                 job.lg_cosets, 2, eq_slab, tp[t].lg_const, mb.arm(job.lg_partials.p, slot), cx.stream));
+                }
             }
             if (next_slot + 4 * MAX_COSETS * N + 128 > Mailbox::SLOTS) throw OvmFail(801, "too many traces for the round-0 mailbox");
         }
@@ -1281,6 +1318,10 @@ struct Prover {
             const unsigned cdeg = job.cdeg;
             if (job.zc_cosets) {
                 auto ev = mb.read(job.zc_slot, (size_t)job.zc_cosets * N);
+                for (uint32_t sb = 1; sb < job.n_slabs; sb++) {
+                    const auto more = mb.read(job.zc_slot + sb * job.zc_stride, (size_t)job.zc_cosets * N);
+                    for (size_t i = 0; i < ev.size(); i++) ev[i] += more[i];
+                }
                 std::vector<std::vector<EF>> ce(job.zc_cosets, std::vector<EF>(N));
                 for (unsigned k = 0; k < job.zc_cosets; k++) {
                     Fp zinv = (g.pow(k + 1).exp_power_of_2(l_skip) - Fp::one()).inv();
@@ -1300,6 +1341,10 @@ struct Prover {
             }
             if (job.lg_cosets) {
                 auto ev = mb.read(job.lg_slot, (size_t)job.lg_cosets * 2 * N);
+                for (uint32_t sb = 1; sb < job.n_slabs; sb++) {
+                    const auto more = mb.read(job.lg_slot + sb * job.lg_stride, (size_t)job.lg_cosets * 2 * N);
+                    for (size_t i = 0; i < ev.size(); i++) ev[i] += more[i];
+                }
                 std::vector<std::vector<EF>> cn(job.lg_cosets, std::vector<EF>(N)), cden(job.lg_cosets, std::vector<EF>(N));
                 for (unsigned k = 0; k < job.lg_cosets; k++)
                     for (size_t z = 0; z < N; z++) {
@@ -1755,7 +1800,15 @@ struct Prover {
         auto d_didx = cx.upload(didx);
         DevBuf<p2::Digest> d_dig(std::max<size_t>(didx.size(), 1));
         DevBuf<Fp> d_vals(std::max<size_t>(rows.size() * cw, 1));
-        OVM_THROW_IF(ovm_hip_gather_rows((const uint32_t *)pcs.codeword.p, cw, 1ull << pcs.log_rows, 1, d_rows.p, rows.size(),
+        const Fp *codeword = pcs.codeword.p;
+        DevBuf<Fp> recomputed;
+        if (!codeword) {  // cache_rs_code_matrix = false at commit time: encode again (one NTT of the commitment)
+            OVM_PROF("whir.reencode", cx.stream);
+            recomputed.alloc(cw << pcs.log_rows);
+            OVM_THROW_IF(ovm_hip_ntt_dif((const uint32_t *)pcs.msg.p, (uint32_t *)recomputed.p, cw, pcs.log_rows, pcs.log_height, cx.stream));
+            codeword = recomputed.p;
+        }
+        OVM_THROW_IF(ovm_hip_gather_rows((const uint32_t *)codeword, cw, 1ull << pcs.log_rows, 1, d_rows.p, rows.size(),
                                          (uint32_t *)d_vals.p, cx.stream));
         OVM_THROW_IF(ovm_hip_gather_digests((const uint32_t *)pcs.layers.p, d_didx.p, didx.size(), (uint32_t *)d_dig.p, cx.stream));
         vals = cx.download(d_vals.p, rows.size() * cw);
@@ -2787,6 +2840,37 @@ int ovm_hip_pk_preprocessed_commitment(const ovm_pk_t *pk_, uint32_t air_idx, ui
     if (air_idx >= dk.pre.size() || !dk.pre[air_idx]) return (int)hipErrorInvalidValue;
     for (int i = 0; i < 8; i++) commitment_out[i] = dk.pre[air_idx]->root.d[i].v;
     return 0;
+}
+
+int ovm_hip_set_prover_config(const ovm_prover_config_t *cfg) {
+    if (!cfg || cfg->round0_slab_log_rows > 30) return (int)hipErrorInvalidValue;
+    ProverConfig &c = prover_config();
+    c.cache_rs_code_matrix = cfg->cache_rs_code_matrix != 0;
+    c.zerocheck_save_memory = cfg->zerocheck_save_memory != 0;
+    if (cfg->round0_slab_log_rows) c.round0_slab_log_rows = cfg->round0_slab_log_rows;
+    block_cache().limit_bytes = cfg->cache_limit_bytes;
+    if (cfg->cache_limit_bytes && block_cache().cached_bytes > cfg->cache_limit_bytes) block_cache().trim();
+    return 0;
+}
+
+int ovm_hip_memory_stats(uint64_t *live_bytes, uint64_t *peak_live_bytes, uint64_t *cached_bytes, int reset_peak) {
+    BlockRegistry &reg = BlockRegistry::get();
+    std::lock_guard<std::mutex> lk(reg.mu);
+    if (live_bytes) *live_bytes = reg.live_bytes;
+    if (peak_live_bytes) *peak_live_bytes = reg.peak_live_bytes;
+    if (cached_bytes) *cached_bytes = block_cache().cached_bytes;
+    if (reset_peak) reg.peak_live_bytes = reg.live_bytes;
+    return 0;
+}
+
+uint64_t ovm_hip_constraint_eval_buffer_size(const ovm_pk_t *pk_, uint32_t air_idx) {
+    if (!pk_) return 0;
+    const DeviceKey &dk = *reinterpret_cast<const DeviceKey *>(pk_);
+    if (air_idx >= dk.pk.airs.size()) return 0;
+    const AirKey &a = dk.pk.airs[air_idx];
+    const uint64_t cdeg = a.max_constraint_degree;
+    const uint64_t n_cosets = std::max<uint64_t>(cdeg ? cdeg - 1 : 0, a.interactions.empty() ? 0 : cdeg);
+    return n_cosets * column_map_of(a).total * sizeof(uint32_t);
 }
 
 int ovm_hip_trim(void) {

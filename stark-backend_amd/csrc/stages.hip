@@ -218,7 +218,7 @@ __global__ __launch_bounds__(LDE_THREADS) void coset_lde_kernel(const ColDesc *c
                                                                 uint32_t n_cols_total, uint32_t log_lifted,
                                                                 uint32_t l_skip, uint32_t tile_log,
                                                                 uint32_t n_cosets, const Fp *shift_pows,
-                                                                Fp inv_n, Fp *lde, Twiddles tw) {
+                                                                Fp inv_n, Fp *lde, Twiddles tw, uint64_t row0) {
     extern __shared__ Fp lds[];
     const uint32_t tile = 1u << tile_log;
     Fp *coef = lds, *work = lds + tile;
@@ -226,7 +226,7 @@ __global__ __launch_bounds__(LDE_THREADS) void coset_lde_kernel(const ColDesc *c
     const ColDesc cd = cols[col];
     const uint64_t base = (uint64_t)blockIdx.x << tile_log;
     const uint64_t hmask = (1ull << cd.log_height) - 1;
-    for (uint32_t i = threadIdx.x; i < tile; i += LDE_THREADS) coef[i] = cd.ptr[(base + i + cd.rot) & hmask];
+    for (uint32_t i = threadIdx.x; i < tile; i += LDE_THREADS) coef[i] = cd.ptr[(row0 + base + i + cd.rot) & hmask];
     __syncthreads();
     const uint32_t half = tile >> 1, N = 1u << l_skip;
     // inverse DIF over the chunk bits: natural -> bit-reversed coefficients
@@ -284,15 +284,16 @@ __device__ __forceinline__ constexpr int bitrev4(int i) {
 
 __global__ __launch_bounds__(256) void coset_lde16_kernel(const ColDesc *cols, const uint32_t *used,
                                                           uint32_t n_cols_total, uint32_t log_lifted,
-                                                          uint32_t n_cosets, const Fp *twist, Fp *lde) {
+                                                          uint32_t n_cosets, const Fp *twist, Fp *lde, uint64_t row0) {
     const uint64_t chunk = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (chunk >= (1ull << (log_lifted - 4))) return;
     const uint32_t col = used[blockIdx.y];
     const ColDesc cd = cols[col];
-    const uint64_t hmask = (1ull << cd.log_height) - 1, base = chunk << 4;
+    // (row0: the slab of rows [row0, row0 + 2^log_lifted) of the columns is extended -- round 0 in slabs)
+    const uint64_t hmask = (1ull << cd.log_height) - 1, base = chunk << 4, sbase = base + row0;
     Fp x[16];
     if (cd.rot == 0 && cd.log_height >= 4) {
-        const uint4 *src = reinterpret_cast<const uint4 *>(cd.ptr + (base & hmask));
+        const uint4 *src = reinterpret_cast<const uint4 *>(cd.ptr + (sbase & hmask));
 #pragma unroll
         for (int v = 0; v < 4; v++) {
             uint4 q = src[v];
@@ -303,7 +304,7 @@ __global__ __launch_bounds__(256) void coset_lde16_kernel(const ColDesc *cols, c
         }
     } else {
 #pragma unroll
-        for (int z = 0; z < 16; z++) x[z] = cd.ptr[(base + z + cd.rot) & hmask];
+        for (int z = 0; z < 16; z++) x[z] = cd.ptr[(sbase + z + cd.rot) & hmask];
     }
     // inverse DIF, natural -> bit-reversed coefficients (unscaled; 1/16 is folded into `twist`)
 #pragma unroll
@@ -348,22 +349,23 @@ __global__ __launch_bounds__(256) void coset_lde16_kernel(const ColDesc *cols, c
 
 int coset_lde(const ColDesc *d_cols, const uint32_t *d_used, uint32_t n_used, uint32_t n_cols_total,
               uint32_t log_lifted, uint32_t l_skip, uint32_t n_cosets, const Fp *d_shift_pows, Fp *lde,
-              hipStream_t s) {
+              hipStream_t s, uint64_t row0) {
     if (n_used == 0 || n_cosets == 0) return 0;
+    if (row0 & ((1ull << l_skip) - 1)) return (int)hipErrorInvalidValue;
     const Twiddles *tw = twiddles();
     if (!tw || l_skip > LDE_TILE_LOG || l_skip > log_lifted) return (int)hipErrorInvalidValue;
     // d_shift_pows[k * N + i] = shift_k^i / N (the caller folds 1/N in)
     if (l_skip == 4) {
         dim3 grid16((unsigned)ceil_div(1ull << (log_lifted - 4), 256), n_used);
         hipLaunchKernelGGL(coset_lde16_kernel, grid16, dim3(256), 0, s, d_cols, d_used, n_cols_total, log_lifted,
-                           n_cosets, d_shift_pows, lde);
+                           n_cosets, d_shift_pows, lde, row0);
         OVM_CHECK_LAUNCH();
         return 0;
     }
     uint32_t tile_log = log_lifted < LDE_TILE_LOG ? log_lifted : LDE_TILE_LOG;
     dim3 grid(1u << (log_lifted - tile_log), n_used);
     hipLaunchKernelGGL(coset_lde_kernel, grid, dim3(LDE_THREADS), 2 * sizeof(Fp) << tile_log, s, d_cols, d_used,
-                       n_cols_total, log_lifted, l_skip, tile_log, n_cosets, d_shift_pows, Fp::one(), lde, *tw);
+                       n_cols_total, log_lifted, l_skip, tile_log, n_cosets, d_shift_pows, Fp::one(), lde, *tw, row0);
     OVM_CHECK_LAUNCH();
     return 0;
 }

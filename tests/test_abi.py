@@ -47,7 +47,8 @@ import re
 _C_TO_RUST = {"void": "c_void", "int": "c_int", "char": "c_char", "uint32_t": "u32", "uint64_t": "u64", "uint8_t": "u8",
               "size_t": "usize", "ovm_stream_t": "OvmStream", "ovm_sponge_t": "OvmSponge", "ovm_pk_t": "OvmPk",
               "ovm_pcs_t": "OvmPcs", "ovm_trace_t": "OvmTrace", "ovm_pcs_params_t": "OvmPcsParams",
-              "ovm_matrix_t": "OvmMatrix", "ovm_shard_t": "OvmShard", "ovm_shm_comm_t": "OvmShmComm"}
+              "ovm_matrix_t": "OvmMatrix", "ovm_shard_t": "OvmShard", "ovm_shm_comm_t": "OvmShmComm",
+              "ovm_prover_config_t": "OvmProverConfig"}
 
 
 def _c_type_to_rust(t):
@@ -136,3 +137,4 @@ def test_struct_layouts_match_header(pkg):
     assert ctypes.sizeof(pkg.TraceStruct) == 48 and pkg.TraceStruct.cached.offset == 40
     assert ctypes.sizeof(pkg.PcsParams) == 16 and ctypes.sizeof(pkg.MatrixStruct) == 24
     assert ctypes.sizeof(pkg.ShardStruct) == 32 and pkg.ShardStruct.allgather_device.offset == 24
+    assert ctypes.sizeof(pkg.ProverConfigStruct) == 24 and pkg.ProverConfigStruct.cache_limit_bytes.offset == 16

@@ -1,0 +1,95 @@
+"""Memory-bounded modes (reference: GpuProverConfig, cuda-backend/src/device.rs:25-30):
+codeword dropped and re-encoded at opening time, round 0 in slabs, capped allocator cache. Proofs must not
+change; the allocator's peak must go down."""
+import numpy as np
+import pytest
+
+import airs
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def _defaults(pkg):
+    yield
+    pkg.set_prover_config()  # back to "everything resident"
+    pkg._lib().ovm_hip_trim()
+
+
+def _prove(dev, pkg, pk, traces):
+    pkg._lib().ovm_hip_trim()
+    pkg.memory_stats(reset_peak=True)
+    proof, _ = dev.prove(pk, traces)
+    return proof, pkg.memory_stats()["peak"]
+
+
+def test_modes_keep_the_proof_and_lower_the_peak(dev, pkg, orc):
+    """2^16 x 40 BenchmarkAir (app-like parameters, log_stacked_height 18): identical bytes in every mode,
+    byte-identical to the oracle, strictly lower peak with the save-memory modes."""
+    params = airs.test_params(l_skip=4, n_stack=14, k_whir=4)
+    air = airs.uniform_runner_air(40)
+    blob = airs.pk_blob(params, [air])
+    pk = pkg.ProvingKey(blob)
+    h = 1 << 16
+    tr = airs.splitmix64_bits(77, 40 * h)
+    d = dev.upload(pkg.to_mont(tr))
+    base, peak_base = _prove(dev, pkg, pk, [(0, d, h, [])])
+    assert base == orc.prove(blob, [(0, tr, h, [])])["proof"]
+    # per-row scratch of round 0: 2 cosets x (3 selectors + 40 columns) x 4 bytes
+    assert pkg.constraint_eval_buffer_size(pk, 0) == 2 * 43 * 4
+    pkg.set_prover_config(cache_rs_code_matrix=False)
+    p1, peak1 = _prove(dev, pkg, pk, [(0, d, h, [])])
+    pkg.set_prover_config(zerocheck_save_memory=True, round0_slab_log_rows=10)   # 64 slabs
+    p2, peak2 = _prove(dev, pkg, pk, [(0, d, h, [])])
+    pkg.set_prover_config(cache_rs_code_matrix=False, zerocheck_save_memory=True, round0_slab_log_rows=12,
+                          cache_limit_bytes=64 << 20)
+    p3, peak3 = _prove(dev, pkg, pk, [(0, d, h, [])])
+    assert p1 == base and p2 == base and p3 == base
+    assert peak2 < peak_base and peak3 < peak_base and peak3 <= peak2
+    assert pkg.memory_stats()["cached"] <= 64 << 20
+    print(f"peak bytes: resident {peak_base}, no codeword cache {peak1}, slabs {peak2}, both + capped cache {peak3}")
+
+
+def test_slabs_with_rotation_preprocessed_and_interactions(dev, pkg, orc):
+    """Slabs on AIRs whose rows look at their neighbours (rotation wraps across slab ends) and at
+    preprocessed / cached partitions."""
+    pkg.set_prover_config(cache_rs_code_matrix=False, zerocheck_save_memory=True, round0_slab_log_rows=2)
+    params = airs.test_params(l_skip=2, n_stack=6, k_whir=2)
+    tr, pvs = airs.fibonacci_trace(0, 1, 64)
+    blob = airs.pk_blob(params, [airs.fibonacci_air()])
+    got, _ = dev.prove(pkg.ProvingKey(blob), [(0, dev.upload(pkg.to_mont(np.asarray(tr, np.uint32))), 64, pvs)])
+    assert got == orc.prove(blob, [(0, tr, 64, pvs)])["proof"]
+    sels = [i % 2 == 0 for i in range(32)]
+    common, cached = airs.preprocessed_cached_traces(sels, 2)
+    pre = {0: (np.array([int(s) for s in sels], np.uint32), len(sels))}
+    air = airs.preprocessed_cached_air(2)
+    blob = airs.pk_blob(airs.test_params(), [air], preprocessed=pre)
+    pk = pkg.ProvingKey(blob)
+    up = lambda a: dev.upload(pkg.to_mont(np.asarray(a, np.uint32)))
+    handles = [dev.commit_matrix(pk, up(cached[i * 32:(i + 1) * 32]), 1, 32) for i in range(2)]
+    got, _ = dev.prove(pk, [(0, up(common), 32, [], handles)])
+    assert got == orc.prove(blob, [(0, common, 32, [], cached)])["proof"]
+
+
+def test_config_e_under_a_capped_cache(dev, pkg, orc):
+    """BASELINE config E (2^24 x 100, blowup 4: a 26.8 GB codeword) with the codeword dropped, round 0 in
+    slabs of 2^20 rows and at most 8 GB kept in the allocator's free lists: the verifier accepts the proof
+    and the peak is tens of GB below the resident run's."""
+    import torch
+    params = airs.stress_params(24)
+    blob = airs.pk_blob(params, [airs.uniform_runner_air(100)])
+    pk = pkg.ProvingKey(blob)
+    h = 1 << 24
+    gen = torch.Generator(device="cuda:0")
+    gen.manual_seed(0xD15EA5E)
+    trace = torch.randint(0, 2, (100 * h,), dtype=torch.int32, device="cuda:0", generator=gen)
+    trace *= int(pkg.to_mont(np.array([1], dtype=np.uint32))[0])
+    resident, peak_res = _prove(dev, pkg, pk, [(0, trace, h, [])])
+    pkg.set_prover_config(cache_rs_code_matrix=False, zerocheck_save_memory=True, round0_slab_log_rows=20,
+                          cache_limit_bytes=8 << 30)
+    bounded, peak_bnd = _prove(dev, pkg, pk, [(0, trace, h, [])])
+    assert bounded == resident
+    orc.verify(blob, bounded)
+    print(f"config E peak: resident {peak_res / 2**30:.1f} GiB, bounded {peak_bnd / 2**30:.1f} GiB")
+    assert peak_bnd < peak_res - (20 << 30)
+    del trace
