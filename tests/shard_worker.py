@@ -32,11 +32,28 @@ def main():
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(args.port))
     dist.init_process_group("gloo", rank=args.rank, world_size=args.world)
     dev = pkg.Device(0)
-    params, air_list, traces, owners = shard_cases.make(args.case, args.world)
-    pk = pkg.ProvingKey(airs.pk_blob(params, air_list))
     shard = pkg.Shard(args.rank, args.world, args.shm)
+    if args.case.startswith("gen:"):
+        # "gen:<log_rows>:<cols>:<log_stacked_height>": one partitioned BenchmarkAir per rank under app parameters, the
+        # seeded boolean trace generated on the device (BASELINE config D's multi-GPU form at any size)
+        log_rows, cols, log_stacked = (int(x) for x in args.case.split(":")[1:])
+        h = 1 << log_rows
+        air = airs.uniform_runner_air_partitioned(cols)
+        pk = pkg.ProvingKey(airs.pk_blob(airs.app_params(log_stacked), [air] * args.world))
+        gen = torch.Generator(device="cuda:0")
+        gen.manual_seed(0xD15EA5E + args.rank)
+        one = int(pkg.to_mont(np.array([1], dtype=np.uint32))[0])
+        cached = torch.randint(0, 2, (cols * h,), dtype=torch.int32, device="cuda:0", generator=gen) * one
+        common = torch.randint(0, 2, (h,), dtype=torch.int32, device="cuda:0", generator=gen) * one
+        handle = dev.commit_matrix(pk, cached, cols, h)
+        owners = list(range(args.world))
+        dtr = [(a, common, h, [], [handle]) if a == args.rank else (a, None, h, [], None) for a in range(args.world)]
+        traces = []
+    else:
+        params, air_list, traces, owners = shard_cases.make(args.case, args.world)
+        pk = pkg.ProvingKey(airs.pk_blob(params, air_list))
+        dtr = []
     up = lambda a: dev.upload(pkg.to_mont(np.asarray(a, dtype=np.uint32)))
-    dtr = []
     for (a, common, h, pvs, cached), o in zip(traces, owners):
         if o != args.rank:
             dtr.append((a, None, h, [], None))

@@ -76,3 +76,16 @@ def test_single_process_equals_sharded(dev, pkg, orc, tmp_path):
         dtr.append((a, up(common), h, pvs, [dev.commit_matrix(pk, up(cached), w, h)]))
     single, _ = dev.prove(pk, dtr)
     assert single == run_sharded("bench_app", 2, tmp_path, repeat=2)
+
+
+def test_config_d_full_size_two_shards_on_one_gpu_verifies(orc, tmp_path):
+    """BASELINE config D in its sharded form AT FULL SIZE -- two AIRs of 2^22 rows x 100 columns (each its own
+    cached-main commitment) + 1-column common mains, app parameters, 2^28-leaf fraction tree split over two
+    ranks -- as two logical shards on this one GPU: the joint proof is accepted by the verifier restatement."""
+    got = run_sharded("gen:22:100:24", 2, tmp_path)
+    blob = airs.pk_blob(airs.app_params(24), [airs.uniform_runner_air_partitioned(100)] * 2)
+    orc.verify(blob, got)
+    bad = bytearray(got)
+    bad[len(bad) // 3] ^= 1
+    with pytest.raises(Exception):
+        orc.verify(blob, bytes(bad))
