@@ -243,7 +243,7 @@ def main():
                 ib["ceiling_source"] = "profiles/r02/poseidon2_mix_ceiling.json"
             roof["issue_bound"] = ib
             if world == 1:
-                gkr_leaves = 1 << ((26 * h - 1).bit_length())  # 13 send/receive pairs -> 26 interactions, padded to a power of two
+                gkr_leaves = 26 * h  # 13 send/receive pairs -> 26 interactions per row (padding leaves are never materialised)
                 roof["classes"] = roofline_classes(prof, args.steps, rows, width, cells, args.log_stacked_height, gkr_leaves)
         cpu = None
         if not args.no_cpu_baseline:

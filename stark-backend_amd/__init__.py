@@ -482,9 +482,21 @@ class Shard:
             self.bulk_bytes += int(nbytes) * self.world
             if dist.get_backend(self.group) == "nccl":
                 dev = torch.device("cuda", torch.cuda.current_device())
-                send = torch.as_tensor(_DevPtr(d_mine, nbytes), device=dev)
-                recv = torch.as_tensor(_DevPtr(d_all, nbytes * self.world), device=dev)
+                try:  # views of the prover's own buffers: no copy
+                    send = torch.as_tensor(_DevPtr(d_mine, nbytes), device=dev)
+                    recv = torch.as_tensor(_DevPtr(d_all, nbytes * self.world), device=dev)
+                    staged = False
+                except Exception:  # a torch build without __cuda_array_interface__ views: stage through torch tensors
+                    send = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+                    recv = torch.empty(nbytes * self.world, dtype=torch.uint8, device=dev)
+                    check(_lib().ovm_hip_memcpy_d2d(send.data_ptr(), d_mine, nbytes, stream), "ovm_hip_memcpy_d2d")
+                    check(_lib().ovm_hip_stream_synchronize(stream), "ovm_hip_stream_synchronize")
+                    staged = True
                 dist.all_gather_into_tensor(recv, send, group=self.group)
+                if staged:
+                    torch.cuda.current_stream().synchronize()
+                    check(_lib().ovm_hip_memcpy_d2d(d_all, recv.data_ptr(), nbytes * self.world, stream), "ovm_hip_memcpy_d2d")
+                    check(_lib().ovm_hip_stream_synchronize(stream), "ovm_hip_stream_synchronize")
             else:  # host-staged (gloo): the same call sequence without a device collective
                 send = torch.empty(nbytes, dtype=torch.uint8)
                 check(_lib().ovm_hip_memcpy_d2h(send.data_ptr(), d_mine, nbytes, stream), "ovm_hip_memcpy_d2h")

@@ -51,11 +51,14 @@ inline GkrRec rec_fold(const GkrRec &a, const GkrRec &b, const EF &r) {
 // sums[X-1] += e * (p0 q1 + p1 q0 + lambda q0 q1)(X), every quantity the line through its values on a
 // (X = 0) and b (X = 1): what the device kernels (stages.hip: gkr_pair_sums) add per pair
 inline void rec_pair_sums(const GkrRec &a, const GkrRec &b, const EF &e, const EF &lambda, unsigned n_points, EF *sums) {
+    EF v[4], d[4];
+    for (int k = 0; k < 4; k++) {
+        v[k] = b.v[k];  // X = 1
+        d[k] = b.v[k] - a.v[k];
+    }
     for (unsigned x = 1; x <= n_points; x++) {
-        const EF X = ef_u64(x);
-        EF v[4];
-        for (int k = 0; k < 4; k++) v[k] = a.v[k] + (b.v[k] - a.v[k]) * X;
         sums[x - 1] += (v[0] * v[3] + v[1] * (v[2] + lambda * v[3])) * e;
+        for (int k = 0; k < 4; k++) v[k] += d[k];
     }
 }
 
@@ -141,10 +144,17 @@ struct GkrDeviceOps {
     // (sr == 0: the tree layer itself). If sr > 0, table(sr) is produced from table(sr - 1) with r_prev
     // for the records of `pairs` (2y, 2y+1 for y in pairs) and for the `n_edges` records edge_idx.
     // S[0..n_points) = sum over y in pairs of eq_rest(y) * pair(table(sr)[2y], table(sr)[2y+1])(X = 1..);
-    // edges[k] = table(sr)[edge_idx[k]]. Blocks until the results are on the host.
+    // edges[k] = table(sr)[edge_idx[k]]; the indices are at most two runs of consecutive records (two unpaired
+    // ends, or ONE run = the rank's whole remaining table handed to the host, at most GKR_HOST_TAIL records).
+    // Blocks until the results are on the host.
     virtual void subround(unsigned round, unsigned sr, URange pairs, const uint64_t *edge_idx, unsigned n_edges, EF r_prev,
                           EF lambda, unsigned n_points, EF *S, GkrRec *edges) = 0;
 };
+
+// A rank whose table has shrunk to this many records hands all of them to the host in one go, and the host
+// (every rank's, identically) finishes the layer: the last sub-rounds of a layer are a kernel launch and a
+// mailbox round trip (~12 us) for a handful of pairs each, which the host sums in a microsecond or two.
+static constexpr unsigned GKR_HOST_TAIL = 32;
 
 struct GkrOutput {
     EF q0_claim = EF::one();
@@ -240,8 +250,8 @@ struct GkrSharded {
         struct Msg {
             EF S[3];
             uint64_t n_edges;
-            uint64_t eidx[2];
-            GkrRec edges[2];
+            uint64_t eidx[GKR_HOST_TAIL];
+            GkrRec edges[GKR_HOST_TAIL];
         };
         const EF inv2 = EF::from_base(fp(2).inv());
         for (unsigned round = 1; round < TR; round++) {
@@ -268,12 +278,23 @@ struct GkrSharded {
                 const EF a = epilogue ? EF::zero() : xi_prev[sr];
                 const EF w0 = c_bound * (EF::one() - a);
                 const unsigned n_points = epilogue ? 0 : ((is_zero(w0) || force_three_points) ? 3 : 2);
+                // a rank with a short table hands ALL its records over and owns nothing from here on
+                std::vector<char> dumps(W, 0);
+                for (uint32_t o = 0; o < W; o++) dumps[o] = !R[o].empty() && R[o].size() <= GKR_HOST_TAIL;
+                Msg mine{};
+                for (auto &s : mine.S) s = EF::zero();
+                URange my_records = R[me];
+                for (uint32_t o = 0; o < W; o++)
+                    if (dumps[o]) R[o] = URange{0, 0};
                 std::vector<URange> Pn(plan.owners());
                 for (uint32_t o = 0; o < plan.owners(); o++) Pn[o] = epilogue ? URange{0, 0} : up(R[o]);
                 // my device part
-                Msg mine{};
-                for (auto &s : mine.S) s = EF::zero();
-                mine.n_edges = range_edges(R[me], mine.eidx);
+                if (dumps[me]) {
+                    mine.n_edges = my_records.size();
+                    for (uint64_t k = 0; k < mine.n_edges; k++) mine.eidx[k] = my_records.lo + k;
+                } else {
+                    mine.n_edges = range_edges(R[me], mine.eidx);
+                }
                 if (!Pn[me].empty() || mine.n_edges)
                     dev.subround(round, sr, Pn[me], mine.eidx, (unsigned)mine.n_edges, r_prev, lambda, n_points, mine.S, mine.edges);
                 std::vector<Msg> all(W);
@@ -283,7 +304,7 @@ struct GkrSharded {
                 EF S[3] = {EF::zero(), EF::zero(), EF::zero()};
                 for (uint32_t o = 0; o < W; o++) {
                     for (unsigned k = 0; k < n_points; k++) S[k] += all[o].S[k];
-                    for (uint64_t k = 0; k < all[o].n_edges && k < 2; k++) known[all[o].eidx[k]] = all[o].edges[k];
+                    for (uint64_t k = 0; k < all[o].n_edges && k < GKR_HOST_TAIL; k++) known[all[o].eidx[k]] = all[o].edges[k];
                 }
                 {  // the padding run: constant records, closed-form sums
                     uint64_t pe[2];

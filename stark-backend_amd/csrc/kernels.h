@@ -154,9 +154,10 @@ EqHeapPlan eq_heap_plan(uint32_t n, const std::vector<std::pair<uint64_t, uint64
 int eq_heap_run(const EF *d_point, const EqHeapPlan &plan, EFPlanes heap, hipStream_t s);
 // fractions at arbitrary plane positions, for the host (n <= 32)
 int gkr_read_list(FracPlanes t, const uint64_t *d_pos, const uint32_t *d_pbase, uint32_t n, const RedOut &ro, hipStream_t s);
-// up to two table records for the host, read (fold = false: two fractions at `at`) or folded by r (four fractions)
-int gkr_edge_records(FracPlanes src, uint64_t at0, uint64_t at1, uint32_t n, bool p_base, bool fold, EF r, const RedOut &ro,
-                     hipStream_t s);
+// table records for the host: n0 consecutive ones from plane offset at0, then n1 from at1 (n0 + n1 <= 64), read
+// (fold = false: two fractions per record) or folded by r (four fractions per record)
+int gkr_edge_records(FracPlanes src, uint64_t at0, uint64_t at1, uint32_t n0, uint32_t n1, bool p_base, bool fold, EF r,
+                     const RedOut &ro, hipStream_t s);
 // p_base: leaf numerators are base-field, only limb plane 0 of P is written / read (stages.hip)
 int gkr_fill_leaves(FracPlanes leaves, uint64_t n, EF alpha, bool p_base, hipStream_t s);
 // The leaf kernels of many traces in one launch (staged programs, one row per lane): job j owns

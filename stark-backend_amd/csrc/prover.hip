@@ -862,12 +862,19 @@ struct Prover {
                 if (have_pairs) ro.flag = nullptr;
                 // record e of table(sr): two fractions of the layer (sr == 0), or the fold by r_prev of records
                 // 2e, 2e+1 of table(sr-1) = four fractions of the layer (sr == 1) / of the previous buffer
-                uint64_t at[2] = {0, 0};
+                // split the indices into (at most two) runs of consecutive records
+                uint32_t n0 = 1;
+                while (n0 < n_edges && edge_idx[n0] == edge_idx[n0 - 1] + 1) n0++;
+                const uint32_t n1 = n_edges - n0;
+                for (uint32_t k = n0 + 1; k < n_edges; k++)
+                    if (edge_idx[k] != edge_idx[k - 1] + 1) throw OvmFail(1, "internal: more than two runs of edge records");
                 const unsigned L = round + 1;
                 const FracPlanes base = sr <= 1 ? tree().at(toff[L]) : recs(sr - 1);
-                for (unsigned k = 0; k < n_edges; k++)
-                    at[k] = sr == 0 ? 2 * edge_idx[k] - fb[L] : sr == 1 ? 4 * edge_idx[k] - fb[L] : 2 * (2 * edge_idx[k] - rbase[sr - 1]);
-                OVM_THROW_IF(gkr_edge_records(base, at[0], at[1], n_edges, leaf_layer && sr <= 1, sr != 0, r_prev, ro, st));
+                auto at_of = [&](uint64_t e) -> uint64_t {
+                    return sr == 0 ? 2 * e - fb[L] : sr == 1 ? 4 * e - fb[L] : 2 * (2 * e - rbase[sr - 1]);
+                };
+                OVM_THROW_IF(gkr_edge_records(base, at_of(edge_idx[0]), n1 ? at_of(edge_idx[n0]) : 0, n0, n1, leaf_layer && sr <= 1, sr != 0,
+                                              r_prev, ro, st));
             }
             if (have_pairs) {
                 const uint64_t y0 = pairs.lo, n_pairs = pairs.size();

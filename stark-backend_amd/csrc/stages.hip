@@ -1681,13 +1681,16 @@ int gkr_read_list(FracPlanes t, const uint64_t *d_pos, const uint32_t *d_pbase, 
     return 0;
 }
 
-// Up to two table records for the host: out[4k..4k+4) = (p0, q0, p1, q1). fold == 0: record k is the two
-// fractions at src[k] (planes offset by at[k]); fold != 0: it is the fold by r of the two records = four
-// fractions there (the gkr_fold_final of round 1, at any index).
-__global__ void gkr_edge_kernel(FracPlanes src, uint64_t at0, uint64_t at1, uint32_t n, int p_base, int fold, EF r, RedOut ro) {
+// Table records for the host: out[4k..4k+4) = (p0, q0, p1, q1) of record k. Records 0..n0-1 are consecutive
+// starting at plane offset at0, records n0..n0+n1-1 consecutive from at1 (two unpaired edge records, or one
+// run = a rank's whole remaining table). fold == 0: a record is the two fractions there; fold != 0: it is the
+// fold by r of two records = four fractions (the gkr_fold_final of round 1, at any index).
+__global__ void gkr_edge_kernel(FracPlanes src, uint64_t at0, uint64_t at1, uint32_t n0, uint32_t n1, int p_base, int fold, EF r,
+                                RedOut ro) {
     const uint32_t k = threadIdx.x;
-    if (k < n) {
-        const uint64_t at = k == 0 ? at0 : at1;
+    if (k < n0 + n1) {
+        const uint64_t step = fold ? 4 : 2;
+        const uint64_t at = k < n0 ? at0 + step * k : at1 + step * (k - n0);
         EF *out = ro.out + 4 * k;
         if (fold) {
             EF p[4], q[4];
@@ -1717,10 +1720,10 @@ __global__ void gkr_edge_kernel(FracPlanes src, uint64_t at0, uint64_t at1, uint
     __syncthreads();
     if (k == 0) publish(ro);
 }
-int gkr_edge_records(FracPlanes src, uint64_t at0, uint64_t at1, uint32_t n, bool p_base, bool fold, EF r, const RedOut &ro,
-                     hipStream_t s) {
-    if (n == 0 || n > 2) return (int)hipErrorInvalidValue;
-    hipLaunchKernelGGL(gkr_edge_kernel, dim3(1), dim3(64), 0, s, src, at0, at1, n, p_base ? 1 : 0, fold ? 1 : 0, r, ro);
+int gkr_edge_records(FracPlanes src, uint64_t at0, uint64_t at1, uint32_t n0, uint32_t n1, bool p_base, bool fold, EF r,
+                     const RedOut &ro, hipStream_t s) {
+    if (n0 + n1 == 0 || n0 + n1 > 64) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(gkr_edge_kernel, dim3(1), dim3(64), 0, s, src, at0, at1, n0, n1, p_base ? 1 : 0, fold ? 1 : 0, r, ro);
     OVM_CHECK_LAUNCH();
     return 0;
 }

@@ -89,3 +89,33 @@ def test_config_d_full_size_two_shards_on_one_gpu_verifies(orc, tmp_path):
     bad[len(bad) // 3] ^= 1
     with pytest.raises(Exception):
         orc.verify(blob, bytes(bad))
+
+
+def test_bulk_exchange_callback_on_nccl(tmp_path):
+    """The RCCL branch of the Python host's bulk exchange (the one line that differs from the gloo branch the
+    logical-shard tests use): zero-copy torch views of raw device ranges + all_gather_into_tensor on the nccl
+    backend. One GPU is all this box has, so the group has one rank; run in a child process (its own
+    process group)."""
+    code = """
+import os, sys, ctypes
+sys.path.insert(0, %r)
+import torch, torch.distributed as dist
+from conftest import load_pkg
+pkg = load_pkg()
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=%r, RANK="0", WORLD_SIZE="1")
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+dev = pkg.Device(0)
+shard = pkg.Shard(0, 1, "/ovm-test-nccl-%%d" %% os.getpid())
+src = torch.arange(1 << 20, dtype=torch.int32, device="cuda:0")
+dst = torch.zeros(1 << 20, dtype=torch.int32, device="cuda:0")
+rc = shard._allgather_device(None, src.data_ptr(), dst.data_ptr(), src.numel() * 4, dev.stream.value or 0)
+torch.cuda.synchronize()
+assert rc == 0 and torch.equal(src, dst), rc
+assert shard.bulk_bytes == 4 << 20
+shard.close()
+dist.destroy_process_group()
+print("nccl bulk exchange ok")
+""" % (HERE, str(_free_port()))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "nccl bulk exchange ok" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
