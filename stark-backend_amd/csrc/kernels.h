@@ -127,12 +127,16 @@ struct FoldJob {
     EF *out;
     uint32_t n_cols, log_h, y0, pad;
 };
+// d_jobs == nullptr: the jobs (at most FoldJobsArg::MAX) are passed to the kernel as an argument -- no upload
+struct FoldJobsArg {
+    static constexpr uint32_t MAX = 16;
+    FoldJob j[MAX];
+};
 int fold_mle_batched(const FoldJob *d_jobs, const FoldJob *h_jobs, uint32_t n_jobs, EF r, hipStream_t s);
 
 // ---- LogUp GKR ----  (layer format: record x = fractions 2x, 2x+1 = (p0,q0),(p1,q1))
-// heap[2^k + y] = eq(point[n-k .. n), y) for k = 0 .. n-1 (2^n entries, node 1 = 1): the weights of
-// sub-round n-1-k of a layer sumcheck whose eq factor is split off (stages.hip)
-int eq_heap(const EF *d_point, uint32_t n, EFPlanes heap, hipStream_t s);
+// Heap of partial eq tables of one layer: depth k holds eq(point[n-k .. n), y) for the LAST k variables (node 1 = 1):
+// the weights of sub-round n-1-k of a layer sumcheck whose eq factor is split off (stages.hip).
 // Windowed form for a rank that owns an index window of the layer's table (sharded GKR, gkr_shard.h):
 // need[d] = [lo, hi) = the entries of depth d the sub-round sums read. Depths <= top are full tables at
 // heap index 2^d + y; a deeper depth d stores entries [lo[d], lo[d] + cnt[d]) at heap index off[d] + (y - lo[d]).
@@ -151,7 +155,12 @@ struct EqHeapPlan {
     uint64_t at(uint32_t d, uint64_t y) const { return off[d] + (y - lo[d]); }
 };
 EqHeapPlan eq_heap_plan(uint32_t n, const std::vector<std::pair<uint64_t, uint64_t>> &need);
-int eq_heap_run(const EF *d_point, const EqHeapPlan &plan, EFPlanes heap, hipStream_t s);
+// `point`: HOST array of plan.n entries (it travels to the kernels as an argument, plan.n <= EqPoint::MAX)
+struct EqPoint {
+    static constexpr uint32_t MAX = 32;
+    EF x[MAX];
+};
+int eq_heap_run(const EF *point, const EqHeapPlan &plan, EFPlanes heap, hipStream_t s);
 // fractions at arbitrary plane positions, for the host (n <= 32)
 int gkr_read_list(FracPlanes t, const uint64_t *d_pos, const uint32_t *d_pbase, uint32_t n, const RedOut &ro, hipStream_t s);
 // table records for the host: n0 consecutive ones from plane offset at0, then n1 from at1 (n0 + n1 <= 64), read

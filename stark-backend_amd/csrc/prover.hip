@@ -749,7 +749,7 @@ struct Prover {
         std::vector<uint64_t> toff, fb;  // per layer: plane offset of my window, global index of its element 0
         uint64_t tree_stride = 0, wcap = 0;
         DevBuf<uint32_t> tree_buf, rec_a, rec_b, eq_buf;
-        DevBuf<EF> partials, d_point;
+        DevBuf<EF> partials;
         EqHeapPlan hp;
         uint64_t eq_stride = 0;
         std::vector<uint64_t> rbase;  // rbase[sr]: global record index of element 0 of table(sr)'s buffer (sr >= 1)
@@ -843,8 +843,7 @@ struct Prover {
             rbase.assign(round + 1, 0);
             for (unsigned sr = 1; sr <= round; sr++) rbase[sr] = (2 * Rchain[sr + 1].lo) & ~uint64_t(31);
             if (hp.empty) return;
-            d_point = pr.cx.upload(point);  // (through the pinned arena: a pageable source would block the host)
-            OVM_THROW_IF(eq_heap_run(d_point.p, hp, EFPlanes{eq_buf.p, eq_stride}, pr.cx.stream));
+            OVM_THROW_IF(eq_heap_run(point.data(), hp, EFPlanes{eq_buf.p, eq_stride}, pr.cx.stream));
         }
         // planes positioned at record y of table(sr) (sr == 0: the tree layer)
         FracPlanes table_at(unsigned round, unsigned sr, uint64_t y) const {
@@ -1633,8 +1632,12 @@ struct Prover {
                 std::vector<FoldJob> fj;
                 auto flush_folds = [&] {
                     if (fj.empty()) return;
-                    auto d_fj = cx.upload(fj);
-                    OVM_THROW_IF(fold_mle_batched(d_fj.p, fj.data(), (uint32_t)fj.size(), rr, cx.stream));
+                    if (fj.size() <= FoldJobsArg::MAX) {
+                        OVM_THROW_IF(fold_mle_batched(nullptr, fj.data(), (uint32_t)fj.size(), rr, cx.stream));
+                    } else {
+                        auto d_fj = cx.upload(fj);
+                        OVM_THROW_IF(fold_mle_batched(d_fj.p, fj.data(), (uint32_t)fj.size(), rr, cx.stream));
+                    }
                     fj.clear();
                 };
                 for (size_t t = 0; t < T; t++) {
@@ -2138,7 +2141,9 @@ struct Prover {
                     else
                         OVM_THROW_IF(fold_mle(in, o, 4, wd.cur_log_h, ur, cx.stream));
                 }
-                if (!fj.empty()) {
+                if (!fj.empty() && fj.size() <= FoldJobsArg::MAX) {
+                    OVM_THROW_IF(fold_mle_batched(nullptr, fj.data(), (uint32_t)fj.size(), ur, cx.stream));
+                } else if (!fj.empty()) {
                     auto d_fj = cx.upload(fj);
                     OVM_THROW_IF(fold_mle_batched(d_fj.p, fj.data(), (uint32_t)fj.size(), ur, cx.stream));
                 }

@@ -1236,6 +1236,20 @@ __global__ void fold_mle_batched_kernel(const FoldJob *jobs, uint32_t n_jobs, EF
     EF t0 = ld_ef(p), t1 = ld_ef(p + 1);
     st_ef(job.out + (uint64_t)col * h2 + y, t0 + (t1 - t0) * r);
 }
+// up to FoldJobsArg::MAX jobs travel as a kernel argument (no upload in front of every round)
+__global__ void fold_mle_batched_arg_kernel(FoldJobsArg a, uint32_t n_jobs, EF r_in) {
+    uint32_t j = 0;
+    while (j + 1 < n_jobs && blockIdx.y >= a.j[j].y0 + a.j[j].n_cols) j++;
+    const FoldJob job = a.j[j];
+    const EF::Pre r = r_in.pre();
+    const uint64_t h2 = 1ull << (job.log_h - 1);
+    const uint64_t y = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (y >= h2) return;
+    const uint32_t col = blockIdx.y - job.y0;
+    const EF *p = job.in + ((uint64_t)col << job.log_h) + 2 * y;
+    EF t0 = ld_ef(p), t1 = ld_ef(p + 1);
+    st_ef(job.out + (uint64_t)col * h2 + y, t0 + (t1 - t0) * r);
+}
 int fold_mle_batched(const FoldJob *d_jobs, const FoldJob *h_jobs, uint32_t n_jobs, EF r, hipStream_t s) {
     if (n_jobs == 0) return 0;
     uint64_t gx = 1, gy = 0;
@@ -1245,6 +1259,14 @@ int fold_mle_batched(const FoldJob *d_jobs, const FoldJob *h_jobs, uint32_t n_jo
         gy += h_jobs[j].n_cols;
     }
     if (gy > 65535) return (int)hipErrorInvalidValue;
+    if (!d_jobs) {
+        if (n_jobs > FoldJobsArg::MAX) return (int)hipErrorInvalidValue;
+        FoldJobsArg a;
+        for (uint32_t j = 0; j < n_jobs; j++) a.j[j] = h_jobs[j];
+        hipLaunchKernelGGL(fold_mle_batched_arg_kernel, dim3((uint32_t)gx, (uint32_t)gy), dim3(256), 0, s, a, n_jobs, r);
+        OVM_CHECK_LAUNCH();
+        return 0;
+    }
     hipLaunchKernelGGL(fold_mle_batched_kernel, dim3((uint32_t)gx, (uint32_t)gy), dim3(256), 0, s, d_jobs, n_jobs, r);
     OVM_CHECK_LAUNCH();
     return 0;
@@ -1504,63 +1526,21 @@ __device__ __forceinline__ void gkr_pair_sums(EF (&a)[4], const EF (&b)[4], cons
 // is the table over the LAST k variables, low bit = variable n-k: exactly the weights sub-round
 // n-1-k needs, so one build serves every sub-round of the layer.
 static constexpr uint32_t EQ_HEAP_DIRECT_DEPTH = 10;
-__global__ void eq_heap_top_kernel(const EF *point, uint32_t n, uint32_t max_depth, EFPlanes heap) {
+// (the point travels as a kernel argument: no upload, no copy command in front of every layer)
+__global__ void eq_heap_top_kernel(EqPoint pt, uint32_t n, uint32_t max_depth, EFPlanes heap) {
+    __shared__ EF point[EqPoint::MAX];
+    for (uint32_t j = threadIdx.x; j < n; j += blockDim.x) point[j] = pt.x[j];
+    __syncthreads();
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;  // heap node
     if (i == 0 || i >= (2u << max_depth)) return;
     const uint32_t k = 31 - __clz(i), y = i - (1u << k);
     EF acc = EF::one();
     for (uint32_t j = 0; j < k; j++) {
-        EF x = ld_ef(point + (n - k + j));
+        EF x = point[n - k + j];
         acc = acc * ((y >> j & 1) ? x : EF::one() - x);
     }
     stp(heap.p, heap.stride, i, acc);
 }
-__global__ void eq_heap_level_kernel(const EF *point, uint32_t n, uint32_t k, EFPlanes heap) {
-    const uint64_t i = (1ull << k) + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (2ull << k)) return;
-    EF lo = ldp(heap.p, heap.stride, i);
-    EF hi = lo * ld_ef(point + (n - 1 - k));
-    stp2(heap.p, heap.stride, 2 * i, lo - hi, hi);
-}
-// Up to three levels per launch: a lane takes node i of level k and writes its 2 + 4 + 8 descendants
-// (consecutive lanes write consecutive runs in every limb plane). A layer of 2^24 weights is 5 launches
-// instead of 14.
-__global__ void eq_heap_levels_kernel(const EF *point, uint32_t n, uint32_t k, uint32_t levels, EFPlanes heap) {
-    const uint64_t i = (1ull << k) + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (2ull << k)) return;
-    EF cur[8];
-    cur[0] = ldp(heap.p, heap.stride, i);
-#pragma unroll
-    for (int l = 0; l < 3; l++) {
-        if ((uint32_t)l >= levels) break;
-        const EF::Pre x = ld_ef(point + (n - 1 - (k + l))).pre();
-        const int cnt = 1 << l;  // nodes of this lane at level k + l: (i << l) .. + cnt
-#pragma unroll
-        for (int t = cnt - 1; t >= 0; t--) {  // expand in place from the back
-            const EF lo = cur[t], hi = lo * x;
-            cur[2 * t] = lo - hi;
-            cur[2 * t + 1] = hi;
-        }
-        const uint64_t base = i << (l + 1);
-#pragma unroll
-        for (int t = 0; t < cnt; t++) stp2(heap.p, heap.stride, base + 2 * t, cur[2 * t], cur[2 * t + 1]);
-    }
-}
-int eq_heap(const EF *d_point, uint32_t n, EFPlanes heap, hipStream_t s) {
-    if (n == 0) return (int)hipErrorInvalidValue;
-    const uint32_t top = n - 1 < EQ_HEAP_DIRECT_DEPTH ? n - 1 : EQ_HEAP_DIRECT_DEPTH;
-    hipLaunchKernelGGL(eq_heap_top_kernel, dim3(ceil_div(2ull << top, 256)), dim3(256), 0, s, d_point, n, top, heap);
-    OVM_CHECK_LAUNCH();
-    for (uint32_t k = top; k + 1 < n;) {
-        const uint32_t levels = n - 1 - k < 3 ? n - 1 - k : 3;
-        hipLaunchKernelGGL(eq_heap_levels_kernel, dim3(ceil_div(1ull << k, 256)), dim3(256), 0, s, d_point, n, k, levels,
-                           heap);
-        OVM_CHECK_LAUNCH();
-        k += levels;
-    }
-    return 0;
-}
-
 // ---- windowed eq heap (sharded GKR) ----------------------------------------------------------
 // A rank that owns the index window [lo, hi) of a layer's table needs, at depth d of the heap, only
 // the entries of its window at that depth (and the parents they are expanded from). Depths up to
@@ -1620,7 +1600,7 @@ EqHeapPlan eq_heap_plan(uint32_t n, const std::vector<std::pair<uint64_t, uint64
     return pl;
 }
 // lane t expands entry src_lo + t of depth k into its descendants of depths k+1 .. k+levels
-__global__ void eq_heap_levels_win_kernel(const EF *point, uint32_t n, uint32_t k, uint32_t levels, EFPlanes heap,
+__global__ void eq_heap_levels_win_kernel(EqPoint pt, uint32_t n, uint32_t k, uint32_t levels, EFPlanes heap,
                                           uint64_t src_off, uint64_t src_lo, uint64_t src_first, uint64_t count,
                                           uint64_t off1, uint64_t off2, uint64_t off3, uint64_t dst_lo) {
     const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1632,7 +1612,7 @@ __global__ void eq_heap_levels_win_kernel(const EF *point, uint32_t n, uint32_t 
 #pragma unroll
     for (int l = 0; l < 3; l++) {
         if ((uint32_t)l >= levels) break;
-        const EF::Pre x = ld_ef(point + (n - 1 - (k + l))).pre();
+        const EF::Pre x = pt.x[n - 1 - (k + l)].pre();  // (uniform index: scalar loads from the argument segment)
         const int cnt = 1 << l;
 #pragma unroll
         for (int u = cnt - 1; u >= 0; u--) {
@@ -1645,9 +1625,11 @@ __global__ void eq_heap_levels_win_kernel(const EF *point, uint32_t n, uint32_t 
         for (int u = 0; u < cnt; u++) stp2(heap.p, heap.stride, base + 2 * u, cur[2 * u], cur[2 * u + 1]);
     }
 }
-int eq_heap_run(const EF *d_point, const EqHeapPlan &pl, EFPlanes heap, hipStream_t s) {
-    if (pl.n == 0) return (int)hipErrorInvalidValue;
+int eq_heap_run(const EF *point, const EqHeapPlan &pl, EFPlanes heap, hipStream_t s) {
+    if (pl.n == 0 || pl.n > EqPoint::MAX) return (int)hipErrorInvalidValue;
     if (pl.empty) return 0;
+    EqPoint d_point;
+    for (uint32_t j = 0; j < pl.n; j++) d_point.x[j] = point[j];
     hipLaunchKernelGGL(eq_heap_top_kernel, dim3(ceil_div(2ull << pl.top, 256)), dim3(256), 0, s, d_point, pl.n, pl.top, heap);
     OVM_CHECK_LAUNCH();
     for (auto &ln : pl.launches) {

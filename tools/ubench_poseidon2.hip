@@ -66,26 +66,29 @@ int main(int argc, char **argv) {
         if (ms < best) best = ms;
     }
     hipMemcpy(ticks, d_ticks, 16, hipMemcpyDeviceToHost);
+    const double wave_instr_per_simd = (double)blocks * 256 * ITER * VALU_PER_PERM / 64.0 / (p.multiProcessorCount * 4.0);
     const double clock_ghz = ticks[1] ? (double)ticks[0] / (double)ticks[1] * 0.1 : 0.0;
-    // one wave ran ITER permutations while waves_per_simd - 1 others shared its SIMD
-    const double real_cyc = ticks[0] / (waves_per_simd * ITER * (double)VALU_PER_PERM);
+    // shader cycles per wave-level VALU instruction per SIMD over the whole launch, at the clock the loop really had
+    const double real_cyc = best * 1e-3 * clock_ghz * 1e9 / wave_instr_per_simd;
+    // how many waves shared the stamped wave's SIMD: its loop took this many instruction slots
+    // (the occupancy API's answer, `waves_per_simd`, is an upper bound: MI355X_MICROARCH.md, correctness boundaries)
+    const double co_resident = real_cyc > 0 ? ticks[0] / (ITER * (double)VALU_PER_PERM * real_cyc) : 0.0;
     const double perms = (double)blocks * 256 * ITER;
     const double gperm = perms / (best * 1e-3) / 1e9;
-    const double wave_instr_per_simd = perms * VALU_PER_PERM / 64.0 / (p.multiProcessorCount * 4.0);
     const double cyc_nominal = best * 1e-3 * 2.4e9 / wave_instr_per_simd;
     // s_memtime counts at a fixed 100 MHz on gfx9: wall time of one wave's loop, for reference
     printf("poseidon2 mix ceiling: %.3f ms for %.3g permutations -> %.3f Gperm/s; %.2f cycles per wave-level VALU instruction per SIMD at a nominal "
            "2.4 GHz (%d CUs, %d blocks of 256 lanes, %d permutations per lane)\n"
-           "in-kernel clock (s_memtime / s_memrealtime): %.3f GHz; %.0f resident waves per SIMD; %.2f shader cycles per wave-level VALU "
-           "instruction per SIMD\n",
-           best, perms, gperm, cyc_nominal, p.multiProcessorCount, blocks, ITER, clock_ghz, waves_per_simd, real_cyc);
+           "in-kernel clock (s_memtime / s_memrealtime): %.3f GHz -> %.2f shader cycles per wave-level VALU instruction per SIMD; "
+           "the stamped wave shared its SIMD with %.1f waves in all (occupancy API: up to %.0f)\n",
+           best, perms, gperm, cyc_nominal, p.multiProcessorCount, blocks, ITER, clock_ghz, real_cyc, co_resident, waves_per_simd);
     if (argc > 1) {
         FILE *f = fopen(argv[1], "w");
         if (f) {
             fprintf(f, "{\"gperm_per_s\": %.4f, \"ms\": %.4f, \"permutations\": %.0f, \"valu_instr_per_permutation\": %d, "
                        "\"cycles_per_wave_valu_instr_per_simd_at_2.4GHz\": %.3f, \"in_kernel_clock_GHz\": %.3f, \"resident_waves_per_simd\": %.0f, "
                        "\"shader_cycles_per_wave_valu_instr_per_simd\": %.3f, \"compute_units\": %d, \"source\": \"tools/ubench_poseidon2.hip\"}\n",
-                    gperm, best, perms, VALU_PER_PERM, cyc_nominal, clock_ghz, waves_per_simd, real_cyc, p.multiProcessorCount);
+                    gperm, best, perms, VALU_PER_PERM, cyc_nominal, clock_ghz, co_resident, real_cyc, p.multiProcessorCount);
             fclose(f);
         }
     }
