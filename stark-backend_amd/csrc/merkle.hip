@@ -19,6 +19,8 @@
 // Roofline: Poseidon2 is integer-ALU bound (~640 32-bit multiplies per permutation), not HBM
 // bound; one lane hashes one row and the codeword is read exactly once with unit stride across
 // the wavefront.
+#include <cstdlib>
+
 #include "device_ctx.h"
 #include "openvm_hip.h"
 #include "poseidon2.h"
@@ -96,6 +98,25 @@ __global__ __launch_bounds__(HASH_THREADS) void compress_layer_kernel(const Dige
     out[o] = p2::compress(l, r);
 }
 
+// The same with 16 lanes per node (p2::permute_coop): lane i < 8 holds word i of the left digest, lane 8 + i word i
+// of the right one. For layers of at most COOP_MAX_NODES nodes: a one-lane permutation is ~12 us of dependent work
+// whether the launch has one node or 65 536, the cooperative one ~2 us.
+static constexpr uint64_t COOP_MAX_NODES = 1ull << 13;
+__global__ __launch_bounds__(HASH_THREADS) void compress_layer_coop_kernel(const Digest *__restrict__ in,
+                                                                           Digest *__restrict__ out, uint64_t n_out,
+                                                                           uint32_t log_half) {
+    const uint64_t t = (uint64_t)blockIdx.x * HASH_THREADS + threadIdx.x;
+    const uint64_t o0 = t >> 4;
+    const uint32_t lane16 = (uint32_t)(t & 15);
+    const uint64_t o = o0 < n_out ? o0 : n_out - 1;  // (whole rows of 16 lanes stay in step for the DPP moves)
+    const uint64_t q = o & ((1ull << log_half) - 1), g = o >> log_half;
+    const uint64_t left = (g << (log_half + 1)) | q;
+    const Digest *src = lane16 < 8 ? in + left : in + left + (1ull << log_half);
+    Fp x = src->d[lane16 & 7];
+    x = p2::permute_coop(x, lane16);
+    if (o0 < n_out && lane16 < 8) out[o].d[lane16] = x;
+}
+
 // Proof-of-work search: witness w = base + global thread id; keeps the minimum hit.
 __global__ __launch_bounds__(HASH_THREADS) void grind_kernel(p2::Sponge sponge, uint32_t bits,
                                                              uint32_t base, uint32_t count,
@@ -144,6 +165,17 @@ __global__ void gather_digests_kernel(const Digest *__restrict__ layers,
     out[i] = layers[idx[i]];
 }
 
+// (OVM_MERKLE_COOP=0 keeps every layer on the one-lane kernel: the parity tests compare the two)
+static void launch_compress(const Digest *in, Digest *out, uint64_t n_out, uint32_t log_half, hipStream_t stream) {
+    static const bool coop = !(getenv("OVM_MERKLE_COOP") && getenv("OVM_MERKLE_COOP")[0] == '0');
+    if (coop && n_out <= COOP_MAX_NODES)
+        hipLaunchKernelGGL(compress_layer_coop_kernel, dim3(ceil_div(n_out * 16, HASH_THREADS)), dim3(HASH_THREADS), 0, stream, in,
+                           out, n_out, log_half);
+    else
+        hipLaunchKernelGGL(compress_layer_kernel, dim3(ceil_div(n_out, HASH_THREADS)), dim3(HASH_THREADS), 0, stream, in, out,
+                           n_out, log_half);
+}
+
 template <int WORDS>
 static int merkle_tree_impl(const uint32_t *d_matrix, uint64_t width, uint32_t log_rows,
                             uint32_t log_rows_per_query, uint32_t *d_scratch,
@@ -171,8 +203,7 @@ static int merkle_tree_impl(const uint32_t *d_matrix, uint64_t width, uint32_t l
         bool last = (j + 1 == log_rows_per_query);
         Digest *dst = last ? layers : ((cur == leaf) ? pong : leaf);
         uint32_t log_half = log_rows_per_query - 1 - j;
-        hipLaunchKernelGGL(compress_layer_kernel, dim3(ceil_div(n_out, HASH_THREADS)),
-                           dim3(HASH_THREADS), 0, stream, cur, dst, n_out, log_half);
+        launch_compress(cur, dst, n_out, log_half, stream);
         OVM_CHECK_LAUNCH();
         cur = dst;
         n = n_out;
@@ -183,8 +214,7 @@ static int merkle_tree_impl(const uint32_t *d_matrix, uint64_t width, uint32_t l
     while (log_n > 0) {
         uint64_t n_out = 1ull << (log_n - 1);
         Digest *dst = layer + (1ull << log_n);
-        hipLaunchKernelGGL(compress_layer_kernel, dim3(ceil_div(n_out, HASH_THREADS)),
-                           dim3(HASH_THREADS), 0, stream, layer, dst, n_out, log_n - 1);
+        launch_compress(layer, dst, n_out, log_n - 1, stream);
         OVM_CHECK_LAUNCH();
         layer = dst;
         log_n--;

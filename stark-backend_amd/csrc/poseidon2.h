@@ -143,6 +143,82 @@ BB_HD void permute(Fp *s) {
     }
 }
 
+#if defined(__HIPCC__)
+// ---- the permutation by 16 cooperating lanes -----------------------------------------------------
+// One lane per state word (a DPP row of 16; a wave64 carries four permutations). What a single lane
+// does in ~7 200 dependent-ish instructions (12 us when there is nothing else to hide it behind) takes
+// ~1 100 here: the S-boxes of a full round run side by side, the linear layers are a few DPP moves. For
+// the LATENCY-bound uses of the permutation -- the small top layers of a Merkle tree, where a launch
+// has fewer nodes than the chip has SIMDs -- not for the bulk hashing (same arithmetic, more overhead).
+// Internal-layer diagonal as Montgomery constants, one per lane.
+#define P2_INV2K(k) bb::cx_powmod(bb::cx_powmod(2, bb::P - 2), (k))
+static constexpr uint32_t COOP_DIAG_CANON[16] = {
+    bb::P - 2, 1, 2, P2_INV2K(1), 3, 4, bb::P - P2_INV2K(1), bb::P - 3, bb::P - 4, P2_INV2K(8),
+    P2_INV2K(2), P2_INV2K(3), P2_INV2K(27), bb::P - P2_INV2K(8), bb::P - P2_INV2K(4), bb::P - P2_INV2K(27)};
+#undef P2_INV2K
+__device__ static const uint32_t COOP_DIAG[16] = {
+    bb::cx_to_mont(COOP_DIAG_CANON[0]),  bb::cx_to_mont(COOP_DIAG_CANON[1]),  bb::cx_to_mont(COOP_DIAG_CANON[2]),
+    bb::cx_to_mont(COOP_DIAG_CANON[3]),  bb::cx_to_mont(COOP_DIAG_CANON[4]),  bb::cx_to_mont(COOP_DIAG_CANON[5]),
+    bb::cx_to_mont(COOP_DIAG_CANON[6]),  bb::cx_to_mont(COOP_DIAG_CANON[7]),  bb::cx_to_mont(COOP_DIAG_CANON[8]),
+    bb::cx_to_mont(COOP_DIAG_CANON[9]),  bb::cx_to_mont(COOP_DIAG_CANON[10]), bb::cx_to_mont(COOP_DIAG_CANON[11]),
+    bb::cx_to_mont(COOP_DIAG_CANON[12]), bb::cx_to_mont(COOP_DIAG_CANON[13]), bb::cx_to_mont(COOP_DIAG_CANON[14]),
+    bb::cx_to_mont(COOP_DIAG_CANON[15])};
+__device__ static const uint32_t COOP_RC_INITIAL[64] = {
+    RC_INITIAL[0],  RC_INITIAL[1],  RC_INITIAL[2],  RC_INITIAL[3],  RC_INITIAL[4],  RC_INITIAL[5],  RC_INITIAL[6],  RC_INITIAL[7],
+    RC_INITIAL[8],  RC_INITIAL[9],  RC_INITIAL[10], RC_INITIAL[11], RC_INITIAL[12], RC_INITIAL[13], RC_INITIAL[14], RC_INITIAL[15],
+    RC_INITIAL[16], RC_INITIAL[17], RC_INITIAL[18], RC_INITIAL[19], RC_INITIAL[20], RC_INITIAL[21], RC_INITIAL[22], RC_INITIAL[23],
+    RC_INITIAL[24], RC_INITIAL[25], RC_INITIAL[26], RC_INITIAL[27], RC_INITIAL[28], RC_INITIAL[29], RC_INITIAL[30], RC_INITIAL[31],
+    RC_INITIAL[32], RC_INITIAL[33], RC_INITIAL[34], RC_INITIAL[35], RC_INITIAL[36], RC_INITIAL[37], RC_INITIAL[38], RC_INITIAL[39],
+    RC_INITIAL[40], RC_INITIAL[41], RC_INITIAL[42], RC_INITIAL[43], RC_INITIAL[44], RC_INITIAL[45], RC_INITIAL[46], RC_INITIAL[47],
+    RC_INITIAL[48], RC_INITIAL[49], RC_INITIAL[50], RC_INITIAL[51], RC_INITIAL[52], RC_INITIAL[53], RC_INITIAL[54], RC_INITIAL[55],
+    RC_INITIAL[56], RC_INITIAL[57], RC_INITIAL[58], RC_INITIAL[59], RC_INITIAL[60], RC_INITIAL[61], RC_INITIAL[62], RC_INITIAL[63]};
+__device__ static const uint32_t COOP_RC_TERMINAL[64] = {
+    RC_TERMINAL[0],  RC_TERMINAL[1],  RC_TERMINAL[2],  RC_TERMINAL[3],  RC_TERMINAL[4],  RC_TERMINAL[5],  RC_TERMINAL[6],  RC_TERMINAL[7],
+    RC_TERMINAL[8],  RC_TERMINAL[9],  RC_TERMINAL[10], RC_TERMINAL[11], RC_TERMINAL[12], RC_TERMINAL[13], RC_TERMINAL[14], RC_TERMINAL[15],
+    RC_TERMINAL[16], RC_TERMINAL[17], RC_TERMINAL[18], RC_TERMINAL[19], RC_TERMINAL[20], RC_TERMINAL[21], RC_TERMINAL[22], RC_TERMINAL[23],
+    RC_TERMINAL[24], RC_TERMINAL[25], RC_TERMINAL[26], RC_TERMINAL[27], RC_TERMINAL[28], RC_TERMINAL[29], RC_TERMINAL[30], RC_TERMINAL[31],
+    RC_TERMINAL[32], RC_TERMINAL[33], RC_TERMINAL[34], RC_TERMINAL[35], RC_TERMINAL[36], RC_TERMINAL[37], RC_TERMINAL[38], RC_TERMINAL[39],
+    RC_TERMINAL[40], RC_TERMINAL[41], RC_TERMINAL[42], RC_TERMINAL[43], RC_TERMINAL[44], RC_TERMINAL[45], RC_TERMINAL[46], RC_TERMINAL[47],
+    RC_TERMINAL[48], RC_TERMINAL[49], RC_TERMINAL[50], RC_TERMINAL[51], RC_TERMINAL[52], RC_TERMINAL[53], RC_TERMINAL[54], RC_TERMINAL[55],
+    RC_TERMINAL[56], RC_TERMINAL[57], RC_TERMINAL[58], RC_TERMINAL[59], RC_TERMINAL[60], RC_TERMINAL[61], RC_TERMINAL[62], RC_TERMINAL[63]};
+
+template <int CTRL>
+__device__ __forceinline__ Fp dpp(Fp x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return Fp::raw((uint32_t)__builtin_amdgcn_update_dpp(0, (int)x.v, CTRL, 0xF, 0xF, false));
+#else
+    return x;  // (host pass of a device-only function)
+#endif
+}
+// lane q of every quad: 2 x_q + 3 x_{q+1} + x_{q+2} + x_{q+3} (M4 is circulant), then + the sum over the 4 quads
+__device__ __forceinline__ Fp coop_external(Fp x) {
+    const Fp b = dpp<0x39>(x), c = dpp<0x4E>(x), d = dpp<0x93>(x);  // quad_perm [1,2,3,0], [2,3,0,1], [3,0,1,2]
+    const Fp y = ((x + b) + (c + d)) + (x + b.dbl());
+    const Fp t = y + dpp<0x128>(y);          // row_ror:8
+    return y + (t + dpp<0x124>(t));          // row_ror:4
+}
+// x = this lane's state word; lane16 = its index in the state (0..15). Returns the permuted word.
+__device__ __forceinline__ Fp permute_coop(Fp x, uint32_t lane16) {
+    x = coop_external(x);
+#pragma unroll
+    for (int r = 0; r < 4; r++) x = coop_external(sbox7_add(x, COOP_RC_INITIAL[16 * r + lane16]));
+    const Fp diag = Fp::raw(COOP_DIAG[lane16]);
+#pragma unroll
+    for (int r = 0; r < 13; r++) {
+        const Fp sb = sbox7_add(x, RC_INTERNAL[r]);
+        x = lane16 == 0 ? sb : x;
+        Fp t = x + dpp<0x128>(x);
+        t = t + dpp<0x124>(t);
+        t = t + dpp<0x122>(t);
+        t = t + dpp<0x121>(t);  // the sum of all 16 words, in every lane
+        x = t + x * diag;
+    }
+#pragma unroll
+    for (int r = 0; r < 4; r++) x = coop_external(sbox7_add(x, COOP_RC_TERMINAL[16 * r + lane16]));
+    return x;
+}
+#endif
+
 // The transcript's permutations run on the host, one after the other (a duplex sponge is sequential:
 // ~900 per config D proof, ~20 000 when a many-AIR proof absorbs its column openings). On x86 hosts
 // with AVX2 they go through an 8-lane implementation (csrc/host_poseidon2.cpp, 2.2x the scalar code);
