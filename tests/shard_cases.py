@@ -32,6 +32,8 @@ def make(name, world):
         p, a, t = _bench_partitioned(len(lh), 6, lh, airs.test_params(l_skip=2, n_stack=7, k_whir=2), seed=7)
     elif name == "bench_app":  # app-like parameters (l_skip 4, k_whir 4), 2^10 rows x 20 columns per AIR
         p, a, t = _bench_partitioned(world, 20, [10] * world, airs.test_params(l_skip=4, n_stack=8, k_whir=4), seed=3)
+    elif name == "three_airs":  # fewer AIRs than ranks when world = 4: the last rank owns nothing
+        p, a, t = _bench_partitioned(3, 8, [5, 4, 4], airs.test_params(l_skip=2, n_stack=6, k_whir=2), seed=11)
     elif name == "mixture":  # Fibonacci (common main only, public values) + partitioned sender/receiver + plain benchmark AIR
         c_airs, c_traces = airs.cached_fixture_11()
         ftr, fpv = airs.fibonacci_trace(0, 1, 16)

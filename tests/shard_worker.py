@@ -20,6 +20,8 @@ def main():
     ap.add_argument("--shm", required=True)
     ap.add_argument("--out", required=True)
     ap.add_argument("--repeat", type=int, default=1)
+    ap.add_argument("--save-memory", action="store_true",
+                    help="prove in the memory-bounded modes (codeword dropped, round 0 in slabs of 8 rows)")
     args = ap.parse_args()
 
     import torch
@@ -32,6 +34,8 @@ def main():
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(args.port))
     dist.init_process_group("gloo", rank=args.rank, world_size=args.world)
     dev = pkg.Device(0)
+    if args.save_memory:
+        pkg.set_prover_config(cache_rs_code_matrix=False, zerocheck_save_memory=True, round0_slab_log_rows=3)
     shard = pkg.Shard(args.rank, args.world, args.shm)
     if args.case.startswith("gen:"):
         # "gen:<log_rows>:<cols>:<log_stacked_height>": one partitioned BenchmarkAir per rank under app parameters, the

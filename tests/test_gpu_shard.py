@@ -24,12 +24,13 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def run_sharded(case, world, tmp_path, repeat=1):
+def run_sharded(case, world, tmp_path, repeat=1, save_memory=False):
     port, shm, out = _free_port(), f"/ovm-test-{uuid.uuid4().hex[:12]}", str(tmp_path / "proof.bin")
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
     env["OVM_SHARD_TIMEOUT_S"] = "60"  # a rank that died must not hold the others for minutes
     procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "shard_worker.py"), "--rank", str(r), "--world", str(world),
-                               "--port", str(port), "--case", case, "--shm", shm, "--out", out, "--repeat", str(repeat)],
+                               "--port", str(port), "--case", case, "--shm", shm, "--out", out, "--repeat", str(repeat)]
+                              + (["--save-memory"] if save_memory else []),
                               env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
     logs = []
     for p in procs:
@@ -53,7 +54,8 @@ def oracle_proof(orc, case, world):
 
 # (every context with 2 shards; with 4 shards the three that differ in structure: one AIR per rank, mixed
 # heights with two AIRs per rank, and the mixture of plain / cached / public-value AIRs)
-RUNS = [(c, 2) for c in shard_cases.CASES] + [(c, 4) for c in ("bench8", "bench_mixed_heights", "mixture")]
+RUNS = [(c, 2) for c in shard_cases.CASES] + [(c, 4) for c in ("bench8", "bench_mixed_heights", "mixture")] + \
+       [("bench8", 3), ("three_airs", 4)]  # a world that is not a power of two; a rank that owns no trace
 
 
 @pytest.mark.parametrize("case,world", RUNS)
@@ -62,6 +64,13 @@ def test_logical_shards_match_oracle(orc, tmp_path, case, world):
     got = run_sharded(case, world, tmp_path)
     assert got == want
     orc.verify(blob, got)
+
+
+def test_sharded_in_the_memory_bounded_modes(orc, tmp_path):
+    """Codeword dropped on every rank (the remote ranks re-encode when rank 0's queries arrive) and round 0 in
+    slabs: the joint proof does not change."""
+    blob, want = oracle_proof(orc, "bench_app", 2)
+    assert run_sharded("bench_app", 2, tmp_path, save_memory=True) == want
 
 
 def test_single_process_equals_sharded(dev, pkg, orc, tmp_path):
