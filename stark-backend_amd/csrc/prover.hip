@@ -903,14 +903,13 @@ struct Prover {
     // -----------------------------------------------------------------------------------------
     // Stage 2: zerocheck + LogUp (MultiRapProver::prove_rap_constraints)
     // -----------------------------------------------------------------------------------------
-    std::vector<EF> prove_rap_constraints() {
-        std::vector<TracePrograms> progs = programs_future.valid() ? programs_future.get() : compile_all_programs();
+    // Per trace: heights, the column map of its view (selectors, preprocessed, cached mains, common main, each with
+    // its rotated twin when the AIR needs it) -- on every rank -- and, on the owner, the device descriptors.
+    // imeta / total_interactions: the interaction layout's input (one entry per trace).
+    std::vector<TraceView> build_trace_views(uint64_t &total_interactions, std::vector<std::pair<size_t, unsigned>> &imeta) {
         const unsigned l_skip = P().l_skip;
-        const size_t N = size_t(1) << l_skip, T = traces.size();
-        const unsigned cdeg_global = P().max_constraint_degree;
+        const size_t T = traces.size();
         std::vector<TraceView> tv(T);
-        uint64_t total_interactions = 0;
-        std::vector<std::pair<size_t, unsigned>> imeta;
         for (size_t t = 0; t < T; t++) {
             TraceView &v = tv[t];
             v.log_height = log2_strict(traces[t].height);
@@ -961,6 +960,180 @@ struct Prover {
             v.cols = cx.upload(cd);
             v.twins = cx.upload(twin);
         }
+        return tv;
+    }
+
+    // LogUp-GKR (prover/logup_zerocheck/fractional_sumcheck_gkr.rs:60-213): this rank's leaves on its device, the
+    // tree over them, the layer sumchecks through the driver of gkr_shard.h (padding and cross-rank records on the host).
+    GkrOutput prove_gkr(const std::vector<TraceView> &tv, std::vector<TracePrograms> &progs, const Layout &ilayout, unsigned TR,
+                        EF alpha, const std::vector<EF> &beta_pows) {
+        const size_t T = traces.size();
+        const uint64_t n_leaves = uint64_t(1) << TR;
+        // The interaction slices are packed from row 0 with no gaps (descending powers of two) in sorted
+        // trace order, so the leaves of a rank (a block of consecutive traces) are one run; what is left
+        // above the last slice is padding.
+        uint64_t used_leaves = 0;
+        std::vector<URange> rank_leaves(sh.world);
+        for (size_t t = 0; t < T; t++)
+            for (size_t k = 0; k < air(t).interactions.size(); k++) {
+                const Slice &sl = ilayout.cols[ilayout.mat_starts[t] + k].slice;
+                const uint64_t lo = sl.row_idx, hi = sl.row_idx + (uint64_t(1) << sl.log_height);
+                used_leaves = std::max(used_leaves, hi);
+                URange &r = rank_leaves[owner[t]];
+                r = r.empty() ? URange{lo, hi} : URange{std::min(r.lo, lo), std::max(r.hi, hi)};
+            }
+        if (used_leaves > n_leaves) throw OvmFail(1, "internal: interaction layout exceeds the tree");
+        const GkrPlan plan(TR, rank_leaves, used_leaves);
+        // big trees: only limb 0 of the leaf numerators exists (small ones are read through generic paths)
+        const bool p_base = TR >= 12;
+        GkrDevice gd(*this, plan, p_base);
+        ProfScope *ps_leaves = new ProfScope("gkr.leaves", cx.stream);
+        gd.clear_leaf_numerators();
+        struct LeafKeep {
+            ProgDev pd;
+            DevBuf<EF> lc;
+            DevBuf<uint64_t> lb;
+            DevBuf<uint32_t> ll;
+        };
+        std::vector<LeafKeep> leaf_keep;
+        std::vector<LeavesJob> leaf_jobs;
+        for (size_t t = 0; t < T; t++) {
+            const AirKey &a = air(t);
+            if (a.interactions.empty() || !mine(t)) continue;
+            std::vector<EF> leaf_const;
+            std::vector<uint64_t> leaf_base;
+            std::vector<uint32_t> leaf_log_len;
+            for (size_t k = 0; k < a.interactions.size(); k++) {
+                const Interaction &it = a.interactions[k];
+                leaf_const.push_back(beta_pows[it.message.size()] * fp((uint64_t)it.bus_index + 1) + alpha);
+                const Slice &s = ilayout.cols[ilayout.mat_starts[t] + k].slice;
+                leaf_base.push_back(s.row_idx - gd.leaf_origin());  // (relative to this rank's leaf window)
+                leaf_log_len.push_back(s.log_height);
+            }
+            auto d_lc = cx.upload(leaf_const);
+            auto d_lb = cx.upload(leaf_base);
+            auto d_ll = cx.upload(leaf_log_len);
+            Fp norm = fp(uint64_t(1) << (tv[t].log_lifted - tv[t].log_height)).inv();
+            // staged for one row per lane (log_lifted 0 selects that plan)
+            ProgDev pd = make_prog(std::move(progs[t].leaves), beta_pows, true, 0, 1);
+            if (pd.staged.blocks && tv[t].log_height < 20) {
+                // small traces: one launch for all of them after the loop (the buffers stay alive till then)
+                LeavesJob j{};
+                j.prog = pd.staged, j.leaf_const = d_lc.p, j.cols = tv[t].cols.p, j.leaf_base = d_lb.p;
+                j.leaf_log_len = d_ll.p, j.norm = norm, j.log_height = tv[t].log_height;
+                j.gx = (uint32_t)ceil_div(1ull << tv[t].log_height, 256);
+                j.wg0 = leaf_jobs.empty() ? 0 : leaf_jobs.back().wg0 + leaf_jobs.back().gx;
+                leaf_jobs.push_back(j);
+                leaf_keep.push_back(LeafKeep{std::move(pd), std::move(d_lc), std::move(d_lb), std::move(d_ll)});
+            } else {
+                OVM_THROW_IF(gkr_eval_leaves(pd.dev(), pd.staged, d_lc.p, tv[t].cols.p, tv[t].log_height, d_lb.p, d_ll.p,
+                                             norm, gd.leaves(), cx.stream));
+            }
+            // no synchronisation: the temporaries go back to the block cache and are only ever reused
+            // by later work on this same stream
+        }
+        if (!leaf_jobs.empty()) {
+            auto d_jobs = cx.upload(leaf_jobs);
+            OVM_THROW_IF(gkr_eval_leaves_batched(d_jobs.p, leaf_jobs.data(), (uint32_t)leaf_jobs.size(), gd.leaves(), cx.stream));
+        }
+        leaf_keep.clear();
+        delete ps_leaves;
+        {
+            OVM_PROF("gkr.build_tree", cx.stream);
+            wt.mark("rap.gkr.leaves");
+            gd.build();
+        }
+        wt.mark("rap.gkr.build");
+        OVM_PROF("gkr.layer_sumchecks", cx.stream);
+        GkrSharded drv(plan, sh, gd, alpha);
+        drv.force_three_points = force_three_points;
+        drv.observe = [this](const EF &e) { ts.observe_ext(e); };
+        drv.sample = [this]() { return ts.sample_ext(); };
+        return drv.run();
+    }
+
+    // The univariate round of the batch sumcheck, host algebra on a few dozen extension-field elements
+    // (reference: cpu-backend/src/logup_zerocheck/mod.rs:1468-1563): sp0[2t], sp0[2t+1] = the LogUp numerator /
+    // denominator polynomials of trace t, sp0[2T + t] its zerocheck quotient part. Observes the per-trace sum
+    // claims, samples mu, observes the coefficients of s_0.
+    struct S0 {
+        std::vector<EF> numer_terms, denom_terms, mu_pows, s0;
+    };
+    S0 assemble_s0(const std::vector<std::vector<EF>> &sp0, const std::vector<EF> &xi) {
+        const unsigned l_skip = P().l_skip, cdeg_global = P().max_constraint_degree;
+        const size_t N = size_t(1) << l_skip, T = traces.size();
+        const unsigned sp0_deg = cdeg_global * (unsigned)(N - 1), s_deg = cdeg_global + 1, s0_deg = s_deg * (unsigned)(N - 1);
+        const size_t large = size_t(1) << log2_ceil(s0_deg + 1);
+        // product with the degree-(N-1) eq polynomial. The reference multiplies on a domain of size
+        // `large` (no wrap-around: deg <= s0_deg < large), i.e. a plain polynomial product; with tens of
+        // AIRs the N-term schoolbook product is much cheaper on the host than two size-`large` DFTs.
+        auto mul_by = [&](const std::vector<EF> &a, const std::vector<EF> &eq_coeffs) {
+            std::vector<EF> out(large, EF::zero());
+            for (size_t j = 0; j < eq_coeffs.size(); j++) {
+                if (is_zero(eq_coeffs[j])) continue;
+                const EF::Pre e = eq_coeffs[j].pre();
+                for (size_t i = 0; i < a.size() && i + j < large; i++) out[i + j] += a[i] * e;
+            }
+            return out;
+        };
+        std::vector<std::vector<EF>> s0_logup(2 * T);
+        {
+            std::vector<EF> eqc = small_dft(eq_hypercube(std::vector<EF>(xi.begin(), xi.begin() + l_skip)), true);
+            for (size_t i = 0; i < 2 * T; i++) {
+                std::vector<EF> c(sp0[i].begin(), sp0[i].begin() + std::min(sp0[i].size(), (size_t)sp0_deg + 1));
+                s0_logup[i] = mul_by(c, eqc);
+            }
+        }
+        std::vector<EF> numer_terms, denom_terms;
+        for (size_t t = 0; t < T; t++) {
+            EF sums[2];
+            for (int dnm = 0; dnm < 2; dnm++) {
+                EF s = EF::zero();
+                for (size_t j = 0; j <= s0_deg; j += N) s += s0_logup[2 * t + dnm][j];
+                sums[dnm] = s * fp(N);
+            }
+            ts.observe_ext(sums[0]);
+            ts.observe_ext(sums[1]);
+            numer_terms.push_back(sums[0]);
+            denom_terms.push_back(sums[1]);
+        }
+        EF mu = ts.sample_ext();
+        std::vector<EF> mu_pows = powers_of(mu, 3 * T);
+        std::vector<EF> s0_zc;
+        {
+            Fp n_inv = Fp::one().halve().pow(l_skip);
+            std::vector<EF> eqc(N);
+            EF xp = xi[0];
+            for (size_t i = 0; i < N; i++) {
+                eqc[i] = xp * n_inv;
+                xp = xp * xi[0];
+            }
+            std::reverse(eqc.begin(), eqc.end());
+            eqc[0] = ef(n_inv);
+            std::vector<EF> c(sp0_deg + 1, EF::zero());
+            for (size_t j = 0; j <= sp0_deg; j++)
+                for (size_t t = 0; t < T; t++)
+                    if (j < sp0[2 * T + t].size()) c[j] += mu_pows[2 * T + t] * sp0[2 * T + t][j];
+            s0_zc = mul_by(c, eqc);
+        }
+        std::vector<EF> s0(s0_deg + 1);
+        for (size_t j = 0; j <= s0_deg; j++) {
+            EF c = s0_zc[j];
+            for (size_t i = 0; i < 2 * T; i++) c += mu_pows[i] * s0_logup[i][j];
+            ts.observe_ext(c);
+            s0[j] = c;
+        }
+        return S0{std::move(numer_terms), std::move(denom_terms), std::move(mu_pows), std::move(s0)};
+    }
+
+    std::vector<EF> prove_rap_constraints() {
+        std::vector<TracePrograms> progs = programs_future.valid() ? programs_future.get() : compile_all_programs();
+        const unsigned l_skip = P().l_skip;
+        const size_t N = size_t(1) << l_skip, T = traces.size();
+        const unsigned cdeg_global = P().max_constraint_degree;
+        uint64_t total_interactions = 0;
+        std::vector<std::pair<size_t, unsigned>> imeta;
+        std::vector<TraceView> tv = build_trace_views(total_interactions, imeta);
         const unsigned n_max = tv[0].n_lift;
         unsigned n_logup = 0;
         if (total_interactions) n_logup = (64 - (unsigned)__builtin_clzll(total_interactions)) - l_skip;
@@ -975,100 +1148,14 @@ struct Prover {
         for (auto &a : pk.airs) max_constraints = std::max(max_constraints, a.constraint_idx.size());
         std::vector<EF> beta_pows = powers_of(beta, max_msg + 1);
 
-        // ---- GKR ---- (gkr_shard.h drives it: this rank's leaf run on the device, padding in closed form)
-        std::vector<EF> xi;
-        EF q0_claim = EF::one();
-        std::vector<std::array<EF, 4>> claims;               // p0,p1,q0,q1 per layer
-        std::vector<std::vector<std::array<EF, 3>>> gkr_polys;
+        // ---- GKR ----
         const unsigned TR = l_skip + n_logup;
-        if (!ilayout.cols.empty()) {
-            const uint64_t n_leaves = uint64_t(1) << TR;
-            // The interaction slices are packed from row 0 with no gaps (descending powers of two) in sorted
-            // trace order, so the leaves of a rank (a block of consecutive traces) are one run; what is left
-            // above the last slice is padding.
-            uint64_t used_leaves = 0;
-            std::vector<URange> rank_leaves(sh.world);
-            for (size_t t = 0; t < T; t++)
-                for (size_t k = 0; k < air(t).interactions.size(); k++) {
-                    const Slice &sl = ilayout.cols[ilayout.mat_starts[t] + k].slice;
-                    const uint64_t lo = sl.row_idx, hi = sl.row_idx + (uint64_t(1) << sl.log_height);
-                    used_leaves = std::max(used_leaves, hi);
-                    URange &r = rank_leaves[owner[t]];
-                    r = r.empty() ? URange{lo, hi} : URange{std::min(r.lo, lo), std::max(r.hi, hi)};
-                }
-            if (used_leaves > n_leaves) throw OvmFail(1, "internal: interaction layout exceeds the tree");
-            const GkrPlan plan(TR, rank_leaves, used_leaves);
-            // big trees: only limb 0 of the leaf numerators exists (small ones are read through generic paths)
-            const bool p_base = TR >= 12;
-            GkrDevice gd(*this, plan, p_base);
-            ProfScope *ps_leaves = new ProfScope("gkr.leaves", cx.stream);
-            gd.clear_leaf_numerators();
-            struct LeafKeep {
-                ProgDev pd;
-                DevBuf<EF> lc;
-                DevBuf<uint64_t> lb;
-                DevBuf<uint32_t> ll;
-            };
-            std::vector<LeafKeep> leaf_keep;
-            std::vector<LeavesJob> leaf_jobs;
-            for (size_t t = 0; t < T; t++) {
-                const AirKey &a = air(t);
-                if (a.interactions.empty() || !mine(t)) continue;
-                std::vector<EF> leaf_const;
-                std::vector<uint64_t> leaf_base;
-                std::vector<uint32_t> leaf_log_len;
-                for (size_t k = 0; k < a.interactions.size(); k++) {
-                    const Interaction &it = a.interactions[k];
-                    leaf_const.push_back(beta_pows[it.message.size()] * fp((uint64_t)it.bus_index + 1) + alpha);
-                    const Slice &s = ilayout.cols[ilayout.mat_starts[t] + k].slice;
-                    leaf_base.push_back(s.row_idx - gd.leaf_origin());  // (relative to this rank's leaf window)
-                    leaf_log_len.push_back(s.log_height);
-                }
-                auto d_lc = cx.upload(leaf_const);
-                auto d_lb = cx.upload(leaf_base);
-                auto d_ll = cx.upload(leaf_log_len);
-                Fp norm = fp(uint64_t(1) << (tv[t].log_lifted - tv[t].log_height)).inv();
-                // staged for one row per lane (log_lifted 0 selects that plan)
-                ProgDev pd = make_prog(std::move(progs[t].leaves), beta_pows, true, 0, 1);
-                if (pd.staged.blocks && tv[t].log_height < 20) {
-                    // small traces: one launch for all of them after the loop (the buffers stay alive till then)
-                    LeavesJob j{};
-                    j.prog = pd.staged, j.leaf_const = d_lc.p, j.cols = tv[t].cols.p, j.leaf_base = d_lb.p;
-                    j.leaf_log_len = d_ll.p, j.norm = norm, j.log_height = tv[t].log_height;
-                    j.gx = (uint32_t)ceil_div(1ull << tv[t].log_height, 256);
-                    j.wg0 = leaf_jobs.empty() ? 0 : leaf_jobs.back().wg0 + leaf_jobs.back().gx;
-                    leaf_jobs.push_back(j);
-                    leaf_keep.push_back(LeafKeep{std::move(pd), std::move(d_lc), std::move(d_lb), std::move(d_ll)});
-                } else {
-                    OVM_THROW_IF(gkr_eval_leaves(pd.dev(), pd.staged, d_lc.p, tv[t].cols.p, tv[t].log_height, d_lb.p, d_ll.p,
-                                                 norm, gd.leaves(), cx.stream));
-                }
-                // no synchronisation: the temporaries go back to the block cache and are only ever reused
-                // by later work on this same stream
-            }
-            if (!leaf_jobs.empty()) {
-                auto d_jobs = cx.upload(leaf_jobs);
-                OVM_THROW_IF(gkr_eval_leaves_batched(d_jobs.p, leaf_jobs.data(), (uint32_t)leaf_jobs.size(), gd.leaves(), cx.stream));
-            }
-            leaf_keep.clear();
-            delete ps_leaves;
-            {
-                OVM_PROF("gkr.build_tree", cx.stream);
-                wt.mark("rap.gkr.leaves");
-                gd.build();
-            }
-            wt.mark("rap.gkr.build");
-            OVM_PROF("gkr.layer_sumchecks", cx.stream);
-            GkrSharded drv(plan, sh, gd, alpha);
-            drv.force_three_points = force_three_points;
-            drv.observe = [this](const EF &e) { ts.observe_ext(e); };
-            drv.sample = [this]() { return ts.sample_ext(); };
-            GkrOutput go = drv.run();
-            q0_claim = go.q0_claim;
-            claims = std::move(go.claims);
-            gkr_polys = std::move(go.polys);
-            xi = std::move(go.xi);
-        }
+        GkrOutput gk;
+        if (!ilayout.cols.empty()) gk = prove_gkr(tv, progs, ilayout, TR, alpha, beta_pows);
+        std::vector<EF> xi = std::move(gk.xi);
+        const EF q0_claim = gk.q0_claim;
+        const std::vector<std::array<EF, 4>> &claims = gk.claims;               // p0,p1,q0,q1 per layer
+        const std::vector<std::vector<std::array<EF, 3>>> &gkr_polys = gk.polys;
         wt.mark("rap.gkr");
         const unsigned n_global = std::max(n_max, n_logup);
         while (xi.size() != l_skip + n_global) xi.push_back(ts.sample_ext());
@@ -1369,68 +1456,10 @@ struct Prover {
         // (sharded: the coefficient vectors of a trace come from its owner)
         share_vectors(sp0, [&](size_t i) { return owner[i < 2 * T ? i / 2 : i - 2 * T]; });
         wt.mark("rap.round0");
-        // ---- s_0 assembly (host; a few dozen extension-field elements) ----
-        const unsigned sp0_deg = cdeg_global * (unsigned)(N - 1), s_deg = cdeg_global + 1, s0_deg = s_deg * (unsigned)(N - 1);
-        const size_t large = size_t(1) << log2_ceil(s0_deg + 1);
-        // product with the degree-(N-1) eq polynomial. The reference multiplies on a domain of size
-        // `large` (no wrap-around: deg <= s0_deg < large), i.e. a plain polynomial product; with tens of
-        // AIRs the N-term schoolbook product is much cheaper on the host than two size-`large` DFTs.
-        auto mul_by = [&](const std::vector<EF> &a, const std::vector<EF> &eq_coeffs) {
-            std::vector<EF> out(large, EF::zero());
-            for (size_t j = 0; j < eq_coeffs.size(); j++) {
-                if (is_zero(eq_coeffs[j])) continue;
-                const EF::Pre e = eq_coeffs[j].pre();
-                for (size_t i = 0; i < a.size() && i + j < large; i++) out[i + j] += a[i] * e;
-            }
-            return out;
-        };
-        std::vector<std::vector<EF>> s0_logup(2 * T);
-        {
-            std::vector<EF> eqc = small_dft(eq_hypercube(std::vector<EF>(xi.begin(), xi.begin() + l_skip)), true);
-            for (size_t i = 0; i < 2 * T; i++) {
-                std::vector<EF> c(sp0[i].begin(), sp0[i].begin() + std::min(sp0[i].size(), (size_t)sp0_deg + 1));
-                s0_logup[i] = mul_by(c, eqc);
-            }
-        }
-        std::vector<EF> numer_terms, denom_terms;
-        for (size_t t = 0; t < T; t++) {
-            EF sums[2];
-            for (int dnm = 0; dnm < 2; dnm++) {
-                EF s = EF::zero();
-                for (size_t j = 0; j <= s0_deg; j += N) s += s0_logup[2 * t + dnm][j];
-                sums[dnm] = s * fp(N);
-            }
-            ts.observe_ext(sums[0]);
-            ts.observe_ext(sums[1]);
-            numer_terms.push_back(sums[0]);
-            denom_terms.push_back(sums[1]);
-        }
-        EF mu = ts.sample_ext();
-        std::vector<EF> mu_pows = powers_of(mu, 3 * T);
-        std::vector<EF> s0_zc;
-        {
-            Fp n_inv = Fp::one().halve().pow(l_skip);
-            std::vector<EF> eqc(N);
-            EF xp = xi[0];
-            for (size_t i = 0; i < N; i++) {
-                eqc[i] = xp * n_inv;
-                xp = xp * xi[0];
-            }
-            std::reverse(eqc.begin(), eqc.end());
-            eqc[0] = ef(n_inv);
-            std::vector<EF> c(sp0_deg + 1, EF::zero());
-            for (size_t j = 0; j <= sp0_deg; j++)
-                for (size_t t = 0; t < T; t++)
-                    if (j < sp0[2 * T + t].size()) c[j] += mu_pows[2 * T + t] * sp0[2 * T + t][j];
-            s0_zc = mul_by(c, eqc);
-        }
-        std::vector<EF> s0(s0_deg + 1);
-        for (size_t j = 0; j <= s0_deg; j++) {
-            EF c = s0_zc[j];
-            for (size_t i = 0; i < 2 * T; i++) c += mu_pows[i] * s0_logup[i][j];
-            ts.observe_ext(c);
-            s0[j] = c;
-        }
+        // ---- s_0 assembly (host) ----
+        const unsigned s_deg = cdeg_global + 1;
+        S0 s0r = assemble_s0(sp0, xi);
+        const std::vector<EF> &numer_terms = s0r.numer_terms, &denom_terms = s0r.denom_terms, &mu_pows = s0r.mu_pows, &s0 = s0r.s0;
         std::vector<EF> r;
         EF r0 = ts.sample_ext();
         r.push_back(r0);
@@ -1825,19 +1854,31 @@ struct Prover {
         digs = cx.download(d_dig.p, didx.size());
     }
 
-    // `common_main`: the common-main PCS data (sharded: on rank 0 only, null elsewhere); its root is known everywhere.
+    // OpeningProver::prove_openings = the stacked opening reduction, then WHIR (the reference has the same two
+    // steps: prove_stacked_opening_reduction, prover/stacked_reduction.rs:65-128, and prove_whir_opening,
+    // prover/whir.rs:78-341). `common_main`: the common-main PCS data (sharded: on rank 0 only, null elsewhere);
+    // its root is known everywhere.
     void prove_openings(const PcsData *common_main, const p2::Digest &common_root, const std::vector<EF> &r) {
+        const std::vector<CommitRef> commits = gather_commits(common_main, common_root);
+        // the stacked matrices of all commitments side by side: commitment c owns columns [coff[c], coff[c+1])
+        std::vector<size_t> coff{0};
+        for (auto &c : commits) coff.push_back(coff.back() + c.layout.width);
+        const std::vector<EF> u = prove_stacked_reduction(commits, coff, r);
+        wt.mark("openings.stacked");
+        prove_whir(commits, coff, u);
+    }
+
+    // Returns the sumcheck point u (u[0] for the univariate round, then one entry per stacked round).
+    std::vector<EF> prove_stacked_reduction(const std::vector<CommitRef> &commits, const std::vector<size_t> &coff_in,
+                                            const std::vector<EF> &r) {
         const unsigned l_skip = P().l_skip, n_stack = P().n_stack;
         const size_t N = size_t(1) << l_skip, H = size_t(1) << (l_skip + n_stack);
-        const std::vector<CommitRef> commits = gather_commits(common_main, common_root);
-        const bool root_rank = sh.rank == 0;
         auto own = [&](size_t com) { return commits[com].owner == sh.rank; };
-        // the stacked matrices of all commitments side by side: commitment c owns columns [coff[c], coff[c+1]);
         // this rank holds the columns of ITS commitments, side by side, at [loff[c], loff[c] + width_c)
-        std::vector<size_t> coff{0}, loff(commits.size(), 0);
+        const std::vector<size_t> &coff = coff_in;
+        std::vector<size_t> loff(commits.size(), 0);
         size_t lwidth = 0;
         for (size_t com = 0; com < commits.size(); com++) {
-            coff.push_back(coff.back() + commits[com].layout.width);
             if (own(com)) {
                 loff[com] = lwidth;
                 lwidth += commits[com].layout.width;
@@ -2196,9 +2237,17 @@ struct Prover {
         for (size_t com = 0; com < commits.size(); com++)
             w.e_slice(std::vector<EF>(stacking_openings.begin() + coff[com], stacking_openings.begin() + coff[com + 1]));
         section_offsets.push_back(w.buf.size());
+        return u;
+    }
 
-        wt.mark("openings.stacked");
-        // ---------------- WHIR ----------------
+    // WHIR over the mu-batch of every commitment's columns. Sharded: every rank batches ITS columns, the vectors
+    // are all-gathered and summed, rank 0 runs the protocol and collects the rows the first round opens.
+    void prove_whir(const std::vector<CommitRef> &commits, const std::vector<size_t> &coff, const std::vector<EF> &u) {
+        const unsigned l_skip = P().l_skip, n_stack = P().n_stack;
+        const bool root_rank = sh.rank == 0;
+        auto own = [&](size_t com) { return commits[com].owner == sh.rank; };
+        const size_t width = coff.back();
+        ByteWriter &w = out;
         std::vector<EF> u_cube;
         {
             EF cur = u[0];
