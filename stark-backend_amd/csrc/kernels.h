@@ -134,6 +134,11 @@ struct FoldJobsArg {
 };
 int fold_mle_batched(const FoldJob *d_jobs, const FoldJob *h_jobs, uint32_t n_jobs, EF r, hipStream_t s);
 
+// merkle.hip: one rank's share of a Merkle tree that dist_n ranks build together (see there)
+int merkle_tree_share(const uint32_t *d_matrix, uint64_t width, uint32_t log_rows_share, uint32_t log_rows_per_query,
+                      uint32_t *d_scratch, uint32_t *d_digest_layers, hipStream_t stream, bool ext, uint32_t dist_n,
+                      uint32_t dist_r);
+
 // ---- LogUp GKR ----  (layer format: record x = fractions 2x, 2x+1 = (p0,q0),(p1,q1))
 // Heap of partial eq tables of one layer: depth k holds eq(point[n-k .. n), y) for the LAST k variables (node 1 = 1):
 // the weights of sub-round n-1-k of a layer sumcheck whose eq factor is split off (stages.hip).

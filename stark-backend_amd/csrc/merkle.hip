@@ -33,15 +33,25 @@ namespace ovm {
 
 static constexpr int HASH_THREADS = 256;
 
+// Which rows of the matrix a launch hashes: all of them (n = 1), or -- one rank's share of a tree that n ranks
+// build together (prover.hip: build_tree) -- the query groups g with g mod n == r, compacted: output row
+// (c << log_group) | t is matrix row (((c * n + r) << log_group) | t).
+struct RowMap {
+    uint32_t n = 1, r = 0, log_group = 0;
+};
+
 // One lane = one row. `words_per_elem` is 1 for base-field matrices and 4 for extension-field
 // matrices (stored as [u32;4] per entry); the row is absorbed coefficient-wise.
 template <int WORDS>
 __global__ __launch_bounds__(HASH_THREADS) void hash_rows_kernel(const Fp *__restrict__ mat,
                                                                  uint64_t width, uint64_t rows,
                                                                  uint64_t col_stride,
-                                                                 Digest *__restrict__ out) {
-    uint64_t row = (uint64_t)blockIdx.x * HASH_THREADS + threadIdx.x;
-    if (row >= rows) return;
+                                                                 Digest *__restrict__ out, RowMap map) {
+    const uint64_t out_row = (uint64_t)blockIdx.x * HASH_THREADS + threadIdx.x;
+    if (out_row >= rows) return;
+    // (a rank of a distributed tree hashes every dist_n-th query group: map.n == 1 is the identity)
+    const uint64_t row = map.n == 1 ? out_row
+                                    : ((((out_row >> map.log_group) * map.n + map.r) << map.log_group) | (out_row & ((1ull << map.log_group) - 1)));
     Fp s[16];
 #pragma unroll
     for (int i = 0; i < 16; i++) s[i] = Fp::zero();
@@ -81,7 +91,7 @@ __global__ __launch_bounds__(HASH_THREADS) void hash_rows_kernel(const Fp *__res
     Digest d;
 #pragma unroll
     for (int i = 0; i < 8; i++) d.d[i] = s[i];
-    out[row] = d;
+    out[out_row] = d;
 }
 
 // out[g*half + q] = compress(in[g*2*half + q], in[g*2*half + q + half]),  q < half
@@ -176,12 +186,14 @@ static void launch_compress(const Digest *in, Digest *out, uint64_t n_out, uint3
                            n_out, log_half);
 }
 
+// log_rows: rows THIS launch hashes (= all rows of the matrix / map.n); the matrix's columns are rows * map.n apart
 template <int WORDS>
 static int merkle_tree_impl(const uint32_t *d_matrix, uint64_t width, uint32_t log_rows,
                             uint32_t log_rows_per_query, uint32_t *d_scratch,
-                            uint32_t *d_digest_layers, hipStream_t stream) {
+                            uint32_t *d_digest_layers, hipStream_t stream, RowMap map = RowMap()) {
     if (log_rows_per_query > log_rows || log_rows > 30) return (int)hipErrorInvalidValue;
     const uint64_t rows = 1ull << log_rows;
+    map.log_group = log_rows_per_query;
     Digest *leaf = (Digest *)d_scratch;          // rows digests
     Digest *pong = leaf + rows;                  // rows/2 digests (only if k >= 2)
     Digest *layers = (Digest *)d_digest_layers;  // 2*query_stride - 1 digests
@@ -190,8 +202,8 @@ static int merkle_tree_impl(const uint32_t *d_matrix, uint64_t width, uint32_t l
         // kept apart so that "merkle.hash_rows" stays the wide codeword hash the roofline is quoted on)
         OVM_PROF(WORDS != 1 ? "merkle.hash_rows_ext" : width <= 8 ? "merkle.hash_rows_narrow" : "merkle.hash_rows", stream);
         hipLaunchKernelGGL(hash_rows_kernel<WORDS>, dim3(ceil_div(rows, HASH_THREADS)),
-                           dim3(HASH_THREADS), 0, stream, (const Fp *)d_matrix, width, rows, rows,
-                           log_rows_per_query == 0 ? layers : leaf);
+                           dim3(HASH_THREADS), 0, stream, (const Fp *)d_matrix, width, rows, rows * map.n,
+                           log_rows_per_query == 0 ? layers : leaf, map);
         OVM_CHECK_LAUNCH();
     }
     OVM_PROF("merkle.compress_layers", stream);
@@ -220,6 +232,23 @@ static int merkle_tree_impl(const uint32_t *d_matrix, uint64_t width, uint32_t l
         log_n--;
     }
     return 0;
+}
+
+
+
+// One rank's share of a tree that dist_n ranks (a power of two) build together: the query groups g with
+// g mod dist_n == dist_r of a matrix of 2^(log_rows_share) * dist_n rows, as a tree of its own (the same buffers as
+// ovm_hip_merkle_tree for 2^log_rows_share rows). Its last digest is the root of the subtree whose leaves those
+// groups are -- entry dist_r of the full tree's layer of dist_n entries (physical order; see the header comment).
+int merkle_tree_share(const uint32_t *d_matrix, uint64_t width, uint32_t log_rows_share, uint32_t log_rows_per_query,
+                      uint32_t *d_scratch, uint32_t *d_digest_layers, hipStream_t stream, bool ext, uint32_t dist_n,
+                      uint32_t dist_r) {
+    if (dist_n == 0 || (dist_n & (dist_n - 1)) || dist_r >= dist_n) return (int)hipErrorInvalidValue;
+    RowMap map;
+    map.n = dist_n;
+    map.r = dist_r;
+    if (ext) return merkle_tree_impl<4>(d_matrix, width, log_rows_share, log_rows_per_query, d_scratch, d_digest_layers, stream, map);
+    return merkle_tree_impl<1>(d_matrix, width, log_rows_share, log_rows_per_query, d_scratch, d_digest_layers, stream, map);
 }
 
 }  // namespace ovm

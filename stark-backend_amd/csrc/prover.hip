@@ -395,6 +395,12 @@ struct PcsData {
     DevBuf<Fp> own_mat;  // backing store when the commitment owns the trace (preprocessed, from the key blob)
     DevBuf<p2::Digest> layers;
     p2::Digest root;
+    // A tree built by dist_n ranks together (sharded proving: the common-main commitment): `layers` is THIS rank's
+    // share -- the tree over the query groups g with g mod dist_n == dist_r, compacted -- and `top` (host) the
+    // layers of dist_n, dist_n / 2, ..., 1 entries above the shares' roots, identical on every rank.
+    uint32_t dist_n = 1, dist_r = 0;
+    bool dist_member = true;  // false: this rank holds no share (ranks beyond the largest power of two)
+    std::vector<p2::Digest> top;
     size_t query_stride() const { return size_t(1) << (log_rows - k); }
 };
 
@@ -474,7 +480,7 @@ struct Prover {
         return commit_mats(mats);
     }
     // stacked_commit (stacked_pcs.rs:103-140) of column-major device matrices sorted by height (descending)
-    PcsData commit_mats(const std::vector<MatIn> &mats) {
+    PcsData commit_mats(const std::vector<MatIn> &mats, bool distributed_tree = false) {
         const unsigned l_skip = P().l_skip, lh = l_skip + P().n_stack;
         PcsData d;
         std::vector<std::pair<size_t, unsigned>> meta;
@@ -530,19 +536,47 @@ struct Prover {
         d.k = P().k_whir;
         d.codeword.alloc(width << d.log_rows);
         OVM_THROW_IF(ovm_hip_ntt_dif((const uint32_t *)d.msg.p, (uint32_t *)d.codeword.p, width, d.log_rows, lh, cx.stream));
-        build_tree(d, (const uint32_t *)d.codeword.p, width, false);
+        build_tree(d, (const uint32_t *)d.codeword.p, width, false, distributed_tree);
         if (!prover_config().cache_rs_code_matrix) d.codeword.release();  // re-encoded from `msg` when rows are opened
         return d;
     }
 
-    void build_tree(PcsData &d, const uint32_t *matrix, size_t width, bool ext) {
-        DevBuf<uint32_t> scratch(std::max<uint64_t>(1, ovm_hip_merkle_scratch_words(d.log_rows, d.k)));
-        d.layers.alloc(ovm_hip_merkle_layers_words(d.log_rows, d.k) / 8);
-        if (ext)
-            OVM_THROW_IF(ovm_hip_merkle_tree_ext(matrix, width, d.log_rows, d.k, scratch.p, (uint32_t *)d.layers.p, cx.stream));
-        else
-            OVM_THROW_IF(ovm_hip_merkle_tree(matrix, width, d.log_rows, d.k, scratch.p, (uint32_t *)d.layers.p, cx.stream));
-        d.root = cx.download(d.layers.p + d.layers.n - 1, 1)[0];
+    // distributed (sharded proving, and only for data every rank holds): the ranks hash a share of the query groups
+    // each and exchange the shares' roots; rank r < dist_n takes the groups g with g mod dist_n == r. In the
+    // bit-reversed layer order of merkle.hip entry p of the layer with dist_n entries covers exactly those groups, so
+    // a share is a tree of its own and the layers above are dist_n - 1 compressions on the host.
+    void build_tree(PcsData &d, const uint32_t *matrix, size_t width, bool ext, bool distributed = false) {
+        uint32_t n = 1;
+        if (distributed && !sh.single()) {
+            while (n * 2 <= sh.world && n * 2 <= (1u << (d.log_rows - d.k))) n *= 2;
+        }
+        if (n == 1) {
+            DevBuf<uint32_t> scratch(std::max<uint64_t>(1, ovm_hip_merkle_scratch_words(d.log_rows, d.k)));
+            d.layers.alloc(ovm_hip_merkle_layers_words(d.log_rows, d.k) / 8);
+            if (ext)
+                OVM_THROW_IF(ovm_hip_merkle_tree_ext(matrix, width, d.log_rows, d.k, scratch.p, (uint32_t *)d.layers.p, cx.stream));
+            else
+                OVM_THROW_IF(ovm_hip_merkle_tree(matrix, width, d.log_rows, d.k, scratch.p, (uint32_t *)d.layers.p, cx.stream));
+            d.root = cx.download(d.layers.p + d.layers.n - 1, 1)[0];
+            return;
+        }
+        d.dist_n = n;
+        d.dist_member = sh.rank < n;
+        d.dist_r = d.dist_member ? sh.rank : 0;
+        const unsigned log_share = d.log_rows - log2_strict(n);
+        p2::Digest mine{};
+        if (d.dist_member) {
+            DevBuf<uint32_t> scratch(std::max<uint64_t>(1, ovm_hip_merkle_scratch_words(log_share, d.k)));
+            d.layers.alloc(ovm_hip_merkle_layers_words(log_share, d.k) / 8);
+            OVM_THROW_IF(merkle_tree_share(matrix, width, log_share, d.k, scratch.p, (uint32_t *)d.layers.p, cx.stream, ext, n, d.dist_r));
+            mine = cx.download(d.layers.p + d.layers.n - 1, 1)[0];
+        }
+        std::vector<p2::Digest> all(sh.world);
+        sh.allgather(&mine, all.data(), sizeof(p2::Digest));
+        d.top.assign(all.begin(), all.begin() + n);
+        for (size_t lo = 0, size = n; size > 1; lo += size, size /= 2)
+            for (size_t o = 0; o < size / 2; o++) d.top.push_back(p2::compress(d.top[lo + o], d.top[lo + o + size / 2]));
+        d.root = d.top.back();
     }
 
     // -----------------------------------------------------------------------------------------
@@ -1821,23 +1855,17 @@ struct Prover {
         }
     }
 
-    // Opened rows and Merkle paths of one initial commitment at WHIR round-0 query indices (whir.rs: the rows
-    // {i + t * query_stride} of query i and the siblings along its path; physical order, see merkle.hip):
-    // vals[(q * 2^k + t) * width + c], digs[q * lq + j].
-    void open_initial_rows(const PcsData &pcs, const std::vector<uint64_t> &qidx, unsigned lq, std::vector<Fp> &vals,
-                           std::vector<p2::Digest> &digs) {
+    // Opened rows of one initial commitment at WHIR round-0 query indices (whir.rs: the rows {i + t * query_stride} of
+    // query i; physical order, see merkle.hip): vals[(q * 2^k + t) * width + c].
+    void open_rows(const PcsData &pcs, const std::vector<uint64_t> &qidx, unsigned lq, std::vector<Fp> &vals) {
         const unsigned k_whir = P().k_whir;
-        const uint64_t qs = 1ull << lq;
-        std::vector<uint64_t> rows, didx;
+        std::vector<uint64_t> rows;
         for (uint64_t i : qidx) {
             uint64_t grp = bitrev64(i, lq);
             for (uint64_t t = 0; t < (1ull << k_whir); t++) rows.push_back((grp << k_whir) + bitrev64(t, k_whir));
-            for (unsigned j = 0; j < lq; j++) didx.push_back(layer_entry(qs, lq, j, (i >> j) ^ 1));
         }
         const size_t cw = pcs.layout.width;
         auto d_rows = cx.upload(rows);
-        auto d_didx = cx.upload(didx);
-        DevBuf<p2::Digest> d_dig(std::max<size_t>(didx.size(), 1));
         DevBuf<Fp> d_vals(std::max<size_t>(rows.size() * cw, 1));
         const Fp *codeword = pcs.codeword.p;
         DevBuf<Fp> recomputed;
@@ -1849,9 +1877,44 @@ struct Prover {
         }
         OVM_THROW_IF(ovm_hip_gather_rows((const uint32_t *)codeword, cw, 1ull << pcs.log_rows, 1, d_rows.p, rows.size(),
                                          (uint32_t *)d_vals.p, cx.stream));
-        OVM_THROW_IF(ovm_hip_gather_digests((const uint32_t *)pcs.layers.p, d_didx.p, didx.size(), (uint32_t *)d_dig.p, cx.stream));
         vals = cx.download(d_vals.p, rows.size() * cw);
-        digs = cx.download(d_dig.p, didx.size());
+    }
+    // Where the Merkle-path siblings of the queries live, in proof order (query-major, bottom layer first): the
+    // sibling of query i at stored layer j is entry (i >> j) ^ 1, at physical position bitrev of it (merkle.hip).
+    // A tree built by one rank holds them all; in a tree built by dist_n ranks together (build_tree) the entry at
+    // physical position p of a layer with more than dist_n entries is in rank p mod dist_n's share at compact
+    // position p / dist_n, and the layers of at most dist_n entries are the host copy `top`.
+    struct PathRef {
+        int rank;      // -1: pcs.top[idx] (host, every rank); else: layers[idx] on that rank
+        uint64_t idx;
+    };
+    std::vector<PathRef> path_refs(const PcsData &pcs, int owner_rank, const std::vector<uint64_t> &qidx, unsigned lq) const {
+        const uint32_t n = pcs.dist_n;
+        const uint64_t qs_share = (1ull << lq) / n;
+        std::vector<PathRef> refs;
+        for (uint64_t i : qidx)
+            for (unsigned j = 0; j < lq; j++) {
+                const uint64_t size = 1ull << (lq - j), p = bitrev64((i >> j) ^ 1, lq - j);
+                if (n > 1 && size <= n) {
+                    refs.push_back({-1, (2ull * n - 2 * size) + p});
+                } else {
+                    uint64_t off = 0;
+                    for (unsigned m2 = 0; m2 < j; m2++) off += qs_share >> m2;
+                    refs.push_back({n > 1 ? (int)(p % n) : owner_rank, off + p / n});
+                }
+            }
+        return refs;
+    }
+    // the digests of `refs` that live in THIS rank's layers, in order
+    std::vector<p2::Digest> serve_paths(const PcsData &pcs, const std::vector<PathRef> &refs) {
+        std::vector<uint64_t> idx;
+        for (auto &r : refs)
+            if (r.rank == (int)sh.rank) idx.push_back(r.idx);
+        if (idx.empty()) return {};
+        auto d_idx = cx.upload(idx);
+        DevBuf<p2::Digest> d_dig(idx.size());
+        OVM_THROW_IF(ovm_hip_gather_digests((const uint32_t *)pcs.layers.p, d_idx.p, idx.size(), (uint32_t *)d_dig.p, cx.stream));
+        return cx.download(d_dig.p, idx.size());
     }
 
     // OpeningProver::prove_openings = the stacked opening reduction, then WHIR (the reference has the same two
@@ -2280,31 +2343,13 @@ struct Prover {
             // THE bulk exchange of a sharded proof (north_star: "RCCL allgather only at the FRI batch-opening
             // step"; prover/whir.rs:95-132 batches all commitments into one vector): every rank holds the
             // mu-weighted sum of ITS columns; all-gather the vectors and add them up. Modular addition is not
-            // an RCCL reduction, hence gather + local add; only rank 0 goes on with the sum.
+            // an RCCL reduction, hence gather + local add. EVERY rank adds them up and runs the WHIR rounds on the sum
+            // (the folds are cheap; the transcript stays replicated) so that the rounds' Merkle trees -- half of WHIR's
+            // time -- can be built by all ranks together (build_tree); rank 0 alone assembles the proof.
             OVM_PROF("whir.mu_allgather", cx.stream);
             DevBuf<EF> gathered((size_t)sh.world << m);
             sh.allgather_device(f_a.p, gathered.p, sizeof(EF) << m, (ovm_stream_t)cx.stream);
-            if (root_rank) OVM_THROW_IF(ef_sum_blocks(gathered.p, sh.world, uint64_t(1) << m, f_a.p, cx.stream));
-        }
-        if (!root_rank) {
-            // This rank's remaining part: the rows and Merkle paths of ITS commitments that the first WHIR round
-            // opens, at the query indices rank 0 samples (nothing later in the transcript depends on them).
-            const unsigned lq0 = m + P().log_blowup - P().k_whir;
-            Unpacker uq(sh.bcast(0, {}));
-            const std::vector<uint64_t> qidx0 = uq.get_vec<uint64_t>();
-            Packer pk_;
-            for (size_t com = 0; com < commits.size(); com++) {
-                if (!own(com)) continue;
-                std::vector<Fp> vals;
-                std::vector<p2::Digest> digs;
-                open_initial_rows(*commits[com].pcs, qidx0, lq0, vals, digs);
-                pk_.put<uint64_t>(com);
-                pk_.put_vec(vals);
-                pk_.put_vec(digs);
-            }
-            sh.allgatherv(pk_.buf);
-            section_offsets.push_back(w.buf.size());
-            return;
+            OVM_THROW_IF(ef_sum_blocks(gathered.p, sh.world, uint64_t(1) << m, f_a.p, cx.stream));
         }
         w_a.alloc(size_t(1) << m);
         w_b.alloc(size_t(1) << (m - 1));
@@ -2371,7 +2416,7 @@ struct Prover {
                 g_tree.k = k_whir;
                 DevBuf<EF> g_rs(size_t(1) << g_tree.log_rows);
                 OVM_THROW_IF(ovm_hip_ntt_dif_ext((const uint32_t *)g_coeffs.p, (uint32_t *)g_rs.p, 1, g_tree.log_rows, m_new, cx.stream));
-                build_tree(g_tree, (const uint32_t *)g_rs.p, 1, true);
+                build_tree(g_tree, (const uint32_t *)g_rs.p, 1, true, /*distributed=*/true);
                 g_tree.codeword = DevBuf<Fp>();
                 g_tree_codeword = std::move(g_rs);
                 ts.observe_digest(g_tree.root);
@@ -2392,70 +2437,108 @@ struct Prover {
             query_pows.push_back(ts.grind(P().query_phase_pow_bits));
             std::vector<uint64_t> qidx(nq);
             for (auto &q : qidx) q = ts.sample_bits(lq);
-            // opened rows + Merkle paths
+            // opened rows + Merkle paths. Rows come from their commitment's owner (round 0) or from this rank's own copy
+            // of the previous round's codeword; path digests from whichever ranks' layers hold them (path_refs).
             {
                 OVM_PROF("whir.queries", cx.stream);
-                const uint64_t qs = 1ull << lq;
-                std::vector<uint64_t> rows, didx;
-                for (uint64_t i : qidx) {
-                    uint64_t grp = bitrev64(i, lq);
-                    for (uint64_t t = 0; t < (1ull << k_whir); t++) rows.push_back((grp << k_whir) + bitrev64(t, k_whir));
-                    for (unsigned j = 0; j < lq; j++) didx.push_back(layer_entry(qs, lq, j, (i >> j) ^ 1));
-                }
-                auto d_rows = cx.upload(rows);
-                auto d_didx = cx.upload(didx);
-                DevBuf<p2::Digest> d_dig(std::max<size_t>(didx.size(), 1));
-                if (wr == 0) {
-                    // sharded: the other ranks open the rows of their own commitments at these indices
-                    std::vector<std::vector<uint8_t>> remote;
-                    if (!sh.single()) {
-                        Packer pq;
-                        pq.put_vec(qidx);
-                        sh.bcast(0, pq.buf);
-                        remote = sh.allgatherv({});
-                    }
-                    std::vector<std::vector<Fp>> vals_of(commits.size());
-                    std::vector<std::vector<p2::Digest>> digs_of(commits.size());
-                    for (size_t com = 0; com < commits.size(); com++)
-                        if (own(com)) open_initial_rows(*commits[com].pcs, qidx, lq, vals_of[com], digs_of[com]);
-                    for (uint32_t rk = 1; rk < sh.world; rk++) {
-                        Unpacker u(remote[rk]);
-                        while (!u.done()) {
-                            const uint64_t com = u.get<uint64_t>();
-                            if (com >= commits.size() || commits[com].owner != rk) throw OvmFail(1, "shard exchange: unexpected opened rows");
-                            vals_of[com] = u.get_vec<Fp>();
-                            digs_of[com] = u.get_vec<p2::Digest>();
+                // per tree that is opened in this round: [rank] -> the digests that rank's layers hold
+                auto exchange = [&](const Packer &mine) -> std::vector<std::vector<uint8_t>> {
+                    if (sh.single()) return {};
+                    return sh.allgatherv(root_rank ? std::vector<uint8_t>() : mine.buf);
+                };
+                auto assemble = [&](const PcsData &pcs, const std::vector<PathRef> &refs, std::vector<std::vector<p2::Digest>> &served) {
+                    std::vector<p2::Digest> digs;
+                    std::vector<size_t> at(sh.world, 0);
+                    for (auto &rf : refs) {
+                        if (rf.rank < 0) {
+                            digs.push_back(pcs.top.at(rf.idx));
+                        } else {
+                            auto &q = served.at(rf.rank);
+                            if (at[rf.rank] >= q.size()) throw OvmFail(1, "shard exchange: Merkle path digests missing");
+                            digs.push_back(q[at[rf.rank]++]);
                         }
                     }
+                    return digs;
+                };
+                if (wr == 0) {
+                    // this rank's part: the rows of its commitments, the digests its layers hold of every tree
+                    Packer mine;
+                    std::vector<std::vector<Fp>> vals_of(commits.size());
+                    std::vector<std::vector<std::vector<p2::Digest>>> served(commits.size(), std::vector<std::vector<p2::Digest>>(sh.world));
+                    std::vector<std::vector<PathRef>> refs_of(commits.size());
                     for (size_t com = 0; com < commits.size(); com++) {
-                        const size_t cw = commits[com].layout.width;
-                        const auto &vals = vals_of[com];
-                        const auto &digs = digs_of[com];
-                        if (vals.size() != rows.size() * cw || digs.size() != didx.size()) throw OvmFail(1, "opened rows of the wrong size");
-                        for (size_t q = 0; q < nq; q++) {
-                            std::vector<std::vector<Fp>> qr;
-                            for (size_t t = 0; t < (size_t(1) << k_whir); t++) {
-                                size_t ro = (q << k_whir) + t;
-                                qr.emplace_back(vals.begin() + ro * cw, vals.begin() + (ro + 1) * cw);
+                        const PcsData *pcs = commits[com].pcs;
+                        if (!pcs || !(own(com) || pcs->dist_n > 1)) continue;
+                        if (own(com)) open_rows(*pcs, qidx, lq, vals_of[com]);
+                        refs_of[com] = path_refs(*pcs, (int)commits[com].owner, qidx, lq);
+                        served[com][sh.rank] = serve_paths(*pcs, refs_of[com]);
+                        mine.put<uint64_t>(com);
+                        mine.put_vec(vals_of[com]);
+                        mine.put_vec(served[com][sh.rank]);
+                    }
+                    const auto remote = exchange(mine);
+                    if (root_rank) {
+                        for (uint32_t rk = 1; rk < sh.world; rk++) {
+                            Unpacker un(remote[rk]);
+                            while (!un.done()) {
+                                const uint64_t com = un.get<uint64_t>();
+                                if (com >= commits.size()) throw OvmFail(1, "shard exchange: unexpected opened rows");
+                                std::vector<Fp> v = un.get_vec<Fp>();
+                                if (commits[com].owner == rk) vals_of[com] = std::move(v);
+                                served[com][rk] = un.get_vec<p2::Digest>();
                             }
-                            init_rows[com].push_back(std::move(qr));
-                            init_proofs[com].emplace_back(digs.begin() + q * lq, digs.begin() + (q + 1) * lq);
+                        }
+                        for (size_t com = 0; com < commits.size(); com++) {
+                            const PcsData *pcs = commits[com].pcs;
+                            const size_t cw = commits[com].layout.width;
+                            // a tree held whole by its (remote) owner: its paths arrive complete
+                            const std::vector<p2::Digest> digs = (!own(com) && !(pcs && pcs->dist_n > 1))
+                                                                     ? std::move(served[com][commits[com].owner])
+                                                                     : assemble(*pcs, refs_of[com], served[com]);
+                            const auto &vals = vals_of[com];
+                            if (vals.size() != (nq << k_whir) * cw || digs.size() != nq * lq) throw OvmFail(1, "opened rows of the wrong size");
+                            for (size_t q = 0; q < nq; q++) {
+                                std::vector<std::vector<Fp>> qr;
+                                for (size_t t = 0; t < (size_t(1) << k_whir); t++) {
+                                    size_t ro = (q << k_whir) + t;
+                                    qr.emplace_back(vals.begin() + ro * cw, vals.begin() + (ro + 1) * cw);
+                                }
+                                init_rows[com].push_back(std::move(qr));
+                                init_proofs[com].emplace_back(digs.begin() + q * lq, digs.begin() + (q + 1) * lq);
+                            }
                         }
                     }
                 } else {
-                    DevBuf<EF> d_vals(std::max<size_t>(rows.size(), 1));
-                    OVM_THROW_IF(gather_ef(prev_codeword.p, d_rows.p, rows.size(), d_vals.p, cx.stream));
-                    OVM_THROW_IF(ovm_hip_gather_digests((const uint32_t *)g_prev.layers.p, d_didx.p, didx.size(), (uint32_t *)d_dig.p, cx.stream));
-                    auto vals = cx.download(d_vals.p, rows.size());
-                    auto digs = cx.download(d_dig.p, didx.size());
-                    std::vector<std::vector<EF>> rv;
-                    std::vector<std::vector<p2::Digest>> rp;
-                    for (size_t q = 0; q < nq; q++) {
-                        rv.emplace_back(vals.begin() + (q << k_whir), vals.begin() + ((q + 1) << k_whir));
-                        rp.emplace_back(digs.begin() + q * lq, digs.begin() + (q + 1) * lq);
+                    const std::vector<PathRef> refs = path_refs(g_prev, 0, qidx, lq);
+                    std::vector<std::vector<p2::Digest>> served(sh.world);
+                    served[sh.rank] = serve_paths(g_prev, refs);
+                    Packer mine;
+                    mine.put_vec(served[sh.rank]);
+                    const auto remote = g_prev.dist_n > 1 ? exchange(mine) : std::vector<std::vector<uint8_t>>();
+                    if (root_rank) {
+                        for (uint32_t rk = 1; rk < sh.world && !remote.empty(); rk++) {
+                            Unpacker un(remote[rk]);
+                            served[rk] = un.get_vec<p2::Digest>();
+                        }
+                        const std::vector<p2::Digest> digs = assemble(g_prev, refs, served);
+                        std::vector<uint64_t> rows;
+                        for (uint64_t i : qidx) {
+                            uint64_t grp = bitrev64(i, lq);
+                            for (uint64_t t = 0; t < (1ull << k_whir); t++) rows.push_back((grp << k_whir) + bitrev64(t, k_whir));
+                        }
+                        auto d_rows = cx.upload(rows);
+                        DevBuf<EF> d_vals(std::max<size_t>(rows.size(), 1));
+                        OVM_THROW_IF(gather_ef(prev_codeword.p, d_rows.p, rows.size(), d_vals.p, cx.stream));
+                        auto vals = cx.download(d_vals.p, rows.size());
+                        std::vector<std::vector<EF>> rv;
+                        std::vector<std::vector<p2::Digest>> rp;
+                        for (size_t q = 0; q < nq; q++) {
+                            rv.emplace_back(vals.begin() + (q << k_whir), vals.begin() + ((q + 1) << k_whir));
+                            rp.emplace_back(digs.begin() + q * lq, digs.begin() + (q + 1) * lq);
+                        }
+                        cw_values.push_back(std::move(rv));
+                        cw_proofs.push_back(std::move(rp));
                     }
-                    cw_values.push_back(std::move(rv));
-                    cw_proofs.push_back(std::move(rp));
                 }
             }
             g_prev = std::move(g_tree);
@@ -2497,6 +2580,10 @@ struct Prover {
             }
             m = m_new;
             log_rs -= 1;
+        }
+        if (!root_rank) {  // (the proof is assembled on rank 0)
+            section_offsets.push_back(w.buf.size());
+            return;
         }
         // whir proof bytes
         w.f(mu_pow_witness);
@@ -2563,9 +2650,9 @@ struct Prover {
         }
     }
 
-    // Sharded: the common mains of all traces are needed where the common-main commitment is built (rank 0).
-    // Every rank contributes the common mains of ITS traces (concatenated in sorted order) to one device
-    // all-gather; rank 0 stacks and commits from the gathered buffer. (The per-AIR bulk -- the cached mains --
+    // Sharded: the common-main commitment stacks the common mains of ALL traces. Every rank contributes the
+    // common mains of ITS traces (concatenated in sorted order) to one device all-gather and commits from the
+    // gathered buffer, with the Merkle tree built by all ranks together. (The per-AIR bulk -- the cached mains --
     // never moves: SURVEY §8(e) "committing each AIR's trace as its own commitment".)
     DevBuf<Fp> common_gathered;
     void commit_common_sharded(PcsData &pcs, p2::Digest &root) {
@@ -2587,18 +2674,14 @@ struct Prover {
             sh.allgather_device(send.p, common_gathered.p, max_words * sizeof(Fp), (ovm_stream_t)cx.stream);
             cx.sync();  // (`send` goes back to the cache: the exchange may have run on another stream)
         }
-        if (sh.rank == 0) {
-            std::vector<MatIn> mats;
-            for (size_t t = 0; t < traces.size(); t++)
-                mats.push_back({common_gathered.p + owner[t] * max_words + off_in_rank[t], air(t).common_main_width, traces[t].height});
-            pcs = commit_mats(mats);
-            root = pcs.root;
-        }
-        std::vector<uint8_t> rb(sizeof(p2::Digest));
-        memcpy(rb.data(), &root, sizeof(p2::Digest));
-        rb = sh.bcast(0, rb);
-        if (rb.size() != sizeof(p2::Digest)) throw OvmFail(1, "shard exchange: common-main root");
-        memcpy(&root, rb.data(), sizeof(p2::Digest));
+        // Every rank now holds every common main: each stacks and encodes them (a column or two) and hashes ITS share of
+        // the codeword's query groups; the shares' roots are exchanged (build_tree). Rank 0 keeps owning the
+        // commitment's columns in the stacked reduction and the mu-batch.
+        std::vector<MatIn> mats;
+        for (size_t t = 0; t < traces.size(); t++)
+            mats.push_back({common_gathered.p + owner[t] * max_words + off_in_rank[t], air(t).common_main_width, traces[t].height});
+        pcs = commit_mats(mats, true);
+        root = pcs.root;
     }
     // Sharded: public values and cached-main commitments of every trace, from its owner.
     void exchange_trace_meta() {
@@ -2687,7 +2770,7 @@ struct Prover {
         section_offsets.push_back(out.buf.size());
         std::vector<EF> r = prove_rap_constraints();
         wt.mark("rap_constraints.rest");
-        prove_openings(sh.rank == 0 ? &pcs : nullptr, common_root, r);
+        prove_openings(&pcs, common_root, r);
         wt.mark("openings.whir");
     }
 };

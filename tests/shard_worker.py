@@ -24,6 +24,8 @@ def main():
                     help="prove in the memory-bounded modes (codeword dropped, round 0 in slabs of 8 rows)")
     args = ap.parse_args()
 
+    import time
+    t_start = time.time()
     import torch
     import torch.distributed as dist
     from conftest import load_pkg
@@ -33,6 +35,7 @@ def main():
     pkg = load_pkg()
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(args.port))
     dist.init_process_group("gloo", rank=args.rank, world_size=args.world)
+    t_pg = time.time()
     dev = pkg.Device(0)
     if args.save_memory:
         pkg.set_prover_config(cache_rs_code_matrix=False, zerocheck_save_memory=True, round0_slab_log_rows=3)
@@ -70,8 +73,12 @@ def main():
                 off += w * h
         dtr.append((a, up(common), h, pvs, handles))
     proof = b""
+    t_ready = time.time()
     for _ in range(args.repeat):
         proof, secs = dev.prove_sharded(pk, shard, dtr, owners)
+    t_done = time.time()
+    print(f"[shard_worker rank {args.rank}] import+rendezvous {t_pg - t_start:.1f} s, device+key+shm+upload {t_ready - t_pg:.1f} s, "
+          f"prove x{args.repeat} {t_done - t_ready:.2f} s", file=sys.stderr, flush=True)
     if args.rank == 0:
         with open(args.out, "wb") as f:
             f.write(proof)

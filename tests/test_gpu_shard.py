@@ -42,6 +42,8 @@ def run_sharded(case, world, tmp_path, repeat=1, save_memory=False):
             raise
         logs.append(o)
     assert all(p.returncode == 0 for p in procs), "\n".join(l[-3000:] for l in logs)
+    for l in logs:  # (where a run's time goes: pytest -s shows it)
+        print("\n".join(x for x in l.splitlines() if x.startswith("[shard_worker")))
     return open(out, "rb").read()
 
 
