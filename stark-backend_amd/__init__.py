@@ -452,12 +452,16 @@ class Shard:
     gloo, which is what the CPU tests and several ranks sharing ONE GPU use) for the one bulk all-gather.
     ``name``: the same unique shared-memory name on every rank (e.g. from rank 0 via broadcast_object_list)."""
 
-    def __init__(self, rank: int, world: int, name: str, slot_bytes: int = 1 << 20, group=None, host_buffers: bool = False):
+    def __init__(self, rank: int, world: int, name: str, slot_bytes: int = 1 << 20, group=None, host_buffers: bool = False,
+                 bulk: str = "torch"):
         import torch
         import torch.distributed as dist
 
         self.rank, self.world, self.group = rank, world, group
         self.host_buffers = host_buffers  # the bulk exchange is handed HOST pointers (CPU tests of the callback)
+        # bulk = "torch": torch.distributed (nccl = RCCL; gloo = host-staged). bulk = "shm": staged through the library's own
+        # shared-memory exchange, no process group at all -- ranks that share one GPU in the tests.
+        self.bulk = bulk
         h = c_void_p(0)
         check(_lib().ovm_hip_shm_comm_create(name.encode(), rank, world, slot_bytes, ctypes.byref(h)), "ovm_hip_shm_comm_create")
         self.comm = h
@@ -480,6 +484,15 @@ class Shard:
                 return 0
             torch.cuda.current_stream().synchronize()  # what the prover enqueued before the exchange
             self.bulk_bytes += int(nbytes) * self.world
+            if self.bulk == "shm":
+                send = np.empty(nbytes, dtype=np.uint8)
+                recv = np.empty(nbytes * self.world, dtype=np.uint8)
+                check(_lib().ovm_hip_memcpy_d2h(send.ctypes.data, d_mine, nbytes, stream), "ovm_hip_memcpy_d2h")
+                check(_lib().ovm_hip_stream_synchronize(stream), "ovm_hip_stream_synchronize")
+                check(_lib().ovm_hip_shm_allgather(self.comm, send.ctypes.data, recv.ctypes.data, nbytes), "ovm_hip_shm_allgather")
+                check(_lib().ovm_hip_memcpy_h2d(d_all, recv.ctypes.data, nbytes * self.world, stream), "ovm_hip_memcpy_h2d")
+                check(_lib().ovm_hip_stream_synchronize(stream), "ovm_hip_stream_synchronize")
+                return 0
             if dist.get_backend(self.group) == "nccl":
                 dev = torch.device("cuda", torch.cuda.current_device())
                 try:  # views of the prover's own buffers: no copy

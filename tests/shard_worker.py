@@ -1,6 +1,7 @@
 """One rank of a sharded proof (tests/test_gpu_shard.py starts `world` of these on ONE GPU: logical shards
-with their own streams and caches, gloo + host staging standing in for RCCL; bench.py runs the same code
-path with one GPU per rank and the nccl backend). Rank 0 writes the joint proof to --out."""
+with their own streams and caches, host staging through the shared-memory exchange standing in for RCCL;
+bench.py runs the same code path with one GPU per rank and the nccl backend). Rank 0 writes the joint proof
+to --out."""
 import argparse
 import os
 import sys
@@ -27,19 +28,18 @@ def main():
     import time
     t_start = time.time()
     import torch
-    import torch.distributed as dist
     from conftest import load_pkg
     import airs
     import shard_cases
 
     pkg = load_pkg()
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(args.port))
-    dist.init_process_group("gloo", rank=args.rank, world_size=args.world)
+    # (no process group: the ranks share one GPU, so the bulk exchange is staged through the library's own
+    # shared-memory exchange; torch.distributed's part is covered by tests/test_shard_cpu.py (gloo) and the nccl test)
     t_pg = time.time()
     dev = pkg.Device(0)
     if args.save_memory:
         pkg.set_prover_config(cache_rs_code_matrix=False, zerocheck_save_memory=True, round0_slab_log_rows=3)
-    shard = pkg.Shard(args.rank, args.world, args.shm)
+    shard = pkg.Shard(args.rank, args.world, args.shm, bulk="shm")
     if args.case.startswith("gen:"):
         # "gen:<log_rows>:<cols>:<log_stacked_height>": one partitioned BenchmarkAir per rank under app parameters, the
         # seeded boolean trace generated on the device (BASELINE config D's multi-GPU form at any size)
@@ -82,13 +82,7 @@ def main():
     if args.rank == 0:
         with open(args.out, "wb") as f:
             f.write(proof)
-    dist.barrier()
     shard.close()
-    # (a throwaway process: tearing the gloo group down costs tens of seconds on boxes where the peer's host name
-    # does not resolve; leave without it)
-    sys.stdout.flush()
-    sys.stderr.flush()
-    os._exit(0)
 
 
 if __name__ == "__main__":

@@ -1,7 +1,8 @@
 """The sharded prover on real hardware: `world` LOGICAL SHARDS ON ONE GPU (one process each: own stream,
-own caches; the shared-memory exchange between them, gloo + host staging standing in for RCCL) produce ONE
-joint proof that must equal, byte for byte, the oracle's proof of the same multi-AIR, per-AIR-commitment
-context -- and the single-process HIP proof."""
+own caches; the shared-memory exchange between them, host staging through it standing in for RCCL) produce
+ONE joint proof that must equal, byte for byte, the oracle's proof of the same multi-AIR,
+per-AIR-commitment context -- and the single-process HIP proof. (torch.distributed's part of the bulk exchange:
+tests/test_shard_cpu.py with gloo, test_bulk_exchange_callback_on_nccl below, bench.py --one-gpu.)"""
 import os
 import socket
 import subprocess
