@@ -15,7 +15,22 @@ static std::vector<Fp> to_fp(const uint32_t *p, size_t n) {
     return v;
 }
 
+#if defined(_OPENMP)
+#include <omp.h>
+#endif
+
 extern "C" {
+
+// Threads of the following calls (0 = all processors). Small test cases on a many-core host spend their time
+// starting and joining 256-thread teams thousands of times; tests/oracle_lib.py picks the count by problem size.
+void orc_set_num_threads(int n) {
+#if defined(_OPENMP)
+    omp_set_num_threads(n > 0 ? n : omp_get_num_procs());
+#else
+    (void)n;
+#endif
+}
+
 
 uint32_t orc_modulus() { return P; }
 uint32_t orc_to_mont(uint32_t x) { return Fp((uint64_t)x).to_mont(); }

@@ -63,8 +63,12 @@ RUNS = [(c, 2) for c in shard_cases.CASES] + [(c, 4) for c in ("bench8", "bench_
 
 @pytest.mark.parametrize("case,world", RUNS)
 def test_logical_shards_match_oracle(orc, tmp_path, case, world):
+    import time
+    t0 = time.time()
     blob, want = oracle_proof(orc, case, world)
+    t1 = time.time()
     got = run_sharded(case, world, tmp_path)
+    print(f"[{case}-{world}] oracle {t1 - t0:.1f} s, {world} worker processes {time.time() - t1:.1f} s")
     assert got == want
     orc.verify(blob, got)
 
