@@ -21,11 +21,12 @@ static std::vector<Fp> to_fp(const uint32_t *p, size_t n) {
 
 extern "C" {
 
-// Threads of the following calls (0 = all processors). Small test cases on a many-core host spend their time
+// Threads of the following calls (0 = the OpenMP runtime's own default). Small test cases on a many-core host spend their time
 // starting and joining 256-thread teams thousands of times; tests/oracle_lib.py picks the count by problem size.
 void orc_set_num_threads(int n) {
 #if defined(_OPENMP)
-    omp_set_num_threads(n > 0 ? n : omp_get_num_procs());
+    static const int initial = omp_get_max_threads();  // what the runtime chose before anybody asked (0 restores it)
+    omp_set_num_threads(n > 0 ? (n < initial ? n : initial) : initial);
 #else
     (void)n;
 #endif

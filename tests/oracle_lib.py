@@ -159,7 +159,7 @@ def _prove(self, blob, traces, proof_cap=1 << 26):
     arrs = [np.ascontiguousarray(t[1], dtype=np.uint32) for t in traces]
     # small cases: a handful of threads (a 256-thread team per tiny loop costs more than the loop)
     cells = sum(a.size for a in arrs) + sum(np.size(t[4]) for t in traces if len(t) > 4 and t[4] is not None)
-    lib.orc_set_num_threads(c_int(min(8, os.cpu_count() or 8) if cells < (1 << 22) else 0))
+    lib.orc_set_num_threads(c_int(8 if cells < (1 << 22) else 0))
     pvs = [np.ascontiguousarray(t[3], dtype=np.uint32) if len(t[3]) else np.zeros(1, np.uint32) for t in traces]
     air_idx = np.array([t[0] for t in traces], dtype=np.uint32)
     heights = np.array([t[2] for t in traces], dtype=np.uint64)
@@ -174,9 +174,12 @@ def _prove(self, blob, traces, proof_cap=1 << 26):
     r = np.zeros(4 * 64, np.uint32); u = np.zeros(4 * 64, np.uint32); pw = np.zeros(256, np.uint32)
     rl = c_uint32(0); ul = c_uint32(0); pl = c_uint32(0)
     lib.orc_last_error.restype = ctypes.c_char_p
-    rc = lib.orc_prove(_p(blob), c_uint64(blob.size), c_uint32(n), _p(air_idx), tptr, _p(heights), cptr, pptr,
-                       _p(npv), _p(out), c_uint64(proof_cap), ctypes.byref(plen), _p(root), _p(r),
-                       ctypes.byref(rl), _p(u), ctypes.byref(ul), _p(pw), ctypes.byref(pl))
+    try:
+        rc = lib.orc_prove(_p(blob), c_uint64(blob.size), c_uint32(n), _p(air_idx), tptr, _p(heights), cptr, pptr,
+                           _p(npv), _p(out), c_uint64(proof_cap), ctypes.byref(plen), _p(root), _p(r),
+                           ctypes.byref(rl), _p(u), ctypes.byref(ul), _p(pw), ctypes.byref(pl))
+    finally:
+        lib.orc_set_num_threads(c_int(0))  # the other entry points (commit, verify) keep the runtime's default
     if rc != 0:
         raise RuntimeError("orc_prove: " + lib.orc_last_error().decode())
     return dict(proof=out[:plen.value].tobytes(), root=root, r=r[:4 * rl.value].reshape(-1, 4),

@@ -138,3 +138,24 @@ def test_struct_layouts_match_header(pkg):
     assert ctypes.sizeof(pkg.PcsParams) == 16 and ctypes.sizeof(pkg.MatrixStruct) == 24
     assert ctypes.sizeof(pkg.ShardStruct) == 32 and pkg.ShardStruct.allgather_device.offset == 24
     assert ctypes.sizeof(pkg.ProverConfigStruct) == 24 and pkg.ProverConfigStruct.cache_limit_bytes.offset == 16
+
+
+def test_rust_crate_only_calls_declared_entries():
+    """Every `ffi::ovm_hip_*` the (uncompiled) Rust crate calls is declared in its ffi.rs, the key-blob magics match
+    the ones the C side parses, and the struct fields the crate touches exist."""
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = os.path.join(root, "crates", "hip-backend", "src")
+    declared = set(rust_declarations())
+    used = set()
+    for f in os.listdir(src):
+        if f.endswith(".rs") and f != "ffi.rs":
+            used |= set(re.findall(r"ffi::(ovm_hip_\w+)", open(os.path.join(src, f)).read()))
+    assert used and used <= declared, used - declared
+    blob_rs = open(os.path.join(src, "pk_blob.rs")).read()
+    host_h = open(os.path.join(root, "stark-backend_amd", "csrc", "host.h")).read()
+    assert "0x4F56_4D31" in blob_rs and "0x4F564D31u" in host_h
+    assert "0x5052_4550" in blob_rs and "0x50524550u" in host_h
+    ffi_rs = open(os.path.join(src, "ffi.rs")).read()
+    for field in ("absorb_idx", "sample_idx", "d_common_main", "num_cached", "allgather_device", "cache_limit_bytes"):
+        assert f"pub {field}:" in ffi_rs
