@@ -4,6 +4,7 @@
 #include "device_common.h"
 #include "device_ctx.h"
 #include "program.h"
+#include "tuning.h"
 
 #include <utility>
 #include <vector>

@@ -24,6 +24,7 @@
 #include "device_ctx.h"
 #include "openvm_hip.h"
 #include "poseidon2.h"
+#include "tuning.h"
 
 using bb::Fp;
 using bb::FpExt;
@@ -177,7 +178,7 @@ __global__ void gather_digests_kernel(const Digest *__restrict__ layers,
 
 // (OVM_MERKLE_COOP=0 keeps every layer on the one-lane kernel: the parity tests compare the two)
 static void launch_compress(const Digest *in, Digest *out, uint64_t n_out, uint32_t log_half, hipStream_t stream) {
-    static const bool coop = !(getenv("OVM_MERKLE_COOP") && getenv("OVM_MERKLE_COOP")[0] == '0');
+    const bool coop = tuning().merkle_coop;
     if (coop && n_out <= COOP_MAX_NODES)
         hipLaunchKernelGGL(compress_layer_coop_kernel, dim3(ceil_div(n_out * 16, HASH_THREADS)), dim3(HASH_THREADS), 0, stream, in,
                            out, n_out, log_half);

@@ -420,7 +420,7 @@ static inline uint64_t layer_entry(uint64_t qs, unsigned lq, unsigned j, uint64_
 struct WallTrace {
     bool on;
     std::chrono::steady_clock::time_point t0;
-    WallTrace() : on(getenv("OVM_TRACE") != nullptr), t0(std::chrono::steady_clock::now()) {}
+    WallTrace() : on(tuning().trace), t0(std::chrono::steady_clock::now()) {}
     void mark(const char *what) {
         if (!on) return;
         (void)hipDeviceSynchronize();
@@ -444,7 +444,7 @@ struct Prover {
     Ctx cx;
     Mailbox &mb;
     // test hook: take the GKR fallback path (three evaluation points from the device) on every sub-round
-    const bool force_three_points = std::getenv("OVM_GKR_THREE_POINTS") != nullptr;
+    const bool force_three_points = tuning().gkr_three_points;
     Transcript ts;
     std::vector<TraceIn> traces;  // sorted
     // Sharded proving: owner[t] = the rank holding sorted trace t. Per-trace device work
@@ -715,7 +715,7 @@ struct Prover {
     // 10 K-instruction program in 16 groups is 600 instructions per lane (OVM_MLE_GROUPS_MAX caps it)
     static constexpr uint32_t MLE_GROUP_INSTRS = 128, MLE_GROUPS_MAX = 128;
     static uint32_t mle_groups_for(size_t n_instr) {
-        static const uint32_t cap = getenv("OVM_MLE_GROUPS_MAX") ? (uint32_t)std::max(1, atoi(getenv("OVM_MLE_GROUPS_MAX"))) : MLE_GROUPS_MAX;
+        const uint32_t cap = tuning().mle_groups_max;
         return (uint32_t)std::min<size_t>(std::max<size_t>(MLE_GROUPS, n_instr / MLE_GROUP_INSTRS), std::max(cap, MLE_GROUPS));
     }
     struct TracePrograms {
@@ -1254,12 +1254,11 @@ struct Prover {
         // (as many groups as keep the job within this many workgroups: on taller traces the lanes are there
         // already, and the job's last workgroup sums workgroups x groups records)
         static constexpr uint32_t R0_GROUP_JOB_WGS = 512;
-        const char *r0_batch_env = getenv("OVM_R0_BATCH");
-        const bool r0_batch = !(r0_batch_env && r0_batch_env[0] == '0');
+        const bool r0_batch = tuning().r0_batch;
         std::vector<R0Job> r0_groups[3][2];  // [log2 rows][n_out - 1]
         // long programs (more groups than the OVM_R0_GROUPS_MIN threshold, default: more than MLE_GROUPS, i.e.
         // > ~2 K instructions) run their groups as extra workgroups of the job
-        const uint32_t r0_groups_min = getenv("OVM_R0_GROUPS_MIN") ? (uint32_t)atoi(getenv("OVM_R0_GROUPS_MIN")) : MLE_GROUPS + 1;
+        const uint32_t r0_groups_min = tuning().r0_groups_min >= 0 ? (uint32_t)tuning().r0_groups_min : MLE_GROUPS + 1;
         auto r0_batchable = [&](const DevStaged &staged, uint32_t log_lifted) {
             return r0_batch && staged.blocks && log_lifted < R0_BATCH_MAX_LOG;
         };
@@ -1553,8 +1552,7 @@ struct Prover {
         // Jobs of at most MLE_BATCH_MAX_WGS workgroups go into one launch per round (the late rounds
         // of a many-AIR proof are otherwise dozens of tiny launches serialised by the stream).
         // (OVM_MLE_BATCH=0 launches every job on its own: parity tests of the unbatched kernels on small traces)
-        const char *mle_batch_env = getenv("OVM_MLE_BATCH");
-        const uint32_t MLE_BATCH_MAX_WGS = mle_batch_env ? (uint32_t)atoi(mle_batch_env) : 256;  // (0: no batching)
+        const uint32_t MLE_BATCH_MAX_WGS = tuning().mle_batch_wgs;  // (0: no batching)
         DevBuf<uint32_t> mle_counters(2 * T + 1);
         OVM_THROW_IF(hipMemsetAsync(mle_counters.p, 0, (2 * T + 1) * sizeof(uint32_t), cx.stream));
         OVM_PROF("constraints.mle_rounds", cx.stream);
@@ -2711,7 +2709,10 @@ struct Prover {
     void prove(std::vector<TraceIn> in) {
         set_traces(std::move(in));
         ts.observe_digest(pk.vk_pre_hash);
-        programs_future = std::async(std::launch::async, [this] { return compile_all_programs(); });
+        programs_future = std::async(std::launch::async, [this, tn = tuning()] {
+            Tuning::current() = tn;  // (thread-local: the helper works under the caller's settings)
+            return compile_all_programs();
+        });
         wt.mark("setup");
         PcsData pcs;
         p2::Digest common_root;
@@ -2875,6 +2876,31 @@ using namespace ovm;
 
 static thread_local std::string g_last_error;
 
+Tuning ovm::Tuning::from_env() {
+    Tuning t;
+    auto num = [](const char *name, int dflt) {
+        const char *e = getenv(name);
+        return e && *e ? atoi(e) : dflt;
+    };
+    auto off = [](const char *name) {  // "=0" switches a default-on feature off
+        const char *e = getenv(name);
+        return e && e[0] == '0';
+    };
+    t.r0_rows = num("OVM_R0_ROWS", 0);
+    t.stage_rows = num("OVM_STAGE_ROWS", 0);
+    t.acc_rows = num("OVM_ACC_ROWS", 0);
+    t.stage_kib = (uint32_t)std::max(1, num("OVM_STAGE_KIB", 36));
+    t.mle_points_in_lane = !off("OVM_MLE_POINTS");
+    t.r0_batch = !off("OVM_R0_BATCH");
+    t.r0_groups_min = num("OVM_R0_GROUPS_MIN", -1);
+    t.mle_batch_wgs = (uint32_t)std::max(0, num("OVM_MLE_BATCH", 256));
+    t.mle_groups_max = (uint32_t)std::max(1, num("OVM_MLE_GROUPS_MAX", 128));
+    t.gkr_three_points = getenv("OVM_GKR_THREE_POINTS") != nullptr;
+    t.merkle_coop = !off("OVM_MERKLE_COOP");
+    t.trace = getenv("OVM_TRACE") != nullptr;
+    return t;
+}
+
 namespace {
 // Validation at the C boundary: every violated precondition is an error code plus a message
 // (ovm_hip_last_error), never a fault.
@@ -2930,6 +2956,7 @@ void sponge_out(const Prover &pr, ovm_sponge_t *sponge) {
 template <class F>
 int guarded(F &&f, bool needs_device = true) {
     try {
+        Tuning::refresh();  // the environment overrides are read here, once per call, and nowhere else
         if (needs_device && !twiddles()) return (int)hipErrorInitializationError;
         return f();
     } catch (const OvmFail &e) {

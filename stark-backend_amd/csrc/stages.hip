@@ -679,10 +679,7 @@ __global__ __launch_bounds__(RED_THREADS) void round0_staged_kernel(DevStaged pr
 // OVM_R0_ROWS=1|2|4 overrides the choice (parity tests run every variant on small traces).
 static int round0_rows(uint32_t log_lifted, uint32_t n_out) {
     int rows = log_lifted >= 20 ? 4 : log_lifted == 19 ? 2 : 1;
-    if (const char *e = getenv("OVM_R0_ROWS")) {
-        const int v = atoi(e);
-        if (v == 1 || v == 2 || v == 4) rows = v;
-    }
+    if (const int v = tuning().r0_rows; v == 1 || v == 2 || v == 4) rows = v;
     while (rows > 1 && (rows * n_out > 4 || (1ull << log_lifted) / rows < RED_THREADS)) rows >>= 1;
     return rows;
 }
@@ -693,9 +690,9 @@ static int round0_rows(uint32_t log_lifted, uint32_t n_out) {
 // and the rest of the budget split between the two staging buffers and the accumulation rows.
 StagedPlan round0_staged_plan(uint32_t log_lifted, uint32_t n_out, uint32_t num_slots) {
     StagedPlan plan;
-    const char *es = getenv("OVM_STAGE_ROWS"), *ea = getenv("OVM_ACC_ROWS");  // (tuning / parity-test overrides)
+    const Tuning &tn = tuning();  // (tuning / parity-test overrides)
     for (int rows = round0_rows(log_lifted, n_out); rows >= 1; rows >>= 1) {
-        const uint32_t first_budget = getenv("OVM_STAGE_KIB") ? (uint32_t)atoi(getenv("OVM_STAGE_KIB")) : 36u;
+        const uint32_t first_budget = tn.stage_kib;
         for (uint32_t budget_kib : {first_budget, 56u}) {
             if (budget_kib > first_budget && rows > 1) continue;  // a larger image only as the last resort
             const uint32_t budget_rows = budget_kib / (uint32_t)rows;
@@ -703,8 +700,8 @@ StagedPlan round0_staged_plan(uint32_t log_lifted, uint32_t n_out, uint32_t num_
             uint32_t each = (budget_rows - num_slots) / 3;  // 2 staging buffers + accumulation rows
             if (each > 8) each = 8;
             plan.rows = (uint32_t)rows;
-            plan.stage_rows = es ? (uint32_t)std::max(2, atoi(es)) : each;
-            plan.acc_rows = ea ? (uint32_t)std::max(1, atoi(ea)) : each;
+            plan.stage_rows = tn.stage_rows ? (uint32_t)std::max(2, tn.stage_rows) : each;
+            plan.acc_rows = tn.acc_rows ? (uint32_t)std::max(1, tn.acc_rows) : each;
             return plan;
         }
     }
@@ -1058,10 +1055,7 @@ __global__ __launch_bounds__(RED_THREADS) void mle_round_points_kernel(const Ins
 }
 
 // OVM_MLE_POINTS=0 selects the one-point-per-lane kernel for the large rounds too (A/B and parity tests)
-static bool mle_points_in_lane() {
-    const char *e = getenv("OVM_MLE_POINTS");
-    return !(e && e[0] == '0');
-}
+static bool mle_points_in_lane() { return tuning().mle_points_in_lane; }
 
 uint32_t mle_round_gx(uint32_t log_h, uint32_t degree, uint32_t n_groups, bool points_in_lane) {
     uint32_t gx = red_grid(1ull << (log_h - 1));

@@ -1,0 +1,33 @@
+// Tuning / test overrides of the prover, read from the environment in ONE place (host only).
+#pragma once
+#include <cstdint>
+
+namespace ovm {
+
+// Every tuning / test override the prover honours, in one place. Production callers leave the environment
+// alone and get the defaults; the parity tests force the alternative kernels and layouts on small traces.
+// Read ONCE per call of a prover entry point (Tuning::refresh in guarded(), prover.hip), never inside a stage;
+// the kernel-level entries (ovm_hip_merkle_tree ...) use what the calling thread read first.
+struct Tuning {
+    int r0_rows = 0;               // OVM_R0_ROWS=1|2|4: trace rows per lane of the staged round 0 (0: by height)
+    int stage_rows = 0;            // OVM_STAGE_ROWS: LDS rows of one staging buffer (0: from the budget)
+    int acc_rows = 0;              // OVM_ACC_ROWS: LDS accumulation rows (0: from the budget)
+    uint32_t stage_kib = 36;       // OVM_STAGE_KIB: LDS image budget per workgroup
+    bool mle_points_in_lane = true;  // OVM_MLE_POINTS=0: one evaluation point per lane in the large rounds too
+    bool r0_batch = true;          // OVM_R0_BATCH=0: every trace's round 0 its own launch
+    int r0_groups_min = -1;        // OVM_R0_GROUPS_MIN: programs of at least this many groups run grouped (-1: default)
+    uint32_t mle_batch_wgs = 256;  // OVM_MLE_BATCH: jobs up to this many workgroups share a launch (0: none)
+    uint32_t mle_groups_max = 128; // OVM_MLE_GROUPS_MAX
+    bool gkr_three_points = false; // OVM_GKR_THREE_POINTS: every GKR sub-round takes the three-point fallback
+    bool merkle_coop = true;       // OVM_MERKLE_COOP=0: no 16-lane cooperative compress for the small layers
+    bool trace = false;            // OVM_TRACE: wall-clock trace of the stages on stderr
+    static Tuning from_env();
+    static void refresh() { current() = from_env(); }
+    static Tuning &current() {
+        static thread_local Tuning t = from_env();
+        return t;
+    }
+};
+inline const Tuning &tuning() { return Tuning::current(); }
+
+}  // namespace ovm
