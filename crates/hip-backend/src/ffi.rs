@@ -88,6 +88,10 @@ pub struct OvmShard {
     pub allgather_device: Option<
         unsafe extern "C" fn(ctx: *mut c_void, d_mine: *const c_void, d_all: *mut c_void, bytes: u64, stream: OvmStream) -> c_int,
     >,
+    /// optional (`None`: the mu-batch vectors are summed through an all-gather of whole vectors)
+    pub alltoall_device: Option<
+        unsafe extern "C" fn(ctx: *mut c_void, d_send: *const c_void, d_recv: *mut c_void, bytes: u64, stream: OvmStream) -> c_int,
+    >,
 }
 
 extern "C" {

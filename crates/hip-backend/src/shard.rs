@@ -1,9 +1,10 @@
 //! Sharded proving: ONE joint proof over the GPUs of a node, one AIR (trace) per GPU, one process
 //! per GPU (DESIGN.md §6 of the HIP backend). Each rank owns the traces it generated
 //! and the cached-main commitments of those traces; the per-round sumcheck values travel through the
-//! library's shared-memory exchange, and the one bulk exchange -- the mu-batched WHIR vector -- goes
-//! through the `allgather_device` callback, which a deployment implements with RCCL
-//! (`ncclAllGather` on the rank's stream). The reference has no peer for this file.
+//! library's shared-memory exchange, and the one bulk exchange -- the sum of the ranks' mu-batched WHIR
+//! vectors -- goes through the `allgather_device` / `alltoall_device` callbacks, which a deployment
+//! implements with RCCL (`ncclAllGather` / `ncclAllToAll` on the rank's stream). The reference has no
+//! peer for this file.
 use std::{
     ffi::{c_void, CString},
     os::raw::c_int,
@@ -24,6 +25,21 @@ use crate::{
 /// ordered after the work already enqueued on `stream` and complete for later work on it on return.
 pub trait BulkExchange: Send {
     fn allgather_device(&mut self, d_mine: *const c_void, d_all: *mut c_void, bytes: u64, stream: ffi::OvmStream) -> i32;
+    /// `d_recv[s * bytes ..] = rank s's d_send[rank * bytes ..]`; `None` when the deployment has no
+    /// all-to-all (the prover then all-gathers whole vectors: N-1 instead of 2 (N-1)/N vectors per GPU).
+    fn alltoall_device(
+        &mut self,
+        _d_send: *const c_void,
+        _d_recv: *mut c_void,
+        _bytes: u64,
+        _stream: ffi::OvmStream,
+    ) -> Option<i32> {
+        None
+    }
+    /// Whether `alltoall_device` is implemented (decides if the callback is handed to the library).
+    fn has_alltoall(&self) -> bool {
+        false
+    }
 }
 
 /// One rank's communicator: the shared-memory segment for the small exchanges + the bulk callback.
@@ -49,6 +65,17 @@ unsafe extern "C" fn device_trampoline(
     comm.bulk.allgather_device(d_mine, d_all, bytes, stream)
 }
 
+unsafe extern "C" fn alltoall_trampoline(
+    ctx: *mut c_void,
+    d_send: *const c_void,
+    d_recv: *mut c_void,
+    bytes: u64,
+    stream: ffi::OvmStream,
+) -> c_int {
+    let comm = &mut *(ctx as *mut ShardComm);
+    comm.bulk.alltoall_device(d_send, d_recv, bytes, stream).unwrap_or(1)
+}
+
 impl ShardComm {
     /// `name`: the same unique shared-memory name on every rank of the job (e.g. "/ovm-<port>-<pid>").
     pub fn new(name: &str, rank: u32, world: u32, bulk: Box<dyn BulkExchange>) -> Result<Box<Self>, HipError> {
@@ -67,6 +94,7 @@ impl ShardComm {
             ctx: (&mut **self) as *mut ShardComm as *mut c_void,
             allgather_host: Some(host_trampoline),
             allgather_device: Some(device_trampoline),
+            alltoall_device: if self.bulk.has_alltoall() { Some(alltoall_trampoline) } else { None },
         }
     }
 }

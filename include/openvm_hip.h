@@ -329,22 +329,28 @@ int ovm_hip_prove(const ovm_pk_t *pk, uint32_t n_traces, const ovm_trace_t *trac
  * (BASELINE config D/E in their 8 x MI355X form). DESIGN.md §6 has the protocol.
  * ------------------------------------------------------------------------------------- */
 
-/* The communicator of a sharded call. Two exchanges exist:
+/* The communicator of a sharded call. The exchanges:
  *   allgather_host   small host buffers, hundreds of times per proof (per-round partial sums of the
  *                    sumchecks, roots, openings): all[r*bytes ..] = rank r's `mine`; every rank calls
  *                    it in the same order with the same `bytes`. Built in: ovm_hip_shm_allgather.
- *   allgather_device device buffers, once per proof: the mu-batched WHIR vector of each rank
- *                    (reference: the batching step of prover/whir.rs:95-132), d_all[r*bytes ..] = rank
- *                    r's d_mine. The host language supplies it on top of RCCL over xGMI
- *                    (torch.distributed in this repository's Python host, an rccl binding in Rust); it
- *                    must be ordered after the work already enqueued on `stream` and complete, from
- *                    the point of view of later work on `stream`, when it returns.
- * Both return 0 or a hipError_t value. */
+ *   allgather_device device buffers: d_all[r*bytes ..] = rank r's d_mine. Used for each AIR's share of
+ *                    the common main at the start and for the mu-batched WHIR vector (reference: the
+ *                    batching step of prover/whir.rs:95-132).
+ *   alltoall_device  OPTIONAL (may be null): d_recv[s*bytes ..] = rank s's d_send[rank*bytes ..]. With it
+ *                    the N per-rank mu-batch vectors are summed as all-to-all + local modular add of
+ *                    one slice + all-gather of the slices -- 2*(N-1)/N of ONE vector in and out of every
+ *                    GPU, spread over all its xGMI links -- instead of an all-gather of N whole vectors
+ *                    ((N-1) vectors into every GPU). Without it the all-gather path runs.
+ * The device exchanges are supplied by the host language on top of RCCL over xGMI (torch.distributed in
+ * this repository's Python host, an rccl binding in Rust); each must be ordered after the work already
+ * enqueued on `stream` and complete, from the point of view of later work on `stream`, when it returns.
+ * All return 0 or a hipError_t value. */
 typedef struct ovm_shard {
     uint32_t rank, world;
     void *ctx;
     int (*allgather_host)(void *ctx, const void *mine, void *all, uint64_t bytes);
     int (*allgather_device)(void *ctx, const void *d_mine, void *d_all, uint64_t bytes, ovm_stream_t stream);
+    int (*alltoall_device)(void *ctx, const void *d_send, void *d_recv, uint64_t bytes, ovm_stream_t stream);
 } ovm_shard_t;
 
 /* Built-in small exchange for the ranks of one node: a POSIX shared-memory segment `name` (a unique
@@ -371,8 +377,9 @@ int ovm_hip_gkr_shard_selftest(uint32_t world, uint32_t TR, const uint64_t *ends
 const char *ovm_hip_selftest_error(void);
 /* Host-only self-test of a communicator: `rounds` small exchanges of round- and rank-dependent sizes (some
  * larger than one shared-memory slot) through allgather_host, and -- if world > 1 and n > 0 -- one bulk
- * exchange of n extension-field elements through allgather_device, called with HOST pointers and a null
- * stream, whose blocks are then added up with the field's addition and compared with the expected sum.
+ * exchange of n extension-field elements through allgather_device (and, when alltoall_device is set, the
+ * all-to-all + add + all-gather form of the same sum), called with HOST pointers and a null stream, whose
+ * blocks are then added up with the field's addition and compared with the expected sum.
  * This is how the CPU tests exercise the callback a host language supplies (tests/test_shard_cpu.py: gloo). */
 int ovm_hip_shard_exchange_selftest(const ovm_shard_t *shard, uint64_t n, uint32_t rounds, uint64_t seed);
 
@@ -384,8 +391,8 @@ int ovm_hip_shard_exchange_selftest(const ovm_shard_t *shard, uint64_t n, uint32
  * non-decreasing. Every rank calls this with the same key and trace list.
  * Work split: per-trace work (cached-main commitments supplied by the caller, LogUp leaves and the
  * sub-tree over them, round 0, multilinear rounds, its columns of the stacked reduction and of the
- * mu-batch) on the owner; the common-main commitment and WHIR after the batching on rank 0; the
- * transcript replicated on every rank from the all-gathered round values.
+ * mu-batch) on the owner; the Merkle trees of the common-main commitment and of the WHIR rounds are
+ * built by all ranks together; the WHIR folds and the transcript are replicated on every rank.
  * The proof (identical to ovm_hip_prove's on one device, byte for byte) is written on rank 0 only;
  * other ranks return 0 with *proof_len = 0. */
 int ovm_hip_prove_sharded(const ovm_pk_t *pk, const ovm_shard_t *shard, uint32_t n_traces, const ovm_trace_t *traces,

@@ -433,7 +433,7 @@ class ShardStruct(Structure):
     """``ovm_shard_t``."""
 
     _fields_ = [("rank", c_uint32), ("world", c_uint32), ("ctx", c_void_p), ("allgather_host", c_void_p),
-                ("allgather_device", c_void_p)]
+                ("allgather_device", c_void_p), ("alltoall_device", c_void_p)]
 
 
 _AG_DEVICE = ctypes.CFUNCTYPE(c_int, c_void_p, c_void_p, c_void_p, c_uint64, c_void_p)
@@ -453,7 +453,7 @@ class Shard:
     ``name``: the same unique shared-memory name on every rank (e.g. from rank 0 via broadcast_object_list)."""
 
     def __init__(self, rank: int, world: int, name: str, slot_bytes: int = 1 << 20, group=None, host_buffers: bool = False,
-                 bulk: str = "torch"):
+                 bulk: str = "torch", alltoall: bool = True):
         import torch
         import torch.distributed as dist
 
@@ -467,9 +467,76 @@ class Shard:
         self.comm = h
         self._torch, self._dist = torch, dist
         self._cb = _AG_DEVICE(self._allgather_device)
+        self._cb_a2a = _AG_DEVICE(self._alltoall_device)
+        # alltoall=False hands the library a null all-to-all: the mu-batch vectors are then all-gathered whole
         self.abi = ShardStruct(rank, world, h, ctypes.cast(_lib().ovm_hip_shm_allgather, c_void_p),
-                               ctypes.cast(self._cb, c_void_p))
+                               ctypes.cast(self._cb, c_void_p), ctypes.cast(self._cb_a2a, c_void_p) if alltoall else None)
         self.bulk_bytes = 0
+        self.alltoall_calls = 0
+
+    def _alltoall_device(self, ctx, d_send, d_recv, nbytes, stream):
+        """d_recv[s * nbytes ..] = rank s's d_send[rank * nbytes ..] (``nbytes`` per PAIR of ranks)."""
+        try:
+            torch, dist = self._torch, self._dist
+            total = nbytes * self.world
+            self.alltoall_calls += 1
+            self.bulk_bytes += int(total)
+            if self.host_buffers:
+                send = torch.frombuffer((ctypes.c_uint8 * total).from_address(d_send), dtype=torch.uint8)
+                recv = torch.empty(total, dtype=torch.uint8)
+                self._host_alltoall(recv, send, nbytes)
+                ctypes.memmove(d_recv, recv.data_ptr(), total)
+                return 0
+            torch.cuda.current_stream().synchronize()
+            if self.bulk == "shm":  # (tests: ranks sharing one GPU, no process group) every rank's whole vector, then pick
+                send = np.empty(total, dtype=np.uint8)
+                everything = np.empty(total * self.world, dtype=np.uint8)
+                check(_lib().ovm_hip_memcpy_d2h(send.ctypes.data, d_send, total, stream), "ovm_hip_memcpy_d2h")
+                check(_lib().ovm_hip_stream_synchronize(stream), "ovm_hip_stream_synchronize")
+                check(_lib().ovm_hip_shm_allgather(self.comm, send.ctypes.data, everything.ctypes.data, total), "ovm_hip_shm_allgather")
+                recv = np.ascontiguousarray(everything.reshape(self.world, self.world, nbytes)[:, self.rank, :])
+                check(_lib().ovm_hip_memcpy_h2d(d_recv, recv.ctypes.data, total, stream), "ovm_hip_memcpy_h2d")
+                check(_lib().ovm_hip_stream_synchronize(stream), "ovm_hip_stream_synchronize")
+                return 0
+            if dist.get_backend(self.group) == "nccl":
+                dev = torch.device("cuda", torch.cuda.current_device())
+                try:
+                    send = torch.as_tensor(_DevPtr(d_send, total), device=dev)
+                    recv = torch.as_tensor(_DevPtr(d_recv, total), device=dev)
+                    staged = False
+                except Exception:
+                    send = torch.empty(total, dtype=torch.uint8, device=dev)
+                    recv = torch.empty(total, dtype=torch.uint8, device=dev)
+                    check(_lib().ovm_hip_memcpy_d2d(send.data_ptr(), d_send, total, stream), "ovm_hip_memcpy_d2d")
+                    check(_lib().ovm_hip_stream_synchronize(stream), "ovm_hip_stream_synchronize")
+                    staged = True
+                dist.all_to_all_single(recv, send, group=self.group)  # equal splits of nbytes
+                if staged:
+                    torch.cuda.current_stream().synchronize()
+                    check(_lib().ovm_hip_memcpy_d2d(d_recv, recv.data_ptr(), total, stream), "ovm_hip_memcpy_d2d")
+                    check(_lib().ovm_hip_stream_synchronize(stream), "ovm_hip_stream_synchronize")
+            else:  # host-staged (gloo)
+                send = torch.empty(total, dtype=torch.uint8)
+                recv = torch.empty(total, dtype=torch.uint8)
+                check(_lib().ovm_hip_memcpy_d2h(send.data_ptr(), d_send, total, stream), "ovm_hip_memcpy_d2h")
+                check(_lib().ovm_hip_stream_synchronize(stream), "ovm_hip_stream_synchronize")
+                self._host_alltoall(recv, send, nbytes)
+                check(_lib().ovm_hip_memcpy_h2d(d_recv, recv.data_ptr(), total, stream), "ovm_hip_memcpy_h2d")
+                check(_lib().ovm_hip_stream_synchronize(stream), "ovm_hip_stream_synchronize")
+            torch.cuda.current_stream().synchronize()
+            return 0
+        except Exception as e:  # never let an exception cross the C boundary
+            import sys
+            print(f"[ovm] alltoall_device failed on rank {self.rank}: {e!r}", file=sys.stderr, flush=True)
+            return 999
+
+    def _host_alltoall(self, recv, send, nbytes):
+        """CPU tensors: gloo has no all_to_all on every build, so gather everything and pick this rank's slices."""
+        dist = self._dist
+        parts = [self._torch.empty(send.numel(), dtype=self._torch.uint8) for _ in range(self.world)]
+        dist.all_gather(parts, send, group=self.group)
+        for s, part in enumerate(parts):
+            recv[s * nbytes:(s + 1) * nbytes] = part[self.rank * nbytes:(self.rank + 1) * nbytes]
 
     def _allgather_device(self, ctx, d_mine, d_all, nbytes, stream):
         try:

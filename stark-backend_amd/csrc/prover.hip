@@ -2323,7 +2323,10 @@ struct Prover {
         Fp mu_pow_witness = ts.grind(P().mu_pow_bits);
         EF mu = ts.sample_ext();
         unsigned m = l_skip + n_stack;
-        DevBuf<EF> f_a(size_t(1) << m), f_b(size_t(1) << (m - 1)), w_a, w_b;
+        // (sharded with an all-to-all: the vector is exchanged in `world` slices of ceil(2^m / world) elements)
+        const size_t mu_slice = sh.has_alltoall() ? ((size_t(1) << m) + sh.world - 1) / sh.world : 0;
+        const size_t mu_padded = std::max(size_t(1) << m, mu_slice * sh.world);
+        DevBuf<EF> f_a(mu_padded), f_b(size_t(1) << (m - 1)), w_a, w_b;
         {
             ProfScope ps_mu("whir.mu_batch", cx.stream);
             std::vector<EF> mu_pows = powers_of(mu, width);
@@ -2340,14 +2343,26 @@ struct Prover {
         if (!sh.single()) {
             // THE bulk exchange of a sharded proof (north_star: "RCCL allgather only at the FRI batch-opening
             // step"; prover/whir.rs:95-132 batches all commitments into one vector): every rank holds the
-            // mu-weighted sum of ITS columns; all-gather the vectors and add them up. Modular addition is not
-            // an RCCL reduction, hence gather + local add. EVERY rank adds them up and runs the WHIR rounds on the sum
-            // (the folds are cheap; the transcript stays replicated) so that the rounds' Merkle trees -- half of WHIR's
-            // time -- can be built by all ranks together (build_tree); rank 0 alone assembles the proof.
+            // mu-weighted sum of ITS columns and every rank needs the sum over the ranks (modular addition is not
+            // an RCCL reduction). EVERY rank then runs the WHIR rounds on the sum (the folds are cheap; the
+            // transcript stays replicated) so that the rounds' Merkle trees -- half of WHIR's time -- can be built
+            // by all ranks together (build_tree); rank 0 alone assembles the proof.
             OVM_PROF("whir.mu_allgather", cx.stream);
-            DevBuf<EF> gathered((size_t)sh.world << m);
-            sh.allgather_device(f_a.p, gathered.p, sizeof(EF) << m, (ovm_stream_t)cx.stream);
-            OVM_THROW_IF(ef_sum_blocks(gathered.p, sh.world, uint64_t(1) << m, f_a.p, cx.stream));
+            if (sh.has_alltoall()) {
+                // all-to-all (rank r receives slice r of every rank's vector) + add + all-gather of the summed
+                // slices: 2 (N-1)/N vectors through every GPU's links instead of N-1, and xGMI is a full mesh of
+                // point-to-point links, which is the pattern an all-to-all uses best
+                if (mu_padded > (size_t(1) << m))
+                    OVM_THROW_IF(hipMemsetAsync(f_a.p + (size_t(1) << m), 0, (mu_padded - (size_t(1) << m)) * sizeof(EF), cx.stream));
+                DevBuf<EF> recv(mu_padded), red(mu_slice);
+                sh.alltoall_device(f_a.p, recv.p, mu_slice * sizeof(EF), (ovm_stream_t)cx.stream);
+                OVM_THROW_IF(ef_sum_blocks(recv.p, sh.world, mu_slice, red.p, cx.stream));
+                sh.allgather_device(red.p, f_a.p, mu_slice * sizeof(EF), (ovm_stream_t)cx.stream);
+            } else {
+                DevBuf<EF> gathered((size_t)sh.world << m);
+                sh.allgather_device(f_a.p, gathered.p, sizeof(EF) << m, (ovm_stream_t)cx.stream);
+                OVM_THROW_IF(ef_sum_blocks(gathered.p, sh.world, uint64_t(1) << m, f_a.p, cx.stream));
+            }
         }
         w_a.alloc(size_t(1) << m);
         w_b.alloc(size_t(1) << (m - 1));

@@ -289,6 +289,21 @@ int ovm_hip_shard_exchange_selftest(const ovm_shard_t *shard, uint64_t n, uint32
                 for (uint32_t r = 1; r < W; r++) acc = acc + all[r * n + i];
                 if (!(acc == sum[i])) throw OvmFail(1, "selftest: sum of the gathered blocks differs");
             }
+            if (comm.has_alltoall()) {
+                // the same sum as the prover forms it when the all-to-all is there: slices of ceil(n / W)
+                const uint64_t slice = (n + W - 1) / W;
+                std::vector<EF> send(slice * W, EF::zero()), recv(slice * W), red(slice), full(slice * W);
+                std::copy(mine.begin(), mine.end(), send.begin());
+                comm.alltoall_device(send.data(), recv.data(), slice * sizeof(EF), nullptr);
+                for (uint64_t i = 0; i < slice; i++) {
+                    EF acc = recv[i];
+                    for (uint32_t r = 1; r < W; r++) acc = acc + recv[r * slice + i];
+                    red[i] = acc;
+                }
+                comm.allgather_device(red.data(), full.data(), slice * sizeof(EF), nullptr);
+                for (uint64_t i = 0; i < n; i++)
+                    if (!(full[i] == sum[i])) throw OvmFail(1, "selftest: all-to-all form of the sum differs at " + std::to_string(i));
+            }
         }
         for (uint32_t k = 0; k < rounds; k++) {
             // sizes differ per round and rank (allgatherv), some beyond one slot

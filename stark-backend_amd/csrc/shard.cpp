@@ -62,6 +62,12 @@ void ShardComm::allgather_device(const void *d_mine, void *d_all, uint64_t bytes
     if (rc != 0) throw OvmFail(rc, "shard exchange: allgather_device failed");
 }
 
+void ShardComm::alltoall_device(const void *d_send, void *d_recv, uint64_t bytes, ovm_stream_t stream) const {
+    if (!has_alltoall()) throw OvmFail(1, "internal: alltoall_device is null");
+    const int rc = abi->alltoall_device(abi->ctx, d_send, d_recv, bytes, stream);
+    if (rc != 0) throw OvmFail(rc, "shard exchange: alltoall_device failed");
+}
+
 }  // namespace ovm
 
 // ---------------------------------------------------------------------------------------------

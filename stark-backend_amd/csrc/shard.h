@@ -47,6 +47,9 @@ struct ShardComm {
     std::vector<uint8_t> bcast(uint32_t root, const std::vector<uint8_t> &mine) const;
     // device buffers: d_all[r * bytes ..] = rank r's d_mine; stream-ordered after what was enqueued on `stream`
     void allgather_device(const void *d_mine, void *d_all, uint64_t bytes, ovm_stream_t stream) const;
+    // optional: d_recv[s * bytes ..] = rank s's d_send[rank * bytes ..]
+    bool has_alltoall() const { return abi && abi->alltoall_device; }
+    void alltoall_device(const void *d_send, void *d_recv, uint64_t bytes, ovm_stream_t stream) const;
 };
 
 // Append / read plain values in a byte string (the payload format of the small exchanges).

@@ -136,7 +136,8 @@ def test_struct_layouts_match_header(pkg):
     import ctypes
     assert ctypes.sizeof(pkg.TraceStruct) == 48 and pkg.TraceStruct.cached.offset == 40
     assert ctypes.sizeof(pkg.PcsParams) == 16 and ctypes.sizeof(pkg.MatrixStruct) == 24
-    assert ctypes.sizeof(pkg.ShardStruct) == 32 and pkg.ShardStruct.allgather_device.offset == 24
+    assert ctypes.sizeof(pkg.ShardStruct) == 40 and pkg.ShardStruct.allgather_device.offset == 24
+    assert pkg.ShardStruct.alltoall_device.offset == 32
     assert ctypes.sizeof(pkg.ProverConfigStruct) == 24 and pkg.ProverConfigStruct.cache_limit_bytes.offset == 16
 
 
@@ -157,5 +158,5 @@ def test_rust_crate_only_calls_declared_entries():
     assert "0x4F56_4D31" in blob_rs and "0x4F564D31u" in host_h
     assert "0x5052_4550" in blob_rs and "0x50524550u" in host_h
     ffi_rs = open(os.path.join(src, "ffi.rs")).read()
-    for field in ("absorb_idx", "sample_idx", "d_common_main", "num_cached", "allgather_device", "cache_limit_bytes"):
+    for field in ("absorb_idx", "sample_idx", "d_common_main", "num_cached", "allgather_device", "alltoall_device", "cache_limit_bytes"):
         assert f"pub {field}:" in ffi_rs

@@ -25,13 +25,13 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def run_sharded(case, world, tmp_path, repeat=1, save_memory=False):
+def run_sharded(case, world, tmp_path, repeat=1, save_memory=False, alltoall=True):
     port, shm, out = _free_port(), f"/ovm-test-{uuid.uuid4().hex[:12]}", str(tmp_path / "proof.bin")
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
     env["OVM_SHARD_TIMEOUT_S"] = "60"  # a rank that died must not hold the others for minutes
     procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "shard_worker.py"), "--rank", str(r), "--world", str(world),
                                "--port", str(port), "--case", case, "--shm", shm, "--out", out, "--repeat", str(repeat)]
-                              + (["--save-memory"] if save_memory else []),
+                              + (["--save-memory"] if save_memory else []) + ([] if alltoall else ["--no-alltoall"]),
                               env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
     logs = []
     for p in procs:
@@ -80,6 +80,15 @@ def test_sharded_in_the_memory_bounded_modes(orc, tmp_path):
     assert run_sharded("bench_app", 2, tmp_path, save_memory=True) == want
 
 
+@pytest.mark.parametrize("case,world", [("bench_app", 2), ("bench8", 3)])
+def test_sum_of_the_mu_batch_vectors_by_allgather_only(orc, tmp_path, case, world):
+    """A communicator without alltoall_device (the callback is optional): the ranks' mu-batch vectors are all-gathered
+    whole and added up -- the same proof as with the all-to-all + add + all-gather every other test here runs
+    (3 ranks: slices of ceil(2^m / 3) elements, a padded tail)."""
+    blob, want = oracle_proof(orc, case, world)
+    assert run_sharded(case, world, tmp_path, alltoall=False) == want
+
+
 def test_single_process_equals_sharded(dev, pkg, orc, tmp_path):
     """The same context through ovm_hip_prove in this process (one device, one rank)."""
     params, air_list, traces, owners = shard_cases.make("bench_app", 2)
@@ -109,8 +118,8 @@ def test_config_d_full_size_two_shards_on_one_gpu_verifies(orc, tmp_path):
 
 def test_bulk_exchange_callback_on_nccl(tmp_path):
     """The RCCL branch of the Python host's bulk exchange (the one line that differs from the gloo branch the
-    logical-shard tests use): zero-copy torch views of raw device ranges + all_gather_into_tensor on the nccl
-    backend. One GPU is all this box has, so the group has one rank; run in a child process (its own
+    logical-shard tests use): zero-copy torch views of raw device ranges + all_gather_into_tensor /
+    all_to_all_single on the nccl backend. One GPU is all this box has, so the group has one rank; run in a child process (its own
     process group)."""
     code = """
 import os, sys, ctypes
@@ -129,6 +138,10 @@ rc = shard._allgather_device(None, src.data_ptr(), dst.data_ptr(), src.numel() *
 torch.cuda.synchronize()
 assert rc == 0 and torch.equal(src, dst), rc
 assert shard.bulk_bytes == 4 << 20
+dst.zero_()
+rc = shard._alltoall_device(None, src.data_ptr(), dst.data_ptr(), src.numel() * 4, dev.stream.value or 0)
+torch.cuda.synchronize()
+assert rc == 0 and torch.equal(src, dst) and shard.alltoall_calls == 1, rc
 shard.close()
 dist.destroy_process_group()
 print("nccl bulk exchange ok")

@@ -50,7 +50,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, shm, q):
+def _worker(rank, world, port, shm, q, alltoall=True):
     import sys
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     import torch.distributed as dist
@@ -59,21 +59,25 @@ def _worker(rank, world, port, shm, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     pkg = load_pkg()
     try:
-        shard = pkg.Shard(rank, world, shm, slot_bytes=1 << 16, host_buffers=True)
-        pkg.shard_exchange_selftest(shard, n=5000, rounds=200, seed=5)
-        q.put((rank, "ok", shard.bulk_bytes))
+        shard = pkg.Shard(rank, world, shm, slot_bytes=1 << 16, host_buffers=True, alltoall=alltoall)
+        pkg.shard_exchange_selftest(shard, n=5001, rounds=200, seed=5)
+        q.put((rank, "ok", shard.bulk_bytes, shard.alltoall_calls))
         shard.close()
     except Exception as e:  # noqa: BLE001
-        q.put((rank, repr(e), 0))
+        q.put((rank, repr(e), 0, 0))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_exchange_protocol_world2_gloo():
+@pytest.mark.parametrize("alltoall", [True, False])
+def test_exchange_protocol_world2_gloo(alltoall):
+    """Two real processes: the small exchanges through shared memory, the bulk ones through the Python callbacks on
+    gloo -- the all-gather of whole vectors and (alltoall=True) the all-to-all + add + all-gather form of the same sum,
+    on a length that does not divide by the world size."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port, shm = _free_port(), f"/ovm-test-{uuid.uuid4().hex[:12]}"
-    ps = [ctx.Process(target=_worker, args=(r, 2, port, shm, q)) for r in range(2)]
+    ps = [ctx.Process(target=_worker, args=(r, 2, port, shm, q, alltoall)) for r in range(2)]
     for p in ps:
         p.start()
     res = sorted(q.get(timeout=180) for _ in range(2))
@@ -81,5 +85,8 @@ def test_exchange_protocol_world2_gloo():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert [r[1] for r in res] == ["ok", "ok"], res
-    assert all(r[2] == 2 * 5000 * 16 for r in res)          # one bulk exchange of n EF elements per rank
+    n, sl = 5001, 2501                                       # slice = ceil(n / 2)
+    whole = 2 * n * 16                                        # the all-gather of whole vectors
+    assert all(r[2] == (whole + 2 * (2 * sl * 16) if alltoall else whole) for r in res)
+    assert all(r[3] == (1 if alltoall else 0) for r in res)
     assert not os.path.exists("/dev/shm" + shm)              # the segment's name is gone after the handshake
