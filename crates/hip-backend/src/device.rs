@@ -43,6 +43,51 @@ impl ProverBackend for HipBackend {
     }
 }
 
+/// Memory-bounded modes (peer of `GpuProverConfig`, cuda-backend/src/device.rs:25-30). The defaults keep
+/// everything resident -- 288 GB of HBM is the normal case; proofs are identical in every mode.
+/// `cache_stacked_matrix` has no counterpart: column-major traces stack by concatenation and a trace
+/// that fills the stacked matrix is never copied.
+#[derive(Clone, Copy, Debug)]
+pub struct HipProverConfig {
+    /// `false`: a commitment drops its codeword once the Merkle tree is built; WHIR re-encodes it when
+    /// it opens rows (cuda-backend/src/whir.rs:404-416).
+    pub cache_rs_code_matrix: bool,
+    /// `true`: round 0 extends and evaluates a tall trace in slabs of `2^round0_slab_log_rows` rows.
+    pub zerocheck_save_memory: bool,
+    pub round0_slab_log_rows: u32,
+    /// `true`: the leaf layer of the LogUp fraction tree is dropped after the first tree layer is built
+    /// and generated again for the last layer's sumcheck (the CUDA backend's reversible in-place tree,
+    /// docs/cuda-backend/gkr-prover.md:129-133, answers the same need).
+    pub gkr_drop_leaves: bool,
+    /// Upper bound on what the thread's caching allocator keeps in free blocks (0: unbounded).
+    pub cache_limit_bytes: u64,
+}
+impl Default for HipProverConfig {
+    fn default() -> Self {
+        Self {
+            cache_rs_code_matrix: true,
+            zerocheck_save_memory: false,
+            round0_slab_log_rows: 20,
+            gkr_drop_leaves: false,
+            cache_limit_bytes: 0,
+        }
+    }
+}
+impl HipProverConfig {
+    /// Applies to the provers of the CALLING thread (one engine per OS thread).
+    pub fn apply(&self) -> Result<(), HipError> {
+        let cfg = ffi::OvmProverConfig {
+            cache_rs_code_matrix: self.cache_rs_code_matrix as u32,
+            zerocheck_save_memory: self.zerocheck_save_memory as u32,
+            round0_slab_log_rows: self.round0_slab_log_rows,
+            gkr_drop_leaves: self.gkr_drop_leaves as u32,
+            cache_limit_bytes: self.cache_limit_bytes,
+        };
+        // SAFETY: plain struct, read during the call only.
+        HipError::from_result("ovm_hip_set_prover_config", unsafe { ffi::ovm_hip_set_prover_config(&cfg) })
+    }
+}
+
 /// Stream-owning device handle (cuda-backend/src/device.rs:49-58). `Clone` shares the stream: one
 /// engine per OS thread is the supported concurrency (cuda-backend/examples/keccakf.rs:88-131).
 #[derive(Clone)]

@@ -72,7 +72,7 @@ pub struct OvmProverConfig {
     pub cache_rs_code_matrix: u32,
     pub zerocheck_save_memory: u32,
     pub round0_slab_log_rows: u32,
-    pub _pad: u32,
+    pub gkr_drop_leaves: u32,
     pub cache_limit_bytes: u64,
 }
 

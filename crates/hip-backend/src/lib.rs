@@ -25,7 +25,7 @@ mod engine;
 mod error;
 
 pub use base::{AirDataHip, DeviceBuffer, HipMatrix, StackedPcsDataHip};
-pub use device::{HipBackend, HipDevice, HipDeviceCtx};
+pub use device::{HipBackend, HipDevice, HipDeviceCtx, HipProverConfig};
 pub use engine::HipEngine;
 pub use error::*;
 pub use transcript::DuplexSpongeHip;

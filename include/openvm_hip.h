@@ -203,6 +203,13 @@ int ovm_hip_host_permute_selftest(uint32_t n, uint64_t seed);
  *   zerocheck_save_memory = 1  round 0 extends and evaluates a tall trace in slabs of 2^round0_slab_log_rows rows
  *                              (0 = default 20): the coset-LDE buffer shrinks from
  *                              ovm_hip_constraint_eval_buffer_size(pk, air) x height to that x the slab.
+ *   gkr_drop_leaves = 1        the leaf layer of the LogUp fraction tree (the largest: 5 of the tree's 13 units)
+ *                              is dropped once the layer above it is built and generated again, from the trace,
+ *                              when the last layer's sumcheck needs it -- by then the rest of the tree is gone.
+ *                              Peak of the tree: leaves + first layer (9 units) instead of everything (13). The
+ *                              reference's CUDA backend halves its tree by un-adding fractions in place
+ *                              (docs/cuda-backend/gkr-prover.md:129-133), which costs extension-field inversions;
+ *                              generating the leaves twice costs 0.7 ms at config D.
  *   cache_limit_bytes          upper bound on the device memory the thread's caching allocator keeps in free
  *                              blocks (0 = unbounded); blocks beyond it go back to the driver.
  * Proofs are identical in every mode. The stacked matrix is never copied when one trace fills it
@@ -211,7 +218,7 @@ typedef struct ovm_prover_config {
     uint32_t cache_rs_code_matrix;
     uint32_t zerocheck_save_memory;
     uint32_t round0_slab_log_rows;
-    uint32_t _pad;
+    uint32_t gkr_drop_leaves;
     uint64_t cache_limit_bytes;
 } ovm_prover_config_t;
 int ovm_hip_set_prover_config(const ovm_prover_config_t *cfg);

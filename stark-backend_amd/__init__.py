@@ -60,7 +60,7 @@ class ProverConfigStruct(Structure):
     """``ovm_prover_config_t`` (reference: GpuProverConfig, crates/cuda-backend/src/device.rs:25-30)."""
 
     _fields_ = [("cache_rs_code_matrix", c_uint32), ("zerocheck_save_memory", c_uint32), ("round0_slab_log_rows", c_uint32),
-                ("_pad", c_uint32), ("cache_limit_bytes", c_uint64)]
+                ("gkr_drop_leaves", c_uint32), ("cache_limit_bytes", c_uint64)]
 
 
 class SpongeState(Structure):
@@ -688,9 +688,10 @@ def staged_selftest(blob, stage_rows: int, acc_rows: int, seed: int = 1) -> int:
 
 
 def set_prover_config(cache_rs_code_matrix: bool = True, zerocheck_save_memory: bool = False,
-                      round0_slab_log_rows: int = 0, cache_limit_bytes: int = 0) -> None:
+                      round0_slab_log_rows: int = 0, cache_limit_bytes: int = 0, gkr_drop_leaves: bool = False) -> None:
     """Memory-bounded modes of the calling thread's provers (include/openvm_hip.h: ovm_prover_config_t)."""
-    cfg = ProverConfigStruct(int(cache_rs_code_matrix), int(zerocheck_save_memory), round0_slab_log_rows, 0, cache_limit_bytes)
+    cfg = ProverConfigStruct(int(cache_rs_code_matrix), int(zerocheck_save_memory), round0_slab_log_rows, int(gkr_drop_leaves),
+                             cache_limit_bytes)
     check(_lib().ovm_hip_set_prover_config(ctypes.byref(cfg)), "ovm_hip_set_prover_config")
 
 

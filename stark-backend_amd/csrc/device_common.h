@@ -20,13 +20,16 @@ struct EFPlanes {
     uint32_t *p;
     uint64_t stride;
 };
-// Fractions: numerator limbs in planes 0..3, denominator limbs in planes 4..7.
+// Fractions: numerator limbs in 4 planes from p, denominator limbs in 4 planes from p + q_off (normally the
+// next four planes; a layer whose numerators are base-field values keeps ONE numerator plane and q_off = stride).
 struct FracPlanes {
     uint32_t *p;
     uint64_t stride;
+    uint64_t q_off;
+    BB_HD static FracPlanes make(uint32_t *p, uint64_t stride) { return FracPlanes{p, stride, 4 * stride}; }
     BB_HD uint32_t *P() const { return p; }
-    BB_HD uint32_t *Q() const { return p + 4 * stride; }
-    BB_HD FracPlanes at(uint64_t first) const { return FracPlanes{p + first, stride}; }
+    BB_HD uint32_t *Q() const { return p + q_off; }
+    BB_HD FracPlanes at(uint64_t first) const { return FracPlanes{p + first, stride, q_off}; }
 };
 
 // Destination of a reduction (stages.hip "last workgroup finishes"): per-workgroup partial

@@ -174,7 +174,6 @@ int gkr_read_list(FracPlanes t, const uint64_t *d_pos, const uint32_t *d_pbase, 
 int gkr_edge_records(FracPlanes src, uint64_t at0, uint64_t at1, uint32_t n0, uint32_t n1, bool p_base, bool fold, EF r,
                      const RedOut &ro, hipStream_t s);
 // p_base: leaf numerators are base-field, only limb plane 0 of P is written / read (stages.hip)
-int gkr_fill_leaves(FracPlanes leaves, uint64_t n, EF alpha, bool p_base, hipStream_t s);
 // The leaf kernels of many traces in one launch (staged programs, one row per lane): job j owns
 // workgroups [wg0, wg0 + gx).
 struct LeavesJob {

@@ -116,6 +116,8 @@ struct ProverConfig {
                                          // and re-encoded when WHIR opens rows of it (cuda-backend/src/whir.rs:404-416)
     bool zerocheck_save_memory = false;  // true: round 0 extends and evaluates a tall trace in slabs of rows
     unsigned round0_slab_log_rows = 20;  // slab size in that mode
+    bool gkr_drop_leaves = false;        // true: the leaf layer of the LogUp fraction tree is dropped once the layer above
+                                         // it is built and generated again for the last layer's sumcheck
 };
 inline ProverConfig &prover_config() {
     static thread_local ProverConfig cfg;
@@ -781,19 +783,24 @@ struct Prover {
         const unsigned TR;
         const bool p_base;  // big trees: only limb 0 of the leaf numerators exists
         std::vector<uint64_t> toff, fb;  // per layer: plane offset of my window, global index of its element 0
-        uint64_t tree_stride = 0, wcap = 0;
-        DevBuf<uint32_t> tree_buf, rec_a, rec_b, eq_buf;
+        uint64_t tree_stride = 0, leaf_stride = 0, wcap = 0;
+        // The layers above the leaves share one buffer (a window per layer); the leaf layer has its own: with
+        // base-field numerators it is 5 planes, not 8, and in the memory-bounded mode it is dropped once the layer
+        // above exists and generated again for the last layer's sumcheck (make_leaves).
+        DevBuf<uint32_t> tree_buf, leaf_buf, rec_a, rec_b, eq_buf;
         DevBuf<EF> partials;
         EqHeapPlan hp;
         uint64_t eq_stride = 0;
         std::vector<uint64_t> rbase;  // rbase[sr]: global record index of element 0 of table(sr)'s buffer (sr >= 1)
         std::vector<URange> Rchain;   // Rchain[s] = my records of table(s) of the current layer
+        bool drop_leaves = false;             // ProverConfig::gkr_drop_leaves (and a tree of at least two layers)
+        std::function<void()> make_leaves;    // enqueues the leaf kernels into leaves()
 
         static uint64_t up64(uint64_t x) { return (x + 63) & ~uint64_t(63); }
         GkrDevice(Prover &pr_, const GkrPlan &pl, bool p_base_)
             : pr(pr_), plan(pl), me(pr_.sh.rank), TR(pl.TR), p_base(p_base_), toff(pl.TR + 1, 0), fb(pl.TR + 1, 0) {
             uint64_t cur = 0;
-            for (unsigned j = 0; j <= TR; j++) {
+            for (unsigned j = 0; j < TR; j++) {
                 const URange &r = plan.F[j][me];
                 toff[j] = cur;
                 if (r.empty()) continue;
@@ -804,22 +811,41 @@ struct Prover {
             // HBM channels)
             tree_stride = std::max<uint64_t>(cur, 64) + PLANE_SKEW;
             tree_buf.alloc(8 * tree_stride);
+            const URange &lr = plan.F[TR][me];
+            if (!lr.empty()) fb[TR] = lr.lo & ~uint64_t(63);
+            leaf_stride = std::max<uint64_t>(lr.empty() ? 0 : up64(lr.hi - fb[TR]), 64) + PLANE_SKEW;
+            alloc_leaves();
+            drop_leaves = prover_config().gkr_drop_leaves && TR >= 3;
+            partials.alloc(RED_BLOCKS * 4);
+            // (memory-bounded mode: the sumcheck buffers come when the build is over, sized for the layers above the
+            // leaves, and again -- with the tree gone -- for the leaf layer: begin_layer)
+            if (!drop_leaves) alloc_round_buffers(TR >= 1 ? TR - 1 : 0);
+        }
+        // the folded tables and the eq heap of the layer sumchecks up to `last_round`
+        void alloc_round_buffers(unsigned last_round) {
+            rec_a.release(), rec_b.release(), eq_buf.release();
             // folded tables: table(1) holds at most half of the layer's records (+ alignment slack), 2 fractions each
-            wcap = up64(plan.F[TR][me].size() / 2 + 128) + PLANE_SKEW;
+            wcap = up64(plan.F[std::min(last_round + 1, TR)][me].size() / 2 + 128) + PLANE_SKEW;
             rec_a.alloc(8 * wcap);
             rec_b.alloc(8 * wcap);
             uint64_t eq_total = 64;
-            for (unsigned round = 1; round < TR; round++) eq_total = std::max(eq_total, heap_plan_for(round).total);
+            for (unsigned round = 1; round <= last_round && round < TR; round++) eq_total = std::max(eq_total, heap_plan_for(round).total);
             eq_stride = up64(eq_total) + PLANE_SKEW;
             eq_buf.alloc(4 * eq_stride);
-            partials.alloc(RED_BLOCKS * 4);
         }
-        FracPlanes tree() const { return FracPlanes{tree_buf.p, tree_stride}; }
+        void alloc_leaves() { leaf_buf.alloc((p_base ? 5 : 8) * leaf_stride); }
+        FracPlanes tree() const { return FracPlanes::make(tree_buf.p, tree_stride); }
+        // element 0 = global leaf fb[TR]; base-field numerators: ONE numerator plane, the denominator planes follow it
+        FracPlanes leaves() const {
+            if (!leaf_buf.p) throw OvmFail(1, "internal: the leaf layer is not resident");
+            return p_base ? FracPlanes{leaf_buf.p, leaf_stride, leaf_stride} : FracPlanes::make(leaf_buf.p, leaf_stride);
+        }
+        // planes positioned at element 0 of my window of layer j
+        FracPlanes layer_planes(unsigned j) const { return j == TR ? leaves() : tree().at(toff[j]); }
         // planes positioned at global fraction i of layer j (i inside my window)
-        FracPlanes layer_at(unsigned j, uint64_t i) const { return tree().at(toff[j] + (i - fb[j])); }
-        FracPlanes leaves() const { return tree().at(toff[TR]); }  // element 0 = global leaf fb[TR]
+        FracPlanes layer_at(unsigned j, uint64_t i) const { return layer_planes(j).at(i - fb[j]); }
         uint64_t leaf_origin() const { return fb[TR]; }
-        FracPlanes recs(unsigned sr) const { return FracPlanes{(sr & 1) ? rec_b.p : rec_a.p, wcap}; }
+        FracPlanes recs(unsigned sr) const { return FracPlanes::make((sr & 1) ? rec_b.p : rec_a.p, wcap); }
 
         // my record ranges of a layer's tables: chain[0] = records of the layer, chain[s + 1] = up(chain[s])
         std::vector<URange> chain_for(unsigned round) const {
@@ -840,7 +866,7 @@ struct Prover {
             const URange &r = plan.F[TR][me];
             if (p_base || r.empty()) return;
             for (int k = 1; k < 4; k++)
-                OVM_THROW_IF(hipMemsetAsync(leaves().p + k * tree_stride + (r.lo - fb[TR]), 0, r.size() * sizeof(uint32_t), pr.cx.stream));
+                OVM_THROW_IF(hipMemsetAsync(leaves().p + k * leaf_stride + (r.lo - fb[TR]), 0, r.size() * sizeof(uint32_t), pr.cx.stream));
         }
         void build() {
             for (unsigned j = TR; j-- > 0;) {
@@ -850,28 +876,47 @@ struct Prover {
             }
         }
         void read_layer_edges(std::vector<std::array<Frac, 2>> &out) override {
-            std::vector<uint64_t> pos;
-            std::vector<uint32_t> pb;
-            std::vector<std::pair<unsigned, int>> where;
-            for (unsigned j = 0; j <= TR; j++) {
-                const URange &r = plan.F[j][me];
-                if (r.empty()) continue;
-                for (int e = 0; e < 2; e++) {
-                    pos.push_back(toff[j] + ((e ? r.hi - 1 : r.lo) - fb[j]));
-                    pb.push_back(p_base && j == TR ? 1 : 0);
-                    where.push_back({j, e});
+            // (the leaf layer lives in its own buffer: its two edge fractions are a list of their own)
+            for (int part = 0; part < 2; part++) {
+                std::vector<uint64_t> pos;
+                std::vector<uint32_t> pb;
+                std::vector<std::pair<unsigned, int>> where;
+                for (unsigned j = part ? TR : 0; j < (part ? TR + 1 : TR); j++) {
+                    const URange &r = plan.F[j][me];
+                    if (r.empty()) continue;
+                    for (int e = 0; e < 2; e++) {
+                        pos.push_back((j == TR ? 0 : toff[j]) + ((e ? r.hi - 1 : r.lo) - fb[j]));
+                        pb.push_back(p_base && j == TR ? 1 : 0);
+                        where.push_back({j, e});
+                    }
+                }
+                if (pos.empty()) continue;
+                const FracPlanes planes = part ? leaves() : tree();
+                for (size_t at = 0; at < pos.size(); at += 32) {
+                    const uint32_t n = (uint32_t)std::min<size_t>(32, pos.size() - at);
+                    auto d_pos = pr.cx.upload(std::vector<uint64_t>(pos.begin() + at, pos.begin() + at + n));
+                    auto d_pb = pr.cx.upload(std::vector<uint32_t>(pb.begin() + at, pb.begin() + at + n));
+                    OVM_THROW_IF(gkr_read_list(planes, d_pos.p, d_pb.p, n, pr.mb.arm(nullptr), pr.cx.stream));
+                    auto v = pr.mb.take(2 * n, pr.cx.stream);
+                    for (uint32_t i = 0; i < n; i++) out[where[at + i].first][where[at + i].second] = Frac{v[2 * i], v[2 * i + 1]};
                 }
             }
-            for (size_t at = 0; at < pos.size(); at += 32) {
-                const uint32_t n = (uint32_t)std::min<size_t>(32, pos.size() - at);
-                auto d_pos = pr.cx.upload(std::vector<uint64_t>(pos.begin() + at, pos.begin() + at + n));
-                auto d_pb = pr.cx.upload(std::vector<uint32_t>(pb.begin() + at, pb.begin() + at + n));
-                OVM_THROW_IF(gkr_read_list(tree(), d_pos.p, d_pb.p, n, pr.mb.arm(nullptr), pr.cx.stream));
-                auto v = pr.mb.take(2 * n, pr.cx.stream);
-                for (uint32_t i = 0; i < n; i++) out[where[at + i].first][where[at + i].second] = Frac{v[2 * i], v[2 * i + 1]};
-            }
+            // memory-bounded mode: every layer above exists and the edges are with the host -- the leaves can go
+            // (the mailbox reads above have drained the stream: nothing in flight reads them)
+            if (drop_leaves) leaf_buf.release();
         }
         void begin_layer(unsigned round, const std::vector<EF> &point) override {
+            if (drop_leaves && round == 1) alloc_round_buffers(TR - 2);
+            if (drop_leaves && round + 1 == TR) {
+                // the last layer's sumcheck reads the leaves and nothing above them: the rest of the tree makes room
+                // for the leaves, which are generated a second time (0.7 ms at config D), and for tables of their size
+                OVM_THROW_IF(hipStreamSynchronize(pr.cx.stream));
+                tree_buf.release();
+                alloc_round_buffers(TR - 1);
+                alloc_leaves();
+                clear_leaf_numerators();
+                make_leaves();
+            }
             Rchain = chain_for(round);
             hp = heap_plan_for(round);
             rbase.assign(round + 1, 0);
@@ -902,7 +947,7 @@ struct Prover {
                 for (uint32_t k = n0 + 1; k < n_edges; k++)
                     if (edge_idx[k] != edge_idx[k - 1] + 1) throw OvmFail(1, "internal: more than two runs of edge records");
                 const unsigned L = round + 1;
-                const FracPlanes base = sr <= 1 ? tree().at(toff[L]) : recs(sr - 1);
+                const FracPlanes base = sr <= 1 ? layer_planes(L) : recs(sr - 1);
                 auto at_of = [&](uint64_t e) -> uint64_t {
                     return sr == 0 ? 2 * e - fb[L] : sr == 1 ? 4 * e - fb[L] : 2 * (2 * e - rbase[sr - 1]);
                 };
@@ -1021,16 +1066,19 @@ struct Prover {
         // big trees: only limb 0 of the leaf numerators exists (small ones are read through generic paths)
         const bool p_base = TR >= 12;
         GkrDevice gd(*this, plan, p_base);
-        ProfScope *ps_leaves = new ProfScope("gkr.leaves", cx.stream);
-        gd.clear_leaf_numerators();
+        // What the leaf kernels of this rank's traces need, kept until the tree no longer wants its leaves (the
+        // memory-bounded mode launches them a second time); traces of fewer than 2^20 rows share one launch.
         struct LeafKeep {
             ProgDev pd;
             DevBuf<EF> lc;
             DevBuf<uint64_t> lb;
             DevBuf<uint32_t> ll;
+            Fp norm;
+            size_t t;
+            bool batched;
         };
-        std::vector<LeafKeep> leaf_keep;
-        std::vector<LeavesJob> leaf_jobs;
+        auto leaf_keep = std::make_shared<std::vector<LeafKeep>>();
+        auto leaf_jobs = std::make_shared<std::vector<LeavesJob>>();
         for (size_t t = 0; t < T; t++) {
             const AirKey &a = air(t);
             if (a.interactions.empty() || !mine(t)) continue;
@@ -1050,28 +1098,35 @@ struct Prover {
             Fp norm = fp(uint64_t(1) << (tv[t].log_lifted - tv[t].log_height)).inv();
             // staged for one row per lane (log_lifted 0 selects that plan)
             ProgDev pd = make_prog(std::move(progs[t].leaves), beta_pows, true, 0, 1);
-            if (pd.staged.blocks && tv[t].log_height < 20) {
-                // small traces: one launch for all of them after the loop (the buffers stay alive till then)
+            const bool batched = pd.staged.blocks && tv[t].log_height < 20;
+            if (batched) {
                 LeavesJob j{};
                 j.prog = pd.staged, j.leaf_const = d_lc.p, j.cols = tv[t].cols.p, j.leaf_base = d_lb.p;
                 j.leaf_log_len = d_ll.p, j.norm = norm, j.log_height = tv[t].log_height;
                 j.gx = (uint32_t)ceil_div(1ull << tv[t].log_height, 256);
-                j.wg0 = leaf_jobs.empty() ? 0 : leaf_jobs.back().wg0 + leaf_jobs.back().gx;
-                leaf_jobs.push_back(j);
-                leaf_keep.push_back(LeafKeep{std::move(pd), std::move(d_lc), std::move(d_lb), std::move(d_ll)});
-            } else {
-                OVM_THROW_IF(gkr_eval_leaves(pd.dev(), pd.staged, d_lc.p, tv[t].cols.p, tv[t].log_height, d_lb.p, d_ll.p,
-                                             norm, gd.leaves(), cx.stream));
+                j.wg0 = leaf_jobs->empty() ? 0 : leaf_jobs->back().wg0 + leaf_jobs->back().gx;
+                leaf_jobs->push_back(j);
             }
+            leaf_keep->push_back(LeafKeep{std::move(pd), std::move(d_lc), std::move(d_lb), std::move(d_ll), norm, t, batched});
+        }
+        gd.make_leaves = [this, &gd, &tv, leaf_keep, leaf_jobs]() {
+            for (const LeafKeep &k : *leaf_keep)
+                if (!k.batched)
+                    OVM_THROW_IF(gkr_eval_leaves(k.pd.dev(), k.pd.staged, k.lc.p, tv[k.t].cols.p, tv[k.t].log_height, k.lb.p, k.ll.p,
+                                                 k.norm, gd.leaves(), cx.stream));
+            if (!leaf_jobs->empty()) {
+                auto d_jobs = cx.upload(*leaf_jobs);
+                OVM_THROW_IF(gkr_eval_leaves_batched(d_jobs.p, leaf_jobs->data(), (uint32_t)leaf_jobs->size(), gd.leaves(), cx.stream));
+            }
+        };
+        {
+            OVM_PROF("gkr.leaves", cx.stream);
+            gd.clear_leaf_numerators();
+            gd.make_leaves();
             // no synchronisation: the temporaries go back to the block cache and are only ever reused
             // by later work on this same stream
+            if (!gd.drop_leaves) leaf_keep->clear(), leaf_jobs->clear();
         }
-        if (!leaf_jobs.empty()) {
-            auto d_jobs = cx.upload(leaf_jobs);
-            OVM_THROW_IF(gkr_eval_leaves_batched(d_jobs.p, leaf_jobs.data(), (uint32_t)leaf_jobs.size(), gd.leaves(), cx.stream));
-        }
-        leaf_keep.clear();
-        delete ps_leaves;
         {
             OVM_PROF("gkr.build_tree", cx.stream);
             wt.mark("rap.gkr.leaves");
@@ -3034,6 +3089,7 @@ int ovm_hip_set_prover_config(const ovm_prover_config_t *cfg) {
     c.cache_rs_code_matrix = cfg->cache_rs_code_matrix != 0;
     c.zerocheck_save_memory = cfg->zerocheck_save_memory != 0;
     if (cfg->round0_slab_log_rows) c.round0_slab_log_rows = cfg->round0_slab_log_rows;
+    c.gkr_drop_leaves = cfg->gkr_drop_leaves != 0;
     block_cache().limit_bytes = cfg->cache_limit_bytes;
     if (cfg->cache_limit_bytes && block_cache().cached_bytes > cfg->cache_limit_bytes) block_cache().trim();
     return 0;

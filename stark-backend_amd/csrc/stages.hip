@@ -1327,21 +1327,6 @@ __device__ __forceinline__ void ldp4_base(const uint32_t *b, uint64_t i, EF (&e)
     e[3] = EF::from_base(Fp::raw(v.w));
 }
 
-__global__ void gkr_fill_kernel(FracPlanes leaves, uint64_t n, EF alpha, bool p_base) {
-    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    if (p_base)
-        leaves.P()[i] = 0;
-    else
-        stp(leaves.P(), leaves.stride, i, EF::zero());
-    stp(leaves.Q(), leaves.stride, i, alpha);
-}
-int gkr_fill_leaves(FracPlanes leaves, uint64_t n, EF alpha, bool p_base, hipStream_t s) {
-    hipLaunchKernelGGL(gkr_fill_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, s, leaves, n, alpha, p_base);
-    OVM_CHECK_LAUNCH();
-    return 0;
-}
-
 template <int NS>
 struct InterpLeaves {
     DevProgram prog;

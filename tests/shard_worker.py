@@ -22,7 +22,7 @@ def main():
     ap.add_argument("--out", required=True)
     ap.add_argument("--repeat", type=int, default=1)
     ap.add_argument("--save-memory", action="store_true",
-                    help="prove in the memory-bounded modes (codeword dropped, round 0 in slabs of 8 rows)")
+                    help="prove in the memory-bounded modes (codeword dropped, round 0 in slabs of 8 rows, leaf layer dropped)")
     ap.add_argument("--no-alltoall", action="store_true",
                     help="hand the library a null alltoall_device: the mu-batch vectors are all-gathered whole")
     args = ap.parse_args()
@@ -40,7 +40,7 @@ def main():
     t_pg = time.time()
     dev = pkg.Device(0)
     if args.save_memory:
-        pkg.set_prover_config(cache_rs_code_matrix=False, zerocheck_save_memory=True, round0_slab_log_rows=3)
+        pkg.set_prover_config(cache_rs_code_matrix=False, zerocheck_save_memory=True, round0_slab_log_rows=3, gkr_drop_leaves=True)
     shard = pkg.Shard(args.rank, args.world, args.shm, bulk="shm", alltoall=not args.no_alltoall)
     if args.case.startswith("gen:"):
         # "gen:<log_rows>:<cols>:<log_stacked_height>": one partitioned BenchmarkAir per rank under app parameters, the

@@ -48,7 +48,41 @@ def test_modes_keep_the_proof_and_lower_the_peak(dev, pkg, orc):
     # (at this size the peak is not in round 0; the strict drop is asserted at config E below)
     assert peak1 <= peak_base and peak2 <= peak_base and peak3 <= peak_base
     assert pkg.memory_stats()["cached"] <= 64 << 20
-    print(f"peak bytes: resident {peak_base}, no codeword cache {peak1}, slabs {peak2}, both + capped cache {peak3}")
+    pkg.set_prover_config(gkr_drop_leaves=True)   # 2^16 rows x 10 interaction slices: a 2^20-leaf tree, base-field numerators
+    p4, peak4 = _prove(dev, pkg, pk, [(0, d, h, [])])
+    assert p4 == base and peak4 <= peak_base + (1 << 20)   # (the peak is elsewhere at this shape: see the next test)
+    print(f"peak bytes: resident {peak_base}, no codeword cache {peak1}, slabs {peak2}, both + capped cache {peak3}, "
+          f"leaf layer dropped {peak4}")
+
+
+def test_dropping_the_leaf_layer_lowers_a_tree_bound_peak(dev, pkg, orc):
+    """An AIR whose fraction tree is what peaks (8 columns, 32 interaction pairs, 2^16 rows: a 2^22-leaf tree against a
+    2 MB codeword): with gkr_drop_leaves the allocator's peak drops by well over the leaf layer's share, and the proof
+    is the oracle's."""
+    params = airs.test_params(l_skip=4, n_stack=12, k_whir=4)
+    air = airs.uniform_runner_air(8, interactions_per_col=4.0)
+    blob = airs.pk_blob(params, [air])
+    pk = pkg.ProvingKey(blob)
+    h = 1 << 16
+    tr = airs.splitmix64_bits(5, 8 * h)
+    d = dev.upload(pkg.to_mont(tr))
+    base, peak_base = _prove(dev, pkg, pk, [(0, d, h, [])])
+    assert base == orc.prove(blob, [(0, tr, h, [])])["proof"]
+    pkg.set_prover_config(gkr_drop_leaves=True)
+    dropped, peak_drop = _prove(dev, pkg, pk, [(0, d, h, [])])
+    assert dropped == base
+    print(f"tree-bound AIR: peak {peak_base / 2**20:.1f} MiB resident, {peak_drop / 2**20:.1f} MiB with the leaf layer dropped")
+    assert peak_drop < 0.85 * peak_base
+
+
+def test_leaf_layer_dropped_and_generated_again(dev, pkg, orc):
+    """gkr_drop_leaves on the tree shapes the leaf kernels distinguish: a tiny tree with full extension-field numerator
+    planes (two dummy-interaction AIRs), several small AIRs whose leaves share one batched launch, mixed heights."""
+    import test_gpu_prove as tp
+    pkg.set_prover_config(gkr_drop_leaves=True, cache_rs_code_matrix=False)
+    tp.test_interactions(dev, pkg, orc)
+    tp.test_multi_air_mixed_heights(dev, pkg, orc)
+    tp.test_benchmark_air(dev, pkg, orc, 20, 8, 4, 8, 4)
 
 
 def test_slabs_with_rotation_preprocessed_and_interactions(dev, pkg, orc):
@@ -74,7 +108,7 @@ def test_slabs_with_rotation_preprocessed_and_interactions(dev, pkg, orc):
 
 def test_config_e_under_a_capped_cache(dev, pkg, orc):
     """BASELINE config E (2^24 x 100, blowup 4: a 26.8 GB codeword) with the codeword dropped, round 0 in
-    slabs of 2^20 rows and at most 8 GB kept in the allocator's free lists: the verifier accepts the proof
+    slabs of 2^20 rows, the fraction tree's leaf layer dropped and at most 8 GB kept in the allocator's free lists: the verifier accepts the proof
     and the peak is tens of GB below the resident run's."""
     import torch
     params = airs.stress_params(24)
@@ -87,7 +121,7 @@ def test_config_e_under_a_capped_cache(dev, pkg, orc):
     trace *= int(pkg.to_mont(np.array([1], dtype=np.uint32))[0])
     resident, peak_res = _prove(dev, pkg, pk, [(0, trace, h, [])])
     pkg.set_prover_config(cache_rs_code_matrix=False, zerocheck_save_memory=True, round0_slab_log_rows=20,
-                          cache_limit_bytes=8 << 30)
+                          cache_limit_bytes=8 << 30, gkr_drop_leaves=True)
     bounded, peak_bnd = _prove(dev, pkg, pk, [(0, trace, h, [])])
     assert bounded == resident
     orc.verify(blob, bounded)

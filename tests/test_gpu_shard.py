@@ -73,11 +73,13 @@ def test_logical_shards_match_oracle(orc, tmp_path, case, world):
     orc.verify(blob, got)
 
 
-def test_sharded_in_the_memory_bounded_modes(orc, tmp_path):
-    """Codeword dropped on every rank (the remote ranks re-encode when rank 0's queries arrive) and round 0 in
-    slabs: the joint proof does not change."""
-    blob, want = oracle_proof(orc, "bench_app", 2)
-    assert run_sharded("bench_app", 2, tmp_path, save_memory=True) == want
+@pytest.mark.parametrize("case,world", [("bench_app", 2), ("no_interactions_on_one_rank", 2), ("bench_mixed_heights", 4)])
+def test_sharded_in_the_memory_bounded_modes(orc, tmp_path, case, world):
+    """Codeword dropped on every rank (the remote ranks re-encode when rank 0's queries arrive), round 0 in
+    slabs, the fraction tree's leaf layer dropped and generated again (also on a rank that has no leaves):
+    the joint proof does not change."""
+    blob, want = oracle_proof(orc, case, world)
+    assert run_sharded(case, world, tmp_path, save_memory=True) == want
 
 
 @pytest.mark.parametrize("case,world", [("bench_app", 2), ("bench8", 3)])
