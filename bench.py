@@ -24,6 +24,9 @@ import time
 
 import numpy as np
 
+# (multi-process GPU work on this pool: the host driver only supports dmabuf IPC; harmless when already set)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))

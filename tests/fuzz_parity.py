@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Parity fuzzing on the GPU (test infrastructure, not collected by pytest): random multi-AIR keys and traces, random settings of the executor
-knobs (rows per lane, staging layout, batching, program groups), HIP proof bytes vs the oracle's.
+knobs (rows per lane, staging layout, batching, program groups) and of the memory-bounded modes, HIP proof bytes vs the oracle's.
 
     python tests/fuzz_parity.py --cases 10 --seed 1      (~30 s per case: the oracle proves on the CPU)
 """
@@ -30,7 +30,8 @@ def main():
     rng = np.random.default_rng(args.seed)
     knobs = {"OVM_R0_ROWS": ["", "1", "2", "4"], "OVM_STAGE_ROWS": ["", "2", "3", "8"], "OVM_ACC_ROWS": ["", "1", "4"],
              "OVM_R0_BATCH": ["", "0"], "OVM_MLE_BATCH": ["", "0", "64"], "OVM_MLE_POINTS": ["", "0"],
-             "OVM_R0_GROUPS_MIN": ["", "2", "4"], "OVM_MLE_GROUPS_MAX": ["", "16", "32"]}
+             "OVM_R0_GROUPS_MIN": ["", "2", "4"], "OVM_MLE_GROUPS_MAX": ["", "16", "32"],
+             "OVM_GKR_THREE_POINTS": ["", "", "1"], "OVM_MERKLE_COOP": ["", "0"]}
     bad = 0
     for case in range(args.cases):
         env = {k: str(rng.choice(v)) for k, v in knobs.items()}
@@ -39,6 +40,10 @@ def main():
                 os.environ[k] = v
             else:
                 os.environ.pop(k, None)
+        # the memory-bounded modes (ovm_prover_config_t): proofs must not depend on them
+        cfg = dict(cache_rs_code_matrix=bool(rng.integers(0, 2)), zerocheck_save_memory=bool(rng.integers(0, 2)),
+                   round0_slab_log_rows=int(rng.integers(1, 7)), gkr_drop_leaves=bool(rng.integers(0, 2)))
+        pkg.set_prover_config(**cfg)
         l_skip = int(rng.integers(1, 5))
         deg = int(rng.choice([3, 4]))
         params = airs.test_params(l_skip=l_skip, n_stack=int(rng.integers(8, 11)), k_whir=int(rng.integers(1, 4)))
@@ -59,7 +64,7 @@ def main():
         got, _ = dev.prove(pk, dtr)
         ok = got == want
         bad += not ok
-        print(f"case {case}: {'ok' if ok else 'MISMATCH'} airs={len(air_list)} l_skip={l_skip} deg={deg} env={ {k: v for k, v in env.items() if v} }", flush=True)
+        print(f"case {case}: {'ok' if ok else 'MISMATCH'} airs={len(air_list)} l_skip={l_skip} deg={deg} env={ {k: v for k, v in env.items() if v} } cfg={cfg}", flush=True)
     print(f"{args.cases - bad}/{args.cases} identical")
     sys.exit(1 if bad else 0)
 
