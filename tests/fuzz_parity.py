@@ -19,6 +19,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cases", type=int, default=10)
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--max-log-height", type=int, default=10)
+    ap.add_argument("--max-width", type=int, default=20)
     args = ap.parse_args()
     os.environ["ORC_SKIP_DEBUG_ASSERTS"] = "1"
     import importlib
@@ -46,21 +48,32 @@ def main():
         pkg.set_prover_config(**cfg)
         l_skip = int(rng.integers(1, 5))
         deg = int(rng.choice([3, 4]))
-        params = airs.test_params(l_skip=l_skip, n_stack=int(rng.integers(8, 11)), k_whir=int(rng.integers(1, 4)))
+        params = airs.test_params(l_skip=l_skip, n_stack=int(rng.integers(8, max(11, args.max_log_height + 1))), k_whir=int(rng.integers(1, 4)))
         params["max_constraint_degree"] = deg
         air_list, traces = [], []
         for i in range(int(rng.integers(1, 6))):
-            width = int(rng.integers(2, 20))
+            width = int(rng.integers(2, args.max_width))
             npv = int(rng.integers(0, 3))
             air_list.append(airs.random_air(rng, width, int(rng.integers(0, 60)), int(rng.integers(0, 4)), max_degree=deg,
                                             num_public_values=npv))
-            h = 1 << int(rng.integers(0, 11))
+            h = 1 << int(rng.integers(0, args.max_log_height + 1))
             traces.append((i, rng.integers(0, airs.P, size=width * h, dtype=np.uint64).astype(np.uint32), h,
                            [int(x) for x in rng.integers(0, airs.P, size=npv)]))
         blob = airs.pk_blob(params, air_list)
-        want = orc.prove(blob, traces)["proof"]
         pk = pkg.ProvingKey(blob)
         dtr = [(a, dev.upload(pkg.to_mont(np.asarray(tr, dtype=np.uint32))), h, pv) for a, tr, h, pv in traces]
+        try:
+            want = orc.prove(blob, traces)["proof"]
+        except RuntimeError as e:
+            # a context the protocol rejects (a trace taller than the stacked matrix): the library must refuse it too
+            try:
+                dev.prove(pk, dtr)
+                ok = False
+            except pkg.OvmError:
+                ok = True
+            bad += not ok
+            print(f"case {case}: {'ok' if ok else 'MISMATCH'} (both reject: {e})", flush=True)
+            continue
         got, _ = dev.prove(pk, dtr)
         ok = got == want
         bad += not ok
