@@ -202,7 +202,9 @@ int ovm_hip_host_permute_selftest(uint32_t n, uint64_t seed);
  *                              per 2^22 x 100 commitment at blowup 2, one extra NTT at opening time.
  *   zerocheck_save_memory = 1  round 0 extends and evaluates a tall trace in slabs of 2^round0_slab_log_rows rows
  *                              (0 = default 20): the coset-LDE buffer shrinks from
- *                              ovm_hip_constraint_eval_buffer_size(pk, air) x height to that x the slab.
+ *                              ovm_hip_constraint_eval_buffer_size(pk, air) x height to that x the slab. (The slab
+ *                              size is a lower bound: a proof whose traces would need more than ~64 K result
+ *                              slots over all slabs -- hundreds of slabs per trace -- gets larger slabs.)
  *   gkr_drop_leaves = 1        the leaf layer of the LogUp fraction tree (the largest: 5 of the tree's 13 units)
  *                              is dropped once the layer above it is built and generated again, from the trace,
  *                              when the last layer's sumcheck needs it -- by then the rest of the tree is gone.

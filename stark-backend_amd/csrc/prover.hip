@@ -1352,6 +1352,35 @@ struct Prover {
         }
         auto d_sp_all = cx.upload(shift_pows);
         auto d_xi = cx.upload(xi);
+        // zerocheck_save_memory: the slab of every trace. Each slab's sums get mailbox slots of their own (all traces
+        // are enqueued before the one wait), so the configured slab size is a LOWER bound: while the slabs of all
+        // traces together would not fit the mailbox, the trace with the most slabs gets slabs twice as large.
+        std::vector<unsigned> slab_logs(T, 0);
+        {
+            const ProverConfig &pcfg = prover_config();
+            std::vector<size_t> per_slab(T, 0);
+            auto round64 = [](size_t x) { return (x + 63) & ~size_t(63); };
+            for (size_t t = 0; t < T; t++) {
+                slab_logs[t] = tv[t].log_lifted;
+                if (!mine(t)) continue;
+                const unsigned cdeg = air(t).max_constraint_degree;
+                const unsigned zc = cdeg ? cdeg - 1 : 0, lg = air(t).interactions.empty() ? 0 : cdeg;
+                per_slab[t] = (zc ? round64(zc * N) : 0) + (lg ? round64(lg * 2 * N) : 0);
+                if (pcfg.zerocheck_save_memory) slab_logs[t] = std::min(tv[t].log_lifted, std::max(pcfg.round0_slab_log_rows, l_skip));
+            }
+            const size_t budget = Mailbox::SLOTS - (4 * MAX_COSETS * N + 128);
+            for (;;) {
+                size_t total = 0, worst = T;
+                for (size_t t = 0; t < T; t++) {
+                    total += per_slab[t] << (tv[t].log_lifted - slab_logs[t]);
+                    if (per_slab[t] && slab_logs[t] < tv[t].log_lifted &&
+                        (worst == T || tv[t].log_lifted - slab_logs[t] > tv[worst].log_lifted - slab_logs[worst]))
+                        worst = t;
+                }
+                if (total <= budget || worst == T) break;
+                slab_logs[worst]++;
+            }
+        }
         for (size_t t = 0; t < T; t++) {
             if (!mine(t)) continue;
             const AirKey &a = air(t);
@@ -1410,9 +1439,7 @@ struct Prover {
             // zerocheck_save_memory: a tall trace is extended and evaluated in slabs of 2^slab rows -- the LDE buffer
             // (n_cosets x columns x rows words: 3.5 GB at config D, 14 GB at config E) shrinks to one slab; the slab
             // sums are linear and are added up on the host. (The chunks of 2^l_skip rows are independent.)
-            const ProverConfig &pcfg = prover_config();
-            const unsigned slab_log = (pcfg.zerocheck_save_memory && v.log_lifted > std::max(pcfg.round0_slab_log_rows, l_skip))
-                                          ? std::max(pcfg.round0_slab_log_rows, l_skip) : v.log_lifted;
+            const unsigned slab_log = slab_logs[t];
             job.n_slabs = 1u << (v.log_lifted - slab_log);
             job.lde.alloc((size_t)n_cosets * v.cm.total << slab_log);
             const size_t red_blocks = std::min<size_t>(RED_BLOCKS, ((size_t(1) << slab_log) + RED_THREADS - 1) / RED_THREADS);
