@@ -24,7 +24,34 @@ def _owners_blocks(traces, world):
     return owners
 
 
+def _fuzz(seed, world):
+    """A random multi-AIR context (as tests/fuzz_parity.py draws them) with a random non-decreasing assignment of the
+    sorted traces to ranks -- ranks may own several traces or none."""
+    rng = np.random.default_rng(seed)
+    l_skip = int(rng.integers(1, 5))
+    deg = int(rng.choice([3, 4]))
+    params = airs.test_params(l_skip=l_skip, n_stack=int(rng.integers(8, 11)), k_whir=int(rng.integers(1, 4)))
+    params["max_constraint_degree"] = deg
+    air_list, traces = [], []
+    for i in range(int(rng.integers(1, 7))):
+        width = int(rng.integers(2, 20))
+        npv = int(rng.integers(0, 3))
+        air_list.append(airs.random_air(rng, width, int(rng.integers(0, 60)), int(rng.integers(0, 4)), max_degree=deg,
+                                        num_public_values=npv))
+        h = 1 << int(rng.integers(0, min(10, l_skip + params["n_stack"]) + 1))
+        traces.append((i, rng.integers(0, airs.P, size=width * h, dtype=np.uint64).astype(np.uint32), h,
+                       [int(x) for x in rng.integers(0, airs.P, size=npv)], None))
+    order = sorted(range(len(traces)), key=lambda i: (-traces[i][2], traces[i][0]))
+    ranks = np.sort(rng.integers(0, world, size=len(traces)))
+    owners = [0] * len(traces)
+    for pos, i in enumerate(order):
+        owners[i] = int(ranks[pos])
+    return params, air_list, traces, owners
+
+
 def make(name, world):
+    if name.startswith("fuzz:"):
+        return _fuzz(int(name.split(":")[1]), world)
     if name == "bench8":  # one partitioned BenchmarkAir per rank, equal heights (config D's multi-GPU form, small)
         p, a, t = _bench_partitioned(world, 8, [5] * world, airs.test_params(l_skip=2, n_stack=6, k_whir=2))
     elif name == "bench_mixed_heights":  # twice as many AIRs as ranks, heights incl. one below 2^l_skip
