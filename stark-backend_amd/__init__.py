@@ -488,6 +488,7 @@ class Shard:
                 ctypes.memmove(d_recv, recv.data_ptr(), total)
                 return 0
             torch.cuda.current_stream().synchronize()
+            check(_lib().ovm_hip_stream_synchronize(stream), "ovm_hip_stream_synchronize")
             if self.bulk == "shm":  # (tests: ranks sharing one GPU, no process group) every rank's whole vector, then pick
                 send = np.empty(total, dtype=np.uint8)
                 everything = np.empty(total * self.world, dtype=np.uint8)
@@ -549,7 +550,10 @@ class Shard:
                     ctypes.memmove(d_all + r * nbytes, part.data_ptr(), nbytes)
                 self.bulk_bytes += int(nbytes) * self.world
                 return 0
-            torch.cuda.current_stream().synchronize()  # what the prover enqueued before the exchange
+            # what the prover enqueued before the exchange: its stream is torch's current stream in this package, but the
+            # collective must not start early if a caller hands the prover another one
+            torch.cuda.current_stream().synchronize()
+            check(_lib().ovm_hip_stream_synchronize(stream), "ovm_hip_stream_synchronize")
             self.bulk_bytes += int(nbytes) * self.world
             if self.bulk == "shm":
                 send = np.empty(nbytes, dtype=np.uint8)
