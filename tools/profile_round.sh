@@ -1,0 +1,22 @@
+#!/bin/bash
+# Reproduces the profile evidence under profiles/<round>/ on a GPU box (run from the repo root):
+#   tools/profile_round.sh gpurun_out/prof_r02
+# 1. rocprofv3 --kernel-trace of `bench.py --steps 1 --warmup 1` (the second prove is the timed one)
+#    -> per-kernel stats csv + idle-gap attribution
+# 2. two separate --pmc passes (FETCH_SIZE, WRITE_SIZE; never combined with a trace domain) -> HBM traffic json
+# The program follows `--` directly (no env / bash -c hop under the profiler).
+set -u
+OUT=${1:-gpurun_out/prof}
+mkdir -p "$OUT"
+export TMPDIR=/tmp
+BENCH="python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline"
+rocprofv3 --kernel-trace --stats -d "$OUT/kt" -o run --output-format rocpd csv -- $BENCH > "$OUT/kt.log" 2>&1
+KT=$(find "$OUT/kt" -name "*_results.db" | head -1)
+python3 tools/rocpd_stats.py "$KT" --second-half --csv "$OUT/prove_kernel_stats.csv" > "$OUT/prove_kernel_stats.txt" 2>&1
+python3 tools/rocpd_gaps.py "$KT" --second-half > "$OUT/idle_gaps.txt" 2>&1
+rocprofv3 --pmc FETCH_SIZE -d "$OUT/fetch" -o run --output-format rocpd -- $BENCH > "$OUT/fetch.log" 2>&1
+rocprofv3 --pmc WRITE_SIZE -d "$OUT/write" -o run --output-format rocpd -- $BENCH > "$OUT/write.log" 2>&1
+FE=$(find "$OUT/fetch" -name "*_results.db" | head -1)
+WR=$(find "$OUT/write" -name "*_results.db" | head -1)
+python3 tools/rocpd_pmc.py "$FE" "$WR" "$OUT/pmc_hbm_traffic.json" > "$OUT/pmc.txt" 2>&1
+ls -la "$OUT"

@@ -17,11 +17,18 @@ def main():
     rows = db.execute(f"select {name_c}, start, end from kernels order by start").fetchall()
     rows = [(n.replace("void ", "").replace("ovm::", "").split("(")[0], s, e) for n, s, e in rows if not n.startswith("at::") and "elementwise" not in n]
     if "--second-half" in sys.argv:
-        # the timed prove = everything after the largest gap in the second half of the trace (between the two proves)
-        mid = len(rows) // 3
-        gaps = [(rows[i + 1][1] - rows[i][2], i) for i in range(mid, len(rows) - 1)]
-        cut = max(gaps)[1] + 1
-        rows = rows[cut:]
+        # bench.py --steps 1 --warmup 1 proves twice on the same input, so the trace ENDS with the same kernel sequence
+        # twice: the timed prove is the longest suffix that repeats the kernels right before it (a cold first prove has
+        # allocation gaps of milliseconds, so gap sizes are no guide)
+        names = [r[0] for r in rows]
+        best = 0
+        for L in range(len(names) // 2, 50, -1):
+            if names[-L:] == names[-2 * L:-L]:
+                best = L
+                break
+        if not best:
+            raise SystemExit("no repeated kernel sequence at the end of the trace")
+        rows = rows[-best:]
     busy = sum(e - s for _, s, e in rows)
     span = rows[-1][2] - rows[0][1]
     per = collections.defaultdict(lambda: [0, 0])
