@@ -2994,6 +2994,7 @@ Tuning ovm::Tuning::from_env() {
     t.mle_groups_max = (uint32_t)std::max(1, num("OVM_MLE_GROUPS_MAX", 128));
     t.gkr_three_points = getenv("OVM_GKR_THREE_POINTS") != nullptr;
     t.merkle_coop = !off("OVM_MERKLE_COOP");
+    t.finish_inline_max = (uint32_t)std::max(1, num("OVM_FINISH_INLINE_MAX", 64));
     t.trace = getenv("OVM_TRACE") != nullptr;
     return t;
 }

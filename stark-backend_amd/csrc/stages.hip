@@ -116,16 +116,18 @@ int sum_partials(const RedOut &ro, uint32_t n_blocks, uint32_t K, hipStream_t s)
 
 // Every agent-scope release on gfx950 writes the XCD's L2 back; with thousands of workgroups doing
 // it the tail costs ~50 ns per workgroup (measured: +100 us on a 2048-workgroup launch). So the
-// in-kernel finish is used for grids of at most FINISH_INLINE_MAX workgroups -- the latency-bound
-// rounds, which are most of them -- and larger grids take one extra sum_partials launch.
-static constexpr uint32_t FINISH_INLINE_MAX = 64;
+// in-kernel finish is used for grids of at most tuning().finish_inline_max (64) workgroups -- the
+// latency-bound rounds, which are most of them -- and larger grids take one extra sum_partials launch.
+// (Round 2 tried storing the records through to memory instead -- agent-scope atomic stores + s_waitcnt, no
+// release fence -- with the in-kernel finish for every grid: correct, 159 tests green, and no faster:
+// 78.1 vs 77.3-78.1 ms per proof; the last workgroup's pass over 2048 records costs what the launch did.)
 static inline RedOut red_inline(const RedOut &ro, uint32_t total_blocks) {
     RedOut r = ro;
-    if (total_blocks > FINISH_INLINE_MAX) r.counter = nullptr;
+    if (total_blocks > tuning().finish_inline_max) r.counter = nullptr;
     return r;
 }
 static inline int red_finish(const RedOut &ro, uint32_t total_blocks, uint32_t n_records, uint32_t K, hipStream_t s) {
-    if (total_blocks > FINISH_INLINE_MAX) return sum_partials(ro, n_records, K, s);
+    if (total_blocks > tuning().finish_inline_max) return sum_partials(ro, n_records, K, s);
     return 0;
 }
 

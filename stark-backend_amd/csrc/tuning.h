@@ -20,6 +20,8 @@ struct Tuning {
     uint32_t mle_groups_max = 128; // OVM_MLE_GROUPS_MAX
     bool gkr_three_points = false; // OVM_GKR_THREE_POINTS: every GKR sub-round takes the three-point fallback
     bool merkle_coop = true;       // OVM_MERKLE_COOP=0: no 16-lane cooperative compress for the small layers
+    uint32_t finish_inline_max = 64;    // OVM_FINISH_INLINE_MAX: grids up to this many workgroups finish their reduction
+                                   // in the kernel (last workgroup sums the records); larger ones take a second launch
     bool trace = false;            // OVM_TRACE: wall-clock trace of the stages on stderr
     static Tuning from_env();
     static void refresh() { current() = from_env(); }
