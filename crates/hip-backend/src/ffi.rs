@@ -225,6 +225,8 @@ extern "C" {
         cached_bytes: *mut u64,
         reset_peak: c_int,
     ) -> c_int;
+    pub fn ovm_hip_pool_stats(out4: *mut u64) -> c_int;
+    pub fn ovm_hip_pool_selftest(seed: u64, ops: u32) -> c_int;
     pub fn ovm_hip_constraint_eval_buffer_size(pk: *const OvmPk, air_idx: u32) -> u64;
     pub fn ovm_hip_trim() -> c_int;
     pub fn ovm_hip_last_error() -> *const c_char;

@@ -227,6 +227,14 @@ int ovm_hip_set_prover_config(const ovm_prover_config_t *cfg);
 /* Device memory handed out by the library's allocator, process-wide: now, at its peak (reset_peak != 0 restarts
  * the peak from the current value), and the calling thread's cached free blocks. Any pointer may be null. */
 int ovm_hip_memory_stats(uint64_t *live_bytes, uint64_t *peak_live_bytes, uint64_t *cached_bytes, int reset_peak);
+/* The pool behind it (csrc/block_pool.h; the role of the reference's VPMM pool, docs/vpmm_spec.md), process-wide:
+ * out4 = { bytes held from the driver in segments now, their peak (restarted by reset_peak above), hipMalloc calls
+ * ever made, blocks handed out now }. Back-to-back proofs of one shape make no driver call after the first. */
+int ovm_hip_pool_stats(uint64_t out4[4]);
+/* Device-free self-test of that pool over host memory: `ops` random allocations / frees of both size classes with
+ * the invariants checked (no overlap, contents intact, accounting, limit, a repeated sequence makes no driver call,
+ * nothing left after trim). 0 = all held; message: ovm_hip_selftest_error(). */
+int ovm_hip_pool_selftest(uint64_t seed, uint32_t ops);
 /* ProverBackend::constraint_eval_buffer_size (hal.rs:57-62): bytes of round-0 scratch per trace ROW of this AIR
  * (the coset LDE of every view column on max(degree - 1, degree if it has interactions) cosets); what memory
  * metering multiplies by the trace height -- or by the slab with zerocheck_save_memory. 0 for a bad index. */

@@ -114,6 +114,8 @@ SIGNATURES = {
     "ovm_hip_trim": (c_int, []),
     "ovm_hip_set_prover_config": (c_int, [POINTER(ProverConfigStruct)]),
     "ovm_hip_memory_stats": (c_int, [_u64p, _u64p, _u64p, c_int]),
+    "ovm_hip_pool_stats": (c_int, [_u64p]),
+    "ovm_hip_pool_selftest": (c_int, [c_uint64, c_uint32]),
     "ovm_hip_constraint_eval_buffer_size": (c_uint64, [c_void_p, c_uint32]),
     "ovm_hip_commit": (c_int, [c_void_p, c_uint32, c_void_p, c_void_p, POINTER(c_void_p), c_void_p]),
     "ovm_hip_commit_matrix": (c_int, [c_void_p, c_void_p, c_uint64, c_uint64, c_void_p, POINTER(c_void_p), c_void_p]),
@@ -700,10 +702,21 @@ def set_prover_config(cache_rs_code_matrix: bool = True, zerocheck_save_memory: 
 
 
 def memory_stats(reset_peak: bool = False) -> dict:
-    """Device bytes handed out by the library's allocator (live / peak, process-wide) and cached by this thread."""
+    """Device bytes handed out by the library's pool (live / peak, process-wide), free in this thread's pool (cached),
+    held from the driver in segments (now / peak), hipMalloc calls ever made, blocks handed out now."""
     live, peak, cached = c_uint64(0), c_uint64(0), c_uint64(0)
     _lib().ovm_hip_memory_stats(ctypes.byref(live), ctypes.byref(peak), ctypes.byref(cached), 1 if reset_peak else 0)
-    return {"live": live.value, "peak": peak.value, "cached": cached.value}
+    pool = (c_uint64 * 4)()
+    _lib().ovm_hip_pool_stats(pool)
+    return {"live": live.value, "peak": peak.value, "cached": cached.value, "segments": int(pool[0]),
+            "peak_segments": int(pool[1]), "driver_allocs": int(pool[2]), "live_blocks": int(pool[3])}
+
+
+def pool_selftest(seed: int = 1, ops: int = 20000) -> None:
+    """Device-free stress of the memory pool over host memory (csrc/block_pool.h)."""
+    rc = _lib().ovm_hip_pool_selftest(seed, ops)
+    if rc != 0:
+        raise OvmError(rc, f"ovm_hip_pool_selftest [{_lib().ovm_hip_selftest_error().decode()}]")
 
 
 def constraint_eval_buffer_size(pk: ProvingKey, air_idx: int) -> int:

@@ -18,6 +18,7 @@
 #include <mutex>
 #include <unordered_map>
 
+#include "block_pool.h"
 #include "gkr_shard.h"
 #include "kernels.h"
 #include "shard.h"
@@ -27,88 +28,8 @@ namespace ovm {
 // ---------------------------------------------------------------------------------------------
 // Device memory helpers
 // ---------------------------------------------------------------------------------------------
-// Caching device allocator: freed blocks go to a free list instead of back to the driver and are
-// handed out again (best fit) by later requests. A proof requests the same sizes every time, so after
-// the first proof no hipMalloc / hipFree happens at all (those cost hundreds of milliseconds for
-// multi-GB buffers and synchronise the device). This is the role the reference gives its VPMM pool
-// (crates/cuda-common/src/memory_manager/); `ovm_hip_trim` returns the cache to the driver.
-//
-// Free lists are per (thread, device): all work of a prover runs on one stream, so a block is reused
-// in stream order by construction. WHO owns a live block and how big it is lives in one process-wide
-// registry, so a block freed on another thread than the one that allocated it (a key or PCS handle
-// dropped elsewhere) is recognised, released to the driver with its true size forgotten nowhere, and
-// never enters a free list under a stale size. A thread's cached blocks go back to the driver when
-// the thread exits.
-struct BlockCache;
-struct BlockRegistry {
-    std::mutex mu;
-    std::unordered_map<void *, std::pair<size_t, const BlockCache *>> live;
-    size_t live_bytes = 0, peak_live_bytes = 0;  // blocks handed out (process-wide): ovm_hip_memory_stats
-    static BlockRegistry &get() {
-        static BlockRegistry *r = new BlockRegistry();  // (leaked on purpose: thread-exit destructors may run late)
-        return *r;
-    }
-};
-struct BlockCache {
-    std::multimap<size_t, void *> free_blocks;  // size -> ptr
-    size_t cached_bytes = 0;
-    // upper bound on the bytes this cache may hold in free blocks (0 = unbounded); see ovm_hip_set_cache_limit
-    size_t limit_bytes = 0;
-    ~BlockCache() { trim(); }
-    void *get(size_t bytes) {
-        bytes = (bytes + 255) & ~size_t(255);
-        auto it = free_blocks.lower_bound(bytes);
-        void *p = nullptr;
-        size_t sz = bytes;
-        if (it != free_blocks.end() && it->first <= bytes + bytes / 8 + 4096) {
-            p = it->second;
-            sz = it->first;
-            free_blocks.erase(it);
-            cached_bytes -= sz;
-        } else {
-            hipError_t e = hipMalloc(&p, bytes);
-            if (e != hipSuccess) {
-                trim();
-                e = hipMalloc(&p, bytes);
-            }
-            if (e != hipSuccess) throw OvmFail((int)e, "hipMalloc");
-        }
-        BlockRegistry &reg = BlockRegistry::get();
-        std::lock_guard<std::mutex> lk(reg.mu);
-        reg.live[p] = {sz, this};
-        reg.live_bytes += sz;
-        reg.peak_live_bytes = std::max(reg.peak_live_bytes, reg.live_bytes);
-        return p;
-    }
-    void put(void *p) {
-        size_t sz = 0;
-        const BlockCache *owner = nullptr;
-        {
-            BlockRegistry &reg = BlockRegistry::get();
-            std::lock_guard<std::mutex> lk(reg.mu);
-            auto it = reg.live.find(p);
-            if (it != reg.live.end()) {
-                sz = it->second.first;
-                owner = it->second.second;
-                reg.live.erase(it);
-                reg.live_bytes -= sz;
-            }
-        }
-        if (owner != this || (limit_bytes && cached_bytes + sz > limit_bytes)) {
-            (void)hipFree(p);  // another thread's block (hipFree waits for the device), or over the cache limit
-            return;
-        }
-        free_blocks.emplace(sz, p);
-        cached_bytes += sz;
-    }
-    void trim() {
-        if (free_blocks.empty()) return;
-        (void)hipDeviceSynchronize();
-        for (auto &b : free_blocks) (void)hipFree(b.second);
-        free_blocks.clear();
-        cached_bytes = 0;
-    }
-};
+// Device memory comes from the per-(thread, device) pool of block_pool.h: segments kept from the driver, blocks split
+// and merged inside them. `ovm_hip_trim` returns the free segments, ovm_hip_memory_stats / ovm_hip_pool_stats report.
 // Memory-bounded modes (reference: GpuProverConfig, cuda-backend/src/device.rs:25-30), per
 // prover thread (one engine per thread). Defaults keep everything resident: 288 GB of HBM is the normal case.
 struct ProverConfig {
@@ -124,12 +45,31 @@ inline ProverConfig &prover_config() {
     return cfg;
 }
 
-inline BlockCache &block_cache() {
-    static thread_local BlockCache caches[16];
+// The calling thread's pool for the current device. Pools are heap objects: one whose thread has exited lives on
+// until the last of its blocks has come back (BlockPool::orphan).
+struct PoolHolder {
+    BlockPool *pools[16] = {};
+    ~PoolHolder() {
+        for (BlockPool *p : pools)
+            if (p && p->orphan()) delete p;
+    }
+};
+inline BlockPool &block_cache() {
+    static thread_local PoolHolder holder;
     int dev = 0;
     (void)hipGetDevice(&dev);
-    return caches[dev & 15];
+    BlockPool *&p = holder.pools[dev & 15];
+    if (!p) p = new BlockPool();
+    return *p;
 }
+inline void *pool_get(size_t bytes) {
+    try {
+        return block_cache().get(bytes);
+    } catch (const BlockPool::Error &e) {
+        throw OvmFail(e.code, "hipMalloc");
+    }
+}
+inline void pool_put(void *p) { BlockPool::put(p, &block_cache()); }
 
 template <class T>
 struct DevBuf {
@@ -154,10 +94,10 @@ struct DevBuf {
     void alloc(size_t count) {
         release();
         n = count;
-        p = (T *)block_cache().get((count ? count : 1) * sizeof(T));
+        p = (T *)pool_get((count ? count : 1) * sizeof(T));
     }
     void release() {
-        if (p) block_cache().put(p);
+        if (p) pool_put(p);
         p = nullptr;
         n = 0;
     }
@@ -3118,18 +3058,29 @@ int ovm_hip_set_prover_config(const ovm_prover_config_t *cfg) {
     c.zerocheck_save_memory = cfg->zerocheck_save_memory != 0;
     if (cfg->round0_slab_log_rows) c.round0_slab_log_rows = cfg->round0_slab_log_rows;
     c.gkr_drop_leaves = cfg->gkr_drop_leaves != 0;
-    block_cache().limit_bytes = cfg->cache_limit_bytes;
-    if (cfg->cache_limit_bytes && block_cache().cached_bytes > cfg->cache_limit_bytes) block_cache().trim();
+    block_cache().set_limit(cfg->cache_limit_bytes);
     return 0;
 }
 
 int ovm_hip_memory_stats(uint64_t *live_bytes, uint64_t *peak_live_bytes, uint64_t *cached_bytes, int reset_peak) {
-    BlockRegistry &reg = BlockRegistry::get();
+    const uint64_t cached = block_cache().cached_bytes();
+    PoolRegistry &reg = PoolRegistry::get();
     std::lock_guard<std::mutex> lk(reg.mu);
     if (live_bytes) *live_bytes = reg.live_bytes;
     if (peak_live_bytes) *peak_live_bytes = reg.peak_live_bytes;
-    if (cached_bytes) *cached_bytes = block_cache().cached_bytes;
-    if (reset_peak) reg.peak_live_bytes = reg.live_bytes;
+    if (cached_bytes) *cached_bytes = cached;
+    if (reset_peak) reg.peak_live_bytes = reg.live_bytes, reg.peak_segment_bytes = reg.segment_bytes;
+    return 0;
+}
+
+int ovm_hip_pool_stats(uint64_t out4[4]) {
+    if (!out4) return (int)hipErrorInvalidValue;
+    PoolRegistry &reg = PoolRegistry::get();
+    std::lock_guard<std::mutex> lk(reg.mu);
+    out4[0] = reg.segment_bytes;
+    out4[1] = reg.peak_segment_bytes;
+    out4[2] = reg.driver_allocs;
+    out4[3] = reg.owner.size();
     return 0;
 }
 

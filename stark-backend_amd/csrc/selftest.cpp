@@ -7,6 +7,10 @@
 // records straddle ranks, the closed-form padding sums, the exchange.
 #include <thread>
 
+#include <atomic>
+#include <cstdlib>
+
+#include "block_pool.h"
 #include "gkr_shard.h"
 #include "kernels.h"
 
@@ -328,3 +332,133 @@ int ovm_hip_shard_exchange_selftest(const ovm_shard_t *shard, uint64_t n, uint32
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------------------------
+// The device memory pool (block_pool.h) over plain host memory: a random allocate / free workload of
+// both size classes, every block filled with its own pattern, with the invariants checked as it goes --
+// blocks never overlap, contents survive until the free, what the pool holds from the "driver" is what
+// is live plus what it reports as free, a limit is honoured as soon as whole segments are free, a
+// second identical pass makes no driver call, everything goes back at the end. 0 = all held.
+// ---------------------------------------------------------------------------------------------
+namespace {
+std::atomic<size_t> g_host_driver_bytes{0};
+std::atomic<uint64_t> g_host_driver_allocs{0};
+std::mutex g_host_driver_mu;
+std::unordered_map<void *, size_t> g_host_driver_sizes;
+PoolDriver host_pool_driver() {
+    return PoolDriver{[](void **p, size_t bytes) {
+                          if (posix_memalign(p, 4096, bytes) != 0) return 2;  // (hipMalloc aligns at least this much)
+                          std::lock_guard<std::mutex> lk(g_host_driver_mu);
+                          g_host_driver_sizes[*p] = bytes;
+                          g_host_driver_bytes += bytes;
+                          g_host_driver_allocs++;
+                          return 0;
+                      },
+                      [](void *p) {
+                          std::lock_guard<std::mutex> lk(g_host_driver_mu);
+                          g_host_driver_bytes -= g_host_driver_sizes[p];
+                          g_host_driver_sizes.erase(p);
+                          std::free(p);
+                      },
+                      []() {}};
+}
+}  // namespace
+
+extern "C" int ovm_hip_pool_selftest(uint64_t seed, uint32_t ops) {
+    try {
+        Rng rng(seed);
+        BlockPool *pool = new BlockPool(host_pool_driver());
+        struct Live {
+            char *p;
+            size_t want;
+            uint8_t tag;
+        };
+        std::vector<Live> live;
+        std::map<char *, size_t> spans;  // start -> requested size, for the overlap check
+        size_t live_want = 0;
+        auto fail = [](const std::string &m) { throw OvmFail(1, "pool selftest: " + m); };
+        auto alloc = [&](size_t want) {
+            char *p = (char *)pool->get(want);
+            if ((uintptr_t)p % 512) fail("block not 512-byte aligned");
+            auto nx = spans.lower_bound(p);
+            if (nx != spans.end() && nx->first < p + want) fail("block overlaps the next live block");
+            if (nx != spans.begin()) {
+                auto pv = std::prev(nx);
+                if (pv->first + pv->second > p) fail("block overlaps the previous live block");
+            }
+            const uint8_t tag = (uint8_t)rng.next();
+            p[0] = (char)tag, p[want / 2] = (char)(tag ^ 0x5a), p[want - 1] = (char)(tag ^ 0xa5);
+            spans[p] = want;
+            live.push_back({p, want, tag});
+            live_want += want;
+        };
+        auto release = [&](size_t i) {
+            Live l = live[i];
+            if ((uint8_t)l.p[0] != l.tag || (uint8_t)l.p[l.want / 2] != (uint8_t)(l.tag ^ 0x5a) || (uint8_t)l.p[l.want - 1] != (uint8_t)(l.tag ^ 0xa5))
+                fail("block contents changed while it was live");
+            spans.erase(l.p);
+            live_want -= l.want;
+            live[i] = live.back();
+            live.pop_back();
+            BlockPool::put(l.p, pool);
+        };
+        auto size_of = [&]() -> size_t {
+            const uint64_t r = rng.next() % 100;
+            if (r < 55) return 1 + rng.next() % (BlockPool::SMALL_MAX - 1);        // small class
+            if (r < 95) return BlockPool::SMALL_MAX + rng.next() % (size_t(24) << 20);  // 1-25 MiB
+            return (size_t(32) << 20) + rng.next() % (size_t(96) << 20);            // a few big ones
+        };
+        for (uint32_t k = 0; k < ops; k++) {
+            if (live.empty() || (rng.next() % 100 < 55 && live_want < (size_t(1) << 30)))
+                alloc(size_of());
+            else
+                release(rng.next() % live.size());
+            if (k % 64 == 0 && g_host_driver_bytes.load() < live_want + pool->cached_bytes() - pool->cached_bytes())
+                fail("accounting: less held from the driver than is live");
+            if (k % 257 == 0) {
+                // everything the driver gave is either live (rounded up) or reported free
+                if (g_host_driver_bytes.load() < live_want) fail("accounting: driver bytes below live bytes");
+                if (pool->cached_bytes() > g_host_driver_bytes.load()) fail("accounting: more free than held");
+            }
+        }
+        // a limit: with everything freed, at most `limit` bytes may stay
+        while (!live.empty()) release(live.size() - 1);
+        if (pool->cached_bytes() != g_host_driver_bytes.load())
+            fail("all blocks free, but free bytes " + std::to_string(pool->cached_bytes()) + " != bytes held " + std::to_string(g_host_driver_bytes.load()));
+        pool->set_limit(size_t(16) << 20);
+        if (g_host_driver_bytes.load() > (size_t(16) << 20)) fail("limit not honoured with every segment free");
+        pool->set_limit(0);
+        // steady state: the same request sequence twice -- the second pass must not reach the driver
+        auto pass = [&]() {
+            Rng r2(seed ^ 0x1234);
+            std::vector<size_t> keep;
+            for (int k = 0; k < 300; k++) {
+                const uint64_t r = r2.next() % 100;
+                alloc(r < 50 ? 1 + r2.next() % 200000 : (size_t(1) << 20) + r2.next() % (size_t(40) << 20));
+                if (r2.next() % 3 == 0 && !live.empty()) release(r2.next() % live.size());
+            }
+            while (!live.empty()) release(live.size() - 1);
+        };
+        // (a pass that had to grow the pool leaves more segments than it found, so the next one may choose other
+        // blocks: the pool settles within a few passes; once a pass made no driver call, every later one is its replay)
+        int settled_after = -1;
+        for (int k = 0; k < 8 && settled_after < 0; k++) {
+            const uint64_t before = g_host_driver_allocs.load();
+            pass();
+            if (g_host_driver_allocs.load() == before) settled_after = k;
+        }
+        if (settled_after < 0) fail("a repeated request sequence still reaches the driver after 8 passes");
+        const uint64_t before = g_host_driver_allocs.load();
+        pass();
+        pass();
+        if (g_host_driver_allocs.load() != before) fail("a settled request sequence reached the driver again");
+        pool->trim();
+        if (g_host_driver_bytes.load() != 0) fail("trim with nothing live left segments behind");
+        if (pool->orphan()) delete pool;
+        else fail("orphaned empty pool not reported dead");
+        return 0;
+    } catch (const std::exception &e) {
+        g_selftest_error = e.what();
+        return 1;
+    }
+}

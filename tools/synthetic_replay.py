@@ -75,7 +75,13 @@ def main(argv=None, verify=None):
         print(f"[{n + 1}/{len(picked)}] segment {segs[si]['idx']}: {len(air_list)} AIRs, {cells / 1e6:.1f} M cells, "
               f"{ms:.1f} ms", file=sys.stderr)
         del traces, pk
+    mem = pkg.memory_stats()
+    free_b, total_b = torch.cuda.mem_get_info(0)
     card = {"workload": "reth-block-23992138 synthetic replay", "every": args.every,
+            # the library's allocator over the whole sweep (no trim between segments): peak of what it handed out, what its
+            # free lists hold at the end, and what the driver reports in use on the device (incl. torch's own pool)
+            "allocator_peak_live_GiB": round(mem["peak"] / 2**30, 2), "allocator_cached_end_GiB": round(mem["cached"] / 2**30, 2),
+            "device_in_use_end_GiB": round((total_b - free_b) / 2**30, 2),
             "max_log_height": args.max_log_height, "sampled_segments": len(picked), "total_segments": len(segs),
             "total_prove_ms": round(total_ms, 1), "total_main_cells": total_cells,
             "cells_per_sec": round(total_cells / (total_ms / 1e3), 1), "verified": verify is not None,
