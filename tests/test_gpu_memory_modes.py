@@ -85,6 +85,29 @@ def test_leaf_layer_dropped_and_generated_again(dev, pkg, orc):
     tp.test_benchmark_air(dev, pkg, orc, 20, 8, 4, 8, 4)
 
 
+def test_repeated_proofs_make_no_driver_allocation(dev, pkg):
+    """Back-to-back proofs of one shape replay the same block splits over the same segments (csrc/block_pool.h): the
+    second proof already finds everything in the pool, the pool holds little more than the peak of what was live, and
+    ovm_hip_trim gives it all back."""
+    params = airs.test_params(l_skip=4, n_stack=14, k_whir=4)
+    pk = pkg.ProvingKey(airs.pk_blob(params, [airs.uniform_runner_air(40)]))
+    h = 1 << 16
+    d = dev.upload(pkg.to_mont(airs.splitmix64_bits(78, 40 * h)))
+    pkg._lib().ovm_hip_trim()
+    pkg.memory_stats(reset_peak=True)
+    first, _ = dev.prove(pk, [(0, d, h, [])])
+    after_first = pkg.memory_stats()
+    for _ in range(3):
+        again, _ = dev.prove(pk, [(0, d, h, [])])
+        assert again == first
+    m = pkg.memory_stats()
+    assert m["driver_allocs"] == after_first["driver_allocs"], "a repeated proof reached hipMalloc"
+    assert m["peak_segments"] <= 1.5 * m["peak"] + (64 << 20)   # held from the driver vs handed out at the peak
+    held = m["segments"]
+    pkg._lib().ovm_hip_trim()
+    assert pkg.memory_stats()["segments"] < held and pkg.memory_stats()["cached"] <= 64 << 20   # (partly used small segments stay)
+
+
 def test_slabs_with_rotation_preprocessed_and_interactions(dev, pkg, orc):
     """Slabs on AIRs whose rows look at their neighbours (rotation wraps across slab ends) and at
     preprocessed / cached partitions."""
