@@ -1456,22 +1456,6 @@ int gkr_build_layer(FracPlanes child, FracPlanes parent, uint64_t n_parent, bool
     return 0;
 }
 
-__global__ void gkr_read_kernel(FracPlanes t, uint64_t first, uint32_t n, RedOut ro) {
-    uint32_t i = threadIdx.x;
-    if (i < n) {
-        st_ef(ro.out + 2 * i, ldp(t.P(), t.stride, first + i));
-        st_ef(ro.out + 2 * i + 1, ldp(t.Q(), t.stride, first + i));
-        __threadfence_system();
-    }
-    __syncthreads();
-    if (i == 0) publish(ro);
-}
-int gkr_read_fracs(FracPlanes t, uint64_t first, uint32_t n, const RedOut &ro, hipStream_t s) {
-    hipLaunchKernelGGL(gkr_read_kernel, dim3(1), dim3(64), 0, s, t, first, n, ro);
-    OVM_CHECK_LAUNCH();
-    return 0;
-}
-
 // sums[X-1] += e * (p0 q1 + p1 q0 + lambda q0 q1)(X) for X = 1, 2, 3 where every quantity is the
 // line through its values on records a (X = 0) and b (X = 1). The eq polynomial is FACTORED: the
 // weight e = eq(xi_rest, y) covers only the variables not yet bound; the factor of the current
@@ -1791,25 +1775,6 @@ int gkr_fold_round(FracPlanes in, bool in_p_base, EFPlanes eq, FracPlanes out, u
 #undef CALL
     OVM_CHECK_LAUNCH();
     return red_finish(ro, grid, grid, n_points, s);
-}
-
-// Last fold of a layer: two records -> the layer's claims, written as out[0..4) = (p0, q0, p1, q1).
-__global__ void gkr_fold_final_kernel(FracPlanes in, EF r, RedOut ro) {
-    if (threadIdx.x != 0) return;
-    EF *out = ro.out;
-    EF p[4], q[4];
-    ldp4(in.P(), in.stride, 0, p);
-    ldp4(in.Q(), in.stride, 0, q);
-    st_ef(out + 0, p[0] + (p[2] - p[0]) * r);
-    st_ef(out + 1, q[0] + (q[2] - q[0]) * r);
-    st_ef(out + 2, p[1] + (p[3] - p[1]) * r);
-    st_ef(out + 3, q[1] + (q[3] - q[1]) * r);
-    publish(ro);
-}
-int gkr_fold_final(FracPlanes in, EF r, const RedOut &ro, hipStream_t s) {
-    hipLaunchKernelGGL(gkr_fold_final_kernel, dim3(1), dim3(64), 0, s, in, r, ro);
-    OVM_CHECK_LAUNCH();
-    return 0;
 }
 
 // ---- stacked reduction -----------------------------------------------------------------------
