@@ -17,6 +17,7 @@ Rank 0 prints ONE JSON line. `roofline` is per kernel class with the dominant ke
 timing on the launch stream); `cpu_baseline` times the CPU oracle on a bounded sample of the same workload.
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -167,6 +168,11 @@ def main():
         name = [f"/ovm-bench-{os.getpid()}-{int(time.time() * 1e3) & 0xFFFFFF}"]
         dist.broadcast_object_list(name, src=0)
         shard = pkg.Shard(rank, world, name[0])
+        # pre-flight of the RCCL exchanges on rank-dependent data; if any rank sees wrong bytes or an error, every rank
+        # switches to host staging through the shared-memory segment (and the JSON line says so)
+        bulk_ok = shard.check_bulk()
+        if not bulk_ok and rank == 0:
+            print("bench.py: the device exchange pre-flight FAILED; staging the bulk exchange through shared memory", file=sys.stderr)
         cached, common = bits(cols * h), bits(h)
         owners = list(range(world))
 
@@ -267,8 +273,10 @@ def main():
         # (6 trace passes + codeword write/read at blowup 2 + the 2^27-leaf fraction tree)
         e2e_gbs = 60.0 * world * cells / (elapsed / args.steps) / 1e9
         par = "1 GPU" if world == 1 else (f"sharded x{world}: ONE joint proof, one AIR (cached-main commitment) per GPU, "
-                                          f"per-round values over shared memory, RCCL all-gather of the mu-batched WHIR vector"
-                                          + (" [--one-gpu: ranks share GPU 0, gloo, host-staged]" if args.one_gpu else ""))
+                                          f"per-round values over shared memory, the mu-batched WHIR vectors summed by "
+                                          + ("RCCL all-to-all + all-gather" if shard.bulk == "torch" and not args.one_gpu else
+                                             "an exchange STAGED THROUGH HOST shared memory (the RCCL pre-flight failed)" if shard.bulk == "shm"
+                                             else "gloo, host-staged [--one-gpu: ranks share GPU 0]"))
         line = {
             "metric": "trace_cells_per_sec", "value": round(value, 1), "unit": "cells/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
@@ -282,7 +290,7 @@ def main():
                                    + ("all-zero trace" if args.zero_trace else "seeded random boolean trace")
                                    + ("" if world == 1 else "; per AIR: 100 columns as a cached-main commitment (committed inside the "
                                       "timed region) + a 1-column common main (not counted in cells)"),
-                       "proof_bytes": len(proof), "parallelism": par},
+                       "proof_bytes": len(proof), "proof_sha256": hashlib.sha256(proof).hexdigest(), "parallelism": par},
             "roofline": roof, "cpu_baseline": cpu,
             "end_to_end": {"algorithmic_bytes_per_cell": 60, "achieved_GBps": round(e2e_gbs, 1),
                            "frac_of_hbm_peak": round(e2e_gbs / (HBM_PEAK_GBS * world), 4)},

@@ -599,6 +599,45 @@ class Shard:
             print(f"[ovm] allgather_device failed on rank {self.rank}: {e!r}", file=sys.stderr, flush=True)
             return 999
 
+    def check_bulk(self, stream=None) -> bool:
+        """Pre-flight of the device exchanges: a small all-gather and all-to-all of rank-dependent bytes through the very
+        callbacks the prover will call, verified on every rank; the ranks then agree (one byte each through the
+        shared-memory exchange) on whether ALL of them saw the right data. On False the communicator has switched itself
+        to bulk="shm" (host-staged through the shared-memory segment: slower, needs nothing but this library), so a
+        deployment whose collective library misbehaves still proves."""
+        torch = self._torch
+        if self.host_buffers or self.world == 1:
+            return True
+        dev = torch.device("cuda", torch.cuda.current_device())
+        sp = stream if stream is not None else c_void_p(torch.cuda.current_stream().cuda_stream)
+        n, W, ok = 1 << 16, self.world, True
+
+        def pattern(a, b):
+            return ((torch.arange(n, dtype=torch.int64) * (2 * a + 3) + 7 * b + 1) % 251).to(torch.uint8)
+        try:
+            send = pattern(self.rank, 0).to(dev)
+            recv = torch.zeros(n * W, dtype=torch.uint8, device=dev)
+            torch.cuda.synchronize()
+            ok &= self._allgather_device(None, send.data_ptr(), recv.data_ptr(), n, sp) == 0
+            torch.cuda.synchronize()
+            ok &= bool(torch.equal(recv.cpu(), torch.cat([pattern(r, 0) for r in range(W)])))
+            send2 = torch.cat([pattern(self.rank, s + 1) for s in range(W)]).to(dev)
+            recv2 = torch.zeros(n * W, dtype=torch.uint8, device=dev)
+            torch.cuda.synchronize()
+            ok &= self._alltoall_device(None, send2.data_ptr(), recv2.data_ptr(), n, sp) == 0
+            torch.cuda.synchronize()
+            ok &= bool(torch.equal(recv2.cpu(), torch.cat([pattern(s, self.rank + 1) for s in range(W)])))
+        except Exception:  # noqa: BLE001
+            ok = False
+        mine = np.array([1 if ok else 0], dtype=np.uint8)
+        every = np.zeros(W, dtype=np.uint8)
+        check(_lib().ovm_hip_shm_allgather(self.comm, mine.ctypes.data, every.ctypes.data, 1), "ovm_hip_shm_allgather")
+        self.bulk_bytes, self.alltoall_calls = 0, 0
+        if not every.all():
+            self.bulk = "shm"
+            return False
+        return True
+
     def close(self):
         if self.comm:
             _lib().ovm_hip_shm_comm_destroy(self.comm)

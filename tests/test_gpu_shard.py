@@ -150,3 +150,74 @@ print("nccl bulk exchange ok")
 """ % (HERE, str(_free_port()))
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "nccl bulk exchange ok" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
+
+
+def test_bulk_preflight_falls_back_to_shared_memory(tmp_path):
+    """Shard.check_bulk: two ranks (gloo, one GPU) run the pre-flight of the device exchanges; with the all-gather
+    callback of rank 1 sabotaged (it delivers wrong bytes) BOTH ranks must report failure and switch to the
+    shared-memory staging -- and the exchange must then deliver the right data."""
+    code = """
+import os, sys
+sys.path.insert(0, %r)
+rank, world, port, shm, sabotage = int(sys.argv[1]), 2, sys.argv[2], sys.argv[3], sys.argv[4] == "1"
+import torch, torch.distributed as dist
+from conftest import load_pkg
+pkg = load_pkg()
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=port, RANK=str(rank), WORLD_SIZE="2")
+dist.init_process_group("gloo", rank=rank, world_size=2)
+dev = pkg.Device(0)
+shard = pkg.Shard(rank, world, shm)
+if sabotage and rank == 1:
+    real = shard._allgather_device
+    def broken(ctx, d_mine, d_all, nbytes, stream):
+        rc = real(ctx, d_mine, d_all, nbytes, stream)
+        pkg.check(pkg._lib().ovm_hip_memset(d_all, 0xFF, 16, stream), "memset")   # (the pattern bytes are all < 251)
+        pkg.check(pkg._lib().ovm_hip_stream_synchronize(stream), "sync")
+        return rc
+    shard._allgather_device = broken
+ok = shard.check_bulk()
+assert ok == (not sabotage), (rank, ok)
+assert shard.bulk == ("shm" if sabotage else "torch")
+# the exchange the prover would now use delivers the right bytes
+src = (torch.arange(4096, dtype=torch.int32, device="cuda:0") + 1000 * rank)
+dst = torch.zeros(2 * 4096, dtype=torch.int32, device="cuda:0")
+cb = type(shard)._allgather_device.__get__(shard)
+assert cb(None, src.data_ptr(), dst.data_ptr(), 4096 * 4, dev.stream.value or 0) == 0
+torch.cuda.synchronize()
+want = torch.cat([torch.arange(4096, dtype=torch.int32) + 1000 * r for r in range(2)])
+assert torch.equal(dst.cpu(), want)
+dist.barrier()
+dist.destroy_process_group()
+print("preflight ok", rank)
+""" % (HERE,)
+    script = tmp_path / "preflight.py"
+    script.write_text(code)
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env["OVM_SHARD_TIMEOUT_S"] = "60"
+    for sabotage in ("0", "1"):
+        port, shm = str(_free_port()), f"/ovm-test-{uuid.uuid4().hex[:12]}"
+        procs = [subprocess.Popen([sys.executable, str(script), str(r), port, shm, sabotage], env=env, stdout=subprocess.PIPE,
+                                  stderr=subprocess.STDOUT, text=True) for r in range(2)]
+        outs = [p.communicate(timeout=300)[0] for p in procs]
+        assert all(p.returncode == 0 for p in procs), "\n".join(o[-2000:] for o in outs)
+
+
+def test_bench_with_two_ranks_on_one_gpu(tmp_path):
+    """`bench.py --gpus 2` end to end on this one GPU (--one-gpu: gloo, host-staged) at a reduced size: the launcher
+    starts its own ranks, the partitioned BenchmarkAir per rank is committed and the joint proof made; one JSON line
+    with n_gpus 2 comes back and two runs give the same proof."""
+    root = os.path.dirname(HERE)
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env["OVM_SHARD_TIMEOUT_S"] = "60"
+    hashes = []
+    for _ in range(2):
+        out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--one-gpu", "--log-rows", "12",
+                              "--log-stacked-height", "16", "--steps", "1", "--warmup", "1", "--no-cpu-baseline"],
+                             env=env, cwd=root, capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stderr[-3000:]
+        import json
+        line = json.loads(out.stdout.strip().splitlines()[-1])
+        assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["config"]["proof_bytes"] > 0
+        assert line["value"] > 0 and "host-staged" in line["config"]["parallelism"]
+        hashes.append(line["config"]["proof_sha256"])
+    assert hashes[0] == hashes[1]
