@@ -92,6 +92,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--zero-trace", action="store_true",
                     help="all-zero trace (what the reference's uniform_runner proves) instead of seeded random bits")
+    ap.add_argument("--bulk", default="rccl", choices=["rccl", "ipc", "shm"],
+                    help="N > 1: the bulk device exchange -- torch.distributed (RCCL; default), the library's own IPC pulls, "
+                         "or host staging through shared memory (the pre-flight falls back along this chain by itself)")
     ap.add_argument("--launch-check", action="store_true",
                     help="only start the ranks, rendezvous (gloo when there is no GPU) and print n_gpus: the launcher's CPU test")
     ap.add_argument("--one-gpu", action="store_true",
@@ -167,7 +170,7 @@ def main():
         pk = pkg.ProvingKey(airs.pk_blob(params, [air] * world))
         name = [f"/ovm-bench-{os.getpid()}-{int(time.time() * 1e3) & 0xFFFFFF}"]
         dist.broadcast_object_list(name, src=0)
-        shard = pkg.Shard(rank, world, name[0])
+        shard = pkg.Shard(rank, world, name[0], bulk={"rccl": "torch"}.get(args.bulk, args.bulk))
         # pre-flight of the RCCL exchanges on rank-dependent data; if any rank sees wrong bytes or an error, every rank
         # switches to host staging through the shared-memory segment (and the JSON line says so)
         bulk_ok = shard.check_bulk()
@@ -275,8 +278,12 @@ def main():
         par = "1 GPU" if world == 1 else (f"sharded x{world}: ONE joint proof, one AIR (cached-main commitment) per GPU, "
                                           f"per-round values over shared memory, the mu-batched WHIR vectors summed by "
                                           + ("RCCL all-to-all + all-gather" if shard.bulk == "torch" and not args.one_gpu else
-                                             "an exchange STAGED THROUGH HOST shared memory (the RCCL pre-flight failed)" if shard.bulk == "shm"
-                                             else "gloo, host-staged [--one-gpu: ranks share GPU 0]"))
+                                             "the library's IPC exchange (peer buffers mapped, device-to-device pulls)"
+                                             + ("" if args.bulk == "ipc" else " -- the RCCL pre-flight FAILED") if shard.bulk == "ipc" else
+                                             "an exchange STAGED THROUGH HOST shared memory"
+                                             + ("" if args.bulk == "shm" else " -- the pre-flights of RCCL and IPC FAILED") if shard.bulk == "shm"
+                                             else "gloo, host-staged")
+                                          + (" [--one-gpu: ranks share GPU 0]" if args.one_gpu else ""))
         line = {
             "metric": "trace_cells_per_sec", "value": round(value, 1), "unit": "cells/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),

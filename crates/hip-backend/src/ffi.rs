@@ -31,6 +31,10 @@ pub struct OvmPcs {
 pub struct OvmShmComm {
     _private: [u8; 0],
 }
+#[repr(C)]
+pub struct OvmIpcComm {
+    _private: [u8; 0],
+}
 
 /// `ovm_trace_t` (reference: AirProvingContext, prover/types.rs:59-73)
 #[repr(C)]
@@ -331,6 +335,23 @@ extern "C" {
         three_points: c_int,
     ) -> c_int;
     pub fn ovm_hip_selftest_error() -> *const c_char;
+    pub fn ovm_hip_ipc_comm_create(shm: *mut OvmShmComm, rank: u32, world: u32, out: *mut *mut OvmIpcComm) -> c_int;
+    pub fn ovm_hip_ipc_comm_destroy(comm: *mut OvmIpcComm);
+    pub fn ovm_hip_ipc_allgather_host(comm: *mut c_void, mine: *const c_void, all: *mut c_void, bytes: u64) -> c_int;
+    pub fn ovm_hip_ipc_allgather_device(
+        comm: *mut c_void,
+        d_mine: *const c_void,
+        d_all: *mut c_void,
+        bytes: u64,
+        stream: OvmStream,
+    ) -> c_int;
+    pub fn ovm_hip_ipc_alltoall_device(
+        comm: *mut c_void,
+        d_send: *const c_void,
+        d_recv: *mut c_void,
+        bytes: u64,
+        stream: OvmStream,
+    ) -> c_int;
     pub fn ovm_hip_shard_exchange_selftest(shard: *const OvmShard, n: u64, rounds: u32, seed: u64) -> c_int;
     pub fn ovm_hip_prove_sharded(
         pk: *const OvmPk,

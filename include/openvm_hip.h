@@ -385,6 +385,20 @@ int ovm_hip_shm_comm_attach(void *base, uint32_t rank, uint32_t world, uint64_t 
 void ovm_hip_shm_comm_destroy(ovm_shm_comm_t *comm);
 int ovm_hip_shm_allgather(void *comm, const void *mine, void *all, uint64_t bytes);
 
+/* Built-in BULK exchange for the ranks of one node, no collective library: every rank publishes an IPC handle of
+ * the allocation its send buffer lives in, the peers map it (once; the mappings are kept) and pull their part with
+ * device-to-device copies on their own stream -- over xGMI between GPUs, or between processes that share a GPU. The
+ * handles and the barriers travel through `shm` (which must outlive the communicator). Use: ovm_shard_t.ctx = the
+ * ipc communicator, .allgather_host = ovm_hip_ipc_allgather_host (forwards to shm), .allgather_device =
+ * ovm_hip_ipc_allgather_device, .alltoall_device = ovm_hip_ipc_alltoall_device. Send buffers must be device
+ * allocations of this process (hipMalloc, directly or through a pool). */
+typedef struct ovm_ipc_comm ovm_ipc_comm_t;
+int ovm_hip_ipc_comm_create(ovm_shm_comm_t *shm, uint32_t rank, uint32_t world, ovm_ipc_comm_t **out);
+void ovm_hip_ipc_comm_destroy(ovm_ipc_comm_t *comm);
+int ovm_hip_ipc_allgather_host(void *comm, const void *mine, void *all, uint64_t bytes);
+int ovm_hip_ipc_allgather_device(void *comm, const void *d_mine, void *d_all, uint64_t bytes, ovm_stream_t stream);
+int ovm_hip_ipc_alltoall_device(void *comm, const void *d_send, void *d_recv, uint64_t bytes, ovm_stream_t stream);
+
 /* Host-only self-test of the sharded LogUp-GKR bookkeeping (csrc/gkr_shard.h): `world` simulated ranks
  * (threads over the shared-memory exchange) own the leaf runs [0, ends[0]), [ends[0], ends[1]), ... of a
  * random fraction tree of 2^TR leaves, the rest is padding; every rank's transcript must equal that of the

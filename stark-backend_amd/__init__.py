@@ -114,6 +114,11 @@ SIGNATURES = {
     "ovm_hip_trim": (c_int, []),
     "ovm_hip_set_prover_config": (c_int, [POINTER(ProverConfigStruct)]),
     "ovm_hip_memory_stats": (c_int, [_u64p, _u64p, _u64p, c_int]),
+    "ovm_hip_ipc_comm_create": (c_int, [c_void_p, c_uint32, c_uint32, POINTER(c_void_p)]),
+    "ovm_hip_ipc_comm_destroy": (None, [c_void_p]),
+    "ovm_hip_ipc_allgather_host": (c_int, [c_void_p, c_void_p, c_void_p, c_uint64]),
+    "ovm_hip_ipc_allgather_device": (c_int, [c_void_p, c_void_p, c_void_p, c_uint64, c_void_p]),
+    "ovm_hip_ipc_alltoall_device": (c_int, [c_void_p, c_void_p, c_void_p, c_uint64, c_void_p]),
     "ovm_hip_pool_stats": (c_int, [_u64p]),
     "ovm_hip_pool_selftest": (c_int, [c_uint64, c_uint32]),
     "ovm_hip_constraint_eval_buffer_size": (c_uint64, [c_void_p, c_uint32]),
@@ -461,7 +466,8 @@ class Shard:
 
         self.rank, self.world, self.group = rank, world, group
         self.host_buffers = host_buffers  # the bulk exchange is handed HOST pointers (CPU tests of the callback)
-        # bulk = "torch": torch.distributed (nccl = RCCL; gloo = host-staged). bulk = "shm": staged through the library's own
+        # bulk = "torch": torch.distributed (nccl = RCCL; gloo = host-staged). bulk = "ipc": the library's own exchange (peer
+        # buffers mapped through HIP IPC, device-to-device pulls; no process group needed). bulk = "shm": staged through the library's own
         # shared-memory exchange, no process group at all -- ranks that share one GPU in the tests.
         self.bulk = bulk
         h = c_void_p(0)
@@ -470,11 +476,25 @@ class Shard:
         self._torch, self._dist = torch, dist
         self._cb = _AG_DEVICE(self._allgather_device)
         self._cb_a2a = _AG_DEVICE(self._alltoall_device)
-        # alltoall=False hands the library a null all-to-all: the mu-batch vectors are then all-gathered whole
-        self.abi = ShardStruct(rank, world, h, ctypes.cast(_lib().ovm_hip_shm_allgather, c_void_p),
-                               ctypes.cast(self._cb, c_void_p), ctypes.cast(self._cb_a2a, c_void_p) if alltoall else None)
+        # bulk = "ipc": the library's own exchange (IPC-mapped peer buffers + device-to-device pulls, csrc/ipc_comm.cpp)
+        self.ipc = c_void_p(0)
+        check(_lib().ovm_hip_ipc_comm_create(h, rank, world, ctypes.byref(self.ipc)), "ovm_hip_ipc_comm_create")
+        self._alltoall = alltoall
+        self._set_abi()
         self.bulk_bytes = 0
         self.alltoall_calls = 0
+
+    def _set_abi(self):
+        """(Re)build the ovm_shard_t for the current ``bulk`` mode. alltoall=False hands the library a null all-to-all:
+        the mu-batch vectors are then all-gathered whole."""
+        lib = _lib()
+        if self.bulk == "ipc" and not self.host_buffers:  # no Python in the data path at all
+            self.abi = ShardStruct(self.rank, self.world, self.ipc, ctypes.cast(lib.ovm_hip_ipc_allgather_host, c_void_p),
+                                   ctypes.cast(lib.ovm_hip_ipc_allgather_device, c_void_p),
+                                   ctypes.cast(lib.ovm_hip_ipc_alltoall_device, c_void_p) if self._alltoall else None)
+        else:
+            self.abi = ShardStruct(self.rank, self.world, self.comm, ctypes.cast(lib.ovm_hip_shm_allgather, c_void_p),
+                                   ctypes.cast(self._cb, c_void_p), ctypes.cast(self._cb_a2a, c_void_p) if self._alltoall else None)
 
     def _alltoall_device(self, ctx, d_send, d_recv, nbytes, stream):
         """d_recv[s * nbytes ..] = rank s's d_send[rank * nbytes ..] (``nbytes`` per PAIR of ranks)."""
@@ -491,6 +511,8 @@ class Shard:
                 return 0
             torch.cuda.current_stream().synchronize()
             check(_lib().ovm_hip_stream_synchronize(stream), "ovm_hip_stream_synchronize")
+            if self.bulk == "ipc":
+                return int(_lib().ovm_hip_ipc_alltoall_device(self.ipc, d_send, d_recv, nbytes, stream))
             if self.bulk == "shm":  # (tests: ranks sharing one GPU, no process group) every rank's whole vector, then pick
                 send = np.empty(total, dtype=np.uint8)
                 everything = np.empty(total * self.world, dtype=np.uint8)
@@ -557,6 +579,8 @@ class Shard:
             torch.cuda.current_stream().synchronize()
             check(_lib().ovm_hip_stream_synchronize(stream), "ovm_hip_stream_synchronize")
             self.bulk_bytes += int(nbytes) * self.world
+            if self.bulk == "ipc":
+                return int(_lib().ovm_hip_ipc_allgather_device(self.ipc, d_mine, d_all, nbytes, stream))
             if self.bulk == "shm":
                 send = np.empty(nbytes, dtype=np.uint8)
                 recv = np.empty(nbytes * self.world, dtype=np.uint8)
@@ -603,8 +627,9 @@ class Shard:
         """Pre-flight of the device exchanges: a small all-gather and all-to-all of rank-dependent bytes through the very
         callbacks the prover will call, verified on every rank; the ranks then agree (one byte each through the
         shared-memory exchange) on whether ALL of them saw the right data. On False the communicator has switched itself
-        to bulk="shm" (host-staged through the shared-memory segment: slower, needs nothing but this library), so a
-        deployment whose collective library misbehaves still proves."""
+        to the next exchange in line -- bulk="ipc" (the library's own: IPC-mapped peer buffers + device-to-device pulls),
+        checked the same way, then bulk="shm" (host-staged through the shared-memory segment: slow, needs nothing but
+        this library) -- so a deployment whose collective library misbehaves still proves."""
         torch = self._torch
         if self.host_buffers or self.world == 1:
             return True
@@ -634,11 +659,18 @@ class Shard:
         check(_lib().ovm_hip_shm_allgather(self.comm, mine.ctypes.data, every.ctypes.data, 1), "ovm_hip_shm_allgather")
         self.bulk_bytes, self.alltoall_calls = 0, 0
         if not every.all():
-            self.bulk = "shm"
+            # next in line: the library's own IPC exchange, then host staging through the shared-memory segment
+            self.bulk = "ipc" if self.bulk == "torch" else "shm"
+            self._set_abi()
+            if self.bulk == "ipc":
+                self.check_bulk(stream)
             return False
         return True
 
     def close(self):
+        if self.ipc:
+            _lib().ovm_hip_ipc_comm_destroy(self.ipc)
+            self.ipc = None
         if self.comm:
             _lib().ovm_hip_shm_comm_destroy(self.comm)
             self.comm = None

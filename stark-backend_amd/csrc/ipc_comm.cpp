@@ -1,0 +1,168 @@
+// Bulk device exchange of a sharded proof WITHOUT a collective library: every rank publishes an IPC
+// handle of the allocation its send buffer lives in, the peers map it once (mappings are kept: the
+// memory pool's segments persist across proofs) and PULL their part with plain device-to-device
+// copies on their own stream -- over xGMI between the GPUs of a node, each pair on its own link, which is
+// exactly the traffic pattern of the all-to-all + all-gather the prover asks for.
+// The handles and the two barriers of an exchange travel through the shared-memory communicator
+// (shard.cpp). Ranks that share one GPU (the tests) work the same way: IPC between processes on one
+// device. The reference has no peer for this file; a deployment that prefers RCCL passes its own
+// callbacks in ovm_shard_t instead (the Python host does, with this as its first fall-back).
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "openvm_hip.h"
+
+extern "C" int ovm_hip_shm_allgather(void *comm, const void *mine, void *all, uint64_t bytes);
+
+struct ovm_ipc_comm {
+    ovm_shm_comm_t *shm = nullptr;
+    uint32_t rank = 0, world = 1;
+    // mappings of peers' allocations, by handle bytes
+    std::map<std::string, void *> opened;
+    // handles of my own allocations, by base address
+    std::map<void *, hipIpcMemHandle_t> mine;
+
+    struct Msg {
+        hipIpcMemHandle_t handle;
+        uint64_t offset;
+        uint64_t bytes;  // of the sender's whole buffer (checked against what the receiver expects)
+        int32_t status;
+        int32_t pad;
+    };
+
+    int barrier() { return ovm_hip_shm_allgather(shm, nullptr, nullptr, 0); }
+
+    // every rank's send buffer, mapped into this process (own rank: the pointer itself)
+    int publish_and_map(const void *d_send, uint64_t send_bytes, hipStream_t stream, std::vector<const uint8_t *> &src) {
+        Msg m{};
+        m.bytes = send_bytes;
+        // what was enqueued before the exchange must have produced the data before a peer reads it
+        hipError_t e = hipStreamSynchronize(stream);
+        void *base = nullptr;
+        size_t size = 0;
+        if (e == hipSuccess) e = hipMemGetAddressRange((hipDeviceptr_t *)&base, &size, (hipDeviceptr_t)d_send);
+        if (e == hipSuccess) {
+            auto it = mine.find(base);
+            if (it == mine.end()) {
+                hipIpcMemHandle_t h;
+                e = hipIpcGetMemHandle(&h, base);
+                if (e == hipSuccess) it = mine.emplace(base, h).first;
+            }
+            if (e == hipSuccess) {
+                m.handle = it->second;
+                m.offset = (uint64_t)((const uint8_t *)d_send - (const uint8_t *)base);
+            }
+        }
+        if (e != hipSuccess) (void)hipGetLastError();
+        m.status = (int32_t)e;
+        std::vector<Msg> all(world);
+        // (this all-gather is also the barrier "every rank's data is ready")
+        const int rc = ovm_hip_shm_allgather(shm, &m, all.data(), sizeof(Msg));
+        if (rc) return rc;
+        for (uint32_t r = 0; r < world; r++)
+            if (all[r].status != 0) return all[r].status;  // every rank sees the same failure
+        src.assign(world, nullptr);
+        int first_error = 0;
+        for (uint32_t r = 0; r < world; r++) {
+            if (all[r].bytes != send_bytes) first_error = first_error ? first_error : (int)hipErrorInvalidValue;
+            if (r == rank) {
+                src[r] = (const uint8_t *)d_send;
+                continue;
+            }
+            const std::string key((const char *)&all[r].handle, sizeof(hipIpcMemHandle_t));
+            auto it = opened.find(key);
+            if (it == opened.end()) {
+                void *p = nullptr;
+                const hipError_t oe = hipIpcOpenMemHandle(&p, all[r].handle, hipIpcMemLazyEnablePeerAccess);
+                if (oe != hipSuccess) {
+                    (void)hipGetLastError();
+                    first_error = first_error ? first_error : (int)oe;
+                    continue;
+                }
+                it = opened.emplace(key, p).first;
+            }
+            src[r] = (const uint8_t *)it->second + all[r].offset;
+        }
+        return first_error;
+    }
+
+    // outcome agreed by all ranks (a rank that failed to map must not leave the others waiting in the pulls' barrier)
+    int agree(int mine_rc) {
+        std::vector<int32_t> all(world);
+        const int32_t v = mine_rc;
+        const int rc = ovm_hip_shm_allgather(shm, &v, all.data(), sizeof(int32_t));
+        if (rc) return rc;
+        for (int32_t x : all)
+            if (x) return x;
+        return 0;
+    }
+
+    int allgather(const void *d_mine, void *d_all, uint64_t bytes, hipStream_t stream) {
+        std::vector<const uint8_t *> src;
+        int rc = agree(publish_and_map(d_mine, bytes, stream, src));
+        if (rc) return rc;
+        hipError_t e = hipSuccess;
+        for (uint32_t k = 0; k < world && e == hipSuccess; k++) {
+            const uint32_t r = (rank + k) % world;  // start with the own block, then spread the peers
+            e = hipMemcpyAsync((uint8_t *)d_all + (uint64_t)r * bytes, src[r], bytes, hipMemcpyDeviceToDevice, stream);
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(stream);
+        if (e != hipSuccess) (void)hipGetLastError();
+        // nobody's send buffer may change before every rank has pulled from it
+        rc = agree((int)e);
+        return rc;
+    }
+
+    int alltoall(const void *d_send, void *d_recv, uint64_t bytes, hipStream_t stream) {
+        std::vector<const uint8_t *> src;
+        int rc = agree(publish_and_map(d_send, bytes * world, stream, src));
+        if (rc) return rc;
+        hipError_t e = hipSuccess;
+        for (uint32_t k = 0; k < world && e == hipSuccess; k++) {
+            const uint32_t s = (rank + k) % world;
+            e = hipMemcpyAsync((uint8_t *)d_recv + (uint64_t)s * bytes, src[s] + (uint64_t)rank * bytes, bytes, hipMemcpyDeviceToDevice, stream);
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(stream);
+        if (e != hipSuccess) (void)hipGetLastError();
+        return agree((int)e);
+    }
+};
+
+extern "C" {
+
+int ovm_hip_ipc_comm_create(ovm_shm_comm_t *shm, uint32_t rank, uint32_t world, ovm_ipc_comm_t **out) {
+    if (!shm || !out || world == 0 || rank >= world) return (int)hipErrorInvalidValue;
+    auto *c = new ovm_ipc_comm();
+    c->shm = shm;
+    c->rank = rank;
+    c->world = world;
+    *out = c;
+    return 0;
+}
+
+void ovm_hip_ipc_comm_destroy(ovm_ipc_comm_t *c) {
+    if (!c) return;
+    for (auto &kv : c->opened) (void)hipIpcCloseMemHandle(kv.second);
+    delete c;
+}
+
+int ovm_hip_ipc_allgather_host(void *ctx, const void *mine, void *all, uint64_t bytes) {
+    if (!ctx) return (int)hipErrorInvalidValue;
+    return ovm_hip_shm_allgather(static_cast<ovm_ipc_comm *>(ctx)->shm, mine, all, bytes);
+}
+
+int ovm_hip_ipc_allgather_device(void *ctx, const void *d_mine, void *d_all, uint64_t bytes, ovm_stream_t stream) {
+    if (!ctx || !d_mine || !d_all || bytes == 0) return (int)hipErrorInvalidValue;
+    return static_cast<ovm_ipc_comm *>(ctx)->allgather(d_mine, d_all, bytes, (hipStream_t)stream);
+}
+
+int ovm_hip_ipc_alltoall_device(void *ctx, const void *d_send, void *d_recv, uint64_t bytes, ovm_stream_t stream) {
+    if (!ctx || !d_send || !d_recv || bytes == 0) return (int)hipErrorInvalidValue;
+    return static_cast<ovm_ipc_comm *>(ctx)->alltoall(d_send, d_recv, bytes, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -35,6 +35,7 @@ def main():
     for case in range(args.cases):
         seed, world = int(rng.integers(0, 1 << 30)), int(rng.integers(2, 5))
         save_memory, alltoall = bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
+        bulk = str(rng.choice(["ipc", "ipc", "shm"]))
         params, air_list, traces, owners = shard_cases.make(f"fuzz:{seed}", world)
         blob = airs.pk_blob(params, air_list)
         try:
@@ -43,11 +44,11 @@ def main():
             print(f"case {case}: skipped (the protocol rejects the context: {e})", flush=True)
             continue
         with tempfile.TemporaryDirectory() as tmp:
-            got = run_sharded(f"fuzz:{seed}", world, pathlib.Path(tmp), save_memory=save_memory, alltoall=alltoall)
+            got = run_sharded(f"fuzz:{seed}", world, pathlib.Path(tmp), save_memory=save_memory, alltoall=alltoall, bulk=bulk)
         ok = got == want
         bad += not ok
         print(f"case {case}: {'ok' if ok else 'MISMATCH'} seed={seed} world={world} airs={len(air_list)} owners={owners} "
-              f"save_memory={save_memory} alltoall={alltoall}", flush=True)
+              f"save_memory={save_memory} alltoall={alltoall} bulk={bulk}", flush=True)
     print(f"{bad} mismatches in {args.cases} cases")
     sys.exit(1 if bad else 0)
 

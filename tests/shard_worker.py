@@ -23,6 +23,8 @@ def main():
     ap.add_argument("--repeat", type=int, default=1)
     ap.add_argument("--save-memory", action="store_true",
                     help="prove in the memory-bounded modes (codeword dropped, round 0 in slabs of 8 rows, leaf layer dropped)")
+    ap.add_argument("--bulk", default="ipc", choices=["ipc", "shm"],
+                    help="the bulk device exchange: the library's IPC pulls, or host staging through the shared-memory segment")
     ap.add_argument("--no-alltoall", action="store_true",
                     help="hand the library a null alltoall_device: the mu-batch vectors are all-gathered whole")
     args = ap.parse_args()
@@ -35,13 +37,14 @@ def main():
     import shard_cases
 
     pkg = load_pkg()
-    # (no process group: the ranks share one GPU, so the bulk exchange is staged through the library's own
-    # shared-memory exchange; torch.distributed's part is covered by tests/test_shard_cpu.py (gloo) and the nccl test)
+    # (no process group: the ranks share one GPU; the bulk exchange is the library's own -- IPC-mapped peer buffers and
+    # device-to-device pulls, or staged through its shared-memory exchange; torch.distributed's part is covered by
+    # tests/test_shard_cpu.py (gloo) and the nccl test)
     t_pg = time.time()
     dev = pkg.Device(0)
     if args.save_memory:
         pkg.set_prover_config(cache_rs_code_matrix=False, zerocheck_save_memory=True, round0_slab_log_rows=3, gkr_drop_leaves=True)
-    shard = pkg.Shard(args.rank, args.world, args.shm, bulk="shm", alltoall=not args.no_alltoall)
+    shard = pkg.Shard(args.rank, args.world, args.shm, bulk=args.bulk, alltoall=not args.no_alltoall)
     if args.case.startswith("gen:"):
         # "gen:<log_rows>:<cols>:<log_stacked_height>": one partitioned BenchmarkAir per rank under app parameters, the
         # seeded boolean trace generated on the device (BASELINE config D's multi-GPU form at any size)

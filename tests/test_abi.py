@@ -47,7 +47,7 @@ import re
 _C_TO_RUST = {"void": "c_void", "int": "c_int", "char": "c_char", "uint32_t": "u32", "uint64_t": "u64", "uint8_t": "u8",
               "size_t": "usize", "ovm_stream_t": "OvmStream", "ovm_sponge_t": "OvmSponge", "ovm_pk_t": "OvmPk",
               "ovm_pcs_t": "OvmPcs", "ovm_trace_t": "OvmTrace", "ovm_pcs_params_t": "OvmPcsParams",
-              "ovm_matrix_t": "OvmMatrix", "ovm_shard_t": "OvmShard", "ovm_shm_comm_t": "OvmShmComm",
+              "ovm_matrix_t": "OvmMatrix", "ovm_shard_t": "OvmShard", "ovm_shm_comm_t": "OvmShmComm", "ovm_ipc_comm_t": "OvmIpcComm",
               "ovm_prover_config_t": "OvmProverConfig"}
 
 

@@ -25,13 +25,14 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def run_sharded(case, world, tmp_path, repeat=1, save_memory=False, alltoall=True):
+def run_sharded(case, world, tmp_path, repeat=1, save_memory=False, alltoall=True, bulk="ipc"):
     port, shm, out = _free_port(), f"/ovm-test-{uuid.uuid4().hex[:12]}", str(tmp_path / "proof.bin")
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
     env["OVM_SHARD_TIMEOUT_S"] = "60"  # a rank that died must not hold the others for minutes
     procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "shard_worker.py"), "--rank", str(r), "--world", str(world),
                                "--port", str(port), "--case", case, "--shm", shm, "--out", out, "--repeat", str(repeat)]
-                              + (["--save-memory"] if save_memory else []) + ([] if alltoall else ["--no-alltoall"]),
+                              + (["--save-memory"] if save_memory else []) + ([] if alltoall else ["--no-alltoall"])
+                              + ["--bulk", bulk],
                               env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
     logs = []
     for p in procs:
@@ -80,6 +81,14 @@ def test_sharded_in_the_memory_bounded_modes(orc, tmp_path, case, world):
     the joint proof does not change."""
     blob, want = oracle_proof(orc, case, world)
     assert run_sharded(case, world, tmp_path, save_memory=True) == want
+
+
+@pytest.mark.parametrize("case,world", [("bench_app", 2), ("bench8", 4), ("mixture", 3)])
+def test_bulk_exchange_staged_through_shared_memory(orc, tmp_path, case, world):
+    """The last fall-back of the bulk exchange (device -> host -> shared-memory segment -> device), which every other test
+    here replaces by the library's IPC exchange: the same proof."""
+    blob, want = oracle_proof(orc, case, world)
+    assert run_sharded(case, world, tmp_path, bulk="shm") == want
 
 
 @pytest.mark.parametrize("case,world", [("bench_app", 2), ("bench8", 3)])
@@ -152,10 +161,10 @@ print("nccl bulk exchange ok")
     assert out.returncode == 0 and "nccl bulk exchange ok" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
 
 
-def test_bulk_preflight_falls_back_to_shared_memory(tmp_path):
+def test_bulk_preflight_falls_back_to_the_builtin_exchange(tmp_path):
     """Shard.check_bulk: two ranks (gloo, one GPU) run the pre-flight of the device exchanges; with the all-gather
-    callback of rank 1 sabotaged (it delivers wrong bytes) BOTH ranks must report failure and switch to the
-    shared-memory staging -- and the exchange must then deliver the right data."""
+    callback of rank 1 sabotaged (it delivers wrong bytes) BOTH ranks must report failure and switch to the next
+    exchange in line, the library's IPC pulls -- and that exchange must then deliver the right data."""
     code = """
 import os, sys
 sys.path.insert(0, %r)
@@ -171,13 +180,14 @@ if sabotage and rank == 1:
     real = shard._allgather_device
     def broken(ctx, d_mine, d_all, nbytes, stream):
         rc = real(ctx, d_mine, d_all, nbytes, stream)
-        pkg.check(pkg._lib().ovm_hip_memset(d_all, 0xFF, 16, stream), "memset")   # (the pattern bytes are all < 251)
-        pkg.check(pkg._lib().ovm_hip_stream_synchronize(stream), "sync")
+        if shard.bulk == "torch":  # (only the process-group exchange is broken: the library's own must then take over)
+            pkg.check(pkg._lib().ovm_hip_memset(d_all, 0xFF, 16, stream), "memset")   # (the pattern bytes are all < 251)
+            pkg.check(pkg._lib().ovm_hip_stream_synchronize(stream), "sync")
         return rc
     shard._allgather_device = broken
 ok = shard.check_bulk()
 assert ok == (not sabotage), (rank, ok)
-assert shard.bulk == ("shm" if sabotage else "torch")
+assert shard.bulk == ("ipc" if sabotage else "torch")
 # the exchange the prover would now use delivers the right bytes
 src = (torch.arange(4096, dtype=torch.int32, device="cuda:0") + 1000 * rank)
 dst = torch.zeros(2 * 4096, dtype=torch.int32, device="cuda:0")
@@ -205,19 +215,19 @@ print("preflight ok", rank)
 def test_bench_with_two_ranks_on_one_gpu(tmp_path):
     """`bench.py --gpus 2` end to end on this one GPU (--one-gpu: gloo, host-staged) at a reduced size: the launcher
     starts its own ranks, the partitioned BenchmarkAir per rank is committed and the joint proof made; one JSON line
-    with n_gpus 2 comes back and two runs give the same proof."""
+    with n_gpus 2 comes back, with each of the three bulk exchanges, and the proof is the same."""
     root = os.path.dirname(HERE)
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
     env["OVM_SHARD_TIMEOUT_S"] = "60"
     hashes = []
-    for _ in range(2):
+    for bulk, says in (("rccl", "host-staged"), ("ipc", "IPC exchange"), ("shm", "shared memory")):
         out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--one-gpu", "--log-rows", "12",
-                              "--log-stacked-height", "16", "--steps", "1", "--warmup", "1", "--no-cpu-baseline"],
+                              "--log-stacked-height", "16", "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--bulk", bulk],
                              env=env, cwd=root, capture_output=True, text=True, timeout=600)
         assert out.returncode == 0, out.stderr[-3000:]
         import json
         line = json.loads(out.stdout.strip().splitlines()[-1])
         assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["config"]["proof_bytes"] > 0
-        assert line["value"] > 0 and "host-staged" in line["config"]["parallelism"]
+        assert line["value"] > 0 and says in line["config"]["parallelism"] and "FAILED" not in line["config"]["parallelism"]
         hashes.append(line["config"]["proof_sha256"])
-    assert hashes[0] == hashes[1]
+    assert len(set(hashes)) == 1   # the same joint proof whichever way the bulk data travelled
