@@ -76,7 +76,52 @@ unsafe extern "C" fn alltoall_trampoline(
     comm.bulk.alltoall_device(d_send, d_recv, bytes, stream).unwrap_or(1)
 }
 
+/// The library's own bulk exchange (`csrc/ipc_comm.cpp`): peers map each other's send buffers through
+/// HIP IPC and pull their slices with device-to-device copies -- over xGMI between the GPUs of a node. No
+/// collective library is linked; `ShardComm::with_ipc` builds a communicator around it.
+pub struct IpcBulk {
+    ipc: *mut ffi::OvmIpcComm,
+}
+// SAFETY: the communicator is only used from the thread that drives the prover.
+unsafe impl Send for IpcBulk {}
+impl BulkExchange for IpcBulk {
+    fn allgather_device(&mut self, d_mine: *const c_void, d_all: *mut c_void, bytes: u64, stream: ffi::OvmStream) -> i32 {
+        // SAFETY: device pointers of this process, valid for `bytes` / `world * bytes`.
+        unsafe { ffi::ovm_hip_ipc_allgather_device(self.ipc as *mut c_void, d_mine, d_all, bytes, stream) }
+    }
+    fn alltoall_device(&mut self, d_send: *const c_void, d_recv: *mut c_void, bytes: u64, stream: ffi::OvmStream) -> Option<i32> {
+        // SAFETY: as above.
+        Some(unsafe { ffi::ovm_hip_ipc_alltoall_device(self.ipc as *mut c_void, d_send, d_recv, bytes, stream) })
+    }
+    fn has_alltoall(&self) -> bool {
+        true
+    }
+}
+impl Drop for IpcBulk {
+    fn drop(&mut self) {
+        // SAFETY: created by ovm_hip_ipc_comm_create, destroyed once -- before the shared-memory communicator it
+        // uses (ShardComm::drop replaces `bulk` first).
+        unsafe { ffi::ovm_hip_ipc_comm_destroy(self.ipc) };
+    }
+}
+
 impl ShardComm {
+    /// A communicator whose bulk exchange is the library's own (no RCCL binding needed).
+    pub fn with_ipc(name: &str, rank: u32, world: u32) -> Result<Box<Self>, HipError> {
+        struct Pending;
+        impl BulkExchange for Pending {
+            fn allgather_device(&mut self, _: *const c_void, _: *mut c_void, _: u64, _: ffi::OvmStream) -> i32 {
+                1
+            }
+        }
+        let mut comm = Self::new(name, rank, world, Box::new(Pending))?;
+        let mut ipc: *mut ffi::OvmIpcComm = ptr::null_mut();
+        // SAFETY: `comm.shm` stays valid for the life of `comm`, which owns the IpcBulk.
+        HipError::from_result("ovm_hip_ipc_comm_create", unsafe { ffi::ovm_hip_ipc_comm_create(comm.shm, rank, world, &mut ipc) })?;
+        comm.bulk = Box::new(IpcBulk { ipc });
+        Ok(comm)
+    }
+
     /// `name`: the same unique shared-memory name on every rank of the job (e.g. "/ovm-<port>-<pid>").
     pub fn new(name: &str, rank: u32, world: u32, bulk: Box<dyn BulkExchange>) -> Result<Box<Self>, HipError> {
         let cname = CString::new(name).expect("shared-memory name with a NUL byte");
@@ -100,6 +145,14 @@ impl ShardComm {
 }
 impl Drop for ShardComm {
     fn drop(&mut self) {
+        // the bulk exchange may hold a pointer to `shm` (IpcBulk): let it go first
+        struct Gone;
+        impl BulkExchange for Gone {
+            fn allgather_device(&mut self, _: *const c_void, _: *mut c_void, _: u64, _: ffi::OvmStream) -> i32 {
+                1
+            }
+        }
+        self.bulk = Box::new(Gone);
         // SAFETY: created by ovm_hip_shm_comm_create, destroyed once.
         unsafe { ffi::ovm_hip_shm_comm_destroy(self.shm) };
     }
