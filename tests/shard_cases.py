@@ -52,6 +52,10 @@ def _fuzz(seed, world):
 def make(name, world):
     if name.startswith("fuzz:"):
         return _fuzz(int(name.split(":")[1]), world)
+    if name.startswith("bench_scale:"):  # config D's multi-GPU form at 2^<log_rows> rows x 100 columns per rank, app parameters
+        lr = int(name.split(":")[1])
+        p, a, t = _bench_partitioned(world, 100, [lr] * world, airs.app_params(lr + 2), seed=lr)
+        return p, a, t, _owners_blocks(t, world)
     if name == "bench8":  # one partitioned BenchmarkAir per rank, equal heights (config D's multi-GPU form, small)
         p, a, t = _bench_partitioned(world, 8, [5] * world, airs.test_params(l_skip=2, n_stack=6, k_whir=2))
     elif name == "bench_mixed_heights":  # twice as many AIRs as ranks, heights incl. one below 2^l_skip

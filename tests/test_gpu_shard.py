@@ -114,6 +114,29 @@ def test_single_process_equals_sharded(dev, pkg, orc, tmp_path):
     assert single == run_sharded("bench_app", 2, tmp_path, repeat=2)
 
 
+def test_sharded_2_16_x_100_per_rank_byte_identical(orc, tmp_path):
+    """Config D's sharded form under app parameters at 2^16 rows x 100 columns per rank, 2 ranks: a 2^22-leaf fraction
+    tree over two leaf runs with base-field numerators, the distributed Merkle trees, the all-to-all form of the mu-batch
+    sum on 2^18-element vectors -- byte-identical to the oracle's proof of the same two AIRs."""
+    blob, want = oracle_proof(orc, "bench_scale:16", 2)
+    got = run_sharded("bench_scale:16", 2, tmp_path)
+    assert got == want
+
+
+@pytest.mark.skipif(not os.environ.get("OVM_FULL_PARITY"), reason="minutes of host time: set OVM_FULL_PARITY=1")
+def test_config_d_full_size_two_shards_byte_identical(orc, tmp_path):
+    """The same at the FULL size of BASELINE config D (2^22 x 100 per rank, 2 ranks on this one GPU), byte for byte
+    (result of the last run: profiles/r02/)."""
+    import time
+    t0 = time.time()
+    blob, want = oracle_proof(orc, "bench_scale:22", 2)
+    t1 = time.time()
+    got = run_sharded("bench_scale:22", 2, tmp_path)
+    print(f"oracle prove of 2 x (2^22 x 100): {t1 - t0:.1f} s; sharded prove incl. upload {time.time() - t1:.1f} s; "
+          f"proof {len(got)} bytes; identical: {got == want}")
+    assert got == want
+
+
 def test_config_d_full_size_two_shards_on_one_gpu_verifies(orc, tmp_path):
     """BASELINE config D in its sharded form AT FULL SIZE -- two AIRs of 2^22 rows x 100 columns (each its own
     cached-main commitment) + 1-column common mains, app parameters, 2^28-leaf fraction tree split over two
