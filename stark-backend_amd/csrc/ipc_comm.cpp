@@ -21,10 +21,15 @@ extern "C" int ovm_hip_shm_allgather(void *comm, const void *mine, void *all, ui
 struct ovm_ipc_comm {
     ovm_shm_comm_t *shm = nullptr;
     uint32_t rank = 0, world = 1;
-    // mappings of peers' allocations, by handle bytes
-    std::map<std::string, void *> opened;
-    // handles of my own allocations, by base address
-    std::map<void *, hipIpcMemHandle_t> mine;
+    // mappings of peers' allocations, by handle bytes, with the exchange that used them last: a mapping nobody has
+    // used for STALE_AFTER exchanges is closed (its owner may have returned the segment to the driver long ago)
+    struct Mapping {
+        void *p;
+        uint64_t last_used;
+    };
+    std::map<std::string, Mapping> opened;
+    uint64_t exchanges = 0;
+    static constexpr uint64_t STALE_AFTER = 64;
 
     struct Msg {
         hipIpcMemHandle_t handle;
@@ -46,16 +51,9 @@ struct ovm_ipc_comm {
         size_t size = 0;
         if (e == hipSuccess) e = hipMemGetAddressRange((hipDeviceptr_t *)&base, &size, (hipDeviceptr_t)d_send);
         if (e == hipSuccess) {
-            auto it = mine.find(base);
-            if (it == mine.end()) {
-                hipIpcMemHandle_t h;
-                e = hipIpcGetMemHandle(&h, base);
-                if (e == hipSuccess) it = mine.emplace(base, h).first;
-            }
-            if (e == hipSuccess) {
-                m.handle = it->second;
-                m.offset = (uint64_t)((const uint8_t *)d_send - (const uint8_t *)base);
-            }
+            // (asked for every time: a segment that went back to the driver may have a successor at the same address)
+            e = hipIpcGetMemHandle(&m.handle, base);
+            m.offset = (uint64_t)((const uint8_t *)d_send - (const uint8_t *)base);
         }
         if (e != hipSuccess) (void)hipGetLastError();
         m.status = (int32_t)e;
@@ -67,6 +65,7 @@ struct ovm_ipc_comm {
             if (all[r].status != 0) return all[r].status;  // every rank sees the same failure
         src.assign(world, nullptr);
         int first_error = 0;
+        exchanges++;
         for (uint32_t r = 0; r < world; r++) {
             if (all[r].bytes != send_bytes) first_error = first_error ? first_error : (int)hipErrorInvalidValue;
             if (r == rank) {
@@ -83,10 +82,18 @@ struct ovm_ipc_comm {
                     first_error = first_error ? first_error : (int)oe;
                     continue;
                 }
-                it = opened.emplace(key, p).first;
+                it = opened.emplace(key, Mapping{p, exchanges}).first;
             }
-            src[r] = (const uint8_t *)it->second + all[r].offset;
+            it->second.last_used = exchanges;
+            src[r] = (const uint8_t *)it->second.p + all[r].offset;
         }
+        for (auto it = opened.begin(); it != opened.end();)
+            if (exchanges - it->second.last_used > STALE_AFTER) {
+                (void)hipIpcCloseMemHandle(it->second.p);
+                it = opened.erase(it);
+            } else {
+                ++it;
+            }
         return first_error;
     }
 
@@ -146,7 +153,7 @@ int ovm_hip_ipc_comm_create(ovm_shm_comm_t *shm, uint32_t rank, uint32_t world, 
 
 void ovm_hip_ipc_comm_destroy(ovm_ipc_comm_t *c) {
     if (!c) return;
-    for (auto &kv : c->opened) (void)hipIpcCloseMemHandle(kv.second);
+    for (auto &kv : c->opened) (void)hipIpcCloseMemHandle(kv.second.p);
     delete c;
 }
 
