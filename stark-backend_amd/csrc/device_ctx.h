@@ -16,6 +16,18 @@
 // (crates/cuda-common/include/launcher.cuh:41-54).
 #define OVM_CHECK_LAUNCH() OVM_CHECK(hipGetLastError())
 
+// Every kernel launch of the library goes through OVM_LAUNCH: small host-to-device uploads are not copied one by
+// one but collected (prover.hip: Ctx::upload) and written by ONE scatter kernel right before the next launch on
+// their stream -- a 36-AIR proof made ~700 separate copies of a few hundred bytes each, ~15 us of stream time apiece.
+namespace ovm {
+void flush_uploads(hipStream_t stream);
+}
+#define OVM_LAUNCH(kernel, grid, block, shmem, stream, ...)                        \
+    do {                                                                           \
+        ovm::flush_uploads(stream);                                                \
+        hipLaunchKernelGGL(kernel, grid, block, shmem, stream, __VA_ARGS__);       \
+    } while (0)
+
 namespace ovm {
 
 static constexpr unsigned TW_LOG_MAX = 27;  // two-adicity of BabyBear

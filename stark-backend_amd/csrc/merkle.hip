@@ -180,10 +180,10 @@ __global__ void gather_digests_kernel(const Digest *__restrict__ layers,
 static void launch_compress(const Digest *in, Digest *out, uint64_t n_out, uint32_t log_half, hipStream_t stream) {
     const bool coop = tuning().merkle_coop;
     if (coop && n_out <= COOP_MAX_NODES)
-        hipLaunchKernelGGL(compress_layer_coop_kernel, dim3(ceil_div(n_out * 16, HASH_THREADS)), dim3(HASH_THREADS), 0, stream, in,
+        OVM_LAUNCH(compress_layer_coop_kernel, dim3(ceil_div(n_out * 16, HASH_THREADS)), dim3(HASH_THREADS), 0, stream, in,
                            out, n_out, log_half);
     else
-        hipLaunchKernelGGL(compress_layer_kernel, dim3(ceil_div(n_out, HASH_THREADS)), dim3(HASH_THREADS), 0, stream, in, out,
+        OVM_LAUNCH(compress_layer_kernel, dim3(ceil_div(n_out, HASH_THREADS)), dim3(HASH_THREADS), 0, stream, in, out,
                            n_out, log_half);
 }
 
@@ -202,7 +202,7 @@ static int merkle_tree_impl(const uint32_t *d_matrix, uint64_t width, uint32_t l
         // (rows of at most 8 words are one permutation each: the 1-column common main of a sharded proof --
         // kept apart so that "merkle.hash_rows" stays the wide codeword hash the roofline is quoted on)
         OVM_PROF(WORDS != 1 ? "merkle.hash_rows_ext" : width <= 8 ? "merkle.hash_rows_narrow" : "merkle.hash_rows", stream);
-        hipLaunchKernelGGL(hash_rows_kernel<WORDS>, dim3(ceil_div(rows, HASH_THREADS)),
+        OVM_LAUNCH(hash_rows_kernel<WORDS>, dim3(ceil_div(rows, HASH_THREADS)),
                            dim3(HASH_THREADS), 0, stream, (const Fp *)d_matrix, width, rows, rows * map.n,
                            log_rows_per_query == 0 ? layers : leaf, map);
         OVM_CHECK_LAUNCH();
@@ -283,7 +283,7 @@ int ovm_hip_merkle_tree_ext(const uint32_t *d_matrix, uint64_t width, uint32_t l
 
 int ovm_hip_poseidon2_permute(uint32_t *d_states, uint64_t n, ovm_stream_t stream) {
     if (n == 0) return 0;
-    hipLaunchKernelGGL(permute_states_kernel, dim3(ceil_div(n, 256)), dim3(256), 0,
+    OVM_LAUNCH(permute_states_kernel, dim3(ceil_div(n, 256)), dim3(256), 0,
                        (hipStream_t)stream, (Fp *)d_states, n);
     OVM_CHECK_LAUNCH();
     return 0;
@@ -325,7 +325,7 @@ int ovm_hip_sponge_grind(const ovm_sponge_t *sponge, uint32_t bits, uint32_t *wi
         uint32_t init = 0xffffffffu;
         OVM_CHECK(hipMemcpyAsync(d_result, &init, 4, hipMemcpyHostToDevice, stream));
         uint32_t count = (uint32_t)((bb::P - base) < batch ? (bb::P - base) : batch);
-        hipLaunchKernelGGL(grind_kernel, dim3(ceil_div(count, HASH_THREADS)), dim3(HASH_THREADS), 0,
+        OVM_LAUNCH(grind_kernel, dim3(ceil_div(count, HASH_THREADS)), dim3(HASH_THREADS), 0,
                            stream, s, bits, (uint32_t)base, count, d_result);
         OVM_CHECK_LAUNCH();
         uint32_t found = 0;
@@ -345,11 +345,11 @@ int ovm_hip_gather_rows(const uint32_t *d_matrix, uint64_t width, uint64_t col_s
     uint64_t total = n_rows * width;
     if (total == 0) return 0;
     if (words_per_elem == 1)
-        hipLaunchKernelGGL(gather_rows_kernel<1>, dim3(ceil_div(total, 256)), dim3(256), 0,
+        OVM_LAUNCH(gather_rows_kernel<1>, dim3(ceil_div(total, 256)), dim3(256), 0,
                            (hipStream_t)stream, (const Fp *)d_matrix, width, col_stride, d_row_idx,
                            n_rows, (Fp *)d_out);
     else if (words_per_elem == 4)
-        hipLaunchKernelGGL(gather_rows_kernel<4>, dim3(ceil_div(total, 256)), dim3(256), 0,
+        OVM_LAUNCH(gather_rows_kernel<4>, dim3(ceil_div(total, 256)), dim3(256), 0,
                            (hipStream_t)stream, (const Fp *)d_matrix, width, col_stride, d_row_idx,
                            n_rows, (Fp *)d_out);
     else
@@ -361,7 +361,7 @@ int ovm_hip_gather_rows(const uint32_t *d_matrix, uint64_t width, uint64_t col_s
 int ovm_hip_gather_digests(const uint32_t *d_layers, const uint64_t *d_idx, uint64_t n,
                            uint32_t *d_out, ovm_stream_t stream) {
     if (n == 0) return 0;
-    hipLaunchKernelGGL(gather_digests_kernel, dim3(ceil_div(n, 256)), dim3(256), 0,
+    OVM_LAUNCH(gather_digests_kernel, dim3(ceil_div(n, 256)), dim3(256), 0,
                        (hipStream_t)stream, (const Digest *)d_layers, d_idx, n, (Digest *)d_out);
     OVM_CHECK_LAUNCH();
     return 0;

@@ -417,7 +417,7 @@ template <class T, int TL>
 static int launch_dif16(const T *src, T *out, uint64_t width, uint32_t L, uint32_t log_n_in, uint32_t s0, uint32_t r,
                         uint32_t c, uint64_t src_stride, uint64_t out_stride, const Twiddles &tw, hipStream_t stream) {
     dim3 grid(1u << (L - TL), (unsigned)width);
-    hipLaunchKernelGGL((dif16_pass_kernel<T, TL>), grid, dim3(1 << (TL - 4)), 0, stream, src, out, L, log_n_in, s0, r,
+    OVM_LAUNCH((dif16_pass_kernel<T, TL>), grid, dim3(1 << (TL - 4)), 0, stream, src, out, L, log_n_in, s0, r,
                        c, src_stride, out_stride, tw);
     OVM_CHECK_LAUNCH();
     return 0;
@@ -498,7 +498,7 @@ static int dif_ntt(const T *in, T *out, uint64_t width, uint32_t L, uint32_t log
         uint64_t tiles = 1ull << (L - r - c);
         dim3 grid((unsigned)tiles, (unsigned)width);
         size_t shmem = sizeof(T) << (r + c);
-        hipLaunchKernelGGL(dif_pass_kernel<T>, grid, dim3(NTT_THREADS), shmem, stream, src, out, L,
+        OVM_LAUNCH(dif_pass_kernel<T>, grid, dim3(NTT_THREADS), shmem, stream, src, out, L,
                            src_log_n, s, r, c, src_stride, out_col_stride, *tw);
         OVM_CHECK_LAUNCH();
         s += r;
@@ -526,7 +526,7 @@ int ovm_hip_eval_to_coeff(const uint32_t *d_in, uint32_t *d_out, uint64_t width,
     if (l_skip == 4) {
         // columns are contiguous (column stride = 2^log_height), so the chunks of all columns form one array
         const uint64_t n_chunks = width << (log_height - 4);
-        hipLaunchKernelGGL(eval_to_coeff16_kernel, dim3((unsigned)((n_chunks + 255) / 256)), dim3(256), 0, stream,
+        OVM_LAUNCH(eval_to_coeff16_kernel, dim3((unsigned)((n_chunks + 255) / 256)), dim3(256), 0, stream,
                            (const Fp *)d_in, (Fp *)d_out, n_chunks, Fp::from_canonical(16).inv());
         OVM_CHECK_LAUNCH();
         return 0;
@@ -534,7 +534,7 @@ int ovm_hip_eval_to_coeff(const uint32_t *d_in, uint32_t *d_out, uint64_t width,
     uint32_t tile_log = log_height < (uint32_t)NTT_TILE_LOG ? log_height : (uint32_t)NTT_TILE_LOG;
     dim3 grid(1u << (log_height - tile_log), (unsigned)width);
     Fp inv_chunk = Fp::from_canonical(1u << l_skip).inv();
-    hipLaunchKernelGGL(eval_to_coeff_kernel, grid, dim3(NTT_THREADS), sizeof(Fp) << tile_log, stream,
+    OVM_LAUNCH(eval_to_coeff_kernel, grid, dim3(NTT_THREADS), sizeof(Fp) << tile_log, stream,
                        (const Fp *)d_in, (Fp *)d_out, log_height, l_skip, tile_log, inv_chunk, *tw);
     OVM_CHECK_LAUNCH();
     return 0;

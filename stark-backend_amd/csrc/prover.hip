@@ -69,7 +69,7 @@ inline void *pool_get(size_t bytes) {
         throw OvmFail(e.code, "hipMalloc");
     }
 }
-inline void pool_put(void *p) { BlockPool::put(p, &block_cache()); }
+inline void pool_put(void *p);
 
 template <class T>
 struct DevBuf {
@@ -120,7 +120,8 @@ struct PinnedStage {
         bytes = std::max<size_t>(need, size_t(16) << 20);
         used = 0;
         void *q = nullptr;
-        if (hipHostMalloc(&q, bytes, hipHostMallocDefault) != hipSuccess) {
+        // (mapped: the scatter kernel of flush_uploads reads the staged bytes straight from this memory)
+        if (hipHostMalloc(&q, bytes, hipHostMallocMapped) != hipSuccess) {
             q = nullptr;
             bytes = 0;
         }
@@ -136,11 +137,90 @@ struct PinnedStage {
         bumps++;
         return r;
     }
-    void rewind() { used = 0; }
+    void rewind();
 };
 inline PinnedStage &pinned_stage() {
     static thread_local PinnedStage st;
     return st;
+}
+
+// Small uploads staged in the arena and not yet copied: flush_uploads writes them all with one kernel, in front of
+// the next launch on their stream (device_ctx.h: OVM_LAUNCH), of a synchronisation or of a download.
+struct UploadJob {
+    const void *src;  // in the pinned arena (device-visible)
+    void *dst;
+    uint64_t bytes;
+    uint32_t wg0, gx;
+};
+static constexpr uint32_t UPLOAD_JOBS_PER_LAUNCH = 24;
+static constexpr uint32_t UPLOAD_WG_BYTES = 256 * 16;
+static constexpr size_t UPLOAD_DEFER_MAX = size_t(256) << 10;  // larger uploads are copied by the runtime as before
+struct UploadJobsArg {
+    UploadJob job[UPLOAD_JOBS_PER_LAUNCH];
+    uint32_t n;
+};
+__global__ __launch_bounds__(256) void upload_scatter_kernel(UploadJobsArg a) {
+    uint32_t k = 0;
+    while (k + 1 < a.n && a.job[k + 1].wg0 <= blockIdx.x) k++;
+    const UploadJob j = a.job[k];
+    const uint64_t first = (uint64_t)(blockIdx.x - j.wg0) * UPLOAD_WG_BYTES;
+    const uint64_t last = first + UPLOAD_WG_BYTES < j.bytes ? first + UPLOAD_WG_BYTES : j.bytes;
+    const uint4 *s4 = reinterpret_cast<const uint4 *>(j.src);
+    uint4 *d4 = reinterpret_cast<uint4 *>(j.dst);
+    const uint64_t i = first / 16 + threadIdx.x;
+    if (i * 16 + 16 <= last) {
+        d4[i] = s4[i];
+    } else if (i * 16 < last) {  // the tail of a buffer whose size is not a multiple of 16
+        const uint8_t *s1 = reinterpret_cast<const uint8_t *>(j.src);
+        uint8_t *d1 = reinterpret_cast<uint8_t *>(j.dst);
+        for (uint64_t b = i * 16; b < last; b++) d1[b] = s1[b];
+    }
+}
+struct PendingUploads {
+    std::vector<UploadJob> jobs;
+    hipStream_t stream = nullptr;
+    void add(const void *src, void *dst, size_t bytes, hipStream_t s) {
+        if (!jobs.empty() && stream != s) flush();  // (one stream per prover thread: this does not happen)
+        stream = s;
+        jobs.push_back(UploadJob{src, dst, bytes, 0, (uint32_t)((bytes + UPLOAD_WG_BYTES - 1) / UPLOAD_WG_BYTES)});
+    }
+    // a destination that goes back to the pool before it was written must not be written later
+    void forget(void *dst) {
+        for (size_t i = 0; i < jobs.size(); i++)
+            if (jobs[i].dst == dst) {
+                jobs.erase(jobs.begin() + i);
+                return;
+            }
+    }
+    void flush() {
+        for (size_t at = 0; at < jobs.size(); at += UPLOAD_JOBS_PER_LAUNCH) {
+            UploadJobsArg a{};
+            a.n = (uint32_t)std::min<size_t>(UPLOAD_JOBS_PER_LAUNCH, jobs.size() - at);
+            uint32_t wg = 0;
+            for (uint32_t k = 0; k < a.n; k++) {
+                a.job[k] = jobs[at + k];
+                a.job[k].wg0 = wg;
+                wg += a.job[k].gx;
+            }
+            hipLaunchKernelGGL(upload_scatter_kernel, dim3(wg), dim3(256), 0, stream, a);
+        }
+        jobs.clear();
+    }
+};
+inline PendingUploads &pending_uploads() {
+    static thread_local PendingUploads pu;
+    return pu;
+}
+inline void pool_put(void *p) {
+    pending_uploads().forget(p);
+    BlockPool::put(p, &block_cache());
+}
+void flush_uploads(hipStream_t) {
+    PendingUploads &pu = pending_uploads();
+    if (!pu.jobs.empty()) pu.flush();
+}
+inline void PinnedStage::rewind() {
+    if (pending_uploads().jobs.empty()) used = 0;  // (staged bytes that are still to be copied stay where they are)
 }
 
 // Host mailbox of the reduction kernels: a host-mapped, coherent page the last workgroup of a
@@ -231,6 +311,7 @@ inline Mailbox &mailbox() {
 struct Ctx {
     hipStream_t stream;
     void sync() const {
+        flush_uploads(stream);
         OVM_THROW_IF(hipStreamSynchronize(stream));
         pinned_stage().rewind();
     }
@@ -248,7 +329,10 @@ struct Ctx {
                 ps.ensure(bytes);
                 stage = ps.bump(bytes);
             }
-            if (stage) {
+            if (stage && bytes <= UPLOAD_DEFER_MAX) {
+                memcpy(stage, v.data(), bytes);
+                pending_uploads().add(stage, b.p, bytes, stream);  // written by the next flush_uploads
+            } else if (stage) {
                 memcpy(stage, v.data(), bytes);
                 OVM_THROW_IF(hipMemcpyAsync(b.p, stage, bytes, hipMemcpyHostToDevice, stream));
             } else {
@@ -263,6 +347,7 @@ struct Ctx {
         std::vector<T> v(n);
         if (n) {
             const size_t bytes = n * sizeof(T);
+            flush_uploads(stream);
             PinnedStage &ps = pinned_stage();
             void *stage = ps.bump(bytes);
             if (!stage) {
@@ -498,7 +583,7 @@ struct Prover {
         }
         if (!jobs.empty()) {
             auto d_jobs = cx.upload(jobs);
-            hipLaunchKernelGGL(stack_batched_kernel, dim3(jobs.back().wg0 + jobs.back().gx), dim3(256), 0, cx.stream, d_jobs.p,
+            OVM_LAUNCH(stack_batched_kernel, dim3(jobs.back().wg0 + jobs.back().gx), dim3(256), 0, cx.stream, d_jobs.p,
                                (uint32_t)jobs.size());
             OVM_THROW_IF(hipGetLastError());
         }
@@ -2159,7 +2244,7 @@ struct Prover {
                 }
                 wd.vec_a.alloc(4 * hw);
                 wd.vec_b.alloc(4 * std::max<size_t>(hw / 2, 1));
-                hipLaunchKernelGGL(stacked_tables_kernel, dim3(ceil_div(hw, 256)), dim3(256), 0, cx.stream, wd.eq_cube.p,
+                OVM_LAUNCH(stacked_tables_kernel, dim3(ceil_div(hw, 256)), dim3(256), 0, cx.stream, wd.eq_cube.p,
                                    (uint64_t)hw, ind * equ, ind * equ_rot, ind * eq_const * eq_u01, wd.vec_a.p + 2 * hw,
                                    wd.vec_a.p + 3 * hw);
                 std::vector<uint64_t> off;
@@ -2637,9 +2722,9 @@ struct Prover {
                 auto d_zp = cx.upload(zp);
                 auto d_sc = cx.upload(scale);
                 DevBuf<EF> tlo(n_q << log_lo), thi(n_q << log_hi);
-                hipLaunchKernelGGL(whir_eq_tables_kernel, dim3(ceil_div((uint64_t)n_q << log_lo, 256)), dim3(256), 0, cx.stream,
+                OVM_LAUNCH(whir_eq_tables_kernel, dim3(ceil_div((uint64_t)n_q << log_lo, 256)), dim3(256), 0, cx.stream,
                                    d_zp.p, m_new, 0u, log_lo, d_sc.p, (uint32_t)n_q, tlo.p);
-                hipLaunchKernelGGL(whir_eq_tables_kernel, dim3(ceil_div((uint64_t)n_q << log_hi, 256)), dim3(256), 0, cx.stream,
+                OVM_LAUNCH(whir_eq_tables_kernel, dim3(ceil_div((uint64_t)n_q << log_hi, 256)), dim3(256), 0, cx.stream,
                                    d_zp.p, m_new, log_lo, log_hi, (const EF *)nullptr, (uint32_t)n_q, thi.p);
                 OVM_THROW_IF(whir_w_accumulate(w_cur, m_new, tlo.p, thi.p, log_lo, (uint32_t)n_q, cx.stream));
                 cx.sync();
@@ -3027,11 +3112,15 @@ int guarded(F &&f, bool needs_device = true) {
     try {
         Tuning::refresh();  // the environment overrides are read here, once per call, and nowhere else
         if (needs_device && !twiddles()) return (int)hipErrorInitializationError;
-        return f();
+        const int rc = f();
+        flush_uploads(nullptr);  // (nothing staged is left behind for a later call to trip over)
+        return rc;
     } catch (const OvmFail &e) {
+        pending_uploads().jobs.clear();
         g_last_error = e.what();
         return e.code ? e.code : (int)hipErrorUnknown;
     } catch (const std::exception &e) {
+        pending_uploads().jobs.clear();
         g_last_error = e.what();
         return (int)hipErrorUnknown;
     }

@@ -109,7 +109,7 @@ __global__ void sum_partials_kernel(RedOut ro, uint32_t n_blocks, uint32_t K) {
 }
 
 int sum_partials(const RedOut &ro, uint32_t n_blocks, uint32_t K, hipStream_t s) {
-    hipLaunchKernelGGL(sum_partials_kernel, dim3(K), dim3(RED_THREADS), 0, s, ro, n_blocks, K);
+    OVM_LAUNCH(sum_partials_kernel, dim3(K), dim3(RED_THREADS), 0, s, ro, n_blocks, K);
     OVM_CHECK_LAUNCH();
     return 0;
 }
@@ -149,7 +149,7 @@ __global__ void build_selectors_kernel(Fp *sels, uint32_t log_lifted, uint32_t l
 }
 int build_selectors(Fp *sels, uint32_t log_lifted, uint32_t log_height, hipStream_t s) {
     uint64_t n = 1ull << log_lifted;
-    hipLaunchKernelGGL(build_selectors_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, s, sels, log_lifted, log_height);
+    OVM_LAUNCH(build_selectors_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, s, sels, log_lifted, log_height);
     OVM_CHECK_LAUNCH();
     return 0;
 }
@@ -195,11 +195,11 @@ static constexpr uint32_t EQ_DIRECT_BITS = 10;
 template <bool MOBIUS, class Out>
 static int eq_table_impl(const EF *d_point, uint32_t n, Out out, hipStream_t s) {
     uint32_t n0 = n < EQ_DIRECT_BITS ? n : EQ_DIRECT_BITS;
-    hipLaunchKernelGGL((eq_table_kernel<MOBIUS, Out>), dim3(ceil_div(1ull << n0, 256)), dim3(256), 0, s, d_point, n0,
+    OVM_LAUNCH((eq_table_kernel<MOBIUS, Out>), dim3(ceil_div(1ull << n0, 256)), dim3(256), 0, s, d_point, n0,
                        out);
     OVM_CHECK_LAUNCH();
     for (uint32_t k = n0; k < n; k++) {
-        hipLaunchKernelGGL((eq_double_kernel<MOBIUS, Out>), dim3(ceil_div(1ull << k, 256)), dim3(256), 0, s, d_point,
+        OVM_LAUNCH((eq_double_kernel<MOBIUS, Out>), dim3(ceil_div(1ull << k, 256)), dim3(256), 0, s, d_point,
                            k, out);
         OVM_CHECK_LAUNCH();
     }
@@ -359,14 +359,14 @@ int coset_lde(const ColDesc *d_cols, const uint32_t *d_used, uint32_t n_used, ui
     // d_shift_pows[k * N + i] = shift_k^i / N (the caller folds 1/N in)
     if (l_skip == 4) {
         dim3 grid16((unsigned)ceil_div(1ull << (log_lifted - 4), 256), n_used);
-        hipLaunchKernelGGL(coset_lde16_kernel, grid16, dim3(256), 0, s, d_cols, d_used, n_cols_total, log_lifted,
+        OVM_LAUNCH(coset_lde16_kernel, grid16, dim3(256), 0, s, d_cols, d_used, n_cols_total, log_lifted,
                            n_cosets, d_shift_pows, lde, row0);
         OVM_CHECK_LAUNCH();
         return 0;
     }
     uint32_t tile_log = log_lifted < LDE_TILE_LOG ? log_lifted : LDE_TILE_LOG;
     dim3 grid(1u << (log_lifted - tile_log), n_used);
-    hipLaunchKernelGGL(coset_lde_kernel, grid, dim3(LDE_THREADS), 2 * sizeof(Fp) << tile_log, s, d_cols, d_used,
+    OVM_LAUNCH(coset_lde_kernel, grid, dim3(LDE_THREADS), 2 * sizeof(Fp) << tile_log, s, d_cols, d_used,
                        n_cols_total, log_lifted, l_skip, tile_log, n_cosets, d_shift_pows, Fp::one(), lde, *tw, row0);
     OVM_CHECK_LAUNCH();
     return 0;
@@ -783,7 +783,7 @@ int round0_eval_batched(const R0Job *d_jobs, const R0Job *h_jobs, uint32_t n_job
         lds_bytes = std::max(lds_bytes, (size_t)job.lds_rows * rows * RED_THREADS * 4);
     }
 #define LAUNCH(R, NOUT)                                                                                                 \
-    hipLaunchKernelGGL((round0_staged_batched_kernel<R, NOUT>), dim3(grid), dim3(RED_THREADS), lds_bytes, s, d_jobs, n_jobs, \
+    OVM_LAUNCH((round0_staged_batched_kernel<R, NOUT>), dim3(grid), dim3(RED_THREADS), lds_bytes, s, d_jobs, n_jobs, \
                        l_skip, d_counters, ro)
     if (n_out == 1) {
         if (rows == 4) LAUNCH(4, 1);
@@ -813,7 +813,7 @@ int round0_eval(const DevProgram &prog, const DevStaged &staged, const Fp *lde, 
         {
             const uint32_t grid = round0_staged_grid(staged, log_lifted);
 #define LAUNCH(R, NOUT)                                                                                             \
-    hipLaunchKernelGGL((round0_staged_kernel<R, NOUT>), dim3(grid), dim3(RED_THREADS), lds_bytes, s, staged, lde, \
+    OVM_LAUNCH((round0_staged_kernel<R, NOUT>), dim3(grid), dim3(RED_THREADS), lds_bytes, s, staged, lde, \
                        n_cols_total, log_lifted, l_skip, n_cosets, n_out, d_eq_xi, add_const, ro.partials)
             if (n_out == 1) {
                 if (rows == 4) LAUNCH(4, 1);
@@ -832,7 +832,7 @@ int round0_eval(const DevProgram &prog, const DevStaged &staged, const Fp *lde, 
     if (lanes < RED_THREADS) lanes = RED_THREADS;
     uint32_t grid = red_grid(lanes);
 #define LAUNCH(NS, R, NOUT)                                                                                      \
-    hipLaunchKernelGGL((round0_eval_kernel<NS, R, NOUT>), dim3(grid), dim3(RED_THREADS), 0, s, prog, lde,       \
+    OVM_LAUNCH((round0_eval_kernel<NS, R, NOUT>), dim3(grid), dim3(RED_THREADS), 0, s, prog, lde,       \
                        n_cols_total, log_lifted, l_skip, n_cosets, n_out, d_eq_xi, add_const, ro.partials)
 #define CALL(NS)                                           \
     do {                                                   \
@@ -911,7 +911,7 @@ int fold_ple(const ColDesc *d_cols, const int32_t *d_twins, uint32_t n_cols, uin
     if (n_cols == 0) return 0;
     if (d_twins && l_skip != 4) d_twins = nullptr;  // (only the 16-row chunk path shares the cells)
     uint64_t nx = 1ull << (log_lifted - l_skip);
-    hipLaunchKernelGGL(fold_ple_kernel, dim3(ceil_div(nx, 256), n_cols), dim3(256), 0, s, d_cols, d_twins, log_lifted, l_skip,
+    OVM_LAUNCH(fold_ple_kernel, dim3(ceil_div(nx, 256), n_cols), dim3(256), 0, s, d_cols, d_twins, log_lifted, l_skip,
                        d_weights, out);
     OVM_CHECK_LAUNCH();
     return 0;
@@ -1153,7 +1153,7 @@ int mle_round_eval_batched(const MleJob *d_jobs, const MleJob *h_jobs, uint32_t 
     // the config B shape)
     dim3 grid(gx, 1, gz);
 #define CALLD(NS, DD) \
-    hipLaunchKernelGGL((mle_round_batched_kernel<NS, DD>), grid, dim3(RED_THREADS), 0, s, d_jobs, n_jobs, d_counters, ro)
+    OVM_LAUNCH((mle_round_batched_kernel<NS, DD>), grid, dim3(RED_THREADS), 0, s, d_jobs, n_jobs, d_counters, ro)
 #define CALL(NS)                                  \
     do {                                          \
         if (degree == 1) CALLD(NS, 1);            \
@@ -1176,7 +1176,7 @@ int mle_round_eval_grouped(const Instr *d_code, const uint32_t *d_off, uint32_t 
     if (mle_points_in_lane()) {
         dim3 grid(gx, 1, n_groups);
 #define CALLD(NS, DD)                                                                                                  \
-    hipLaunchKernelGGL((mle_round_points_kernel<NS, DD>), grid, dim3(RED_THREADS), 0, s, d_code, d_off, d_weights, mats, \
+    OVM_LAUNCH((mle_round_points_kernel<NS, DD>), grid, dim3(RED_THREADS), 0, s, d_code, d_off, d_weights, mats, \
                        log_h, n_out, d_eq, add_const, red_inline(ro, gx * n_groups))
 #define CALL(NS)                                  \
     do {                                          \
@@ -1193,7 +1193,7 @@ int mle_round_eval_grouped(const Instr *d_code, const uint32_t *d_off, uint32_t 
     }
     dim3 grid(gx, degree, n_groups);
 #define CALL(NS)                                                                                               \
-    hipLaunchKernelGGL(mle_round_grouped_kernel<NS>, grid, dim3(RED_THREADS), 0, s, d_code, d_off, d_weights, mats, \
+    OVM_LAUNCH(mle_round_grouped_kernel<NS>, grid, dim3(RED_THREADS), 0, s, d_code, d_off, d_weights, mats, \
                        log_h, n_out, d_eq, add_const, red_inline(ro, gx * degree * n_groups))
     DISPATCH_SLOTS(max_slots, CALL);
 #undef CALL
@@ -1213,7 +1213,7 @@ __global__ void fold_mle_kernel(const EF *in, EF *out, uint32_t log_h, EF r_in) 
 }
 int fold_mle(const EF *in, EF *out, uint32_t n_cols, uint32_t log_h, EF r, hipStream_t s) {
     if (n_cols == 0 || log_h == 0) return 0;
-    hipLaunchKernelGGL(fold_mle_kernel, dim3(ceil_div(1ull << (log_h - 1), 256), n_cols), dim3(256), 0, s, in, out,
+    OVM_LAUNCH(fold_mle_kernel, dim3(ceil_div(1ull << (log_h - 1), 256), n_cols), dim3(256), 0, s, in, out,
                        log_h, r);
     OVM_CHECK_LAUNCH();
     return 0;
@@ -1259,11 +1259,11 @@ int fold_mle_batched(const FoldJob *d_jobs, const FoldJob *h_jobs, uint32_t n_jo
         if (n_jobs > FoldJobsArg::MAX) return (int)hipErrorInvalidValue;
         FoldJobsArg a;
         for (uint32_t j = 0; j < n_jobs; j++) a.j[j] = h_jobs[j];
-        hipLaunchKernelGGL(fold_mle_batched_arg_kernel, dim3((uint32_t)gx, (uint32_t)gy), dim3(256), 0, s, a, n_jobs, r);
+        OVM_LAUNCH(fold_mle_batched_arg_kernel, dim3((uint32_t)gx, (uint32_t)gy), dim3(256), 0, s, a, n_jobs, r);
         OVM_CHECK_LAUNCH();
         return 0;
     }
-    hipLaunchKernelGGL(fold_mle_batched_kernel, dim3((uint32_t)gx, (uint32_t)gy), dim3(256), 0, s, d_jobs, n_jobs, r);
+    OVM_LAUNCH(fold_mle_batched_kernel, dim3((uint32_t)gx, (uint32_t)gy), dim3(256), 0, s, d_jobs, n_jobs, r);
     OVM_CHECK_LAUNCH();
     return 0;
 }
@@ -1406,7 +1406,7 @@ int gkr_eval_leaves_batched(const LeavesJob *d_jobs, const LeavesJob *h_jobs, ui
         grid += h_jobs[j].gx;
         lds_bytes = std::max(lds_bytes, (size_t)h_jobs[j].prog.num_rows * RED_THREADS * 4);
     }
-    hipLaunchKernelGGL(gkr_leaves_staged_batched_kernel, dim3(grid), dim3(256), lds_bytes, s, d_jobs, n_jobs, leaves);
+    OVM_LAUNCH(gkr_leaves_staged_batched_kernel, dim3(grid), dim3(256), lds_bytes, s, d_jobs, n_jobs, leaves);
     OVM_CHECK_LAUNCH();
     return 0;
 }
@@ -1417,13 +1417,13 @@ int gkr_eval_leaves(const DevProgram &prog, const DevStaged &staged, const EF *d
     uint32_t grid = ceil_div(1ull << log_height, 256);
     if (staged.blocks) {
         const size_t lds_bytes = (size_t)staged.num_rows * RED_THREADS * 4;
-        hipLaunchKernelGGL(gkr_leaves_staged_kernel, dim3(grid), dim3(256), lds_bytes, s, staged, d_leaf_const, d_cols,
+        OVM_LAUNCH(gkr_leaves_staged_kernel, dim3(grid), dim3(256), lds_bytes, s, staged, d_leaf_const, d_cols,
                            log_height, d_leaf_base, d_leaf_log_len, norm, leaves);
         OVM_CHECK_LAUNCH();
         return 0;
     }
 #define CALL(NS)                                                                                           \
-    hipLaunchKernelGGL(gkr_leaves_kernel<NS>, dim3(grid), dim3(256), 0, s, prog, d_leaf_const, d_cols, log_height, \
+    OVM_LAUNCH(gkr_leaves_kernel<NS>, dim3(grid), dim3(256), 0, s, prog, d_leaf_const, d_cols, log_height, \
                        d_leaf_base, d_leaf_log_len, norm, leaves)
     DISPATCH_SLOTS(prog.num_slots, CALL);
 #undef CALL
@@ -1447,10 +1447,10 @@ __global__ void gkr_build_kernel(FracPlanes child, FracPlanes parent, uint64_t n
 }
 int gkr_build_layer(FracPlanes child, FracPlanes parent, uint64_t n_parent, bool child_p_base, hipStream_t s) {
     if (child_p_base)
-        hipLaunchKernelGGL(gkr_build_kernel<true>, dim3(ceil_div(n_parent, 256)), dim3(256), 0, s, child, parent,
+        OVM_LAUNCH(gkr_build_kernel<true>, dim3(ceil_div(n_parent, 256)), dim3(256), 0, s, child, parent,
                            n_parent);
     else
-        hipLaunchKernelGGL(gkr_build_kernel<false>, dim3(ceil_div(n_parent, 256)), dim3(256), 0, s, child, parent,
+        OVM_LAUNCH(gkr_build_kernel<false>, dim3(ceil_div(n_parent, 256)), dim3(256), 0, s, child, parent,
                            n_parent);
     OVM_CHECK_LAUNCH();
     return 0;
@@ -1595,11 +1595,11 @@ int eq_heap_run(const EF *point, const EqHeapPlan &pl, EFPlanes heap, hipStream_
     if (pl.empty) return 0;
     EqPoint d_point;
     for (uint32_t j = 0; j < pl.n; j++) d_point.x[j] = point[j];
-    hipLaunchKernelGGL(eq_heap_top_kernel, dim3(ceil_div(2ull << pl.top, 256)), dim3(256), 0, s, d_point, pl.n, pl.top, heap);
+    OVM_LAUNCH(eq_heap_top_kernel, dim3(ceil_div(2ull << pl.top, 256)), dim3(256), 0, s, d_point, pl.n, pl.top, heap);
     OVM_CHECK_LAUNCH();
     for (auto &ln : pl.launches) {
         const uint32_t k = ln.k;
-        hipLaunchKernelGGL(eq_heap_levels_win_kernel, dim3(ceil_div(ln.count, 256)), dim3(256), 0, s, d_point, pl.n, k, ln.levels,
+        OVM_LAUNCH(eq_heap_levels_win_kernel, dim3(ceil_div(ln.count, 256)), dim3(256), 0, s, d_point, pl.n, k, ln.levels,
                            heap, pl.off[k], pl.lo[k], ln.src_first, ln.count, pl.off[k + 1], ln.levels > 1 ? pl.off[k + 2] : 0,
                            ln.levels > 2 ? pl.off[k + 3] : 0, ln.src_first);
         OVM_CHECK_LAUNCH();
@@ -1623,7 +1623,7 @@ __global__ void gkr_read_list_kernel(FracPlanes t, const uint64_t *pos, const ui
 }
 int gkr_read_list(FracPlanes t, const uint64_t *d_pos, const uint32_t *d_pbase, uint32_t n, const RedOut &ro, hipStream_t s) {
     if (n > 64) return (int)hipErrorInvalidValue;
-    hipLaunchKernelGGL(gkr_read_list_kernel, dim3(1), dim3(64), 0, s, t, d_pos, d_pbase, n, ro);
+    OVM_LAUNCH(gkr_read_list_kernel, dim3(1), dim3(64), 0, s, t, d_pos, d_pbase, n, ro);
     OVM_CHECK_LAUNCH();
     return 0;
 }
@@ -1670,7 +1670,7 @@ __global__ void gkr_edge_kernel(FracPlanes src, uint64_t at0, uint64_t at1, uint
 int gkr_edge_records(FracPlanes src, uint64_t at0, uint64_t at1, uint32_t n0, uint32_t n1, bool p_base, bool fold, EF r,
                      const RedOut &ro, hipStream_t s) {
     if (n0 + n1 == 0 || n0 + n1 > 64) return (int)hipErrorInvalidValue;
-    hipLaunchKernelGGL(gkr_edge_kernel, dim3(1), dim3(64), 0, s, src, at0, at1, n0, n1, p_base ? 1 : 0, fold ? 1 : 0, r, ro);
+    OVM_LAUNCH(gkr_edge_kernel, dim3(1), dim3(64), 0, s, src, at0, at1, n0, n1, p_base ? 1 : 0, fold ? 1 : 0, r, ro);
     OVM_CHECK_LAUNCH();
     return 0;
 }
@@ -1703,7 +1703,7 @@ int gkr_round(FracPlanes rec, bool p_base, EFPlanes eq, uint64_t n_pairs, EF lam
     if (n_points != 2 && n_points != 3) return (int)hipErrorInvalidValue;
     uint32_t grid = red_grid(n_pairs);
 #define CALL(PB, NP)                                                                                             \
-    hipLaunchKernelGGL((gkr_round_kernel<PB, NP>), dim3(grid), dim3(RED_THREADS), 0, s, rec, eq, n_pairs, lambda, \
+    OVM_LAUNCH((gkr_round_kernel<PB, NP>), dim3(grid), dim3(RED_THREADS), 0, s, rec, eq, n_pairs, lambda, \
                        red_inline(ro, grid))
     if (p_base) {
         if (n_points == 2) CALL(true, 2); else CALL(true, 3);
@@ -1765,7 +1765,7 @@ int gkr_fold_round(FracPlanes in, bool in_p_base, EFPlanes eq, FracPlanes out, u
     if (n_points != 2 && n_points != 3) return (int)hipErrorInvalidValue;
     uint32_t grid = red_grid(n_pairs);
 #define CALL(PB, NP)                                                                                               \
-    hipLaunchKernelGGL((gkr_fold_round_kernel<PB, NP>), dim3(grid), dim3(RED_THREADS), 0, s, in, eq, out, n_pairs, r, \
+    OVM_LAUNCH((gkr_fold_round_kernel<PB, NP>), dim3(grid), dim3(RED_THREADS), 0, s, in, eq, out, n_pairs, r, \
                        lambda, red_inline(ro, grid))
     if (in_p_base) {
         if (n_points == 2) CALL(true, 2); else CALL(true, 3);
@@ -1837,7 +1837,7 @@ int stacked_round0(const Fp *base, uint32_t n_slices, uint32_t log_len, uint32_t
     if ((1u << l_skip) > RED_THREADS) return (int)hipErrorInvalidValue;
     uint32_t grid = red_grid(1ull << log_len);
     const uint32_t chunks = stacked_round0_chunks(n_slices, log_len);
-    hipLaunchKernelGGL(stacked_round0_kernel, dim3(grid, chunks), dim3(RED_THREADS), 0, s, base, n_slices, log_len, l_skip,
+    OVM_LAUNCH(stacked_round0_kernel, dim3(grid, chunks), dim3(RED_THREADS), 0, s, base, n_slices, log_len, l_skip,
                        d_lam_eq, d_lam_rot, d_eq_cube, ro.partials);
     OVM_CHECK_LAUNCH();
     return sum_partials(ro, grid * chunks, 3u << l_skip, s);
@@ -1903,10 +1903,10 @@ int stacked_combine(const EF *q, const uint64_t *d_slice_off, uint32_t n_slices,
                     uint32_t chunks, hipStream_t s) {
     if (4ull * n_slices >= bb::P || chunks < 1 || (chunks > 1 && !d_scratch)) return (int)hipErrorInvalidValue;
     const uint32_t gx = (uint32_t)ceil_div(1ull << log_len, 256);
-    hipLaunchKernelGGL(stacked_combine_kernel, dim3(gx, chunks), dim3(256), 0, s, q, d_slice_off, n_slices, log_len,
+    OVM_LAUNCH(stacked_combine_kernel, dim3(gx, chunks), dim3(256), 0, s, q, d_slice_off, n_slices, log_len,
                        (const CoefPre *)d_coef_eq_pre, (const CoefPre *)d_coef_rot_pre, out_eq, out_rot, d_scratch);
     if (chunks > 1)
-        hipLaunchKernelGGL(stacked_combine_reduce_kernel, dim3(gx), dim3(256), 0, s, d_scratch, chunks, log_len, out_eq,
+        OVM_LAUNCH(stacked_combine_reduce_kernel, dim3(gx), dim3(256), 0, s, d_scratch, chunks, log_len, out_eq,
                            out_rot);
     OVM_CHECK_LAUNCH();
     return 0;
@@ -1930,7 +1930,7 @@ __global__ __launch_bounds__(RED_THREADS) void stacked_round_kernel(const EF *ve
 }
 int stacked_round(const EF *vec4, uint32_t log_h, const RedOut &ro, hipStream_t s) {
     uint32_t grid = red_grid(1ull << (log_h - 1));
-    hipLaunchKernelGGL(stacked_round_kernel, dim3(grid), dim3(RED_THREADS), 0, s, vec4, log_h, red_inline(ro, grid));
+    OVM_LAUNCH(stacked_round_kernel, dim3(grid), dim3(RED_THREADS), 0, s, vec4, log_h, red_inline(ro, grid));
     OVM_CHECK_LAUNCH();
     return red_finish(ro, grid, grid, 2, s);
 }
@@ -1949,7 +1949,7 @@ __global__ void whir_mu_batch_kernel(const Fp *msg, uint32_t width, uint32_t log
 }
 int whir_mu_batch(const Fp *msg, uint32_t width, uint32_t log_h, const EF *d_mu_pows, uint32_t mu_offset, EF *f,
                   int accumulate, hipStream_t s) {
-    hipLaunchKernelGGL(whir_mu_batch_kernel, dim3(ceil_div(1ull << log_h, 256)), dim3(256), 0, s, msg, width, log_h,
+    OVM_LAUNCH(whir_mu_batch_kernel, dim3(ceil_div(1ull << log_h, 256)), dim3(256), 0, s, msg, width, log_h,
                        d_mu_pows, mu_offset, f, accumulate);
     OVM_CHECK_LAUNCH();
     return 0;
@@ -1998,7 +1998,7 @@ int zeta_transform(EF *v, uint32_t log_n, int dir, hipStream_t s) {
             nb = log_n - b < ZT_TILE_LOG - c ? log_n - b : ZT_TILE_LOG - c;
         }
         uint32_t tiles = 1u << (log_n - nb - c);
-        hipLaunchKernelGGL(zeta_pass_kernel, dim3(tiles), dim3(256), sizeof(EF) << (nb + c), s, v, log_n, b, nb, c, dir);
+        OVM_LAUNCH(zeta_pass_kernel, dim3(tiles), dim3(256), sizeof(EF) << (nb + c), s, v, log_n, b, nb, c, dir);
         OVM_CHECK_LAUNCH();
         b += nb;
     }
@@ -2019,7 +2019,7 @@ __global__ __launch_bounds__(RED_THREADS) void whir_round_kernel(const EF *f, co
 }
 int whir_round(const EF *f, const EF *w, uint64_t n_pairs, const RedOut &ro, hipStream_t s) {
     uint32_t grid = red_grid(n_pairs);
-    hipLaunchKernelGGL(whir_round_kernel, dim3(grid), dim3(RED_THREADS), 0, s, f, w, n_pairs, red_inline(ro, grid));
+    OVM_LAUNCH(whir_round_kernel, dim3(grid), dim3(RED_THREADS), 0, s, f, w, n_pairs, red_inline(ro, grid));
     OVM_CHECK_LAUNCH();
     return red_finish(ro, grid, grid, 2, s);
 }
@@ -2050,7 +2050,7 @@ __global__ __launch_bounds__(RED_THREADS) void whir_fold_round_kernel(const EF *
 int whir_fold_round(const EF *f_in, const EF *w_in, EF *f_out, EF *w_out, uint64_t n_pairs, EF alpha, const RedOut &ro,
                     hipStream_t s) {
     uint32_t grid = red_grid(n_pairs);
-    hipLaunchKernelGGL(whir_fold_round_kernel, dim3(grid), dim3(RED_THREADS), 0, s, f_in, w_in, f_out, w_out, n_pairs, alpha,
+    OVM_LAUNCH(whir_fold_round_kernel, dim3(grid), dim3(RED_THREADS), 0, s, f_in, w_in, f_out, w_out, n_pairs, alpha,
                        red_inline(ro, grid));
     OVM_CHECK_LAUNCH();
     return red_finish(ro, grid, grid, 2, s);
@@ -2065,7 +2065,7 @@ __global__ void whir_fold_kernel(const EF *f_in, const EF *w_in, EF *f_out, EF *
     st_ef(w_out + y, w0 + (w1 - w0) * alpha);
 }
 int whir_fold(const EF *f_in, const EF *w_in, EF *f_out, EF *w_out, uint64_t n_out, EF alpha, hipStream_t s) {
-    hipLaunchKernelGGL(whir_fold_kernel, dim3(ceil_div(n_out, 256)), dim3(256), 0, s, f_in, w_in, f_out, w_out, n_out,
+    OVM_LAUNCH(whir_fold_kernel, dim3(ceil_div(n_out, 256)), dim3(256), 0, s, f_in, w_in, f_out, w_out, n_out,
                        alpha);
     OVM_CHECK_LAUNCH();
     return 0;
@@ -2089,7 +2089,7 @@ __global__ __launch_bounds__(RED_THREADS) void horner_kernel(const EF *coeffs, u
 }
 int horner_eval(const EF *coeffs, uint64_t n, EF z, const RedOut &ro, hipStream_t s) {
     uint32_t grid = red_grid((n + HORNER_RUN - 1) / HORNER_RUN);
-    hipLaunchKernelGGL(horner_kernel, dim3(grid), dim3(RED_THREADS), 0, s, coeffs, n, z, z.pow(HORNER_RUN),
+    OVM_LAUNCH(horner_kernel, dim3(grid), dim3(RED_THREADS), 0, s, coeffs, n, z, z.pow(HORNER_RUN),
                        red_inline(ro, grid));
     OVM_CHECK_LAUNCH();
     return red_finish(ro, grid, grid, 1, s);
@@ -2109,7 +2109,7 @@ __global__ void whir_w_accumulate_kernel(EF *w, uint32_t log_n, const EF *tab_lo
 }
 int whir_w_accumulate(EF *w, uint32_t log_n, const EF *d_tab_lo, const EF *d_tab_hi, uint32_t log_lo, uint32_t n_q,
                       hipStream_t s) {
-    hipLaunchKernelGGL(whir_w_accumulate_kernel, dim3(ceil_div(1ull << log_n, 256)), dim3(256), 0, s, w, log_n,
+    OVM_LAUNCH(whir_w_accumulate_kernel, dim3(ceil_div(1ull << log_n, 256)), dim3(256), 0, s, w, log_n,
                        d_tab_lo, d_tab_hi, log_lo, n_q);
     OVM_CHECK_LAUNCH();
     return 0;
@@ -2121,7 +2121,7 @@ __global__ void gather_ef_kernel(const EF *src, const uint64_t *idx, uint64_t n,
 }
 int gather_ef(const EF *src, const uint64_t *d_idx, uint64_t n, EF *out, hipStream_t s) {
     if (n == 0) return 0;
-    hipLaunchKernelGGL(gather_ef_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, s, src, d_idx, n, out);
+    OVM_LAUNCH(gather_ef_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, s, src, d_idx, n, out);
     OVM_CHECK_LAUNCH();
     return 0;
 }
@@ -2137,7 +2137,7 @@ __global__ void ef_sum_blocks_kernel(const EF *in, uint32_t n_blocks, uint64_t n
 }
 int ef_sum_blocks(const EF *in, uint32_t n_blocks, uint64_t n, EF *out, hipStream_t s) {
     if (n_blocks == 0) return (int)hipErrorInvalidValue;
-    hipLaunchKernelGGL(ef_sum_blocks_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, s, in, n_blocks, n, out);
+    OVM_LAUNCH(ef_sum_blocks_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, s, in, n_blocks, n, out);
     OVM_CHECK_LAUNCH();
     return 0;
 }
