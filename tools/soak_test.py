@@ -38,3 +38,30 @@ for i in range(60):
     if first is None: first = proof
     assert proof == first, f"many-AIR proof {i} differs"
 free, total = torch.cuda.mem_get_info(); print(f"{len(air_list)} AIRs x 60 proofs identical, {time.time() - t0:.1f} s, used GB", round((total - free) / 2**30, 3))
+# DIFFERENT proofs interleaved (a repeated identical proof would hide a buffer that still holds the previous proof's
+# bytes: stale uploads, a pool block handed out twice): three contexts of different shapes in rotation, every proof
+# compared with the first one of its context
+rng = np.random.default_rng(7)
+ctxs = []
+for k, (n_airs, lh) in enumerate([(1, 12), (4, 9), (7, 6)]):
+    al = [airs.random_air(rng, int(rng.integers(3, 16)), int(rng.integers(5, 40)), int(rng.integers(0, 3))) for _ in range(n_airs)]
+    p3 = airs.test_params(l_skip=int(rng.integers(2, 5)), n_stack=10, k_whir=3)
+    key = pkg.ProvingKey(airs.pk_blob(p3, al))
+    trs = []
+    for i, a in enumerate(al):
+        hh = 1 << int(rng.integers(max(lh - 3, 0), lh + 1))
+        w = a["common_main_width"]
+        trs.append((i, dev.upload(pkg.to_mont(rng.integers(0, airs.P, size=w * hh, dtype=np.uint64).astype(np.uint32))), hh, []))
+    ctxs.append((key, trs, None))
+t0 = time.time()
+for it in range(300):
+    k = it % len(ctxs)
+    key, trs, first = ctxs[k]
+    proof, _ = dev.prove(key, trs)
+    if first is None:
+        ctxs[k] = (key, trs, proof)
+    else:
+        assert proof == first, f"interleaved proof {it} (context {k}) differs"
+m = pkg.memory_stats()
+print(f"300 interleaved proofs of 3 contexts identical to their first, {time.time() - t0:.1f} s; pool holds {m['segments'] / 2**20:.0f} MiB, "
+      f"{m['driver_allocs']} hipMalloc calls in the process so far")
