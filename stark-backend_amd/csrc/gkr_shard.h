@@ -154,7 +154,7 @@ struct GkrDeviceOps {
 // A rank whose table has shrunk to this many records hands all of them to the host in one go, and the host
 // (every rank's, identically) finishes the layer: the last sub-rounds of a layer are a kernel launch and a
 // mailbox round trip (~12 us) for a handful of pairs each, which the host sums in a microsecond or two.
-static constexpr unsigned GKR_HOST_TAIL = 32;
+static constexpr unsigned GKR_HOST_TAIL = 64;
 
 struct GkrOutput {
     EF q0_claim = EF::one();
