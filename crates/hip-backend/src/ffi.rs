@@ -183,6 +183,7 @@ extern "C" {
         stream: OvmStream,
     ) -> c_int;
     pub fn ovm_hip_poseidon2_permute(d_states: *mut u32, n: u64, stream: OvmStream) -> c_int;
+    pub fn ovm_hip_poseidon2_permute_rc(d_states: *mut u32, n: u64, d_rc141: *const u32, stream: OvmStream) -> c_int;
     pub fn ovm_hip_sponge_grind(
         sponge: *const OvmSponge,
         bits: u32,

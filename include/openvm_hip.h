@@ -54,8 +54,11 @@ const char *ovm_hip_error_name(int code);
 
 /* Per-stage timing with HIP events on the launching stream (reference: the `tracing` spans /
  * NVTX ranges of crates/stark-sdk/src/{metrics_tracing,nvtx_tracing}.rs). enable(1) resets and
- * starts recording, enable(0) stops. report() synchronises the device and writes one
- * "label calls total_ms" line per label; returns the buffer size needed. */
+ * starts recording every stage, enable(2) records only the dominant kernel's label
+ * ("merkle.hash_rows": one event pair per commitment -- what a timed benchmark region can afford),
+ * enable(0) stops. report() synchronises the device and writes one "label calls total_ms" line per
+ * label; returns the buffer size needed. With OVM_ROCTX=1 in the environment the same labels are also
+ * emitted as roctx ranges (rocprofv3 --marker-trace), the analogue of nvtx_tracing.rs:9-33. */
 int ovm_hip_profile_enable(int on);
 uint64_t ovm_hip_profile_report(char *buf, uint64_t cap);
 
@@ -131,6 +134,11 @@ int ovm_hip_merkle_tree_ext(const uint32_t *d_matrix, uint64_t width, uint32_t l
 /* n independent Poseidon2 permutations of 16-word states, in place (test / micro-benchmark entry;
  * reference: crates/cuda-common/include/poseidon2.cuh:184-202). */
 int ovm_hip_poseidon2_permute(uint32_t *d_states, uint64_t n, ovm_stream_t stream);
+/* The same S-box and linear layers over round constants read from device memory: d_rc141 = 64 initial, 64
+ * terminal, 13 internal Montgomery words (what `Poseidon2BabyBear::new_from_rng_128` would build, p3-baby-bear
+ * 0.4.3). Test entry: runs Plonky3's published known-answer vector, whose constants are drawn from a seeded RNG,
+ * through the product's own layer code (tests/golden/poseidon2_p3_kat.json). */
+int ovm_hip_poseidon2_permute_rc(uint32_t *d_states, uint64_t n, const uint32_t *d_rc141, ovm_stream_t stream);
 
 /* Proof-of-work: the MINIMUM canonical witness w such that observing w and sampling yields
  * `bits` zero low bits (reference: crates/stark-backend/src/transcript/traits.rs:62-89; replaces

@@ -56,6 +56,13 @@ void orc_poseidon2_permute(uint32_t *state16) {
     poseidon2_permute(s);
     for (int i = 0; i < 16; i++) state16[i] = s[i].v;
 }
+void orc_poseidon2_permute_rc(uint32_t *state16, const uint32_t *initial64, const uint32_t *terminal64,
+                              const uint32_t *internal13) {
+    Fp s[16];
+    for (int i = 0; i < 16; i++) s[i] = Fp((uint64_t)state16[i]);
+    poseidon2_permute_rc(s, initial64, terminal64, internal13);
+    for (int i = 0; i < 16; i++) state16[i] = s[i].v;
+}
 void orc_poseidon2_constants(uint32_t *initial64, uint32_t *terminal64, uint32_t *internal13,
                               uint32_t *diag16) {
     memcpy(initial64, RC_INITIAL, sizeof(RC_INITIAL));

@@ -73,21 +73,26 @@ inline void internal_linear(Fp *s) {
     for (int i = 0; i < 16; i++) s[i] = sum + s[i] * Fp((uint64_t)INTERNAL_DIAG[i]);
 }
 
-inline void poseidon2_permute(Fp *s) {
+// The permutation over caller-supplied round constants (canonical): the layer code below is the ONLY copy, the
+// default permutation is this function over the in-tree tables. Exists so that Plonky3's published known-answer
+// vector -- which uses constants drawn from a seeded RNG, not the default ones -- can pin the layer structure
+// (tests/golden/poseidon2_p3_kat.json, tests/test_oracle_golden.py).
+inline void poseidon2_permute_rc(Fp *s, const uint32_t *rc_initial, const uint32_t *rc_terminal, const uint32_t *rc_internal) {
     external_linear(s);
     for (int r = 0; r < 4; r++) {
-        for (int i = 0; i < 16; i++) s[i] = sbox7(s[i] + Fp((uint64_t)RC_INITIAL[16 * r + i]));
+        for (int i = 0; i < 16; i++) s[i] = sbox7(s[i] + Fp((uint64_t)rc_initial[16 * r + i]));
         external_linear(s);
     }
     for (int r = 0; r < 13; r++) {
-        s[0] = sbox7(s[0] + Fp((uint64_t)RC_INTERNAL[r]));
+        s[0] = sbox7(s[0] + Fp((uint64_t)rc_internal[r]));
         internal_linear(s);
     }
     for (int r = 0; r < 4; r++) {
-        for (int i = 0; i < 16; i++) s[i] = sbox7(s[i] + Fp((uint64_t)RC_TERMINAL[16 * r + i]));
+        for (int i = 0; i < 16; i++) s[i] = sbox7(s[i] + Fp((uint64_t)rc_terminal[16 * r + i]));
         external_linear(s);
     }
 }
+inline void poseidon2_permute(Fp *s) { poseidon2_permute_rc(s, RC_INITIAL, RC_TERMINAL, RC_INTERNAL); }
 
 using Digest = std::array<Fp, 8>;
 

@@ -101,6 +101,7 @@ SIGNATURES = {
     "ovm_hip_merkle_tree_ext": (c_int, [c_void_p, c_uint64, c_uint32, c_uint32, c_void_p, c_void_p,
                                         c_void_p]),
     "ovm_hip_poseidon2_permute": (c_int, [c_void_p, c_uint64, c_void_p]),
+    "ovm_hip_poseidon2_permute_rc": (c_int, [c_void_p, c_uint64, c_void_p, c_void_p]),
     "ovm_hip_sponge_grind": (c_int, [POINTER(SpongeState), c_uint32, _u32p, c_void_p]),
     "ovm_hip_gather_rows": (c_int, [c_void_p, c_uint64, c_uint64, c_uint32, c_void_p, c_uint64,
                                     c_void_p, c_void_p]),
@@ -281,6 +282,10 @@ class Device:
     def poseidon2_permute(self, d_states, n):
         check(_lib().ovm_hip_poseidon2_permute(d_states.data_ptr(), n, self.stream),
               "ovm_hip_poseidon2_permute")
+
+    def poseidon2_permute_rc(self, d_states, n, d_rc141):
+        check(_lib().ovm_hip_poseidon2_permute_rc(d_states.data_ptr(), n, d_rc141.data_ptr(), self.stream),
+              "ovm_hip_poseidon2_permute_rc")
 
     def grind(self, sponge: SpongeState, bits: int) -> int:
         w = c_uint32(0)
@@ -794,8 +799,10 @@ def constraint_eval_buffer_size(pk: ProvingKey, air_idx: int) -> int:
     return int(_lib().ovm_hip_constraint_eval_buffer_size(pk.handle, air_idx))
 
 
-def profile_enable(on: bool) -> None:
-    _lib().ovm_hip_profile_enable(1 if on else 0)
+def profile_enable(on) -> None:
+    """False/0: off; True/1: every stage; 2: only the dominant kernel's label (``merkle.hash_rows``) -- one event pair
+    per commitment, what bench.py keeps on inside its timed region."""
+    _lib().ovm_hip_profile_enable(int(on))
 
 
 def profile_report() -> dict:

@@ -56,6 +56,7 @@ const Twiddles *twiddles();
 // through ovm_hip_profile_*). Off by default: no events are created.
 struct ProfScope {
     int slot = -1;
+    bool ranged = false;  // a roctx range is open (OVM_ROCTX=1)
     hipStream_t stream;
     ProfScope(const char *label, hipStream_t s);
     ~ProfScope();

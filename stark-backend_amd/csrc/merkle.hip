@@ -154,6 +154,17 @@ __global__ void permute_states_kernel(Fp *states, uint64_t n) {
     for (int k = 0; k < 16; k++) states[i * 16 + k] = s[k];
 }
 
+__global__ void permute_states_rc_kernel(Fp *states, uint64_t n, const uint32_t *rc) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Fp s[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) s[k] = states[i * 16 + k];
+    p2::permute_rc(s, rc);
+#pragma unroll
+    for (int k = 0; k < 16; k++) states[i * 16 + k] = s[k];
+}
+
 // Gather `n_rows` rows (given by physical row index) of a column-major matrix into a row-major
 // buffer of n_rows x width entries.
 template <int WORDS>
@@ -285,6 +296,15 @@ int ovm_hip_poseidon2_permute(uint32_t *d_states, uint64_t n, ovm_stream_t strea
     if (n == 0) return 0;
     OVM_LAUNCH(permute_states_kernel, dim3(ceil_div(n, 256)), dim3(256), 0,
                        (hipStream_t)stream, (Fp *)d_states, n);
+    OVM_CHECK_LAUNCH();
+    return 0;
+}
+
+int ovm_hip_poseidon2_permute_rc(uint32_t *d_states, uint64_t n, const uint32_t *d_rc141, ovm_stream_t stream) {
+    if (n == 0) return 0;
+    if (!d_states || !d_rc141) return (int)hipErrorInvalidValue;
+    OVM_LAUNCH(permute_states_rc_kernel, dim3(ceil_div(n, 256)), dim3(256), 0,
+                       (hipStream_t)stream, (Fp *)d_states, n, d_rc141);
     OVM_CHECK_LAUNCH();
     return 0;
 }

@@ -143,6 +143,27 @@ BB_HD void permute(Fp *s) {
     }
 }
 
+// The same layers over round constants read from memory (`rc`: 64 initial, 64 terminal, 13 internal Montgomery words).
+// Not used by the prover: it lets Plonky3's published known-answer vector -- whose constants come from a seeded RNG,
+// not the default table -- run through THIS file's S-box and linear layers (ovm_hip_poseidon2_permute_rc).
+BB_HD void permute_rc(Fp *s, const uint32_t *rc) {
+    external_linear(s);
+    for (int r = 0; r < 4; r++) {
+#pragma unroll
+        for (int i = 0; i < 16; i++) s[i] = sbox7_add(s[i], rc[16 * r + i]);
+        external_linear(s);
+    }
+    for (int r = 0; r < 13; r++) {
+        s[0] = sbox7_add(s[0], rc[128 + r]);
+        internal_linear(s);
+    }
+    for (int r = 0; r < 4; r++) {
+#pragma unroll
+        for (int i = 0; i < 16; i++) s[i] = sbox7_add(s[i], rc[64 + 16 * r + i]);
+        external_linear(s);
+    }
+}
+
 #if defined(__HIPCC__)
 // ---- the permutation by 16 cooperating lanes -----------------------------------------------------
 // One lane per state word (a DPP row of 16; a wave64 carries four permutations). What a single lane

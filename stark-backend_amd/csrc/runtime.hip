@@ -5,6 +5,9 @@
 #include "device_ctx.h"
 #include "openvm_hip.h"
 
+#include <dlfcn.h>
+
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -16,12 +19,41 @@ struct ProfRec {
     const char *label;
     hipEvent_t a, b;
 };
-bool g_prof_on = false;
+int g_prof_mode = 0;  // 0 off, 1 every stage, 2 the dominant kernel's label only
 std::vector<ProfRec> g_prof;
+
+// roctx ranges under the same labels (reference: the NVTX layer of crates/stark-sdk/src/nvtx_tracing.rs:9-33).
+// OVM_ROCTX=1 in the environment turns them on; the marker library is looked up at run time, so the product has no
+// link-time dependency on a profiler (rocprofv3 --marker-trace preloads it and sees the ranges).
+struct Roctx {
+    int (*push)(const char *) = nullptr;
+    int (*pop)() = nullptr;
+    Roctx() {
+        const char *e = getenv("OVM_ROCTX");
+        if (!e || !*e || *e == '0') return;
+        for (const char *name : {"librocprofiler-sdk-roctx.so", "librocprofiler-sdk-roctx.so.1", "libroctx64.so", "libroctx64.so.4"}) {
+            if (void *h = dlopen(name, RTLD_NOW | RTLD_GLOBAL)) {
+                push = (int (*)(const char *))dlsym(h, "roctxRangePushA");
+                pop = (int (*)())dlsym(h, "roctxRangePop");
+                if (push && pop) return;
+                push = nullptr, pop = nullptr;
+            }
+        }
+    }
+};
+const Roctx &roctx() {
+    static Roctx r;
+    return r;
+}
 }  // namespace
 
 ProfScope::ProfScope(const char *label, hipStream_t s) : stream(s) {
-    if (!g_prof_on) return;
+    if (roctx().push) {
+        roctx().push(label);
+        ranged = true;
+    }
+    if (!g_prof_mode) return;
+    if (g_prof_mode == 2 && strcmp(label, "merkle.hash_rows") != 0) return;
     ProfRec r{label, nullptr, nullptr};
     if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return;
     (void)hipEventRecord(r.a, s);
@@ -30,6 +62,7 @@ ProfScope::ProfScope(const char *label, hipStream_t s) : stream(s) {
 }
 ProfScope::~ProfScope() {
     if (slot >= 0) (void)hipEventRecord(g_prof[slot].b, stream);
+    if (ranged) roctx().pop();
 }
 }  // namespace ovm
 
@@ -41,7 +74,7 @@ int ovm_hip_profile_enable(int on) {
         (void)hipEventDestroy(r.b);
     }
     ovm::g_prof.clear();
-    ovm::g_prof_on = on != 0;
+    ovm::g_prof_mode = on < 0 || on > 2 ? 1 : on;
     return 0;
 }
 

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Parity fuzzing of the SHARDED prover on one GPU (test infrastructure, not collected by pytest): random multi-AIR
-contexts, a random number of logical ranks (2-4 processes sharing the GPU), random assignment of the traces to ranks
+contexts, a random number of logical ranks (2-8 processes sharing the GPU), random assignment of the traces to ranks
 (a rank may own none), random memory-bounded modes and with / without the all-to-all form of the mu-batch sum; the joint
 proof must be byte-identical to the oracle's single proof.
 
@@ -33,7 +33,7 @@ def main():
     rng = np.random.default_rng(args.seed)
     bad = 0
     for case in range(args.cases):
-        seed, world = int(rng.integers(0, 1 << 30)), int(rng.integers(2, 5))
+        seed, world = int(rng.integers(0, 1 << 30)), int(rng.integers(2, 9))
         save_memory, alltoall = bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
         bulk = str(rng.choice(["ipc", "ipc", "shm"]))
         params, air_list, traces, owners = shard_cases.make(f"fuzz:{seed}", world)

@@ -51,6 +51,14 @@ class Oracle:
         self.lib.orc_poseidon2_permute(_p(s))
         return s
 
+    def permute_rc(self, state, initial, terminal, internal):
+        """The oracle's layer code over caller-supplied (canonical) round constants."""
+        s = np.ascontiguousarray(state, dtype=np.uint32).copy()
+        a, b, c = (np.ascontiguousarray(x, dtype=np.uint32) for x in (initial, terminal, internal))
+        assert a.size == 64 and b.size == 64 and c.size == 13
+        self.lib.orc_poseidon2_permute_rc(_p(s), _p(a), _p(b), _p(c))
+        return s
+
     def hash_slice(self, vals):
         v = np.ascontiguousarray(vals, dtype=np.uint32)
         out = np.zeros(8, dtype=np.uint32)

@@ -59,7 +59,7 @@ def make(name, world):
     if name == "bench8":  # one partitioned BenchmarkAir per rank, equal heights (config D's multi-GPU form, small)
         p, a, t = _bench_partitioned(world, 8, [5] * world, airs.test_params(l_skip=2, n_stack=6, k_whir=2))
     elif name == "bench_mixed_heights":  # twice as many AIRs as ranks, heights incl. one below 2^l_skip
-        lh = [6, 5, 5, 4, 3, 3, 1, 0][:2 * world]
+        lh = ([6, 5, 5, 4, 3, 3, 1, 0] if world <= 4 else [7, 6, 6, 5, 5, 5, 4, 4, 3, 3, 2, 2, 1, 1, 0, 0])[:2 * world]
         p, a, t = _bench_partitioned(len(lh), 6, lh, airs.test_params(l_skip=2, n_stack=7, k_whir=2), seed=7)
     elif name == "bench_app":  # app-like parameters (l_skip 4, k_whir 4), 2^10 rows x 20 columns per AIR
         p, a, t = _bench_partitioned(world, 20, [10] * world, airs.test_params(l_skip=4, n_stack=8, k_whir=4), seed=3)

@@ -134,3 +134,24 @@ def test_commit_full_size_properties(dev, pkg):
     cb = pkg.from_mont(dev.download(dev.rs_encode(dev.upload(pkg.to_mont(b)), width, log_h, l_skip, 1)))
     cs = pkg.from_mont(dev.download(dev.rs_encode(dev.upload(pkg.to_mont(s)), width, log_h, l_skip, 1)))
     assert np.array_equal(cs, ((ca.astype(np.uint64) + cb) % P).astype(np.uint32))
+
+
+def test_p3_known_answer_through_the_hip_layers(dev, pkg, orc):
+    """Plonky3's published Poseidon2 vector (tests/golden/poseidon2_p3_kat.json: RNG-drawn round constants) through the
+    PRODUCT's S-box and linear-layer code on the GPU (ovm_hip_poseidon2_permute_rc), and random states against the oracle
+    under the same constants; the default permutation is the same layer code over the in-tree default tables."""
+    import json
+    import os
+    import p3_rng
+    kat = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "poseidon2_p3_kat.json")))
+    ri, rt, rn = p3_rng.poseidon2_constants_from_rng_128(kat["seed"])
+    d_rc = dev.upload(pkg.to_mont(np.array(ri + rt + rn, dtype=np.uint32)))
+    rng = np.random.default_rng(5)
+    states = rng.integers(0, P, size=(257, 16), dtype=np.uint64).astype(np.uint32)
+    states[0] = kat["input"]
+    d = dev.upload(pkg.to_mont(states.reshape(-1)))
+    dev.poseidon2_permute_rc(d, 257, d_rc)
+    got = pkg.from_mont(dev.download(d)).reshape(257, 16)
+    assert [int(x) for x in got[0]] == kat["output"]
+    for i in (1, 2, 100, 256):
+        assert np.array_equal(got[i], orc.permute_rc(states[i], ri, rt, rn))

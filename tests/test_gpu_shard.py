@@ -59,7 +59,10 @@ def oracle_proof(orc, case, world):
 # (every context with 2 shards; with 4 shards the three that differ in structure: one AIR per rank, mixed
 # heights with two AIRs per rank, and the mixture of plain / cached / public-value AIRs)
 RUNS = [(c, 2) for c in shard_cases.CASES] + [(c, 4) for c in ("bench8", "bench_mixed_heights", "mixture")] + \
-       [("bench8", 3), ("three_airs", 4)]  # a world that is not a power of two; a rank that owns no trace
+       [("bench8", 3), ("three_airs", 4)] + \
+       [("bench8", 8), ("bench_mixed_heights", 8), ("three_airs", 8)]
+# (3: a world that is not a power of two; three_airs with 4 or 8 ranks: ranks that own no trace; 8 = the north star's
+# world size -- one AIR per rank, 16 AIRs of mixed heights (two per rank), and 3 AIRs over 8 ranks)
 
 
 @pytest.mark.parametrize("case,world", RUNS)
@@ -254,3 +257,46 @@ def test_bench_with_two_ranks_on_one_gpu(tmp_path):
         assert line["value"] > 0 and says in line["config"]["parallelism"] and "FAILED" not in line["config"]["parallelism"]
         hashes.append(line["config"]["proof_sha256"])
     assert len(set(hashes)) == 1   # the same joint proof whichever way the bulk data travelled
+
+
+def test_bench_with_eight_ranks_on_one_gpu(tmp_path):
+    """The north star's world size through `bench.py --gpus 8` on this one GPU (--one-gpu, reduced size): eight ranks,
+    one partitioned BenchmarkAir each, one joint proof; the JSON line must carry positive evidence of what ran -- the
+    process group's backend and size as torch reports them, one entry per rank with its device, the bulk carrier the
+    pre-flight settled on, per-rank stage times -- and the proof must not depend on the carrier."""
+    import json
+    root = os.path.dirname(HERE)
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env["OVM_SHARD_TIMEOUT_S"] = "60"
+    hashes = []
+    for bulk in ("ipc", "rccl"):
+        out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--one-gpu", "--log-rows", "12",
+                              "--log-stacked-height", "16", "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--bulk", bulk],
+                             env=env, cwd=root, capture_output=True, text=True, timeout=900)
+        assert out.returncode == 0, out.stderr[-3000:]
+        line = json.loads(out.stdout.strip().splitlines()[-1])
+        assert line["n_gpus"] == 8 and line["scaling"] == "weak" and line["value"] > 0
+        d = line["dist"]
+        assert d["world_size"] == 8 and d["backend"] == "gloo" and len(d["ranks"]) == 8
+        assert sorted(r["rank"] for r in d["ranks"]) == list(range(8)) and len({r["pid"] for r in d["ranks"]}) == 8
+        assert d["bulk_carrier"] == (["ipc"] if bulk == "ipc" else ["torch"]) and d["bulk_preflight_ok"]
+        if bulk == "rccl":  # (the IPC carrier has no Python in its data path, so nothing counts its calls)
+            assert all(r["alltoall_calls"] >= 2 for r in d["ranks"])   # the all-to-all form of the mu-batch sum, every rank
+        assert len(line["stage_ms_per_rank"]) == 8 and all("merkle.hash_rows" in s for s in line["stage_ms_per_rank"])
+        hashes.append(line["config"]["proof_sha256"])
+    assert len(set(hashes)) == 1
+
+
+def test_bench_dry_run_two_ranks(tmp_path):
+    """`bench.py --gpus 2 --one-gpu --dry-run`: rendezvous + pre-flight + the bulk steps at the full vector size of the
+    given stacked height, no proof; one JSON line with the timings and a data check per carrier."""
+    import json
+    root = os.path.dirname(HERE)
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env["OVM_SHARD_TIMEOUT_S"] = "60"
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--one-gpu", "--dry-run",
+                          "--log-stacked-height", "20", "--bulk", "ipc"], env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    assert line["dry_run"] and line["n_gpus"] == 2 and line["vector_bytes"] == 16 << 20
+    assert all(e["data_ok"] for e in line["exchanges"].values())
