@@ -214,6 +214,15 @@ extern "C" {
         air_idx: u32,
         commitment_out: *mut u32,
     ) -> c_int;
+    pub fn ovm_hip_program_stats(
+        blob: *const u32,
+        words: u64,
+        air_idx: u32,
+        kind: u32,
+        instrs_out: *mut u32,
+        slots_out: *mut u32,
+        remat_limit_out: *mut u32,
+    ) -> c_int;
     pub fn ovm_hip_staged_selftest(
         blob: *const u32,
         words: u64,

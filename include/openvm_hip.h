@@ -198,6 +198,11 @@ int ovm_hip_pk_preprocessed_commitment(const ovm_pk_t *pk, uint32_t air_idx, uin
  * to the plain interpreter. Needs no device. 0 = all equal; `blocks_out` (optional) = blocks staged. */
 int ovm_hip_staged_selftest(const uint32_t *blob, uint64_t words, uint32_t stage_rows, uint32_t acc_rows,
                             uint64_t seed, uint64_t *blocks_out);
+/* Host-only: size of the register program one AIR of the key compiles to (kind 0 zerocheck, 1 LogUp round sums,
+ * 2 GKR leaves): instructions, slots (simultaneously live intermediates) and the recomputation limit the compiler
+ * settled on (csrc/program.h compile_program; 0 = nothing is computed twice). Diagnostics / tests. */
+int ovm_hip_program_stats(const uint32_t *blob, uint64_t words, uint32_t air_idx, uint32_t kind, uint32_t *instrs_out,
+                          uint32_t *slots_out, uint32_t *remat_limit_out);
 /* Host-only self-test of the transcript's permutation: the run-time selected host implementation
  * (AVX2 where the CPU has it, csrc/host_poseidon2.cpp) against the scalar one on n pseudo-random
  * states. 1 = equal on all of them. */

@@ -110,6 +110,7 @@ SIGNATURES = {
     "ovm_hip_pk_free": (None, [c_void_p]),
     "ovm_hip_pk_preprocessed_commitment": (c_int, [c_void_p, c_uint32, c_void_p]),
     "ovm_hip_staged_selftest": (c_int, [c_void_p, c_uint64, c_uint32, c_uint32, c_uint64, _u64p]),
+    "ovm_hip_program_stats": (c_int, [c_void_p, c_uint64, c_uint32, c_uint32, c_void_p, c_void_p, c_void_p]),
     "ovm_hip_host_permute_selftest": (c_int, [c_uint32, c_uint64]),
     "ovm_hip_last_error": (c_char_p, []),
     "ovm_hip_trim": (c_int, []),
@@ -755,6 +756,16 @@ def gkr_shard_selftest(world: int, TR: int, ends, seed: int = 1, three_points: b
     rc = _lib().ovm_hip_gkr_shard_selftest(world, TR, e, seed, 1 if three_points else 0)
     if rc != 0:
         raise OvmError(rc, f"ovm_hip_gkr_shard_selftest [{_lib().ovm_hip_selftest_error().decode()}]")
+
+
+def program_stats(blob, air_idx: int = 0, kind: int = 0) -> dict:
+    """{instrs, slots, remat_limit} of the register program AIR ``air_idx`` compiles to (kind 0 zerocheck, 1 LogUp, 2 leaves)."""
+    b = np.ascontiguousarray(blob, dtype=np.uint32)
+    out = (c_uint32 * 3)()
+    rc = _lib().ovm_hip_program_stats(b.ctypes.data, b.size, air_idx, kind, ctypes.byref(out, 0), ctypes.byref(out, 4), ctypes.byref(out, 8))
+    if rc != 0:
+        _fail(rc, "ovm_hip_program_stats")
+    return {"instrs": int(out[0]), "slots": int(out[1]), "remat_limit": int(out[2])}
 
 
 def staged_selftest(blob, stage_rows: int, acc_rows: int, seed: int = 1) -> int:

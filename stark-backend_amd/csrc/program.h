@@ -115,142 +115,227 @@ inline std::vector<Root> roots_leaves(const AirKey &a) {
     return roots;
 }
 
-// Compiles the nodes needed by `roots` (emitted in the given order, each right after its node is
-// available). Public values are folded to constants.
-inline Program compile_program(const AirKey &air, const ColumnMap &cm, const std::vector<Fp> &public_values,
-                               const std::vector<Root> &roots, uint32_t num_weights) {
-    // Only the index range [lo, n) of the DAG that the roots reach is visited (children precede their
-    // parents): a group of consecutive constraints touches a small window of a big DAG, and this runs
-    // once per AIR, group and proof.
+// Compiles the nodes the `roots` need into a register program. Roots fire strictly in the given order (a LEAF closes
+// the DENs before it). Public values are folded to constants.
+//
+// Scheduling is DEMAND-DRIVEN: for each root in turn its expression is emitted depth-first (the operand that needs more
+// registers first, Sethi-Ullman), so a value is computed right before its first use and its slot is recycled after the
+// last one -- the slot count is the live set of a depth-first walk, not of the DAG's construction order. A node whose whole
+// expression tree costs at most `remat_limit` instructions is never kept: every use recomputes it (limit 1 = an operation
+// on two leaves, e.g. the `q + q` of x xor q = x + q - x (q + q), which p3-keccak-air's constraints share between columns
+// that are hundreds of constraints apart). compile_program() raises the limit until the program fits `max_slots`:
+// the first version emitted nodes in DAG index order and the real Keccak-f AIR (39 K instructions) needed 645 slots --
+// more than any executor holds -- where this order needs a dozen.
+struct CompileStats {
+    uint32_t remat_limit = 0, recomputed = 0;
+};
+inline Program compile_program_with(const AirKey &air, const ColumnMap &cm, const std::vector<Fp> &public_values,
+                                    const std::vector<Root> &roots, uint32_t num_weights, uint32_t remat_limit,
+                                    CompileStats *stats = nullptr) {
     size_t n = 0;
     for (auto &r : roots) n = std::max(n, (size_t)r.node + 1);
     if (n > air.nodes.size()) throw OvmFail(1, "program compiler: root out of range");
+    auto is_op = [&](uint32_t i) { return air.nodes[i].kind >= N_ADD; };
+    auto binary = [&](uint32_t i) { return air.nodes[i].kind != N_NEG; };
+    // Reachable operation nodes in index order (children precede their parents): tree cost, register need, and -- for
+    // the nodes that are kept -- how many kept parents / root firings will read them.
     std::vector<char> need(n, 0);
-    size_t pending = 0, lo = n;
-    for (auto &r : roots)
-        if (!need[r.node]) need[r.node] = 1, pending++;
-    for (size_t i = n; i-- > 0 && pending > 0;) {
-        if (!need[i]) continue;
-        pending--;
-        lo = i;
-        const Node &nd = air.nodes[i];
-        if (nd.kind >= N_ADD) {
-            if (nd.left >= i || (nd.kind != N_NEG && nd.right >= i)) throw OvmFail(1, "program compiler: DAG not topological");
-            if (!need[nd.left]) need[nd.left] = 1, pending++;
-            if (nd.kind != N_NEG && !need[nd.right]) need[nd.right] = 1, pending++;
-        }
-    }
-    // Roots fire strictly in sequence (a LEAF closes the DENs before it): root r fires at time
-    // fire[r] = max node index over roots 0..r. A node's slot is released at the end of the time
-    // step of its last use (last consuming instruction or last root firing on it).
-    std::vector<size_t> fire(roots.size());
     {
-        size_t f = 0;
-        for (size_t r = 0; r < roots.size(); r++) {
-            f = std::max(f, (size_t)roots[r].node);
-            fire[r] = f;
+        std::vector<uint32_t> stack;
+        for (auto &r : roots)
+            if (!need[r.node]) need[r.node] = 1, stack.push_back(r.node);
+        while (!stack.empty()) {
+            const uint32_t i = stack.back();
+            stack.pop_back();
+            if (!is_op(i)) continue;
+            const Node &nd = air.nodes[i];
+            if (nd.left >= i || (binary(i) && nd.right >= i)) throw OvmFail(1, "program compiler: DAG not topological");
+            if (!need[nd.left]) need[nd.left] = 1, stack.push_back(nd.left);
+            if (binary(i) && !need[nd.right]) need[nd.right] = 1, stack.push_back(nd.right);
         }
     }
-    std::vector<size_t> last_use(n, 0);
-    for (size_t i = lo; i < n; i++) {
-        if (!need[i]) continue;
+    std::vector<uint32_t> cost(n, 0), regs(n, 0), uses(n, 0);
+    size_t lo = n;
+    for (size_t i = 0; i < n; i++) {
+        if (!need[i] || !is_op((uint32_t)i)) continue;
+        lo = std::min(lo, i);
         const Node &nd = air.nodes[i];
-        last_use[i] = std::max(last_use[i], i);
-        if (nd.kind >= N_ADD) {
-            last_use[nd.left] = std::max(last_use[nd.left], i);
-            if (nd.kind != N_NEG) last_use[nd.right] = std::max(last_use[nd.right], i);
-        }
+        const uint64_t c = 1ull + cost[nd.left] + (binary((uint32_t)i) ? cost[nd.right] : 0);
+        cost[i] = (uint32_t)std::min<uint64_t>(c, 1u << 30);
+        const uint32_t rl = regs[nd.left], rr = binary((uint32_t)i) ? regs[nd.right] : 0;
+        regs[i] = std::max<uint32_t>(1, rl == rr ? rl + (rl ? 1 : 0) : std::max(rl, rr));
     }
-    for (size_t r = 0; r < roots.size(); r++)
-        last_use[roots[r].node] = std::max(last_use[roots[r].node], fire[r]);
-    // release lists per time step as intrusive singly linked lists (no per-node allocation: this runs
-    // once per AIR, group and proof)
-    std::vector<int32_t> release_head(n, -1), release_next(n, -1);
-    for (size_t i = n; i-- > lo;)
-        if (need[i] && air.nodes[i].kind >= N_ADD) {
-            release_next[i] = release_head[last_use[i]];
-            release_head[last_use[i]] = (int32_t)i;
-        }
+    auto remat = [&](uint32_t i) { return cost[i] <= remat_limit; };
+    for (size_t i = lo; i < n; i++) {
+        if (!need[i] || !is_op((uint32_t)i) || remat((uint32_t)i)) continue;  // (a recomputed node's operands are recomputed too)
+        const Node &nd = air.nodes[i];
+        if (is_op(nd.left)) uses[nd.left]++;
+        if (binary((uint32_t)i) && is_op(nd.right)) uses[nd.right]++;
+    }
+    for (auto &r : roots)
+        if (is_op(r.node)) uses[r.node]++;
 
     Program prog;
     prog.num_weights = num_weights;
     std::vector<int32_t> slot_of(n, -1);
     std::vector<uint32_t> free_slots;
     std::vector<char> col_used(cm.total, 0);
-    auto operand = [&](uint32_t node, uint8_t &kind, uint32_t &payload) {
+    struct Operand {
+        uint8_t kind;
+        uint32_t payload;
+        int32_t node;  // the operation node whose slot this is (-1: a leaf)
+    };
+    auto leaf_operand = [&](uint32_t node) -> Operand {
         const Node &nd = air.nodes[node];
         switch (nd.kind) {
             case N_VAR:
-                if (nd.entry == E_PUBLIC) {
-                    kind = K_CONST;
-                    payload = public_values.at(nd.index).v;
-                } else if (nd.entry == E_MAIN) {
+                if (nd.entry == E_PUBLIC) return {K_CONST, public_values.at(nd.index).v, -1};
+                if (nd.entry == E_MAIN) {
                     if (nd.part_index >= cm.part_width.size() || nd.index >= cm.part_width[nd.part_index] ||
                         (nd.offset && !cm.need_rot))
                         throw OvmFail(1, "main variable out of range");
-                    kind = K_COL;
-                    payload = cm.col(nd.part_index, nd.offset, nd.index);
-                    col_used[payload] = 1;
-                } else if (nd.entry == E_PREPROCESSED) {
+                    const uint32_t c = cm.col(nd.part_index, nd.offset, nd.index);
+                    col_used[c] = 1;
+                    return {K_COL, c, -1};
+                }
+                if (nd.entry == E_PREPROCESSED) {
                     if (nd.index >= cm.pre_width || (nd.offset && !cm.need_rot))
                         throw OvmFail(1, "preprocessed variable out of range");
-                    kind = K_COL;
-                    payload = cm.pre_col(nd.offset, nd.index);
-                    col_used[payload] = 1;
-                } else {
-                    throw OvmFail(801, "challenge variables not supported");
+                    const uint32_t c = cm.pre_col(nd.offset, nd.index);
+                    col_used[c] = 1;
+                    return {K_COL, c, -1};
                 }
-                break;
-            case N_IS_FIRST: kind = K_COL; payload = 0; col_used[0] = 1; break;
-            case N_IS_TRANSITION: kind = K_COL; payload = 1; col_used[1] = 1; break;
-            case N_IS_LAST: kind = K_COL; payload = 2; col_used[2] = 1; break;
-            case N_CONST: kind = K_CONST; payload = nd.constant.v; break;
-            default:
-                if (slot_of[node] < 0) throw OvmFail(1, "program compiler: value not live");
-                kind = K_SLOT;
-                payload = (uint32_t)slot_of[node];
+                throw OvmFail(801, "challenge variables not supported");
+            case N_IS_FIRST: col_used[0] = 1; return {K_COL, 0, -1};
+            case N_IS_TRANSITION: col_used[1] = 1; return {K_COL, 1, -1};
+            case N_IS_LAST: col_used[2] = 1; return {K_COL, 2, -1};
+            case N_CONST: return {K_CONST, nd.constant.v, -1};
+            default: throw OvmFail(1, "program compiler: not a leaf");
         }
     };
-    size_t next_root = 0;
-    for (size_t i = lo; i < n; i++) {
-        if (need[i] && air.nodes[i].kind >= N_ADD) {
-            const Node &nd = air.nodes[i];
+    auto take_slot = [&]() {
+        uint32_t s;
+        if (!free_slots.empty()) {
+            s = free_slots.back();
+            free_slots.pop_back();
+        } else {
+            s = prog.num_slots++;
+        }
+        if (s > 0xFFFF) throw OvmFail(801, "program needs too many slots");
+        return s;
+    };
+    // one read of an operand by an instruction or a root firing is over: recycle its slot when nothing else will read it
+    auto consumed = [&](const Operand &o) {
+        if (o.node < 0) return;
+        if (remat((uint32_t)o.node)) {
+            free_slots.push_back(o.payload);
+        } else if (--uses[o.node] == 0) {
+            free_slots.push_back((uint32_t)slot_of[o.node]);
+            slot_of[o.node] = -2;
+        }
+    };
+    // value of `node` as an operand, emitting whatever it takes (explicit stack: an expression can be thousands deep)
+    struct Frame {
+        uint32_t node;
+        uint8_t state;  // 0: nothing done, 1: first operand done, 2: both done
+        bool right_first;
+        Operand first, second;
+    };
+    std::vector<Frame> stack;
+    auto value_of = [&](uint32_t root_node) -> Operand {
+        if (!is_op(root_node)) return leaf_operand(root_node);
+        if (!remat(root_node) && slot_of[root_node] >= 0) return {K_SLOT, (uint32_t)slot_of[root_node], (int32_t)root_node};
+        Operand result{};
+        stack.clear();
+        stack.push_back({root_node, 0, false, {}, {}});
+        while (!stack.empty()) {
+            Frame &f = stack.back();
+            const Node &nd = air.nodes[f.node];
+            const bool bin = binary(f.node);
+            if (f.state == 0) f.right_first = bin && regs[nd.right] > regs[nd.left];
+            if (f.state < (bin ? 2 : 1)) {
+                const uint32_t child = (f.state == 0) == f.right_first && bin ? nd.right : nd.left;
+                Operand *into = f.state == 0 ? &f.first : &f.second;
+                f.state++;
+                if (!is_op(child)) {
+                    *into = leaf_operand(child);
+                } else if (!remat(child) && slot_of[child] >= 0) {
+                    *into = {K_SLOT, (uint32_t)slot_of[child], (int32_t)child};
+                } else if (!remat(child) && slot_of[child] == -2) {
+                    throw OvmFail(1, "program compiler: value not live");
+                } else {
+                    stack.push_back({child, 0, false, {}, {}});  // (invalidates f: the loop re-reads stack.back())
+                }
+                continue;
+            }
+            const Operand &l = bin && f.right_first ? f.second : f.first;
+            const Operand &r = bin && f.right_first ? f.first : f.second;
             Instr in{};
             in.op = nd.kind == N_ADD ? OP_ADD : nd.kind == N_SUB ? OP_SUB : nd.kind == N_MUL ? OP_MUL : OP_NEG;
-            operand(nd.left, in.ak, in.a);
-            if (nd.kind != N_NEG) operand(nd.right, in.bk, in.b);
-            uint32_t s;
-            if (!free_slots.empty()) {
-                s = free_slots.back();
-                free_slots.pop_back();
-            } else {
-                s = prog.num_slots++;
-            }
-            if (s > 0xFFFF) throw OvmFail(801, "program needs too many slots");
-            slot_of[i] = (int32_t)s;
+            in.ak = l.kind, in.a = l.payload;
+            if (bin) in.bk = r.kind, in.b = r.payload;
+            const uint32_t s = take_slot();  // (before the operands' slots are recycled: dst never aliases an operand)
             in.dst = (uint16_t)s;
             prog.code.push_back(in);
+            consumed(l);
+            if (bin) consumed(r);
+            const uint32_t me = f.node;
+            if (remat(me)) {
+                if (stats && slot_of[me] == -3) stats->recomputed++;
+                slot_of[me] = -3;  // (only marks "was computed before" for the statistics)
+            } else {
+                slot_of[me] = (int32_t)s;
+            }
+            const Operand mine{K_SLOT, s, (int32_t)me};
+            stack.pop_back();
+            if (stack.empty()) {
+                result = mine;
+            } else {
+                Frame &p = stack.back();
+                (p.state == 1 ? p.first : p.second) = mine;
+            }
         }
-        while (next_root < roots.size() && fire[next_root] == i) {
-            const Root &r = roots[next_root];
-            Instr in{};
-            in.op = r.op;
-            in.acc = r.acc;
-            operand(r.node, in.ak, in.a);
-            in.b = r.weight;
-            prog.code.push_back(in);
-            next_root++;
-        }
-        for (int32_t node = release_head[i]; node >= 0; node = release_next[node]) {
-            free_slots.push_back((uint32_t)slot_of[node]);
-            slot_of[node] = -2;
-        }
+        return result;
+    };
+    for (const Root &r : roots) {
+        const Operand o = value_of(r.node);
+        Instr in{};
+        in.op = r.op;
+        in.acc = r.acc;
+        in.ak = o.kind, in.a = o.payload;
+        in.b = r.weight;
+        prog.code.push_back(in);
+        consumed(o);
     }
-    if (next_root != roots.size()) throw OvmFail(1, "program compiler: roots left over");
     for (size_t c = 0; c < cm.total; c++)
         if (col_used[c]) prog.used_cols.push_back((uint32_t)c);
     if (prog.num_slots == 0) prog.num_slots = 1;
+    if (stats) stats->remat_limit = remat_limit;
     return prog;
+}
+
+// The program with the smallest recomputation limit that fits `max_slots` (the plain interpreter holds up to 512 slots
+// in private memory, the staged VM ~50 rows of LDS). Limits 1, 2, 4, ...: in the end every shared subexpression is
+// recomputed at each use and the slot count is the register need of one expression tree.
+static constexpr uint32_t PROGRAM_SLOT_TARGET = 40;
+inline Program compile_program(const AirKey &air, const ColumnMap &cm, const std::vector<Fp> &public_values,
+                               const std::vector<Root> &roots, uint32_t num_weights, uint32_t max_slots = PROGRAM_SLOT_TARGET,
+                               CompileStats *stats = nullptr) {
+    Program best = compile_program_with(air, cm, public_values, roots, num_weights, 0, stats);
+    // (a program that fits the target recomputes nothing; otherwise trade instructions for slots while that at most doubles
+    // the code, and past the hard limit of the executors at any price)
+    for (uint32_t limit = 1; best.num_slots > max_slots && limit <= (1u << 20); limit *= 2) {  // 1, 2, 4, ...
+        CompileStats st;
+        Program p = compile_program_with(air, cm, public_values, roots, num_weights, limit, &st);
+        const bool must = best.num_slots > 512;
+        if (p.num_slots < best.num_slots && (must || p.code.size() <= 2 * best.code.size())) {
+            best = std::move(p);
+            if (stats) *stats = st;
+        } else if (!must && p.code.size() > 2 * best.code.size()) {
+            break;
+        }
+    }
+    return best;
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -3263,6 +3263,38 @@ int ovm_hip_staged_selftest(const uint32_t *blob, uint64_t words, uint32_t stage
                 EF want[2] = {EF::zero(), EF::zero()}, got[2] = {EF::zero(), EF::zero()};
                 std::vector<Fp> slots(p.num_slots);
                 run_program_acc<Fp>(p.code.data(), (uint32_t)p.code.size(), w.data(), slots.data(), fetch, want);
+                {   // independent of the compiler: every DAG node in index order, then sum_r W[r] * value(root r)
+                    std::vector<Fp> val(air.nodes.size());
+                    for (size_t i = 0; i < air.nodes.size(); i++) {
+                        const Node &nd = air.nodes[i];
+                        switch (nd.kind) {
+                            case N_VAR:
+                                val[i] = nd.entry == E_PUBLIC ? pv.at(nd.index)
+                                         : nd.entry == E_MAIN ? row[cm.col(nd.part_index, nd.offset, nd.index)]
+                                                              : row[cm.pre_col(nd.offset, nd.index)];
+                                break;
+                            case N_IS_FIRST: val[i] = row[0]; break;
+                            case N_IS_TRANSITION: val[i] = row[1]; break;
+                            case N_IS_LAST: val[i] = row[2]; break;
+                            case N_CONST: val[i] = nd.constant; break;
+                            case N_ADD: val[i] = val[nd.left] + val[nd.right]; break;
+                            case N_SUB: val[i] = val[nd.left] - val[nd.right]; break;
+                            case N_MUL: val[i] = val[nd.left] * val[nd.right]; break;
+                            default: val[i] = -val[nd.left];
+                        }
+                    }
+                    EF naive[2] = {EF::zero(), EF::zero()};
+                    for (auto &r : roots) naive[r.acc] = naive[r.acc] + w[r.weight] * val[r.node];
+                    if (!(naive[0] == want[0]) || !(naive[1] == want[1])) fail(kind == 0 ? "zerocheck (compiled vs DAG)" : "LogUp (compiled vs DAG)");
+                }
+                // the recomputation ladder and the grouped form give the same sums
+                for (uint32_t limit : {1u, 3u, 1000u}) {
+                    const Program q = compile_program_with(air, cm, pv, roots, nw, limit);
+                    EF alt[2] = {EF::zero(), EF::zero()};
+                    std::vector<Fp> sl(q.num_slots);
+                    run_program_acc<Fp>(q.code.data(), (uint32_t)q.code.size(), w.data(), sl.data(), fetch, alt);
+                    if (!(alt[0] == want[0]) || !(alt[1] == want[1])) fail("recomputing");
+                }
                 const StagedProgram sp = stage_program(p, w, layout);
                 n_blocks += sp.blocks.size();
                 staged_host_eval(sp, row, got, [&](uint32_t, Fp, const EF &) { fail("ACC (unexpected LEAF)"); });
@@ -3288,6 +3320,25 @@ int ovm_hip_staged_selftest(const uint32_t *blob, uint64_t words, uint32_t stage
             }
         }
         if (blocks_out) *blocks_out = n_blocks;
+        return 0;
+    }, false);
+}
+
+// Size of the compiled register program of one AIR (kind 0: zerocheck, 1: LogUp round sums, 2: GKR leaves).
+int ovm_hip_program_stats(const uint32_t *blob, uint64_t words, uint32_t air_idx, uint32_t kind, uint32_t *instrs_out,
+                          uint32_t *slots_out, uint32_t *remat_limit_out) {
+    if (!blob || kind > 2) return (int)hipErrorInvalidValue;
+    return guarded([&]() -> int {
+        const ProvingKey pk = parse_pk_blob(blob, words);
+        if (air_idx >= pk.airs.size()) throw OvmFail(1, "program stats: no such AIR");
+        const AirKey &air = pk.airs[air_idx];
+        const std::vector<Fp> pv(air.num_public_values, Fp::zero());
+        const std::vector<Root> roots = kind == 0 ? roots_zerocheck(air) : kind == 1 ? roots_logup(air) : roots_leaves(air);
+        CompileStats st;
+        const Program p = compile_program(air, column_map_of(air), pv, roots, 0, PROGRAM_SLOT_TARGET, &st);
+        if (instrs_out) *instrs_out = (uint32_t)p.code.size();
+        if (slots_out) *slots_out = p.num_slots;
+        if (remat_limit_out) *remat_limit_out = st.remat_limit;
         return 0;
     }, false);
 }

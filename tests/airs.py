@@ -539,3 +539,240 @@ def random_air(rng, width, n_constraints, n_pairs, max_degree=3, use_next=True, 
         a.push_interaction(bus, fields, count)
         a.push_interaction(bus, fields, NEG_ONE() * count)
     return a.finish()
+
+
+# ---- Keccak-f[1600] AIR (BASELINE config B; crates/cpu-backend/benches/keccakf.rs:49-86) ---------------------
+# The reference proves p3-keccak-air 0.4.3's `KeccakAir` (a Plonky3 crate that is NOT in /root/reference and cannot be
+# fetched here). Restated from the published design of that AIR -- one row per round, 24 rows per permutation:
+# theta through the column parities C, C' and the bits of A' (A = A' xor C xor C'), rho/pi as a re-indexing of A' bits,
+# chi on 16-bit limbs, iota through the bits of A''[0][0] -- with its column layout (`KeccakCols`, 2 633 columns) and its
+# constraint list in its `eval` order (3 182 constraints, degree 3). Cross-checks against facts that ARE in the reference:
+# OpenVM's KeccakfPermAir wraps this AIR with one extra column and one extra constraint, and the captured workload shape
+# of that chip is 2 634 columns / 3 183 constraints (tests/golden/reth_block_23992138_shapes.json.gz, derived from
+# benchmarks/synthetic/reth-block-23992138-profile.jsonl). Constraint ORDER only matters for bit-identity against the
+# real crate, which nothing here can check; the trace generator is checked against an independent Keccak-f[1600]
+# (hashlib's SHA3 through the sponge) in tests/test_keccak_air.py.
+KECCAK_ROUNDS = 24
+KECCAK_RC = [0x0000000000000001, 0x0000000000008082, 0x800000000000808A, 0x8000000080008000, 0x000000000000808B,
+             0x0000000080000001, 0x8000000080008081, 0x8000000000008009, 0x000000000000008A, 0x0000000000000088,
+             0x0000000080008009, 0x000000008000000A, 0x000000008000808B, 0x800000000000008B, 0x8000000000008089,
+             0x8000000000008003, 0x8000000000008002, 0x8000000000000080, 0x000000000000800A, 0x800000008000000A,
+             0x8000000080008081, 0x8000000000008080, 0x0000000080000001, 0x8000000080008008]
+KECCAK_R = [[0, 36, 3, 41, 18], [1, 44, 10, 45, 2], [62, 6, 43, 15, 61], [28, 55, 25, 21, 56], [27, 20, 39, 8, 14]]  # r[x][y]
+
+
+class KeccakCols:
+    """Column offsets of `KeccakCols<T>` (repr(C) field order)."""
+    STEP_FLAGS = 0                       # [24]
+    EXPORT = 24
+    PREIMAGE = 25                        # [y][x][limb]  5 x 5 x 4
+    A = PREIMAGE + 100                   # [y][x][limb]
+    C = A + 100                          # [x][z]        5 x 64
+    C_PRIME = C + 320                    # [x][z]
+    A_PRIME = C_PRIME + 320              # [y][x][z]     5 x 5 x 64
+    A_PRIME_PRIME = A_PRIME + 1600       # [y][x][limb]
+    A_PP_00_BITS = A_PRIME_PRIME + 100   # [64]
+    A_PPP_00_LIMBS = A_PP_00_BITS + 64   # [4]
+    WIDTH = A_PPP_00_LIMBS + 4           # 2633
+
+    @staticmethod
+    def b_source(x, y, z):
+        """B[x][y] bit z is A' bit: B[x, y] = ROT(A'[a, b], r[a][b]) with a = (x + 3y) % 5, b = x. -> (y, x, z) of a_prime"""
+        a, b = (x + 3 * y) % 5, x
+        return b, a, (z + 64 - KECCAK_R[a][b]) % 64
+
+
+def keccak_air():
+    K = KeccakCols
+    air = Air("KeccakAir", K.WIDTH)
+    L, N = air.local, air.next
+    TWO = Expr.lift(2)
+
+    def xor(p, q):
+        return p + q - p * (q + q)
+
+    def xor3(p, q, r):
+        return xor(xor(p, q), r)
+
+    def andn(p, q):
+        return (ONE() - p) * q
+
+    def limb_of(bit, limb):
+        acc = Expr.lift(0)
+        for z in reversed(range(16 * limb, 16 * limb + 16)):
+            acc = (acc + acc) + bit(z)
+        return acc
+
+    flag = lambda r: L(K.STEP_FLAGS + r)
+    pre = lambda y, x, l, row=L: row(K.PREIMAGE + (5 * y + x) * 4 + l)
+    a_in = lambda y, x, l, row=L: row(K.A + (5 * y + x) * 4 + l)
+    c = lambda x, z: L(K.C + 64 * x + z)
+    cp = lambda x, z: L(K.C_PRIME + 64 * x + z)
+    ap = lambda y, x, z: L(K.A_PRIME + (5 * y + x) * 64 + z)
+    app = lambda y, x, l: L(K.A_PRIME_PRIME + (5 * y + x) * 4 + l)
+    app00 = lambda z: L(K.A_PP_00_BITS + z)
+    appp = lambda y, x, l: L(K.A_PPP_00_LIMBS + l) if (y, x) == (0, 0) else app(y, x, l)
+    b = lambda x, y, z: ap(*K.b_source(x, y, z))
+
+    # round flags (round_flags.rs): first row starts a permutation, the flags rotate
+    air.assert_zero(flag(0) - ONE(), when=IS_FIRST())
+    for r in range(1, KECCAK_ROUNDS):
+        air.assert_zero(flag(r), when=IS_FIRST())
+    for r in range(KECCAK_ROUNDS):
+        air.assert_zero(flag(r) - N(K.STEP_FLAGS + (r + 1) % KECCAK_ROUNDS), when=IS_TRANSITION())
+
+    first_step, final_step = flag(0), flag(KECCAK_ROUNDS - 1)
+    not_final = ONE() - final_step
+    # first step: the input A is the preimage
+    for y in range(5):
+        for x in range(5):
+            for l in range(4):
+                air.assert_zero(pre(y, x, l) - a_in(y, x, l), when=first_step)
+    # not the final step: the preimage is carried to the next row
+    for y in range(5):
+        for x in range(5):
+            for l in range(4):
+                air.assert_zero(pre(y, x, l) - pre(y, x, l, N), when=not_final * IS_TRANSITION())
+    air.assert_bool(L(K.EXPORT))
+    air.assert_zero(L(K.EXPORT), when=not_final)
+    # C'[x, z] = xor(C[x, z], C[x - 1, z], C[x + 1, z - 1])
+    for x in range(5):
+        for z in range(64):
+            air.assert_bool(c(x, z))
+        for z in range(64):
+            air.assert_zero(cp(x, z) - xor3(c(x, z), c((x + 4) % 5, z), c((x + 1) % 5, (z + 63) % 64)))
+    # A[x, y, z] = xor(A'[x, y, z], C[x, z], C'[x, z]), checked per 16-bit limb of A
+    for y in range(5):
+        for x in range(5):
+            for z in range(64):
+                air.assert_bool(ap(y, x, z))
+            for l in range(4):
+                air.assert_zero(limb_of(lambda z: xor3(ap(y, x, z), c(x, z), cp(x, z)), l) - a_in(y, x, l))
+    # xor_y A'[x, y, z] = C'[x, z]: diff in {0, 2, 4}
+    for x in range(5):
+        for z in range(64):
+            s = ap(0, x, z)
+            for y in range(1, 5):
+                s = s + ap(y, x, z)
+            diff = s - cp(x, z)
+            air.assert_zero(diff * (diff - TWO) * (diff - Expr.lift(4)))
+    # A''[x, y] = xor(B[x, y], andn(B[x + 1, y], B[x + 2, y]))
+    for y in range(5):
+        for x in range(5):
+            for l in range(4):
+                bit = lambda z: xor(andn(b((x + 1) % 5, y, z), b((x + 2) % 5, y, z)), b(x, y, z))
+                air.assert_zero(limb_of(bit, l) - app(y, x, l))
+    # A'''[0, 0] = A''[0, 0] xor RC
+    for z in range(64):
+        air.assert_bool(app00(z))
+    for l in range(4):
+        air.assert_zero(limb_of(app00, l) - app(0, 0, l))
+
+    def xored_bit(z):
+        rc = Expr.lift(0)
+        for r in range(KECCAK_ROUNDS):
+            rc = rc + flag(r) * Expr.lift((KECCAK_RC[r] >> z) & 1)
+        return xor(rc, app00(z))
+    for l in range(4):
+        air.assert_zero(limb_of(xored_bit, l) - L(K.A_PPP_00_LIMBS + l))
+    # this round's output is the next round's input
+    for x in range(5):
+        for y in range(5):
+            for l in range(4):
+                air.assert_zero(appp(y, x, l) - a_in(y, x, l, N), when=IS_TRANSITION() * not_final)
+    assert len(air.constraints) == 3182
+    return air.finish()
+
+
+def keccak_f1600(lanes):
+    """Plain Keccak-f[1600] on 25 python ints, lane index x + 5y (FIPS 202) -- the trace generator's cross-check."""
+    M = (1 << 64) - 1
+    rot = lambda v, n: ((v << n) | (v >> (64 - n))) & M if n else v
+    a = list(lanes)
+    for rnd in range(KECCAK_ROUNDS):
+        cc = [a[x] ^ a[x + 5] ^ a[x + 10] ^ a[x + 15] ^ a[x + 20] for x in range(5)]
+        d = [cc[(x + 4) % 5] ^ rot(cc[(x + 1) % 5], 1) for x in range(5)]
+        a = [a[i] ^ d[i % 5] for i in range(25)]
+        bb = [0] * 25
+        for x in range(5):
+            for y in range(5):
+                bb[y + 5 * ((2 * x + 3 * y) % 5)] = rot(a[x + 5 * y], KECCAK_R[x][y])
+        a = [bb[x + 5 * y] ^ (~bb[(x + 1) % 5 + 5 * y] & bb[(x + 2) % 5 + 5 * y] & M) for y in range(5) for x in range(5)]
+        a[0] ^= KECCAK_RC[rnd]
+    return a
+
+
+def keccak_inputs(n_perms, seed=42):
+    """Seeded 25-lane inputs as an (n_perms, 25) uint64 array, lane index x + 5y. NOT the reference bench's
+    `StdRng::seed_from_u64(42)` stream (ChaCha12 is not restated; any inputs make a valid trace): splitmix64."""
+    M = 0xFFFFFFFFFFFFFFFF
+    x0 = (seed * 0x9E3779B97F4A7C15 + 1) & M
+    with np.errstate(over="ignore"):
+        x = np.uint64(x0) + np.arange(1, n_perms * 25 + 1, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15)
+        z = (x ^ (x >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        out = z ^ (z >> np.uint64(31))
+    return out.reshape(n_perms, 25)
+
+
+def keccak_trace(inputs, log_rows, device="cpu", mont_one=None):
+    """`generate_trace_rows` for KeccakAir: 24 rows per permutation, zero-input permutations appended (the last one cut
+    off) up to 2^log_rows rows; `export` stays 0. Vectorised over the permutations in torch (runs on the GPU for the
+    2^20-row config): returns the COLUMN-MAJOR trace as a flat int32/int64 tensor of 2633 * 2^log_rows values --
+    canonical, or multiplied by `mont_one` (then Montgomery words) when given -- plus the final states (n_perms, 25)
+    of the real inputs as python ints for cross-checking."""
+    import torch
+    K = KeccakCols
+    h = 1 << log_rows
+    n_real = len(inputs)
+    n_perm = -(-h // KECCAK_ROUNDS)
+    assert n_real <= n_perm
+    lanes = np.zeros((n_perm, 25), dtype=np.uint64)
+    lanes[:n_real] = inputs
+    # bits[p, y, x, z]
+    bits_np = ((lanes.reshape(n_perm, 5, 5, 1) >> np.arange(64, dtype=np.uint64)) & np.uint64(1)).astype(np.uint8)
+    A = torch.from_numpy(bits_np).to(device)
+    rows_total = n_perm * KECCAK_ROUNDS
+    dt = torch.int32
+    trace = torch.zeros((K.WIDTH, n_perm, KECCAK_ROUNDS), dtype=dt, device=device)
+    w16 = (1 << torch.arange(16, dtype=dt, device=device))
+
+    def limbs(bits):   # (..., 64) -> (..., 4)
+        return (bits.to(dt).reshape(*bits.shape[:-1], 4, 16) * w16).sum(-1)
+
+    def put(col0, vals, r):   # vals: (n_perm, k) -> columns col0 .. col0 + k at round r
+        trace[col0:col0 + vals.shape[1], :, r] = vals.t()
+
+    pre_l = limbs(A).reshape(n_perm, 100)
+    zsrc = torch.arange(64, device=device)
+    for r in range(KECCAK_ROUNDS):
+        trace[K.STEP_FLAGS + r, :, r] = 1
+        put(K.PREIMAGE, pre_l, r)
+        put(K.A, limbs(A).reshape(n_perm, 100), r)
+        Cb = A[:, 0] ^ A[:, 1] ^ A[:, 2] ^ A[:, 3] ^ A[:, 4]                         # [p, x, z]
+        Cp = Cb ^ Cb.roll(1, dims=1) ^ Cb.roll(-1, dims=1).roll(1, dims=2)            # C[x-1, z] and C[x+1, z-1]
+        Ap = A ^ (Cb ^ Cp).unsqueeze(1)                                               # A' = A xor D, D = C xor C'
+        put(K.C, Cb.reshape(n_perm, 320), r)
+        put(K.C_PRIME, Cp.reshape(n_perm, 320), r)
+        put(K.A_PRIME, Ap.reshape(n_perm, 1600), r)
+        B = torch.empty_like(Ap)                                                      # B[p, y, x, z]
+        for x in range(5):
+            for y in range(5):
+                sy, sx, _ = K.b_source(x, y, 0)
+                a_, b_ = (x + 3 * y) % 5, x
+                B[:, y, x] = Ap[:, sy, sx].roll(KECCAK_R[a_][b_], dims=1)
+        App = B ^ ((1 - B.roll(-1, dims=2)) & B.roll(-2, dims=2))
+        put(K.A_PRIME_PRIME, limbs(App).reshape(n_perm, 100), r)
+        put(K.A_PP_00_BITS, App[:, 0, 0], r)
+        rc = torch.tensor([(KECCAK_RC[r] >> z) & 1 for z in range(64)], dtype=torch.uint8, device=device)
+        A = App.clone()
+        A[:, 0, 0] = App[:, 0, 0] ^ rc
+        put(K.A_PPP_00_LIMBS, limbs(A[:, 0, 0]), r)
+    final_bits = A[:n_real].to(torch.int64).cpu().numpy().astype(np.uint64)
+    final = [[int(sum(int(b) << z for z, b in enumerate(final_bits[p, i // 5, i % 5]))) for i in range(25)] for p in range(n_real)]
+    src = trace.reshape(K.WIDTH, rows_total)
+    flat = torch.empty((K.WIDTH, h), dtype=dt, device=device)
+    for c0 in range(0, K.WIDTH, 256):   # (column blocks: the Montgomery conversion goes through int64)
+        blk = src[c0:c0 + 256, :h]
+        flat[c0:c0 + 256] = blk if mont_one is None else ((blk.to(torch.int64) * int(mont_one)) % P).to(dt)
+    return flat.reshape(-1), final
