@@ -96,11 +96,17 @@ pub struct OvmShard {
     pub alltoall_device: Option<
         unsafe extern "C" fn(ctx: *mut c_void, d_send: *const c_void, d_recv: *mut c_void, bytes: u64, stream: OvmStream) -> c_int,
     >,
+    /// optional: "this rank failed in the middle of a joint call" (built in: `ovm_hip_shm_comm_abort` / `ovm_hip_ipc_abort`)
+    pub abort: Option<unsafe extern "C" fn(ctx: *mut c_void, code: c_int) -> c_int>,
 }
+pub const OVM_ESHARD_TIMEOUT: c_int = 10006;
+pub const OVM_ESHARD_PEER_ABORTED: c_int = 10007;
+pub const OVM_ESHARD_POISONED: c_int = 10008;
 
 extern "C" {
     pub fn ovm_hip_abi_version() -> u32;
     pub fn ovm_hip_init(device: c_int, cu_count: *mut u32) -> c_int;
+    pub fn ovm_hip_thread_shutdown() -> c_int;
     pub fn ovm_hip_error_name(code: c_int) -> *const c_char;
     pub fn ovm_hip_profile_enable(on: c_int) -> c_int;
     pub fn ovm_hip_profile_report(buf: *mut c_char, cap: u64) -> u64;
@@ -337,6 +343,10 @@ extern "C" {
         all: *mut c_void,
         bytes: u64,
     ) -> c_int;
+    pub fn ovm_hip_shm_comm_abort(comm: *mut c_void, code: c_int) -> c_int;
+    pub fn ovm_hip_shm_comm_poisoned(comm: *const OvmShmComm) -> c_int;
+    pub fn ovm_hip_shard_last_error() -> *const c_char;
+    pub fn ovm_hip_ipc_abort(comm: *mut c_void, code: c_int) -> c_int;
     pub fn ovm_hip_gkr_shard_selftest(
         world: u32,
         tr: u32,

@@ -54,6 +54,12 @@ unsafe extern "C" fn host_trampoline(ctx: *mut c_void, mine: *const c_void, all:
     let comm = &*(ctx as *const ShardComm);
     ffi::ovm_hip_shm_allgather(comm.shm as *mut c_void, mine, all, bytes)
 }
+/// `ovm_shard_t.abort`: this rank failed in the middle of a joint call; the peers stop waiting and every rank's
+/// communicator is poisoned (see `ShardComm::poisoned`).
+unsafe extern "C" fn abort_trampoline(ctx: *mut c_void, code: c_int) -> c_int {
+    let comm = &*(ctx as *const ShardComm);
+    ffi::ovm_hip_shm_comm_abort(comm.shm as *mut c_void, code)
+}
 unsafe extern "C" fn device_trampoline(
     ctx: *mut c_void,
     d_mine: *const c_void,
@@ -140,7 +146,14 @@ impl ShardComm {
             allgather_host: Some(host_trampoline),
             allgather_device: Some(device_trampoline),
             alltoall_device: if self.bulk.has_alltoall() { Some(alltoall_trampoline) } else { None },
+            abort: Some(abort_trampoline),
         }
+    }
+    /// A joint call over this communicator timed out or was aborted by a peer: the ranks' sequence numbers no longer
+    /// agree; drop it and create a new one (every later call fails with `OVM_ESHARD_POISONED`).
+    pub fn poisoned(&self) -> bool {
+        // SAFETY: `shm` is valid for the life of `self`.
+        unsafe { ffi::ovm_hip_shm_comm_poisoned(self.shm) != 0 }
     }
 }
 impl Drop for ShardComm {

@@ -49,7 +49,12 @@ uint32_t ovm_hip_abi_version(void);
  * (reference: crates/cuda-backend/src/cuda/ntt.rs:12-22, batch_ntt_small.rs:49) and
  * `_cuda_get_sm_count` (device_info.rs:4): *cu_count receives the number of compute units. */
 int ovm_hip_init(int device, uint32_t *cu_count);
-/* Name of a non-zero return code (hipGetErrorName). */
+/* Releases the calling thread's device resources NOW -- result mailboxes, the pinned upload arena, the proof-of-work
+ * scratch word, the free segments of its memory pools -- instead of at thread exit; for hosts that tear the HIP
+ * runtime down themselves or recycle worker threads. They are created again on demand. (At process exit the
+ * library's thread-exit destructors leave device memory alone rather than call into a runtime that is going away.) */
+int ovm_hip_thread_shutdown(void);
+/* Name of a non-zero return code (hipGetErrorName; OVM_ESHARD_* for the exchange's own codes). */
 const char *ovm_hip_error_name(int code);
 
 /* Per-stage timing with HIP events on the launching stream (reference: the `tracing` spans /
@@ -374,14 +379,30 @@ int ovm_hip_prove(const ovm_pk_t *pk, uint32_t n_traces, const ovm_trace_t *trac
  * The device exchanges are supplied by the host language on top of RCCL over xGMI (torch.distributed in
  * this repository's Python host, an rccl binding in Rust); each must be ordered after the work already
  * enqueued on `stream` and complete, from the point of view of later work on `stream`, when it returns.
- * All return 0 or a hipError_t value. */
+ *   abort            OPTIONAL (may be null): called by a rank whose part of a joint call FAILED after the ranks had
+ *                    started working (an exception, out of memory, a failing kernel): "I will not make my remaining
+ *                    contributions". The built-in exchange raises a flag in the shared segment: peers waiting in (or
+ *                    entering) allgather_host return OVM_ESHARD_PEER_ABORTED at once instead of spinning until the
+ *                    time-out, and the communicator is POISONED on every rank (later calls return
+ *                    OVM_ESHARD_POISONED): after an aborted call the ranks' sequence numbers differ, and reusing the
+ *                    communicator could pair a fresh contribution with a stale one. The host destroys and recreates it.
+ *                    Input validation is NOT such a failure: ovm_hip_prove_sharded exchanges every rank's validation
+ *                    result before any work, all ranks refuse together, and the communicator stays usable.
+ * All return 0 or a hipError_t value (or one of the OVM_ESHARD_* codes below). */
 typedef struct ovm_shard {
     uint32_t rank, world;
     void *ctx;
     int (*allgather_host)(void *ctx, const void *mine, void *all, uint64_t bytes);
     int (*allgather_device)(void *ctx, const void *d_mine, void *d_all, uint64_t bytes, ovm_stream_t stream);
     int (*alltoall_device)(void *ctx, const void *d_send, void *d_recv, uint64_t bytes, ovm_stream_t stream);
+    int (*abort)(void *ctx, int code);
 } ovm_shard_t;
+/* Return codes of the built-in exchange that are not hipError_t values. */
+#define OVM_ESHARD_TIMEOUT 10006      /* a peer did not contribute within OVM_SHARD_TIMEOUT_S seconds (default 30) */
+#define OVM_ESHARD_PEER_ABORTED 10007 /* a peer called abort() */
+#define OVM_ESHARD_POISONED 10008     /* this communicator saw one of the two above earlier */
+/* Message of the calling thread's last exchange failure: which rank was waited for / which rank aborted. */
+const char *ovm_hip_shard_last_error(void);
 
 /* Built-in small exchange for the ranks of one node: a POSIX shared-memory segment `name` (a unique
  * name per job, e.g. "/ovm-<port>-<pid>"; every rank passes the same one) with two slots of
@@ -397,13 +418,16 @@ uint64_t ovm_hip_shm_segment_bytes(uint32_t world, uint64_t slot_bytes);
 int ovm_hip_shm_comm_attach(void *base, uint32_t rank, uint32_t world, uint64_t slot_bytes, ovm_shm_comm_t **out);
 void ovm_hip_shm_comm_destroy(ovm_shm_comm_t *comm);
 int ovm_hip_shm_allgather(void *comm, const void *mine, void *all, uint64_t bytes);
+/* ovm_shard_t.abort for the built-in exchange (ctx = the communicator), and whether this rank's handle is poisoned. */
+int ovm_hip_shm_comm_abort(void *comm, int code);
+int ovm_hip_shm_comm_poisoned(const ovm_shm_comm_t *comm);
 
 /* Built-in BULK exchange for the ranks of one node, no collective library: every rank publishes an IPC handle of
  * the allocation its send buffer lives in, the peers map it (once; the mappings are kept) and pull their part with
  * device-to-device copies on their own stream -- over xGMI between GPUs, or between processes that share a GPU. The
  * handles and the barriers travel through `shm` (which must outlive the communicator). Use: ovm_shard_t.ctx = the
  * ipc communicator, .allgather_host = ovm_hip_ipc_allgather_host (forwards to shm), .allgather_device =
- * ovm_hip_ipc_allgather_device, .alltoall_device = ovm_hip_ipc_alltoall_device. Send buffers must be device
+ * ovm_hip_ipc_allgather_device, .alltoall_device = ovm_hip_ipc_alltoall_device, .abort = ovm_hip_ipc_abort. Send buffers must be device
  * allocations of this process (hipMalloc, directly or through a pool). */
 typedef struct ovm_ipc_comm ovm_ipc_comm_t;
 int ovm_hip_ipc_comm_create(ovm_shm_comm_t *shm, uint32_t rank, uint32_t world, ovm_ipc_comm_t **out);
@@ -411,6 +435,7 @@ void ovm_hip_ipc_comm_destroy(ovm_ipc_comm_t *comm);
 int ovm_hip_ipc_allgather_host(void *comm, const void *mine, void *all, uint64_t bytes);
 int ovm_hip_ipc_allgather_device(void *comm, const void *d_mine, void *d_all, uint64_t bytes, ovm_stream_t stream);
 int ovm_hip_ipc_alltoall_device(void *comm, const void *d_send, void *d_recv, uint64_t bytes, ovm_stream_t stream);
+int ovm_hip_ipc_abort(void *comm, int code);
 
 /* Host-only self-test of the sharded LogUp-GKR bookkeeping (csrc/gkr_shard.h): `world` simulated ranks
  * (threads over the shared-memory exchange) own the leaf runs [0, ends[0]), [ends[0], ends[1]), ... of a
@@ -438,7 +463,10 @@ int ovm_hip_shard_exchange_selftest(const ovm_shard_t *shard, uint64_t n, uint32
  * mu-batch) on the owner; the Merkle trees of the common-main commitment and of the WHIR rounds are
  * built by all ranks together; the WHIR folds and the transcript are replicated on every rank.
  * The proof (identical to ovm_hip_prove's on one device, byte for byte) is written on rank 0 only;
- * other ranks return 0 with *proof_len = 0. */
+ * other ranks return 0 with *proof_len = 0. `sponge` (optional) is advanced on EVERY rank (the transcript is
+ * replicated, the final states are identical). Failures: a rank whose inputs are invalid makes ALL ranks return its
+ * code before any work (communicator still usable); a rank that fails later calls shard->abort (if set), the others
+ * return OVM_ESHARD_PEER_ABORTED and the communicator is poisoned. On any failure the caller's sponge is untouched. */
 int ovm_hip_prove_sharded(const ovm_pk_t *pk, const ovm_shard_t *shard, uint32_t n_traces, const ovm_trace_t *traces,
                           const uint32_t *owner, ovm_sponge_t *sponge, uint8_t *proof_out, uint64_t proof_cap,
                           uint64_t *proof_len, uint64_t *section_offsets5, ovm_stream_t stream);

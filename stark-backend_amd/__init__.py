@@ -76,6 +76,7 @@ _u32p = POINTER(c_uint32)
 _u64p = POINTER(c_uint64)
 SIGNATURES = {
     "ovm_hip_abi_version": (c_uint32, []),
+    "ovm_hip_thread_shutdown": (c_int, []),
     "ovm_hip_init": (c_int, [c_int, _u32p]),
     "ovm_hip_error_name": (c_char_p, [c_int]),
     "ovm_hip_profile_enable": (c_int, [c_int]),
@@ -121,6 +122,7 @@ SIGNATURES = {
     "ovm_hip_ipc_allgather_host": (c_int, [c_void_p, c_void_p, c_void_p, c_uint64]),
     "ovm_hip_ipc_allgather_device": (c_int, [c_void_p, c_void_p, c_void_p, c_uint64, c_void_p]),
     "ovm_hip_ipc_alltoall_device": (c_int, [c_void_p, c_void_p, c_void_p, c_uint64, c_void_p]),
+    "ovm_hip_ipc_abort": (c_int, [c_void_p, c_int]),
     "ovm_hip_pool_stats": (c_int, [_u64p]),
     "ovm_hip_pool_selftest": (c_int, [c_uint64, c_uint32]),
     "ovm_hip_constraint_eval_buffer_size": (c_uint64, [c_void_p, c_uint32]),
@@ -140,6 +142,9 @@ SIGNATURES = {
     "ovm_hip_shm_comm_attach": (c_int, [c_void_p, c_uint32, c_uint32, c_uint64, POINTER(c_void_p)]),
     "ovm_hip_shm_comm_destroy": (None, [c_void_p]),
     "ovm_hip_shm_allgather": (c_int, [c_void_p, c_void_p, c_void_p, c_uint64]),
+    "ovm_hip_shm_comm_abort": (c_int, [c_void_p, c_int]),
+    "ovm_hip_shm_comm_poisoned": (c_int, [c_void_p]),
+    "ovm_hip_shard_last_error": (ctypes.c_char_p, []),
     "ovm_hip_gkr_shard_selftest": (c_int, [c_uint32, c_uint32, _u64p, c_uint64, c_int]),
     "ovm_hip_selftest_error": (c_char_p, []),
     "ovm_hip_shard_exchange_selftest": (c_int, [c_void_p, c_uint64, c_uint32, c_uint64]),
@@ -446,7 +451,7 @@ class ShardStruct(Structure):
     """``ovm_shard_t``."""
 
     _fields_ = [("rank", c_uint32), ("world", c_uint32), ("ctx", c_void_p), ("allgather_host", c_void_p),
-                ("allgather_device", c_void_p), ("alltoall_device", c_void_p)]
+                ("allgather_device", c_void_p), ("alltoall_device", c_void_p), ("abort", c_void_p)]
 
 
 _AG_DEVICE = ctypes.CFUNCTYPE(c_int, c_void_p, c_void_p, c_void_p, c_uint64, c_void_p)
@@ -497,10 +502,12 @@ class Shard:
         if self.bulk == "ipc" and not self.host_buffers:  # no Python in the data path at all
             self.abi = ShardStruct(self.rank, self.world, self.ipc, ctypes.cast(lib.ovm_hip_ipc_allgather_host, c_void_p),
                                    ctypes.cast(lib.ovm_hip_ipc_allgather_device, c_void_p),
-                                   ctypes.cast(lib.ovm_hip_ipc_alltoall_device, c_void_p) if self._alltoall else None)
+                                   ctypes.cast(lib.ovm_hip_ipc_alltoall_device, c_void_p) if self._alltoall else None,
+                                   ctypes.cast(lib.ovm_hip_ipc_abort, c_void_p))
         else:
             self.abi = ShardStruct(self.rank, self.world, self.comm, ctypes.cast(lib.ovm_hip_shm_allgather, c_void_p),
-                                   ctypes.cast(self._cb, c_void_p), ctypes.cast(self._cb_a2a, c_void_p) if self._alltoall else None)
+                                   ctypes.cast(self._cb, c_void_p), ctypes.cast(self._cb_a2a, c_void_p) if self._alltoall else None,
+                                   ctypes.cast(lib.ovm_hip_shm_comm_abort, c_void_p))
 
     def _alltoall_device(self, ctx, d_send, d_recv, nbytes, stream):
         """d_recv[s * nbytes ..] = rank s's d_send[rank * nbytes ..] (``nbytes`` per PAIR of ranks)."""
@@ -672,6 +679,11 @@ class Shard:
                 self.check_bulk(stream)
             return False
         return True
+
+    @property
+    def poisoned(self) -> bool:
+        """A joint call over this communicator timed out or was aborted by a peer: it must be closed and recreated."""
+        return bool(self.comm) and bool(_lib().ovm_hip_shm_comm_poisoned(self.comm))
 
     def close(self):
         if self.ipc:

@@ -55,15 +55,37 @@ struct PoolRegistry {
 // (ovm_hip_pool_selftest).
 struct PoolDriver {
     int (*alloc)(void **p, size_t bytes);
-    void (*release)(void *p);
-    void (*sync)();
+    void (*release)(int device, void *p);
+    void (*sync)(int device);
+    int device = 0;  // the device the pool's memory lives on (a block may come back on a thread whose current device is another)
+    // the calling thread's current device for the duration of a call on `device`
+    struct OnDevice {
+        int saved = -1;
+        explicit OnDevice(int device) {
+            int cur = 0;
+            if (hipGetDevice(&cur) == hipSuccess && cur != device && hipSetDevice(device) == hipSuccess) saved = cur;
+        }
+        ~OnDevice() {
+            if (saved >= 0) (void)hipSetDevice(saved);
+        }
+    };
     static PoolDriver hip() {
-        return PoolDriver{[](void **p, size_t bytes) {
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        return PoolDriver{[](void **p, size_t bytes) {  // (new segments are only ever taken by the owning thread, on its device)
                               const hipError_t e = hipMalloc(p, bytes);
                               if (e != hipSuccess) (void)hipGetLastError();
                               return (int)e;
                           },
-                          [](void *p) { (void)hipFree(p); }, []() { (void)hipDeviceSynchronize(); }};
+                          [](int device, void *p) {
+                              OnDevice g(device);
+                              (void)hipFree(p);
+                          },
+                          [](int device) {
+                              OnDevice g(device);
+                              (void)hipDeviceSynchronize();
+                          },
+                          dev};
     }
 };
 
@@ -130,7 +152,7 @@ class BlockPool {
             reg.owner.erase(it);
         }
         // another thread's block: its stream knows nothing of what this thread's work did with the memory
-        if (pool != caller) pool->drv_.sync();
+        if (pool != caller) pool->drv_.sync(pool->drv_.device);
         if (pool->give_back(p)) delete pool;
     }
 
@@ -160,15 +182,14 @@ class BlockPool {
     // (returns true when the caller should delete the pool)
     bool orphan() {
         std::vector<void *> victims;
-        bool empty;
         {
             std::lock_guard<std::mutex> lk(mu_);
             orphaned_ = true;
+            busy_++;
             collect_free_segments(victims, 0);
-            empty = live_.empty();
         }
         release(victims);
-        return empty;
+        return leave();
     }
 
   private:
@@ -193,6 +214,14 @@ class BlockPool {
     std::unordered_map<void *, Block *> live_;
     size_t cached_ = 0, limit_ = 0;
     bool orphaned_ = false;
+    // Calls that may still touch the pool after dropping mu_ (they release victims to the driver). Whether an orphaned,
+    // empty pool may be deleted is decided by the LAST of them on its way out -- a give_back that saw "empty" while
+    // another thread was still inside release() used to delete the pool under it.
+    unsigned busy_ = 0;
+    bool leave() {
+        std::lock_guard<std::mutex> lk(mu_);
+        return --busy_ == 0 && orphaned_ && live_.empty();
+    }
 
     static size_t round_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
     void insert_free(Block *b) {  // (mu_ held)
@@ -236,11 +265,11 @@ class BlockPool {
     bool give_back(void *p) {
         std::vector<void *> victims;
         size_t size = 0;
-        bool dead = false;
         {
             std::lock_guard<std::mutex> lk(mu_);
             auto it = live_.find(p);
             if (it == live_.end()) return false;
+            busy_++;
             Block *b = it->second;
             live_.erase(it);
             size = b->size;
@@ -267,7 +296,6 @@ class BlockPool {
                 collect_free_segments(victims, 0);
             else if (limit_ && cached_ > limit_)
                 collect_free_segments(victims, limit_);
-            dead = orphaned_ && live_.empty();
         }
         {
             PoolRegistry &reg = PoolRegistry::get();
@@ -275,7 +303,7 @@ class BlockPool {
             reg.live_bytes -= size;
         }
         release(victims);
-        return dead;
+        return leave();
     }
 
     // (mu_ held) take fully free segments out of the pool, largest first, until at most `keep` free bytes remain
@@ -302,8 +330,8 @@ class BlockPool {
             for (size_t s : seg_sizes_) total += s;
             seg_sizes_.clear();
         }
-        drv_.sync();
-        for (void *v : victims) drv_.release(v);
+        drv_.sync(drv_.device);
+        for (void *v : victims) drv_.release(drv_.device, v);
         victims.clear();
         PoolRegistry &reg = PoolRegistry::get();
         std::lock_guard<std::mutex> lk(reg.mu);

@@ -21,6 +21,17 @@
 // their stream -- a 36-AIR proof made ~700 separate copies of a few hundred bytes each, ~15 us of stream time apiece.
 namespace ovm {
 void flush_uploads(hipStream_t stream);
+// Per-thread device resources (result mailboxes, the pinned upload arena, the grind result word, the memory pools)
+// are released by the thread's exit -- or at once by ovm_hip_thread_shutdown(). Their destructors must not call into
+// a HIP runtime that is already being torn down: runtime_exiting() turns true in an atexit handler registered on
+// first use of the library (i.e. after the runtime's own, so it runs before them), and the destructors then leave the
+// memory to the dying process.
+bool runtime_exiting();
+struct ThreadResource {  // a TLS object with device memory: release() frees it now (idempotent)
+    ThreadResource();
+    virtual ~ThreadResource();
+    virtual void release() = 0;
+};
 }
 #define OVM_LAUNCH(kernel, grid, block, shmem, stream, ...)                        \
     do {                                                                           \

@@ -17,15 +17,20 @@
 #include "openvm_hip.h"
 
 extern "C" int ovm_hip_shm_allgather(void *comm, const void *mine, void *all, uint64_t bytes);
+extern "C" int ovm_hip_shm_comm_abort(void *comm, int code);
 
 struct ovm_ipc_comm {
     ovm_shm_comm_t *shm = nullptr;
     uint32_t rank = 0, world = 1;
-    // mappings of peers' allocations, by handle bytes, with the exchange that used them last: a mapping nobody has
-    // used for STALE_AFTER exchanges is closed (its owner may have returned the segment to the driver long ago)
+    // mappings of peers' allocations, by (owner rank, handle bytes), with the owner's BUFFER ID of the allocation and the
+    // exchange that used them last. The buffer id is unique per allocation for the life of the owner's process: if the
+    // owner returned a segment to the driver and a later allocation came back with the same handle bytes, the id
+    // differs and the stale mapping is closed and replaced instead of being pulled through. A mapping nobody
+    // has used for STALE_AFTER exchanges is closed as well (its owner may have freed the segment long ago).
     struct Mapping {
         void *p;
         uint64_t last_used;
+        uint64_t buffer_id;
     };
     std::map<std::string, Mapping> opened;
     uint64_t exchanges = 0;
@@ -35,6 +40,7 @@ struct ovm_ipc_comm {
         hipIpcMemHandle_t handle;
         uint64_t offset;
         uint64_t bytes;  // of the sender's whole buffer (checked against what the receiver expects)
+        uint64_t buffer_id;  // HIP_POINTER_ATTRIBUTE_BUFFER_ID of the allocation (0 = not available)
         int32_t status;
         int32_t pad;
     };
@@ -54,6 +60,9 @@ struct ovm_ipc_comm {
             // (asked for every time: a segment that went back to the driver may have a successor at the same address)
             e = hipIpcGetMemHandle(&m.handle, base);
             m.offset = (uint64_t)((const uint8_t *)d_send - (const uint8_t *)base);
+            unsigned long long id = 0;
+            if (hipPointerGetAttribute(&id, HIP_POINTER_ATTRIBUTE_BUFFER_ID, (hipDeviceptr_t)base) == hipSuccess) m.buffer_id = id;
+            else (void)hipGetLastError();
         }
         if (e != hipSuccess) (void)hipGetLastError();
         m.status = (int32_t)e;
@@ -72,8 +81,14 @@ struct ovm_ipc_comm {
                 src[r] = (const uint8_t *)d_send;
                 continue;
             }
-            const std::string key((const char *)&all[r].handle, sizeof(hipIpcMemHandle_t));
+            std::string key((const char *)&all[r].handle, sizeof(hipIpcMemHandle_t));
+            key.append((const char *)&r, sizeof r);
             auto it = opened.find(key);
+            if (it != opened.end() && it->second.buffer_id != all[r].buffer_id) {  // same handle bytes, another allocation
+                (void)hipIpcCloseMemHandle(it->second.p);
+                opened.erase(it);
+                it = opened.end();
+            }
             if (it == opened.end()) {
                 void *p = nullptr;
                 const hipError_t oe = hipIpcOpenMemHandle(&p, all[r].handle, hipIpcMemLazyEnablePeerAccess);
@@ -82,7 +97,7 @@ struct ovm_ipc_comm {
                     first_error = first_error ? first_error : (int)oe;
                     continue;
                 }
-                it = opened.emplace(key, Mapping{p, exchanges}).first;
+                it = opened.emplace(key, Mapping{p, exchanges, all[r].buffer_id}).first;
             }
             it->second.last_used = exchanges;
             src[r] = (const uint8_t *)it->second.p + all[r].offset;
@@ -160,6 +175,11 @@ void ovm_hip_ipc_comm_destroy(ovm_ipc_comm_t *c) {
 int ovm_hip_ipc_allgather_host(void *ctx, const void *mine, void *all, uint64_t bytes) {
     if (!ctx) return (int)hipErrorInvalidValue;
     return ovm_hip_shm_allgather(static_cast<ovm_ipc_comm *>(ctx)->shm, mine, all, bytes);
+}
+
+int ovm_hip_ipc_abort(void *ctx, int code) {
+    if (!ctx) return (int)hipErrorInvalidValue;
+    return ovm_hip_shm_comm_abort(static_cast<ovm_ipc_comm *>(ctx)->shm, code);
 }
 
 int ovm_hip_ipc_allgather_device(void *ctx, const void *d_mine, void *d_all, uint64_t bytes, ovm_stream_t stream) {

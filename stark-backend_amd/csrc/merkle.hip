@@ -324,11 +324,14 @@ int ovm_hip_sponge_grind(const ovm_sponge_t *sponge, uint32_t bits, uint32_t *wi
     if (s.absorb_idx >= 8 || s.sample_idx > 8) return (int)hipErrorInvalidValue;
     OVM_PROF("grind", stream);
     // one result word per (thread, device), released when the thread exits
-    struct GrindScratch {
+    struct GrindScratch : ovm::ThreadResource {
         uint32_t *p[16] = {};
-        ~GrindScratch() {
-            for (uint32_t *q : p)
-                if (q) (void)hipFree(q);
+        void release() override {
+            for (uint32_t *&q : p)
+                if (q) (void)hipFree(q), q = nullptr;
+        }
+        ~GrindScratch() override {
+            if (!ovm::runtime_exiting()) release();
         }
     };
     static thread_local GrindScratch scratch;

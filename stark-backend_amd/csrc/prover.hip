@@ -47,9 +47,14 @@ inline ProverConfig &prover_config() {
 
 // The calling thread's pool for the current device. Pools are heap objects: one whose thread has exited lives on
 // until the last of its blocks has come back (BlockPool::orphan).
-struct PoolHolder {
+struct PoolHolder : ThreadResource {
     BlockPool *pools[16] = {};
-    ~PoolHolder() {
+    void release() override {  // (ovm_hip_thread_shutdown: what is free goes back to the driver, live blocks stay valid)
+        for (BlockPool *p : pools)
+            if (p) p->trim();
+    }
+    ~PoolHolder() override {
+        if (runtime_exiting()) return;
         for (BlockPool *p : pools)
             if (p && p->orphan()) delete p;
     }
@@ -107,26 +112,31 @@ struct DevBuf {
 // (a D2H/H2D copy from pageable memory takes a slow bounce-buffer path and an upload that
 // synchronises per call costs ~20 us: with tens of AIRs per proof those add up). The arena is
 // rewound whenever the stream is known to be idle past every issued copy (Ctx::sync, Mailbox::wait).
-struct PinnedStage {
+struct PinnedStage : ThreadResource {
     char *p = nullptr;
+    char *dp = nullptr;  // the device's address of the same memory (hipHostGetDevicePointer): what the scatter kernel reads
     size_t bytes = 0, used = 0;
     uint64_t bumps = 0;  // allocations ever made: Mailbox::wait rewinds only if none came after its arm()
-    ~PinnedStage() {
-        if (p) (void)hipHostFree(p);
+    void release() override;
+    ~PinnedStage() override {
+        if (p && !runtime_exiting()) (void)hipHostFree(p);
     }
     void ensure(size_t need) {
         if (need <= bytes) return;
         if (p) (void)hipHostFree(p);
         bytes = std::max<size_t>(need, size_t(16) << 20);
         used = 0;
-        void *q = nullptr;
+        void *q = nullptr, *dq = nullptr;
         // (mapped: the scatter kernel of flush_uploads reads the staged bytes straight from this memory)
-        if (hipHostMalloc(&q, bytes, hipHostMallocMapped) != hipSuccess) {
-            q = nullptr;
+        if (hipHostMalloc(&q, bytes, hipHostMallocMapped) != hipSuccess || hipHostGetDevicePointer(&dq, q, 0) != hipSuccess) {
+            if (q) (void)hipHostFree(q);
+            q = dq = nullptr;
             bytes = 0;
         }
         p = (char *)q;
+        dp = (char *)dq;
     }
+    const void *device_view(const void *host) const { return dp + ((const char *)host - p); }
     // nullptr when the request does not fit any more: the caller synchronises, rewinds and retries
     void *bump(size_t need) {
         need = (need + 63) & ~size_t(63);
@@ -179,6 +189,7 @@ __global__ __launch_bounds__(256) void upload_scatter_kernel(UploadJobsArg a) {
 struct PendingUploads {
     std::vector<UploadJob> jobs;
     hipStream_t stream = nullptr;
+    hipEvent_t done = nullptr;  // recorded behind a flush whose launch goes to ANOTHER stream than the uploads' own
     void add(const void *src, void *dst, size_t bytes, hipStream_t s) {
         if (!jobs.empty() && stream != s) flush();  // (one stream per prover thread: this does not happen)
         stream = s;
@@ -215,9 +226,26 @@ inline void pool_put(void *p) {
     pending_uploads().forget(p);
     BlockPool::put(p, &block_cache());
 }
-void flush_uploads(hipStream_t) {
+// `launch_stream`: the stream of the kernel about to be launched (nullptr = the uploads' own). The scatter kernel runs on
+// the stream the uploads were staged for; a launch on a different stream (a second Device used from the same thread)
+// is ordered behind it through an event -- it used to run with no ordering after the writes of its own arguments
+// (ADVICE r2).
+void flush_uploads(hipStream_t launch_stream) {
     PendingUploads &pu = pending_uploads();
-    if (!pu.jobs.empty()) pu.flush();
+    if (pu.jobs.empty()) return;
+    const hipStream_t own = pu.stream;
+    pu.flush();
+    if (launch_stream != nullptr && launch_stream != own) {
+        if (!pu.done && hipEventCreateWithFlags(&pu.done, hipEventDisableTiming) != hipSuccess) pu.done = nullptr;
+        if (pu.done && hipEventRecord(pu.done, own) == hipSuccess) (void)hipStreamWaitEvent(launch_stream, pu.done, 0);
+        else (void)hipStreamSynchronize(own);
+    }
+}
+inline void PinnedStage::release() {
+    if (!pending_uploads().jobs.empty()) return;  // (staged bytes still to be copied)
+    if (p) (void)hipHostFree(p);
+    p = dp = nullptr;
+    bytes = used = 0;
 }
 inline void PinnedStage::rewind() {
     if (pending_uploads().jobs.empty()) used = 0;  // (staged bytes that are still to be copied stay where they are)
@@ -226,7 +254,7 @@ inline void PinnedStage::rewind() {
 // Host mailbox of the reduction kernels: a host-mapped, coherent page the last workgroup of a
 // reduction writes its results and a sequence flag into; the host spins on the flag instead of
 // issuing a D2H copy and a stream synchronisation per sumcheck round.
-struct Mailbox {
+struct Mailbox : ThreadResource {
     static constexpr size_t SLOTS = 65536;  // extension-field result slots (1 MiB page)
     struct Page {
         uint32_t flag;
@@ -237,9 +265,14 @@ struct Mailbox {
     uint32_t *d_counter = nullptr;
     uint32_t seq = 0;
     uint64_t bumps_at_arm = 0;  // pinned-stage allocations at the time of the last arm()
-    ~Mailbox() {
+    void release() override {
         if (h) (void)hipHostFree(h);
         if (d_counter) (void)hipFree(d_counter);
+        h = d = nullptr;
+        d_counter = nullptr;
+    }
+    ~Mailbox() override {
+        if (!runtime_exiting()) release();
     }
     void init() {
         if (h) return;
@@ -331,7 +364,7 @@ struct Ctx {
             }
             if (stage && bytes <= UPLOAD_DEFER_MAX) {
                 memcpy(stage, v.data(), bytes);
-                pending_uploads().add(stage, b.p, bytes, stream);  // written by the next flush_uploads
+                pending_uploads().add(ps.device_view(stage), b.p, bytes, stream);  // written by the next flush_uploads
             } else if (stage) {
                 memcpy(stage, v.data(), bytes);
                 OVM_THROW_IF(hipMemcpyAsync(b.p, stage, bytes, hipMemcpyHostToDevice, stream));
@@ -2861,6 +2894,10 @@ struct Prover {
 
     void prove(std::vector<TraceIn> in) {
         set_traces(std::move(in));
+        prove_loaded();
+    }
+    // (after set_traces: the sharded entry point lets the ranks agree on their validation results in between)
+    void prove_loaded() {
         ts.observe_digest(pk.vk_pre_hash);
         programs_future = std::async(std::launch::async, [this, tn = tuning()] {
             Tuning::current() = tn;  // (thread-local: the helper works under the caller's settings)
@@ -2875,6 +2912,8 @@ struct Prover {
         } else {
             commit_common_sharded(pcs, common_root);
             exchange_trace_meta();
+            if (tuning().test_fail_rank == (int)sh.rank)  // (tests: a rank that dies in the middle of a joint proof)
+                throw OvmFail((int)hipErrorOutOfMemory, "test hook OVM_TEST_FAIL_RANK: simulated failure after the commitment");
         }
         wt.mark("commit");
         const size_t num_airs = pk.airs.size();
@@ -3052,6 +3091,7 @@ Tuning ovm::Tuning::from_env() {
     t.merkle_coop = !off("OVM_MERKLE_COOP");
     t.finish_inline_max = (uint32_t)std::max(1, num("OVM_FINISH_INLINE_MAX", 64));
     t.trace = getenv("OVM_TRACE") != nullptr;
+    t.test_fail_rank = num("OVM_TEST_FAIL_RANK", -1);
     return t;
 }
 
@@ -3378,29 +3418,58 @@ int ovm_hip_prove_sharded(const ovm_pk_t *pk_, const ovm_shard_t *shard, uint32_
     if (!pk_ || !proof_len || n_traces == 0 || !traces || !shard || !owner || shard->world == 0 || shard->rank >= shard->world)
         return (int)hipErrorInvalidValue;
     const DeviceKey &dk = *reinterpret_cast<const DeviceKey *>(pk_);
-    return guarded([&]() -> int {
+    bool working = false;  // past the unanimous validation: a failure from here on leaves the peers waiting
+    const int rc = guarded([&]() -> int {
         const bool root = shard->rank == 0;
-        std::vector<ShapeIn> sh;
-        for (uint32_t t = 0; t < n_traces; t++) sh.push_back({traces[t].air_idx, (size_t)traces[t].height});
-        const uint64_t need = proof_section_ends(dk.pk, sh)[4];
-        *proof_len = root ? need : 0;
-        // (a refusal must be unanimous or the other ranks would wait for this one: only rank 0's buffer matters,
-        // and a rank-0 buffer that is too small fails here on every rank's own copy of the same test)
-        if (root && (need > proof_cap || !proof_out))
-            throw OvmFail((int)hipErrorInvalidValue, "proof buffer too small: " + std::to_string(need) + " bytes needed");
         Prover pr(dk, (hipStream_t)stream);
         pr.sh = ShardComm(shard);
-        sponge_in(pr, sponge);
-        pr.prove(traces_from_abi(dk.pk, n_traces, traces, true, owner, shard->rank));
+        // Validation: each rank checks what only it can see (rank 0 its proof buffer, an owner its trace pointers, public
+        // values and cached handles), then ONE exchange of the results: either every rank starts working or every rank
+        // refuses with the first failing rank's code -- nobody is left waiting, the communicator stays in step.
+        int32_t mine_rc = 0;
+        std::string mine_msg;
+        uint64_t need = 0;
+        try {
+            std::vector<ShapeIn> sh;
+            for (uint32_t t = 0; t < n_traces; t++) sh.push_back({traces[t].air_idx, (size_t)traces[t].height});
+            need = proof_section_ends(dk.pk, sh)[4];
+            *proof_len = root ? need : 0;
+            if (root && (need > proof_cap || !proof_out))
+                throw OvmFail((int)hipErrorInvalidValue, "proof buffer too small: " + std::to_string(need) + " bytes needed");
+            sponge_in(pr, sponge);
+            pr.set_traces(traces_from_abi(dk.pk, n_traces, traces, true, owner, shard->rank));
+        } catch (const OvmFail &e) {
+            mine_rc = e.code ? e.code : (int)hipErrorUnknown;
+            mine_msg = e.what();
+        }
+        if (!pr.sh.single()) {
+            std::vector<int32_t> all(pr.sh.world);
+            pr.sh.allgather(&mine_rc, all.data(), sizeof(int32_t));
+            for (uint32_t r = 0; r < pr.sh.world; r++)
+                if (all[r] != 0)
+                    throw OvmFail(all[r], r == shard->rank ? mine_msg
+                                                           : "rank " + std::to_string(r) + " rejected its inputs (code " + std::to_string(all[r]) +
+                                                                 "); no rank started working");
+        } else if (mine_rc) {
+            throw OvmFail(mine_rc, mine_msg);
+        }
+        working = true;
+        pr.prove_loaded();
+        // the transcript is replicated: every rank hands its caller the same final sponge state
+        sponge_out(pr, sponge);
         if (root) {
             if (pr.out.buf.size() != need) throw OvmFail((int)hipErrorUnknown, "internal: proof length differs from ovm_hip_proof_size");
             if (section_offsets5)
                 for (size_t i = 0; i < 5 && i < pr.section_offsets.size(); i++) section_offsets5[i] = pr.section_offsets[i];
-            sponge_out(pr, sponge);
             memcpy(proof_out, pr.out.buf.data(), pr.out.buf.size());
         }
         return 0;
     });
+    // This rank failed while the others work on: tell them (they return OVM_ESHARD_PEER_ABORTED instead of waiting for
+    // the time-out) -- unless the failure IS a peer's abort or the exchange's own verdict, which every rank already has.
+    if (rc != 0 && working && shard->world > 1 && shard->abort && rc != OVM_ESHARD_PEER_ABORTED && rc != OVM_ESHARD_POISONED)
+        (void)shard->abort(shard->ctx, rc);
+    return rc;
 }
 
 int ovm_hip_commit(const ovm_pk_t *pk_, uint32_t n_traces, const ovm_trace_t *traces, uint32_t commitment_out[8],

@@ -9,6 +9,8 @@
 
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
+#include <mutex>
 #include <map>
 #include <string>
 #include <vector>
@@ -46,6 +48,31 @@ const Roctx &roctx() {
     return r;
 }
 }  // namespace
+
+namespace {
+std::atomic<bool> g_exiting{false};
+std::once_flag g_exit_once;
+struct ThreadResources {
+    std::vector<ThreadResource *> list;
+};
+ThreadResources &thread_resources() {
+    static thread_local ThreadResources r;
+    return r;
+}
+}  // namespace
+bool runtime_exiting() { return g_exiting.load(std::memory_order_acquire); }
+ThreadResource::ThreadResource() {
+    std::call_once(g_exit_once, [] { atexit([] { g_exiting.store(true, std::memory_order_release); }); });
+    thread_resources().list.push_back(this);
+}
+ThreadResource::~ThreadResource() {
+    auto &l = thread_resources().list;
+    for (size_t i = 0; i < l.size(); i++)
+        if (l[i] == this) {
+            l.erase(l.begin() + i);
+            break;
+        }
+}
 
 ProfScope::ProfScope(const char *label, hipStream_t s) : stream(s) {
     if (roctx().push) {
@@ -105,7 +132,16 @@ uint64_t ovm_hip_profile_report(char *buf, uint64_t cap) {
     return out.size() + 1;
 }
 
-uint32_t ovm_hip_abi_version(void) { return 2; }
+// Releases the calling thread's device resources now (mailboxes, pinned upload arena, grind scratch, free pool
+// segments); the thread may keep using the library afterwards -- they are created again on demand.
+int ovm_hip_thread_shutdown(void) {
+    (void)hipDeviceSynchronize();
+    // (a resource's release() does not unregister it: the objects live until the thread exits)
+    for (ovm::ThreadResource *r : std::vector<ovm::ThreadResource *>(ovm::thread_resources().list)) r->release();
+    return 0;
+}
+
+uint32_t ovm_hip_abi_version(void) { return 3; }  // 3: ovm_shard_t.abort
 
 int ovm_hip_init(int device, uint32_t *cu_count) {
     OVM_CHECK(hipSetDevice(device));
@@ -116,7 +152,14 @@ int ovm_hip_init(int device, uint32_t *cu_count) {
     return 0;
 }
 
-const char *ovm_hip_error_name(int code) { return hipGetErrorName((hipError_t)code); }
+const char *ovm_hip_error_name(int code) {
+    switch (code) {
+        case OVM_ESHARD_TIMEOUT: return "OVM_ESHARD_TIMEOUT";
+        case OVM_ESHARD_PEER_ABORTED: return "OVM_ESHARD_PEER_ABORTED";
+        case OVM_ESHARD_POISONED: return "OVM_ESHARD_POISONED";
+        default: return hipGetErrorName((hipError_t)code);
+    }
+}
 
 int ovm_hip_malloc(void **d_ptr, size_t bytes) {
     if (!d_ptr) return (int)hipErrorInvalidValue;

@@ -354,13 +354,13 @@ PoolDriver host_pool_driver() {
                           g_host_driver_allocs++;
                           return 0;
                       },
-                      [](void *p) {
+                      [](int, void *p) {
                           std::lock_guard<std::mutex> lk(g_host_driver_mu);
                           g_host_driver_bytes -= g_host_driver_sizes[p];
                           g_host_driver_sizes.erase(p);
                           std::free(p);
                       },
-                      []() {}};
+                      [](int) {}, 0};
 }
 }  // namespace
 

@@ -9,6 +9,7 @@
 #include <unistd.h>
 
 #include <chrono>
+#include <cstdio>
 #include <cstdlib>
 #include <stdexcept>
 
@@ -27,7 +28,10 @@ void ShardComm::allgather(const void *mine, void *all, uint64_t bytes) const {
     }
     if (!abi->allgather_host) throw OvmFail(1, "ovm_shard_t: allgather_host is null");
     const int rc = abi->allgather_host(abi->ctx, mine, all, bytes);
-    if (rc != 0) throw OvmFail(rc, "shard exchange: allgather_host failed");
+    if (rc != 0) {
+        const char *why = ovm_hip_shard_last_error();
+        throw OvmFail(rc, std::string("shard exchange: allgather_host failed") + (why && *why ? std::string(": ") + why : std::string()));
+    }
 }
 
 std::vector<std::vector<uint8_t>> ShardComm::allgatherv(const std::vector<uint8_t> &mine) const {
@@ -77,11 +81,45 @@ void ShardComm::alltoall_device(const void *d_send, void *d_recv, uint64_t bytes
 // enters exchange k+2 has completed k+1, which needed every peer's contribution to k+1, which a peer
 // only makes after it finished reading exchange k: so two slots per rank are enough and nobody ever
 // overwrites data that is still being read.
+namespace {
+thread_local std::string g_shard_error;
+}
+extern "C" const char *ovm_hip_shard_last_error(void) { return g_shard_error.c_str(); }
+
 struct ovm_shm_comm {
     struct alignas(64) Slot {
         uint64_t seq;
         uint64_t pad[7];
     };
+    // The segment's first line. abort_code != 0: some rank gave up in the middle of a joint call (it threw, ran out of
+    // memory, ...) and will not make its remaining contributions: every waiter returns at once instead of spinning
+    // until the timeout, and the communicator is POISONED on every rank -- the sequence numbers of the ranks no longer
+    // agree, so a later exchange could pair a fresh slot with a stale one and deliver bytes of the aborted proof.
+    struct Header {
+        uint32_t abort_code;
+        uint32_t abort_rank_plus1;
+    };
+    bool poisoned = false;
+    Header *header() const { return reinterpret_cast<Header *>(base); }
+    int fail(int code, const std::string &what) {
+        poisoned = true;
+        g_shard_error = "rank " + std::to_string(rank) + ": " + what;
+        fprintf(stderr, "[ovm shard] %s\n", g_shard_error.c_str());
+        return code;
+    }
+    int peer_aborted() {
+        const Header h{__atomic_load_n(&header()->abort_code, __ATOMIC_ACQUIRE), __atomic_load_n(&header()->abort_rank_plus1, __ATOMIC_ACQUIRE)};
+        return fail(OVM_ESHARD_PEER_ABORTED, "rank " + std::to_string((int)h.abort_rank_plus1 - 1) + " aborted the joint call with code " +
+                                                 std::to_string(h.abort_code) + "; this communicator is unusable, create a new one");
+    }
+    int abort(int code) {
+        uint32_t expected = 0;
+        const uint32_t c = code ? (uint32_t)code : 1u;
+        if (__atomic_compare_exchange_n(&header()->abort_code, &expected, c, false, __ATOMIC_ACQ_REL, __ATOMIC_ACQUIRE))
+            __atomic_store_n(&header()->abort_rank_plus1, rank + 1, __ATOMIC_RELEASE);
+        poisoned = true;
+        return 0;
+    }
     uint8_t *base = nullptr;
     size_t total = 0;
     uint32_t rank = 0, world = 1;
@@ -89,7 +127,7 @@ struct ovm_shm_comm {
     uint64_t seq = 0;
     std::string name;
     bool owns_mapping = false;
-    double timeout_s = 300.0;
+    double timeout_s = 30.0;
 
     size_t slot_stride() const { return sizeof(Slot) + ((slot_bytes + 63) & ~uint64_t(63)); }
     Slot *slot(uint32_t r, unsigned parity) const { return reinterpret_cast<Slot *>(base + 64 + (size_t)(2 * r + parity) * slot_stride()); }
@@ -99,6 +137,11 @@ struct ovm_shm_comm {
     }
 
     int exchange_chunk(const uint8_t *mine, uint8_t *all, uint64_t stride_all, uint64_t bytes) {
+        if (poisoned) {
+            g_shard_error = "rank " + std::to_string(rank) + ": the communicator was poisoned by an earlier failure (time-out or aborted peer); create a new one";
+            return OVM_ESHARD_POISONED;
+        }
+        if (__atomic_load_n(&header()->abort_code, __ATOMIC_ACQUIRE)) return peer_aborted();
         const uint64_t s = ++seq;
         const unsigned par = (unsigned)(s & 1);
         Slot *me = slot(rank, par);
@@ -112,9 +155,15 @@ struct ovm_shm_comm {
 #if defined(__x86_64__)
                 __builtin_ia32_pause();
 #endif
-                if ((++spins & 0x3FFF) == 0) {
-                    sched_yield();
-                    if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeout_s) return 6;  // hipErrorNotReady-like
+                if ((++spins & 0x3FF) == 0) {
+                    if (__atomic_load_n(&header()->abort_code, __ATOMIC_ACQUIRE)) return peer_aborted();
+                    if ((spins & 0x3FFF) == 0) {
+                        sched_yield();
+                        const double waited = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+                        if (waited > timeout_s)
+                            return fail(OVM_ESHARD_TIMEOUT, "timed out after " + std::to_string((int)waited) + " s waiting for rank " + std::to_string(r) +
+                                                                " at exchange " + std::to_string(s) + " (OVM_SHARD_TIMEOUT_S)");
+                    }
                 }
             }
             if (bytes) memcpy(all + r * stride_all, reinterpret_cast<uint8_t *>(sl) + sizeof(Slot), bytes);
@@ -189,6 +238,12 @@ void ovm_hip_shm_comm_destroy(ovm_shm_comm_t *c) {
     if (c->owns_mapping && c->base) munmap(c->base, c->total);
     delete c;
 }
+
+int ovm_hip_shm_comm_abort(void *comm, int code) {
+    if (!comm) return 1;
+    return static_cast<ovm_shm_comm *>(comm)->abort(code);
+}
+int ovm_hip_shm_comm_poisoned(const ovm_shm_comm_t *comm) { return comm && comm->poisoned ? 1 : 0; }
 
 int ovm_hip_shm_allgather(void *comm, const void *mine, void *all, uint64_t bytes) {
     if (!comm || (bytes && (!mine || !all))) return 1;

@@ -23,6 +23,7 @@ struct Tuning {
     uint32_t finish_inline_max = 64;    // OVM_FINISH_INLINE_MAX: grids up to this many workgroups finish their reduction
                                    // in the kernel (last workgroup sums the records); larger ones take a second launch
     bool trace = false;            // OVM_TRACE: wall-clock trace of the stages on stderr
+    int test_fail_rank = -1;       // OVM_TEST_FAIL_RANK: this rank of a sharded proof throws after its commitment (tests)
     static Tuning from_env();
     static void refresh() { current() = from_env(); }
     static Tuning &current() {

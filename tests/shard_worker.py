@@ -25,6 +25,11 @@ def main():
                     help="prove in the memory-bounded modes (codeword dropped, round 0 in slabs of 8 rows, leaf layer dropped)")
     ap.add_argument("--bulk", default="ipc", choices=["ipc", "shm"],
                     help="the bulk device exchange: the library's IPC pulls, or host staging through the shared-memory segment")
+    ap.add_argument("--fail-mode", default="none", choices=["none", "invalid", "midproof"],
+                    help="before the real proof: 'invalid' = --fail-rank passes a public-values list of the wrong length (every "
+                         "rank must refuse, the communicator stays usable); 'midproof' = --fail-rank throws after its commitment "
+                         "(the peers must return OVM_ESHARD_PEER_ABORTED quickly, the communicator is poisoned and is recreated)")
+    ap.add_argument("--fail-rank", type=int, default=1)
     ap.add_argument("--no-alltoall", action="store_true",
                     help="hand the library a null alltoall_device: the mu-batch vectors are all-gathered whole")
     args = ap.parse_args()
@@ -77,6 +82,38 @@ def main():
                 handles.append(dev.commit_matrix(pk, up(cached[off:off + w * h]), w, h))
                 off += w * h
         dtr.append((a, up(common), h, pvs, handles))
+    if args.fail_mode != "none":
+        t0 = time.time()
+        if args.fail_mode == "invalid":
+            bad = [(a, c, h, list(pv) + [1], k) if o == args.rank == args.fail_rank else (a, c, h, pv, k)
+                   for (a, c, h, pv, k), o in zip(dtr, owners)]
+            try:
+                dev.prove_sharded(pk, shard, bad, owners)
+                raise SystemExit("the invalid input was accepted")
+            except pkg.OvmError as e:
+                mine = "public values length" in str(e)
+                assert mine == (args.rank == args.fail_rank) and (mine or f"rank {args.fail_rank} rejected" in str(e)), str(e)
+            assert not shard.poisoned                      # nobody had started working: the same communicator proves next
+        else:
+            os.environ["OVM_TEST_FAIL_RANK"] = str(args.fail_rank)
+            try:
+                dev.prove_sharded(pk, shard, dtr, owners)
+                raise SystemExit("the failing proof succeeded")
+            except pkg.OvmError as e:
+                assert e.code == (2 if args.rank == args.fail_rank else 10007), (e.code, str(e))
+            finally:
+                del os.environ["OVM_TEST_FAIL_RANK"]
+            assert shard.poisoned
+            try:
+                dev.prove_sharded(pk, shard, dtr, owners)   # a poisoned communicator refuses at once
+                raise SystemExit("a poisoned communicator was used")
+            except pkg.OvmError as e:
+                assert e.code == 10008, (e.code, str(e))
+            shard.close()
+            shard = pkg.Shard(args.rank, args.world, args.shm + "-again", bulk=args.bulk, alltoall=not args.no_alltoall)
+        dt = time.time() - t0
+        assert dt < 20, f"failure handling took {dt:.1f} s"
+        print(f"[shard_worker rank {args.rank}] {args.fail_mode}: refused / aborted in {dt:.2f} s", file=sys.stderr, flush=True)
     proof = b""
     t_ready = time.time()
     for _ in range(args.repeat):

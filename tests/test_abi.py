@@ -136,8 +136,8 @@ def test_struct_layouts_match_header(pkg):
     import ctypes
     assert ctypes.sizeof(pkg.TraceStruct) == 48 and pkg.TraceStruct.cached.offset == 40
     assert ctypes.sizeof(pkg.PcsParams) == 16 and ctypes.sizeof(pkg.MatrixStruct) == 24
-    assert ctypes.sizeof(pkg.ShardStruct) == 40 and pkg.ShardStruct.allgather_device.offset == 24
-    assert pkg.ShardStruct.alltoall_device.offset == 32
+    assert ctypes.sizeof(pkg.ShardStruct) == 48 and pkg.ShardStruct.allgather_device.offset == 24
+    assert pkg.ShardStruct.alltoall_device.offset == 32 and pkg.ShardStruct.abort.offset == 40
     assert ctypes.sizeof(pkg.ProverConfigStruct) == 24 and pkg.ProverConfigStruct.cache_limit_bytes.offset == 16
 
 

@@ -397,3 +397,20 @@ def test_two_host_threads_prove_concurrently(dev, pkg, orc):
     for t in ts:
         t.join()
     assert not errors, errors
+
+
+def test_thread_shutdown_releases_and_the_thread_keeps_working(dev, pkg, orc):
+    """ovm_hip_thread_shutdown: the calling thread's mailboxes, pinned arena, grind scratch and free pool segments are
+    released now; the next proof creates them again and is the same proof."""
+    params = airs.test_params(l_skip=2, n_stack=6, k_whir=2)
+    blob = airs.pk_blob(params, [airs.uniform_runner_air(8)])
+    pk = pkg.ProvingKey(blob)
+    tr = dev.upload(pkg.to_mont(airs.splitmix64_bits(5, 8 * 32)))
+    a, _ = dev.prove(pk, [(0, tr, 32, [])])
+    before = pkg.memory_stats()
+    assert pkg._lib().ovm_hip_thread_shutdown() == 0
+    after = pkg.memory_stats()
+    assert after["cached"] == 0 and after["cached"] <= before["cached"]
+    b, _ = dev.prove(pk, [(0, tr, 32, [])])
+    assert a == b
+    orc.verify(blob, b)

@@ -25,14 +25,14 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def run_sharded(case, world, tmp_path, repeat=1, save_memory=False, alltoall=True, bulk="ipc"):
+def run_sharded(case, world, tmp_path, repeat=1, save_memory=False, alltoall=True, bulk="ipc", fail_mode="none", fail_rank=1):
     port, shm, out = _free_port(), f"/ovm-test-{uuid.uuid4().hex[:12]}", str(tmp_path / "proof.bin")
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
     env["OVM_SHARD_TIMEOUT_S"] = "60"  # a rank that died must not hold the others for minutes
     procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "shard_worker.py"), "--rank", str(r), "--world", str(world),
                                "--port", str(port), "--case", case, "--shm", shm, "--out", out, "--repeat", str(repeat)]
                               + (["--save-memory"] if save_memory else []) + ([] if alltoall else ["--no-alltoall"])
-                              + ["--bulk", bulk],
+                              + ["--bulk", bulk, "--fail-mode", fail_mode, "--fail-rank", str(fail_rank)],
                               env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
     logs = []
     for p in procs:
@@ -101,6 +101,17 @@ def test_sum_of_the_mu_batch_vectors_by_allgather_only(orc, tmp_path, case, worl
     (3 ranks: slices of ceil(2^m / 3) elements, a padded tail)."""
     blob, want = oracle_proof(orc, case, world)
     assert run_sharded(case, world, tmp_path, alltoall=False) == want
+
+
+@pytest.mark.parametrize("mode,world,fail_rank", [("invalid", 2, 1), ("invalid", 4, 0), ("midproof", 2, 1), ("midproof", 4, 2)])
+def test_a_failing_rank_stops_every_rank_and_the_next_proof_is_right(orc, tmp_path, mode, world, fail_rank):
+    """ADVICE r2 (medium). 'invalid': one rank's inputs are invalid -> EVERY rank refuses before any work, with that
+    rank's code, and the SAME communicator then makes the right proof. 'midproof': one rank throws after its commitment
+    -> it raises the abort flag, its peers return OVM_ESHARD_PEER_ABORTED within seconds instead of the time-out, the
+    communicator is poisoned on every rank (a second call returns OVM_ESHARD_POISONED at once: no stale slot is ever
+    read), and a recreated communicator makes the right proof."""
+    blob, want = oracle_proof(orc, "bench_app", world)
+    assert run_sharded("bench_app", world, tmp_path, fail_mode=mode, fail_rank=fail_rank) == want
 
 
 def test_single_process_equals_sharded(dev, pkg, orc, tmp_path):

@@ -90,3 +90,63 @@ def test_exchange_protocol_world2_gloo(alltoall):
     assert all(r[2] == (whole + 2 * (2 * sl * 16) if alltoall else whole) for r in res)
     assert all(r[3] == (1 if alltoall else 0) for r in res)
     assert not os.path.exists("/dev/shm" + shm)              # the segment's name is gone after the handshake
+
+
+def _abort_worker(rank, world, shm, q, mode):
+    """Rank 1 makes 3 exchanges and then fails ('abort': raises the abort flag; 'die': just stops contributing); the
+    others keep exchanging and report what their next exchange returned and how long that took."""
+    import ctypes
+    import sys
+    import time
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from conftest import load_pkg
+    pkg = load_pkg()
+    lib = pkg._lib()
+    h = ctypes.c_void_p(0)
+    pkg.check(lib.ovm_hip_shm_comm_create(shm.encode(), rank, world, 4096, ctypes.byref(h)), "create")
+    mine = np.array([rank], dtype=np.uint32)
+    every = np.zeros(world, dtype=np.uint32)
+    rcs = []
+    for i in range(3):
+        rcs.append(lib.ovm_hip_shm_allgather(h, mine.ctypes.data, every.ctypes.data, 4))
+    t0 = time.time()
+    why = ""
+    if rank == 1:
+        if mode == "abort":
+            lib.ovm_hip_shm_comm_abort(h, 2)
+        rcs.append(lib.ovm_hip_shm_allgather(h, mine.ctypes.data, every.ctypes.data, 4) if mode == "abort" else -1)
+    else:
+        rcs.append(lib.ovm_hip_shm_allgather(h, mine.ctypes.data, every.ctypes.data, 4))   # rank 1 never joins this one
+        why = lib.ovm_hip_shard_last_error().decode()
+        rcs.append(lib.ovm_hip_shm_allgather(h, mine.ctypes.data, every.ctypes.data, 4))   # afterwards: poisoned, at once
+    q.put((rank, rcs, time.time() - t0, int(lib.ovm_hip_shm_comm_poisoned(h)), why))
+
+
+@pytest.mark.parametrize("mode", ["abort", "die"])
+def test_a_failed_rank_does_not_hold_its_peers(mode):
+    """a rank that fails in the middle of a joint call. With the abort flag its peers return
+    OVM_ESHARD_PEER_ABORTED within milliseconds, naming the rank; without it (the process just died) they time out after
+    OVM_SHARD_TIMEOUT_S naming the rank they waited for. Either way the communicator is POISONED: the next exchange
+    fails at once instead of pairing a fresh slot with a stale one."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    shm = f"/ovm-test-{uuid.uuid4().hex[:12]}"
+    os.environ["OVM_SHARD_TIMEOUT_S"] = "2"
+    try:
+        ps = [ctx.Process(target=_abort_worker, args=(r, 3, shm, q, mode)) for r in range(3)]
+        for p in ps:
+            p.start()
+        res = sorted(q.get(timeout=120) for _ in range(3))
+        for p in ps:
+            p.join(timeout=60)
+    finally:
+        del os.environ["OVM_SHARD_TIMEOUT_S"]
+    TIMEOUT, ABORTED, POISONED = 10006, 10007, 10008
+    for rank, rcs, dt, poisoned, msg in res:
+        assert rcs[:3] == [0, 0, 0]
+        if rank == 1:
+            assert rcs[3] == (POISONED if mode == "abort" else -1)
+            continue
+        assert rcs[3] == (ABORTED if mode == "abort" else TIMEOUT) and rcs[4] == POISONED and poisoned == 1, (rank, rcs, msg)
+        assert (dt < 1.0) if mode == "abort" else (1.5 < dt < 10.0), dt
+    assert any("rank 1" in r[4] for r in res if r[0] != 1)
