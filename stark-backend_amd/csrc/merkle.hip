@@ -56,15 +56,16 @@ __global__ __launch_bounds__(HASH_THREADS) void hash_rows_kernel(const Fp *__res
     Fp s[16];
 #pragma unroll
     for (int i = 0; i < 16; i++) s[i] = Fp::zero();
-    // Absorb 8 words (= CPB columns) per permutation with static register indices.
+    // Absorb 8 words (= CPB columns) per permutation with static register indices. The FIRST permutation of a row sees
+    // a zero capacity (and, for a one-element extension-field row, 12 zero words), the LAST one only has to deliver the
+    // 8 digest words: p2::permute_t leaves the additions on known zeros / unused words out.
     constexpr int CPB = 8 / WORDS;
     const Fp *src = mat + row * WORDS;
     const uint64_t cstride = col_stride * WORDS;
-    uint64_t cidx = 0;
-    for (; cidx + CPB <= width; cidx += CPB) {
+    auto absorb_full = [&](uint64_t c0) {
 #pragma unroll
         for (int j = 0; j < CPB; j++) {
-            const Fp *p = src + (cidx + j) * cstride;
+            const Fp *p = src + (c0 + j) * cstride;
             if constexpr (WORDS == 4) {
                 uint4 v = *reinterpret_cast<const uint4 *>(p);
                 s[4 * j + 0] = Fp::raw(v.x);
@@ -75,19 +76,38 @@ __global__ __launch_bounds__(HASH_THREADS) void hash_rows_kernel(const Fp *__res
                 s[j] = p[0];
             }
         }
-        p2::permute(s);
-    }
-    if (cidx < width) {
-        // partial tail: overwrite the first words only, stale words stay (padding-free sponge)
-#pragma unroll
-        for (int j = 0; j < CPB; j++) {
-            if (cidx + j < width) {
-                const Fp *p = src + (cidx + j) * cstride;
-#pragma unroll
-                for (int k = 0; k < WORDS; k++) s[WORDS * j + k] = p[k];
-            }
+    };
+    if (WORDS == 4 && width == 1) {  // the WHIR round codewords: one extension-field element per row, one permutation
+        uint4 v = *reinterpret_cast<const uint4 *>(src);
+        s[0] = Fp::raw(v.x), s[1] = Fp::raw(v.y), s[2] = Fp::raw(v.z), s[3] = Fp::raw(v.w);
+        p2::permute_t<4, true>(s);
+    } else {
+        uint64_t cidx = 0;
+        const bool tail = width % CPB != 0;
+        if (width >= CPB) {
+            absorb_full(0);
+            cidx = CPB;
+            if (cidx == width) p2::permute_t<8, true>(s);
+            else p2::permute_t<8, false>(s);
         }
-        p2::permute(s);
+        for (; cidx + CPB <= width; cidx += CPB) {
+            absorb_full(cidx);
+            if (!tail && cidx + CPB == width) p2::permute_t<16, true>(s);
+            else p2::permute(s);
+        }
+        if (tail) {
+            // partial tail: overwrite the first words only, stale words stay (padding-free sponge)
+#pragma unroll
+            for (int j = 0; j < CPB; j++) {
+                if (cidx + j < width) {
+                    const Fp *p = src + (cidx + j) * cstride;
+#pragma unroll
+                    for (int k = 0; k < WORDS; k++) s[WORDS * j + k] = p[k];
+                }
+            }
+            if (width < CPB) p2::permute_t<8, true>(s);  // (a row narrower than the rate: its only permutation)
+            else p2::permute_t<16, true>(s);
+        }
     }
     Digest d;
 #pragma unroll

@@ -68,33 +68,60 @@ BB_HD Fp sbox7_add(Fp x, uint32_t rc) {
     return Fp::raw(bb::from_signed(bb::smont_mul(s4, s3)));
 }
 
-// state <- M_E * state, M_E = circ(2*M4, M4, M4, M4), M4 = [2 3 1 1; 1 2 3 1; 1 1 2 3; 3 1 1 2]
+// y = M4 x,  M4 = [2 3 1 1; 1 2 3 1; 1 1 2 3; 3 1 1 2]  (Plonky3's additive form: 9 additions, 2 doublings)
+BB_HD void mat4(Fp *x) {
+    Fp t01 = x[0] + x[1];
+    Fp t23 = x[2] + x[3];
+    Fp t0123 = t01 + t23;
+    Fp t01123 = t0123 + x[1];
+    Fp t01233 = t0123 + x[3];
+    x[3] = t01233 + x[0].dbl();
+    x[1] = t01123 + x[2].dbl();
+    x[0] = t01123 + t01;
+    x[2] = t01233 + t23;
+}
+// state <- M_E * state, M_E = circ(2*M4, M4, M4, M4).
+// IN  = how many leading words of the state can be non-zero (16; 8 = a sponge's first permutation, capacity still zero;
+//       4 = the one-permutation hash of an extension-field row): M4 of a zero block and sums over zero blocks are skipped.
+// OUT8 = only words 0..7 of the result are needed (a compression, a sponge's last permutation): the other eight are left
+//       unspecified. These are the same field operations with the ones on known zeros / unused words left out -- every
+//       value that is computed is the value the full layer computes.
+template <int IN = 16, bool OUT8 = false>
 BB_HD void external_linear(Fp *s) {
+    static_assert(IN == 16 || IN == 8 || IN == 4, "IN");
 #pragma unroll
-    for (int b = 0; b < 4; b++) {
-        Fp *x = s + 4 * b;
-        Fp t01 = x[0] + x[1];
-        Fp t23 = x[2] + x[3];
-        Fp t0123 = t01 + t23;
-        Fp t01123 = t0123 + x[1];
-        Fp t01233 = t0123 + x[3];
-        x[3] = t01233 + x[0].dbl();
-        x[1] = t01123 + x[2].dbl();
-        x[0] = t01123 + t01;
-        x[2] = t01233 + t23;
-    }
+    for (int b = 0; b < IN / 4; b++) mat4(s + 4 * b);
     Fp sums[4];
 #pragma unroll
-    for (int j = 0; j < 4; j++) sums[j] = (s[j] + s[4 + j]) + (s[8 + j] + s[12 + j]);
+    for (int j = 0; j < 4; j++)
+        sums[j] = IN == 16 ? (s[j] + s[4 + j]) + (s[8 + j] + s[12 + j]) : IN == 8 ? s[j] + s[4 + j] : s[j];
 #pragma unroll
-    for (int i = 0; i < 16; i++) s[i] += sums[i & 3];
+    for (int i = 0; i < (OUT8 ? 8 : 16); i++) s[i] = i < IN ? s[i] + sums[i & 3] : sums[i & 3];
 }
 
 // x * 2^-k for a Montgomery word: reduce (x << (32 - k)) -- a single Montgomery reduction, no
-// full multiply (reference: fp.h:205-214 mul_2exp_neg_n).
+// full multiply (reference: fp.h:205-214 mul_2exp_neg_n). The compiler reduces it to 6 VALU (+3 for the addition).
 template <int K>
 BB_HD Fp mul_2exp_neg(Fp x) {
     return Fp::raw(bb::mont_reduce((uint64_t)x.v << (32 - K)));
+}
+// sum +- x * 2^-8 in 8 VALU instead of 9. P = 15 * 2^27 + 1, so 2^-K = -15 * 2^(27-K) (mod P) and, with
+// x = hi * 2^K + lo,  x * 2^-K = hi - lo * 15 * 2^(27-K)  (the product is < 15 * 2^27 < P: nothing to reduce). For K = 8
+// both factors fit 24 bits and `sum -+ lo * c` is ONE v_mad_i32_i24; for the other K of the diagonal the product costs
+// a full-rate multiply or two shifts and a subtract, which is what the reduction form costs too (measured: DESIGN §3).
+BB_HD Fp add_div256(Fp sum, Fp x) {
+    const uint32_t hi = x.v >> 8, m = (x.v & 255u) * (15u << 19);
+    uint32_t b = sum.v - m;  // sum - m (mod P)
+    b = bb::umin32(b, b + bb::P);
+    const uint32_t r = b + hi;  // < P + 2^23
+    return Fp::raw(bb::umin32(r, r - bb::P));
+}
+BB_HD Fp sub_div256(Fp sum, Fp x) {
+    const uint32_t hi = x.v >> 8, m = (x.v & 255u) * (15u << 19);
+    uint32_t b = sum.v + m;  // < 2P
+    b = bb::umin32(b, b - bb::P);
+    const uint32_t r = b - hi;  // wraps iff negative
+    return Fp::raw(bb::umin32(r, r + bb::P));
 }
 
 // state <- (J + diag(V)) * state,
@@ -113,17 +140,19 @@ BB_HD void internal_linear(Fp *s) {
     s[6] = sum - s[6].halve();
     s[7] = sum - (s[7].dbl() + s[7]);
     s[8] = sum - s[8].dbl().dbl();
-    s[9] = sum + mul_2exp_neg<8>(s[9]);
+    s[9] = add_div256(sum, s[9]);
     s[10] = sum + mul_2exp_neg<2>(s[10]);
     s[11] = sum + mul_2exp_neg<3>(s[11]);
     s[12] = sum + mul_2exp_neg<27>(s[12]);
-    s[13] = sum - mul_2exp_neg<8>(s[13]);
+    s[13] = sub_div256(sum, s[13]);
     s[14] = sum - mul_2exp_neg<4>(s[14]);
     s[15] = sum - mul_2exp_neg<27>(s[15]);
 }
 
-BB_HD void permute(Fp *s) {
-    external_linear(s);
+// IN / OUT8: see external_linear (they describe the FIRST and the LAST linear layer only).
+template <int IN = 16, bool OUT8 = false>
+BB_HD void permute_t(Fp *s) {
+    external_linear<IN, false>(s);
 #pragma unroll
     for (int r = 0; r < 4; r++) {
 #pragma unroll
@@ -139,9 +168,11 @@ BB_HD void permute(Fp *s) {
     for (int r = 0; r < 4; r++) {
 #pragma unroll
         for (int i = 0; i < 16; i++) s[i] = sbox7_add(s[i], RC_TERMINAL[16 * r + i]);
-        external_linear(s);
+        if (r == 3) external_linear<16, OUT8>(s);
+        else external_linear(s);
     }
 }
+BB_HD void permute(Fp *s) { permute_t<16, false>(s); }
 
 // The same layers over round constants read from memory (`rc`: 64 initial, 64 terminal, 13 internal Montgomery words).
 // Not used by the prover: it lets Plonky3's published known-answer vector -- whose constants come from a seeded RNG,
@@ -266,7 +297,7 @@ BB_HD Digest compress(const Digest &l, const Digest &r) {
         s[i] = l.d[i];
         s[8 + i] = r.d[i];
     }
-    permute(s);
+    permute_t<16, true>(s);  // (only the first 8 words of the result are the digest)
     Digest o;
 #pragma unroll
     for (int i = 0; i < 8; i++) o.d[i] = s[i];
