@@ -41,7 +41,12 @@ struct RedOut {
     EF *out;            // device-visible address of the K results (host-mapped)
     uint32_t *flag;     // device-visible address of the completion flag (host-mapped), may be null
     uint32_t seq;       // value stored to *flag once out[] is visible to the host
+    // 64-bit accumulators (device, zero before the launch, reset by the last workgroup), or null. Non-null = the
+    // "atomic finish" of a LARGE grid: every workgroup adds the Montgomery words of its K totals into acc[4K] with
+    // device-scope atomics instead of storing a record; the last workgroup reduces the sums mod P into out[].
+    unsigned long long *acc;
 };
+static constexpr unsigned RED_ATOMIC_MAX_K = 16;  // acc[] holds 4 * 16 words
 
 static constexpr unsigned MAX_COSETS = 4;
 static constexpr unsigned RED_BLOCKS = 2048;  // grid cap of the partial-sum kernels (8 workgroups per CU)

@@ -282,12 +282,14 @@ struct Mailbox : ThreadResource {
         memset(hp, 0, sizeof(Page));
         h = (Page *)hp;
         d = (Page *)dp;
-        OVM_THROW_IF(hipMalloc((void **)&d_counter, 64));
+        // 64 bytes of counters, then the 64 accumulators of the atomic finish (device_common.h: RedOut::acc)
+        OVM_THROW_IF(hipMalloc((void **)&d_counter, 64 + 64 * 8));
+        OVM_THROW_IF(hipMemset(d_counter, 0, 64 + 64 * 8));
     }
     // call once per prove, before the first reduction (a failed launch may have left the counter dirty)
     void reset(hipStream_t s) {
         init();
-        OVM_THROW_IF(hipMemsetAsync(d_counter, 0, 64, s));
+        OVM_THROW_IF(hipMemsetAsync(d_counter, 0, 64 + 64 * 8, s));
     }
     // Results of this reduction go to slots [slot, slot + K). Several reductions may be in flight on
     // the stream with disjoint slot ranges; they complete in stream order, so waiting for the one
@@ -296,7 +298,7 @@ struct Mailbox : ThreadResource {
         if (slot + 64 > SLOTS) throw OvmFail((int)hipErrorInvalidValue, "mailbox: slot out of range");
         ++seq;
         bumps_at_arm = pinned_stage().bumps;
-        return RedOut{partials, d_counter, d->data + slot, &d->flag, seq};
+        return RedOut{partials, d_counter, d->data + slot, &d->flag, seq, (unsigned long long *)(d_counter + 16)};
     }
     // device address of result slot `slot` (for kernels that finish several reductions, see mle_round_eval_batched)
     EF *slot_ptr(size_t slot) const {
@@ -3090,6 +3092,7 @@ Tuning ovm::Tuning::from_env() {
     t.gkr_three_points = getenv("OVM_GKR_THREE_POINTS") != nullptr;
     t.merkle_coop = !off("OVM_MERKLE_COOP");
     t.finish_inline_max = (uint32_t)std::max(1, num("OVM_FINISH_INLINE_MAX", 64));
+    t.finish_atomic_max = (uint32_t)std::max(0, num("OVM_FINISH_ATOMIC_MAX", 0));
     t.trace = getenv("OVM_TRACE") != nullptr;
     t.test_fail_rank = num("OVM_TEST_FAIL_RANK", -1);
     return t;

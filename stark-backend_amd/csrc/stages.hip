@@ -52,6 +52,36 @@ __device__ void block_sum_store(EF (&v)[K], EF *out, bool fence = true) {
     __syncthreads();
 }
 
+// The atomic finish of a large grid (RedOut::acc): the workgroup's K totals are added, word by word, into 64-bit
+// accumulators with device-scope atomics. A sum of up to 2^20 words < 2^31 fits 64 bits with room to spare, and
+// (sum of Montgomery words) mod P is the Montgomery word of the field sum. The atomics RETURN their old value and the
+// value is consumed: the wave's wait for it is what guarantees the addition has been performed before this workgroup
+// bumps the counter (a non-returning atomic and the counter's atomic go to different channels and may pass each other:
+// tools/ubench_finish.hip showed wrong sums at 2048 workgroups exactly then). No release fence, no records, no second
+// launch: measured 10-16 us faster per reduction than records + sum_partials for kernels with real work
+// (profiles/r03/ubench_finish.json); with K <= 16 only -- round 0's 32..96 values per workgroup would serialise.
+template <int K>
+__device__ void block_sum_atomic(EF (&v)[K], const RedOut &ro, uint32_t k_off) {
+    __shared__ EF sh_a[(RED_THREADS / 64) * K];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        EF s = wave_sum(v[k]);
+        if (lane == 0) sh_a[wave * K + k] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < 4 * K) {
+        const int k = threadIdx.x >> 2, c = threadIdx.x & 3;
+        uint32_t w = sh_a[k].c[c].v;
+        unsigned long long sum = w;
+        for (int wv = 1; wv < (int)(blockDim.x >> 6); wv++) sum += sh_a[wv * K + k].c[c].v;
+        const unsigned long long seen =
+            __hip_atomic_fetch_add(ro.acc + 4 * (k_off + k) + c, sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (seen == ~0ull) ro.counter[15] = 1;  // (never: keeps the returned value, and with it the wait, alive)
+    }
+    __syncthreads();
+}
+
 // Make everything this thread stored visible to the host, then raise the mailbox flag.
 __device__ __forceinline__ void publish(const RedOut &ro) {
     if (ro.flag) {
@@ -76,6 +106,19 @@ __device__ void finish_reduction(const RedOut &ro, uint32_t n_records, uint32_t 
     }
     __syncthreads();
     if (!s_last) return;
+    if (ro.acc) {  // atomic finish: the sums are complete (every workgroup's atomics were performed before its counter bump)
+        if (threadIdx.x < 4 * K) {
+            const unsigned long long sum = __hip_atomic_exchange(ro.acc + threadIdx.x, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            ((volatile uint32_t *)ro.out)[threadIdx.x] = (uint32_t)(sum % bb::P);
+        }
+        __threadfence_system();
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            __hip_atomic_store(ro.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            publish(ro);
+        }
+        return;
+    }
     __threadfence();
     EF acc[KMAX];
 #pragma unroll
@@ -121,14 +164,34 @@ int sum_partials(const RedOut &ro, uint32_t n_blocks, uint32_t K, hipStream_t s)
 // (Round 2 tried storing the records through to memory instead -- agent-scope atomic stores + s_waitcnt, no
 // release fence -- with the in-kernel finish for every grid: correct, 159 tests green, and no faster:
 // 78.1 vs 77.3-78.1 ms per proof; the last workgroup's pass over 2048 records costs what the launch did.)
-static inline RedOut red_inline(const RedOut &ro, uint32_t total_blocks) {
+// Round 3 built a third way to finish a large grid: 64-bit atomic accumulators (block_sum_atomic), no records and no second
+// launch. In isolation it wins (tools/ubench_finish.hip: launch-to-flag 80 vs 96 us for 2048 workgroups of real work, 11 vs
+// 23 us for 256 empty ones); inside the prover it does not: gkr.layer_sumchecks 10.19 ms with the second launch, 10.21 /
+// 10.70 / 10.53 ms with the atomic finish for grids up to 256 / 512 / 2048 workgroups, the other sumcheck stages likewise
+// (profiles/r03/finish_atomic_sweep.json) -- a workgroup of a streaming kernel waits for its stores to drain before its
+// atomics return, which the fire-and-forget record store never did. It stays behind OVM_FINISH_ATOMIC_MAX (default 0 = off)
+// with a parity test.
+static inline bool red_atomic(const RedOut &ro, uint32_t total_blocks, uint32_t K) {
+    return total_blocks > tuning().finish_inline_max && total_blocks <= tuning().finish_atomic_max && K <= RED_ATOMIC_MAX_K &&
+           ro.acc != nullptr;
+}
+static inline RedOut red_inline(const RedOut &ro, uint32_t total_blocks, uint32_t K) {
     RedOut r = ro;
+    if (red_atomic(ro, total_blocks, K)) return r;
+    r.acc = nullptr;
     if (total_blocks > tuning().finish_inline_max) r.counter = nullptr;
     return r;
 }
 static inline int red_finish(const RedOut &ro, uint32_t total_blocks, uint32_t n_records, uint32_t K, hipStream_t s) {
+    if (red_atomic(ro, total_blocks, K)) return 0;
     if (total_blocks > tuning().finish_inline_max) return sum_partials(ro, n_records, K, s);
     return 0;
+}
+// a workgroup's K totals: into the accumulators (atomic finish) or as its record
+template <int K>
+__device__ __forceinline__ void block_sum_out(EF (&v)[K], const RedOut &ro, size_t record_off, uint32_t k_off = 0) {
+    if (ro.acc) block_sum_atomic<K>(v, ro, k_off);
+    else block_sum_store<K>(v, ro.partials + record_off, ro.counter != nullptr);
 }
 
 static inline uint32_t red_grid(uint64_t work_items) {
@@ -950,7 +1013,7 @@ __global__ __launch_bounds__(RED_THREADS) void mle_round_grouped_kernel(const In
         sums[0] = sums[0] + e * out[0];
         if (n_out > 1) sums[1] = sums[1] + e * out[1];
     }
-    block_sum_store<2>(sums, ro.partials + ((size_t)(blockIdx.x * gridDim.z + grp)) * K + 2 * blockIdx.y, ro.counter != nullptr);
+    block_sum_out<2>(sums, ro, ((size_t)(blockIdx.x * gridDim.z + grp)) * K + 2 * blockIdx.y, 2 * blockIdx.y);
     finish_reduction<8>(ro, gridDim.x * gridDim.z, K);
 }
 
@@ -1052,7 +1115,7 @@ __global__ __launch_bounds__(RED_THREADS) void mle_round_points_kernel(const Ins
     EF sums[2 * D];
     mle_round_points_body<NS, D>(code + off[grp], off[grp + 1] - off[grp], weights, mats, log_h, n_out, eq,
                                  grp == 0 ? add_const : EF::zero(), gridDim.x, sums);
-    block_sum_store<2 * D>(sums, ro.partials + ((size_t)(blockIdx.x * gridDim.z + grp)) * (2 * D), ro.counter != nullptr);
+    block_sum_out<2 * D>(sums, ro, ((size_t)(blockIdx.x * gridDim.z + grp)) * (2 * D));
     finish_reduction<8>(ro, gridDim.x * gridDim.z, 2 * D);
 }
 
@@ -1177,7 +1240,7 @@ int mle_round_eval_grouped(const Instr *d_code, const uint32_t *d_off, uint32_t 
         dim3 grid(gx, 1, n_groups);
 #define CALLD(NS, DD)                                                                                                  \
     OVM_LAUNCH((mle_round_points_kernel<NS, DD>), grid, dim3(RED_THREADS), 0, s, d_code, d_off, d_weights, mats, \
-                       log_h, n_out, d_eq, add_const, red_inline(ro, gx * n_groups))
+                       log_h, n_out, d_eq, add_const, red_inline(ro, gx * n_groups, 2 * degree))
 #define CALL(NS)                                  \
     do {                                          \
         if (degree == 1) CALLD(NS, 1);            \
@@ -1194,7 +1257,7 @@ int mle_round_eval_grouped(const Instr *d_code, const uint32_t *d_off, uint32_t 
     dim3 grid(gx, degree, n_groups);
 #define CALL(NS)                                                                                               \
     OVM_LAUNCH(mle_round_grouped_kernel<NS>, grid, dim3(RED_THREADS), 0, s, d_code, d_off, d_weights, mats, \
-                       log_h, n_out, d_eq, add_const, red_inline(ro, gx * degree * n_groups))
+                       log_h, n_out, d_eq, add_const, red_inline(ro, gx * degree * n_groups, 2 * degree))
     DISPATCH_SLOTS(max_slots, CALL);
 #undef CALL
     OVM_CHECK_LAUNCH();
@@ -1695,7 +1758,7 @@ __global__ __launch_bounds__(RED_THREADS) void gkr_round_kernel(FracPlanes rec, 
         const EF b[4] = {p[2], q[2], p[3], q[3]};
         gkr_pair_sums<NP>(a, b, e, lambda, sums);
     }
-    block_sum_store<NP>(sums, ro.partials + (size_t)blockIdx.x * NP, ro.counter != nullptr);
+    block_sum_out<NP>(sums, ro, (size_t)blockIdx.x * NP);
     finish_reduction<NP>(ro, gridDim.x, NP);
 }
 int gkr_round(FracPlanes rec, bool p_base, EFPlanes eq, uint64_t n_pairs, EF lambda, uint32_t n_points,
@@ -1704,7 +1767,7 @@ int gkr_round(FracPlanes rec, bool p_base, EFPlanes eq, uint64_t n_pairs, EF lam
     uint32_t grid = red_grid(n_pairs);
 #define CALL(PB, NP)                                                                                             \
     OVM_LAUNCH((gkr_round_kernel<PB, NP>), dim3(grid), dim3(RED_THREADS), 0, s, rec, eq, n_pairs, lambda, \
-                       red_inline(ro, grid))
+                       red_inline(ro, grid, n_points))
     if (p_base) {
         if (n_points == 2) CALL(true, 2); else CALL(true, 3);
     } else {
@@ -1757,7 +1820,7 @@ __global__ __launch_bounds__(RED_THREADS) void gkr_fold_round_kernel(FracPlanes 
         const EF b[4] = {fp[2], fq[2], fp[3], fq[3]};
         gkr_pair_sums<NP>(a, b, e, lambda, sums);
     }
-    block_sum_store<NP>(sums, ro.partials + (size_t)blockIdx.x * NP, ro.counter != nullptr);
+    block_sum_out<NP>(sums, ro, (size_t)blockIdx.x * NP);
     finish_reduction<NP>(ro, gridDim.x, NP);
 }
 int gkr_fold_round(FracPlanes in, bool in_p_base, EFPlanes eq, FracPlanes out, uint64_t n_pairs, EF r, EF lambda,
@@ -1766,7 +1829,7 @@ int gkr_fold_round(FracPlanes in, bool in_p_base, EFPlanes eq, FracPlanes out, u
     uint32_t grid = red_grid(n_pairs);
 #define CALL(PB, NP)                                                                                               \
     OVM_LAUNCH((gkr_fold_round_kernel<PB, NP>), dim3(grid), dim3(RED_THREADS), 0, s, in, eq, out, n_pairs, r, \
-                       lambda, red_inline(ro, grid))
+                       lambda, red_inline(ro, grid, n_points))
     if (in_p_base) {
         if (n_points == 2) CALL(true, 2); else CALL(true, 3);
     } else {
@@ -1925,12 +1988,12 @@ __global__ __launch_bounds__(RED_THREADS) void stacked_round_kernel(const EF *ve
         EF a2 = a1.dbl() - a0, b2 = b1.dbl() - b0, e2 = e1.dbl() - e0, k2 = k1.dbl() - k0;
         sums[1] = sums[1] + a2 * e2 + b2 * k2;
     }
-    block_sum_store<2>(sums, ro.partials + (size_t)blockIdx.x * 2, ro.counter != nullptr);
+    block_sum_out<2>(sums, ro, (size_t)blockIdx.x * 2);
     finish_reduction<2>(ro, gridDim.x, 2);
 }
 int stacked_round(const EF *vec4, uint32_t log_h, const RedOut &ro, hipStream_t s) {
     uint32_t grid = red_grid(1ull << (log_h - 1));
-    OVM_LAUNCH(stacked_round_kernel, dim3(grid), dim3(RED_THREADS), 0, s, vec4, log_h, red_inline(ro, grid));
+    OVM_LAUNCH(stacked_round_kernel, dim3(grid), dim3(RED_THREADS), 0, s, vec4, log_h, red_inline(ro, grid, 2));
     OVM_CHECK_LAUNCH();
     return red_finish(ro, grid, grid, 2, s);
 }
@@ -2014,12 +2077,12 @@ __global__ __launch_bounds__(RED_THREADS) void whir_round_kernel(const EF *f, co
         sums[0] = sums[0] + f1 * w1;
         sums[1] = sums[1] + (f1.dbl() - f0) * (w1.dbl() - w0);
     }
-    block_sum_store<2>(sums, ro.partials + (size_t)blockIdx.x * 2, ro.counter != nullptr);
+    block_sum_out<2>(sums, ro, (size_t)blockIdx.x * 2);
     finish_reduction<2>(ro, gridDim.x, 2);
 }
 int whir_round(const EF *f, const EF *w, uint64_t n_pairs, const RedOut &ro, hipStream_t s) {
     uint32_t grid = red_grid(n_pairs);
-    OVM_LAUNCH(whir_round_kernel, dim3(grid), dim3(RED_THREADS), 0, s, f, w, n_pairs, red_inline(ro, grid));
+    OVM_LAUNCH(whir_round_kernel, dim3(grid), dim3(RED_THREADS), 0, s, f, w, n_pairs, red_inline(ro, grid, 2));
     OVM_CHECK_LAUNCH();
     return red_finish(ro, grid, grid, 2, s);
 }
@@ -2044,14 +2107,14 @@ __global__ __launch_bounds__(RED_THREADS) void whir_fold_round_kernel(const EF *
         sums[0] = sums[0] + f1 * w1;
         sums[1] = sums[1] + (f1.dbl() - f0) * (w1.dbl() - w0);
     }
-    block_sum_store<2>(sums, ro.partials + (size_t)blockIdx.x * 2, ro.counter != nullptr);
+    block_sum_out<2>(sums, ro, (size_t)blockIdx.x * 2);
     finish_reduction<2>(ro, gridDim.x, 2);
 }
 int whir_fold_round(const EF *f_in, const EF *w_in, EF *f_out, EF *w_out, uint64_t n_pairs, EF alpha, const RedOut &ro,
                     hipStream_t s) {
     uint32_t grid = red_grid(n_pairs);
     OVM_LAUNCH(whir_fold_round_kernel, dim3(grid), dim3(RED_THREADS), 0, s, f_in, w_in, f_out, w_out, n_pairs, alpha,
-                       red_inline(ro, grid));
+                       red_inline(ro, grid, 2));
     OVM_CHECK_LAUNCH();
     return red_finish(ro, grid, grid, 2, s);
 }
@@ -2084,13 +2147,13 @@ __global__ __launch_bounds__(RED_THREADS) void horner_kernel(const EF *coeffs, u
         for (uint64_t i = hi; i-- > lo;) acc = acc * z + ld_ef(coeffs + i);
         sums[0] = sums[0] + acc * z_run.pow(r);
     }
-    block_sum_store<1>(sums, ro.partials + blockIdx.x, ro.counter != nullptr);
+    block_sum_out<1>(sums, ro, blockIdx.x);
     finish_reduction<1>(ro, gridDim.x, 1);
 }
 int horner_eval(const EF *coeffs, uint64_t n, EF z, const RedOut &ro, hipStream_t s) {
     uint32_t grid = red_grid((n + HORNER_RUN - 1) / HORNER_RUN);
     OVM_LAUNCH(horner_kernel, dim3(grid), dim3(RED_THREADS), 0, s, coeffs, n, z, z.pow(HORNER_RUN),
-                       red_inline(ro, grid));
+                       red_inline(ro, grid, 1));
     OVM_CHECK_LAUNCH();
     return red_finish(ro, grid, grid, 1, s);
 }

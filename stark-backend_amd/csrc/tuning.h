@@ -22,6 +22,9 @@ struct Tuning {
     bool merkle_coop = true;       // OVM_MERKLE_COOP=0: no 16-lane cooperative compress for the small layers
     uint32_t finish_inline_max = 64;    // OVM_FINISH_INLINE_MAX: grids up to this many workgroups finish their reduction
                                    // in the kernel (last workgroup sums the records); larger ones take a second launch
+    uint32_t finish_atomic_max = 0;     // OVM_FINISH_ATOMIC_MAX: grids above finish_inline_max and up to this many workgroups
+                                   // finish in the kernel through 64-bit atomic accumulators. 0 (default): never --
+                                   // measured no faster in the prover than the second launch (stages.hip)
     bool trace = false;            // OVM_TRACE: wall-clock trace of the stages on stderr
     int test_fail_rank = -1;       // OVM_TEST_FAIL_RANK: this rank of a sharded proof throws after its commitment (tests)
     static Tuning from_env();

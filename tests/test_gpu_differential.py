@@ -160,3 +160,21 @@ def test_round0_program_groups(dev, pkg, orc, monkeypatch, seed):
         traces.append((i, rng.integers(0, airs.P, size=width * h, dtype=np.uint64).astype(np.uint32), h,
                        [int(rng.integers(0, airs.P))]))
     _run(dev, pkg, orc, params, air_list, traces)
+
+
+@pytest.mark.parametrize("seed", range(3))
+def test_atomic_finish_of_large_reductions(dev, pkg, orc, monkeypatch, seed):
+    """The opt-in third way to finish a reduction (stages.hip: block_sum_atomic -- 64-bit atomic accumulators instead of
+    records + a second launch), forced for every grid of more than ONE workgroup: the same proof."""
+    monkeypatch.setenv("OVM_FINISH_ATOMIC_MAX", "1000000")
+    monkeypatch.setenv("OVM_FINISH_INLINE_MAX", "1")
+    monkeypatch.setenv("OVM_MLE_BATCH", "0")
+    rng = np.random.default_rng(8100 + seed)
+    params = airs.test_params(l_skip=3, n_stack=11, k_whir=2)
+    air_list, traces = [], []
+    for i in range(2):
+        width = int(rng.integers(3, 10))
+        air_list.append(airs.random_air(rng, width, int(rng.integers(4, 20)), int(rng.integers(1, 3))))
+        h = 1 << int(rng.integers(10, 13))
+        traces.append((i, rng.integers(0, airs.P, size=width * h, dtype=np.uint64).astype(np.uint32), h, []))
+    _run(dev, pkg, orc, params, air_list, traces)
