@@ -20,6 +20,7 @@
 // bound; one lane hashes one row and the codeword is read exactly once with unit stride across
 // the wavefront.
 #include <cstdlib>
+#include <cstring>
 
 #include "device_ctx.h"
 #include "openvm_hip.h"
@@ -161,6 +162,17 @@ __global__ __launch_bounds__(HASH_THREADS) void grind_kernel(p2::Sponge sponge, 
     p2::Sponge s = sponge;
     s.observe(Fp::from_canonical(w));
     if (s.sample_bits(bits) == 0) atomicMin(result, w);
+}
+// Hands a batch's result to the host through a host-mapped word + sequence flag and re-arms the result word for the next
+// batch: no upload of the initial value, no download, no stream synchronisation per batch (6 grinds per config D proof,
+// each used to cost two runtime copies and a synchronisation). Its own one-lane launch behind the search: a "last
+// workgroup publishes" counter in the search kernel itself cost 2 ms per proof (65 536 workgroups on one address).
+__global__ void grind_publish_kernel(uint32_t *result, uint32_t *host_page /* [0] flag, [1] result */, uint32_t seq) {
+    const uint32_t found = *result;
+    *result = 0xffffffffu;
+    ((volatile uint32_t *)host_page)[1] = found;
+    __threadfence_system();
+    ((volatile uint32_t *)host_page)[0] = seq;
 }
 
 __global__ void permute_states_kernel(Fp *states, uint64_t n) {
@@ -343,12 +355,15 @@ int ovm_hip_sponge_grind(const ovm_sponge_t *sponge, uint32_t bits, uint32_t *wi
     s.sample_idx = sponge->sample_idx;
     if (s.absorb_idx >= 8 || s.sample_idx > 8) return (int)hipErrorInvalidValue;
     OVM_PROF("grind", stream);
-    // one result word per (thread, device), released when the thread exits
+    // per (thread, device): the device result word and a host-mapped page (flag, result)
     struct GrindScratch : ovm::ThreadResource {
-        uint32_t *p[16] = {};
+        uint32_t *p[16] = {}, *h[16] = {}, *hd[16] = {};
+        uint32_t seq[16] = {};
         void release() override {
-            for (uint32_t *&q : p)
-                if (q) (void)hipFree(q), q = nullptr;
+            for (int i = 0; i < 16; i++) {
+                if (p[i]) (void)hipFree(p[i]), p[i] = nullptr;
+                if (h[i]) (void)hipHostFree(h[i]), h[i] = hd[i] = nullptr;
+            }
         }
         ~GrindScratch() override {
             if (!ovm::runtime_exiting()) release();
@@ -357,23 +372,39 @@ int ovm_hip_sponge_grind(const ovm_sponge_t *sponge, uint32_t bits, uint32_t *wi
     static thread_local GrindScratch scratch;
     int dev = 0;
     OVM_CHECK(hipGetDevice(&dev));
-    uint32_t *&d_result = scratch.p[dev & 15];
-    if (!d_result) OVM_CHECK(hipMalloc(&d_result, sizeof(uint32_t)));
+    dev &= 15;
+    if (!scratch.p[dev]) {
+        const uint32_t init[2] = {0xffffffffu, 0};  // (re-armed by every publish)
+        OVM_CHECK(hipMalloc(&scratch.p[dev], 64));
+        OVM_CHECK(hipMemcpy(scratch.p[dev], init, sizeof init, hipMemcpyHostToDevice));
+        void *hp = nullptr, *dp = nullptr;
+        OVM_CHECK(hipHostMalloc(&hp, 64, hipHostMallocMapped | hipHostMallocCoherent));
+        OVM_CHECK(hipHostGetDevicePointer(&dp, hp, 0));
+        memset(hp, 0, 64);
+        scratch.h[dev] = (uint32_t *)hp, scratch.hd[dev] = (uint32_t *)dp;
+    }
+    volatile uint32_t *page = scratch.h[dev];
     // Expected 2^bits candidates per hit: scan ascending in batches of four times that (a batch holds a
     // hit with probability 1 - e^-4; the candidates above the first hit exit early), so the first batch
     // with a hit yields the global minimum witness.
     uint64_t batch = 4ull << (bits < 16 ? 16 : bits);
     if (batch > (1ull << 24)) batch = 1ull << 24;
     for (uint64_t base = 0; base < bb::P; base += batch) {
-        uint32_t init = 0xffffffffu;
-        OVM_CHECK(hipMemcpyAsync(d_result, &init, 4, hipMemcpyHostToDevice, stream));
         uint32_t count = (uint32_t)((bb::P - base) < batch ? (bb::P - base) : batch);
+        const uint32_t seq = ++scratch.seq[dev];
         OVM_LAUNCH(grind_kernel, dim3(ceil_div(count, HASH_THREADS)), dim3(HASH_THREADS), 0,
-                           stream, s, bits, (uint32_t)base, count, d_result);
+                           stream, s, bits, (uint32_t)base, count, scratch.p[dev]);
+        OVM_LAUNCH(grind_publish_kernel, dim3(1), dim3(1), 0, stream, scratch.p[dev], scratch.hd[dev], seq);
         OVM_CHECK_LAUNCH();
-        uint32_t found = 0;
-        OVM_CHECK(hipMemcpyAsync(&found, d_result, 4, hipMemcpyDeviceToHost, stream));
-        OVM_CHECK(hipStreamSynchronize(stream));
+        uint64_t spins = 0;
+        while (page[0] != seq) {
+            if ((++spins & 0xFFFF) == 0) {  // a faulted kernel never raises the flag
+                const hipError_t q = hipStreamQuery(stream);
+                if (q != hipSuccess && q != hipErrorNotReady) return (int)q;
+                if (q == hipSuccess && page[0] != seq && spins > (1ull << 34)) return (int)hipErrorUnknown;
+            }
+        }
+        const uint32_t found = page[1];
         if (found != 0xffffffffu) {
             *witness_out = found;
             return 0;

@@ -25,6 +25,7 @@ struct Tuning {
     uint32_t finish_atomic_max = 0;     // OVM_FINISH_ATOMIC_MAX: grids above finish_inline_max and up to this many workgroups
                                    // finish in the kernel through 64-bit atomic accumulators. 0 (default): never --
                                    // measured no faster in the prover than the second launch (stages.hip)
+    bool download_kernel = true;   // OVM_DOWNLOAD_KERNEL=0: small downloads through the runtime's copy + stream synchronisation
     bool trace = false;            // OVM_TRACE: wall-clock trace of the stages on stderr
     int test_fail_rank = -1;       // OVM_TEST_FAIL_RANK: this rank of a sharded proof throws after its commitment (tests)
     static Tuning from_env();
