@@ -12,6 +12,8 @@ use crate::{error::HipError, ffi, prelude::F};
 pub struct DeviceBuffer<T> {
     ptr: *mut T,
     len: usize,
+    /// `Some`: the memory belongs to the device key (a preprocessed trace) and is kept alive by it, not freed here
+    borrowed_from: Option<Arc<PkHandle>>,
 }
 // SAFETY: the allocation is plain device memory; access is ordered by the streams of the calls using it.
 unsafe impl<T: Send> Send for DeviceBuffer<T> {}
@@ -24,7 +26,11 @@ impl<T> DeviceBuffer<T> {
         HipError::from_result("ovm_hip_malloc", unsafe {
             ffi::ovm_hip_malloc(&mut p, len.max(1) * std::mem::size_of::<T>())
         })?;
-        Ok(Self { ptr: p as *mut T, len })
+        Ok(Self { ptr: p as *mut T, len, borrowed_from: None })
+    }
+    /// A view of `len` elements that live inside the device key `owner` (never freed by this buffer).
+    pub(crate) fn borrowed(ptr: *const T, len: usize, owner: Arc<PkHandle>) -> Self {
+        Self { ptr: ptr as *mut T, len, borrowed_from: Some(owner) }
     }
     pub fn from_host(host: &[T], stream: ffi::OvmStream) -> Result<Self, HipError> {
         let buf = Self::with_capacity(host.len())?;
@@ -58,8 +64,10 @@ impl<T> DeviceBuffer<T> {
 }
 impl<T> Drop for DeviceBuffer<T> {
     fn drop(&mut self) {
-        // SAFETY: allocated by ovm_hip_malloc, freed once.
-        unsafe { ffi::ovm_hip_free(self.ptr as *mut c_void) };
+        if self.borrowed_from.is_none() {
+            // SAFETY: allocated by ovm_hip_malloc, freed once.
+            unsafe { ffi::ovm_hip_free(self.ptr as *mut c_void) };
+        }
     }
 }
 
@@ -99,6 +107,8 @@ pub struct StackedPcsDataHip {
     pub(crate) handle: *mut ffi::OvmPcs,
     pub commitment: [F; 8],
     _keep_alive: Vec<Arc<DeviceBuffer<F>>>,
+    /// `Some`: the handle is the key's own PCS data of a preprocessed trace -- borrowed, not freed here
+    borrowed_from: Option<Arc<PkHandle>>,
     _marker: PhantomData<F>,
 }
 // SAFETY: the handle is only read by prover calls; the library's PCS data is immutable after commit.
@@ -107,13 +117,18 @@ unsafe impl Sync for StackedPcsDataHip {}
 
 impl StackedPcsDataHip {
     pub(crate) fn new(handle: *mut ffi::OvmPcs, commitment: [F; 8], keep_alive: Vec<Arc<DeviceBuffer<F>>>) -> Self {
-        Self { handle, commitment, _keep_alive: keep_alive, _marker: PhantomData }
+        Self { handle, commitment, _keep_alive: keep_alive, borrowed_from: None, _marker: PhantomData }
+    }
+    pub(crate) fn borrowed(handle: *mut ffi::OvmPcs, commitment: [F; 8], owner: Arc<PkHandle>) -> Self {
+        Self { handle, commitment, _keep_alive: Vec::new(), borrowed_from: Some(owner), _marker: PhantomData }
     }
 }
 impl Drop for StackedPcsDataHip {
     fn drop(&mut self) {
-        // SAFETY: handle came from ovm_hip_commit_matrices, freed once.
-        unsafe { ffi::ovm_hip_pcs_free(self.handle) };
+        if self.borrowed_from.is_none() {
+            // SAFETY: handle came from ovm_hip_commit_matrices, freed once.
+            unsafe { ffi::ovm_hip_pcs_free(self.handle) };
+        }
     }
 }
 

@@ -37,17 +37,23 @@ impl DeviceDataTransporter<SC, HipBackend> for HipDevice {
             .iter()
             .enumerate()
             .map(|(air_idx, pk)| {
-                // The preprocessed trace lives inside the key handle; the trait type still wants the
-                // (commitment, trace, data) triple, so hand out the host trace and a re-commit of it.
-                let preprocessed_data = pk.preprocessed_data.as_ref().map(|d| {
-                    let trace = self.transport_matrix_to_device(&d.mat_view(0).to_matrix());
-                    let (commitment, data) = self.commit(&[&trace]).expect("preprocessed commit failed");
-                    let mut from_key = [0u32; 8];
-                    HipError::from_result("ovm_hip_pk_preprocessed_commitment", unsafe {
-                        ffi::ovm_hip_pk_preprocessed_commitment(key.0, air_idx as u32, from_key.as_mut_ptr())
+                // The preprocessed trace and its PCS data live inside the key handle (ovm_hip_pk_load uploaded and
+                // committed them): the trait's (commitment, trace, data) triple is handed out as BORROWED views of
+                // exactly those -- no second upload, no second commit (the CUDA peer unstacks the host data once,
+                // data_transporter.rs:44-51).
+                let preprocessed_data = pk.preprocessed_data.as_ref().map(|_| {
+                    let (mut d_trace, mut width, mut height) = (ptr::null::<u32>(), 0u64, 0u64);
+                    let mut root = [0u32; 8];
+                    let mut pcs: *mut ffi::OvmPcs = ptr::null_mut();
+                    HipError::from_result("ovm_hip_pk_preprocessed_data", unsafe {
+                        ffi::ovm_hip_pk_preprocessed_data(key.0, air_idx as u32, &mut d_trace, &mut width, &mut height, root.as_mut_ptr(), &mut pcs)
                     })
-                    .expect("preprocessed commitment missing in the key");
-                    debug_assert_eq!(unsafe { std::mem::transmute::<[u32; 8], Digest>(from_key) }, commitment);
+                    .expect("preprocessed data missing in the key");
+                    // SAFETY: `F` is `repr(transparent)` over its Montgomery word; `Digest` is `[F; 8]`.
+                    let commitment: Digest = unsafe { std::mem::transmute::<[u32; 8], Digest>(root) };
+                    let buffer = DeviceBuffer::borrowed(d_trace as *const F, (width * height) as usize, key.clone());
+                    let trace = HipMatrix::new(Arc::new(buffer), height as usize, width as usize);
+                    let data = StackedPcsDataHip::borrowed(pcs, commitment, key.clone());
                     CommittedTraceData { commitment, trace, data: Arc::new(data) }
                 });
                 DeviceStarkProvingKey {

@@ -220,6 +220,15 @@ extern "C" {
         air_idx: u32,
         commitment_out: *mut u32,
     ) -> c_int;
+    pub fn ovm_hip_pk_preprocessed_data(
+        pk: *const OvmPk,
+        air_idx: u32,
+        d_trace_out: *mut *const u32,
+        width_out: *mut u64,
+        height_out: *mut u64,
+        commitment_out: *mut u32,
+        pcs_out: *mut *mut OvmPcs,
+    ) -> c_int;
     pub fn ovm_hip_program_stats(
         blob: *const u32,
         words: u64,

@@ -197,6 +197,12 @@ void ovm_hip_pk_free(ovm_pk_t *pk);
  * must equal `vk.preprocessed_data.commit` (keygen/types.rs:99-107). hipErrorInvalidValue if the
  * AIR has none. */
 int ovm_hip_pk_preprocessed_commitment(const ovm_pk_t *pk, uint32_t air_idx, uint32_t commitment_out[8]);
+/* The key's own device copy of that trace (column-major, `width` x `height` Montgomery words) and its PCS data, BORROWED:
+ * valid while the key lives, never passed to ovm_hip_pcs_free. This is what a backend hands out as
+ * `DeviceStarkProvingKey::preprocessed_data` (prover/types.rs:18-25 CommittedTraceData{commitment, trace, data};
+ * CUDA peer: data_transporter.rs:44-51) without uploading and committing the trace a second time. */
+int ovm_hip_pk_preprocessed_data(const ovm_pk_t *pk, uint32_t air_idx, const uint32_t **d_trace_out, uint64_t *width_out,
+                                 uint64_t *height_out, uint32_t commitment_out[8], ovm_pcs_t **pcs_out);
 /* Host-only self-test of the staged constraint-program form (csrc/program.h stage_program: what the
  * round-0 and GKR-leaf kernels execute): every program of every AIR of the key is staged with
  * `stage_rows` staging rows per buffer and `acc_rows` accumulation rows and run on one random row next

@@ -93,7 +93,7 @@ struct ProvingKey {
 
 // Ranges the kernels and the index arithmetic are built for (two-adicity 27 bounds every domain).
 inline void check_pcs_params(const Params &p) {
-    if (p.l_skip == 0 || p.l_skip > 10) throw OvmFail(1, "l_skip out of range (1..10)");
+    if (p.l_skip > 10) throw OvmFail(1, "l_skip out of range (0..10)");
     if (p.l_skip + p.n_stack + p.log_blowup > 27) throw OvmFail(1, "l_skip + n_stack + log_blowup exceeds the two-adicity 27");
     if (p.k_whir == 0 || p.k_whir > 8 || p.k_whir > p.l_skip + p.n_stack) throw OvmFail(1, "k_whir out of range");
     if (p.log_blowup == 0 || p.log_blowup > 8) throw OvmFail(1, "log_blowup out of range (1..8)");

@@ -3293,6 +3293,23 @@ int ovm_hip_pk_preprocessed_commitment(const ovm_pk_t *pk_, uint32_t air_idx, ui
     return 0;
 }
 
+// The key's own device copy of AIR air_idx's preprocessed trace and its PCS data, BORROWED (valid while the key lives;
+// never freed by the caller): what `DeviceStarkProvingKey::preprocessed_data` hands out, without committing the trace
+// a second time.
+int ovm_hip_pk_preprocessed_data(const ovm_pk_t *pk_, uint32_t air_idx, const uint32_t **d_trace_out, uint64_t *width_out,
+                                 uint64_t *height_out, uint32_t commitment_out[8], ovm_pcs_t **pcs_out) {
+    if (!pk_ || !d_trace_out || !width_out || !height_out || !commitment_out || !pcs_out) return (int)hipErrorInvalidValue;
+    const DeviceKey &dk = *reinterpret_cast<const DeviceKey *>(pk_);
+    if (air_idx >= dk.pre.size() || !dk.pre[air_idx]) return (int)hipErrorInvalidValue;
+    PcsData *pcs = dk.pre[air_idx].get();
+    *d_trace_out = (const uint32_t *)pcs->own_mat.p;
+    *width_out = dk.pk.airs[air_idx].preprocessed_width;
+    *height_out = dk.pk.airs[air_idx].preprocessed_height;
+    for (int i = 0; i < 8; i++) commitment_out[i] = pcs->root.d[i].v;
+    *pcs_out = reinterpret_cast<ovm_pcs_t *>(pcs);
+    return 0;
+}
+
 int ovm_hip_set_prover_config(const ovm_prover_config_t *cfg) {
     if (!cfg || cfg->round0_slab_log_rows > 30) return (int)hipErrorInvalidValue;
     ProverConfig &c = prover_config();

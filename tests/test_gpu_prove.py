@@ -267,6 +267,34 @@ def test_mixture_fixture(dev, pkg, orc):
     run_partitioned(dev, pkg, orc, airs.test_params(), air_list, traces, pre)
 
 
+def test_interactions_with_l_skip_zero(dev, pkg, orc):
+    """`test_interactions_roundtrip_with_l_skip_zero` (crates/cuda-backend/src/tests.rs:562-573): InteractionsFixture11
+    under test_system_params_small(0, 8, 3) -- no univariate skip domain at all: byte-identical to the oracle."""
+    params = airs.test_params(l_skip=0, n_stack=8, k_whir=3)
+    air_list = [airs.dummy_interaction_air(1, True, 0), airs.dummy_interaction_air(1, False, 0)]
+    traces = [(0, np.array([0, 3, 7, 546, 1, 5, 4, 889], np.uint32), 4, []),
+              (1, np.array([1, 3, 4, 2, 0, 545, 1, 0, 5, 4, 4, 5, 123, 889, 889, 456], np.uint32), 8, [])]
+    run_case(dev, pkg, orc, params, air_list, traces)
+    tr, pv = airs.fibonacci_trace(0, 1, 64)
+    run_case(dev, pkg, orc, params, [airs.fibonacci_air(), airs.uniform_runner_air(8)],
+             [(0, tr, 64, pv), (1, airs.splitmix64_bits(3, 8 * 32), 32, [])])
+
+
+@pytest.mark.parametrize("l_skip", [0, 6, 9])
+def test_mixture_fixture_other_skip_domains(dev, pkg, orc, l_skip):
+    """`test_mixture_fixture_gpu_roundtrip_large_l_skip` (crates/cuda-backend/src/tests.rs:609-624: l_skip 6 and 9,
+    n_stack = 13 - l_skip) and the degenerate l_skip = 0: cached, preprocessed, interaction and plain traces, every
+    one of them SHORTER than the skip domain for l_skip 6 and 9 (lifted traces)."""
+    c_airs, c_traces = airs.cached_fixture_11()
+    sels = [i % 2 == 0 for i in range(8)]
+    ptr, ppv = airs.fibonacci_selector_trace(0, 1, sels)
+    ftr, fpv = airs.fibonacci_trace(0, 1, 16)
+    air_list = [airs.fibonacci_air()] + c_airs + [airs.fibonacci_selector_air()]
+    pre = {3: (np.array([int(s) for s in sels], np.uint32), len(sels))}
+    traces = [(0, ftr, 16, fpv)] + [(a + 1, c, h, p, k) for a, c, h, p, k in c_traces] + [(3, ptr, len(sels), ppv)]
+    run_partitioned(dev, pkg, orc, airs.test_params(l_skip=l_skip, n_stack=13 - l_skip if l_skip else 8, k_whir=3), air_list, traces, pre)
+
+
 def test_blowup4_degree4_parity(dev, pkg, orc):
     """Leaf-like parameters (log_blowup 2, global constraint degree 4 -> 3 zerocheck / 4 logup cosets)
     at a size the oracle proves in seconds: byte-exact."""
