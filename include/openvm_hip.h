@@ -170,6 +170,7 @@ int ovm_hip_gather_digests(const uint32_t *d_layers, const uint64_t *d_idx, uint
  * `transport_pk_to_device` (reference: crates/stark-backend/src/prover/hal.rs:141-160,
  * crates/cuda-backend/src/data_transporter.rs:35-79). */
 typedef struct ovm_pk_t ovm_pk_t;
+typedef struct ovm_pcs ovm_pcs_t; /* opaque StackedPcsData: stacked matrix, codeword, Merkle layers */
 
 /* Builds a proving key from the flat u32 "proving-key blob" (all field constants CANONICAL):
  *   0x4F564D31, l_skip, n_stack, w_stack, log_blowup, k_whir, mu_pow_bits, query_phase_pow_bits,
@@ -276,7 +277,6 @@ const char *ovm_hip_last_error(void);
  * transcript state (reference: DeviceSpongeState, crates/cuda-backend/src/sponge.rs:39-48), read
  * at entry and written back at exit. Traces may be passed in any order; the stages sort them as
  * `ProvingContext::into_sorted` does (prover/types.rs:137-148). */
-typedef struct ovm_pcs ovm_pcs_t; /* opaque StackedPcsData: stacked matrix, codeword, Merkle layers */
 
 /* One AIR's proving input (reference: AirProvingContext, prover/types.rs:59-73). POD. */
 typedef struct ovm_trace {
