@@ -93,7 +93,11 @@ __device__ __forceinline__ void round0_eval_body(const Prog &prog, const Fp *lde
     __shared__ EF sh[RED_THREADS];
     const uint32_t N = 1u << l_skip;
     const uint64_t total = 1ull << log_lifted;
-    const uint64_t stride = (uint64_t)gx * RED_THREADS;  // multiple of N (N <= RED_THREADS)
+    // A lane's rows all have the same z = row mod N: the stride is a multiple of N -- for N <= RED_THREADS always, for a
+    // larger skip domain (l_skip 9: N = 512) because the launcher makes gx a multiple of N / RED_THREADS. A workgroup then
+    // covers the RED_THREADS residues from zbase on and writes zeros for the rest of its record.
+    const uint64_t stride = (uint64_t)gx * RED_THREADS;
+    const uint32_t zbase = N > RED_THREADS ? (uint32_t)(((uint64_t)bx * RED_THREADS) & (N - 1)) : 0;
     EF sums[MAX_COSETS * 2];
 #pragma unroll
     for (int i = 0; i < (int)(MAX_COSETS * 2); i++) sums[i] = EF::zero();
@@ -132,7 +136,10 @@ __device__ __forceinline__ void round0_eval_body(const Prog &prog, const Fp *lde
             if (threadIdx.x < N) {
                 EF acc = sh[threadIdx.x];
                 for (uint32_t j = threadIdx.x + N; j < RED_THREADS; j += N) acc = acc + sh[j];
-                st_ef(partials + ((size_t)bx * n_cosets * n_out + k * n_out + o) * N + threadIdx.x, acc);
+                EF *rec = partials + ((size_t)bx * n_cosets * n_out + k * n_out + o) * N;
+                st_ef(rec + zbase + threadIdx.x, acc);
+                for (uint32_t seg = 0; N > RED_THREADS && seg < N; seg += RED_THREADS)
+                    if (seg != zbase) st_ef(rec + seg + threadIdx.x, EF::zero());
                 if (fence) __threadfence();
             }
             __syncthreads();

@@ -1484,7 +1484,8 @@ struct Prover {
         // > ~2 K instructions) run their groups as extra workgroups of the job
         const uint32_t r0_groups_min = tuning().r0_groups_min >= 0 ? (uint32_t)tuning().r0_groups_min : MLE_GROUPS + 1;
         auto r0_batchable = [&](const DevStaged &staged, uint32_t log_lifted) {
-            return r0_batch && staged.blocks && log_lifted < R0_BATCH_MAX_LOG;
+            // (a skip domain larger than a workgroup goes through round0_eval, which sizes its grid in whole domains)
+            return r0_batch && staged.blocks && log_lifted < R0_BATCH_MAX_LOG && N <= RED_THREADS;
         };
         // workgroups (= partial records) the job will use
         auto r0_job_grid = [&](const DevStaged &staged, const StagedGroups *sg, uint32_t log_lifted) -> uint32_t {
@@ -2242,7 +2243,10 @@ struct Prover {
         ProfScope *ps_st0 = new ProfScope("stacked.round0", cx.stream);
         // phase A: the round-0 sums of every window are enqueued (own partial records, own mailbox slots);
         // phase B: one wait, then the host algebra per window
-        if (64 * W + 64 > Mailbox::SLOTS) throw OvmFail(801, "too many stacking windows for the mailbox");
+        // mailbox slots of a window: its 3 N round-0 sums (64 used to be assumed, which 3 * 16 fits: with l_skip >= 5 the
+        // windows of a proof with several of them overwrote each other -- found by the reference's l_skip 6 / 9 tests)
+        const size_t wslots = (3 * N + 63) & ~size_t(63);
+        if (wslots * W + 64 > Mailbox::SLOTS) throw OvmFail(801, "too many stacking windows for the mailbox");
         std::vector<DevBuf<EF>> r0_partials(W);
         bool any_own_window = false;
         for (size_t wi = 0; wi < W; wi++) {
@@ -2273,14 +2277,14 @@ struct Prover {
             for (auto &x : lrot) any_rot |= !is_zero(x);
             r0_partials[wi].alloc((size_t)RED_BLOCKS * 3 * N + 64);  // (grid * slice chunks <= RED_BLOCKS records)
             OVM_THROW_IF(stacked_round0(base, (uint32_t)(w1 - w0), log_len, l_skip, d_leq.p, any_rot ? d_lrot.p : nullptr, wd.eq_cube.p,
-                                        mb.arm(r0_partials[wi].p, 64 * wi), cx.stream));
+                                        mb.arm(r0_partials[wi].p, wslots * wi), cx.stream));
         }
         if (any_own_window) mb.wait(cx.stream);
         r0_partials.clear();
         for (size_t wi = 0; wi < W; wi++) {
             Window &wd = ws[wi];
             if (!wd.own) continue;
-            auto R = mb.read(64 * wi, 3 * N);
+            auto R = mb.read(wslots * wi, 3 * N);
             // host: chunk-aggregated vectors -> coset evaluations with the univariate factors
             std::vector<std::vector<EF>> coef(3);
             for (int v = 0; v < 3; v++) coef[v] = small_dft(std::vector<EF>(R.begin() + v * N, R.begin() + (v + 1) * N), true);

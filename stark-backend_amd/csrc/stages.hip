@@ -867,14 +867,17 @@ int round0_eval(const DevProgram &prog, const DevStaged &staged, const Fp *lde, 
                 uint32_t log_lifted, uint32_t l_skip, uint32_t n_cosets, uint32_t n_out, const EF *d_eq_xi,
                 EF add_const, const RedOut &ro, hipStream_t s) {
     if (n_cosets == 0) return 0;
-    if (n_cosets > MAX_COSETS || n_out < 1 || n_out > 2 || (1u << l_skip) > RED_THREADS)
+    if (n_cosets > MAX_COSETS || n_out < 1 || n_out > 2 || (1u << l_skip) > 4 * RED_THREADS || log_lifted < l_skip)
         return (int)hipErrorInvalidValue;
+    // a skip domain larger than a workgroup (l_skip 9, 10): the grid is a multiple of N / RED_THREADS (eval.cuh)
+    const uint32_t wg_per_domain = (1u << l_skip) > RED_THREADS ? (1u << l_skip) / RED_THREADS : 1;
+    auto whole_domains = [&](uint32_t g) { return (g + wg_per_domain - 1) / wg_per_domain * wg_per_domain; };
     int rows = round0_rows(log_lifted, n_out);
     if (staged.blocks) {
         rows = (int)staged.rows;  // fixed when the program was staged (round0_staged_rows)
         const size_t lds_bytes = (size_t)staged.num_rows * rows * RED_THREADS * 4;
         {
-            const uint32_t grid = round0_staged_grid(staged, log_lifted);
+            const uint32_t grid = whole_domains(round0_staged_grid(staged, log_lifted));
 #define LAUNCH(R, NOUT)                                                                                             \
     OVM_LAUNCH((round0_staged_kernel<R, NOUT>), dim3(grid), dim3(RED_THREADS), lds_bytes, s, staged, lde, \
                        n_cols_total, log_lifted, l_skip, n_cosets, n_out, d_eq_xi, add_const, ro.partials)
@@ -893,7 +896,7 @@ int round0_eval(const DevProgram &prog, const DevStaged &staged, const Fp *lde, 
     }
     uint64_t lanes = (1ull << log_lifted) / rows;
     if (lanes < RED_THREADS) lanes = RED_THREADS;
-    uint32_t grid = red_grid(lanes);
+    uint32_t grid = whole_domains(red_grid(lanes));
 #define LAUNCH(NS, R, NOUT)                                                                                      \
     OVM_LAUNCH((round0_eval_kernel<NS, R, NOUT>), dim3(grid), dim3(RED_THREADS), 0, s, prog, lde,       \
                        n_cols_total, log_lifted, l_skip, n_cosets, n_out, d_eq_xi, add_const, ro.partials)
@@ -1882,7 +1885,13 @@ __global__ __launch_bounds__(RED_THREADS) void stacked_round0_kernel(const Fp *b
         if (threadIdx.x < N) {
             EF acc = sh[threadIdx.x];
             for (uint32_t j = threadIdx.x + N; j < RED_THREADS; j += N) acc = acc + sh[j];
-            st_ef(partials + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 3 + v) * N + threadIdx.x, acc);
+            // (N > RED_THREADS: the grid is a power of two >= N / RED_THREADS, so a lane's positions share one residue
+            // mod N; the workgroup covers the residues from zbase on and zero-fills the rest of its record)
+            const uint32_t zbase = N > RED_THREADS ? (blockIdx.x * RED_THREADS) & (N - 1) : 0;
+            EF *rec = partials + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 3 + v) * N;
+            st_ef(rec + zbase + threadIdx.x, acc);
+            for (uint32_t seg = 0; N > RED_THREADS && seg < N; seg += RED_THREADS)
+                if (seg != zbase) st_ef(rec + seg + threadIdx.x, EF::zero());
         }
         __syncthreads();
     }
@@ -1897,8 +1906,8 @@ uint32_t stacked_round0_chunks(uint32_t n_slices, uint32_t log_len) {
 }
 int stacked_round0(const Fp *base, uint32_t n_slices, uint32_t log_len, uint32_t l_skip, const EF *d_lam_eq,
                    const EF *d_lam_rot, const EF *d_eq_cube, const RedOut &ro, hipStream_t s) {
-    if ((1u << l_skip) > RED_THREADS) return (int)hipErrorInvalidValue;
-    uint32_t grid = red_grid(1ull << log_len);
+    if ((1u << l_skip) > 4 * RED_THREADS || log_len < l_skip) return (int)hipErrorInvalidValue;
+    uint32_t grid = red_grid(1ull << log_len);  // a power of two >= 2^l_skip / RED_THREADS
     const uint32_t chunks = stacked_round0_chunks(n_slices, log_len);
     OVM_LAUNCH(stacked_round0_kernel, dim3(grid, chunks), dim3(RED_THREADS), 0, s, base, n_slices, log_len, l_skip,
                        d_lam_eq, d_lam_rot, d_eq_cube, ro.partials);

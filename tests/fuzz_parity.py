@@ -46,9 +46,12 @@ def main():
         cfg = dict(cache_rs_code_matrix=bool(rng.integers(0, 2)), zerocheck_save_memory=bool(rng.integers(0, 2)),
                    round0_slab_log_rows=int(rng.integers(1, 7)), gkr_drop_leaves=bool(rng.integers(0, 2)))
         pkg.set_prover_config(**cfg)
-        l_skip = int(rng.integers(1, 5))
+        # skip domains 2^0 .. 2^9 (the reference's GPU backend accepts 0..9: crates/cuda-backend/src/tests.rs:562-641);
+        # round 3 found two bugs at l_skip >= 5 and 9 that the 1..4 of rounds 1-2 could not reach
+        l_skip = int(rng.choice([0, 1, 2, 3, 4, 1, 2, 3, 4, 5, 6, 7, 8, 9]))
         deg = int(rng.choice([3, 4]))
-        params = airs.test_params(l_skip=l_skip, n_stack=int(rng.integers(8, max(11, args.max_log_height + 1))), k_whir=int(rng.integers(1, 4)))
+        n_stack = max(int(rng.integers(8, max(11, args.max_log_height + 1))) - max(l_skip - 4, 0), 4)
+        params = airs.test_params(l_skip=l_skip, n_stack=n_stack, k_whir=int(rng.integers(1, 4)))
         params["max_constraint_degree"] = deg
         air_list, traces = [], []
         for i in range(int(rng.integers(1, 6))):

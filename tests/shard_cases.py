@@ -28,9 +28,9 @@ def _fuzz(seed, world):
     """A random multi-AIR context (as tests/fuzz_parity.py draws them) with a random non-decreasing assignment of the
     sorted traces to ranks -- ranks may own several traces or none."""
     rng = np.random.default_rng(seed)
-    l_skip = int(rng.integers(1, 5))
+    l_skip = int(rng.choice([0, 1, 2, 3, 4, 1, 2, 3, 4, 5, 6, 9]))
     deg = int(rng.choice([3, 4]))
-    params = airs.test_params(l_skip=l_skip, n_stack=int(rng.integers(8, 11)), k_whir=int(rng.integers(1, 4)))
+    params = airs.test_params(l_skip=l_skip, n_stack=max(int(rng.integers(8, 11)) - max(l_skip - 4, 0), 4), k_whir=int(rng.integers(1, 4)))
     params["max_constraint_degree"] = deg
     air_list, traces = [], []
     for i in range(int(rng.integers(1, 7))):
