@@ -168,6 +168,10 @@ def main():
                          "or host staging through shared memory (the pre-flight falls back along this chain by itself)")
     ap.add_argument("--launch-check", action="store_true",
                     help="only start the ranks, rendezvous (gloo when there is no GPU) and print n_gpus: the launcher's CPU test")
+    ap.add_argument("--profile-steps", type=int, default=-1,
+                    help="fully profiled steps AFTER the timed region that stage_ms / roofline.classes come from (default: "
+                         "min(steps, 3); 0: none -- what tools/profile_round.sh uses so that the process makes exactly "
+                         "warmup + steps proofs)")
     ap.add_argument("--dry-run", action="store_true",
                     help="N > 1: rendezvous, the pre-flight of the bulk exchange, then the two collectives of the mu-batch sum and "
                          "one transfer per peer at the FULL vector size (2^log_stacked_height x 16 B = 268 MB at config D), timed; "
@@ -285,16 +289,18 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     prof_dom = pkg.profile_report()
-    prof_steps = max(1, min(args.steps, 3))
-    pkg.profile_enable(1)
-    barrier()
-    for _ in range(prof_steps):
-        step()
-    barrier()
-    prof = pkg.profile_report()
+    prof_steps = max(1, min(args.steps, 3)) if args.profile_steps < 0 else args.profile_steps
+    prof = {}
+    if prof_steps:
+        pkg.profile_enable(1)
+        barrier()
+        for _ in range(prof_steps):
+            step()
+        barrier()
+        prof = pkg.profile_report()
     pkg.profile_enable(0)
     elapsed = pkg.max_over_ranks(elapsed, "cpu" if args.one_gpu else devname)
-    stages_mine = {k: v[1] / prof_steps for k, v in prof.items()}
+    stages_mine = {k: v[1] / max(prof_steps, 1) for k, v in prof.items()}
     dist_info, stages_ranks = None, None
     if world > 1:
         # positive evidence of what ran: the process group's backend and size as torch reports
@@ -338,35 +344,41 @@ def main():
             algo_bytes = 4 * rows * width + 32 * rows // rows_per_query
             achieved = algo_bytes / (avg_ms * 1e-3) / 1e9
             traffic, src = None, None
-            pmc = os.path.join(ROOT, "profiles", "r02", "pmc_hbm_traffic_r02.json")
+            pmc = next((q for q in (os.path.join(ROOT, "profiles", "r03", "pmc_hbm_traffic_r03.json"),
+                                    os.path.join(ROOT, "profiles", "r02", "pmc_hbm_traffic_r02.json")) if os.path.exists(q)), "")
             if world == 1 and (log_rows, cols, args.log_stacked_height, args.log_blowup) == (22, 100, 24, 1) and os.path.exists(pmc):
                 k = json.load(open(pmc))["kernels"].get("hash_rows_kernel<1>")
                 if k:
                     traffic = int((k["fetch_bytes_corrected"] + k["write_bytes"]) // k["launches"])
-                    src = "profiles/r02/pmc_hbm_traffic_r02.json (separate --pmc FETCH_SIZE / WRITE_SIZE passes of this command)"
+                    src = os.path.relpath(pmc, ROOT) + " (separate --pmc FETCH_SIZE / WRITE_SIZE passes of this command)"
             roof = {"kernel": "hash_rows_kernel<1> (Poseidon2 leaf hash of the codeword; VALU-bound, see issue_bound)",
                     "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": src,
                     "avg_launch_ms": round(avg_ms, 3), "algorithmic_bytes": algo_bytes, "launches_timed": calls}
-            # VALU view of the same kernel. 7233 VALU instructions per permutation (static count, tools/isa_count.py).
+            # VALU view of the same kernel. VALU instructions per permutation (static counts of the four forms a row's
+            # permutations take, round 3: first one 7104 -- zero capacity --, middle ones 7218, last one 7194 -- only the
+            # digest words; 7233 each in round 2), averaged over the permutations of a row.
             # Peaks: (a) MI355X_MICROARCH.md's SIMD-32 figure, one wave64 VALU instruction per 2 cycles per SIMD
             # (256 CUs x 4 SIMDs x 32 lanes x 2.4 GHz); (b) the MEASURED ceiling of this instruction mix: the same
             # permutation code on register-resident states, no memory (tools/ubench_poseidon2.hip ->
             # profiles/r02/poseidon2_mix_ceiling.json), which is what bounds the kernel in practice.
-            perms = rows * ((width + 7) // 8)
+            ppr = (width + 7) // 8
+            valu_pp = round((7104 + 7194 + 7218 * (ppr - 2)) / ppr) if ppr >= 2 else 7080
+            perms = rows * ppr
             props = torch.cuda.get_device_properties(local_rank)
             guide_peak = props.multi_processor_count * 4 * 32 * 2.4e9
-            ib = {"valu_instr_per_permutation": 7233, "permutations_per_launch": perms,
+            ib = {"valu_instr_per_permutation": valu_pp, "permutations_per_launch": perms,
                   "achieved_Gperm_s": round(perms / (avg_ms * 1e-3) / 1e9, 3),
-                  "achieved_Tlaneops": round(7233 * perms / (avg_ms * 1e-3) / 1e12, 2),
+                  "achieved_Tlaneops": round(valu_pp * perms / (avg_ms * 1e-3) / 1e12, 2),
                   "guide_simd32_peak_Tlaneops": round(guide_peak / 1e12, 2),
-                  "frac_of_guide_peak": round(7233 * perms / (avg_ms * 1e-3) / guide_peak, 3)}
-            ceil_path = os.path.join(ROOT, "profiles", "r02", "poseidon2_mix_ceiling.json")
+                  "frac_of_guide_peak": round(valu_pp * perms / (avg_ms * 1e-3) / guide_peak, 3)}
+            ceil_path = next((q for q in (os.path.join(ROOT, "profiles", "r03", "poseidon2_mix_ceiling.json"),
+                                          os.path.join(ROOT, "profiles", "r02", "poseidon2_mix_ceiling.json")) if os.path.exists(q)), "")
             if os.path.exists(ceil_path):
                 c = json.load(open(ceil_path))
                 ib["measured_mix_ceiling_Gperm_s"] = c["gperm_per_s"]
                 ib["frac_of_measured_ceiling"] = round(ib["achieved_Gperm_s"] / c["gperm_per_s"], 3)
-                ib["ceiling_source"] = "profiles/r02/poseidon2_mix_ceiling.json"
+                ib["ceiling_source"] = os.path.relpath(ceil_path, ROOT)
             roof["issue_bound"] = ib
             if world == 1:
                 gkr_leaves = 26 * h  # 13 send/receive pairs -> 26 interactions per row (padding leaves are never materialised)
@@ -420,7 +432,7 @@ def main():
             "dominant_stage": dom,
         }
         if shard is not None:
-            line["config"]["bulk_exchange_bytes_per_proof"] = shard.bulk_bytes // (args.steps + args.warmup + prof_steps)
+            line["config"]["bulk_exchange_bytes_per_proof"] = shard.bulk_bytes // max(args.steps + args.warmup + prof_steps, 1)
             line["dist"] = dist_info
             line["stage_ms_per_rank"] = [{k: round(v, 3) for k, v in sr.items()} for sr in stages_ranks]
         print(json.dumps(line), flush=True)

@@ -26,9 +26,18 @@ def main():
             if names[-L:] == names[-2 * L:-L]:
                 best = L
                 break
-        if not best:
-            raise SystemExit("no repeated kernel sequence at the end of the trace")
-        rows = rows[-best:]
+        if best:
+            rows = rows[-best:]
+        else:
+            # the first prove of a process also runs one-time initialisation kernels (fills of freshly allocated pages),
+            # so the two sequences need not be equal: cut at the second launch of the first kernel that runs exactly once
+            # per prove
+            count = collections.Counter(names)
+            first = next((i for i, n in enumerate(names) if count[n] == 2), None)
+            if first is None:
+                raise SystemExit("no kernel that runs once per prove: cannot find the timed prove")
+            second = max(i for i, n in enumerate(names) if n == names[first])
+            rows = rows[second:]
     busy = sum(e - s for _, s, e in rows)
     span = rows[-1][2] - rows[0][1]
     per = collections.defaultdict(lambda: [0, 0])

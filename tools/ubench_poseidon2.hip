@@ -17,7 +17,7 @@
 
 using bb::Fp;
 static constexpr int ITER = 256;
-static constexpr int VALU_PER_PERM = 7233;  // tools/isa_count.py on merkle.hip
+static constexpr int VALU_PER_PERM = 7218;  // the full permutation (p2::permute), static count; round 2: 7233
 
 // ticks[0] = shader cycles (s_memtime), ticks[1] = 100 MHz reference ticks (s_memrealtime) of one wave's loop, taken in a
 // workgroup from the middle of the grid (every SIMD is full then): the clock the loop ran at is their ratio x 100 MHz
