@@ -24,9 +24,14 @@ enum OperandKind : uint8_t { K_SLOT = 0, K_COL, K_CONST };
 
 struct Instr {
     uint8_t op, ak, bk, acc;
-    uint16_t dst, pad;
+    uint16_t dst, fwd;  // fwd: FWD_* hints (an executor may ignore them: they never change what is computed)
     uint32_t a, b;  // operand payloads: slot / flat column / Montgomery constant / weight index
 };
+// Forwarding hints: operand a / b (a slot) is the result of the instruction right before this one, and -- NOSTORE, set on
+// that earlier instruction -- nothing but the next instruction ever reads its result. An executor that keeps the last
+// result in registers skips the slot read, and for NOSTORE the slot write as well (stages.hip:
+// mle_round_points_lds_kernel, where slot traffic is LDS bandwidth).
+enum : uint16_t { FWD_A = 1, FWD_B = 2, FWD_NOSTORE = 4 };
 static_assert(sizeof(Instr) == 16, "Instr is 16 bytes");
 
 struct Program {
@@ -234,6 +239,21 @@ inline Program compile_program_with(const AirKey &air, const ColumnMap &cm, cons
             slot_of[o.node] = -2;
         }
     };
+    // forwarding hints (see FWD_*): `in` is about to be appended and reads operands l (and r)
+    auto mark_forwards = [&](Instr &in, const Operand &l, const Operand *r) {
+        if (prog.code.empty()) return;
+        Instr &prev = prog.code.back();
+        if (prev.op > OP_NEG) return;  // (only arithmetic instructions produce a slot value)
+        const bool fa = l.kind == K_SLOT && l.node >= 0 && l.payload == prev.dst;
+        const bool fb = r && r->kind == K_SLOT && r->node >= 0 && r->payload == prev.dst;
+        if (!fa && !fb) return;
+        if (fa) in.fwd |= FWD_A;
+        if (fb) in.fwd |= FWD_B;
+        // the value dies here when these reads are all that is left of it (a recomputed node's instance has one reader)
+        const Operand &o = fa ? l : *r;
+        const uint32_t reads = (fa ? 1u : 0u) + (fb ? 1u : 0u);
+        if (remat((uint32_t)o.node) || uses[o.node] == reads) prev.fwd |= FWD_NOSTORE;
+    };
     // value of `node` as an operand, emitting whatever it takes (explicit stack: an expression can be thousands deep)
     struct Frame {
         uint32_t node;
@@ -276,6 +296,7 @@ inline Program compile_program_with(const AirKey &air, const ColumnMap &cm, cons
             if (bin) in.bk = r.kind, in.b = r.payload;
             const uint32_t s = take_slot();  // (before the operands' slots are recycled: dst never aliases an operand)
             in.dst = (uint16_t)s;
+            mark_forwards(in, l, bin ? &r : nullptr);
             prog.code.push_back(in);
             consumed(l);
             if (bin) consumed(r);
@@ -304,6 +325,7 @@ inline Program compile_program_with(const AirKey &air, const ColumnMap &cm, cons
         in.acc = r.acc;
         in.ak = o.kind, in.a = o.payload;
         in.b = r.weight;
+        mark_forwards(in, o, nullptr);
         prog.code.push_back(in);
         consumed(o);
     }
@@ -604,19 +626,64 @@ struct GroupedProgram {
     std::vector<uint32_t> off;  // n_groups + 1 offsets into code
     uint32_t max_slots = 1;
 };
+// `slot_target`: the groups are what the multilinear rounds interpret on extension-field values, D points at a time,
+// with their slots in LDS (stages.hip: mle_round_points_lds_kernel): a group qualifies with at most 19 / D slots, so the
+// compiler is asked for that few (it recomputes cheap shared nodes until the group fits or its code would double).
+inline uint32_t mle_slot_target(uint32_t points) { return std::max<uint32_t>(2, 19 / std::max<uint32_t>(points, 1)); }
 inline GroupedProgram compile_grouped(const AirKey &air, const ColumnMap &cm, const std::vector<Fp> &public_values,
-                                      const std::vector<Root> &roots, uint32_t num_weights, uint32_t n_groups) {
+                                      const std::vector<Root> &roots, uint32_t num_weights, uint32_t n_groups,
+                                      uint32_t slot_target = PROGRAM_SLOT_TARGET) {
     GroupedProgram g;
     if (n_groups < 1) n_groups = 1;
     if (n_groups > roots.size()) n_groups = roots.empty() ? 1 : (uint32_t)roots.size();
+    // Groups are runs of consecutive roots of about equal COST (instructions of the roots' expression trees), not of equal
+    // root count: the real Keccak-f AIR mixes 3-instruction boolean checks with 330-instruction limb constraints, and with
+    // 25 roots per group the longest group was ~100x the shortest -- the grouped kernels ran at 0.6 waves per SIMD waiting
+    // for it (SQ counters, round 3).
+    std::vector<uint64_t> prefix(roots.size() + 1, 0);
+    {
+        size_t n = 0;
+        for (auto &r : roots) n = std::max(n, (size_t)r.node + 1);
+        if (n > air.nodes.size()) throw OvmFail(1, "program compiler: root out of range");
+        // cost of a root = the distinct operation nodes its expression reaches (what a group of its own would emit,
+        // give or take recomputation); a tree count would double at every `x + x`
+        std::vector<uint32_t> seen(n, 0);
+        std::vector<uint32_t> stack;
+        for (size_t r = 0; r < roots.size(); r++) {
+            const uint32_t stamp = (uint32_t)r + 1;
+            uint64_t c = 1;
+            stack.assign(1, roots[r].node);
+            while (!stack.empty()) {
+                const uint32_t i = stack.back();
+                stack.pop_back();
+                const Node &nd = air.nodes[i];
+                if (nd.kind < N_ADD || seen[i] == stamp) continue;
+                seen[i] = stamp;
+                c++;
+                stack.push_back(nd.left);
+                if (nd.kind != N_NEG) stack.push_back(nd.right);
+            }
+            prefix[r + 1] = prefix[r] + c;
+        }
+    }
     g.off.push_back(0);
+    size_t lo = 0;
     for (uint32_t k = 0; k < n_groups; k++) {
-        size_t lo = roots.size() * k / n_groups, hi = roots.size() * (k + 1) / n_groups;
+        // the group ends where the cost prefix passes its share; every group gets at least one root
+        size_t hi = lo + 1;
+        const uint64_t want = prefix.back() * (k + 1) / n_groups;
+        while (hi < roots.size() && prefix[hi] < want && roots.size() - hi > n_groups - 1 - k) hi++;
+        if (k + 1 == n_groups) hi = roots.size();
+        if (lo >= roots.size()) {  // (fewer roots than groups cannot happen: n_groups <= roots.size())
+            g.off.push_back((uint32_t)g.code.size());
+            continue;
+        }
         std::vector<Root> sub(roots.begin() + lo, roots.begin() + hi);
-        Program p = compile_program(air, cm, public_values, sub, num_weights);
+        Program p = compile_program(air, cm, public_values, sub, num_weights, slot_target);
         g.code.insert(g.code.end(), p.code.begin(), p.code.end());
         g.off.push_back((uint32_t)g.code.size());
         g.max_slots = std::max(g.max_slots, p.num_slots);
+        lo = hi;
     }
     return g;
 }

@@ -905,12 +905,14 @@ struct Prover {
             {
                 const std::vector<Root> roots = roots_zerocheck(a);
                 out[t].zc = compile_program(a, cm, pv, roots, 0);
-                if (tall) out[t].zc_g = compile_grouped(a, cm, pv, roots, 0, mle_groups_for(out[t].zc.code.size()));
+                if (tall) out[t].zc_g = compile_grouped(a, cm, pv, roots, 0, mle_groups_for(out[t].zc.code.size()),
+                                                        mle_slot_target(pk.params.max_constraint_degree));
             }
             if (!a.interactions.empty()) {
                 const std::vector<Root> roots = roots_logup(a);
                 out[t].lg = compile_program(a, cm, pv, roots, 0);
-                if (tall) out[t].lg_g = compile_grouped(a, cm, pv, roots, 0, mle_groups_for(out[t].lg.code.size()));
+                if (tall) out[t].lg_g = compile_grouped(a, cm, pv, roots, 0, mle_groups_for(out[t].lg.code.size()),
+                                                        mle_slot_target(pk.params.max_constraint_degree));
                 out[t].leaves = compile_program(a, cm, pv, roots_leaves(a), 0);
             }
         }
@@ -3168,6 +3170,8 @@ Tuning ovm::Tuning::from_env() {
     t.stage_kib = (uint32_t)std::max(1, num("OVM_STAGE_KIB", 36));
     t.mle_points_in_lane = !off("OVM_MLE_POINTS");
     t.r0_batch = !off("OVM_R0_BATCH");
+    t.mle_lds_slots = !off("OVM_MLE_LDS");
+    t.mle_forward = !off("OVM_MLE_FWD");
     t.r0_groups_min = num("OVM_R0_GROUPS_MIN", -1);
     t.mle_batch_wgs = (uint32_t)std::max(0, num("OVM_MLE_BATCH", 256));
     t.mle_groups_max = (uint32_t)std::max(1, num("OVM_MLE_GROUPS_MAX", 128));

@@ -1122,6 +1122,153 @@ __global__ __launch_bounds__(RED_THREADS) void mle_round_points_kernel(const Ins
     finish_reduction<8>(ro, gridDim.x * gridDim.z, 2 * D);
 }
 
+// ---- the same kernel with its slots in LDS and the column operands of a block of instructions in flight together ------
+// mle_eval_points keeps EF slots[NS][D] in a dynamically indexed array, which the compiler places in scratch memory:
+// every interpreted instruction then reads up to 2 x D x 16 bytes of scratch and writes D x 16 (400 B of private segment,
+// 150 VGPRs), and a column operand is a dependent global load issued where it is used. On the real Keccak-f AIR
+// (42 514 instructions, 6 slots, 2^20 rows: config B) that is ~600 GB of scratch traffic per proof and the multilinear
+// rounds took 113 ms of a 413 ms proof. Here:
+//   * slot s, point x, limb c of this lane is the LDS word ((s * D + x) * 4 + c) * RED_THREADS + lane (conflict-free,
+//     nothing in scratch); the image is num_slots x D KiB per workgroup, so programs of up to MLE_LDS_MAX_ROWS / D slots
+//     qualify (two workgroups per CU) -- the demand-driven compiler of round 3 gets the real programs there;
+//   * instructions go in blocks of MLE_BLOCK: first every column operand of the block is requested (t0, t1 of the pair,
+//     static register indices), then the block runs -- the loads of a block overlap each other and, with a second
+//     resident workgroup, the arithmetic of the other one.
+static constexpr int MLE_BLOCK = 4;
+static constexpr uint32_t MLE_LDS_MAX_ROWS = 19;  // num_slots * D (KiB of LDS per workgroup): 2 workgroups per CU
+template <int D>
+__global__ __launch_bounds__(RED_THREADS) void mle_round_points_lds_kernel(const Instr *code, const uint32_t *off,
+                                                                           const EF *weights, const EF *mats,
+                                                                           uint32_t log_h, uint32_t n_out, const EF *eq,
+                                                                           EF add_const, RedOut ro, uint32_t fwd_mask) {
+    extern __shared__ uint32_t mle_lds[];
+    const uint32_t grp = blockIdx.z;
+    const Instr *gcode = code + off[grp];
+    const uint32_t n_instr = off[grp + 1] - off[grp];
+    uint32_t *mine = mle_lds + threadIdx.x;
+    auto slot_ld = [&](uint32_t s, EF (&v)[D]) {
+#pragma unroll
+        for (int x = 0; x < D; x++)
+#pragma unroll
+            for (int c = 0; c < 4; c++) v[x].c[c] = Fp::raw(mine[((s * D + x) * 4 + c) * RED_THREADS]);
+    };
+    auto slot_st = [&](uint32_t s, const EF (&v)[D]) {
+#pragma unroll
+        for (int x = 0; x < D; x++)
+#pragma unroll
+            for (int c = 0; c < 4; c++) mine[((s * D + x) * 4 + c) * RED_THREADS] = v[x].c[c].v;
+    };
+    const uint64_t n_y = 1ull << (log_h - 1);
+    const uint64_t stride = (uint64_t)gridDim.x * RED_THREADS;
+    EF sums[2 * D];
+#pragma unroll
+    for (int k = 0; k < 2 * D; k++) sums[k] = EF::zero();
+    const EF first_const = grp == 0 ? add_const : EF::zero();
+    EF prev[D];  // the result of the instruction before (program.h FWD_*: forwarded operands skip the LDS round trip)
+#pragma unroll
+    for (int x = 0; x < D; x++) prev[x] = EF::zero();
+    for (uint64_t y = (uint64_t)blockIdx.x * RED_THREADS + threadIdx.x; y < n_y; y += stride) {
+        EF out[D][2];
+#pragma unroll
+        for (int x = 0; x < D; x++) {
+            out[x][0] = EF::zero();
+            out[x][1] = first_const;
+        }
+        for (uint32_t pc0 = 0; pc0 < n_instr; pc0 += MLE_BLOCK) {
+            // phase 1: the pairs (t0, t1) of every column operand of the block
+            EF pa[MLE_BLOCK][2], pb[MLE_BLOCK][2];
+#pragma unroll
+            for (int j = 0; j < MLE_BLOCK; j++) {
+                if (pc0 + j < n_instr) {
+                    const Instr in = gcode[pc0 + j];
+                    if (in.ak == K_COL) {
+                        const EF *q = mats + ((uint64_t)in.a << log_h) + 2 * y;
+                        pa[j][0] = ld_ef(q), pa[j][1] = ld_ef(q + 1);
+                    }
+                    if (in.op <= OP_MUL && in.bk == K_COL) {
+                        const EF *q = mats + ((uint64_t)in.b << log_h) + 2 * y;
+                        pb[j][0] = ld_ef(q), pb[j][1] = ld_ef(q + 1);
+                    }
+                }
+            }
+            // phase 2: run the block
+#pragma unroll
+            for (int j = 0; j < MLE_BLOCK; j++) {
+                if (pc0 + j >= n_instr) break;
+                Instr in = gcode[pc0 + j];
+                in.fwd &= (uint16_t)fwd_mask;  // (OVM_MLE_FWD=0: ignore the forwarding hints)
+                EF a[D], b[D];
+                auto operand = [&](uint8_t kind, uint32_t payload, const EF (&pre)[2], EF (&v)[D]) {
+                    if (kind == K_SLOT) {
+                        slot_ld(payload, v);
+                    } else if (kind == K_COL) {
+                        const EF d = pre[1] - pre[0];
+                        v[0] = pre[1];
+#pragma unroll
+                        for (int x = 1; x < D; x++) v[x] = v[x - 1] + d;
+                    } else {
+                        const EF cst = EF::from_base(Fp::raw(payload));
+#pragma unroll
+                        for (int x = 0; x < D; x++) v[x] = cst;
+                    }
+                };
+                if (in.fwd & FWD_A) {
+#pragma unroll
+                    for (int x = 0; x < D; x++) a[x] = prev[x];
+                } else {
+                    operand(in.ak, in.a, pa[j], a);
+                }
+                if (in.op <= OP_MUL) {
+                    if (in.fwd & FWD_B) {
+#pragma unroll
+                        for (int x = 0; x < D; x++) b[x] = prev[x];
+                    } else {
+                        operand(in.bk, in.b, pb[j], b);
+                    }
+                    EF r[D];
+                    if (in.op == OP_ADD) {
+#pragma unroll
+                        for (int x = 0; x < D; x++) r[x] = a[x] + b[x];
+                    } else if (in.op == OP_SUB) {
+#pragma unroll
+                        for (int x = 0; x < D; x++) r[x] = a[x] - b[x];
+                    } else {
+#pragma unroll
+                        for (int x = 0; x < D; x++) r[x] = a[x] * b[x];
+                    }
+                    if (!(in.fwd & FWD_NOSTORE)) slot_st(in.dst, r);
+#pragma unroll
+                    for (int x = 0; x < D; x++) prev[x] = r[x];
+                } else if (in.op == OP_NEG) {
+                    EF r[D];
+#pragma unroll
+                    for (int x = 0; x < D; x++) r[x] = -a[x];
+                    if (!(in.fwd & FWD_NOSTORE)) slot_st(in.dst, r);
+#pragma unroll
+                    for (int x = 0; x < D; x++) prev[x] = r[x];
+                } else {  // OP_ACC
+                    const EF::Pre w = ld_ef(weights + in.b).pre();
+                    if (in.acc) {
+#pragma unroll
+                        for (int x = 0; x < D; x++) out[x][1] = out[x][1] + a[x] * w;
+                    } else {
+#pragma unroll
+                        for (int x = 0; x < D; x++) out[x][0] = out[x][0] + a[x] * w;
+                    }
+                }
+            }
+        }
+        const EF::Pre e = ld_ef(eq + y).pre();
+#pragma unroll
+        for (int x = 0; x < D; x++) {
+            sums[2 * x] = sums[2 * x] + out[x][0] * e;
+            if (n_out > 1) sums[2 * x + 1] = sums[2 * x + 1] + out[x][1] * e;
+        }
+    }
+    block_sum_out<2 * D>(sums, ro, ((size_t)(blockIdx.x * gridDim.z + grp)) * (2 * D));
+    finish_reduction<8>(ro, gridDim.x * gridDim.z, 2 * D);
+}
+
 // OVM_MLE_POINTS=0 selects the one-point-per-lane kernel for the large rounds too (A/B and parity tests)
 static bool mle_points_in_lane() { return tuning().mle_points_in_lane; }
 
@@ -1239,6 +1386,21 @@ int mle_round_eval_grouped(const Instr *d_code, const uint32_t *d_off, uint32_t 
                            const EF *d_eq, EF add_const, const RedOut &ro, hipStream_t s) {
     if (degree == 0 || degree > 4 || n_out > 2 || log_h == 0 || n_groups == 0) return (int)hipErrorInvalidValue;
     const uint32_t gx = mle_round_gx(log_h, degree, n_groups, mle_points_in_lane());
+    if (mle_points_in_lane() && tuning().mle_lds_slots && max_slots * degree <= MLE_LDS_MAX_ROWS) {
+        dim3 grid(gx, 1, n_groups);
+        const size_t lds_bytes = (size_t)max_slots * degree * 4 * RED_THREADS * sizeof(uint32_t);
+#define CALLD(DD)                                                                                                        \
+    OVM_LAUNCH((mle_round_points_lds_kernel<DD>), grid, dim3(RED_THREADS), lds_bytes, s, d_code, d_off, d_weights, mats, \
+                       log_h, n_out, d_eq, add_const, red_inline(ro, gx * n_groups, 2 * degree),               \
+                       tuning().mle_forward ? 0xFFFFu : 0u)
+        if (degree == 1) CALLD(1);
+        else if (degree == 2) CALLD(2);
+        else if (degree == 3) CALLD(3);
+        else CALLD(4);
+#undef CALLD
+        OVM_CHECK_LAUNCH();
+        return red_finish(ro, gx * n_groups, gx * n_groups, 2 * degree, s);
+    }
     if (mle_points_in_lane()) {
         dim3 grid(gx, 1, n_groups);
 #define CALLD(NS, DD)                                                                                                  \

@@ -14,6 +14,8 @@ struct Tuning {
     int acc_rows = 0;              // OVM_ACC_ROWS: LDS accumulation rows (0: from the budget)
     uint32_t stage_kib = 36;       // OVM_STAGE_KIB: LDS image budget per workgroup
     bool mle_points_in_lane = true;  // OVM_MLE_POINTS=0: one evaluation point per lane in the large rounds too
+    bool mle_lds_slots = true;     // OVM_MLE_LDS=0: the large multilinear rounds keep their slots in private memory (rounds 1-2)
+    bool mle_forward = true;       // OVM_MLE_FWD=0: the LDS-slot kernel ignores the compiler's forwarding hints
     bool r0_batch = true;          // OVM_R0_BATCH=0: every trace's round 0 its own launch
     int r0_groups_min = -1;        // OVM_R0_GROUPS_MIN: programs of at least this many groups run grouped (-1: default)
     uint32_t mle_batch_wgs = 256;  // OVM_MLE_BATCH: jobs up to this many workgroups share a launch (0: none)
