@@ -34,7 +34,7 @@ struct DevStaged {
 struct StagedPlan {
     uint32_t rows = 0, stage_rows = 0, acc_rows = 0;
 };
-StagedPlan round0_staged_plan(uint32_t log_lifted, uint32_t n_out, uint32_t num_slots);
+StagedPlan round0_staged_plan(uint32_t log_lifted, uint32_t n_out, uint32_t num_slots, uint32_t n_instr = 0);
 
 // ro.out[k] = sum_b ro.partials[b * K + k], then the flag (for reductions with many outputs)
 int sum_partials(const RedOut &ro, uint32_t n_blocks, uint32_t K, hipStream_t s);

@@ -784,7 +784,7 @@ struct Prover {
                       uint32_t n_out = 1) {
         ProgDev d;
         d.weights = cx.upload(weights);
-        const StagedPlan plan = staged ? round0_staged_plan(log_lifted, n_out, p.num_slots) : StagedPlan();
+        const StagedPlan plan = staged ? round0_staged_plan(log_lifted, n_out, p.num_slots, (uint32_t)p.code.size()) : StagedPlan();
         if (plan.rows == 0) {
             d.code = cx.upload(p.code);
             d.prog = std::move(p);
@@ -3167,7 +3167,7 @@ Tuning ovm::Tuning::from_env() {
     t.r0_rows = num("OVM_R0_ROWS", 0);
     t.stage_rows = num("OVM_STAGE_ROWS", 0);
     t.acc_rows = num("OVM_ACC_ROWS", 0);
-    t.stage_kib = (uint32_t)std::max(1, num("OVM_STAGE_KIB", 36));
+    t.stage_kib = (uint32_t)std::max(0, num("OVM_STAGE_KIB", 0));
     t.mle_points_in_lane = !off("OVM_MLE_POINTS");
     t.r0_batch = !off("OVM_R0_BATCH");
     t.mle_lds_slots = !off("OVM_MLE_LDS");

@@ -753,11 +753,17 @@ static int round0_rows(uint32_t log_lifted, uint32_t n_out) {
 // scalar work per field operation) against LDS per workgroup (R KiB per LDS row), i.e. resident
 // waves. Measured on the Keccak-shaped program: 4 workgroups per CU (<= 36 KiB of image) with R = 2
 // and the rest of the budget split between the two staging buffers and the accumulation rows.
-StagedPlan round0_staged_plan(uint32_t log_lifted, uint32_t n_out, uint32_t num_slots) {
+// A LONG program on a tall trace gets twice the image (2 workgroups per CU instead of 4) so that it runs R = 4 rows per
+// lane with room for staging: measured on the real Keccak-f AIR (42.5 K instructions, 6 slots, 2^20 rows) round 0 takes
+// 66.2 ms with 36 KiB, 52.8 with 72-80 KiB and 101 with 104+ (one workgroup per CU); on config D's 300-instruction program
+// the larger image is 0.3 ms slower, hence the threshold (profiles/r03/round0_layout_sweep.txt).
+// The larger image is taken only when it buys MORE ROWS PER LANE than the 36 KiB plan has (the Keccak-shaped stand-in,
+// 2 slots, already runs R = 4 at 36 KiB and loses 2.6 ms of 9.7 with the larger image).
+static constexpr uint32_t R0_LONG_PROGRAM = 4096, R0_LONG_PROGRAM_KIB = 72;
+static StagedPlan staged_plan_for_budget(uint32_t log_lifted, uint32_t n_out, uint32_t num_slots, uint32_t first_budget) {
     StagedPlan plan;
     const Tuning &tn = tuning();  // (tuning / parity-test overrides)
     for (int rows = round0_rows(log_lifted, n_out); rows >= 1; rows >>= 1) {
-        const uint32_t first_budget = tn.stage_kib;
         for (uint32_t budget_kib : {first_budget, 56u}) {
             if (budget_kib > first_budget && rows > 1) continue;  // a larger image only as the last resort
             const uint32_t budget_rows = budget_kib / (uint32_t)rows;
@@ -771,6 +777,13 @@ StagedPlan round0_staged_plan(uint32_t log_lifted, uint32_t n_out, uint32_t num_
         }
     }
     return plan;  // rows == 0: does not fit, use the plain interpreter
+}
+StagedPlan round0_staged_plan(uint32_t log_lifted, uint32_t n_out, uint32_t num_slots, uint32_t n_instr) {
+    if (tuning().stage_kib) return staged_plan_for_budget(log_lifted, n_out, num_slots, tuning().stage_kib);
+    const StagedPlan small = staged_plan_for_budget(log_lifted, n_out, num_slots, 36);
+    if (n_instr < R0_LONG_PROGRAM || log_lifted < 18) return small;
+    const StagedPlan large = staged_plan_for_budget(log_lifted, n_out, num_slots, R0_LONG_PROGRAM_KIB);
+    return large.rows > small.rows ? large : small;
 }
 
 uint32_t round0_staged_grid(const DevStaged &staged, uint32_t log_lifted) {

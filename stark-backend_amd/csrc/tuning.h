@@ -12,7 +12,7 @@ struct Tuning {
     int r0_rows = 0;               // OVM_R0_ROWS=1|2|4: trace rows per lane of the staged round 0 (0: by height)
     int stage_rows = 0;            // OVM_STAGE_ROWS: LDS rows of one staging buffer (0: from the budget)
     int acc_rows = 0;              // OVM_ACC_ROWS: LDS accumulation rows (0: from the budget)
-    uint32_t stage_kib = 36;       // OVM_STAGE_KIB: LDS image budget per workgroup
+    uint32_t stage_kib = 0;        // OVM_STAGE_KIB: LDS image budget per workgroup (0: 36 KiB, 72 for long programs on tall traces)
     bool mle_points_in_lane = true;  // OVM_MLE_POINTS=0: one evaluation point per lane in the large rounds too
     bool mle_lds_slots = true;     // OVM_MLE_LDS=0: the large multilinear rounds keep their slots in private memory (rounds 1-2)
     bool mle_forward = true;       // OVM_MLE_FWD=0: the LDS-slot kernel ignores the compiler's forwarding hints
