@@ -11,6 +11,10 @@
 //   crates/cuda-backend/cuda/src/merkle_tree.cu:32-51,166-176   row sponge / compress semantics
 //   crates/stark-backend/src/transcript/duplex_sponge.rs:62-83  duplex sponge
 //   crates/stark-backend/src/transcript/traits.rs:46-89         sample_bits / check_witness / grind
+// Pinned (round 3): the layer code below reproduces Plonky3's published known-answer vector
+// (baby-bear/src/poseidon2.rs: test_poseidon2_width_16_random) over the RNG-drawn constants of that test
+// (poseidon2_permute_rc; tests/golden/poseidon2_p3_kat.json); the default constants are the in-tree table above.
+// Proof bytes of the real reference stay unpinned (oracle/README.md).
 #pragma once
 #include "field.hpp"
 
