@@ -246,6 +246,7 @@ extern "C" {
         seed: u64,
         blocks_out: *mut u64,
     ) -> c_int;
+    pub fn ovm_hip_host_gkr_batch_selftest(rounds: u32, seed: u64) -> c_int;
     pub fn ovm_hip_host_permute_selftest(n: u32, seed: u64) -> c_int;
     pub fn ovm_hip_set_prover_config(cfg: *const OvmProverConfig) -> c_int;
     pub fn ovm_hip_memory_stats(

@@ -219,6 +219,9 @@ int ovm_hip_program_stats(const uint32_t *blob, uint64_t words, uint32_t air_idx
  * (AVX2 where the CPU has it, csrc/host_poseidon2.cpp) against the scalar one on n pseudo-random
  * states. 1 = equal on all of them. */
 int ovm_hip_host_permute_selftest(uint32_t n, uint64_t seed);
+/* Host-only self-test of the vectorised host arithmetic of the LogUp-GKR layer tails (csrc/host_gkr_batch.cpp: AVX2 where
+ * the CPU has it) against the scalar code on `rounds` x 40 random batches. 1 = equal on all of them. */
+int ovm_hip_host_gkr_batch_selftest(uint32_t rounds, uint64_t seed);
 /* Memory-bounded modes of the calling thread's provers (reference: GpuProverConfig{cache_stacked_matrix,
  * cache_rs_code_matrix, zerocheck_save_memory}, crates/cuda-backend/src/device.rs:25-30). Defaults: everything
  * resident (all fields zero except cache_rs_code_matrix = 1).

@@ -113,6 +113,7 @@ SIGNATURES = {
     "ovm_hip_staged_selftest": (c_int, [c_void_p, c_uint64, c_uint32, c_uint32, c_uint64, _u64p]),
     "ovm_hip_pk_preprocessed_data": (c_int, [c_void_p, c_uint32, c_void_p, _u64p, _u64p, c_void_p, c_void_p]),
     "ovm_hip_program_stats": (c_int, [c_void_p, c_uint64, c_uint32, c_uint32, c_void_p, c_void_p, c_void_p]),
+    "ovm_hip_host_gkr_batch_selftest": (c_int, [c_uint32, c_uint64]),
     "ovm_hip_host_permute_selftest": (c_int, [c_uint32, c_uint64]),
     "ovm_hip_last_error": (c_char_p, []),
     "ovm_hip_trim": (c_int, []),

@@ -62,6 +62,11 @@ inline void rec_pair_sums(const GkrRec &a, const GkrRec &b, const EF &e, const E
     }
 }
 
+// The same over a batch of pairs, vectorised on hosts with AVX2 (host_gkr_batch.cpp): sums[x-1] += sum_i e[i] * (...)(x);
+// out[i] = rec_fold(A[i], B[i], r); out[i] = eq_at(pt, nv, y[i]). Bit-identical to the scalar functions.
+void gkr_pair_sums_batch(const GkrRec *A, const GkrRec *B, const EF *e, size_t n, const EF &lambda, unsigned n_points, EF *sums);
+void gkr_fold_batch(const GkrRec *A, const GkrRec *B, size_t n, const EF &r, GkrRec *out);
+
 struct URange {
     uint64_t lo = 0, hi = 0;
     bool empty() const { return lo >= hi; }
@@ -101,6 +106,8 @@ inline EF eq_at(const EF *point, unsigned nv, uint64_t y) {
     for (unsigned k = 0; k < nv; k++) acc = acc * eq1b(point[k], (y >> k) & 1);
     return acc;
 }
+
+void gkr_eq_batch(const EF *point, unsigned nv, const uint64_t *y, size_t n, EF *out);
 
 // Who owns what. Owners 0..world-1 are the ranks, owner `world` is the padding run (maybe empty).
 struct GkrPlan {
@@ -321,19 +328,27 @@ struct GkrSharded {
                     final_rec = it->second;
                     break;
                 }
-                // pairs nobody owns: both records are known
+                // pairs nobody owns: both records are known. Gathered first, then summed as ONE batch (eight pairs per
+                // AVX2 step): a layer's tail is up to 32 + 16 + ... pairs, ~950 extension-field products
                 std::map<uint64_t, GkrRec> Hn;
-                std::vector<std::pair<uint64_t, std::pair<GkrRec, GkrRec>>> host_pairs;
+                std::vector<uint64_t> hy;
+                std::vector<GkrRec> ha, hb;
                 for (auto &kv : known) {
                     const uint64_t y = kv.first >> 1;
-                    if (!host_pairs.empty() && host_pairs.back().first == y) continue;
+                    if (!hy.empty() && hy.back() == y) continue;
                     bool owned = false;
                     for (uint32_t o = 0; o < plan.owners(); o++) owned |= Pn[o].has(y);
                     if (owned) throw OvmFail(1, "internal: GKR edge record inside an owned pair");
                     auto ia = known.find(2 * y), ib = known.find(2 * y + 1);
                     if (ia == known.end() || ib == known.end()) throw OvmFail(1, "internal: GKR host pair incomplete");
-                    host_pairs.push_back({y, {ia->second, ib->second}});
-                    rec_pair_sums(ia->second, ib->second, eq_at(pt, nv, y), lambda, n_points, S);
+                    hy.push_back(y);
+                    ha.push_back(ia->second);
+                    hb.push_back(ib->second);
+                }
+                if (!hy.empty()) {
+                    std::vector<EF> he(hy.size());
+                    gkr_eq_batch(pt, nv, hy.data(), hy.size(), he.data());
+                    gkr_pair_sums_batch(ha.data(), hb.data(), he.data(), hy.size(), lambda, n_points, S);
                 }
                 // s(X) = c_bound * eq1(a, X) * S(X), S quadratic: two points + the claim give the third
                 std::vector<EF> Sv(S, S + n_points);
@@ -354,7 +369,11 @@ struct GkrSharded {
                 c_bound = c_bound * (a * r_prev + (EF::one() - a) * (EF::one() - r_prev));
                 const EF rm1 = r_prev - EF::one(), rm2 = rm1 - EF::one();
                 claim = c_bound * (S0 * (rm1 * rm2) * inv2 - Sv[0] * (r_prev * rm2) + Sv[1] * (r_prev * rm1) * inv2);
-                for (auto &hp : host_pairs) Hn[hp.first] = rec_fold(hp.second.first, hp.second.second, r_prev);
+                if (!hy.empty()) {
+                    std::vector<GkrRec> folded(hy.size());
+                    gkr_fold_batch(ha.data(), hb.data(), hy.size(), r_prev, folded.data());
+                    for (size_t i = 0; i < hy.size(); i++) Hn.emplace_hint(Hn.end(), hy[i], folded[i]);
+                }
                 H = std::move(Hn);
                 R = Pn;
             }

@@ -53,3 +53,9 @@ def test_host_transcript_permutation_matches_scalar(pkg):
     """The Fiat-Shamir transcript's host permutation is dispatched at run time (AVX2 where available,
     csrc/host_poseidon2.cpp); it must equal the scalar Poseidon2 on every state."""
     assert pkg._lib().ovm_hip_host_permute_selftest(20000, 7) == 1
+
+
+def test_host_gkr_batch_arithmetic_matches_scalar(pkg):
+    """The host side of the LogUp-GKR layer tails (pair sums, folds, eq weights over batches of records) is vectorised
+    with AVX2 where the CPU has it (csrc/host_gkr_batch.cpp); it must equal the scalar code on every batch size."""
+    assert pkg._lib().ovm_hip_host_gkr_batch_selftest(20, 11) == 1
