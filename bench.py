@@ -159,6 +159,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--log-rows", type=int, default=22)
     ap.add_argument("--cols", type=int, default=100)
+    ap.add_argument("--num-airs", type=int, default=1,
+                    help="N = 1 only: this many BenchmarkAirs of the same shape in ONE proof (uniform_runner's --num-airs; "
+                         "BASELINE config C is --num-airs 4 --log-rows 20 --log-stacked-height 24)")
     ap.add_argument("--log-stacked-height", type=int, default=24)
     ap.add_argument("--cpu-log-rows", type=int, default=18, help="rows of the CPU-baseline sample")
     ap.add_argument("--log-blowup", type=int, default=1,
@@ -240,9 +243,9 @@ def main():
     shard = None
     if world == 1:
         air = airs.uniform_runner_air(cols)
-        pk = pkg.ProvingKey(airs.pk_blob(params, [air]))
-        trace = bits(cols * h)
-        traces = [(0, trace, h, [])]
+        pk = pkg.ProvingKey(airs.pk_blob(params, [air] * args.num_airs))
+        traces = [(a, bits(cols * h), h, []) for a in range(args.num_airs)]
+        cells *= args.num_airs
 
         def step():
             return dev.prove(pk, traces)
@@ -334,7 +337,7 @@ def main():
                     stages[k] = max(stages.get(k, 0.0), v)
         dom = max(stages, key=lambda k: stages[k]) if stages else None
         rows = 1 << (args.log_stacked_height + params["log_blowup"])
-        width = (cols * h) >> args.log_stacked_height
+        width = (cols * h * (args.num_airs if world == 1 else 1)) >> args.log_stacked_height
         roof = None
         if "merkle.hash_rows" in prof_dom and width > 0:
             calls, total_ms = prof_dom["merkle.hash_rows"]   # HIP events over the TIMED region
@@ -384,7 +387,7 @@ def main():
                 ib["ceiling_source"] = os.path.relpath(ceil_path, ROOT)
             roof["issue_bound"] = ib
             if world == 1:
-                gkr_leaves = 26 * h  # 13 send/receive pairs -> 26 interactions per row (padding leaves are never materialised)
+                gkr_leaves = 26 * h * args.num_airs  # 13 send/receive pairs -> 26 interactions per row (padding leaves are never materialised)
                 roof["classes"] = roofline_classes(prof, prof_steps, rows, width, cells, args.log_stacked_height, gkr_leaves)
                 roof["classes_source"] = f"{prof_steps} fully profiled steps after the timed region"
         cpu = None
@@ -419,7 +422,7 @@ def main():
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
             "prove_ms": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u32 (BabyBear Montgomery; F_p^4 challenges)", "data": "synthetic",
-            "config": {"workload": f"uniform_runner BenchmarkAir 2^{log_rows} rows x {cols} cols per GPU, "
+            "config": {"workload": ("" if args.num_airs == 1 else f"{args.num_airs} x ") + f"uniform_runner BenchmarkAir 2^{log_rows} rows x {cols} cols per GPU, "
                                    f"200 boolean constraints, 13 send/receive pairs, app params "
                                    f"(l_skip 4, n_stack {args.log_stacked_height - 4}, log_blowup {args.log_blowup}, k_whir 4, "
                                    f"PoW {params['logup_pow_bits']}/{params['mu_pow_bits']}/"
