@@ -9,6 +9,8 @@
 // callbacks in ovm_shard_t instead (the Python host does, with this as its first fall-back).
 #include <hip/hip_runtime.h>
 
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>

@@ -2578,6 +2578,7 @@ struct Prover {
         const unsigned k_whir = P().k_whir, log_blowup = P().log_blowup;
         const size_t n_rounds = P().whir_num_queries.size();
         Fp mu_pow_witness = ts.grind(P().mu_pow_bits);
+        wt.mark("openings.whir.mu_pow");
         EF mu = ts.sample_ext();
         unsigned m = l_skip + n_stack;
         // (sharded with an all-to-all: the vector is exchanged in `world` slices of ceil(2^m / world) elements)
@@ -2597,6 +2598,8 @@ struct Prover {
             }
             if (first) OVM_THROW_IF(hipMemsetAsync(f_a.p, 0, sizeof(EF) << m, cx.stream));  // (a rank without commitments)
         }
+        if (wt.on) cx.sync();
+        wt.mark("openings.whir.mu_batch");
         if (!sh.single()) {
             // THE bulk exchange of a sharded proof (north_star: "RCCL allgather only at the FRI batch-opening
             // step"; prover/whir.rs:95-132 batches all commitments into one vector): every rank holds the
@@ -2621,6 +2624,8 @@ struct Prover {
                 OVM_THROW_IF(ef_sum_blocks(gathered.p, sh.world, uint64_t(1) << m, f_a.p, cx.stream));
             }
         }
+        if (wt.on) cx.sync();
+        wt.mark("openings.whir.mu_exchange");
         w_a.alloc(size_t(1) << m);
         w_b.alloc(size_t(1) << (m - 1));
         {

@@ -51,12 +51,16 @@ def main():
         pkg.set_prover_config(cache_rs_code_matrix=False, zerocheck_save_memory=True, round0_slab_log_rows=3, gkr_drop_leaves=True)
     shard = pkg.Shard(args.rank, args.world, args.shm, bulk=args.bulk, alltoall=not args.no_alltoall)
     if args.case.startswith("gen:"):
-        # "gen:<log_rows>:<cols>:<log_stacked_height>": one partitioned BenchmarkAir per rank under app parameters, the
-        # seeded boolean trace generated on the device (BASELINE config D's multi-GPU form at any size)
-        log_rows, cols, log_stacked = (int(x) for x in args.case.split(":")[1:])
+        # "gen:<log_rows>:<cols>:<log_stacked_height>[:<log_blowup>]": one partitioned BenchmarkAir per rank under app
+        # parameters (log_blowup 2: the leaf-like parameters of BASELINE config E), the seeded boolean trace generated on
+        # the device (BASELINE config D's / E's multi-GPU form at any size)
+        fields = [int(x) for x in args.case.split(":")[1:]]
+        log_rows, cols, log_stacked = fields[:3]
+        log_blowup = fields[3] if len(fields) > 3 else 1
         h = 1 << log_rows
         air = airs.uniform_runner_air_partitioned(cols)
-        pk = pkg.ProvingKey(airs.pk_blob(airs.app_params(log_stacked), [air] * args.world))
+        params = airs.app_params(log_stacked) if log_blowup == 1 else airs.stress_params(log_stacked, log_blowup)
+        pk = pkg.ProvingKey(airs.pk_blob(params, [air] * args.world))
         gen = torch.Generator(device="cuda:0")
         gen.manual_seed(0xD15EA5E + args.rank)
         one = int(pkg.to_mont(np.array([1], dtype=np.uint32))[0])

@@ -164,6 +164,26 @@ def test_config_d_full_size_two_shards_on_one_gpu_verifies(orc, tmp_path):
         orc.verify(blob, bytes(bad))
 
 
+def test_config_e_two_shards_on_one_gpu_verifies(orc, tmp_path):
+    """BASELINE config E in its sharded form -- per rank a 2^24-row x 100-column AIR as its own commitment under the
+    leaf-like parameters (blowup 4, constraint degree 4): 26.8 GB of codeword per rank, a 2^30-leaf fraction tree over two
+    leaf runs -- as two logical shards on this one GPU: the joint proof is accepted by the verifier restatement."""
+    import torch
+    free, _ = torch.cuda.mem_get_info()
+    if free < 200 * (1 << 30):
+        pytest.skip("needs ~200 GB of free HBM")
+    # (bulk exchange staged through shared memory: with two 85 GB processes on ONE GPU, hipIpcOpenMemHandle of the
+    # peer's segment did not return -- observed at this size only, 184 GB of the 288 in use; the IPC carrier is what
+    # every other logical-shard test runs, and on real hardware each rank has a GPU of its own)
+    got = run_sharded("gen:24:100:24:2", 2, tmp_path, bulk="shm")
+    blob = airs.pk_blob(airs.stress_params(24, 2), [airs.uniform_runner_air_partitioned(100)] * 2)
+    orc.verify(blob, got)
+    bad = bytearray(got)
+    bad[len(bad) // 2] ^= 1
+    with pytest.raises(Exception):
+        orc.verify(blob, bytes(bad))
+
+
 def test_bulk_exchange_callback_on_nccl(tmp_path):
     """The RCCL branch of the Python host's bulk exchange (the one line that differs from the gloo branch the
     logical-shard tests use): zero-copy torch views of raw device ranges + all_gather_into_tensor /
