@@ -26,6 +26,9 @@
 // indices is a prefix product -- so its contribution to every round is a closed form. (For the
 // 1-GPU config D proof that removes the 6/32 of the GKR work that was padding.)
 #pragma once
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <array>
 #include <functional>
 #include <map>
@@ -261,6 +264,9 @@ struct GkrSharded {
             GkrRec edges[GKR_HOST_TAIL];
         };
         const EF inv2 = EF::from_base(fp(2).inv());
+        const bool trace_host = getenv("OVM_TRACE") != nullptr;  // (host time between two device sub-rounds, summed)
+        auto host_t0 = std::chrono::steady_clock::now();
+        uint64_t host_ns = 0, host_segments = 0;
         for (unsigned round = 1; round < TR; round++) {
             const unsigned L = round + 1;
             const EF lambda = sample();
@@ -302,8 +308,14 @@ struct GkrSharded {
                 } else {
                     mine.n_edges = range_edges(R[me], mine.eidx);
                 }
-                if (!Pn[me].empty() || mine.n_edges)
+                if (!Pn[me].empty() || mine.n_edges) {
+                    if (trace_host) {
+                        host_ns += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - host_t0).count();
+                        host_segments++;
+                    }
                     dev.subround(round, sr, Pn[me], mine.eidx, (unsigned)mine.n_edges, r_prev, lambda, n_points, mine.S, mine.edges);
+                    if (trace_host) host_t0 = std::chrono::steady_clock::now();
+                }
                 std::vector<Msg> all(W);
                 comm.allgather(&mine, all.data(), sizeof(Msg));
                 // table records known to the host in this sub-round: edges of every owner + host records
@@ -386,6 +398,9 @@ struct GkrSharded {
             out.polys.push_back(std::move(polys));
         }
         out.xi = xi_prev;
+        if (trace_host)
+            fprintf(stderr, "[ovm] gkr host time between device sub-rounds: %.3f ms over %llu segments\n", host_ns / 1e6,
+                    (unsigned long long)host_segments);
         return out;
     }
 };
