@@ -178,6 +178,10 @@ def main():
                     help="fully profiled steps AFTER the timed region that stage_ms / roofline.classes come from (default: "
                          "min(steps, 3); 0: none -- what tools/profile_round.sh uses so that the process makes exactly "
                          "warmup + steps proofs)")
+    ap.add_argument("--no-pin", action="store_true",
+                    help="do not pin this rank's process to two physical host cores (default: cores 8 + 2 * local_rank and the "
+                         "next one when the machine has them: the prover's host thread spins on device flags between ~900 "
+                         "launches per proof, and staying on one core pair is worth ~1 ms of 76 at config D)")
     ap.add_argument("--dry-run", action="store_true",
                     help="N > 1: rendezvous, the pre-flight of the bulk exchange, then the two collectives of the mu-batch sum and "
                          "one transfer per peer at the FULL vector size (2^log_stacked_height x 16 B = 268 MB at config D), timed; "
@@ -212,6 +216,20 @@ def main():
     import airs
 
     pkg = ge._load_pkg()
+    # Host placement: the prover thread (it spins on host-mapped flags between launches) and its helper thread stay on two
+    # PHYSICAL cores -- measured on the 2 x 64-core box (profiles/r03/host_pinning.txt): unpinned 76.0-76.6 ms, cores 8,9
+    # 74.9-75.4 ms, two SMT siblings of one core 78 ms. Done after the imports (the OpenMP runtime the CPU baseline uses
+    # sizes itself from the mask it sees when it loads) and undone before the CPU baseline. Stated in the JSON line.
+    host_affinity, all_cpus = None, None
+    if not args.no_pin and hasattr(os, "sched_setaffinity"):
+        try:
+            all_cpus = sorted(os.sched_getaffinity(0))
+            c0 = 8 + 2 * local_rank
+            if len(all_cpus) >= 32 and c0 in all_cpus and c0 + 1 in all_cpus:
+                os.sched_setaffinity(0, {c0, c0 + 1})
+                host_affinity = [c0, c0 + 1]
+        except OSError:
+            host_affinity = None
     dist = None
     devname = f"cuda:{local_rank}"
     torch.cuda.set_device(local_rank)
@@ -392,8 +410,11 @@ def main():
                 roof["classes_source"] = f"{prof_steps} fully profiled steps after the timed region"
         cpu = None
         if not args.no_cpu_baseline:
+            if host_affinity is not None:
+                os.sched_setaffinity(0, set(all_cpus))  # the baseline gets every host core again
             import oracle_lib
             orc = oracle_lib.load()
+            orc.lib.orc_set_num_threads(len(all_cpus) if all_cpus else (os.cpu_count() or 1))
             lr = args.cpu_log_rows
             small = args.log_stacked_height - (log_rows - lr)
             p2 = airs.app_params(small) if args.log_blowup == 1 else airs.stress_params(small, args.log_blowup)
@@ -430,7 +451,8 @@ def main():
                                    + ("all-zero trace" if args.zero_trace else "seeded random boolean trace")
                                    + ("" if world == 1 else "; per AIR: 100 columns as a cached-main commitment (committed inside the "
                                       "timed region) + a 1-column common main (not counted in cells)"),
-                       "proof_bytes": len(proof), "proof_sha256": hashlib.sha256(proof).hexdigest(), "parallelism": par},
+                       "proof_bytes": len(proof), "proof_sha256": hashlib.sha256(proof).hexdigest(), "parallelism": par,
+                       "host_affinity": host_affinity},
             "roofline": roof, "cpu_baseline": cpu,
             "end_to_end": {"algorithmic_bytes_per_cell": 60, "achieved_GBps": round(e2e_gbs, 1),
                            "frac_of_hbm_peak": round(e2e_gbs / (HBM_PEAK_GBS * world), 4)},
