@@ -224,7 +224,7 @@ def main():
     if not args.no_pin and hasattr(os, "sched_setaffinity"):
         try:
             all_cpus = sorted(os.sched_getaffinity(0))
-            c0 = 8 + 2 * local_rank
+            c0 = 8 + 2 * int(os.environ.get("LOCAL_RANK", "0"))  # (--one-gpu: the ranks share GPU 0 but not their cores)
             if len(all_cpus) >= 32 and c0 in all_cpus and c0 + 1 in all_cpus:
                 os.sched_setaffinity(0, {c0, c0 + 1})
                 host_affinity = [c0, c0 + 1]
