@@ -3,11 +3,11 @@
 set -euo pipefail
 here="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
 src="$here/csrc"
-out="$here/libopenvm_hip.so"
-obj="$here/build"
+out="${OVM_OUT:-$here/libopenvm_hip.so}"  # (OVM_OUT / OVM_OBJ / OVM_EXTRA_FLAGS: A/B builds of a variant next to the product)
+obj="${OVM_OBJ:-$here/build}"
 mkdir -p "$obj"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
-FLAGS=(--offload-arch=gfx950 -O3 -std=c++17 -fPIC -DOVM_HOST_FAST_PERMUTE=1 -I"$here/../include" -I"$src" -Wall -Wno-unused-function -Wno-unused-variable -Wno-unused-result)
+FLAGS=(--offload-arch=gfx950 -O3 -std=c++17 -fPIC -DOVM_HOST_FAST_PERMUTE=1 -I"$here/../include" -I"$src" -Wall -Wno-unused-function -Wno-unused-variable -Wno-unused-result ${OVM_EXTRA_FLAGS:-})
 pids=()
 objs=()
 for f in "$src"/*.hip "$src"/*.cpp; do

@@ -46,7 +46,46 @@ struct RedOut {
     // device-scope atomics instead of storing a record; the last workgroup reduces the sums mod P into out[].
     unsigned long long *acc;
 };
-static constexpr unsigned RED_ATOMIC_MAX_K = 16;  // acc[] holds 4 * 16 words
+static constexpr unsigned RED_ATOMIC_MAX_K = 16;
+
+// ---- stores another agent waits for, without a release FENCE ------------------------------------------------------
+// `__threadfence_system()` / `__threadfence()` compile to `buffer_wbl2` + `s_waitcnt` + `buffer_inv`: the wave waits for
+// the write-back of EVERY dirty line of its L2 (megabytes right after a fold kernel), then throws the L2's contents
+// away. What a mailbox or a partial record needs is only that THESE stores are performed before the flag / counter that
+// announces them: store them write-through at the scope of the reader (`sc0 sc1` = system: the host; `sc1` = agent: a
+// workgroup on another XCD) and wait for their acknowledgement (`s_waitcnt vmcnt(0)`), which for a write-through store
+// arrives from the coherence point of that scope. The READER still acquires (the host's loads are ordered by x86; the
+// last workgroup runs one `__threadfence()` before it reads the records). OVM_RELEASE_FENCES=1 builds the fenced form.
+#ifndef OVM_RELEASE_FENCES
+#define OVM_RELEASE_FENCES 0
+#endif
+__device__ __forceinline__ void st_word_sys(uint32_t *p, uint32_t v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ void st_word_agent(uint32_t *p, uint32_t v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void stores_performed() {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+}
+// after the stores to a host mailbox, before its flag
+__device__ __forceinline__ void release_to_host() {
+#if OVM_RELEASE_FENCES
+    __threadfence_system();
+#else
+    stores_performed();
+#endif
+}
+// after the stores of a partial record, before the arrival counter
+__device__ __forceinline__ void release_to_device() {
+#if OVM_RELEASE_FENCES
+    __threadfence();
+#else
+    stores_performed();
+#endif
+}  // acc[] holds 4 * 16 words
 
 static constexpr unsigned MAX_COSETS = 4;
 static constexpr unsigned RED_BLOCKS = 2048;  // grid cap of the partial-sum kernels (8 workgroups per CU)

@@ -18,6 +18,15 @@ __device__ __forceinline__ EF ld_ef(const EF *p) {
 __device__ __forceinline__ void st_ef(EF *p, const EF &x) {
     *reinterpret_cast<uint4 *>(p) = make_uint4(x.c[0].v, x.c[1].v, x.c[2].v, x.c[3].v);
 }
+// (write-through forms for mailboxes and partial records: see release_to_host / release_to_device)
+__device__ __forceinline__ void st_ef_sys(EF *p, const EF &x) {
+#pragma unroll
+    for (int k = 0; k < 4; k++) st_word_sys(&p->c[k].v, x.c[k].v);
+}
+__device__ __forceinline__ void st_ef_agent(EF *p, const EF &x) {
+#pragma unroll
+    for (int k = 0; k < 4; k++) st_word_agent(&p->c[k].v, x.c[k].v);
+}
 __device__ __forceinline__ void stp(uint32_t *b, uint64_t st, uint64_t i, const EF &x) {
 #pragma unroll
     for (int k = 0; k < 4; k++) b[k * st + i] = x.c[k].v;
@@ -137,10 +146,16 @@ __device__ __forceinline__ void round0_eval_body(const Prog &prog, const Fp *lde
                 EF acc = sh[threadIdx.x];
                 for (uint32_t j = threadIdx.x + N; j < RED_THREADS; j += N) acc = acc + sh[j];
                 EF *rec = partials + ((size_t)bx * n_cosets * n_out + k * n_out + o) * N;
-                st_ef(rec + zbase + threadIdx.x, acc);
-                for (uint32_t seg = 0; N > RED_THREADS && seg < N; seg += RED_THREADS)
-                    if (seg != zbase) st_ef(rec + seg + threadIdx.x, EF::zero());
-                if (fence) __threadfence();
+                if (fence) {
+                    st_ef_agent(rec + zbase + threadIdx.x, acc);
+                    for (uint32_t seg = 0; N > RED_THREADS && seg < N; seg += RED_THREADS)
+                        if (seg != zbase) st_ef_agent(rec + seg + threadIdx.x, EF::zero());
+                    release_to_device();
+                } else {
+                    st_ef(rec + zbase + threadIdx.x, acc);
+                    for (uint32_t seg = 0; N > RED_THREADS && seg < N; seg += RED_THREADS)
+                        if (seg != zbase) st_ef(rec + seg + threadIdx.x, EF::zero());
+                }
             }
             __syncthreads();
         }

@@ -22,6 +22,7 @@
 #include <cstdlib>
 #include <cstring>
 
+#include "device_common.h"
 #include "device_ctx.h"
 #include "openvm_hip.h"
 #include "poseidon2.h"
@@ -170,9 +171,9 @@ __global__ __launch_bounds__(HASH_THREADS) void grind_kernel(p2::Sponge sponge, 
 __global__ void grind_publish_kernel(uint32_t *result, uint32_t *host_page /* [0] flag, [1] result */, uint32_t seq) {
     const uint32_t found = *result;
     *result = 0xffffffffu;
-    ((volatile uint32_t *)host_page)[1] = found;
-    __threadfence_system();
-    ((volatile uint32_t *)host_page)[0] = seq;
+    st_word_sys(host_page + 1, found);
+    release_to_host();
+    st_word_sys(host_page, seq);
 }
 
 __global__ void permute_states_kernel(Fp *states, uint64_t n) {

@@ -353,14 +353,14 @@ __global__ __launch_bounds__(256) void download_kernel(const uint32_t *src, uint
                                                        uint32_t *flag, uint32_t seq) {
     const uint32_t first = blockIdx.x * DOWNLOAD_WG_WORDS;
     const uint32_t last = first + DOWNLOAD_WG_WORDS < n_words ? first + DOWNLOAD_WG_WORDS : n_words;
-    for (uint32_t i = first + threadIdx.x; i < last; i += 256) page[i] = src[i];
-    __threadfence_system();
+    for (uint32_t i = first + threadIdx.x; i < last; i += 256) st_word_sys(page + i, src[i]);
+    release_to_host();
     __syncthreads();
     if (threadIdx.x == 0) {
         if (gridDim.x == 1 || atomicAdd(counter, 1u) == gridDim.x - 1) {
             if (gridDim.x > 1) *counter = 0;
-            __threadfence_system();
-            *(volatile uint32_t *)flag = seq;
+            release_to_host();
+            st_word_sys(flag, seq);
         }
     }
 }

@@ -43,11 +43,15 @@ __device__ void block_sum_store(EF (&v)[K], EF *out, bool fence = true) {
     if (threadIdx.x < K) {
         EF s = sh[threadIdx.x];
         for (int w = 1; w < (int)(blockDim.x >> 6); w++) s = s + sh[w * K + threadIdx.x];
-        st_ef(out + threadIdx.x, s);
-        if (SYS)
-            __threadfence_system();
-        else if (fence)
-            __threadfence();
+        if (SYS) {
+            st_ef_sys(out + threadIdx.x, s);
+            release_to_host();
+        } else if (fence) {
+            st_ef_agent(out + threadIdx.x, s);
+            release_to_device();
+        } else {
+            st_ef(out + threadIdx.x, s);
+        }
     }
     __syncthreads();
 }
@@ -85,8 +89,8 @@ __device__ void block_sum_atomic(EF (&v)[K], const RedOut &ro, uint32_t k_off) {
 // Make everything this thread stored visible to the host, then raise the mailbox flag.
 __device__ __forceinline__ void publish(const RedOut &ro) {
     if (ro.flag) {
-        __threadfence_system();
-        *(volatile uint32_t *)ro.flag = ro.seq;
+        release_to_host();
+        st_word_sys(ro.flag, ro.seq);
     }
 }
 
@@ -109,9 +113,9 @@ __device__ void finish_reduction(const RedOut &ro, uint32_t n_records, uint32_t 
     if (ro.acc) {  // atomic finish: the sums are complete (every workgroup's atomics were performed before its counter bump)
         if (threadIdx.x < 4 * K) {
             const unsigned long long sum = __hip_atomic_exchange(ro.acc + threadIdx.x, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            ((volatile uint32_t *)ro.out)[threadIdx.x] = (uint32_t)(sum % bb::P);
+            st_word_sys((uint32_t *)ro.out + threadIdx.x, (uint32_t)(sum % bb::P));
         }
-        __threadfence_system();
+        release_to_host();
         __syncthreads();
         if (threadIdx.x == 0) {
             __hip_atomic_store(ro.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -830,9 +834,9 @@ __global__ __launch_bounds__(RED_THREADS) void round0_staged_batched_kernel(cons
     for (uint32_t k = threadIdx.x; k < K; k += RED_THREADS) {
         EF acc = EF::zero();
         for (uint32_t b = 0; b < job.gx; b++) acc = acc + ld_ef(job.partials + (size_t)b * K + k);
-        st_ef(job.out + k, acc);
+        st_ef_sys(job.out + k, acc);
     }
-    __threadfence_system();
+    release_to_host();
     __syncthreads();
     if (threadIdx.x == 0) {
         counters[1 + j] = 0;
@@ -1855,9 +1859,9 @@ __global__ void gkr_read_list_kernel(FracPlanes t, const uint64_t *pos, const ui
     if (i < n) {
         const uint64_t at = pos[i];
         EF p = pbase[i] ? EF::from_base(Fp::raw(t.P()[at])) : ldp(t.P(), t.stride, at);
-        st_ef(ro.out + 2 * i, p);
-        st_ef(ro.out + 2 * i + 1, ldp(t.Q(), t.stride, at));
-        __threadfence_system();
+        st_ef_sys(ro.out + 2 * i, p);
+        st_ef_sys(ro.out + 2 * i + 1, ldp(t.Q(), t.stride, at));
+        release_to_host();
     }
     __syncthreads();
     if (i == 0) publish(ro);
@@ -1887,10 +1891,10 @@ __global__ void gkr_edge_kernel(FracPlanes src, uint64_t at0, uint64_t at1, uint
             else
                 ldp4(src.P(), src.stride, at, p);
             ldp4(src.Q(), src.stride, at, q);
-            st_ef(out + 0, p[0] + (p[2] - p[0]) * r);
-            st_ef(out + 1, q[0] + (q[2] - q[0]) * r);
-            st_ef(out + 2, p[1] + (p[3] - p[1]) * r);
-            st_ef(out + 3, q[1] + (q[3] - q[1]) * r);
+            st_ef_sys(out + 0, p[0] + (p[2] - p[0]) * r);
+            st_ef_sys(out + 1, q[0] + (q[2] - q[0]) * r);
+            st_ef_sys(out + 2, p[1] + (p[3] - p[1]) * r);
+            st_ef_sys(out + 3, q[1] + (q[3] - q[1]) * r);
         } else {
             EF p0, p1, q0, q1;
             if (p_base)
@@ -1898,12 +1902,12 @@ __global__ void gkr_edge_kernel(FracPlanes src, uint64_t at0, uint64_t at1, uint
             else
                 ldp2(src.P(), src.stride, at, p0, p1);
             ldp2(src.Q(), src.stride, at, q0, q1);
-            st_ef(out + 0, p0);
-            st_ef(out + 1, q0);
-            st_ef(out + 2, p1);
-            st_ef(out + 3, q1);
+            st_ef_sys(out + 0, p0);
+            st_ef_sys(out + 1, q0);
+            st_ef_sys(out + 2, p1);
+            st_ef_sys(out + 3, q1);
         }
-        __threadfence_system();
+        release_to_host();
     }
     __syncthreads();
     if (k == 0) publish(ro);
