@@ -54,8 +54,8 @@ static constexpr unsigned RED_ATOMIC_MAX_K = 16;
 // away. What a mailbox or a partial record needs is only that THESE stores are performed before the flag / counter that
 // announces them: store them write-through at the scope of the reader (`sc0 sc1` = system: the host; `sc1` = agent: a
 // workgroup on another XCD) and wait for their acknowledgement (`s_waitcnt vmcnt(0)`), which for a write-through store
-// arrives from the coherence point of that scope. The READER still acquires (the host's loads are ordered by x86; the
-// last workgroup runs one `__threadfence()` before it reads the records). OVM_RELEASE_FENCES=1 builds the fenced form.
+// arrives from the coherence point of that scope. The READER: the host's loads are ordered by x86; the last workgroup
+// reads the records with agent-scope loads (acquire_from_device). OVM_RELEASE_FENCES=1 builds the fenced form.
 #ifndef OVM_RELEASE_FENCES
 #define OVM_RELEASE_FENCES 0
 #endif
@@ -76,6 +76,24 @@ __device__ __forceinline__ void release_to_host() {
     __threadfence_system();
 #else
     stores_performed();
+#endif
+}
+// the last workgroup, after it has seen the full arrival counter and before it reads the records: nothing here -- the
+// records are READ at agent scope (ld_ef_agent: `sc1` loads, which never hit a stale line of this XCD's L2), so the
+// `buffer_wbl2` + `buffer_inv` of a fence (write back, then drop, this L2) is not needed either
+#ifndef OVM_ACQUIRE_FENCES
+#define OVM_ACQUIRE_FENCES OVM_RELEASE_FENCES
+#endif
+__device__ __forceinline__ void acquire_from_device() {
+#if OVM_ACQUIRE_FENCES
+    __threadfence();
+#endif
+}
+__device__ __forceinline__ uint32_t ld_word_agent(const uint32_t *p) {
+#if OVM_ACQUIRE_FENCES
+    return *p;
+#else
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #endif
 }
 // after the stores of a partial record, before the arrival counter

@@ -23,6 +23,12 @@ __device__ __forceinline__ void st_ef_sys(EF *p, const EF &x) {
 #pragma unroll
     for (int k = 0; k < 4; k++) st_word_sys(&p->c[k].v, x.c[k].v);
 }
+__device__ __forceinline__ EF ld_ef_agent(const EF *p) {
+    EF r;
+#pragma unroll
+    for (int k = 0; k < 4; k++) r.c[k] = Fp::raw(ld_word_agent(&p->c[k].v));
+    return r;
+}
 __device__ __forceinline__ void st_ef_agent(EF *p, const EF &x) {
 #pragma unroll
     for (int k = 0; k < 4; k++) st_word_agent(&p->c[k].v, x.c[k].v);

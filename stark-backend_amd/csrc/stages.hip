@@ -123,14 +123,14 @@ __device__ void finish_reduction(const RedOut &ro, uint32_t n_records, uint32_t 
         }
         return;
     }
-    __threadfence();
+    acquire_from_device();
     EF acc[KMAX];
 #pragma unroll
     for (int k = 0; k < KMAX; k++) acc[k] = EF::zero();
     for (uint32_t b = threadIdx.x; b < n_records; b += RED_THREADS) {
 #pragma unroll
         for (int k = 0; k < KMAX; k++)
-            if ((uint32_t)k < K) acc[k] = acc[k] + ld_ef(ro.partials + (size_t)b * K + k);
+            if ((uint32_t)k < K) acc[k] = acc[k] + ld_ef_agent(ro.partials + (size_t)b * K + k);
     }
     block_sum_store<KMAX, true>(acc, ro.out);  // KMAX totals (entries >= K are zero)
     if (threadIdx.x == 0) {
@@ -830,10 +830,10 @@ __global__ __launch_bounds__(RED_THREADS) void round0_staged_batched_kernel(cons
     if (threadIdx.x == 0) s_last = atomicAdd(counters + 1 + j, 1u) == job.gx - 1;
     __syncthreads();
     if (!s_last) return;
-    __threadfence();
+    acquire_from_device();
     for (uint32_t k = threadIdx.x; k < K; k += RED_THREADS) {
         EF acc = EF::zero();
-        for (uint32_t b = 0; b < job.gx; b++) acc = acc + ld_ef(job.partials + (size_t)b * K + k);
+        for (uint32_t b = 0; b < job.gx; b++) acc = acc + ld_ef_agent(job.partials + (size_t)b * K + k);
         st_ef_sys(job.out + k, acc);
     }
     release_to_host();
@@ -1338,7 +1338,7 @@ __global__ __launch_bounds__(RED_THREADS) void mle_round_batched_kernel(const Ml
     if (threadIdx.x == 0) s_last = atomicAdd(counters + 1 + j, 1u) == job.gx * job.n_groups - 1;
     __syncthreads();
     if (!s_last) return;
-    __threadfence();
+    acquire_from_device();
     EF acc[8];
 #pragma unroll
     for (int k = 0; k < 8; k++) acc[k] = EF::zero();
@@ -1346,7 +1346,7 @@ __global__ __launch_bounds__(RED_THREADS) void mle_round_batched_kernel(const Ml
     for (uint32_t b = threadIdx.x; b < n_records; b += RED_THREADS) {
 #pragma unroll
         for (int k = 0; k < 8; k++)
-            if ((uint32_t)k < K) acc[k] = acc[k] + ld_ef(job.partials + (size_t)b * K + k);
+            if ((uint32_t)k < K) acc[k] = acc[k] + ld_ef_agent(job.partials + (size_t)b * K + k);
     }
     block_sum_store<8, true>(acc, job.out);  // (system-scope fence after the stores)
     if (threadIdx.x == 0) {
