@@ -50,7 +50,9 @@ int mobius_eq_table(const EF *d_point, uint32_t n, EF *out, hipStream_t s);
 // into an lde buffer laid out for 2^log_lifted rows -- round 0 in slabs (zerocheck_save_memory)
 int coset_lde(const ColDesc *d_cols, const uint32_t *d_used, uint32_t n_used, uint32_t n_cols_total,
               uint32_t log_lifted, uint32_t l_skip, uint32_t n_cosets, const Fp *d_shift_pows, Fp *lde,
-              hipStream_t s, uint64_t row0 = 0);
+              hipStream_t s, uint64_t row0 = 0, uint32_t pad_lds_bytes = 0);
+// (pad_lds_bytes: LDS every workgroup claims without using it -- caps the workgroups per CU of a launch that runs beside
+// latency-critical kernels of another stream)
 
 // Round 0: out[((k * n_out) + o) * N + z] = sum_x eq_xi[x] * program_o(lde_k row (x<<l)+z) (+ add_const for o==1)
 // Round 0 of many traces in ONE launch (staged programs of equal rows-per-lane and output count): the

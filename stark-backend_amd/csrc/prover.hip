@@ -415,6 +415,40 @@ inline DownloadPage &download_page() {
     return pages[dev & 15];
 }
 
+// The library's own second stream (lowest priority) for work that needs no challenge: the device spends the first
+// layers of the GKR sumcheck waiting for the host (a handful of pairs per launch, a mailbox round trip per sub-round),
+// and round 0's coset LDE -- a function of the traces alone -- runs beside them (prove_rap_constraints: EarlyLde).
+// fork: recorded on the caller's stream, waited for here; join: recorded here, waited for on the caller's stream.
+struct SideStream : ThreadResource {
+    hipStream_t s = nullptr;
+    hipEvent_t fork = nullptr, join = nullptr;
+    void release() override {
+        if (join) (void)hipEventDestroy(join);
+        if (fork) (void)hipEventDestroy(fork);
+        if (s) (void)hipStreamDestroy(s);
+        s = nullptr, fork = join = nullptr;
+    }
+    ~SideStream() override {
+        if (!runtime_exiting()) release();
+    }
+    void init() {
+        if (s) return;
+        // (a CU-masked stream -- hipExtStreamCreateWithCUMask leaving four CUs per XCD to the caller's stream -- was
+        // tried: the two streams then do not overlap at all, 79.1 ms against 74.6 ms)
+        int least = 0, greatest = 0;
+        OVM_THROW_IF(hipDeviceGetStreamPriorityRange(&least, &greatest));
+        OVM_THROW_IF(hipStreamCreateWithPriority(&s, hipStreamNonBlocking, least));
+        OVM_THROW_IF(hipEventCreateWithFlags(&fork, hipEventDisableTiming));
+        OVM_THROW_IF(hipEventCreateWithFlags(&join, hipEventDisableTiming));
+    }
+};
+inline SideStream &side_stream() {
+    static thread_local SideStream streams[16];
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    return streams[dev & 15];
+}
+
 struct Ctx {
     hipStream_t stream;
     void sync() const {
@@ -1216,7 +1250,7 @@ struct Prover {
     // LogUp-GKR (prover/logup_zerocheck/fractional_sumcheck_gkr.rs:60-213): this rank's leaves on its device, the
     // tree over them, the layer sumchecks through the driver of gkr_shard.h (padding and cross-rank records on the host).
     GkrOutput prove_gkr(const std::vector<TraceView> &tv, std::vector<TracePrograms> &progs, const Layout &ilayout, unsigned TR,
-                        EF alpha, const std::vector<EF> &beta_pows) {
+                        EF alpha, const std::vector<EF> &beta_pows, const std::function<void()> &after_build) {
         const size_t T = traces.size();
         const uint64_t n_leaves = uint64_t(1) << TR;
         // The interaction slices are packed from row 0 with no gaps (descending powers of two) in sorted
@@ -1304,6 +1338,7 @@ struct Prover {
             gd.build();
         }
         wt.mark("rap.gkr.build");
+        if (after_build) after_build();  // (the tree is enqueued: what follows is latency-bound for its first dozen layers)
         OVM_PROF("gkr.layer_sumchecks", cx.stream);
         GkrSharded drv(plan, sh, gd, alpha);
         drv.force_three_points = force_three_points;
@@ -1408,10 +1443,98 @@ struct Prover {
         for (auto &a : pk.airs) max_constraints = std::max(max_constraints, a.constraint_idx.size());
         std::vector<EF> beta_pows = powers_of(beta, max_msg + 1);
 
+        // shift^i / N per coset (the iDFT scale is folded in): the same for every trace
+        const Fp g = fp(bb::GENERATOR), omega_skip = bb::two_adic_generator(l_skip);
+        std::vector<Fp> shift_pows(MAX_COSETS * N);
+        for (unsigned k = 0; k < MAX_COSETS; k++) {
+            Fp sh = g.pow(k + 1), cur = fp((uint64_t)N).inv();
+            for (size_t i = 0; i < N; i++) {
+                shift_pows[k * N + i] = cur;
+                cur *= sh;
+            }
+        }
+        auto d_sp_all = cx.upload(shift_pows);
+
+        // ---- round 0's coset LDE, early ----
+        // The extension of a trace to the cosets depends on no challenge. Once the GKR tree is enqueued the device
+        // has ~3 ms of layer sumchecks ahead in which it mostly waits for the host (tables of a few pairs, one mailbox
+        // round trip per sub-round): the LDE (1.6 ms at config D) runs beside them on the library's low-priority side
+        // stream and round 0 finds it done. Not with zerocheck_save_memory (the LDE buffer is a slab there, reused),
+        // and not when the buffer cannot be had (round 0 then allocates it after the tree has been freed).
+        struct EarlyLde {
+            DevBuf<Fp> lde;
+            DevBuf<uint32_t> d_used;
+            std::vector<uint32_t> used;
+            unsigned n_cosets = 0;
+            bool done = false;
+        };
+        struct EarlyLdeSet {  // (a proof that fails between fork and join must not hand the buffers back while the kernel runs)
+            std::vector<EarlyLde> per_trace;
+            bool in_flight = false;
+            ~EarlyLdeSet() {
+                if (in_flight) (void)hipStreamSynchronize(side_stream().s);
+            }
+        } early;
+        early.per_trace.resize(T);
+        auto used_columns = [&](size_t t, const std::vector<uint32_t> &zc_used, const std::vector<uint32_t> *lg_used) {
+            std::vector<char> usedm(tv[t].cm.total, 0);
+            for (auto c : zc_used) usedm[c] = 1;
+            if (lg_used)
+                for (auto c : *lg_used) usedm[c] = 1;
+            std::vector<uint32_t> used;
+            for (size_t c = 0; c < usedm.size(); c++)
+                if (usedm[c]) used.push_back((uint32_t)c);
+            return used;
+        };
+        std::function<void()> enqueue_early_lde;
+        if (tuning().early_lde && !prover_config().zerocheck_save_memory) {
+            for (size_t t = 0; t < T; t++) {
+                if (!mine(t)) continue;
+                const AirKey &a = air(t);
+                EarlyLde &e = early.per_trace[t];
+                const unsigned cdeg = a.max_constraint_degree;
+                e.n_cosets = std::max(cdeg ? cdeg - 1 : 0u, a.interactions.empty() ? 0u : cdeg);
+                if (!e.n_cosets || e.n_cosets > MAX_COSETS) continue;
+                e.used = used_columns(t, progs[t].zc.used_cols, a.interactions.empty() ? nullptr : &progs[t].lg.used_cols);
+            }
+            enqueue_early_lde = [&]() {
+                SideStream &ss = side_stream();
+                ss.init();
+                bool any = false;
+                for (size_t t = 0; t < T; t++) {
+                    EarlyLde &e = early.per_trace[t];
+                    if (e.used.empty()) continue;
+                    try {
+                        e.lde.alloc((size_t)e.n_cosets * tv[t].cm.total << tv[t].log_lifted);
+                    } catch (const OvmFail &) {
+                        continue;
+                    }
+                    e.d_used = cx.upload(e.used);
+                    e.done = true;
+                    any = true;
+                }
+                if (!any) return;
+                flush_uploads(cx.stream);
+                OVM_THROW_IF(hipEventRecord(ss.fork, cx.stream));
+                OVM_THROW_IF(hipStreamWaitEvent(ss.s, ss.fork, 0));
+                early.in_flight = true;
+                {
+                    OVM_PROF("round0.coset_lde", ss.s);
+                    for (size_t t = 0; t < T; t++) {
+                        EarlyLde &e = early.per_trace[t];
+                        if (!e.done) continue;
+                        OVM_THROW_IF(coset_lde(tv[t].cols.p, e.d_used.p, (uint32_t)e.used.size(), (uint32_t)tv[t].cm.total, tv[t].log_lifted,
+                                               l_skip, e.n_cosets, d_sp_all.p, e.lde.p, ss.s, 0, tuning().early_lde_lds_kib << 10));
+                    }
+                }
+                OVM_THROW_IF(hipEventRecord(ss.join, ss.s));
+            };
+        }
+
         // ---- GKR ----
         const unsigned TR = l_skip + n_logup;
         GkrOutput gk;
-        if (!ilayout.cols.empty()) gk = prove_gkr(tv, progs, ilayout, TR, alpha, beta_pows);
+        if (!ilayout.cols.empty()) gk = prove_gkr(tv, progs, ilayout, TR, alpha, beta_pows, enqueue_early_lde);
         std::vector<EF> xi = std::move(gk.xi);
         const EF q0_claim = gk.q0_claim;
         const std::vector<std::array<EF, 4>> &claims = gk.claims;               // p0,p1,q0,q1 per layer
@@ -1433,7 +1556,6 @@ struct Prover {
 
         EF lambda = ts.sample_ext();
         std::vector<EF> lambda_pows = powers_of(lambda, std::max<size_t>(max_constraints, 1));
-        const Fp g = fp(bb::GENERATOR), omega_skip = bb::two_adic_generator(l_skip);
         std::vector<Fp> omega_pows = powers_of(omega_skip, N);
 
         // ---- programs, eq weights, round 0 ----
@@ -1513,17 +1635,11 @@ struct Prover {
             return true;
         };
         size_t next_slot = 0;
-        // shift^i / N per coset (the iDFT scale is folded in): the same for every trace
-        std::vector<Fp> shift_pows(MAX_COSETS * N);
-        for (unsigned k = 0; k < MAX_COSETS; k++) {
-            Fp sh = g.pow(k + 1), cur = fp((uint64_t)N).inv();
-            for (size_t i = 0; i < N; i++) {
-                shift_pows[k * N + i] = cur;
-                cur *= sh;
-            }
-        }
-        auto d_sp_all = cx.upload(shift_pows);
         auto d_xi = cx.upload(xi);
+        if (early.in_flight) {  // the early LDEs: round 0's kernels on the caller's stream come after them
+            OVM_THROW_IF(hipStreamWaitEvent(cx.stream, side_stream().join, 0));
+            early.in_flight = false;
+        }
         // zerocheck_save_memory: the slab of every trace. Each slab's sums get mailbox slots of their own (all traces
         // are enqueued before the one wait), so the configured slab size is a LOWER bound: while the slabs of all
         // traces together would not fit the mailbox, the trace with the most slabs gets slabs twice as large.
@@ -1600,20 +1716,19 @@ struct Prover {
             // eq(xi[l_skip..l_skip+n_lift], x)
             job.d_eq.alloc(size_t(1) << v.n_lift);
             OVM_THROW_IF(eq_table(d_xi.p + l_skip, v.n_lift, job.d_eq.p, cx.stream));
-            std::vector<char> usedm(v.cm.total, 0);
-            for (auto c : tp[t].zc->prog.used_cols) usedm[c] = 1;
-            if (tp[t].lg)
-                for (auto c : tp[t].lg->prog.used_cols) usedm[c] = 1;
-            std::vector<uint32_t> used;
-            for (size_t c = 0; c < usedm.size(); c++)
-                if (usedm[c]) used.push_back((uint32_t)c);
-            job.d_used = cx.upload(used);
+            EarlyLde &early_t = early.per_trace[t];
+            const bool lde_done = early_t.done && early_t.n_cosets == n_cosets;
+            const std::vector<uint32_t> used =
+                lde_done ? early_t.used : used_columns(t, tp[t].zc->prog.used_cols, tp[t].lg ? &tp[t].lg->prog.used_cols : nullptr);
+            if (lde_done) job.d_used = std::move(early_t.d_used);
+            else job.d_used = cx.upload(used);
             // zerocheck_save_memory: a tall trace is extended and evaluated in slabs of 2^slab rows -- the LDE buffer
             // (n_cosets x columns x rows words: 3.5 GB at config D, 14 GB at config E) shrinks to one slab; the slab
             // sums are linear and are added up on the host. (The chunks of 2^l_skip rows are independent.)
             const unsigned slab_log = slab_logs[t];
             job.n_slabs = 1u << (v.log_lifted - slab_log);
-            job.lde.alloc((size_t)n_cosets * v.cm.total << slab_log);
+            if (lde_done) job.lde = std::move(early_t.lde);
+            else job.lde.alloc((size_t)n_cosets * v.cm.total << slab_log);
             const size_t red_blocks = std::min<size_t>(RED_BLOCKS, ((size_t(1) << slab_log) + RED_THREADS - 1) / RED_THREADS);
             const bool batch_zc = job.zc_cosets && job.n_slabs == 1 && r0_batchable(tp[t].zc->staged, v.log_lifted);
             const bool batch_lg = job.lg_cosets && job.n_slabs == 1 && r0_batchable(tp[t].lg->staged, v.log_lifted);
@@ -1641,7 +1756,7 @@ struct Prover {
             for (uint32_t sb = 0; sb < job.n_slabs; sb++) {
                 const uint64_t row0 = (uint64_t)sb << slab_log;
                 const EF *eq_slab = job.d_eq.p + (row0 >> l_skip);
-                {
+                if (!lde_done) {
                     OVM_PROF("round0.coset_lde", cx.stream);
                     OVM_THROW_IF(coset_lde(v.cols.p, job.d_used.p, (uint32_t)used.size(), (uint32_t)v.cm.total, slab_log, l_skip,
                                            n_cosets, d_sp_all.p, job.lde.p, cx.stream, row0));
@@ -3185,6 +3300,8 @@ Tuning ovm::Tuning::from_env() {
     t.finish_inline_max = (uint32_t)std::max(1, num("OVM_FINISH_INLINE_MAX", 64));
     t.finish_atomic_max = (uint32_t)std::max(0, num("OVM_FINISH_ATOMIC_MAX", 0));
     t.download_kernel = !off("OVM_DOWNLOAD_KERNEL");
+    t.early_lde = !off("OVM_EARLY_LDE");
+    t.early_lde_lds_kib = (uint32_t)std::max(0, num("OVM_EARLY_LDE_LDS_KIB", 64));
     t.trace = getenv("OVM_TRACE") != nullptr;
     t.test_fail_rank = num("OVM_TEST_FAIL_RANK", -1);
     return t;

@@ -418,7 +418,7 @@ __global__ __launch_bounds__(256) void coset_lde16_kernel(const ColDesc *cols, c
 
 int coset_lde(const ColDesc *d_cols, const uint32_t *d_used, uint32_t n_used, uint32_t n_cols_total,
               uint32_t log_lifted, uint32_t l_skip, uint32_t n_cosets, const Fp *d_shift_pows, Fp *lde,
-              hipStream_t s, uint64_t row0) {
+              hipStream_t s, uint64_t row0, uint32_t pad_lds_bytes) {
     if (n_used == 0 || n_cosets == 0) return 0;
     if (row0 & ((1ull << l_skip) - 1)) return (int)hipErrorInvalidValue;
     const Twiddles *tw = twiddles();
@@ -426,7 +426,7 @@ int coset_lde(const ColDesc *d_cols, const uint32_t *d_used, uint32_t n_used, ui
     // d_shift_pows[k * N + i] = shift_k^i / N (the caller folds 1/N in)
     if (l_skip == 4) {
         dim3 grid16((unsigned)ceil_div(1ull << (log_lifted - 4), 256), n_used);
-        OVM_LAUNCH(coset_lde16_kernel, grid16, dim3(256), 0, s, d_cols, d_used, n_cols_total, log_lifted,
+        OVM_LAUNCH(coset_lde16_kernel, grid16, dim3(256), pad_lds_bytes > 65536 ? 65536 : pad_lds_bytes, s, d_cols, d_used, n_cols_total, log_lifted,
                            n_cosets, d_shift_pows, lde, row0);
         OVM_CHECK_LAUNCH();
         return 0;

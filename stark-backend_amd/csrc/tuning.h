@@ -27,6 +27,11 @@ struct Tuning {
     uint32_t finish_atomic_max = 0;     // OVM_FINISH_ATOMIC_MAX: grids above finish_inline_max and up to this many workgroups
                                    // finish in the kernel through 64-bit atomic accumulators. 0 (default): never --
                                    // measured no faster in the prover than the second launch (stages.hip)
+    bool early_lde = true;         // OVM_EARLY_LDE=0: round 0's coset LDE runs where it is used, not beside the GKR layer sumchecks
+    // OVM_EARLY_LDE_LDS_KIB: LDS each workgroup of the early LDE claims without using it. 64 KiB = two workgroups per
+    // CU: the sumcheck kernels of the caller's stream find free wave slots at once (0 / 32 / 48 / 64 KiB: 75.8 / 75.3 /
+    // 75.2 / 74.8 ms per proof, 75.8 ms without the early LDE; profiles/r03/early_lde_sweep.txt)
+    uint32_t early_lde_lds_kib = 64;
     bool download_kernel = true;   // OVM_DOWNLOAD_KERNEL=0: small downloads through the runtime's copy + stream synchronisation
     bool trace = false;            // OVM_TRACE: wall-clock trace of the stages on stderr
     int test_fail_rank = -1;       // OVM_TEST_FAIL_RANK: this rank of a sharded proof throws after its commitment (tests)
