@@ -26,6 +26,7 @@
 // indices is a prefix product -- so its contribution to every round is a closed form. (For the
 // 1-GPU config D proof that removes the 6/32 of the GKR work that was padding.)
 #pragma once
+#include <algorithm>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -263,6 +264,17 @@ struct GkrSharded {
             uint64_t eidx[GKR_HOST_TAIL];
             GkrRec edges[GKR_HOST_TAIL];
         };
+        using HostRec = std::pair<uint64_t, GkrRec>;
+        using HostRecs = std::vector<HostRec>;
+        // scratch of the sub-round loop (kept across sub-rounds: no allocation per sub-round)
+        HostRecs known;
+        std::vector<Msg> all;
+        std::vector<uint64_t> hy;
+        std::vector<GkrRec> ha, hb, folded;
+        std::vector<EF> he;
+        std::vector<char> dumps;
+        std::vector<URange> Pn;
+        Msg mine{};
         const EF inv2 = EF::from_base(fp(2).inv());
         const bool trace_host = getenv("OVM_TRACE") != nullptr;  // (host time between two device sub-rounds, summed)
         auto host_t0 = std::chrono::steady_clock::now();
@@ -273,8 +285,10 @@ struct GkrSharded {
             // record ranges of every owner; host records = the layer's boundary fractions' children
             std::vector<URange> R(plan.owners());
             for (uint32_t o = 0; o < plan.owners(); o++) R[o] = up(plan.F[L][o]);
-            std::map<uint64_t, GkrRec> H;
-            for (auto &kv : boundary[L - 1]) H[kv.first] = rec_of(frac_at(L, 2 * kv.first), frac_at(L, 2 * kv.first + 1));
+            // (flat, sorted by record index: a layer's tail is six sub-rounds on 64, 32, ... records, and a tree node per
+            // record per sub-round -- copy, two lookups, re-insert -- was half of the ~33 us the host spent per tail)
+            HostRecs H;
+            for (auto &kv : boundary[L - 1]) H.push_back({kv.first, rec_of(frac_at(L, 2 * kv.first), frac_at(L, 2 * kv.first + 1))});
             const GkrRec pad_rec{{EF::zero(), pad_q[L], EF::zero(), pad_q[L]}};
             dev.begin_layer(round, xi_prev);
             std::vector<std::array<EF, 3>> polys;
@@ -292,14 +306,14 @@ struct GkrSharded {
                 const EF w0 = c_bound * (EF::one() - a);
                 const unsigned n_points = epilogue ? 0 : ((is_zero(w0) || force_three_points) ? 3 : 2);
                 // a rank with a short table hands ALL its records over and owns nothing from here on
-                std::vector<char> dumps(W, 0);
+                dumps.assign(W, 0);
                 for (uint32_t o = 0; o < W; o++) dumps[o] = !R[o].empty() && R[o].size() <= GKR_HOST_TAIL;
-                Msg mine{};
+                mine.n_edges = 0;  // (eidx / edges beyond n_edges are never read: no 4.6 KB clear per sub-round)
                 for (auto &s : mine.S) s = EF::zero();
                 URange my_records = R[me];
                 for (uint32_t o = 0; o < W; o++)
                     if (dumps[o]) R[o] = URange{0, 0};
-                std::vector<URange> Pn(plan.owners());
+                Pn.resize(plan.owners());
                 for (uint32_t o = 0; o < plan.owners(); o++) Pn[o] = epilogue ? URange{0, 0} : up(R[o]);
                 // my device part
                 if (dumps[me]) {
@@ -316,60 +330,68 @@ struct GkrSharded {
                     dev.subround(round, sr, Pn[me], mine.eidx, (unsigned)mine.n_edges, r_prev, lambda, n_points, mine.S, mine.edges);
                     if (trace_host) host_t0 = std::chrono::steady_clock::now();
                 }
-                std::vector<Msg> all(W);
-                comm.allgather(&mine, all.data(), sizeof(Msg));
+                all.resize(W);
+                if (W == 1) all[0] = mine;  // (allgather of one rank)
+                else comm.allgather(&mine, all.data(), sizeof(Msg));
                 // table records known to the host in this sub-round: edges of every owner + host records
-                std::map<uint64_t, GkrRec> known = H;
+                known.assign(H.begin(), H.end());
                 EF S[3] = {EF::zero(), EF::zero(), EF::zero()};
                 for (uint32_t o = 0; o < W; o++) {
                     for (unsigned k = 0; k < n_points; k++) S[k] += all[o].S[k];
-                    for (uint64_t k = 0; k < all[o].n_edges && k < GKR_HOST_TAIL; k++) known[all[o].eidx[k]] = all[o].edges[k];
+                    for (uint64_t k = 0; k < all[o].n_edges && k < GKR_HOST_TAIL; k++) known.push_back({all[o].eidx[k], all[o].edges[k]});
                 }
                 {  // the padding run: constant records, closed-form sums
                     uint64_t pe[2];
                     const unsigned ne = range_edges(R[W], pe);
-                    for (unsigned k = 0; k < ne; k++) known[pe[k]] = pad_rec;
+                    for (unsigned k = 0; k < ne; k++) known.push_back({pe[k], pad_rec});
                     if (!Pn[W].empty()) {
                         const EF wsum = eq_prefix_sum(pt, nv, Pn[W].hi) - eq_prefix_sum(pt, nv, Pn[W].lo);
                         rec_pair_sums(pad_rec, pad_rec, wsum, lambda, n_points, S);
                     }
                 }
+                // in index order; a record reported twice keeps the later report (what operator[] of a map did)
+                std::stable_sort(known.begin(), known.end(), [](const HostRec &a, const HostRec &b) { return a.first < b.first; });
+                {
+                    size_t n = 0;
+                    for (size_t i = 0; i < known.size(); i++) {
+                        if (n && known[n - 1].first == known[i].first) known[n - 1] = known[i];
+                        else known[n++] = known[i];
+                    }
+                    known.resize(n);
+                }
                 if (epilogue) {
-                    auto it = known.find(0);
-                    if (it == known.end()) throw OvmFail(1, "internal: GKR layer claims missing");
-                    final_rec = it->second;
+                    if (known.empty() || known[0].first != 0) throw OvmFail(1, "internal: GKR layer claims missing");
+                    final_rec = known[0].second;
                     break;
                 }
                 // pairs nobody owns: both records are known. Gathered first, then summed as ONE batch (eight pairs per
                 // AVX2 step): a layer's tail is up to 32 + 16 + ... pairs, ~950 extension-field products
-                std::map<uint64_t, GkrRec> Hn;
-                std::vector<uint64_t> hy;
-                std::vector<GkrRec> ha, hb;
-                for (auto &kv : known) {
-                    const uint64_t y = kv.first >> 1;
-                    if (!hy.empty() && hy.back() == y) continue;
+                hy.clear(), ha.clear(), hb.clear();
+                for (size_t i = 0; i < known.size(); i += 2) {
+                    const uint64_t y = known[i].first >> 1;
                     bool owned = false;
                     for (uint32_t o = 0; o < plan.owners(); o++) owned |= Pn[o].has(y);
                     if (owned) throw OvmFail(1, "internal: GKR edge record inside an owned pair");
-                    auto ia = known.find(2 * y), ib = known.find(2 * y + 1);
-                    if (ia == known.end() || ib == known.end()) throw OvmFail(1, "internal: GKR host pair incomplete");
+                    // sorted and distinct: the two records of pair y are neighbours
+                    if (i + 1 >= known.size() || known[i].first != 2 * y || known[i + 1].first != 2 * y + 1)
+                        throw OvmFail(1, "internal: GKR host pair incomplete");
                     hy.push_back(y);
-                    ha.push_back(ia->second);
-                    hb.push_back(ib->second);
+                    ha.push_back(known[i].second);
+                    hb.push_back(known[i + 1].second);
                 }
                 if (!hy.empty()) {
-                    std::vector<EF> he(hy.size());
+                    he.resize(hy.size());
                     gkr_eq_batch(pt, nv, hy.data(), hy.size(), he.data());
                     gkr_pair_sums_batch(ha.data(), hb.data(), he.data(), hy.size(), lambda, n_points, S);
                 }
                 // s(X) = c_bound * eq1(a, X) * S(X), S quadratic: two points + the claim give the third
-                std::vector<EF> Sv(S, S + n_points);
+                EF Sv[3] = {S[0], S[1], S[2]};
                 const EF a2 = a.dbl(), a3 = a2 + a, a5 = a3 + a2;
                 const EF w[3] = {c_bound * a, c_bound * (a3 - EF::one()), c_bound * (a5 - EF::one().dbl())};
                 EF S0;
                 if (n_points == 2) {
                     S0 = (claim - w[0] * Sv[0]) * w0.inv();
-                    Sv.push_back(S0 - (Sv[0].dbl() + Sv[0]) + (Sv[1].dbl() + Sv[1]));
+                    Sv[2] = S0 - (Sv[0].dbl() + Sv[0]) + (Sv[1].dbl() + Sv[1]);
                 } else {
                     S0 = (Sv[0].dbl() + Sv[0]) - (Sv[1].dbl() + Sv[1]) + Sv[2];
                 }
@@ -381,12 +403,12 @@ struct GkrSharded {
                 c_bound = c_bound * (a * r_prev + (EF::one() - a) * (EF::one() - r_prev));
                 const EF rm1 = r_prev - EF::one(), rm2 = rm1 - EF::one();
                 claim = c_bound * (S0 * (rm1 * rm2) * inv2 - Sv[0] * (r_prev * rm2) + Sv[1] * (r_prev * rm1) * inv2);
+                H.clear();
                 if (!hy.empty()) {
-                    std::vector<GkrRec> folded(hy.size());
+                    folded.resize(hy.size());
                     gkr_fold_batch(ha.data(), hb.data(), hy.size(), r_prev, folded.data());
-                    for (size_t i = 0; i < hy.size(); i++) Hn.emplace_hint(Hn.end(), hy[i], folded[i]);
+                    for (size_t i = 0; i < hy.size(); i++) H.push_back({hy[i], folded[i]});  // (ascending y: stays sorted)
                 }
-                H = std::move(Hn);
                 R = Pn;
             }
             out.claims.push_back({final_rec.v[0], final_rec.v[2], final_rec.v[1], final_rec.v[3]});

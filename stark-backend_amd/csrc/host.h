@@ -276,17 +276,13 @@ struct Transcript {
     Fp grind(unsigned bits) {
         if (bits == 0) return Fp::zero();
         if (bits <= 6) {
-            // ~2^bits candidates: a host search (about 1.5 us per candidate) beats a device launch plus
+            // ~2^bits candidates: a host search (about 0.25 us per candidate) beats a device launch plus
             // two copies and a synchronisation (~85 us); same minimum witness
-            for (uint32_t w = 0; w < bb::P; w++) {
-                p2::Sponge t = s;
-                t.observe(Fp::from_canonical(w));
-                if (t.sample_bits(bits) == 0) {
-                    s = t;
-                    return Fp::from_canonical(w);
-                }
-            }
-            throw OvmFail(1, "grind: no witness");
+            const uint32_t w = p2::host_grind_min_witness(s, bits);  // (eight candidates per step: host_poseidon2.cpp)
+            if (w == ~0u) throw OvmFail(1, "grind: no witness");
+            s.observe(Fp::from_canonical(w));
+            if (s.sample_bits(bits) != 0) throw OvmFail(1, "grind: witness does not verify");
+            return Fp::from_canonical(w);
         }
         ovm_sponge_t st;
         for (int i = 0; i < 16; i++) st.state[i] = s.state[i].v;

@@ -345,4 +345,20 @@ struct Sponge {
     BB_HD uint32_t sample_bits(unsigned bits) { return sample().canonical() & ((1u << bits) - 1); }
 };
 
+// The minimum witness w of a `bits`-bit proof-of-work on s: the smallest w with (s; observe(w); sample_bits(bits)) == 0,
+// or ~0. Host searches only (small `bits`; the device search is ovm_hip_sponge_grind). host_poseidon2.cpp tries eight
+// candidates per step with AVX2.
+#if !defined(__HIPCC_RTC__) && defined(__x86_64__) && defined(OVM_HOST_FAST_PERMUTE)
+uint32_t host_grind_min_witness(const Sponge &s, unsigned bits);  // (a host function; declared in both compilation passes)
+#elif !defined(__HIPCC_RTC__)
+inline uint32_t host_grind_min_witness(const Sponge &s, unsigned bits) {
+    for (uint32_t w = 0; w < bb::P; w++) {
+        Sponge t = s;
+        t.observe(Fp::from_canonical(w));
+        if (t.sample_bits(bits) == 0) return w;
+    }
+    return ~0u;
+}
+#endif
+
 }  // namespace p2

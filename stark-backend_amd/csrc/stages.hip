@@ -103,6 +103,10 @@ __device__ __forceinline__ void publish(const RedOut &ro) {
 template <int KMAX>
 __device__ void finish_reduction(const RedOut &ro, uint32_t n_records, uint32_t K) {
     if (ro.counter == nullptr) return;  // large grid: sum_partials finishes (see red_finish)
+    if (gridDim.x * gridDim.y * gridDim.z == 1 && ro.acc == nullptr) {  // block_sum_out wrote the totals themselves
+        if (threadIdx.x == 0) publish(ro);
+        return;
+    }
     __shared__ uint32_t s_last;
     if (threadIdx.x == 0) {
         const uint32_t total = gridDim.x * gridDim.y * gridDim.z;
@@ -191,10 +195,16 @@ static inline int red_finish(const RedOut &ro, uint32_t total_blocks, uint32_t n
     if (total_blocks > tuning().finish_inline_max) return sum_partials(ro, n_records, K, s);
     return 0;
 }
+__device__ __forceinline__ bool solo_workgroup(const RedOut &ro) {
+    return gridDim.x * gridDim.y * gridDim.z == 1 && ro.counter != nullptr && ro.acc == nullptr;
+}
 // a workgroup's K totals: into the accumulators (atomic finish) or as its record
 template <int K>
 __device__ __forceinline__ void block_sum_out(EF (&v)[K], const RedOut &ro, size_t record_off, uint32_t k_off = 0) {
+    // (a launch of ONE workgroup -- most sub-rounds of the small GKR layers, the tails of every sumcheck -- has no
+    // records to combine: its totals go straight to the mailbox, and finish_reduction only raises the flag)
     if (ro.acc) block_sum_atomic<K>(v, ro, k_off);
+    else if (solo_workgroup(ro)) block_sum_store<K, true>(v, ro.out + record_off);
     else block_sum_store<K>(v, ro.partials + record_off, ro.counter != nullptr);
 }
 
@@ -257,7 +267,7 @@ __global__ void eq_double_kernel(const EF *point, uint32_t k, Out out) {
     out.st(y, MOBIUS ? lo - hi.dbl() : lo - hi);
 }
 
-static constexpr uint32_t EQ_DIRECT_BITS = 10;
+static constexpr uint32_t EQ_DIRECT_BITS = 16;  // (a launch is ~4.5 us, 2^16 entries x 16 products are ~2 us of the device: the MLE rounds built their tables with up to 8 doubling launches each)
 
 template <bool MOBIUS, class Out>
 static int eq_table_impl(const EF *d_point, uint32_t n, Out out, hipStream_t s) {
