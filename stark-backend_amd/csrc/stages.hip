@@ -2216,13 +2216,20 @@ int whir_mu_batch(const Fp *msg, uint32_t width, uint32_t log_h, const EF *d_mu_
     return 0;
 }
 
-// One pass of up to ZT_BITS butterfly stages (bits [b0, b0+nb)) of the subset-zeta / Moebius
-// transform, staged through LDS: tile = 2^nb x 2^c elements, c low bits contiguous.
+// One pass of up to ZT_TILE_LOG butterfly stages (bits [b0, b0+nb)) of the subset-zeta / Moebius
+// transform, staged through LDS: tile = 2^nb x 2^c elements, c low bits contiguous. The stages run FOUR AT A TIME in
+// registers: a lane takes the 16 elements that differ in four tile bits, applies the four stages (they act on
+// different bits, so their order does not matter: exact field additions) and puts them back -- one LDS round trip and
+// one barrier per four stages instead of per stage (the per-stage form moved 24 bytes of LDS per element per stage and
+// ran at 1.7 TB/s of HBM: 0.66 ms for the 2^24-point transform of the mu-batch). The tile is padded by one element
+// per 16, like the NTT's (a lane reading 16 consecutive elements / lanes reading consecutive elements: both
+// conflict-free).
 static constexpr uint32_t ZT_TILE_LOG = 11;
 __global__ __launch_bounds__(256) void zeta_pass_kernel(EF *v, uint32_t log_n, uint32_t b0, uint32_t nb, uint32_t c,
                                                         int dir) {
     extern __shared__ unsigned char zsm[];
     EF *tile = reinterpret_cast<EF *>(zsm);
+    auto pad = [](uint32_t l) -> uint32_t { return l + (l >> 4); };
     const uint32_t tile_size = 1u << (nb + c), c_mask = (1u << c) - 1;
     // position = (hi << (b0 + nb)) | (t << b0) | (mid << c) | cc   (c <= b0)
     const uint64_t tile_id = blockIdx.x;
@@ -2230,20 +2237,38 @@ __global__ __launch_bounds__(256) void zeta_pass_kernel(EF *v, uint32_t log_n, u
     const uint64_t base = (hi << (b0 + nb)) | (mid << c);
     for (uint32_t l = threadIdx.x; l < tile_size; l += 256) {
         uint64_t p = base | ((uint64_t)(l >> c) << b0) | (l & c_mask);
-        tile[l] = ld_ef(v + p);
+        tile[pad(l)] = ld_ef(v + p);
     }
     __syncthreads();
-    for (uint32_t k = 0; k < nb; k++) {
+    uint32_t k = 0;
+    for (; k + 4 <= nb; k += 4) {
+        const uint32_t lbit = k + c, lo_mask = (1u << lbit) - 1;
+        for (uint32_t g = threadIdx.x; g < (tile_size >> 4); g += 256) {
+            const uint32_t l_base = ((g & ~lo_mask) << 4) | (g & lo_mask);
+            EF x[16];
+#pragma unroll
+            for (int e = 0; e < 16; e++) x[e] = tile[pad(l_base | ((uint32_t)e << lbit))];
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+#pragma unroll
+                for (int e = 0; e < 16; e++)
+                    if (e >> j & 1) x[e] = dir > 0 ? x[e] + x[e ^ (1 << j)] : x[e] - x[e ^ (1 << j)];
+#pragma unroll
+            for (int e = 0; e < 16; e++) tile[pad(l_base | ((uint32_t)e << lbit))] = x[e];
+        }
+        __syncthreads();
+    }
+    for (; k < nb; k++) {
         const uint32_t lbit = k + c, lo_mask = (1u << lbit) - 1;
         for (uint32_t bf = threadIdx.x; bf < (tile_size >> 1); bf += 256) {
             uint32_t l0 = ((bf & ~lo_mask) << 1) | (bf & lo_mask), l1 = l0 | (1u << lbit);
-            tile[l1] = dir > 0 ? tile[l1] + tile[l0] : tile[l1] - tile[l0];
+            tile[pad(l1)] = dir > 0 ? tile[pad(l1)] + tile[pad(l0)] : tile[pad(l1)] - tile[pad(l0)];
         }
         __syncthreads();
     }
     for (uint32_t l = threadIdx.x; l < tile_size; l += 256) {
         uint64_t p = base | ((uint64_t)(l >> c) << b0) | (l & c_mask);
-        st_ef(v + p, tile[l]);
+        st_ef(v + p, tile[pad(l)]);
     }
 }
 int zeta_transform(EF *v, uint32_t log_n, int dir, hipStream_t s) {
@@ -2259,7 +2284,8 @@ int zeta_transform(EF *v, uint32_t log_n, int dir, hipStream_t s) {
             nb = log_n - b < ZT_TILE_LOG - c ? log_n - b : ZT_TILE_LOG - c;
         }
         uint32_t tiles = 1u << (log_n - nb - c);
-        OVM_LAUNCH(zeta_pass_kernel, dim3(tiles), dim3(256), sizeof(EF) << (nb + c), s, v, log_n, b, nb, c, dir);
+        OVM_LAUNCH(zeta_pass_kernel, dim3(tiles), dim3(256), sizeof(EF) * ((1u << (nb + c)) + (1u << (nb + c) >> 4) + 1), s, v, log_n, b, nb,
+                   c, dir);
         OVM_CHECK_LAUNCH();
         b += nb;
     }
