@@ -3301,6 +3301,7 @@ Tuning ovm::Tuning::from_env() {
     t.finish_atomic_max = (uint32_t)std::max(0, num("OVM_FINISH_ATOMIC_MAX", 0));
     t.download_kernel = !off("OVM_DOWNLOAD_KERNEL");
     t.early_lde = !off("OVM_EARLY_LDE");
+    t.lazy_w_accumulate = !off("OVM_LAZY_W");
     t.early_lde_lds_kib = (uint32_t)std::max(0, num("OVM_EARLY_LDE_LDS_KIB", 64));
     t.trace = getenv("OVM_TRACE") != nullptr;
     t.test_fail_rank = num("OVM_TEST_FAIL_RANK", -1);

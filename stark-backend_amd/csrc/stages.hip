@@ -2394,8 +2394,55 @@ __global__ void whir_w_accumulate_kernel(EF *w, uint32_t log_n, const EF *tab_lo
         acc = acc + ld_ef(tab_lo + ((uint64_t)q << log_lo) + lo) * ld_ef(tab_hi + ((uint64_t)q << log_hi) + hi);
     st_ef(w + x, acc);
 }
+// The same sum with the products left unreduced: for log_lo >= 6 a wave's 64 positions share x_hi, so tab_hi's entry is
+// wave-uniform (scalar loads) and  sum_q a_q * b_q  over F[X]/(X^4 - 11) is 16 multiply-adds per q into SEVEN 96-bit
+// accumulators (the coefficients of X^0..X^6 of the plain polynomial product), reduced once after the loop and folded
+// with X^4 = 11 -- instead of, per q, three products for 11 * b, four Montgomery reductions and an extension-field
+// addition (~100 issue slots against 48; the n_q = 194 queries of a config D round: 458 -> ~230 us).
+__global__ __launch_bounds__(256) void whir_w_accumulate_lazy_kernel(EF *w, uint32_t log_n, const EF *tab_lo, const EF *tab_hi,
+                                                                     uint32_t log_lo, uint32_t n_q) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const uint64_t x = (uint64_t)blockIdx.x * 256 + threadIdx.x;  // (the grid is exactly 2^log_n / 256)
+    const uint32_t lo = (uint32_t)(x & ((1ull << log_lo) - 1));
+    const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(x >> log_lo));
+    const uint32_t log_hi = log_n - log_lo;
+    uint64_t alo[7];
+    uint32_t ahi[7];
+#pragma unroll
+    for (int k = 0; k < 7; k++) alo[k] = 0, ahi[k] = 0;
+    for (uint32_t q = 0; q < n_q; q++) {
+        const EF a = ld_ef(tab_lo + ((uint64_t)q << log_lo) + lo);
+        const uint4 b4 = ((const OVM_CONST_AS uint4 *)tab_hi)[((uint64_t)q << log_hi) + hi];
+        const uint32_t b[4] = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) mac96(alo[i + j], ahi[i + j], a.c[i].v, b[j]);
+    }
+    Fp f[7];
+#pragma unroll
+    for (int k = 0; k < 7; k++) {  // (hi * 2^64 + lo) * 2^-32 mod P, as Acc96::finish
+        uint32_t xh = (uint32_t)(alo[k] >> 32);
+        xh = bb::umin32(xh, xh - bb::P);
+        xh = bb::umin32(xh, xh - bb::P);
+        f[k] = Fp::raw(bb::mont_reduce(((uint64_t)xh << 32) | (uint32_t)alo[k])) + Fp::raw(ahi[k]) * Fp::raw(bb::R2);
+    }
+    const Fp W = bb::fp_const<11>();
+    EF acc = ld_ef(w + x);
+    acc.c[0] += f[0] + f[4] * W;
+    acc.c[1] += f[1] + f[5] * W;
+    acc.c[2] += f[2] + f[6] * W;
+    acc.c[3] += f[3];
+    st_ef(w + x, acc);
+#endif
+}
 int whir_w_accumulate(EF *w, uint32_t log_n, const EF *d_tab_lo, const EF *d_tab_hi, uint32_t log_lo, uint32_t n_q,
                       hipStream_t s) {
+    if (log_lo >= 6 && log_n >= 8 && tuning().lazy_w_accumulate) {
+        OVM_LAUNCH(whir_w_accumulate_lazy_kernel, dim3(1u << (log_n - 8)), dim3(256), 0, s, w, log_n, d_tab_lo, d_tab_hi, log_lo, n_q);
+        OVM_CHECK_LAUNCH();
+        return 0;
+    }
     OVM_LAUNCH(whir_w_accumulate_kernel, dim3(ceil_div(1ull << log_n, 256)), dim3(256), 0, s, w, log_n,
                        d_tab_lo, d_tab_hi, log_lo, n_q);
     OVM_CHECK_LAUNCH();

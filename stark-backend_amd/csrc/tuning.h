@@ -32,6 +32,7 @@ struct Tuning {
     // CU: the sumcheck kernels of the caller's stream find free wave slots at once (0 / 32 / 48 / 64 KiB: 75.8 / 75.3 /
     // 75.2 / 74.8 ms per proof, 75.8 ms without the early LDE; profiles/r03/early_lde_sweep.txt)
     uint32_t early_lde_lds_kib = 64;
+    bool lazy_w_accumulate = true;  // OVM_LAZY_W=0: whir_w_accumulate reduces every product (the parity tests compare the two)
     bool download_kernel = true;   // OVM_DOWNLOAD_KERNEL=0: small downloads through the runtime's copy + stream synchronisation
     bool trace = false;            // OVM_TRACE: wall-clock trace of the stages on stderr
     int test_fail_rank = -1;       // OVM_TEST_FAIL_RANK: this rank of a sharded proof throws after its commitment (tests)

@@ -33,7 +33,8 @@ def main():
     knobs = {"OVM_R0_ROWS": ["", "1", "2", "4"], "OVM_STAGE_ROWS": ["", "2", "3", "8"], "OVM_ACC_ROWS": ["", "1", "4"],
              "OVM_R0_BATCH": ["", "0"], "OVM_MLE_BATCH": ["", "0", "64"], "OVM_MLE_POINTS": ["", "0"],
              "OVM_R0_GROUPS_MIN": ["", "2", "4"], "OVM_MLE_GROUPS_MAX": ["", "16", "32"],
-             "OVM_GKR_THREE_POINTS": ["", "", "1"], "OVM_MERKLE_COOP": ["", "0"]}
+             "OVM_GKR_THREE_POINTS": ["", "", "1"], "OVM_MERKLE_COOP": ["", "0"], "OVM_LAZY_W": ["", "0"],
+             "OVM_EARLY_LDE": ["", "", "0"]}
     bad = 0
     for case in range(args.cases):
         env = {k: str(rng.choice(v)) for k, v in knobs.items()}

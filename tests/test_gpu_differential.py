@@ -178,3 +178,20 @@ def test_atomic_finish_of_large_reductions(dev, pkg, orc, monkeypatch, seed):
         h = 1 << int(rng.integers(10, 13))
         traces.append((i, rng.integers(0, airs.P, size=width * h, dtype=np.uint64).astype(np.uint32), h, []))
     _run(dev, pkg, orc, params, air_list, traces)
+
+
+@pytest.mark.parametrize("lazy", ["1", "0"])
+def test_whir_w_accumulate_lazy_and_reduced(dev, pkg, orc, monkeypatch, lazy):
+    """WHIR's  w += sum_q gamma_q eq(., z_q)  with the products accumulated unreduced in 96-bit words (stages.hip:
+    whir_w_accumulate_lazy_kernel, taken when the folded polynomial has >= 2^12 coefficients) and with every product
+    reduced (OVM_LAZY_W=0): the same proof as the oracle's either way."""
+    monkeypatch.setenv("OVM_LAZY_W", lazy)
+    rng = np.random.default_rng(9200)
+    params = airs.test_params(l_skip=3, n_stack=12, k_whir=2)
+    air_list, traces = [], []
+    for i in range(2):
+        width = int(rng.integers(3, 8))
+        air_list.append(airs.random_air(rng, width, int(rng.integers(4, 12)), int(rng.integers(1, 3))))
+        h = 1 << int(rng.integers(11, 14))
+        traces.append((i, rng.integers(0, airs.P, size=width * h, dtype=np.uint64).astype(np.uint32), h, []))
+    _run(dev, pkg, orc, params, air_list, traces)
