@@ -89,16 +89,27 @@ __attribute__((target("avx2"))) void permute_avx2(Fp *s) {
         v1 = sbox(v1, _mm256_load_si256((const __m256i *)(t.rc_initial + 16 * r + 8)));
         external_linear(v0, v1);
     }
+    // Internal layers. Word 0 lives in a scalar for the 13 rounds (lane 0 of v0 is kept at zero): its S-box -- three
+    // dependent Montgomery products, the longest chain of the round -- then runs BESIDE the vector work that does not
+    // need it (the sum of words 1..15 and the diagonal products), and the round's critical path is the scalar chain
+    // alone:  s0' = part - y,  s_i' = d_i s_i + (part + y)  with  y = (s0 + rc)^7,  part = s_1 + ... + s_15.
+    const __m256i zero = _mm256_setzero_si256();
+    Fp x0 = Fp::raw((uint32_t)_mm256_cvtsi256_si32(v0));
+    v0 = _mm256_blend_epi32(v0, zero, 0x01);
     for (int r = 0; r < 13; r++) {
-        const Fp x0 = sbox7_add(Fp::raw((uint32_t)_mm256_cvtsi256_si32(v0)), RC_INTERNAL[r]);
-        v0 = _mm256_blend_epi32(v0, _mm256_castsi128_si256(_mm_cvtsi32_si128((int)x0.v)), 0x01);
-        __m256i sum = add_p(v0, v1);
-        sum = add_p(sum, _mm256_permute2x128_si256(sum, sum, 0x01));
-        sum = add_p(sum, _mm256_shuffle_epi32(sum, 0x4E));
-        sum = add_p(sum, _mm256_shuffle_epi32(sum, 0xB1));  // every lane: the sum of all 16 words
-        v0 = add_p(mont_mul(v0, d0), sum);
-        v1 = add_p(mont_mul(v1, d1), sum);
+        const Fp y = sbox7_add(x0, RC_INTERNAL[r]);
+        __m256i part = add_p(v0, v1);
+        part = add_p(part, _mm256_permute2x128_si256(part, part, 0x01));
+        part = add_p(part, _mm256_shuffle_epi32(part, 0x4E));
+        part = add_p(part, _mm256_shuffle_epi32(part, 0xB1));  // every lane: s_1 + ... + s_15
+        const __m256i p0 = mont_mul(v0, d0), p1 = mont_mul(v1, d1);  // (lane 0 of p0 stays zero)
+        const Fp part_s = Fp::raw((uint32_t)_mm256_cvtsi256_si32(part));
+        x0 = part_s - y;
+        const __m256i sum = _mm256_set1_epi32((int)(part_s + y).v);
+        v0 = _mm256_blend_epi32(add_p(p0, sum), zero, 0x01);
+        v1 = add_p(p1, sum);
     }
+    v0 = _mm256_blend_epi32(v0, _mm256_castsi128_si256(_mm_cvtsi32_si128((int)x0.v)), 0x01);
     for (int r = 0; r < 4; r++) {
         v0 = sbox(v0, _mm256_load_si256((const __m256i *)(t.rc_terminal + 16 * r)));
         v1 = sbox(v1, _mm256_load_si256((const __m256i *)(t.rc_terminal + 16 * r + 8)));
