@@ -116,6 +116,11 @@ struct MleJob {
 };
 int mle_round_eval_batched(const MleJob *d_jobs, const MleJob *h_jobs, uint32_t n_jobs, uint32_t degree,
                            uint32_t *d_counters, const RedOut &ro, hipStream_t s);
+// The same for jobs that qualify for the LDS-slot interpreter (mle_lds_eligible) and have at least a workgroup of pairs:
+// lanes enumerate pairs, all points in the lane; job.gx from mle_round_gx(log_h, degree, n_groups, true).
+int mle_round_eval_batched_lds(const MleJob *d_jobs, const MleJob *h_jobs, uint32_t n_jobs, uint32_t degree,
+                               uint32_t *d_counters, const RedOut &ro, hipStream_t s);
+bool mle_lds_eligible(uint32_t max_slots, uint32_t degree);
 // workgroups per (job, group) of the batched kernel (lanes enumerate (pair, point))
 uint32_t mle_round_batched_gx(uint32_t log_h, uint32_t degree, uint32_t n_groups);
 // workgroups along y that mle_round_eval_grouped uses for 2^(log_h-1) pairs and this many groups

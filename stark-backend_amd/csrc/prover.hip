@@ -1922,8 +1922,11 @@ struct Prover {
         // of a many-AIR proof are otherwise dozens of tiny launches serialised by the stream).
         // (OVM_MLE_BATCH=0 launches every job on its own: parity tests of the unbatched kernels on small traces)
         const uint32_t MLE_BATCH_MAX_WGS = tuning().mle_batch_wgs;  // (0: no batching)
-        DevBuf<uint32_t> mle_counters(2 * T + 1);
-        OVM_THROW_IF(hipMemsetAsync(mle_counters.p, 0, (2 * T + 1) * sizeof(uint32_t), cx.stream));
+        // (two batches per round: the (pair, point)-per-lane kernel for the short jobs and the LDS-slot kernel for jobs of at
+        // least 2^mle_batch_lds_min_log pairs; each with its own arrival counters)
+        DevBuf<uint32_t> mle_counters(2 * (2 * T + 1));
+        OVM_THROW_IF(hipMemsetAsync(mle_counters.p, 0, 2 * (2 * T + 1) * sizeof(uint32_t), cx.stream));
+        const uint32_t batch_lds_min_log = tuning().mle_batch_lds_min_log;
         OVM_PROF("constraints.mle_rounds", cx.stream);
         for (unsigned round = 1; round <= n_max; round++) {
             EF r_prev = r[round - 1];
@@ -1931,20 +1934,22 @@ struct Prover {
             // phase A: enqueue the round sums of every trace that still has rows to fold
             std::vector<char> eq_done(n_max + 1, 0);
             bool any_launch = false;
-            std::vector<MleJob> jobs;
+            std::vector<MleJob> jobs, jobs_lds;
             auto enqueue = [&](const GroupedDev &gd, const EF *weights, const EF *mats, unsigned log_h, uint32_t n_out,
                                const EF *eq, EF add_const, EF *partials, size_t partials_cap, size_t slot) {
                 const uint32_t n_groups = (uint32_t)gd.gp.off.size() - 1;
-                const uint32_t gx = mle_round_batched_gx(log_h, cdeg_global, n_groups);
+                const bool lds = log_h > batch_lds_min_log && mle_lds_eligible(gd.gp.max_slots, cdeg_global);
+                const uint32_t gx = lds ? mle_round_gx(log_h, cdeg_global, n_groups, true) : mle_round_batched_gx(log_h, cdeg_global, n_groups);
                 if (gx * n_groups <= MLE_BATCH_MAX_WGS) {
+                    std::vector<MleJob> &into = lds ? jobs_lds : jobs;
                     MleJob j{};
                     j.code = gd.code.p, j.off = gd.off.p, j.weights = weights, j.mats = mats, j.eq = eq;
                     j.partials = partials, j.out = mb.slot_ptr(slot), j.add_const = add_const;
                     j.log_h = log_h, j.n_out = n_out, j.n_groups = n_groups, j.gx = gx;
-                    j.z0 = jobs.empty() ? 0 : jobs.back().z0 + jobs.back().n_groups;
+                    j.z0 = into.empty() ? 0 : into.back().z0 + into.back().n_groups;
                     j.max_slots = gd.gp.max_slots;
                     j.partials_cap = (uint32_t)partials_cap;
-                    jobs.push_back(j);
+                    into.push_back(j);
                 } else {
                     OVM_THROW_IF(mle_round_eval_grouped(gd.code.p, gd.off.p, n_groups, gd.gp.max_slots, weights, mats, log_h,
                                                         cdeg_global, n_out, eq, add_const, mb.arm(partials, slot), cx.stream));
@@ -1967,6 +1972,11 @@ struct Prover {
                     enqueue(*tp[t].lg_g, tp[t].lg->weights.p, mats, v.cur_log_h, 2, d_eqr.p, tp[t].lg_const,
                             mle_partials[2 * t + 1].p, mle_partials[2 * t + 1].n, 16 * t + 8);
                 any_launch = true;
+            }
+            if (!jobs_lds.empty()) {
+                auto d_jobs = cx.upload(jobs_lds);
+                OVM_THROW_IF(mle_round_eval_batched_lds(d_jobs.p, jobs_lds.data(), (uint32_t)jobs_lds.size(), cdeg_global,
+                                                        mle_counters.p + (2 * T + 1), mb.arm(nullptr, 0), cx.stream));
             }
             if (!jobs.empty()) {  // armed last: its flag means every reduction of the round is done
                 auto d_jobs = cx.upload(jobs);
@@ -3301,6 +3311,7 @@ Tuning ovm::Tuning::from_env() {
     t.finish_atomic_max = (uint32_t)std::max(0, num("OVM_FINISH_ATOMIC_MAX", 0));
     t.download_kernel = !off("OVM_DOWNLOAD_KERNEL");
     t.early_lde = !off("OVM_EARLY_LDE");
+    t.mle_batch_lds_min_log = (uint32_t)std::max(0, num("OVM_MLE_BATCH_LDS_MIN_LOG", 9));
     t.lazy_w_accumulate = !off("OVM_LAZY_W");
     t.early_lde_lds_kib = (uint32_t)std::max(0, num("OVM_EARLY_LDE_LDS_KIB", 64));
     t.trace = getenv("OVM_TRACE") != nullptr;

@@ -208,6 +208,20 @@ __device__ __forceinline__ void block_sum_out(EF (&v)[K], const RedOut &ro, size
     else block_sum_store<K>(v, ro.partials + record_off, ro.counter != nullptr);
 }
 
+// The job a workgroup of a batched launch belongs to: the last one whose first index is <= v (the jobs' index ranges are
+// contiguous and ascending). A binary search: a 46-AIR proof batches ~90 jobs, and the linear scan this replaces was
+// up to 90 dependent scalar loads before a workgroup of the last jobs did anything.
+template <class First>
+__device__ __forceinline__ uint32_t find_job(uint32_t n_jobs, uint32_t v, First first) {
+    uint32_t lo = 0, hi = n_jobs - 1;
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi + 1) >> 1;
+        if (first(mid) <= v) lo = mid;
+        else hi = mid - 1;
+    }
+    return lo;
+}
+
 static inline uint32_t red_grid(uint64_t work_items) {
     uint64_t b = (work_items + RED_THREADS - 1) / RED_THREADS;
     if (b < 1) b = 1;
@@ -816,7 +830,7 @@ __global__ __launch_bounds__(RED_THREADS) void round0_staged_batched_kernel(cons
                                                                             uint32_t l_skip, uint32_t *counters,
                                                                             RedOut ro) {
     uint32_t j = 0;
-    while (j + 1 < n_jobs && blockIdx.x >= jobs[j].wg0 + jobs[j].gx) j++;
+    j = find_job(n_jobs, blockIdx.x, [&](uint32_t i) { return jobs[i].wg0; });
     const R0Job job = jobs[j];
     const uint32_t bx = blockIdx.x - job.wg0;
     const uint32_t K = (job.n_cosets * NOUT) << l_skip;
@@ -1163,15 +1177,12 @@ __global__ __launch_bounds__(RED_THREADS) void mle_round_points_kernel(const Ins
 //     resident workgroup, the arithmetic of the other one.
 static constexpr int MLE_BLOCK = 4;
 static constexpr uint32_t MLE_LDS_MAX_ROWS = 19;  // num_slots * D (KiB of LDS per workgroup): 2 workgroups per CU
+// (bx, gx: this workgroup's index and the number of workgroups along y of ITS job -- a batched launch runs several jobs)
 template <int D>
-__global__ __launch_bounds__(RED_THREADS) void mle_round_points_lds_kernel(const Instr *code, const uint32_t *off,
-                                                                           const EF *weights, const EF *mats,
-                                                                           uint32_t log_h, uint32_t n_out, const EF *eq,
-                                                                           EF add_const, RedOut ro, uint32_t fwd_mask) {
+__device__ __forceinline__ void mle_points_lds_body(const Instr *gcode, uint32_t n_instr, const EF *weights, const EF *mats,
+                                                    uint32_t log_h, uint32_t n_out, const EF *eq, EF first_const,
+                                                    uint32_t fwd_mask, uint32_t bx, uint32_t gx, EF (&sums)[2 * D]) {
     extern __shared__ uint32_t mle_lds[];
-    const uint32_t grp = blockIdx.z;
-    const Instr *gcode = code + off[grp];
-    const uint32_t n_instr = off[grp + 1] - off[grp];
     uint32_t *mine = mle_lds + threadIdx.x;
     auto slot_ld = [&](uint32_t s, EF (&v)[D]) {
 #pragma unroll
@@ -1186,15 +1197,13 @@ __global__ __launch_bounds__(RED_THREADS) void mle_round_points_lds_kernel(const
             for (int c = 0; c < 4; c++) mine[((s * D + x) * 4 + c) * RED_THREADS] = v[x].c[c].v;
     };
     const uint64_t n_y = 1ull << (log_h - 1);
-    const uint64_t stride = (uint64_t)gridDim.x * RED_THREADS;
-    EF sums[2 * D];
+    const uint64_t stride = (uint64_t)gx * RED_THREADS;
 #pragma unroll
     for (int k = 0; k < 2 * D; k++) sums[k] = EF::zero();
-    const EF first_const = grp == 0 ? add_const : EF::zero();
     EF prev[D];  // the result of the instruction before (program.h FWD_*: forwarded operands skip the LDS round trip)
 #pragma unroll
     for (int x = 0; x < D; x++) prev[x] = EF::zero();
-    for (uint64_t y = (uint64_t)blockIdx.x * RED_THREADS + threadIdx.x; y < n_y; y += stride) {
+    for (uint64_t y = (uint64_t)bx * RED_THREADS + threadIdx.x; y < n_y; y += stride) {
         EF out[D][2];
 #pragma unroll
         for (int x = 0; x < D; x++) {
@@ -1292,6 +1301,16 @@ __global__ __launch_bounds__(RED_THREADS) void mle_round_points_lds_kernel(const
             if (n_out > 1) sums[2 * x + 1] = sums[2 * x + 1] + out[x][1] * e;
         }
     }
+}
+template <int D>
+__global__ __launch_bounds__(RED_THREADS) void mle_round_points_lds_kernel(const Instr *code, const uint32_t *off,
+                                                                           const EF *weights, const EF *mats,
+                                                                           uint32_t log_h, uint32_t n_out, const EF *eq,
+                                                                           EF add_const, RedOut ro, uint32_t fwd_mask) {
+    const uint32_t grp = blockIdx.z;
+    EF sums[2 * D];
+    mle_points_lds_body<D>(code + off[grp], off[grp + 1] - off[grp], weights, mats, log_h, n_out, eq,
+                           grp == 0 ? add_const : EF::zero(), fwd_mask, blockIdx.x, gridDim.x, sums);
     block_sum_out<2 * D>(sums, ro, ((size_t)(blockIdx.x * gridDim.z + grp)) * (2 * D));
     finish_reduction<8>(ro, gridDim.x * gridDim.z, 2 * D);
 }
@@ -1307,6 +1326,37 @@ uint32_t mle_round_gx(uint32_t log_h, uint32_t degree, uint32_t n_groups, bool p
     return gx > cap ? cap : gx;
 }
 
+// Tail of the batched kernels: the workgroup's 2 D sums become its record; the job's last workgroup sums the job's
+// records into the job's mailbox slot; the last job raises the flag.
+template <int D>
+__device__ __forceinline__ void mle_job_finish(EF (&sums)[2 * D], const MleJob &job, uint32_t j, uint32_t grp, uint32_t n_jobs,
+                                               uint32_t *counters, const RedOut &ro) {
+    constexpr uint32_t K = 2 * D;
+    block_sum_store<2 * D>(sums, job.partials + ((size_t)(blockIdx.x * job.n_groups + grp)) * K, true);
+    __shared__ uint32_t s_last;
+    if (threadIdx.x == 0) s_last = atomicAdd(counters + 1 + j, 1u) == job.gx * job.n_groups - 1;
+    __syncthreads();
+    if (!s_last) return;
+    acquire_from_device();
+    EF acc[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) acc[k] = EF::zero();
+    const uint32_t n_records = job.gx * job.n_groups;
+    for (uint32_t b = threadIdx.x; b < n_records; b += RED_THREADS) {
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+            if ((uint32_t)k < K) acc[k] = acc[k] + ld_ef_agent(job.partials + (size_t)b * K + k);
+    }
+    block_sum_store<8, true>(acc, job.out);  // (released to the host)
+    if (threadIdx.x == 0) {
+        counters[1 + j] = 0;
+        if (atomicAdd(counters, 1u) == n_jobs - 1) {
+            counters[0] = 0;
+            publish(ro);
+        }
+    }
+}
+
 // Batched short rounds: lanes enumerate (pair y, point X) of a (job, group), so a round of 8 pairs and
 // 4 points fills 32 lanes of ONE wave instead of 8 lanes of four (the short rounds are bound by the
 // number of mostly-empty waves the machine has to run, not by latency: prefetching operands or
@@ -1315,7 +1365,7 @@ template <int NS, int D>
 __global__ __launch_bounds__(RED_THREADS) void mle_round_batched_kernel(const MleJob *jobs, uint32_t n_jobs,
                                                                         uint32_t *counters, RedOut ro) {
     uint32_t j = 0;
-    while (j + 1 < n_jobs && blockIdx.z >= jobs[j].z0 + jobs[j].n_groups) j++;
+    j = find_job(n_jobs, blockIdx.z, [&](uint32_t i) { return jobs[i].z0; });
     const MleJob job = jobs[j];
     if (blockIdx.x >= job.gx) return;
     const uint64_t n_items = (uint64_t)D << (job.log_h - 1);  // (y, X) pairs
@@ -1342,30 +1392,26 @@ __global__ __launch_bounds__(RED_THREADS) void mle_round_batched_kernel(const Ml
                 sums[2 * x + 1] = sums[2 * x + 1] + s1;
             }
     }
-    block_sum_store<2 * D>(sums, job.partials + ((size_t)(blockIdx.x * job.n_groups + grp)) * K, true);
-    // the job's last workgroup sums the job; the last job raises the flag
-    __shared__ uint32_t s_last;
-    if (threadIdx.x == 0) s_last = atomicAdd(counters + 1 + j, 1u) == job.gx * job.n_groups - 1;
-    __syncthreads();
-    if (!s_last) return;
-    acquire_from_device();
-    EF acc[8];
-#pragma unroll
-    for (int k = 0; k < 8; k++) acc[k] = EF::zero();
-    const uint32_t n_records = job.gx * job.n_groups;
-    for (uint32_t b = threadIdx.x; b < n_records; b += RED_THREADS) {
-#pragma unroll
-        for (int k = 0; k < 8; k++)
-            if ((uint32_t)k < K) acc[k] = acc[k] + ld_ef_agent(job.partials + (size_t)b * K + k);
-    }
-    block_sum_store<8, true>(acc, job.out);  // (system-scope fence after the stores)
-    if (threadIdx.x == 0) {
-        counters[1 + j] = 0;
-        if (atomicAdd(counters, 1u) == n_jobs - 1) {
-            counters[0] = 0;
-            publish(ro);
-        }
-    }
+    mle_job_finish<D>(sums, job, j, grp, n_jobs, counters, ro);
+}
+
+// The same batch with the LDS-slot, points-in-lane interpreter of the large rounds (mle_points_lds_body): for jobs of at
+// least a workgroup's worth of pairs. A many-AIR proof has dozens of wide, short traces with programs of 1 000-10 000
+// instructions (a reth segment: 46 AIRs, 12 815 columns): in the kernel above every column operand of theirs is a dependent
+// global load in front of its instruction and four lanes fetch the same pair, and that kernel was the largest of the
+// multilinear rounds (9.6 of 23 ms); here the operands of four instructions are in flight together and a pair is
+// fetched once.
+template <int D>
+__global__ __launch_bounds__(RED_THREADS) void mle_round_batched_lds_kernel(const MleJob *jobs, uint32_t n_jobs,
+                                                                            uint32_t *counters, RedOut ro, uint32_t fwd_mask) {
+    const uint32_t j = find_job(n_jobs, blockIdx.z, [&](uint32_t i) { return jobs[i].z0; });
+    const MleJob job = jobs[j];
+    if (blockIdx.x >= job.gx) return;
+    const uint32_t grp = blockIdx.z - job.z0;
+    EF sums[2 * D];
+    mle_points_lds_body<D>(job.code + job.off[grp], job.off[grp + 1] - job.off[grp], job.weights, job.mats, job.log_h, job.n_out,
+                           job.eq, grp == 0 ? job.add_const : EF::zero(), fwd_mask, blockIdx.x, job.gx, sums);
+    mle_job_finish<D>(sums, job, j, grp, n_jobs, counters, ro);
 }
 
 // workgroups per (job, group) of the batched kernel
@@ -1406,6 +1452,37 @@ int mle_round_eval_batched(const MleJob *d_jobs, const MleJob *h_jobs, uint32_t 
 #undef CALLD
     OVM_CHECK_LAUNCH();
     return 0;
+}
+
+int mle_round_eval_batched_lds(const MleJob *d_jobs, const MleJob *h_jobs, uint32_t n_jobs, uint32_t degree,
+                               uint32_t *d_counters, const RedOut &ro, hipStream_t s) {
+    if (n_jobs == 0) return 0;
+    if (degree == 0 || degree > 4) return (int)hipErrorInvalidValue;
+    uint32_t gx = 1, gz = 0, max_slots = 1;
+    for (uint32_t j = 0; j < n_jobs; j++) {
+        if (h_jobs[j].log_h == 0 || h_jobs[j].n_groups == 0 || h_jobs[j].n_out > 2 || h_jobs[j].z0 != gz ||
+            h_jobs[j].max_slots * degree > MLE_LDS_MAX_ROWS ||
+            (uint64_t)h_jobs[j].gx * h_jobs[j].n_groups * 2 * degree > h_jobs[j].partials_cap)
+            return (int)hipErrorInvalidValue;
+        gx = std::max(gx, h_jobs[j].gx);
+        gz += h_jobs[j].n_groups;
+        max_slots = std::max(max_slots, h_jobs[j].max_slots);
+    }
+    dim3 grid(gx, 1, gz);
+    const size_t lds_bytes = (size_t)max_slots * degree * 4 * RED_THREADS * sizeof(uint32_t);
+    const uint32_t fwd_mask = tuning().mle_forward ? 0xFFFFu : 0u;
+#define CALLD(DD) \
+    OVM_LAUNCH((mle_round_batched_lds_kernel<DD>), grid, dim3(RED_THREADS), lds_bytes, s, d_jobs, n_jobs, d_counters, ro, fwd_mask)
+    if (degree == 1) CALLD(1);
+    else if (degree == 2) CALLD(2);
+    else if (degree == 3) CALLD(3);
+    else CALLD(4);
+#undef CALLD
+    OVM_CHECK_LAUNCH();
+    return 0;
+}
+bool mle_lds_eligible(uint32_t max_slots, uint32_t degree) {
+    return mle_points_in_lane() && tuning().mle_lds_slots && max_slots * degree <= MLE_LDS_MAX_ROWS;
 }
 
 int mle_round_eval_grouped(const Instr *d_code, const uint32_t *d_off, uint32_t n_groups, uint32_t max_slots,
@@ -1476,7 +1553,7 @@ int fold_mle(const EF *in, EF *out, uint32_t n_cols, uint32_t log_h, EF r, hipSt
 
 __global__ void fold_mle_batched_kernel(const FoldJob *jobs, uint32_t n_jobs, EF r_in) {
     uint32_t j = 0;
-    while (j + 1 < n_jobs && blockIdx.y >= jobs[j].y0 + jobs[j].n_cols) j++;
+    j = find_job(n_jobs, blockIdx.y, [&](uint32_t i) { return jobs[i].y0; });
     const FoldJob job = jobs[j];
     const EF::Pre r = r_in.pre();
     const uint64_t h2 = 1ull << (job.log_h - 1);
@@ -1490,7 +1567,7 @@ __global__ void fold_mle_batched_kernel(const FoldJob *jobs, uint32_t n_jobs, EF
 // up to FoldJobsArg::MAX jobs travel as a kernel argument (no upload in front of every round)
 __global__ void fold_mle_batched_arg_kernel(FoldJobsArg a, uint32_t n_jobs, EF r_in) {
     uint32_t j = 0;
-    while (j + 1 < n_jobs && blockIdx.y >= a.j[j].y0 + a.j[j].n_cols) j++;
+    j = find_job(n_jobs, blockIdx.y, [&](uint32_t i) { return a.j[i].y0; });
     const FoldJob job = a.j[j];
     const EF::Pre r = r_in.pre();
     const uint64_t h2 = 1ull << (job.log_h - 1);
@@ -1645,7 +1722,7 @@ __global__ __launch_bounds__(256) void gkr_leaves_staged_kernel(DevStaged prog, 
 __global__ __launch_bounds__(256) void gkr_leaves_staged_batched_kernel(const LeavesJob *jobs, uint32_t n_jobs,
                                                                         FracPlanes leaves) {
     uint32_t j = 0;
-    while (j + 1 < n_jobs && blockIdx.x >= jobs[j].wg0 + jobs[j].gx) j++;
+    j = find_job(n_jobs, blockIdx.x, [&](uint32_t i) { return jobs[i].wg0; });
     const LeavesJob job = jobs[j];
     gkr_leaves_staged_body(job.prog, job.leaf_const, job.cols, job.log_height, job.leaf_base, job.leaf_log_len, job.norm,
                            leaves, blockIdx.x - job.wg0);
