@@ -221,6 +221,14 @@ int stacked_combine(const EF *q, const uint64_t *d_slice_off, uint32_t n_slices,
                     uint32_t chunks, hipStream_t s);
 // s[X-1] = sum_y Qeq(X,y) eq(X,y) + Qrot(X,y) krot(X,y), X = 1,2 ; vec = 4 columns of 2^log_h
 int stacked_round(const EF *vec4, uint32_t log_h, const RedOut &ro, hipStream_t s);
+// The round's two sums over the slices that have no variables left (round > n_lift), D_i kept in d_tail (see stages.hip).
+struct TailSlice {
+    uint64_t row;      // row_idx of the slice in its stacked column
+    uint32_t gcol;     // its column among this rank's stacked columns
+    uint32_t n_lift;   // its own rounds; ~0: not this rank's
+};
+int stacked_tail(const EF *q, uint32_t q_log_h, const TailSlice *d_slices, EF *d_tail, uint32_t n, uint32_t l_skip, uint32_t round,
+                 EF u_prev, const RedOut &ro, hipStream_t s);
 
 // ---- WHIR ----
 int whir_mu_batch(const Fp *msg, uint32_t width, uint32_t log_h, const EF *d_mu_pows, uint32_t mu_offset,

@@ -2472,6 +2472,35 @@ struct Prover {
         // per-window tables and combined vectors
         std::vector<EF> tail_d(tvs.size(), EF::zero());  // D_i of the finished slices (see the round loop)
         std::vector<char> tail_ready(tvs.size(), 0);
+        // The finished slices on the device (stages.hip: stacked_tail_kernel; OVM_STACKED_TAIL_DEVICE=0: the host loop):
+        // their D_i are uploaded once, when their window's last fold has produced (eq_fin, krot_fin).
+        const bool tail_on_device = tuning().stacked_tail_device && !tvs.empty();
+        DevBuf<TailSlice> d_tail_slices;
+        DevBuf<EF> d_tail, tail_partials;
+        if (tail_on_device) {
+            std::vector<TailSlice> ts_host(tvs.size());
+            for (size_t i = 0; i < tvs.size(); i++) {
+                const unsigned nl = tvs[i].s.log_height > l_skip ? tvs[i].s.log_height - l_skip : 0;
+                ts_host[i] = TailSlice{(uint64_t)tvs[i].s.row_idx, own(tvs[i].com) ? (uint32_t)(loff[tvs[i].com] + tvs[i].s.col_idx) : 0u,
+                                       own(tvs[i].com) ? nl : ~0u};
+            }
+            d_tail_slices = cx.upload(ts_host);
+            d_tail.alloc(tvs.size());
+            tail_partials.alloc(2 * RED_BLOCKS + 64);
+        }
+        auto tail_init_window = [&](size_t wi) {  // (eq_fin, krot_fin) of window wi are known: D_i of its slices
+            if (!tail_on_device) return;
+            const Window &wd = ws[wi];
+            std::vector<EF> init;
+            for (size_t i = win[wi]; i < win[wi + 1]; i++) {
+                EF dd = lam[tvs[i].leq] * wd.eq_fin;
+                if (tvs[i].lrot >= 0) dd += lam[(size_t)tvs[i].lrot] * wd.krot_fin;
+                init.push_back(dd);
+            }
+            auto d_init = cx.upload(init);
+            flush_uploads(cx.stream);
+            OVM_THROW_IF(hipMemcpyAsync(d_tail.p + win[wi], d_init.p, init.size() * sizeof(EF), hipMemcpyDeviceToDevice, cx.stream));
+        };
         {
             EF eq_u0r0 = eq_uni(l_skip, u0, r0), eq_u0r0_rot = eq_uni(l_skip, u0, r0 * omega_skip), eq_u01 = eq_uni_at_one(l_skip, u0);
             for (size_t wi = 0; wi < W; wi++) {
@@ -2522,6 +2551,7 @@ struct Prover {
                     auto fin = cx.download(wd.vec_a.p, 4);
                     wd.eq_fin = fin[2];
                     wd.krot_fin = fin[3];
+                    tail_init_window(wi);
                 }
             }
         }
@@ -2546,11 +2576,18 @@ struct Prover {
                 OVM_THROW_IF(stacked_round(vec, wd.cur_log_h, mb.arm(round_partials[wi].p, 8 * wi), cx.stream));
                 any_window_launch = true;
             }
-            // tail slices: gather their two entries
+            // tail slices: their sums on the device, or (host loop) gather their two entries
+            bool any_tail = false;
+            for (size_t wi = 0; wi < W; wi++) any_tail |= round > ws[wi].n_lift && ws[wi].own;
+            if (tail_on_device && any_tail) {
+                OVM_THROW_IF(stacked_tail(q_cur, q_log_h, d_tail_slices.p, d_tail.p, (uint32_t)tvs.size(), l_skip, round,
+                                          round > 1 ? u.back() : EF::zero(), mb.arm(tail_partials.p, 8 * W), cx.stream));
+                any_window_launch = true;
+            }
             std::vector<uint64_t> gidx;
             std::vector<size_t> gslice;
             for (size_t wi = 0; wi < W; wi++)
-                if (round > ws[wi].n_lift && ws[wi].own)
+                if (!tail_on_device && round > ws[wi].n_lift && ws[wi].own)
                     for (size_t i = win[wi]; i < win[wi + 1]; i++) {
                         uint64_t row_start = (tvs[i].s.row_idx >> (l_skip + round)) << 1;
                         const uint64_t gcol = loff[tvs[i].com] + tvs[i].s.col_idx;
@@ -2573,6 +2610,8 @@ struct Prover {
                     auto sv = mb.read(8 * wi, 2);
                     batch[0] += sv[0];
                     batch[1] += sv[1];
+                } else if (tail_on_device) {
+                    continue;  // (summed below, all finished slices at once)
                 } else {
                     // A finished slice contributes q(X) * eq1b(X, b) * D_i with
                     //   D_i = eq_ub_i * (lambda_eq * eq_fin + lambda_rot * krot_fin)   (constant in X),
@@ -2596,6 +2635,11 @@ struct Prover {
                         }
                     }
                 }
+            }
+            if (tail_on_device && any_tail) {
+                auto sv = mb.read(8 * W, 2);
+                batch[0] += sv[0];
+                batch[1] += sv[1];
             }
             if (!sh.single()) {  // every rank has summed its own windows and finished slices
                 std::vector<EF> bv{batch[0], batch[1]};
@@ -2641,10 +2685,11 @@ struct Prover {
                         auto fin = cx.download(o, 4);
                         wd.eq_fin = fin[2];
                         wd.krot_fin = fin[3];
+                        tail_init_window(wi);
                     }
                 }
             }
-            for (size_t i = 0; i < tvs.size(); i++) {
+            for (size_t i = 0; i < tvs.size() && !tail_on_device; i++) {
                 unsigned n_lift = tvs[i].s.log_height > l_skip ? tvs[i].s.log_height - l_skip : 0;
                 if (round > n_lift && tail_ready[i]) tail_d[i] = tail_d[i] * eq1b(ur, (tvs[i].s.row_idx >> (l_skip + round - 1)) & 1);
             }
@@ -3311,6 +3356,7 @@ Tuning ovm::Tuning::from_env() {
     t.finish_atomic_max = (uint32_t)std::max(0, num("OVM_FINISH_ATOMIC_MAX", 0));
     t.download_kernel = !off("OVM_DOWNLOAD_KERNEL");
     t.early_lde = !off("OVM_EARLY_LDE");
+    t.stacked_tail_device = !off("OVM_STACKED_TAIL_DEVICE");
     t.mle_batch_lds_min_log = (uint32_t)std::max(0, num("OVM_MLE_BATCH_LDS_MIN_LOG", 9));
     t.lazy_w_accumulate = !off("OVM_LAZY_W");
     t.early_lde_lds_kib = (uint32_t)std::max(0, num("OVM_EARLY_LDE_LDS_KIB", 64));

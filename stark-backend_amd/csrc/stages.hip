@@ -2273,6 +2273,52 @@ int stacked_round(const EF *vec4, uint32_t log_h, const RedOut &ro, hipStream_t 
     return red_finish(ro, grid, grid, 2, s);
 }
 
+// The finished slices of a stacked-reduction round (prover.hip: prove_stacked_reduction). A slice whose own variables are
+// all bound contributes  q(X) * eq1b(X, b) * D_i  to the round polynomial, with q's two entries (t0, t1) read from the
+// folded stacked matrix and D_i constant in X:  s(1) += b ? t1 D_i : 0,  s(2) += b ? 2 v : -v,  v = (2 t1 - t0) D_i;
+// after the round D_i picks up eq1b(u_round, b). A many-AIR proof has ~13 000 such slices from the first rounds on, and
+// the host looped over all of them every round with the device idle (gather + download + ~175 us of host products per
+// round, 20 rounds). Here d[i] lives on the device: this kernel first applies the PREVIOUS round's factor (u_prev) to
+// the slices that were already finished then, then sums the round's two values.
+__global__ __launch_bounds__(RED_THREADS) void stacked_tail_kernel(const EF *q, uint32_t q_log_h, const TailSlice *slices, EF *d,
+                                                                   uint32_t n, uint32_t l_skip, uint32_t round, EF u_prev_in,
+                                                                   RedOut ro) {
+    const EF::Pre u1 = u_prev_in.pre(), u0 = (EF::one() - u_prev_in).pre();
+    EF sums[2] = {EF::zero(), EF::zero()};
+    const uint32_t stride = gridDim.x * RED_THREADS;
+    for (uint32_t i = blockIdx.x * RED_THREADS + threadIdx.x; i < n; i += stride) {
+        const TailSlice sl = slices[i];
+        if (round <= sl.n_lift) continue;  // still has variables of its own (or is another rank's: n_lift = ~0)
+        EF di = ld_ef(d + i);
+        if (round - 1 > sl.n_lift) {
+            di = ((sl.row >> (l_skip + round - 2)) & 1) ? di * u1 : di * u0;
+            st_ef(d + i, di);
+        }
+        const uint64_t at = ((uint64_t)sl.gcol << q_log_h) + ((sl.row >> (l_skip + round)) << 1);
+        const EF t0 = ld_ef(q + at), t1 = ld_ef(q + at + 1);
+        const EF::Pre dp = di.pre();
+        const EF v = (t1 + t1 - t0) * dp;
+        if ((sl.row >> (l_skip + round - 1)) & 1) {
+            sums[0] = sums[0] + t1 * dp;
+            sums[1] = sums[1] + v + v;
+        } else {
+            sums[1] = sums[1] - v;
+        }
+    }
+    block_sum_out<2>(sums, ro, (size_t)blockIdx.x * 2);
+    finish_reduction<2>(ro, gridDim.x, 2);
+}
+int stacked_tail(const EF *q, uint32_t q_log_h, const TailSlice *d_slices, EF *d_tail, uint32_t n, uint32_t l_skip, uint32_t round,
+                 EF u_prev, const RedOut &ro, hipStream_t s) {
+    if (n == 0 || round == 0) return (int)hipErrorInvalidValue;
+    uint32_t grid = red_grid(n);
+    if (grid > tuning().finish_inline_max) grid = tuning().finish_inline_max;  // (always finished in the kernel)
+    OVM_LAUNCH(stacked_tail_kernel, dim3(grid), dim3(RED_THREADS), 0, s, q, q_log_h, d_slices, d_tail, n, l_skip, round, u_prev,
+               red_inline(ro, grid, 2));
+    OVM_CHECK_LAUNCH();
+    return 0;
+}
+
 // ---- WHIR ------------------------------------------------------------------------------------
 __global__ void whir_mu_batch_kernel(const Fp *msg, uint32_t width, uint32_t log_h, const EF *mu_pows,
                                      uint32_t mu_offset, EF *f, int accumulate) {
