@@ -614,6 +614,40 @@ static inline uint64_t layer_entry(uint64_t qs, unsigned lq, unsigned j, uint64_
     return off + bitrev64(y, lq - j);
 }
 
+// Host time of named pieces of the prove call, summed and printed with the OVM_TRACE marks (where does a stage's HOST share
+// go: a many-AIR proof spends a quarter of its wall time with the device idle).
+struct HostTime {
+    struct Slot {
+        const char *name;
+        double ms;
+        uint64_t calls;
+    };
+    static std::vector<Slot> &slots() {
+        static thread_local std::vector<Slot> s;
+        return s;
+    }
+    const char *name;
+    std::chrono::steady_clock::time_point t0;
+    bool on;
+    explicit HostTime(const char *n) : name(n), on(tuning().trace) {
+        if (on) t0 = std::chrono::steady_clock::now();
+    }
+    ~HostTime() {
+        if (!on) return;
+        const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        for (auto &s : slots())
+            if (s.name == name) {
+                s.ms += ms, s.calls++;
+                return;
+            }
+        slots().push_back({name, ms, 1});
+    }
+    static void report() {
+        for (auto &s : slots()) fprintf(stderr, "[ovm] host %-32s %9.3f ms over %llu calls\n", s.name, s.ms, (unsigned long long)s.calls);
+        slots().clear();
+    }
+};
+
 struct WallTrace {
     bool on;
     std::chrono::steady_clock::time_point t0;
@@ -818,6 +852,7 @@ struct Prover {
                       uint32_t n_out = 1) {
         ProgDev d;
         d.weights = cx.upload(weights);
+        HostTime ht_all("make_prog");
         const StagedPlan plan = staged ? round0_staged_plan(log_lifted, n_out, p.num_slots, (uint32_t)p.code.size()) : StagedPlan();
         if (plan.rows == 0) {
             d.code = cx.upload(p.code);
@@ -827,8 +862,12 @@ struct Prover {
         StagedLayout layout;
         layout.stage_rows = plan.stage_rows;
         layout.acc_rows = plan.acc_rows;
-        StagedProgram sp = stage_program(p, weights, layout);
-        sp.scale_rows(plan.rows);
+        StagedProgram sp;
+        {
+            HostTime ht("make_prog.stage_program");
+            sp = stage_program(p, weights, layout);
+            sp.scale_rows(plan.rows);
+        }
         static_assert(sizeof(StagedBlock) == 32 && sizeof(StagedAcc) == 32 && sizeof(StagedInstr) == 16, "staged layout");
         const size_t w_blocks = sp.blocks.size() * 8, w_accs = sp.accs.size() * 8, w_code = sp.code.size() * 4;
         std::vector<uint32_t> words(w_blocks + w_accs + w_code + sp.loads.size());
@@ -1687,15 +1726,14 @@ struct Prover {
                 }
                 tp[t].eq3b.push_back(e);
             }
+            HostTime ht_trace("round0.per_trace_setup");
             {
-                std::vector<Root> roots = roots_zerocheck(a);
                 tp[t].zc_w = lambda_pows;
                 tp[t].zc = std::make_unique<ProgDev>(make_prog(std::move(progs[t].zc), lambda_pows, true, v.log_lifted, 1));
                 if (v.n_lift > 0)
                     tp[t].zc_g = make_grouped(std::move(progs[t].zc_g));
             }
             if (!a.interactions.empty()) {
-                std::vector<Root> roots = roots_logup(a);
                 std::vector<EF> wts;  // in the order roots_logup numbers them
                 for (size_t k = 0; k < a.interactions.size(); k++) {
                     const Interaction &it = a.interactions[k];
@@ -1858,6 +1896,7 @@ struct Prover {
         // (sharded: the coefficient vectors of a trace come from its owner)
         share_vectors(sp0, [&](size_t i) { return owner[i < 2 * T ? i / 2 : i - 2 * T]; });
         wt.mark("rap.round0");
+        if (wt.on) HostTime::report();
         // ---- s_0 assembly (host) ----
         const unsigned s_deg = cdeg_global + 1;
         S0 s0r = assemble_s0(sp0, xi);
