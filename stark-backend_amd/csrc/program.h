@@ -389,6 +389,11 @@ struct StagedLayout {
     uint32_t slot_row0() const { return 2 * stage_rows + acc_rows; }
 };
 static constexpr uint32_t S_B_CONST = 0x100;
+// Forwarding (the compiler's FWD_* hints carried into the staged form): operand a / b is the result of the staged
+// instruction right before this one and comes from a register, not from its LDS row; S_NOSTORE: the result is read by the
+// next instruction only, through that register -- no LDS store. A staged instruction moves up to 3 R words of LDS per
+// lane, and the LDS port, not the ALU, is what bounds the interpreter on long programs.
+static constexpr uint32_t S_FWD_A = 0x200, S_FWD_B = 0x400, S_NOSTORE = 0x800;
 
 
 struct StagedInstr {
@@ -431,7 +436,7 @@ struct StagedProgram {
 };
 
 inline StagedProgram stage_program(const Program &p, const std::vector<FpExt> &weights,
-                                   const StagedLayout &layout = StagedLayout()) {
+                                   const StagedLayout &layout = StagedLayout(), bool forward = true) {
     const uint32_t STAGE_ROWS = layout.stage_rows, ACC_ROWS = layout.acc_rows, SLOT_ROW0 = layout.slot_row0();
     StagedProgram sp;
     sp.num_rows = SLOT_ROW0 + p.num_slots;
@@ -543,20 +548,36 @@ inline StagedProgram stage_program(const Program &p, const std::vector<FpExt> &w
                 emit(S_MOV | S_B_CONST, acc_row, a.v, 0);
                 list.push_back(acc_entry(acc_row, in.b));
             }
-        } else if (in.op == OP_NEG) {
-            if (a.is_const) emit(S_MOVC | S_B_CONST, dst, 0, (-Fp::raw(a.v)).v);
-            else emit(S_NEG | S_B_CONST, dst, a.v, 0);
         } else {
-            const Opnd b = opnd(in.bk, in.b);
-            if (a.is_const && b.is_const) {
-                const Fp x = Fp::raw(a.v), y = Fp::raw(b.v);
-                const Fp r = in.op == OP_ADD ? x + y : in.op == OP_SUB ? x - y : x * y;
-                emit(S_MOVC | S_B_CONST, dst, 0, r.v);
-            } else if (a.is_const) {  // constant on the left: commute, or b - a reversed
-                emit((in.op == OP_ADD ? S_ADD : in.op == OP_MUL ? S_MUL : S_RSUB) | S_B_CONST, dst, b.v, a.v);
+            // Forwarding flags of this (arithmetic) instruction. The producer the compiler means is the program's previous
+            // instruction, which is arithmetic and therefore exactly the staged instruction emitted last. The store is
+            // dropped only when the one reader is the NEXT arithmetic instruction, by register: an accumulation reads its
+            // operand from an LDS row in the block's accumulation loop, so its producer always stores.
+            uint32_t f_a = 0, f_b = 0, f_ns = 0;
+            if (forward) {
+                f_a = (in.fwd & FWD_A) ? 1 : 0;
+                f_b = (in.fwd & FWD_B) ? 1 : 0;
+                const bool next_takes_it = idx + 1 < p.code.size() && p.code[idx + 1].op <= OP_NEG &&
+                                           (p.code[idx + 1].fwd & (FWD_A | FWD_B));
+                f_ns = ((in.fwd & FWD_NOSTORE) && next_takes_it) ? S_NOSTORE : 0;
+            }
+            if (in.op == OP_NEG) {
+                if (a.is_const) emit(S_MOVC | S_B_CONST | f_ns, dst, 0, (-Fp::raw(a.v)).v);
+                else emit(S_NEG | S_B_CONST | (f_a ? S_FWD_A : 0) | f_ns, dst, a.v, 0);
             } else {
-                emit((in.op == OP_ADD ? S_ADD : in.op == OP_MUL ? S_MUL : S_SUB) | (b.is_const ? S_B_CONST : 0), dst, a.v,
-                     b.v);
+                const Opnd b = opnd(in.bk, in.b);
+                if (a.is_const && b.is_const) {
+                    const Fp x = Fp::raw(a.v), y = Fp::raw(b.v);
+                    const Fp r = in.op == OP_ADD ? x + y : in.op == OP_SUB ? x - y : x * y;
+                    emit(S_MOVC | S_B_CONST | f_ns, dst, 0, r.v);
+                } else if (a.is_const) {  // constant on the left: commute, or b - a reversed (the program's b is the staged a)
+                    emit((in.op == OP_ADD ? S_ADD : in.op == OP_MUL ? S_MUL : S_RSUB) | S_B_CONST | (f_b ? S_FWD_A : 0) | f_ns, dst,
+                         b.v, a.v);
+                } else {
+                    emit((in.op == OP_ADD ? S_ADD : in.op == OP_MUL ? S_MUL : S_SUB) | (b.is_const ? S_B_CONST : 0) |
+                             (f_a ? S_FWD_A : 0) | ((f_b && !b.is_const) ? S_FWD_B : 0) | f_ns,
+                         dst, a.v, b.v);
+                }
             }
         }
     }
@@ -576,13 +597,15 @@ inline void staged_host_eval(const StagedProgram &sp, const std::vector<Fp> &row
     std::vector<Fp> lds(sp.num_rows, Fp::zero());
     FpExt den = FpExt::zero();
     const uint32_t stage_rows = sp.stage_rows;
+    Fp prev = Fp::zero();  // the result of the staged instruction before (S_FWD_*), kept across blocks as the kernel does
+    const Fp poison = Fp::from_canonical(0x5eed);  // what an LDS row holds after an S_NOSTORE "store": never the value
     for (size_t b = 0; b < sp.blocks.size(); b++) {
         const StagedBlock &blk = sp.blocks[b];
         for (uint32_t j = 0; j < blk.n_loads; j++) lds.at((b & 1) * stage_rows + j) = row.at(sp.loads[blk.load_off + j]);
         for (uint32_t i = 0; i < blk.n_instr; i++) {
             const StagedInstr &in = sp.code[blk.instr_off + i];
-            const Fp a = lds.at(in.a);
-            const Fp bv = (in.op & S_B_CONST) ? Fp::raw(in.b) : lds.at(in.b);
+            const Fp a = (in.op & S_FWD_A) ? prev : lds.at(in.a);
+            const Fp bv = (in.op & S_B_CONST) ? Fp::raw(in.b) : (in.op & S_FWD_B) ? prev : lds.at(in.b);
             Fp r;
             if (in.op & S_MUL) r = a * bv;
             else if (in.op & S_ADD) r = a + bv;
@@ -591,7 +614,8 @@ inline void staged_host_eval(const StagedProgram &sp, const std::vector<Fp> &row
             else if (in.op & S_NEG) r = -a;
             else if (in.op & S_MOV) r = a;
             else r = bv;
-            lds.at(in.dst) = r;
+            lds.at(in.dst) = (in.op & S_NOSTORE) ? poison : r;
+            prev = r;
         }
         auto weight = [&](const StagedAcc &e) {
             FpExt w;

@@ -865,7 +865,7 @@ struct Prover {
         StagedProgram sp;
         {
             HostTime ht("make_prog.stage_program");
-            sp = stage_program(p, weights, layout);
+            sp = stage_program(p, weights, layout, tuning().staged_forward);
             sp.scale_rows(plan.rows);
         }
         static_assert(sizeof(StagedBlock) == 32 && sizeof(StagedAcc) == 32 && sizeof(StagedInstr) == 16, "staged layout");
@@ -915,7 +915,7 @@ struct Prover {
             Program pg;
             pg.code.assign(gp.code.begin() + gp.off[src_groups * k / n_groups], gp.code.begin() + gp.off[src_groups * (k + 1) / n_groups]);
             pg.num_slots = gp.max_slots;
-            StagedProgram sp = stage_program(pg, weights, layout);
+            StagedProgram sp = stage_program(pg, weights, layout, tuning().staged_forward);
             sp.scale_rows(plan.rows);
             while (words.size() % 8) words.push_back(0);  // 32-byte alignment of the block / entry arrays
             const size_t w_blocks = sp.blocks.size() * 8, w_accs = sp.accs.size() * 8, w_code = sp.code.size() * 4;
@@ -3395,6 +3395,7 @@ Tuning ovm::Tuning::from_env() {
     t.finish_atomic_max = (uint32_t)std::max(0, num("OVM_FINISH_ATOMIC_MAX", 0));
     t.download_kernel = !off("OVM_DOWNLOAD_KERNEL");
     t.early_lde = !off("OVM_EARLY_LDE");
+    t.staged_forward = !off("OVM_STAGED_FWD");
     t.stacked_tail_device = !off("OVM_STACKED_TAIL_DEVICE");
     t.mle_batch_lds_min_log = (uint32_t)std::max(0, num("OVM_MLE_BATCH_LDS_MIN_LOG", 9));
     t.lazy_w_accumulate = !off("OVM_LAZY_W");

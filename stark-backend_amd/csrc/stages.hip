@@ -638,34 +638,47 @@ struct StagedVM {
         }
 #endif
     }
-    static __device__ __forceinline__ void exec(const uint4 in, uint32_t *mine) {
+    // prev: the result of the instruction before, per row of the lane (S_FWD_A / S_FWD_B read it instead of an LDS row,
+    // S_NOSTORE leaves the result there only)
+    static __device__ __forceinline__ void exec(const uint4 in, uint32_t *mine, Fp (&prev)[R]) {
         const uint32_t op = in.x;  // op | flags, dst, a, b: operand fields are word offsets of LDS rows
-        const uint32_t *arow = mine + in.z;
-        uint32_t *drow = mine + in.y;
         Fp a[R], b[R];
+        if (op & S_FWD_A) {
 #pragma unroll
-        for (int r = 0; r < R; r++) a[r] = Fp::raw(arow[r * RED_THREADS]);
+            for (int r = 0; r < R; r++) a[r] = prev[r];
+        } else {
+            const uint32_t *arow = mine + in.z;
+#pragma unroll
+            for (int r = 0; r < R; r++) a[r] = Fp::raw(arow[r * RED_THREADS]);
+        }
         if (op & S_B_CONST) {
 #pragma unroll
             for (int r = 0; r < R; r++) b[r] = Fp::raw(in.w);
+        } else if (op & S_FWD_B) {
+#pragma unroll
+            for (int r = 0; r < R; r++) b[r] = prev[r];
         } else {
             const uint32_t *brow = mine + in.w;
 #pragma unroll
             for (int r = 0; r < R; r++) b[r] = Fp::raw(brow[r * RED_THREADS]);
         }
-#define OVM_STORE(EXPR)                                                                  \
-    {                                                                                    \
-        _Pragma("unroll") for (int r = 0; r < R; r++) drow[r * RED_THREADS] = (EXPR).v; \
-        return;                                                                          \
+#define OVM_RESULT(EXPR)                                            \
+    {                                                               \
+        _Pragma("unroll") for (int r = 0; r < R; r++) prev[r] = (EXPR); \
     }
-        if (op & S_MUL) OVM_STORE(a[r] * b[r])
-        if (op & S_ADD) OVM_STORE(a[r] + b[r])
-        if (op & S_SUB) OVM_STORE(a[r] - b[r])
-        if (op & S_RSUB) OVM_STORE(b[r] - a[r])
-        if (op & S_NEG) OVM_STORE(-a[r])
-        if (op & S_MOV) OVM_STORE(a[r])
-        OVM_STORE(b[r])  // S_MOVC
-#undef OVM_STORE
+        if (op & S_MUL) OVM_RESULT(a[r] * b[r])
+        else if (op & S_ADD) OVM_RESULT(a[r] + b[r])
+        else if (op & S_SUB) OVM_RESULT(a[r] - b[r])
+        else if (op & S_RSUB) OVM_RESULT(b[r] - a[r])
+        else if (op & S_NEG) OVM_RESULT(-a[r])
+        else if (op & S_MOV) OVM_RESULT(a[r])
+        else OVM_RESULT(b[r])  // S_MOVC
+#undef OVM_RESULT
+        if (!(op & S_NOSTORE)) {
+            uint32_t *drow = mine + in.y;
+#pragma unroll
+            for (int r = 0; r < R; r++) drow[r * RED_THREADS] = prev[r].v;
+        }
     }
     // Runs every block. src(col, r) = address of the lane's r-th cell of column `col`;
     // after(second header word: acc_off, n_acc0, n_acc1 | numerator row, leaf) runs once the block's
@@ -698,6 +711,9 @@ struct StagedVM {
                 }
             }
         };
+        Fp prev[R];
+#pragma unroll
+        for (int r = 0; r < R; r++) prev[r] = Fp::zero();
         request(0);
         for (uint32_t blk = 0; blk < prog.n_blocks; blk++) {
             const uint4 hd = blocks[2 * blk];       // load_off, n_loads, instr_off, n_instr
@@ -711,12 +727,12 @@ struct StagedVM {
             uint32_t i = hd.w;
             for (; i >= 4; i -= 4, ip += 4) {
                 const uint4 g0 = ip[0], g1 = ip[1], g2 = ip[2], g3 = ip[3];
-                exec(g0, mine);
-                exec(g1, mine);
-                exec(g2, mine);
-                exec(g3, mine);
+                exec(g0, mine, prev);
+                exec(g1, mine, prev);
+                exec(g2, mine, prev);
+                exec(g3, mine, prev);
             }
-            for (; i != 0; --i, ++ip) exec(*ip, mine);
+            for (; i != 0; --i, ++ip) exec(*ip, mine, prev);
             after(hd2);
         }
 #endif

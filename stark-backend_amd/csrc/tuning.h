@@ -36,6 +36,7 @@ struct Tuning {
     // (all points of a pair in the lane); shorter ones keep one (pair, point) per lane. 31 = never.
     uint32_t mle_batch_lds_min_log = 9;  // (a 46-AIR reth segment: 7 / 8 / 9 / 10 -> 19.0 / 17.2 / 16.3 / 16.9 ms of multilinear rounds, 22.3 without)
     bool stacked_tail_device = true;  // OVM_STACKED_TAIL_DEVICE=0: the finished slices of a stacked-reduction round are summed by the host
+    bool staged_forward = true;    // OVM_STAGED_FWD=0: the staged VM reads every operand from LDS and stores every result
     bool lazy_w_accumulate = true;  // OVM_LAZY_W=0: whir_w_accumulate reduces every product (the parity tests compare the two)
     bool download_kernel = true;   // OVM_DOWNLOAD_KERNEL=0: small downloads through the runtime's copy + stream synchronisation
     bool trace = false;            // OVM_TRACE: wall-clock trace of the stages on stderr
