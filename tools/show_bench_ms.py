@@ -1,3 +1,7 @@
+"""Prints ms_per_step of bench.py JSON lines matched by the glob arguments (mean and median): A/B runs of one box.
+
+    python tools/show_bench_ms.py "gpurun_out/new_*.json" "gpurun_out/old_*.json"
+"""
 import json,sys,glob
 for pat in sys.argv[1:]:
     vals=[]
