@@ -27,9 +27,9 @@ __device__ __forceinline__ EF wave_sum(EF v) {
     return v;
 }
 
-// Sum K values per lane over the workgroup; lanes 0..K-1 store them at out[0..K). With SYS the
-// stores are followed by a system-scope fence (out is a host mailbox), otherwise by a device-scope
-// one (out is a partials record another workgroup will read).
+// Sum K values per lane over the workgroup; lanes 0..K-1 store them at out[0..K). With SYS the stores are released
+// to the host (out is a host mailbox), otherwise -- if `fence` -- to the device (out is a partials record another
+// workgroup will read): write-through stores and a wait for them, not a fence (device_common.h: release_to_*).
 template <int K, bool SYS = false>
 __device__ void block_sum_store(EF (&v)[K], EF *out, bool fence = true) {
     __shared__ EF sh[(RED_THREADS / 64) * K];
