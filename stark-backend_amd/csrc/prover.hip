@@ -2022,6 +2022,22 @@ struct Prover {
                 OVM_THROW_IF(mle_round_eval_batched(d_jobs.p, jobs.data(), (uint32_t)jobs.size(), cdeg_global, mle_counters.p,
                                                     mb.arm(nullptr, 0), cx.stream));
             }
+            // While the round's kernels run: the traces that have just run out of rows (their last row came back with the
+            // previous round's fold) are evaluated on the host -- the whole constraint program on one row of extension-field
+            // values, 50-500 us for the wide AIRs of a reth segment, which used to happen after the wait, device idle.
+            for (size_t t = 0; t < T; t++) {
+                if (!mine(t) || round != tv[t].n_lift + 1) continue;
+                TraceView &v = tv[t];
+                const bool has_int = !air(t).interactions.empty();
+                const Fp norm = fp(uint64_t(1) << (v.log_lifted - v.log_height)).inv();
+                EF o[2];
+                host_eval(tp[t].zc->prog, tp[t].zc_w, v.final_row, EF::zero(), o);
+                zc_tilde[t] = eq_ns.back() * o[0];
+                if (has_int) {
+                    host_eval(tp[t].lg->prog, tp[t].lg_w, v.final_row, tp[t].lg_const, o);
+                    lg_tilde[t] = {eq_sharp_ns.back() * o[0] * norm, eq_sharp_ns.back() * o[1]};
+                }
+            }
             if (any_launch) mb.wait(cx.stream);
             // phase B: host (the owner of a trace evaluates its round polynomials; sharded: then all-gathered)
             for (size_t t = 0; t < T; t++) {
@@ -2032,13 +2048,7 @@ struct Prover {
                 Fp norm = fp(uint64_t(1) << (v.log_lifted - v.log_height)).inv();
                 if (round > v.n_lift) {
                     if (round == v.n_lift + 1) {
-                        EF o[2];
-                        host_eval(tp[t].zc->prog, tp[t].zc_w, v.final_row, EF::zero(), o);
-                        zc_tilde[t] = eq_ns.back() * o[0];
-                        if (has_int) {
-                            host_eval(tp[t].lg->prog, tp[t].lg_w, v.final_row, tp[t].lg_const, o);
-                            lg_tilde[t] = {eq_sharp_ns.back() * o[0] * norm, eq_sharp_ns.back() * o[1]};
-                        }
+                        // (evaluated above, while the device was busy)
                     } else {
                         zc_tilde[t] *= r_prev;
                         lg_tilde[t][0] *= r_prev;
