@@ -442,3 +442,21 @@ def test_thread_shutdown_releases_and_the_thread_keeps_working(dev, pkg, orc):
     b, _ = dev.prove(pk, [(0, tr, 32, [])])
     assert a == b
     orc.verify(blob, b)
+
+
+def test_failure_while_the_early_lde_is_in_flight(dev, pkg, orc):
+    """Round 0's coset LDE is forked onto the library's side stream when the GKR tree is enqueued; the LogUp root check
+    comes right after. A proof that fails there (interactions that do not balance) must wait for the side stream before
+    its buffers go back to the pool: the next proofs on the same thread are byte-identical to the oracle's."""
+    params = airs.test_params(l_skip=3, n_stack=14, k_whir=2)
+    h = 1 << 16
+    send = airs.dummy_interaction_air(3, True, 0)
+    pk_bad = pkg.ProvingKey(airs.pk_blob(params, [send]))
+    tr = np.arange(4 * h, dtype=np.uint32) % 9973 + 1  # counts >= 1: a sender without a receiver
+    d = dev.upload(pkg.to_mont(tr))
+    for _ in range(3):
+        with pytest.raises(pkg.OvmError, match="non-zero root sum"):
+            dev.prove(pk_bad, [(0, d, h, [])])
+        cols = 12
+        good = airs.splitmix64_bits(0xFEED, cols * h)
+        run_case(dev, pkg, orc, params, [airs.uniform_runner_air(cols)], [(0, good, h, [])])
