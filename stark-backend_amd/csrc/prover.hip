@@ -1538,7 +1538,11 @@ struct Prover {
             }
             enqueue_early_lde = [&]() {
                 SideStream &ss = side_stream();
-                ss.init();
+                try {
+                    ss.init();
+                } catch (const OvmFail &) {
+                    return;  // (no second stream to be had: round 0 extends the traces where it uses them)
+                }
                 bool any = false;
                 for (size_t t = 0; t < T; t++) {
                     EarlyLde &e = early.per_trace[t];
