@@ -436,10 +436,14 @@ struct SideStream : ThreadResource {
         // (a CU-masked stream -- hipExtStreamCreateWithCUMask leaving four CUs per XCD to the caller's stream -- was
         // tried: the two streams then do not overlap at all, 79.1 ms against 74.6 ms)
         int least = 0, greatest = 0;
-        OVM_THROW_IF(hipDeviceGetStreamPriorityRange(&least, &greatest));
-        OVM_THROW_IF(hipStreamCreateWithPriority(&s, hipStreamNonBlocking, least));
-        OVM_THROW_IF(hipEventCreateWithFlags(&fork, hipEventDisableTiming));
-        OVM_THROW_IF(hipEventCreateWithFlags(&join, hipEventDisableTiming));
+        if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess ||
+            hipStreamCreateWithPriority(&s, hipStreamNonBlocking, least) != hipSuccess ||
+            hipEventCreateWithFlags(&fork, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&join, hipEventDisableTiming) != hipSuccess) {
+            (void)hipGetLastError();
+            release();  // (all or nothing: a half-made set would pass the `if (s)` above next time)
+            throw OvmFail((int)hipErrorUnknown, "side stream");
+        }
     }
 };
 inline SideStream &side_stream() {
