@@ -2531,7 +2531,11 @@ struct Prover {
         std::vector<char> tail_ready(tvs.size(), 0);
         // The finished slices on the device (stages.hip: stacked_tail_kernel; OVM_STACKED_TAIL_DEVICE=0: the host loop):
         // their D_i are uploaded once, when their window's last fold has produced (eq_fin, krot_fin).
-        const bool tail_on_device = tuning().stacked_tail_device && !tvs.empty();
+        // (from STACKED_TAIL_DEVICE_MIN slices on: below that the host loop is a few microseconds and a kernel per round
+        // is not -- a 2^12 x 20 proof was 0.4 ms slower with its 20 slices on the device; OVM_STACKED_TAIL_DEVICE=2: always)
+        static constexpr size_t STACKED_TAIL_DEVICE_MIN = 1024;
+        const bool tail_on_device = !tvs.empty() && (tuning().stacked_tail_device == 2 ||
+                                                     (tuning().stacked_tail_device == 1 && tvs.size() >= STACKED_TAIL_DEVICE_MIN));
         DevBuf<TailSlice> d_tail_slices;
         DevBuf<EF> d_tail, tail_partials;
         if (tail_on_device) {
@@ -3414,7 +3418,7 @@ Tuning ovm::Tuning::from_env() {
     t.download_kernel = !off("OVM_DOWNLOAD_KERNEL");
     t.early_lde = !off("OVM_EARLY_LDE");
     t.staged_forward = !off("OVM_STAGED_FWD");
-    t.stacked_tail_device = !off("OVM_STACKED_TAIL_DEVICE");
+    t.stacked_tail_device = std::max(0, std::min(2, num("OVM_STACKED_TAIL_DEVICE", 1)));
     t.mle_batch_lds_min_log = (uint32_t)std::max(0, num("OVM_MLE_BATCH_LDS_MIN_LOG", 9));
     t.lazy_w_accumulate = !off("OVM_LAZY_W");
     t.early_lde_lds_kib = (uint32_t)std::max(0, num("OVM_EARLY_LDE_LDS_KIB", 64));

@@ -35,7 +35,9 @@ struct Tuning {
     // OVM_MLE_BATCH_LDS_MIN_LOG: batched multilinear-round jobs of at least 2^this pairs run on the LDS-slot interpreter
     // (all points of a pair in the lane); shorter ones keep one (pair, point) per lane. 31 = never.
     uint32_t mle_batch_lds_min_log = 9;  // (a 46-AIR reth segment: 7 / 8 / 9 / 10 -> 19.0 / 17.2 / 16.3 / 16.9 ms of multilinear rounds, 22.3 without)
-    bool stacked_tail_device = true;  // OVM_STACKED_TAIL_DEVICE=0: the finished slices of a stacked-reduction round are summed by the host
+    // OVM_STACKED_TAIL_DEVICE: the finished slices of a stacked-reduction round are summed 0 = by the host, 1 = on the device
+    // when there are at least 1 024 of them (a many-AIR proof), 2 = always on the device (parity tests)
+    int stacked_tail_device = 1;
     bool staged_forward = true;    // OVM_STAGED_FWD=0: the staged VM reads every operand from LDS and stores every result
     bool lazy_w_accumulate = true;  // OVM_LAZY_W=0: whir_w_accumulate reduces every product (the parity tests compare the two)
     bool download_kernel = true;   // OVM_DOWNLOAD_KERNEL=0: small downloads through the runtime's copy + stream synchronisation
