@@ -155,8 +155,8 @@ def dry_run(args, pkg, dist, shard, rank, world, devname, bulk_ok):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)  # (20 x ~75 ms: the first few timed steps of a cold process read 2-3 % high)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--log-rows", type=int, default=22)
     ap.add_argument("--cols", type=int, default=100)
     ap.add_argument("--num-airs", type=int, default=1,
