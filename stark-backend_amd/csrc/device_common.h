@@ -20,6 +20,15 @@ struct EFPlanes {
     uint32_t *p;
     uint64_t stride;
 };
+// The eq weight of pair y in a GKR layer sumcheck, either read from one table (`lo`, already positioned at the launch's
+// first pair: lo_bits = EQ_WHOLE) or as the product of two small tables indexed by the halves of the GLOBAL pair index
+// y_first + y:  eq(point, y) = eq(point_lo, y mod 2^lo_bits) * eq(point_hi, y >> lo_bits)  (lo_bits = 0: hi alone).
+struct EqSplit {
+    EFPlanes lo, hi;
+    uint32_t lo_bits;
+    uint64_t y_first;
+};
+static constexpr uint32_t EQ_WHOLE = 0xffffffffu;
 // Fractions: numerator limbs in 4 planes from p, denominator limbs in 4 planes from p + q_off (normally the
 // next four planes; a layer whose numerators are base-field values keeps ONE numerator plane and q_off = stride).
 struct FracPlanes {

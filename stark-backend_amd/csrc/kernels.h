@@ -200,10 +200,10 @@ int gkr_eval_leaves(const DevProgram &prog, const DevStaged &staged, const EF *d
                     hipStream_t s);
 int gkr_build_layer(FracPlanes child, FracPlanes parent, uint64_t n_parent, bool child_p_base, hipStream_t s);
 // out[X-1] = sum_y eq[y] * (p0 q1 + p1 q0 + lambda q0 q1)(X, y), X = 1..n_points (2 or 3; eq: n_pairs weights)
-int gkr_round(FracPlanes rec, bool p_base, EFPlanes eq, uint64_t n_pairs, EF lambda, uint32_t n_points,
+int gkr_round(FracPlanes rec, bool p_base, EqSplit eq, uint64_t n_pairs, EF lambda, uint32_t n_points,
               const RedOut &ro, hipStream_t s);
 // fold the previous round with r and return the NEXT round's sums over the n_pairs folded pairs
-int gkr_fold_round(FracPlanes in, bool in_p_base, EFPlanes eq, FracPlanes out, uint64_t n_pairs, EF r, EF lambda,
+int gkr_fold_round(FracPlanes in, bool in_p_base, EqSplit eq, FracPlanes out, uint64_t n_pairs, EF r, EF lambda,
                    uint32_t n_points, const RedOut &ro, hipStream_t s);
 
 // ---- stacked reduction ----

@@ -1036,6 +1036,11 @@ struct Prover {
         // base-field numerators it is 5 planes, not 8, and in the memory-bounded mode it is dropped once the layer
         // above exists and generated again for the last layer's sumcheck (make_leaves).
         DevBuf<uint32_t> tree_buf, leaf_buf, rec_a, rec_b, eq_buf;
+        // split eq tables of the big layers (begin_layer): grown on demand, a few hundred KiB
+        DevBuf<uint32_t> eq_lo_buf, eq_hi_buf;
+        uint64_t eq_lo_stride = 0, eq_hi_stride = 0;
+        EqHeapPlan hp_lo, hp_hi;
+        unsigned split_m = 0;  // 0: this layer reads its weights from the whole heap
         DevBuf<EF> partials;
         EqHeapPlan hp;
         uint64_t eq_stride = 0;
@@ -1077,7 +1082,11 @@ struct Prover {
             rec_a.alloc(8 * wcap);
             rec_b.alloc(8 * wcap);
             uint64_t eq_total = 64;
-            for (unsigned round = 1; round <= last_round && round < TR; round++) eq_total = std::max(eq_total, heap_plan_for(round).total);
+            // (the layers that take split tables -- begin_layer -- never touch this buffer: at config D it shrinks from
+            // 1.1 GB to a megabyte)
+            const bool split = tuning().gkr_split_eq;
+            for (unsigned round = 1; round <= last_round && round < TR; round++)
+                if (!split || round < tuning().gkr_split_min_round) eq_total = std::max(eq_total, heap_plan_for(round).total);
             eq_stride = up64(eq_total) + PLANE_SKEW;
             eq_buf.alloc(4 * eq_stride);
         }
@@ -1169,7 +1178,34 @@ struct Prover {
             hp = heap_plan_for(round);
             rbase.assign(round + 1, 0);
             for (unsigned sr = 1; sr <= round; sr++) rbase[sr] = (2 * Rchain[sr + 1].lo) & ~uint64_t(31);
+            split_m = 0;
             if (hp.empty) return;
+            if (tuning().gkr_split_eq && round >= tuning().gkr_split_min_round) {
+                // Two small heaps instead of the layer's whole one (device_common.h: EqSplit): variables [0, M) of the
+                // point and variables [M, round). Depth d of a heap = the table over the LAST d entries of its point, so
+                // the hi heap is built on point[M-1 ..) (its first entry belongs to no table) and its depth round - M is
+                // the full hi table; sub-round sr takes depth M - sr - 1 of the lo heap.
+                split_m = round / 2;
+                auto full = [](uint32_t n) {
+                    std::vector<std::pair<uint64_t, uint64_t>> need(n);
+                    for (uint32_t d = 0; d < n; d++) need[d] = {0, uint64_t(1) << d};
+                    return need;
+                };
+                hp_lo = eq_heap_plan(split_m, full(split_m));
+                hp_hi = eq_heap_plan(round - split_m + 1, full(round - split_m + 1));
+                auto fit = [&](DevBuf<uint32_t> &buf, uint64_t &stride, const EqHeapPlan &pl) {
+                    const uint64_t need = up64(pl.total) + PLANE_SKEW;
+                    if (stride < need) {
+                        stride = need;
+                        buf.alloc(4 * stride);
+                    }
+                };
+                fit(eq_lo_buf, eq_lo_stride, hp_lo);
+                fit(eq_hi_buf, eq_hi_stride, hp_hi);
+                OVM_THROW_IF(eq_heap_run(point.data(), hp_lo, EFPlanes{eq_lo_buf.p, eq_lo_stride}, pr.cx.stream));
+                OVM_THROW_IF(eq_heap_run(point.data() + split_m - 1, hp_hi, EFPlanes{eq_hi_buf.p, eq_hi_stride}, pr.cx.stream));
+                return;
+            }
             OVM_THROW_IF(eq_heap_run(point.data(), hp, EFPlanes{eq_buf.p, eq_stride}, pr.cx.stream));
         }
         // planes positioned at record y of table(sr) (sr == 0: the tree layer)
@@ -1205,7 +1241,21 @@ struct Prover {
             if (have_pairs) {
                 const uint64_t y0 = pairs.lo, n_pairs = pairs.size();
                 const unsigned d = round - 1 - sr;
-                const EFPlanes eq{eq_buf.p + hp.at(d, y0), eq_stride};
+                EqSplit eq{EFPlanes{nullptr, 0}, EFPlanes{nullptr, 0}, EQ_WHOLE, y0};
+                if (!split_m) eq.lo = EFPlanes{eq_buf.p + hp.at(d, y0), eq_stride};
+                if (split_m) {
+                    const unsigned n_hi = round - split_m;
+                    if (sr + 1 < split_m) {
+                        const unsigned d_lo = split_m - sr - 1;
+                        eq.lo = EFPlanes{eq_lo_buf.p + hp_lo.at(d_lo, 0), eq_lo_stride};
+                        eq.hi = EFPlanes{eq_hi_buf.p + hp_hi.at(n_hi, 0), eq_hi_stride};
+                        eq.lo_bits = d_lo;
+                    } else {
+                        eq.lo = EFPlanes{nullptr, 0};
+                        eq.hi = EFPlanes{eq_hi_buf.p + hp_hi.at(d, 0), eq_hi_stride};
+                        eq.lo_bits = 0;
+                    }
+                }
                 if (sr == 0) {
                     OVM_THROW_IF(gkr_round(table_at(round, 0, 2 * y0), leaf_layer, eq, n_pairs, lambda, n_points, pr.mb.arm(partials.p), st));
                 } else {
@@ -3417,6 +3467,8 @@ Tuning ovm::Tuning::from_env() {
     t.finish_atomic_max = (uint32_t)std::max(0, num("OVM_FINISH_ATOMIC_MAX", 0));
     t.download_kernel = !off("OVM_DOWNLOAD_KERNEL");
     t.early_lde = !off("OVM_EARLY_LDE");
+    t.gkr_split_eq = !off("OVM_GKR_SPLIT_EQ");
+    t.gkr_split_min_round = (uint32_t)std::max(3, num("OVM_GKR_SPLIT_MIN", 14));
     t.staged_forward = !off("OVM_STAGED_FWD");
     t.stacked_tail_device = std::max(0, std::min(2, num("OVM_STACKED_TAIL_DEVICE", 1)));
     t.mle_batch_lds_min_log = (uint32_t)std::max(0, num("OVM_MLE_BATCH_LDS_MIN_LOG", 9));

@@ -2023,8 +2023,17 @@ int gkr_edge_records(FracPlanes src, uint64_t at0, uint64_t at1, uint32_t n0, ui
     return 0;
 }
 
+// The weight of pair y (see EqSplit): the full table of a big layer is a gigabyte to build and as much again to read
+// -- a quarter of the layer's traffic -- while two tables of the square root of its size stay in cache, at one extra
+// extension-field product per pair.
+__device__ __forceinline__ EF eq_weight(const EqSplit &eq, uint64_t y) {
+    if (eq.lo_bits == EQ_WHOLE) return ldp(eq.lo.p, eq.lo.stride, y);
+    const uint64_t gy = eq.y_first + y;
+    if (eq.lo_bits == 0) return ldp(eq.hi.p, eq.hi.stride, gy);
+    return ldp(eq.lo.p, eq.lo.stride, gy & ((1ull << eq.lo_bits) - 1)) * ldp(eq.hi.p, eq.hi.stride, gy >> eq.lo_bits);
+}
 template <bool PBASE, int NP>
-__global__ __launch_bounds__(RED_THREADS) void gkr_round_kernel(FracPlanes rec, EFPlanes eq, uint64_t n_pairs,
+__global__ __launch_bounds__(RED_THREADS) void gkr_round_kernel(FracPlanes rec, EqSplit eq, uint64_t n_pairs,
                                                                 EF lambda_in, RedOut ro) {
     const uint64_t stride = (uint64_t)gridDim.x * RED_THREADS;
     const EF::Pre lambda = lambda_in.pre();
@@ -2038,7 +2047,7 @@ __global__ __launch_bounds__(RED_THREADS) void gkr_round_kernel(FracPlanes rec, 
         else
             ldp4(rec.P(), rec.stride, 4 * y, p);
         ldp4(rec.Q(), rec.stride, 4 * y, q);
-        const EF e = ldp(eq.p, eq.stride, y);
+        const EF e = eq_weight(eq, y);
         EF a[4] = {p[0], q[0], p[1], q[1]};
         const EF b[4] = {p[2], q[2], p[3], q[3]};
         gkr_pair_sums<NP>(a, b, e, lambda, sums);
@@ -2046,7 +2055,7 @@ __global__ __launch_bounds__(RED_THREADS) void gkr_round_kernel(FracPlanes rec, 
     block_sum_out<NP>(sums, ro, (size_t)blockIdx.x * NP);
     finish_reduction<NP>(ro, gridDim.x, NP);
 }
-int gkr_round(FracPlanes rec, bool p_base, EFPlanes eq, uint64_t n_pairs, EF lambda, uint32_t n_points,
+int gkr_round(FracPlanes rec, bool p_base, EqSplit eq, uint64_t n_pairs, EF lambda, uint32_t n_points,
               const RedOut &ro, hipStream_t s) {
     if (n_points != 2 && n_points != 3) return (int)hipErrorInvalidValue;
     uint32_t grid = red_grid(n_pairs);
@@ -2068,7 +2077,7 @@ int gkr_round(FracPlanes rec, bool p_base, EFPlanes eq, uint64_t n_pairs, EF lam
 // stored and immediately used for the degree-3 round sums with weight eq[y], so every sub-round
 // after the first is ONE pass over the data.
 template <bool PBASE, int NP>
-__global__ __launch_bounds__(RED_THREADS) void gkr_fold_round_kernel(FracPlanes in, EFPlanes eq, FracPlanes out,
+__global__ __launch_bounds__(RED_THREADS) void gkr_fold_round_kernel(FracPlanes in, EqSplit eq, FracPlanes out,
                                                                      uint64_t n_pairs, EF r_in, EF lambda_in,
                                                                      RedOut ro) {
     const uint64_t stride = (uint64_t)gridDim.x * RED_THREADS;
@@ -2090,7 +2099,7 @@ __global__ __launch_bounds__(RED_THREADS) void gkr_fold_round_kernel(FracPlanes 
         }
         ldp4(in.Q(), in.stride, 8 * y, uq);
         ldp4(in.Q(), in.stride, 8 * y + 4, vq);
-        const EF e = ldp(eq.p, eq.stride, y);
+        const EF e = eq_weight(eq, y);
         fp[0] = up[0] + (up[2] - up[0]) * r;
         fp[1] = up[1] + (up[3] - up[1]) * r;
         fp[2] = vp[0] + (vp[2] - vp[0]) * r;
@@ -2108,7 +2117,7 @@ __global__ __launch_bounds__(RED_THREADS) void gkr_fold_round_kernel(FracPlanes 
     block_sum_out<NP>(sums, ro, (size_t)blockIdx.x * NP);
     finish_reduction<NP>(ro, gridDim.x, NP);
 }
-int gkr_fold_round(FracPlanes in, bool in_p_base, EFPlanes eq, FracPlanes out, uint64_t n_pairs, EF r, EF lambda,
+int gkr_fold_round(FracPlanes in, bool in_p_base, EqSplit eq, FracPlanes out, uint64_t n_pairs, EF r, EF lambda,
                    uint32_t n_points, const RedOut &ro, hipStream_t s) {
     if (n_points != 2 && n_points != 3) return (int)hipErrorInvalidValue;
     uint32_t grid = red_grid(n_pairs);

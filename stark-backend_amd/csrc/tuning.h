@@ -39,6 +39,8 @@ struct Tuning {
     // when there are at least 1 024 of them (a many-AIR proof), 2 = always on the device (parity tests)
     int stacked_tail_device = 1;
     bool staged_forward = true;    // OVM_STAGED_FWD=0: the staged VM reads every operand from LDS and stores every result
+    bool gkr_split_eq = true;      // OVM_GKR_SPLIT_EQ=0: every GKR layer builds and reads its whole eq table
+    uint32_t gkr_split_min_round = 14;  // OVM_GKR_SPLIT_MIN: layers of at least 2^this records use split tables (>= 3; parity tests lower it)
     bool lazy_w_accumulate = true;  // OVM_LAZY_W=0: whir_w_accumulate reduces every product (the parity tests compare the two)
     bool download_kernel = true;   // OVM_DOWNLOAD_KERNEL=0: small downloads through the runtime's copy + stream synchronisation
     bool trace = false;            // OVM_TRACE: wall-clock trace of the stages on stderr

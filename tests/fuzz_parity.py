@@ -35,7 +35,8 @@ def main():
              "OVM_R0_GROUPS_MIN": ["", "2", "4"], "OVM_MLE_GROUPS_MAX": ["", "16", "32"],
              "OVM_GKR_THREE_POINTS": ["", "", "1"], "OVM_MERKLE_COOP": ["", "0"], "OVM_LAZY_W": ["", "0"],
              "OVM_EARLY_LDE": ["", "", "0"], "OVM_MLE_BATCH_LDS_MIN_LOG": ["", "1", "3", "31"],
-             "OVM_STACKED_TAIL_DEVICE": ["", "0", "2", "2"], "OVM_STAGED_FWD": ["", "", "0"]}
+             "OVM_STACKED_TAIL_DEVICE": ["", "0", "2", "2"], "OVM_STAGED_FWD": ["", "", "0"], "OVM_GKR_SPLIT_MIN": ["", "3", "4", "7"],
+             "OVM_GKR_SPLIT_EQ": ["", "", "0"]}
     bad = 0
     for case in range(args.cases):
         env = {k: str(rng.choice(v)) for k, v in knobs.items()}
