@@ -541,6 +541,24 @@ def random_air(rng, width, n_constraints, n_pairs, max_degree=3, use_next=True, 
     return a.finish()
 
 
+def drop_random_airs(rng, air_list, traces, p_optional=0.5, p_absent=0.5):
+    """Marks a random subset of the AIRs optional (`MultiStarkKeygenBuilder::add_air`, keygen/mod.rs:58-60; what
+    `StarkEngine::keygen` does for every AIR) and removes the traces of a random subset of those -- the contexts of the
+    reference's `optional_air` test (crates/backend-tests/src/lib.rs:642-750). At least one trace stays. Returns
+    (air_list, traces, number of absent AIRs); the AIRs are copied, the traces keep their AIR indices."""
+    out, absent = [], set()
+    for i, a in enumerate(air_list):
+        a = dict(a)
+        if rng.random() < p_optional:
+            a["is_required"] = False
+            if rng.random() < p_absent:
+                absent.add(i)
+        out.append(a)
+    if len(absent) == len(air_list):
+        absent.discard(int(rng.integers(0, len(air_list))))
+    return out, [t for t in traces if t[0] not in absent], len(absent)
+
+
 # ---- Keccak-f[1600] AIR (BASELINE config B; crates/cpu-backend/benches/keccakf.rs:49-86) ---------------------
 # The reference proves p3-keccak-air 0.4.3's `KeccakAir` (a Plonky3 crate that is NOT in /root/reference and cannot be
 # fetched here). Restated from the published design of that AIR -- one row per round, 24 rows per permutation:

@@ -41,6 +41,9 @@ def _fuzz(seed, world):
         h = 1 << int(rng.integers(0, min(10, l_skip + params["n_stack"]) + 1))
         traces.append((i, rng.integers(0, airs.P, size=width * h, dtype=np.uint64).astype(np.uint32), h,
                        [int(x) for x in rng.integers(0, airs.P, size=npv)], None))
+    # absent AIRs: optional AIRs lose their traces at random (tests/fuzz_parity.py); with fewer traces than ranks some ranks
+    # own nothing -- "a rank whose AIRs are all absent"
+    air_list, traces, _ = airs.drop_random_airs(rng, air_list, traces)
     order = sorted(range(len(traces)), key=lambda i: (-traces[i][2], traces[i][0]))
     ranks = np.sort(rng.integers(0, world, size=len(traces)))
     owners = [0] * len(traces)
@@ -80,9 +83,21 @@ def make(name, world):
         a = [air] * (world - 1) + [airs.fibonacci_air()]
         t = [(i, airs.splitmix64_bits(40 + i, 32), 32, [], airs.splitmix64_bits(50 + i, 8 * 32)) for i in range(world - 1)]
         t.append((world - 1, ftr, 4, fpv, None))
+    elif name == "absent_airs":  # a key of six optional AIRs, three of them without a trace (AIR indices 0, 2, 5)
+        p = airs.test_params(l_skip=2, n_stack=7, k_whir=2)
+        air = dict(airs.uniform_runner_air_partitioned(6), is_required=False)
+        lh = {1: 6, 3: 4, 4: 5}
+        a = [air] * 6
+        t = [(i, airs.splitmix64_bits(70 + i, 1 << lh[i]), 1 << lh[i], [], airs.splitmix64_bits(80 + i, 6 << lh[i])) for i in sorted(lh)]
+    elif name.startswith("optional_air:"):  # the reference's `optional_air` contexts 1 and 2 (tests/conformance.py), sharded
+        import conformance
+        c = conformance.optional_air(int(name.split(":")[1]))
+        p, a = c.params, c.airs
+        t = [tuple(x) + (None,) * (5 - len(x)) for x in c.traces]
     else:
         raise KeyError(name)
     return p, a, t, _owners_blocks(t, world)
 
 
-CASES = ["bench8", "bench_mixed_heights", "bench_app", "mixture", "no_interactions_on_one_rank"]
+CASES = ["bench8", "bench_mixed_heights", "bench_app", "mixture", "no_interactions_on_one_rank", "absent_airs", "optional_air:1",
+         "optional_air:2"]

@@ -59,9 +59,10 @@ def oracle_proof(orc, case, world):
 # (every context with 2 shards; with 4 shards the three that differ in structure: one AIR per rank, mixed
 # heights with two AIRs per rank, and the mixture of plain / cached / public-value AIRs)
 RUNS = [(c, 2) for c in shard_cases.CASES] + [(c, 4) for c in ("bench8", "bench_mixed_heights", "mixture")] + \
-       [("bench8", 3), ("three_airs", 4)] + \
+       [("bench8", 3), ("three_airs", 4), ("absent_airs", 4), ("optional_air:2", 3)] + \
        [("bench8", 8), ("bench_mixed_heights", 8), ("three_airs", 8)]
-# (3: a world that is not a power of two; three_airs with 4 or 8 ranks: ranks that own no trace; 8 = the north star's
+# (absent_airs / optional_air: keys with more AIRs than the context has traces -- with 4 (3) ranks over 3 (2) traces a rank
+# owns nothing; 3: a world that is not a power of two; three_airs with 4 or 8 ranks: ranks that own no trace; 8 = the north star's
 # world size -- one AIR per rank, 16 AIRs of mixed heights (two per rank), and 3 AIRs over 8 ranks)
 
 
