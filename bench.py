@@ -27,9 +27,9 @@ import numpy as np
 
 # (multi-process GPU work on this pool: the host driver only supports dmabuf IPC; harmless when already set)
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-# (the exchange's default time-out is 30 s -- right for a prover, short for a benchmark's FIRST step on 8 GPUs, where one
-# rank may still be creating its RCCL communicators or loading code objects while the others already wait for it)
-os.environ.setdefault("OVM_SHARD_TIMEOUT_S", "180")
+# (the shared-memory exchange waits up to OVM_SHARD_TIMEOUT_S = 300 s by default for a SILENT peer -- long enough for a
+# first step on 8 GPUs, where one rank may still be creating its RCCL communicators or loading code objects; a peer that
+# fails is announced through the abort word and noticed within milliseconds)
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)

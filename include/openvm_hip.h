@@ -407,7 +407,7 @@ typedef struct ovm_shard {
     int (*abort)(void *ctx, int code);
 } ovm_shard_t;
 /* Return codes of the built-in exchange that are not hipError_t values. */
-#define OVM_ESHARD_TIMEOUT 10006      /* a peer did not contribute within OVM_SHARD_TIMEOUT_S seconds (default 30) */
+#define OVM_ESHARD_TIMEOUT 10006      /* a peer did not contribute within OVM_SHARD_TIMEOUT_S seconds (default 300; a peer that FAILS is announced through the abort word within milliseconds) */
 #define OVM_ESHARD_PEER_ABORTED 10007 /* a peer called abort() */
 #define OVM_ESHARD_POISONED 10008     /* this communicator saw one of the two above earlier */
 /* Message of the calling thread's last exchange failure: which rank was waited for / which rank aborted. */

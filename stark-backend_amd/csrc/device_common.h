@@ -65,8 +65,23 @@ static constexpr unsigned RED_ATOMIC_MAX_K = 16;
 // workgroup on another XCD) and wait for their acknowledgement (`s_waitcnt vmcnt(0)`), which for a write-through store
 // arrives from the coherence point of that scope. The READER: the host's loads are ordered by x86; the last workgroup
 // reads the records with agent-scope loads (acquire_from_device). OVM_RELEASE_FENCES=1 builds the fenced form.
+//
+// INVARIANT of the fence-free form: EVERY word a flag or an arrival counter announces is written through st_*_sys /
+// st_*_agent (stages.hip: st_ef_sys, st_ef_agent). A plain store added ahead of release_to_host() / release_to_device()
+// is NOT ordered by `s_waitcnt vmcnt(0)` against the announcement (it may still sit in this XCD's L2 when the reader
+// looks) and nothing diagnoses it -- round 3 found exactly that by parity at 2^20 rows. The fenced build
+// (-DOVM_RELEASE_FENCES=1, tools/build_fenced.sh + tests/test_gpu_fenced_build.py) is the cross-check that stays in the suite.
+// The wait itself is architecture-specific: on the gfx9 family (gfx90a / gfx942 / gfx950) stores count in vmcnt; from
+// gfx10 on they count in vscnt and `s_waitcnt vmcnt(0)` orders nothing -- any other target builds the fenced form.
 #ifndef OVM_RELEASE_FENCES
+#if defined(__HIP_DEVICE_COMPILE__) && !(defined(__gfx950__) || defined(__gfx942__) || defined(__gfx90a__))
+#define OVM_RELEASE_FENCES 1
+#else
 #define OVM_RELEASE_FENCES 0
+#endif
+#endif
+#if defined(__HIP_DEVICE_COMPILE__) && !OVM_RELEASE_FENCES && !(defined(__gfx950__) || defined(__gfx942__) || defined(__gfx90a__))
+#error "fence-free mailbox stores rely on gfx9 vmcnt semantics: build this target with -DOVM_RELEASE_FENCES=1"
 #endif
 __device__ __forceinline__ void st_word_sys(uint32_t *p, uint32_t v) {
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);

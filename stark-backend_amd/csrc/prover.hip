@@ -3868,7 +3868,10 @@ int ovm_hip_prove_sharded(const ovm_pk_t *pk_, const ovm_shard_t *shard, uint32_
     });
     // This rank failed while the others work on: tell them (they return OVM_ESHARD_PEER_ABORTED instead of waiting for
     // the time-out) -- unless the failure IS a peer's abort or the exchange's own verdict, which every rank already has.
-    if (rc != 0 && working && shard->world > 1 && shard->abort && rc != OVM_ESHARD_PEER_ABORTED && rc != OVM_ESHARD_POISONED)
+    // A TIME-OUT is announced whether or not work had started: it poisons only the rank that timed out, so without the
+    // abort word the peers of a rank that gave up in the validation exchange would spin for their own full time-out.
+    if (rc != 0 && (working || rc == OVM_ESHARD_TIMEOUT) && shard->world > 1 && shard->abort && rc != OVM_ESHARD_PEER_ABORTED &&
+        rc != OVM_ESHARD_POISONED)
         (void)shard->abort(shard->ctx, rc);
     return rc;
 }

@@ -95,12 +95,14 @@ struct ovm_shm_comm {
     // memory, ...) and will not make its remaining contributions: every waiter returns at once instead of spinning
     // until the timeout, and the communicator is POISONED on every rank -- the sequence numbers of the ranks no longer
     // agree, so a later exchange could pair a fresh slot with a stale one and deliver bytes of the aborted proof.
+    // Code and rank are ONE 64-bit word written by a single compare-and-swap (low half: code, high half: rank + 1), so a
+    // peer that sees the code also sees who raised it.
     struct Header {
-        uint32_t abort_code;
-        uint32_t abort_rank_plus1;
+        uint64_t abort_word;
     };
     bool poisoned = false;
     Header *header() const { return reinterpret_cast<Header *>(base); }
+    uint64_t abort_word() const { return __atomic_load_n(&header()->abort_word, __ATOMIC_ACQUIRE); }
     int fail(int code, const std::string &what) {
         poisoned = true;
         g_shard_error = "rank " + std::to_string(rank) + ": " + what;
@@ -108,15 +110,14 @@ struct ovm_shm_comm {
         return code;
     }
     int peer_aborted() {
-        const Header h{__atomic_load_n(&header()->abort_code, __ATOMIC_ACQUIRE), __atomic_load_n(&header()->abort_rank_plus1, __ATOMIC_ACQUIRE)};
-        return fail(OVM_ESHARD_PEER_ABORTED, "rank " + std::to_string((int)h.abort_rank_plus1 - 1) + " aborted the joint call with code " +
-                                                 std::to_string(h.abort_code) + "; this communicator is unusable, create a new one");
+        const uint64_t w = abort_word();
+        return fail(OVM_ESHARD_PEER_ABORTED, "rank " + std::to_string((int)(w >> 32) - 1) + " aborted the joint call with code " +
+                                                 std::to_string((uint32_t)w) + "; this communicator is unusable, create a new one");
     }
     int abort(int code) {
-        uint32_t expected = 0;
-        const uint32_t c = code ? (uint32_t)code : 1u;
-        if (__atomic_compare_exchange_n(&header()->abort_code, &expected, c, false, __ATOMIC_ACQ_REL, __ATOMIC_ACQUIRE))
-            __atomic_store_n(&header()->abort_rank_plus1, rank + 1, __ATOMIC_RELEASE);
+        uint64_t expected = 0;
+        const uint64_t w = (uint64_t(rank + 1) << 32) | (code ? (uint32_t)code : 1u);
+        __atomic_compare_exchange_n(&header()->abort_word, &expected, w, false, __ATOMIC_ACQ_REL, __ATOMIC_ACQUIRE);  // (the first abort wins)
         poisoned = true;
         return 0;
     }
@@ -127,7 +128,10 @@ struct ovm_shm_comm {
     uint64_t seq = 0;
     std::string name;
     bool owns_mapping = false;
-    double timeout_s = 30.0;
+    // How long a rank waits for a peer that neither contributes nor aborts (a peer that FAILS raises the abort word and
+    // is noticed within milliseconds, so this only bounds silent deaths and start-up skew: the first exchange of a job
+    // waits for every rank's runtime, code objects and RCCL communicators -- tens of seconds on an 8-GPU node).
+    double timeout_s = 300.0;
 
     size_t slot_stride() const { return sizeof(Slot) + ((slot_bytes + 63) & ~uint64_t(63)); }
     Slot *slot(uint32_t r, unsigned parity) const { return reinterpret_cast<Slot *>(base + 64 + (size_t)(2 * r + parity) * slot_stride()); }
@@ -141,7 +145,7 @@ struct ovm_shm_comm {
             g_shard_error = "rank " + std::to_string(rank) + ": the communicator was poisoned by an earlier failure (time-out or aborted peer); create a new one";
             return OVM_ESHARD_POISONED;
         }
-        if (__atomic_load_n(&header()->abort_code, __ATOMIC_ACQUIRE)) return peer_aborted();
+        if (abort_word()) return peer_aborted();
         const uint64_t s = ++seq;
         const unsigned par = (unsigned)(s & 1);
         Slot *me = slot(rank, par);
@@ -156,7 +160,7 @@ struct ovm_shm_comm {
                 __builtin_ia32_pause();
 #endif
                 if ((++spins & 0x3FF) == 0) {
-                    if (__atomic_load_n(&header()->abort_code, __ATOMIC_ACQUIRE)) return peer_aborted();
+                    if (abort_word()) return peer_aborted();
                     if ((spins & 0x3FFF) == 0) {
                         sched_yield();
                         const double waited = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
