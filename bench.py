@@ -152,6 +152,60 @@ def dry_run(args, pkg, dist, shard, rank, world, devname, bulk_ok):
     dist.destroy_process_group()
 
 
+def engines_run(args, pkg, torch, pk, traces, cells, barrier, local_rank):
+    """The reference's throughput mode on one GPU (crates/cuda-backend/examples/keccakf.rs:55-131: N OS threads x N engines
+    x N streams, one shared proving key): K host threads, each with its own stream and `Device` (the library keeps its
+    mailboxes, pools and side stream per thread), prove the SAME resident trace `steps` times each; K = 1 is measured the
+    same way for the comparison. Returns the record for the JSON line."""
+    import threading
+    out = {"reference": "crates/cuda-backend/examples/keccakf.rs:55-131", "runs": []}
+    steps = max(2, min(args.steps, 8))
+    for k in sorted({1, args.engines}):
+        per_engine, errors, proofs = [0.0] * k, [], [None] * k
+        start = threading.Barrier(k + 1)
+
+        def worker(i):
+            try:
+                with torch.cuda.stream(torch.cuda.Stream(device=local_rank)):
+                    d = pkg.Device(local_rank)
+                    d.prove(pk, traces)            # this thread's pools, mailboxes and twiddles: outside the timing
+                    torch.cuda.current_stream().synchronize()
+                    start.wait()
+                    t0 = time.perf_counter()
+                    for _ in range(steps):
+                        proofs[i], _ = d.prove(pk, traces)
+                    torch.cuda.current_stream().synchronize()
+                    per_engine[i] = (time.perf_counter() - t0) / steps * 1e3
+                    pkg._lib().ovm_hip_thread_shutdown()
+            except Exception as e:  # noqa: BLE001
+                errors.append(repr(e))
+                try:
+                    start.abort()
+                except Exception:  # noqa: BLE001
+                    pass
+        ts = [threading.Thread(target=worker, args=(i,)) for i in range(k)]
+        for t in ts:
+            t.start()
+        try:
+            start.wait()
+        except threading.BrokenBarrierError:
+            pass
+        t0 = time.perf_counter()
+        for t in ts:
+            t.join()
+        wall = time.perf_counter() - t0
+        barrier()
+        rec = {"engines": k, "steps_per_engine": steps, "wall_ms": round(wall * 1e3, 2),
+               "cells_per_s": round(k * steps * cells / wall, 1), "per_engine_prove_ms": [round(x, 3) for x in per_engine],
+               "identical_proofs": len({hashlib.sha256(p or b"").hexdigest() for p in proofs}) == 1}
+        if errors:
+            rec["errors"] = errors
+        out["runs"].append(rec)
+    base = out["runs"][0]["cells_per_s"]
+    out["gain_over_one_engine"] = round(out["runs"][-1]["cells_per_s"] / base, 4) if base else None
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -179,9 +233,18 @@ def main():
                          "min(steps, 3); 0: none -- what tools/profile_round.sh uses so that the process makes exactly "
                          "warmup + steps proofs)")
     ap.add_argument("--no-pin", action="store_true",
-                    help="do not pin this rank's process to two physical host cores (default: cores 8 + 2 * local_rank and the "
-                         "next one when the machine has them: the prover's host thread spins on device flags between ~900 "
-                         "launches per proof, and staying on one core pair is worth ~1 ms of 76 at config D)")
+                    help="do not pin this rank's process to two physical host cores (default: two distinct physical cores on the "
+                         "NUMA node of the rank's GPU, stark-backend_amd/placement.py: the prover's host thread spins on device "
+                         "flags between ~900 launches per proof, and staying on one core pair is worth ~1 ms of 76 at config D)")
+    ap.add_argument("--partitioned", action="store_true",
+                    help="N = 1: make the PARTITIONED form the headline -- the AIR's 100 columns as a cached-main commitment "
+                         "(committed inside the timed region) + a 1-column common main, i.e. exactly what each rank of an N > 1 "
+                         "run proves. Without the flag the N = 1 line still reports it as `n1_partitioned_form`, so that the "
+                         "N = 1 point of a scaling curve can be read in the same units as N >= 2")
+    ap.add_argument("--engines", type=int, default=0,
+                    help="N = 1: after the timed region, K host threads x K streams prove the same resident trace concurrently "
+                         "(the reference's throughput mode, crates/cuda-backend/examples/keccakf.rs:55-131); reported as the "
+                         "extra key `throughput`, the headline is unchanged")
     ap.add_argument("--dry-run", action="store_true",
                     help="N > 1: rendezvous, the pre-flight of the bulk exchange, then the two collectives of the mu-batch sum and "
                          "one transfer per peer at the FULL vector size (2^log_stacked_height x 16 B = 268 MB at config D), timed; "
@@ -220,16 +283,15 @@ def main():
     # PHYSICAL cores -- measured on the 2 x 64-core box (profiles/r03/host_pinning.txt): unpinned 76.0-76.6 ms, cores 8,9
     # 74.9-75.4 ms, two SMT siblings of one core 78 ms. Done after the imports (the OpenMP runtime the CPU baseline uses
     # sizes itself from the mask it sees when it loads) and undone before the CPU baseline. Stated in the JSON line.
-    host_affinity, all_cpus = None, None
-    if not args.no_pin and hasattr(os, "sched_setaffinity"):
-        try:
-            all_cpus = sorted(os.sched_getaffinity(0))
-            c0 = 8 + 2 * int(os.environ.get("LOCAL_RANK", "0"))  # (--one-gpu: the ranks share GPU 0 but not their cores)
-            if len(all_cpus) >= 32 and c0 in all_cpus and c0 + 1 in all_cpus:
-                os.sched_setaffinity(0, {c0, c0 + 1})
-                host_affinity = [c0, c0 + 1]
-        except OSError:
-            host_affinity = None
+    # The pair: two distinct PHYSICAL cores on the NUMA node of this rank's GPU (placement.py reads sysfs; VERDICT r3: the
+    # fixed pair 8 + 2r put all eight ranks on socket 0 and assumed that CPUs c, c + 1 are different cores).
+    host_affinity, all_cpus, placement_rec = None, None, {"cpus": None, "reason": "--no-pin"}
+    if hasattr(os, "sched_getaffinity"):
+        all_cpus = sorted(os.sched_getaffinity(0))
+    if not args.no_pin:
+        from stark_backend_amd import placement
+        placement_rec = placement.pin_this_process(local_rank, slot_rank=int(os.environ.get("LOCAL_RANK", "0")) if args.one_gpu else None)
+        host_affinity = placement_rec["cpus"]
     dist = None
     devname = f"cuda:{local_rank}"
     torch.cuda.set_device(local_rank)
@@ -259,14 +321,28 @@ def main():
 
     cells = cols * h  # per AIR (N > 1: the 100 cached-main columns; the extra 1-column common main is not counted)
     shard = None
+    step_partitioned = None
     if world == 1:
         air = airs.uniform_runner_air(cols)
         pk = pkg.ProvingKey(airs.pk_blob(params, [air] * args.num_airs))
         traces = [(a, bits(cols * h), h, []) for a in range(args.num_airs)]
+        if args.num_airs == 1:
+            # the same AIR as ONE rank of an N > 1 run proves it: 100 columns as a cached-main commitment
+            # made inside the step + a 1-column common main; the cells counted are the 100 columns', as for N > 1
+            pk_p = pkg.ProvingKey(airs.pk_blob(params, [airs.uniform_runner_air_partitioned(cols)]))
+            cached_p = traces[0][1] if not args.partitioned else bits(cols * h)
+            common_p = bits(h)
+
+            def step_partitioned():
+                handle = dev.commit_matrix(pk_p, cached_p, cols, h)
+                out = dev.prove(pk_p, [(0, common_p, h, [], [handle])])
+                handle.free()
+                return out
         cells *= args.num_airs
 
-        def step():
+        def step_plain():
             return dev.prove(pk, traces)
+        step = step_partitioned if args.partitioned and step_partitioned else step_plain
     else:
         # one partitioned BenchmarkAir per rank: 100 columns as a cached-main commitment + a 1-column common main
         air = airs.uniform_runner_air_partitioned(cols)
@@ -323,6 +399,25 @@ def main():
         barrier()
         prof = pkg.profile_report()
     pkg.profile_enable(0)
+    other_form = None
+    if world == 1 and step_partitioned is not None:
+        # the N = 1 point in the units of N >= 2 (or, with --partitioned, the plain form beside it): a few more steps
+        other = step_plain if args.partitioned else step_partitioned
+        other()
+        barrier()
+        o0 = time.perf_counter()
+        n_other = max(1, min(args.steps, 5))
+        for _ in range(n_other):
+            other()
+        barrier()
+        o_ms = (time.perf_counter() - o0) / n_other * 1e3
+        other_form = {"form": "plain: one common-main commitment (the reference bench's form)" if args.partitioned else
+                              "partitioned: 100 cached-main columns committed inside the step + 1-column common main "
+                              "(what each rank of an N > 1 run proves)",
+                      "steps": n_other, "ms_per_step": round(o_ms, 3), "value": round(cells / (o_ms * 1e-3), 1), "unit": "cells/s"}
+    throughput = None
+    if world == 1 and args.engines > 0:
+        throughput = engines_run(args, pkg, torch, pk, traces, cells, barrier, local_rank)
     elapsed = pkg.max_over_ranks(elapsed, "cpu" if args.one_gpu else devname)
     stages_mine = {k: v[1] / max(prof_steps, 1) for k, v in prof.items()}
     dist_info, stages_ranks = None, None
@@ -333,7 +428,7 @@ def main():
         mine = {"rank": rank, "local_rank": local_rank, "device_index": torch.cuda.current_device(), "device_name": props.name,
                 "device_uuid": str(getattr(props, "uuid", "")), "pci_bus_id": getattr(props, "pci_bus_id", None),
                 "pid": os.getpid(), "bulk_carrier": shard.bulk, "alltoall_calls": shard.alltoall_calls,
-                "bulk_bytes": shard.bulk_bytes, "stage_ms": stages_mine}
+                "bulk_bytes": shard.bulk_bytes, "stage_ms": stages_mine, "host_placement": placement_rec}
         every = [None] * world
         dist.all_gather_object(every, mine)
         stages_ranks = [e["stage_ms"] for e in every]
@@ -342,7 +437,7 @@ def main():
                      "distinct_devices": len({(e["device_index"], e["device_uuid"]) for e in every}),
                      "bulk_preflight_ok": bool(bulk_ok), "bulk_carrier": sorted({e["bulk_carrier"] for e in every}),
                      "ranks": [{k: e[k] for k in ("rank", "local_rank", "device_index", "device_name", "device_uuid",
-                                                  "pci_bus_id", "pid", "alltoall_calls", "bulk_bytes")} for e in every]}
+                                                  "pci_bus_id", "pid", "alltoall_calls", "bulk_bytes", "host_placement")} for e in every]}
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
@@ -452,13 +547,19 @@ def main():
                                    + ("" if world == 1 else "; per AIR: 100 columns as a cached-main commitment (committed inside the "
                                       "timed region) + a 1-column common main (not counted in cells)"),
                        "proof_bytes": len(proof), "proof_sha256": hashlib.sha256(proof).hexdigest(), "parallelism": par,
-                       "host_affinity": host_affinity},
+                       "host_affinity": host_affinity, "host_placement": placement_rec,
+                       "form": ("partitioned (cached-main commitment inside the step + 1-column common main)"
+                                if (world > 1 or (args.partitioned and step_partitioned is not None)) else "plain (one common-main commitment)")},
             "roofline": roof, "cpu_baseline": cpu,
             "end_to_end": {"algorithmic_bytes_per_cell": 60, "achieved_GBps": round(e2e_gbs, 1),
                            "frac_of_hbm_peak": round(e2e_gbs / (HBM_PEAK_GBS * world), 4)},
             "stage_ms": {k: round(v, 3) for k, v in sorted(stages.items(), key=lambda kv: -kv[1])},
             "dominant_stage": dom,
         }
+        if other_form is not None:
+            line["n1_plain_form" if args.partitioned else "n1_partitioned_form"] = other_form
+        if throughput is not None:
+            line["throughput"] = throughput
         if shard is not None:
             line["config"]["bulk_exchange_bytes_per_proof"] = shard.bulk_bytes // max(args.steps + args.warmup + prof_steps, 1)
             line["dist"] = dist_info

@@ -36,6 +36,19 @@ pub struct OvmIpcComm {
     _private: [u8; 0],
 }
 
+/// `ovm_ipc_status_t`: which carrier the library's IPC exchange is on (mapped peer buffers, or -- after a failed or overdue
+/// `hipIpcOpenMemHandle` -- staged through host memory) and why.
+#[repr(C)]
+#[derive(Clone, Copy)]
+pub struct OvmIpcStatus {
+    pub degraded: u32,
+    pub mappings: u32,
+    pub opens: u64,
+    pub exchanges: u64,
+    pub staged_exchanges: u64,
+    pub reason: [c_char; 192],
+}
+
 /// `ovm_trace_t` (reference: AirProvingContext, prover/types.rs:59-73)
 #[repr(C)]
 #[derive(Clone, Copy, Debug)]
@@ -382,6 +395,7 @@ extern "C" {
         bytes: u64,
         stream: OvmStream,
     ) -> c_int;
+    pub fn ovm_hip_ipc_comm_status(comm: *const OvmIpcComm, out: *mut OvmIpcStatus) -> c_int;
     pub fn ovm_hip_shard_exchange_selftest(shard: *const OvmShard, n: u64, rounds: u32, seed: u64) -> c_int;
     pub fn ovm_hip_prove_sharded(
         pk: *const OvmPk,

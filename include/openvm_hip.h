@@ -445,6 +445,20 @@ int ovm_hip_ipc_allgather_host(void *comm, const void *mine, void *all, uint64_t
 int ovm_hip_ipc_allgather_device(void *comm, const void *d_mine, void *d_all, uint64_t bytes, ovm_stream_t stream);
 int ovm_hip_ipc_alltoall_device(void *comm, const void *d_send, void *d_recv, uint64_t bytes, ovm_stream_t stream);
 int ovm_hip_ipc_abort(void *comm, int code);
+/* Mapping a peer's buffer is the one step of this exchange that depends on the driver's IPC path. It is guarded: the ranks
+ * map IN TURN (never two processes inside hipIpcOpenMemHandle at once), every open has a deadline (OVM_IPC_OPEN_TIMEOUT_S,
+ * default 20 s), and a failed or overdue open -- agreed by all ranks -- DEGRADES the communicator: this and every later
+ * bulk exchange is staged through pinned host memory and the shared-memory all-gather (slow, never stuck); the proof in
+ * flight completes. ovm_hip_ipc_comm_status reports which carrier a communicator is on and why. */
+typedef struct {
+    uint32_t degraded;          /* 1: bulk exchanges are staged through host memory */
+    uint32_t mappings;          /* peer allocations currently mapped */
+    uint64_t opens;             /* hipIpcOpenMemHandle calls made so far */
+    uint64_t exchanges;         /* bulk exchanges that went through the mapped path's set-up */
+    uint64_t staged_exchanges;  /* bulk exchanges staged through host memory */
+    char reason[192];           /* why it degraded (empty otherwise) */
+} ovm_ipc_status_t;
+int ovm_hip_ipc_comm_status(const ovm_ipc_comm_t *comm, ovm_ipc_status_t *out);
 
 /* Host-only self-test of the sharded LogUp-GKR bookkeeping (csrc/gkr_shard.h): `world` simulated ranks
  * (threads over the shared-memory exchange) own the leaf runs [0, ends[0]), [ends[0], ends[1]), ... of a

@@ -63,6 +63,12 @@ class ProverConfigStruct(Structure):
                 ("gkr_drop_leaves", c_uint32), ("cache_limit_bytes", c_uint64)]
 
 
+class IpcStatusStruct(Structure):
+    """ovm_ipc_status_t"""
+    _fields_ = [("degraded", c_uint32), ("mappings", c_uint32), ("opens", c_uint64), ("exchanges", c_uint64),
+                ("staged_exchanges", c_uint64), ("reason", ctypes.c_char * 192)]
+
+
 class SpongeState(Structure):
     """``ovm_sponge_t`` (reference: crates/cuda-backend/src/sponge.rs:39-48)."""
 
@@ -125,6 +131,7 @@ SIGNATURES = {
     "ovm_hip_ipc_allgather_device": (c_int, [c_void_p, c_void_p, c_void_p, c_uint64, c_void_p]),
     "ovm_hip_ipc_alltoall_device": (c_int, [c_void_p, c_void_p, c_void_p, c_uint64, c_void_p]),
     "ovm_hip_ipc_abort": (c_int, [c_void_p, c_int]),
+    "ovm_hip_ipc_comm_status": (c_int, [c_void_p, c_void_p]),
     "ovm_hip_pool_stats": (c_int, [_u64p]),
     "ovm_hip_pool_selftest": (c_int, [c_uint64, c_uint32]),
     "ovm_hip_constraint_eval_buffer_size": (c_uint64, [c_void_p, c_uint32]),
@@ -496,6 +503,13 @@ class Shard:
         self._set_abi()
         self.bulk_bytes = 0
         self.alltoall_calls = 0
+
+    def ipc_status(self) -> dict:
+        """ovm_hip_ipc_comm_status: is the library's IPC exchange on mapped peer buffers or degraded to host staging, and why."""
+        st = IpcStatusStruct()
+        check(_lib().ovm_hip_ipc_comm_status(self.ipc, ctypes.byref(st)), "ovm_hip_ipc_comm_status")
+        return {"degraded": bool(st.degraded), "mappings": int(st.mappings), "opens": int(st.opens), "exchanges": int(st.exchanges),
+                "staged_exchanges": int(st.staged_exchanges), "reason": st.reason.decode(errors="replace")}
 
     def _set_abi(self):
         """(Re)build the ovm_shard_t for the current ``bulk`` mode. alltoall=False hands the library a null all-to-all:

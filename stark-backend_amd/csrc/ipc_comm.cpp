@@ -9,11 +9,16 @@
 // callbacks in ovm_shard_t instead (the Python host does, with this as its first fall-back).
 #include <hip/hip_runtime.h>
 
+#include <chrono>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <memory>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "openvm_hip.h"
@@ -21,9 +26,72 @@
 extern "C" int ovm_hip_shm_allgather(void *comm, const void *mine, void *all, uint64_t bytes);
 extern "C" int ovm_hip_shm_comm_abort(void *comm, int code);
 
+// ---- hipIpcOpenMemHandle that cannot hold a proof for ever --------------------------------------------------------
+// Round 3 saw `hipIpcOpenMemHandle` of a peer's 3.2 GB segment not return when two 85 GB processes shared one GPU
+// (DESIGN.md §9). Two defences, both on the MAPPING path only (a mapping is made once per peer segment and kept):
+//  (1) opens are PHASED: rank 0 maps what it needs while every other rank waits in a barrier, then rank 1, ... -- no two
+//      processes are ever inside the call at the same time. (With dmabuf IPC the importer asks the exporter PROCESS for
+//      the buffer; two processes importing from each other at once is the one pattern the small-size runs that work and
+//      the large-size run that hung differ in only by how long the call takes.)
+//  (2) every open runs on a helper thread the caller waits for with a deadline (OVM_IPC_OPEN_TIMEOUT_S, default 20 s).
+//      A call that misses it is abandoned (the thread is detached; if it ever returns, its mapping is closed), the
+//      failure is agreed by all ranks, and the communicator DEGRADES for good: this and every later bulk exchange is
+//      staged through pinned host memory and the shared-memory all-gather -- slow (a few GB/s), never stuck.
+// Test hooks: OVM_IPC_FORCE_OPEN_FAIL=1 (every open fails), OVM_IPC_FORCE_OPEN_HANG=1 (the helper never returns).
+namespace {
+struct OpenJob {
+    std::mutex m;
+    std::condition_variable cv;
+    bool done = false, abandoned = false;
+    hipError_t err = hipSuccess;
+    void *p = nullptr;
+};
+
+hipError_t open_with_deadline(void **out, const hipIpcMemHandle_t &handle, double timeout_s, int force /*0 none, 1 fail, 2 hang*/,
+                              bool &timed_out) {
+    timed_out = false;
+    if (force == 1) return hipErrorMapFailed;
+    int device = 0;
+    (void)hipGetDevice(&device);
+    auto job = std::make_shared<OpenJob>();
+    std::thread([job, handle, device, force]() {
+        void *p = nullptr;
+        hipError_t e = hipSetDevice(device);
+        if (force == 2) std::this_thread::sleep_for(std::chrono::hours(24 * 365));
+        if (e == hipSuccess) e = hipIpcOpenMemHandle(&p, handle, hipIpcMemLazyEnablePeerAccess);
+        if (e != hipSuccess) (void)hipGetLastError();
+        std::unique_lock<std::mutex> lk(job->m);
+        job->err = e;
+        job->p = p;
+        job->done = true;
+        const bool abandoned = job->abandoned;
+        lk.unlock();
+        job->cv.notify_all();
+        if (abandoned && e == hipSuccess && p) (void)hipIpcCloseMemHandle(p);  // nobody is waiting for it any more
+    }).detach();
+    std::unique_lock<std::mutex> lk(job->m);
+    if (!job->cv.wait_for(lk, std::chrono::duration<double>(timeout_s), [&] { return job->done; })) {
+        job->abandoned = true;
+        timed_out = true;
+        return hipErrorNotReady;
+    }
+    *out = job->p;
+    return job->err;
+}
+}  // namespace
+
 struct ovm_ipc_comm {
     ovm_shm_comm_t *shm = nullptr;
     uint32_t rank = 0, world = 1;
+    // degraded: mapping a peer's buffer failed or timed out once (agreed by all ranks): bulk exchanges are staged
+    // through host memory from then on. `why` says what happened (ovm_hip_ipc_comm_status).
+    bool degraded = false;
+    std::string why;
+    double open_timeout_s = 20.0;
+    int force_open = 0;
+    uint64_t opens = 0, staged_exchanges = 0;
+    uint8_t *h_send = nullptr, *h_recv = nullptr;  // pinned staging of the degraded mode
+    uint64_t h_send_cap = 0, h_recv_cap = 0;
     // mappings of peers' allocations, by (owner rank, handle bytes), with the owner's BUFFER ID of the allocation and the
     // exchange that used them last. The buffer id is unique per allocation for the life of the owner's process: if the
     // owner returned a segment to the driver and a later allocation came back with the same handle bytes, the id
@@ -73,33 +141,66 @@ struct ovm_ipc_comm {
         const int rc = ovm_hip_shm_allgather(shm, &m, all.data(), sizeof(Msg));
         if (rc) return rc;
         for (uint32_t r = 0; r < world; r++)
-            if (all[r].status != 0) return all[r].status;  // every rank sees the same failure
+            if (all[r].status != 0) {  // every rank sees the same failure
+                if (why.empty()) why = "rank " + std::to_string(r) + " could not export its buffer (code " + std::to_string(all[r].status) + ")";
+                return all[r].status;
+            }
         src.assign(world, nullptr);
         int first_error = 0;
         exchanges++;
+        std::vector<std::string> keys(world);
+        std::vector<uint32_t> to_open;
         for (uint32_t r = 0; r < world; r++) {
             if (all[r].bytes != send_bytes) first_error = first_error ? first_error : (int)hipErrorInvalidValue;
             if (r == rank) {
                 src[r] = (const uint8_t *)d_send;
                 continue;
             }
-            std::string key((const char *)&all[r].handle, sizeof(hipIpcMemHandle_t));
-            key.append((const char *)&r, sizeof r);
-            auto it = opened.find(key);
+            keys[r].assign((const char *)&all[r].handle, sizeof(hipIpcMemHandle_t));
+            keys[r].append((const char *)&r, sizeof r);
+            auto it = opened.find(keys[r]);
             if (it != opened.end() && it->second.buffer_id != all[r].buffer_id) {  // same handle bytes, another allocation
                 (void)hipIpcCloseMemHandle(it->second.p);
                 opened.erase(it);
                 it = opened.end();
             }
-            if (it == opened.end()) {
-                void *p = nullptr;
-                const hipError_t oe = hipIpcOpenMemHandle(&p, all[r].handle, hipIpcMemLazyEnablePeerAccess);
-                if (oe != hipSuccess) {
-                    (void)hipGetLastError();
-                    first_error = first_error ? first_error : (int)oe;
-                    continue;
+            if (it == opened.end()) to_open.push_back(r);
+        }
+        // does ANY rank have something to map? (all ranks take the phased path together, or none does)
+        std::vector<uint32_t> needs(world);
+        const uint32_t mine_needs = (uint32_t)to_open.size();
+        if (int rc2 = ovm_hip_shm_allgather(shm, &mine_needs, needs.data(), sizeof(uint32_t))) return rc2;
+        bool any = false;
+        for (uint32_t n : needs) any = any || n != 0;
+        if (any) {
+            for (uint32_t turn = 0; turn < world; turn++) {
+                if (turn == rank) {
+                    for (uint32_t r : to_open) {
+                        void *p = nullptr;
+                        bool timed_out = false;
+                        const hipError_t oe = open_with_deadline(&p, all[r].handle, open_timeout_s, force_open, timed_out);
+                        opens++;
+                        if (oe != hipSuccess) {
+                            (void)hipGetLastError();
+                            first_error = first_error ? first_error : (int)oe;
+                            if (why.empty())
+                                why = timed_out ? "hipIpcOpenMemHandle of rank " + std::to_string(r) + "'s buffer did not return within " +
+                                                      std::to_string((int)open_timeout_s) + " s (OVM_IPC_OPEN_TIMEOUT_S)"
+                                                : "hipIpcOpenMemHandle of rank " + std::to_string(r) + "'s buffer failed with code " + std::to_string((int)oe);
+                            break;  // (one failure degrades the communicator: no point in trying the other peers)
+                        }
+                        opened.emplace(keys[r], Mapping{p, exchanges, all[r].buffer_id});
+                    }
                 }
-                it = opened.emplace(key, Mapping{p, exchanges, all[r].buffer_id}).first;
+                if (int rc2 = barrier()) return rc2;
+            }
+        }
+        for (uint32_t r = 0; r < world; r++) {
+            if (r == rank) continue;
+            auto it = opened.find(keys[r]);
+            if (it == opened.end()) {
+                first_error = first_error ? first_error : (int)hipErrorMapFailed;
+                continue;
             }
             it->second.last_used = exchanges;
             src[r] = (const uint8_t *)it->second.p + all[r].offset;
@@ -125,10 +226,92 @@ struct ovm_ipc_comm {
         return 0;
     }
 
+    // The shared-memory exchange's own verdicts (a peer died, aborted, the communicator is poisoned) are final; anything
+    // else that went wrong while exporting or mapping degrades the communicator on every rank.
+    static bool is_exchange_error(int rc) { return rc == OVM_ESHARD_TIMEOUT || rc == OVM_ESHARD_PEER_ABORTED || rc == OVM_ESHARD_POISONED; }
+    // 0: mapped (src valid); 1: degraded (agreed by all ranks), stage this exchange; else: error
+    int map_or_degrade(const void *d_send, uint64_t send_bytes, hipStream_t stream, std::vector<const uint8_t *> &src, int &err) {
+        err = 0;
+        if (degraded) return 1;
+        const int mine = publish_and_map(d_send, send_bytes, stream, src);
+        if (is_exchange_error(mine)) {
+            err = mine;
+            return 2;
+        }
+        const int rc = agree(mine);
+        if (rc == 0) return 0;
+        if (is_exchange_error(rc) || rc == (int)hipErrorInvalidValue) {  // (invalid value: the ranks disagree on the size -- a caller bug)
+            err = rc;
+            return 2;
+        }
+        degraded = true;
+        if (why.empty()) why = "a peer could not map this rank's buffer (code " + std::to_string(rc) + ")";
+        fprintf(stderr, "[ovm ipc] rank %u: %s -- bulk exchanges are STAGED THROUGH HOST MEMORY from now on\n", rank, why.c_str());
+        return 1;
+    }
+    int ensure_host(uint8_t *&buf, uint64_t &cap, uint64_t need) {
+        if (cap >= need) return 0;
+        if (buf) (void)hipHostFree(buf);
+        buf = nullptr;
+        cap = 0;
+        const hipError_t e = hipHostMalloc((void **)&buf, need, hipHostMallocDefault);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            return (int)e;
+        }
+        cap = need;
+        return 0;
+    }
+    // degraded mode: device -> pinned host -> shared-memory all-gather -> device
+    int staged_allgather(const void *d_mine, void *d_all, uint64_t bytes, hipStream_t stream) {
+        staged_exchanges++;
+        int rc = ensure_host(h_send, h_send_cap, bytes);
+        if (!rc) rc = ensure_host(h_recv, h_recv_cap, bytes * world);
+        hipError_t e = hipSuccess;
+        if (!rc) {
+            e = hipMemcpyAsync(h_send, d_mine, bytes, hipMemcpyDeviceToHost, stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(stream);
+            if (e != hipSuccess) rc = (int)e;
+        }
+        rc = agree(rc);
+        if (rc) return rc;
+        if ((rc = ovm_hip_shm_allgather(shm, h_send, h_recv, bytes))) return rc;
+        e = hipMemcpyAsync(d_all, h_recv, bytes * world, hipMemcpyHostToDevice, stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(stream);
+        if (e != hipSuccess) (void)hipGetLastError();
+        return agree((int)e);
+    }
+    int staged_alltoall(const void *d_send, void *d_recv, uint64_t bytes, hipStream_t stream) {
+        staged_exchanges++;
+        int rc = ensure_host(h_send, h_send_cap, bytes * world);
+        if (!rc) rc = ensure_host(h_recv, h_recv_cap, bytes * world);
+        hipError_t e = hipSuccess;
+        if (!rc) {
+            e = hipMemcpyAsync(h_send, d_send, bytes * world, hipMemcpyDeviceToHost, stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(stream);
+            if (e != hipSuccess) rc = (int)e;
+        }
+        rc = agree(rc);
+        if (rc) return rc;
+        // block j of every rank is gathered in turn; rank j keeps it (world x the bytes a pairwise exchange would move:
+        // this is the fall-back that needs nothing, not the fast path)
+        for (uint32_t j = 0; j < world; j++) {
+            if ((rc = ovm_hip_shm_allgather(shm, h_send + (uint64_t)j * bytes, h_recv, bytes))) return rc;
+            if (j == rank) {
+                e = hipMemcpyAsync(d_recv, h_recv, bytes * world, hipMemcpyHostToDevice, stream);
+                if (e == hipSuccess) e = hipStreamSynchronize(stream);
+                if (e != hipSuccess) (void)hipGetLastError();
+            }
+        }
+        return agree((int)e);
+    }
+
     int allgather(const void *d_mine, void *d_all, uint64_t bytes, hipStream_t stream) {
         std::vector<const uint8_t *> src;
-        int rc = agree(publish_and_map(d_mine, bytes, stream, src));
-        if (rc) return rc;
+        int rc = 0;
+        const int how = map_or_degrade(d_mine, bytes, stream, src, rc);
+        if (how == 2) return rc;
+        if (how == 1) return staged_allgather(d_mine, d_all, bytes, stream);
         hipError_t e = hipSuccess;
         for (uint32_t k = 0; k < world && e == hipSuccess; k++) {
             const uint32_t r = (rank + k) % world;  // start with the own block, then spread the peers
@@ -143,8 +326,10 @@ struct ovm_ipc_comm {
 
     int alltoall(const void *d_send, void *d_recv, uint64_t bytes, hipStream_t stream) {
         std::vector<const uint8_t *> src;
-        int rc = agree(publish_and_map(d_send, bytes * world, stream, src));
-        if (rc) return rc;
+        int rc = 0;
+        const int how = map_or_degrade(d_send, bytes * world, stream, src, rc);
+        if (how == 2) return rc;
+        if (how == 1) return staged_alltoall(d_send, d_recv, bytes, stream);
         hipError_t e = hipSuccess;
         for (uint32_t k = 0; k < world && e == hipSuccess; k++) {
             const uint32_t s = (rank + k) % world;
@@ -164,6 +349,9 @@ int ovm_hip_ipc_comm_create(ovm_shm_comm_t *shm, uint32_t rank, uint32_t world, 
     c->shm = shm;
     c->rank = rank;
     c->world = world;
+    if (const char *e = getenv("OVM_IPC_OPEN_TIMEOUT_S")) c->open_timeout_s = std::max(0.05, atof(e));
+    if (const char *e = getenv("OVM_IPC_FORCE_OPEN_FAIL")) c->force_open = atoi(e) ? 1 : 0;
+    if (const char *e = getenv("OVM_IPC_FORCE_OPEN_HANG")) c->force_open = atoi(e) ? 2 : c->force_open;
     *out = c;
     return 0;
 }
@@ -171,7 +359,21 @@ int ovm_hip_ipc_comm_create(ovm_shm_comm_t *shm, uint32_t rank, uint32_t world, 
 void ovm_hip_ipc_comm_destroy(ovm_ipc_comm_t *c) {
     if (!c) return;
     for (auto &kv : c->opened) (void)hipIpcCloseMemHandle(kv.second.p);
+    if (c->h_send) (void)hipHostFree(c->h_send);
+    if (c->h_recv) (void)hipHostFree(c->h_recv);
     delete c;
+}
+
+int ovm_hip_ipc_comm_status(const ovm_ipc_comm_t *c, ovm_ipc_status_t *out) {
+    if (!c || !out) return (int)hipErrorInvalidValue;
+    memset(out, 0, sizeof *out);
+    out->degraded = c->degraded ? 1 : 0;
+    out->mappings = (uint32_t)c->opened.size();
+    out->opens = c->opens;
+    out->exchanges = c->exchanges;
+    out->staged_exchanges = c->staged_exchanges;
+    snprintf(out->reason, sizeof out->reason, "%s", c->why.c_str());
+    return 0;
 }
 
 int ovm_hip_ipc_allgather_host(void *ctx, const void *mine, void *all, uint64_t bytes) {

@@ -32,6 +32,7 @@ def main():
     orc = oracle_lib.load()
     rng = np.random.default_rng(args.seed)
     bad = 0
+    with_absent = 0
     for case in range(args.cases):
         seed, world = int(rng.integers(0, 1 << 30)), int(rng.integers(2, 9))
         save_memory, alltoall = bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
@@ -47,9 +48,13 @@ def main():
             got = run_sharded(f"fuzz:{seed}", world, pathlib.Path(tmp), save_memory=save_memory, alltoall=alltoall, bulk=bulk)
         ok = got == want
         bad += not ok
-        print(f"case {case}: {'ok' if ok else 'MISMATCH'} seed={seed} world={world} airs={len(air_list)} owners={owners} "
+        n_absent = len(air_list) - len(traces)
+        idle = world - len(set(owners))
+        with_absent += n_absent > 0
+        print(f"case {case}: {'ok' if ok else 'MISMATCH'} seed={seed} world={world} airs={len(air_list)} absent={n_absent} "
+              f"ranks_without_a_trace={idle} owners={owners} "
               f"save_memory={save_memory} alltoall={alltoall} bulk={bulk}", flush=True)
-    print(f"{bad} mismatches in {args.cases} cases")
+    print(f"{bad} mismatches in {args.cases} cases ({with_absent} proved contexts had absent AIRs)")
     sys.exit(1 if bad else 0)
 
 

@@ -30,6 +30,9 @@ def main():
                          "rank must refuse, the communicator stays usable); 'midproof' = --fail-rank throws after its commitment "
                          "(the peers must return OVM_ESHARD_PEER_ABORTED quickly, the communicator is poisoned and is recreated)")
     ap.add_argument("--fail-rank", type=int, default=1)
+    ap.add_argument("--expect-ipc", default="any", choices=["any", "mapped", "degraded"],
+                    help="after the proof: the library's IPC exchange must have stayed on mapped peer buffers / must have degraded "
+                         "to host staging (OVM_IPC_FORCE_OPEN_FAIL / OVM_IPC_FORCE_OPEN_HANG in the environment)")
     ap.add_argument("--no-alltoall", action="store_true",
                     help="hand the library a null alltoall_device: the mu-batch vectors are all-gathered whole")
     args = ap.parse_args()
@@ -125,6 +128,13 @@ def main():
     t_done = time.time()
     print(f"[shard_worker rank {args.rank}] import+rendezvous {t_pg - t_start:.1f} s, device+key+shm+upload {t_ready - t_pg:.1f} s, "
           f"prove x{args.repeat} {t_done - t_ready:.2f} s", file=sys.stderr, flush=True)
+    if args.bulk == "ipc" and args.world > 1:
+        st = shard.ipc_status()
+        print(f"[shard_worker rank {args.rank}] ipc: {st}", file=sys.stderr, flush=True)
+        if args.expect_ipc == "degraded":
+            assert st["degraded"] and st["staged_exchanges"] > 0 and st["reason"], st
+        elif args.expect_ipc == "mapped":
+            assert not st["degraded"] and st["staged_exchanges"] == 0 and st["mappings"] >= 1, st
     if args.rank == 0:
         with open(args.out, "wb") as f:
             f.write(proof)

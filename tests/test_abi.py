@@ -48,7 +48,7 @@ _C_TO_RUST = {"void": "c_void", "int": "c_int", "char": "c_char", "uint32_t": "u
               "size_t": "usize", "ovm_stream_t": "OvmStream", "ovm_sponge_t": "OvmSponge", "ovm_pk_t": "OvmPk",
               "ovm_pcs_t": "OvmPcs", "ovm_trace_t": "OvmTrace", "ovm_pcs_params_t": "OvmPcsParams",
               "ovm_matrix_t": "OvmMatrix", "ovm_shard_t": "OvmShard", "ovm_shm_comm_t": "OvmShmComm", "ovm_ipc_comm_t": "OvmIpcComm",
-              "ovm_prover_config_t": "OvmProverConfig"}
+              "ovm_prover_config_t": "OvmProverConfig", "ovm_ipc_status_t": "OvmIpcStatus"}
 
 
 def _c_type_to_rust(t):
@@ -139,6 +139,7 @@ def test_struct_layouts_match_header(pkg):
     assert ctypes.sizeof(pkg.ShardStruct) == 48 and pkg.ShardStruct.allgather_device.offset == 24
     assert pkg.ShardStruct.alltoall_device.offset == 32 and pkg.ShardStruct.abort.offset == 40
     assert ctypes.sizeof(pkg.ProverConfigStruct) == 24 and pkg.ProverConfigStruct.cache_limit_bytes.offset == 16
+    assert ctypes.sizeof(pkg.IpcStatusStruct) == 224 and pkg.IpcStatusStruct.reason.offset == 32
 
 
 def test_rust_crate_only_calls_declared_entries():

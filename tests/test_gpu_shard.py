@@ -25,14 +25,16 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def run_sharded(case, world, tmp_path, repeat=1, save_memory=False, alltoall=True, bulk="ipc", fail_mode="none", fail_rank=1):
+def run_sharded(case, world, tmp_path, repeat=1, save_memory=False, alltoall=True, bulk="ipc", fail_mode="none", fail_rank=1,
+                extra_env=None, expect_ipc="any"):
     port, shm, out = _free_port(), f"/ovm-test-{uuid.uuid4().hex[:12]}", str(tmp_path / "proof.bin")
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
     env["OVM_SHARD_TIMEOUT_S"] = "60"  # a rank that died must not hold the others for minutes
+    env.update(extra_env or {})
     procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "shard_worker.py"), "--rank", str(r), "--world", str(world),
                                "--port", str(port), "--case", case, "--shm", shm, "--out", out, "--repeat", str(repeat)]
                               + (["--save-memory"] if save_memory else []) + ([] if alltoall else ["--no-alltoall"])
-                              + ["--bulk", bulk, "--fail-mode", fail_mode, "--fail-rank", str(fail_rank)],
+                              + ["--bulk", bulk, "--fail-mode", fail_mode, "--fail-rank", str(fail_rank), "--expect-ipc", expect_ipc],
                               env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
     logs = []
     for p in procs:
@@ -93,6 +95,25 @@ def test_bulk_exchange_staged_through_shared_memory(orc, tmp_path, case, world):
     here replaces by the library's IPC exchange: the same proof."""
     blob, want = oracle_proof(orc, case, world)
     assert run_sharded(case, world, tmp_path, bulk="shm") == want
+
+
+@pytest.mark.parametrize("hook,world", [("OVM_IPC_FORCE_OPEN_FAIL", 2), ("OVM_IPC_FORCE_OPEN_FAIL", 4), ("OVM_IPC_FORCE_OPEN_HANG", 3)])
+def test_ipc_exchange_degrades_to_host_staging_instead_of_hanging(orc, tmp_path, hook, world):
+    """`hipIpcOpenMemHandle` once did not return (two 85 GB processes on one GPU). Every open now has
+    a deadline and the ranks map in turn; a failed (FAIL hook) or overdue (HANG hook: the helper thread never returns,
+    deadline 1 s) open is agreed by all ranks and the communicator stages this and every later bulk exchange through
+    host memory: the proof in flight completes, byte-identical, and a second proof over the same communicator too."""
+    import time
+    blob, want = oracle_proof(orc, "bench_app", world)
+    t0 = time.time()
+    got = run_sharded("bench_app", world, tmp_path, repeat=2, extra_env={hook: "1", "OVM_IPC_OPEN_TIMEOUT_S": "1"}, expect_ipc="degraded")
+    assert got == want
+    assert time.time() - t0 < 120
+
+
+def test_ipc_exchange_stays_on_mapped_buffers_when_nothing_fails(orc, tmp_path):
+    blob, want = oracle_proof(orc, "bench_app", 4)
+    assert run_sharded("bench_app", 4, tmp_path, repeat=3, expect_ipc="mapped") == want
 
 
 @pytest.mark.parametrize("case,world", [("bench_app", 2), ("bench8", 3)])

@@ -1,0 +1,97 @@
+"""Host placement rules (stark-backend_amd/placement.py) over a synthetic sysfs tree shaped like the MI355X host
+(2 sockets x 64 cores x 2 threads, SMT sibling of CPU k is k + 128, GPUs 0-3 on node 0 and 4-7 on node 1) and over
+degenerate trees: no hardware needed."""
+import os
+
+import pytest
+
+from conftest import load_pkg
+
+load_pkg()
+from stark_backend_amd import placement  # noqa: E402
+
+
+def make_sysfs(root, sockets=2, cores=64, smt=2, adjacent_siblings=False, gpu_nodes=(0, 0, 0, 0, 1, 1, 1, 1)):
+    ncpu = sockets * cores * smt
+    def sibs(c):
+        if adjacent_siblings:
+            base = c - c % smt
+            return list(range(base, base + smt))
+        phys = c % (sockets * cores)
+        return [phys + k * sockets * cores for k in range(smt)]
+    def node_of(c):
+        phys = (c // smt) if adjacent_siblings else c % (sockets * cores)
+        return phys // cores
+    for c in range(ncpu):
+        d = root / "devices" / "system" / "cpu" / f"cpu{c}" / "topology"
+        d.mkdir(parents=True)
+        (d / "thread_siblings_list").write_text(",".join(str(s) for s in sibs(c)) + "\n")
+    for n in range(sockets):
+        d = root / "devices" / "system" / "node" / f"node{n}"
+        d.mkdir(parents=True)
+        (d / "cpulist").write_text(",".join(str(c) for c in range(ncpu) if node_of(c) == n) + "\n")
+    bdfs = []
+    for i, n in enumerate(gpu_nodes):
+        bdf = f"0000:{0x05 + 0x10 * i:02x}:00.0"
+        d = root / "bus" / "pci" / "devices" / bdf
+        d.mkdir(parents=True)
+        (d / "numa_node").write_text(f"{n}\n")
+        bdfs.append(bdf)
+    return bdfs, list(range(ncpu))
+
+
+def test_parse_cpulist():
+    assert placement.parse_cpulist("0-3,8,10-11\n") == [0, 1, 2, 3, 8, 10, 11]
+    assert placement.parse_cpulist("") == []
+
+
+def test_each_rank_gets_two_physical_cores_on_its_gpus_node(tmp_path):
+    bdfs, cpus = make_sysfs(tmp_path)
+    used = set()
+    for r in range(8):
+        pair, facts = placement.pick_cores(r, bdfs, cpus, sysfs=str(tmp_path))
+        node = 0 if r < 4 else 1
+        assert facts["numa_node"] == node and facts["slot_on_node"] == r % 4 and facts["physical_cores_on_node"] == 64
+        assert all(64 * node <= c < 64 * (node + 1) for c in pair)       # first hardware thread of cores on that socket
+        assert pair[0] != pair[1] and abs(pair[0] - pair[1]) != 128      # not SMT siblings
+        assert not used & set(pair)
+        used |= set(pair)
+    assert placement.pick_cores(0, bdfs, cpus, sysfs=str(tmp_path))[0] == [8, 9]      # the measured pair of round 3
+    assert placement.pick_cores(4, bdfs, cpus, sysfs=str(tmp_path))[0] == [72, 73]    # rank 4: the other socket
+
+
+def test_adjacent_smt_numbering_never_pairs_siblings(tmp_path):
+    """Hosts that number the two threads of a core 2k, 2k + 1: CPUs c and c + 1 would be ONE core."""
+    bdfs, cpus = make_sysfs(tmp_path, adjacent_siblings=True)
+    pair, _ = placement.pick_cores(1, bdfs, cpus, sysfs=str(tmp_path))
+    assert pair == [20, 22] and pair[0] // 2 != pair[1] // 2
+
+
+def test_restricted_affinity_and_missing_information(tmp_path):
+    bdfs, cpus = make_sysfs(tmp_path)
+    # a container that may only use 8 CPUs of node 0: not enough physical cores after the skipped ones -> no pinning
+    pair, why = placement.pick_cores(0, bdfs, list(range(8)), sysfs=str(tmp_path))
+    assert pair is None and "not enough" in why
+    # GPU without NUMA information (numa_node = -1) -> pairs from all allowed CPUs, by local rank
+    (tmp_path / "bus" / "pci" / "devices" / bdfs[2] / "numa_node").write_text("-1\n")
+    pair, facts = placement.pick_cores(2, bdfs, cpus, sysfs=str(tmp_path))
+    assert facts["numa_node"] is None and pair == [12, 13]
+    # unknown PCI address, unreadable sibling lists -> None, with the reason
+    assert placement.pick_cores(9, bdfs, cpus, sysfs=str(tmp_path))[0] is None
+    assert placement.pick_cores(0, bdfs, cpus, sysfs=str(tmp_path / "nowhere"))[0] in (None, [8, 9])
+    pair, why = placement.pick_cores(0, [None], cpus, sysfs=str(tmp_path / "nowhere"))
+    assert pair is None and "unreadable" in why
+
+
+def test_pin_this_process_states_what_it_did(tmp_path):
+    if not hasattr(os, "sched_setaffinity"):
+        pytest.skip("no sched_setaffinity")
+    before = os.sched_getaffinity(0)
+    try:
+        rec = placement.pin_this_process(0, gpu_bdfs=[None], sysfs="/sys")
+        if rec["cpus"] is None:   # this container: 8 CPUs -> "not enough", and nothing was changed
+            assert os.sched_getaffinity(0) == before and rec["reason"]
+        else:
+            assert os.sched_getaffinity(0) == set(rec["cpus"]) and len(set(rec["cpus"])) == 2
+    finally:
+        os.sched_setaffinity(0, before)
