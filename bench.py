@@ -53,11 +53,39 @@ def launch_ranks(args):
     sys.exit(subprocess.run(cmd, env=env).returncode)
 
 
-def roofline_classes(prof, steps, rows, width, cells, log_stacked, gkr_leaves):
-    """Per kernel class: algorithmic bytes per proof (SURVEY §8(d) formulas) / device time of the class's
-    launches (HIP events on the launch stream) -> achieved GB/s against the 8 TB/s HBM peak."""
+# The ISSUE roof of the integer kernels: a wave64 integer VALU instruction occupies its SIMD for 4.05 shader
+# cycles at 2.4 GHz (measured, tools/ubench_poseidon2.hip + tools/ubench_int.hip; the guide's 2-cycle figure is for
+# v_fma_f32), so the chip issues at most CUs x 4 SIMDs x 2.4e9 / 4.05 wave-level VALU instructions per second.
+ISSUE_CYCLES_PER_WAVE_VALU = 4.05
+SHADER_CLOCK_HZ = 2.4e9
+# which kernels make up a class (prefixes of the demangled names in profiles/*/sq_valu*.json)
+CLASS_KERNELS = {
+    "ntt (eval_to_coeff + DIF passes)": ("eval_to_coeff", "dif16_pass_kernel<bb::Fp", "dif_pass_kernel<bb::Fp", "bitrev"),
+    "gkr (leaves + tree + layer sumchecks)": ("gkr_", "eq_heap", "eq_double", "eq_split", "sum_partials"),
+    "folds (fold_ple + MLE rounds)": ("fold_ple", "mle_round", "fold_mle"),
+    "whir mu-batch": ("whir_mu_batch", "zeta_pass"),
+    "poseidon2 (row hash + compress + grind)": ("hash_rows", "compress_layer", "grind"),
+}
+
+
+def load_sq_valu():
+    for rel in (("profiles", "r04", "sq_valu_r04.json"), ("profiles", "r03", "sq_valu_r03.json")):
+        q = os.path.join(ROOT, *rel)
+        if os.path.exists(q):
+            return json.load(open(q))["kernels"], os.path.join(*rel)
+    return None, None
+
+
+def roofline_classes(prof, steps, rows, width, cells, log_stacked, gkr_leaves, n_cus=256, headline=False):
+    """Per kernel class, BOTH roofs: `frac` = algorithmic bytes per proof (SURVEY §8(d) formulas) /
+    device time of the class's launches (HIP events on the launch stream) against the 8 TB/s HBM peak, and `issue_frac` =
+    the wave-level VALU instructions the class's kernels execute per proof (SQ_INSTS_VALU, a property of the workload: read
+    from the committed counter pass like `traffic`) / the same device time against the measured issue ceiling. `bound` names
+    the roof the class sits closer to."""
     def ms(label):
         return prof[label][1] / steps if label in prof else None
+    sq, sq_src = load_sq_valu() if headline else (None, None)
+    issue_peak = n_cus * 4 * SHADER_CLOCK_HZ / ISSUE_CYCLES_PER_WAVE_VALU
     E_code, E_msg = rows * width, (rows // 2) * width
     out = {}
     cls = {
@@ -70,14 +98,27 @@ def roofline_classes(prof, steps, rows, width, cells, log_stacked, gkr_leaves):
         # fold_ple: 4 B/cell + 16 B per 2^l_skip cells; MLE folds 1.5 * 16 B per element over a halving series
         "folds (fold_ple + MLE rounds)": (4 * cells + cells + 48 * (cells // 16), ["constraints.fold_ple", "constraints.mle_rounds"]),
         "whir mu-batch": (4 * E_msg + 16 * (1 << log_stacked), ["whir.mu_batch"]),
+        # not an HBM class (integer-ALU bound): listed so that its issue fraction stands beside the others'
+        "poseidon2 (row hash + compress + grind)": (4 * rows * width + 32 * rows // 16 + 96 * 2 * (rows // 16),
+                                                    ["merkle.hash_rows", "merkle.hash_rows_ext", "merkle.compress_layers", "grind"]),
     }
     for name, (algo, labels) in cls.items():
         t = [ms(l) for l in labels]
         if any(x is None for x in t):
             continue
         tot = sum(t)
-        out[name] = {"algorithmic_bytes": int(algo), "ms": round(tot, 3), "achieved_GBps": round(algo / (tot * 1e-3) / 1e9, 1),
-                     "frac": round(algo / (tot * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+        ent = {"algorithmic_bytes": int(algo), "ms": round(tot, 3), "achieved_GBps": round(algo / (tot * 1e-3) / 1e9, 1),
+               "frac": round(algo / (tot * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+        if sq:
+            insts = sum(v["valu_wave_insts"] for k, v in sq.items() if k.startswith(CLASS_KERNELS[name]))
+            if insts:
+                ent["valu_wave_insts"] = int(insts)
+                ent["issue_frac"] = round(insts / (tot * 1e-3) / issue_peak, 4)
+                ent["bound"] = "valu issue" if ent["issue_frac"] > ent["frac"] else "hbm"
+        out[name] = ent
+    if sq:
+        out["_issue_roof"] = {"peak_wave_valu_per_s": round(issue_peak, 1), "cycles_per_wave_valu": ISSUE_CYCLES_PER_WAVE_VALU,
+                              "clock_hz": SHADER_CLOCK_HZ, "valu_counts_source": sq_src}
     return out
 
 
@@ -390,14 +431,17 @@ def main():
     elapsed = time.perf_counter() - t0
     prof_dom = pkg.profile_report()
     prof_steps = max(1, min(args.steps, 3)) if args.profile_steps < 0 else args.profile_steps
-    prof = {}
+    prof, prof_detail, prof_step_ms = {}, {}, None
     if prof_steps:
         pkg.profile_enable(1)
         barrier()
+        p0 = time.perf_counter()
         for _ in range(prof_steps):
             step()
         barrier()
+        prof_step_ms = (time.perf_counter() - p0) / prof_steps * 1e3
         prof = pkg.profile_report()
+        prof_detail = pkg.profile_report_detail()
     pkg.profile_enable(0)
     other_form = None
     if world == 1 and step_partitioned is not None:
@@ -501,7 +545,9 @@ def main():
             roof["issue_bound"] = ib
             if world == 1:
                 gkr_leaves = 26 * h * args.num_airs  # 13 send/receive pairs -> 26 interactions per row (padding leaves are never materialised)
-                roof["classes"] = roofline_classes(prof, prof_steps, rows, width, cells, args.log_stacked_height, gkr_leaves)
+                roof["classes"] = roofline_classes(prof, prof_steps, rows, width, cells, args.log_stacked_height, gkr_leaves,
+                                                   n_cus=props.multi_processor_count,
+                                                   headline=(log_rows, cols, args.log_stacked_height, args.log_blowup, args.num_airs) == (22, 100, 24, 1, 1))
                 roof["classes_source"] = f"{prof_steps} fully profiled steps after the timed region"
         cpu = None
         if not args.no_cpu_baseline:
@@ -556,6 +602,19 @@ def main():
             "stage_ms": {k: round(v, 3) for k, v in sorted(stages.items(), key=lambda kv: -kv[1])},
             "dominant_stage": dom,
         }
+        if prof_detail and world == 1:
+            # The ADDITIVE table (the labels of `stage_ms` nest -- whir.rs_commit contains Merkle and NTT labels --
+            # and one runs on the side stream, so they summed to more than the step): per label only the time measured at
+            # top level on the caller's stream; nested and side-stream time are listed apart; the remainder of a profiled
+            # step is host round trips and unlabelled launches.
+            add = {k: (v["ms"] - v["nested_ms"] - v["side_ms"]) / prof_steps for k, v in prof_detail.items()}
+            add = {k: round(v, 3) for k, v in sorted(add.items(), key=lambda kv: -kv[1]) if v > 0.0005}
+            line["stage_ms_additive"] = {
+                "top_level_on_the_callers_stream": add, "sum": round(sum(add.values()), 3),
+                "profiled_step_ms": round(prof_step_ms, 3),
+                "unlabelled_or_idle": round(prof_step_ms - sum(add.values()), 3),
+                "nested_in_another_label": {k: round(v["nested_ms"] / prof_steps, 3) for k, v in prof_detail.items() if v["nested_ms"] > 0},
+                "on_the_side_stream": {k: round(v["side_ms"] / prof_steps, 3) for k, v in prof_detail.items() if v["side_ms"] > 0}}
         if other_form is not None:
             line["n1_plain_form" if args.partitioned else "n1_partitioned_form"] = other_form
         if throughput is not None:

@@ -484,6 +484,8 @@ inline ConstraintsResult prove_zerocheck_and_logup(Transcript &ts, const MultiPk
         }
     }
 
+    // l_skip = 0, every trace one row tall, no interactions: xi is empty and `prover.xi[0]` panics in the reference (mod.rs:255)
+    if (xi.empty()) throw std::runtime_error("EmptyXi: l_skip = 0 and no trace taller than one row (reference panics at logup_zerocheck/mod.rs:255)");
     // --- s_0 assembly (mod.rs:186-305) ---
     const unsigned sp_0_deg = sumcheck_round0_deg(l_skip, constraint_degree);
     const unsigned s_deg = constraint_degree + 1;

@@ -850,8 +850,20 @@ def profile_report() -> dict:
     _lib().ovm_hip_profile_report(buf, len(buf))
     out = {}
     for line in buf.value.decode().splitlines():
-        label, calls, ms = line.rsplit(" ", 2)
+        label, calls, ms, _nested, _side = line.rsplit(" ", 4)
         out[label] = (int(calls), float(ms))
+    return out
+
+
+def profile_report_detail() -> dict:
+    """{label: {calls, ms, nested_ms, side_ms}}: nested_ms was measured inside another open scope (whir.rs_commit contains
+    Merkle and NTT labels), side_ms on the library's side stream; ms - nested_ms - side_ms is additive over the labels."""
+    buf = ctypes.create_string_buffer(1 << 16)
+    _lib().ovm_hip_profile_report(buf, len(buf))
+    out = {}
+    for line in buf.value.decode().splitlines():
+        label, calls, ms, nested, side = line.rsplit(" ", 4)
+        out[label] = {"calls": int(calls), "ms": float(ms), "nested_ms": float(nested), "side_ms": float(side)}
     return out
 
 

@@ -1639,6 +1639,9 @@ struct Prover {
         wt.mark("rap.gkr");
         const unsigned n_global = std::max(n_max, n_logup);
         while (xi.size() != l_skip + n_global) xi.push_back(ts.sample_ext());
+        // l_skip = 0 with every trace one row tall and no interactions: xi is EMPTY and the protocol has no round-0 variable
+        // to bind -- the reference indexes `prover.xi[0]` and panics (prover/logup_zerocheck/mod.rs:255); refused here.
+        if (xi.empty()) throw OvmFail((int)hipErrorInvalidValue, "degenerate context: l_skip = 0 and no trace taller than one row (xi is empty; the reference panics at logup_zerocheck/mod.rs:255)");
 
         // gkr proof bytes
         w.f(logup_pow);

@@ -20,7 +20,10 @@ namespace {
 struct ProfRec {
     const char *label;
     hipEvent_t a, b;
+    int depth;           // number of scopes open on this thread when this one started (0 = a top-level stage)
+    hipStream_t stream;  // the stream the events were recorded on
 };
+thread_local int g_prof_depth = 0;
 int g_prof_mode = 0;  // 0 off, 1 every stage, 2 the dominant kernel's label only
 std::vector<ProfRec> g_prof;
 
@@ -81,14 +84,18 @@ ProfScope::ProfScope(const char *label, hipStream_t s) : stream(s) {
     }
     if (!g_prof_mode) return;
     if (g_prof_mode == 2 && strcmp(label, "merkle.hash_rows") != 0) return;
-    ProfRec r{label, nullptr, nullptr};
+    ProfRec r{label, nullptr, nullptr, g_prof_depth, s};
     if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return;
     (void)hipEventRecord(r.a, s);
     slot = (int)g_prof.size();
     g_prof.push_back(r);
+    g_prof_depth++;
 }
 ProfScope::~ProfScope() {
-    if (slot >= 0) (void)hipEventRecord(g_prof[slot].b, stream);
+    if (slot >= 0) {
+        (void)hipEventRecord(g_prof[slot].b, stream);
+        g_prof_depth--;
+    }
     if (ranged) roctx().pop();
 }
 }  // namespace ovm
@@ -105,23 +112,34 @@ int ovm_hip_profile_enable(int on) {
     return 0;
 }
 
-// Writes "label calls total_ms\n" lines (aggregated per label) into buf; returns bytes needed.
+// Writes "label calls total_ms nested_ms side_ms\n" lines (aggregated per label) into buf; returns bytes needed.
+// nested_ms: the part of total_ms measured while ANOTHER scope was open on the thread (e.g. the Merkle and NTT labels inside
+// whir.rs_commit); side_ms: the part measured on a stream other than the first one seen (the early coset LDE beside the GKR
+// layers). total - nested - side summed over the labels is additive: it cannot exceed the step's time.
 uint64_t ovm_hip_profile_report(char *buf, uint64_t cap) {
     (void)hipDeviceSynchronize();
-    std::map<std::string, std::pair<uint64_t, double>> agg;
+    struct Agg {
+        uint64_t calls = 0;
+        double ms = 0, nested = 0, side = 0;
+    };
+    std::map<std::string, Agg> agg;
     std::vector<std::string> order;
+    const hipStream_t main_stream = ovm::g_prof.empty() ? nullptr : ovm::g_prof.front().stream;
     for (auto &r : ovm::g_prof) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, r.a, r.b) != hipSuccess) continue;
         if (!agg.count(r.label)) order.push_back(r.label);
         auto &e = agg[r.label];
-        e.first++;
-        e.second += ms;
+        e.calls++;
+        e.ms += ms;
+        if (r.stream != main_stream) e.side += ms;
+        else if (r.depth > 0) e.nested += ms;
     }
     std::string out;
     for (auto &l : order) {
         char line[256];
-        snprintf(line, sizeof line, "%s %llu %.6f\n", l.c_str(), (unsigned long long)agg[l].first, agg[l].second);
+        snprintf(line, sizeof line, "%s %llu %.6f %.6f %.6f\n", l.c_str(), (unsigned long long)agg[l].calls, agg[l].ms, agg[l].nested,
+                 agg[l].side);
         out += line;
     }
     if (buf && cap) {

@@ -695,20 +695,43 @@ struct StagedVM {
         // Destination: wave-uniform base in M0, the hardware adds lane * 4.
         const uint32_t lds_base = (uint32_t)(size_t)(__attribute__((address_space(3))) uint32_t *)lds_image +
                                   (__builtin_amdgcn_readfirstlane(threadIdx.x) & ~63u) * 4;
+        // M0 is the compiler's register too (it does not honour an "m0" clobber: -Winline-asm): ONE asm statement per
+        // column saves it, issues the R loads of the lane's R cells -- M0 = destination row, advanced by one LDS row
+        // (RED_THREADS words) between loads -- and restores it, so no compiler-visible instruction ever sees a changed M0 and
+        // nothing can be scheduled between a `s_mov_b32 m0` and the DMA that reads it.
         auto request = [&](uint32_t blk) {
             const uint4 hd = blocks[2 * blk];
             uint32_t dst = lds_base + (blk & 1) * prog.stage_rows * (R * RED_THREADS * 4);
             for (uint32_t j = 0; j < hd.y; j++) {
                 const uint32_t col = loads[hd.x + j];
-#pragma unroll
-                for (int r = 0; r < R; r++) {
-                    const Fp *cell = src(col, r);
-                    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, off"
-                                 :
-                                 : "s"(__builtin_amdgcn_readfirstlane(dst)), "v"(cell)
-                                 : "memory", "m0");
-                    dst += RED_THREADS * 4;
+                const uint32_t d = __builtin_amdgcn_readfirstlane(dst);
+                uint32_t saved;
+                static_assert(R == 1 || R == 2 || R == 4, "one asm form per R");
+                static_assert(RED_THREADS * 4 == 0x400, "the asm advances M0 by one LDS row = 0x400 bytes");
+                if constexpr (R == 1) {
+                    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %2, off\n\t"
+                                 "s_mov_b32 m0, %0"
+                                 : "=&s"(saved)
+                                 : "s"(d), "v"(src(col, 0))
+                                 : "memory");
+                } else if constexpr (R == 2) {
+                    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %2, off\n\t"
+                                 "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dword %3, off\n\t"
+                                 "s_mov_b32 m0, %0"
+                                 : "=&s"(saved)
+                                 : "s"(d), "v"(src(col, 0)), "v"(src(col, 1))
+                                 : "memory", "scc");
+                } else {
+                    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %2, off\n\t"
+                                 "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dword %3, off\n\t"
+                                 "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dword %4, off\n\t"
+                                 "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dword %5, off\n\t"
+                                 "s_mov_b32 m0, %0"
+                                 : "=&s"(saved)
+                                 : "s"(d), "v"(src(col, 0)), "v"(src(col, 1)), "v"(src(col, 2)), "v"(src(col, 3))
+                                 : "memory", "scc");
                 }
+                dst += R * RED_THREADS * 4;
             }
         };
         Fp prev[R];

@@ -193,16 +193,21 @@ def test_stage_level_entries_match_monolithic(dev, pkg, orc):
 import test_oracle_golden as _golden
 
 
-@pytest.mark.skipif(not _golden.reference_cases(), reason="no reference proofs (run tools/gen_golden.rs)")
+@pytest.mark.skipif(not _golden.reference_cases(), reason="no reference proofs (run tools/run_on_cargo_box.sh)")
 @pytest.mark.parametrize("path", _golden.reference_cases())
 def test_reference_golden_proofs(dev, pkg, path):
-    """When real reference output is present: ovm_hip_prove must reproduce it byte for byte."""
+    """When real reference output is present: ovm_hip_prove must reproduce it byte for byte (a negative case must be
+    refused)."""
     import json
+    import parity_util
     doc = json.load(open(path))
     blob = np.array(doc["pk_blob"], dtype=np.uint32)
     pk = pkg.ProvingKey(blob)
-    dtr = [(t["air_idx"], dev.upload(pkg.to_mont(np.array(t["values"], dtype=np.uint32))), t["height"],
-            t["public_values"]) for t in doc["traces"]]
+    dtr = parity_util.upload_traces(dev, pkg, pk, _golden.blob_airs(blob), _golden.doc_traces(doc))
+    if doc.get("proof_hex") is None:
+        with pytest.raises(pkg.OvmError):
+            dev.prove(pk, dtr)
+        return
     got, _ = dev.prove(pk, dtr)
     assert got == bytes.fromhex(doc["proof_hex"])
 
@@ -390,6 +395,17 @@ def test_error_paths(dev, pkg, orc):
     rc = pkg._lib().ovm_hip_prove(pkf.handle, 1, arrf, None, outf.ctypes.data, outf.size, ctypes.byref(plen), None, dev.stream)
     assert rc == 1 and b">= P" in pkg._lib().ovm_hip_last_error()
     orc.verify(airs.pk_blob(params, air_list), proof)
+    # 9. the degenerate context the sharded fuzzer found in round 4: l_skip = 0, every trace ONE row tall, no interactions ->
+    # xi is empty; the reference indexes xi[0] and panics (prover/logup_zerocheck/mod.rs:255): oracle and library both refuse
+    p0 = airs.test_params(l_skip=0, n_stack=8, k_whir=1)
+    blob0 = airs.pk_blob(p0, [airs.fibonacci_air()])
+    tr1, pv1 = airs.fibonacci_trace(0, 1, 1)
+    with pytest.raises(RuntimeError, match="EmptyXi"):
+        orc.prove(blob0, [(0, tr1, 1, pv1)])
+    with pytest.raises(pkg.OvmError, match="xi is empty"):
+        dev.prove(pkg.ProvingKey(blob0), [(0, up(tr1), 1, pv1)])
+    tr2, pv2 = airs.fibonacci_trace(0, 1, 2)   # two rows: one variable, fine
+    run_case(dev, pkg, orc, p0, [airs.fibonacci_air()], [(0, tr2, 2, pv2)])
 
 
 def test_two_host_threads_prove_concurrently(dev, pkg, orc):

@@ -93,3 +93,17 @@ def test_fibonacci_2_12_config_a(orc):
     bad[-5] ^= 1
     with pytest.raises(RuntimeError):
         orc.verify(blob, bytes(bad))
+
+
+def test_empty_xi_is_refused_not_crashed(orc):
+    """l_skip = 0, one trace of ONE row, no interactions: xi has no entry, the reference panics at `prover.xi[0]`
+    (prover/logup_zerocheck/mod.rs:255). The oracle used to read xi[0] of an empty vector (found by tests/fuzz_shard.py in
+    round 4 as a crash of the checker); it now refuses."""
+    import pytest
+    p0 = airs.test_params(l_skip=0, n_stack=8, k_whir=1)
+    blob = airs.pk_blob(p0, [airs.fibonacci_air()])
+    tr, pv = airs.fibonacci_trace(0, 1, 1)
+    with pytest.raises(RuntimeError, match="EmptyXi"):
+        orc.prove(blob, [(0, tr, 1, pv)])
+    tr, pv = airs.fibonacci_trace(0, 1, 2)
+    orc.verify(blob, orc.prove(blob, [(0, tr, 2, pv)])["proof"])

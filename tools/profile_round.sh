@@ -19,4 +19,13 @@ rocprofv3 --pmc WRITE_SIZE -d "$OUT/write" -o run --output-format rocpd -- $BENC
 FE=$(find "$OUT/fetch" -name "*_results.db" | head -1)
 WR=$(find "$OUT/write" -name "*_results.db" | head -1)
 python3 tools/rocpd_pmc.py "$FE" "$WR" "$OUT/pmc_hbm_traffic.json" > "$OUT/pmc.txt" 2>&1
+# 3. two SQ counter passes (instruction mix, waits, LDS conflicts) -> sq_counters.txt + the per-kernel VALU instruction
+#    counts bench.py's per-class issue fractions are computed from
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAIT_INST_LDS \
+  -d "$OUT/sqa" -o run --output-format rocpd -- $BENCH > "$OUT/sqa.log" 2>&1
+rocprofv3 --pmc SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_ACTIVE_INST_SCA SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE \
+  -d "$OUT/sqb" -o run --output-format rocpd -- $BENCH > "$OUT/sqb.log" 2>&1
+SA=$(find "$OUT/sqa" -name "*_results.db" | head -1)
+SB=$(find "$OUT/sqb" -name "*_results.db" | head -1)
+python3 tools/rocpd_sq.py "$SA" "$SB" --json "$OUT/sq_valu.json" > "$OUT/sq_counters.txt" 2>&1
 ls -la "$OUT"

@@ -14,8 +14,9 @@ def main():
     db = sqlite3.connect(sys.argv[1])
     cols = [r[1] for r in db.execute("pragma table_info(kernels)")]
     name_c = "name" if "name" in cols else [c for c in cols if "name" in c][0]
-    rows = db.execute(f"select {name_c}, start, end from kernels order by start").fetchall()
-    rows = [(n.replace("void ", "").replace("ovm::", "").split("(")[0], s, e) for n, s, e in rows if not n.startswith("at::") and "elementwise" not in n]
+    stream_c = next((c for c in ("stream_id", "queue_id", "stream") if c in cols), None)
+    rows = db.execute(f"select {name_c}, start, end, {stream_c or '0'} from kernels order by start").fetchall()
+    rows = [(n.replace("void ", "").replace("ovm::", "").split("(")[0], s, e, q) for n, s, e, q in rows if not n.startswith("at::") and "elementwise" not in n]
     if "--second-half" in sys.argv:
         # bench.py --steps 1 --warmup 1 proves twice on the same input, so the trace ENDS with the same kernel sequence
         # twice: the timed prove is the longest suffix that repeats the kernels right before it (a cold first prove has
@@ -38,19 +39,43 @@ def main():
                 raise SystemExit("no kernel that runs once per prove: cannot find the timed prove")
             second = max(i for i, n in enumerate(names) if n == names[first])
             rows = rows[second:]
-    busy = sum(e - s for _, s, e in rows)
+    streams = collections.defaultdict(lambda: [0, 0])
+    for _, s0, e0, q in rows:
+        streams[q][0] += 1
+        streams[q][1] += e0 - s0
+    if not stream_c:
+        streams = {}
+    rows = [(n, s0, e0) for n, s0, e0, _ in rows]
+    # Kernels of different streams overlap (the early coset LDE runs on the library's side stream beside the GKR layers), so
+    # "busy" is the UNION of the kernel intervals and a gap is a stretch in which NO kernel of any stream runs; it is
+    # attributed to the kernel that ended last before it. (Round 3 summed per-kernel durations and consecutive start - end
+    # differences: with overlap its headline and its histogram disagreed.)
     span = rows[-1][2] - rows[0][1]
+    kernel_time = sum(e - s for _, s, e in rows)
     per = collections.defaultdict(lambda: [0, 0])
     hist = collections.Counter()
-    for (n0, s0, e0), (n1, s1, e1) in zip(rows, rows[1:]):
-        g = max(0, s1 - e0)
-        per[n0][0] += g
-        per[n0][1] += 1
-        b = 0
-        while (2 << b) * 1000 < g:
-            b += 1
-        hist[b] += g
-    print(f"kernels {len(rows)}, span {span / 1e6:.2f} ms, busy {busy / 1e6:.2f} ms, idle {(span - busy) / 1e6:.2f} ms")
+    busy, cur_end, last_name = 0, rows[0][1], rows[0][0]
+    for n, s0, e0 in rows:
+        if s0 > cur_end:
+            g = s0 - cur_end
+            per[last_name][0] += g
+            per[last_name][1] += 1
+            b = 0
+            while (2 << b) * 1000 < g:
+                b += 1
+            hist[b] += g
+            busy += e0 - s0
+            cur_end, last_name = e0, n
+        else:
+            if e0 > cur_end:
+                busy += e0 - cur_end
+                cur_end, last_name = e0, n
+    print(f"kernels {len(rows)}, span {span / 1e6:.2f} ms, some kernel running {busy / 1e6:.2f} ms, idle {(span - busy) / 1e6:.2f} ms "
+          f"(sum of kernel durations {kernel_time / 1e6:.2f} ms: {max(kernel_time - busy, 0) / 1e6:.2f} ms ran concurrently)")
+    if streams:
+        print("per stream (kernels, time):")
+        for sid, (c, t) in sorted(streams.items(), key=lambda kv: -kv[1][1]):
+            print(f"  stream {sid}: {c:5d} kernels, {t / 1e6:7.2f} ms")
     print("idle by gap size:")
     for b in sorted(hist):
         print(f"  < {2 << b:5d} us : {hist[b] / 1e6:7.3f} ms")

@@ -3,7 +3,11 @@
     python tools/rocpd_sq.py pass_a.db pass_b.db
 pass A: SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAIT_INST_LDS
 pass B: SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_ACTIVE_INST_SCA SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE
-Only the later half of each kernel's dispatches is used (the timed prove)."""
+Only the later half of each kernel's dispatches is used (the timed prove).
+    python tools/rocpd_sq.py pass_a.db pass_b.db --json out.json
+also writes, per kernel of the timed prove, the wave-level VALU instructions it executed (SQ_INSTS_VALU: a property of the
+workload, not of the clock), its launches and its time under the profiler: what bench.py's `roofline.classes[*].issue_frac`
+is computed from."""
 import collections
 import sqlite3
 import sys
@@ -28,6 +32,17 @@ def main():
         v = v[len(v) // 2:]
         return sum(x[0] for x in v)
 
+    if "--json" in sys.argv:
+        import json
+        out = {}
+        for k in a:
+            v = a[k].get("SQ_INSTS_VALU", [])
+            v = v[len(v) // 2:]
+            if v:
+                out[k] = {"valu_wave_insts": int(sum(x[0] for x in v)), "launches": len(v), "ms": round(sum(x[1] for x in v) / 1e6, 4)}
+        json.dump({"what": "wave-level VALU instructions per kernel over ONE prove (rocprofv3 --pmc SQ_INSTS_VALU ..., later half of "
+                           "each kernel's dispatches of `bench.py --steps 1 --warmup 1`)", "kernels": out},
+                  open(sys.argv[sys.argv.index("--json") + 1], "w"), indent=1)
     ks = sorted(a, key=lambda k: -sum(x[1] for x in a[k].get("SQ_WAVE_CYCLES", [])))[:14]
     print("kernel                           ms   wait_any wait_inst act_inst valu_act lds_wait | per wave-cycle; "
           "valu lds vmem_rd vmem_wr salu insts (1e6) | lds bank-conflict frac")
