@@ -15,6 +15,9 @@
 // layout fixtures, in-tree constants, and by oracle/verifier.hpp (a restatement of the
 // reference VERIFIER written from different files) accepting these proofs.
 #pragma once
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstdlib>
 #include <functional>
 #include <map>
@@ -1113,8 +1116,21 @@ struct ProveOutput {
     std::shared_ptr<StackedPcsData> common_main_pcs;  // kept for stage-level parity tests
 };
 
+// ORC_TRACE=1: wall time of the coordinator's stages on stderr (where the checker's minutes go at BASELINE sizes)
+struct StageClock {
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    bool on = std::getenv("ORC_TRACE") != nullptr;
+    void mark(const char *what) {
+        if (!on) return;
+        auto t1 = std::chrono::steady_clock::now();
+        fprintf(stderr, "[oracle] %-28s %9.3f s\n", what, std::chrono::duration<double>(t1 - t0).count());
+        t0 = t1;
+    }
+};
+
 inline ProveOutput prove(Transcript &ts, const MultiPk &mpk, ProvingCtx ctx) {
     const SystemParams &params = mpk.params;
+    StageClock clk;
     ts.observe_commit(mpk.vk_pre_hash);
     std::stable_sort(ctx.per_trace.begin(), ctx.per_trace.end(), [](const AirCtx &a, const AirCtx &b) {
         if (a.common_main.height != b.common_main.height) return a.common_main.height > b.common_main.height;
@@ -1125,6 +1141,7 @@ inline ProveOutput prove(Transcript &ts, const MultiPk &mpk, ProvingCtx ctx) {
     auto common = std::make_shared<StackedPcsData>(
         stacked_commit(params.l_skip, params.n_stack, params.log_blowup, params.k_whir, traces));
     Digest common_commit = common->commit();
+    clk.mark("commit (common main)");
 
     ProveOutput out;
     Proof &proof = out.proof;
@@ -1154,6 +1171,7 @@ inline ProveOutput prove(Transcript &ts, const MultiPk &mpk, ProvingCtx ctx) {
     }
 
     ConstraintsResult cr = prove_zerocheck_and_logup(ts, mpk, ctx);
+    clk.mark("zerocheck + logup");
 
     // prove_openings (cpu_backend.rs:143-222)
     std::vector<bool> need_rot_per_trace;
@@ -1182,7 +1200,9 @@ inline ProveOutput prove(Transcript &ts, const MultiPk &mpk, ProvingCtx ctx) {
         }
         u_cube.insert(u_cube.end(), u_prisma.begin() + 1, u_prisma.end());
     }
+    clk.mark("stacked opening reduction");
     WhirProof whir = prove_whir_opening(ts, params, stacked, u_cube);
+    clk.mark("whir");
 
     proof.common_main_commit = common_commit;
     proof.gkr_proof = cr.gkr;

@@ -177,8 +177,9 @@ int eq_heap_run(const EF *point, const EqHeapPlan &plan, EFPlanes heap, hipStrea
 // fractions at arbitrary plane positions, for the host (n <= 32)
 int gkr_read_list(FracPlanes t, const uint64_t *d_pos, const uint32_t *d_pbase, uint32_t n, const RedOut &ro, hipStream_t s);
 // table records for the host: n0 consecutive ones from plane offset at0, then n1 from at1 (n0 + n1 <= 64), read
-// (fold = false: two fractions per record) or folded by r (four fractions per record)
-int gkr_edge_records(FracPlanes src, uint64_t at0, uint64_t at1, uint32_t n0, uint32_t n1, bool p_base, bool fold, EF r,
+// as they are (folds = 0: two fractions per record), folded by r1 (1: four fractions per record) or folded by r1 and then r2
+// (2: eight fractions per record)
+int gkr_edge_records(FracPlanes src, uint64_t at0, uint64_t at1, uint32_t n0, uint32_t n1, bool p_base, int folds, EF r1, EF r2,
                      const RedOut &ro, hipStream_t s);
 // p_base: leaf numerators are base-field, only limb plane 0 of P is written / read (stages.hip)
 // The leaf kernels of many traces in one launch (staged programs, one row per lane): job j owns
@@ -205,6 +206,16 @@ int gkr_round(FracPlanes rec, bool p_base, EqSplit eq, uint64_t n_pairs, EF lamb
 // fold the previous round with r and return the NEXT round's sums over the n_pairs folded pairs
 int gkr_fold_round(FracPlanes in, bool in_p_base, EqSplit eq, FracPlanes out, uint64_t n_pairs, EF r, EF lambda,
                    uint32_t n_points, const RedOut &ro, hipStream_t s);
+
+// One pass of a layer's sumcheck (stages.hip "two sub-rounds per pass"): table(s) = the `folds`-fold (0, 1, 2; challenges
+// r1 then r2) of the source table `in`, written to `out` when folds > 0; sums of sub-round s at X = 1..n_points into the first
+// n_points results; `lookahead` (n_points = 2 only): six more results = sub-round s+1's sums at (r, X) = (0,1) (0,2) (1,1)
+// (1,2) (2,1) (2,2) for its challenge r still to come. eq_s / eq_n: the weights of sub-round s / s+1 (eq_n, xi_next used with
+// lookahead only; xi_next = the point's entry that separates the two). want0 / want1: pairs (relative to the first, ~0 = none)
+// whose two records are also stored to dump[0..8) / dump[8..16) (host-mapped).
+int gkr_pass(FracPlanes in, bool in_p_base, int folds, EqSplit eq_s, EqSplit eq_n, FracPlanes out, uint64_t n_pairs, EF r1, EF r2,
+             EF lambda, uint32_t n_points, bool lookahead, EF xi_next, uint64_t want0, uint64_t want1, EF *dump, const RedOut &ro,
+             hipStream_t s);
 
 // ---- stacked reduction ----
 // R[v * N + z] for v in {eq, rot1, rot2} over one window of `n_slices` contiguous slices of

@@ -1046,6 +1046,22 @@ struct Prover {
         uint64_t eq_stride = 0;
         std::vector<uint64_t> rbase;  // rbase[sr]: global record index of element 0 of table(sr)'s buffer (sr >= 1)
         std::vector<URange> Rchain;   // Rchain[s] = my records of table(s) of the current layer
+        // Two sub-rounds per pass (stages.hip: gkr_pass_kernel). Not every table(s) is written any more:
+        std::vector<EF> point;        // the current layer's eq point
+        unsigned mat_sr = 0;          // the latest table of the current layer that exists on the device (0 = the tree layer)
+        std::vector<uint8_t> tbuf;    // tbuf[s]: which of rec_a / rec_b holds table(s)
+        std::vector<EF> r_hist;       // r_hist[s] = the challenge that folds table(s) into table(s + 1)
+        struct Lookahead {            // what the pass at sub-round sr - 1 left for sub-round sr
+            bool valid = false;
+            unsigned sr = 0;
+            URange pairs;
+            EF v[3][2];               // S(X; r) at r = 0, 1, 2 (first index) and X = 1, 2
+            unsigned n_src = 0;       // source pairs of table(sr - 1) dumped for sub-round sr's unpaired edge records
+            uint64_t src_pair[2] = {0, 0};
+            GkrRec src[2][2];
+        } la;
+        uint64_t la_hits = 0, la_passes = 0, plain_passes = 0;
+        static constexpr size_t LA_DUMP_SLOT = 1024;  // mailbox slots of the dumped source records (sums: 0.., edges: 8..)
         bool drop_leaves = false;             // ProverConfig::gkr_drop_leaves (and a tree of at least two layers)
         std::function<void()> make_leaves;    // enqueues the leaf kernels into leaves()
 
@@ -1102,7 +1118,7 @@ struct Prover {
         // planes positioned at global fraction i of layer j (i inside my window)
         FracPlanes layer_at(unsigned j, uint64_t i) const { return layer_planes(j).at(i - fb[j]); }
         uint64_t leaf_origin() const { return fb[TR]; }
-        FracPlanes recs(unsigned sr) const { return FracPlanes::make((sr & 1) ? rec_b.p : rec_a.p, wcap); }
+        FracPlanes recs(unsigned sr) const { return FracPlanes::make(tbuf[sr] ? rec_b.p : rec_a.p, wcap); }
 
         // my record ranges of a layer's tables: chain[0] = records of the layer, chain[s + 1] = up(chain[s])
         std::vector<URange> chain_for(unsigned round) const {
@@ -1162,7 +1178,7 @@ struct Prover {
             // (the mailbox reads above have drained the stream: nothing in flight reads them)
             if (drop_leaves) leaf_buf.release();
         }
-        void begin_layer(unsigned round, const std::vector<EF> &point) override {
+        void begin_layer(unsigned round, const std::vector<EF> &pt_in) override {
             if (drop_leaves && round == 1) alloc_round_buffers(TR - 2);
             if (drop_leaves && round + 1 == TR) {
                 // the last layer's sumcheck reads the leaves and nothing above them: the rest of the tree makes room
@@ -1176,6 +1192,11 @@ struct Prover {
             }
             Rchain = chain_for(round);
             hp = heap_plan_for(round);
+            point = pt_in;
+            mat_sr = 0;
+            tbuf.assign(round + 2, 0);
+            r_hist.assign(round + 2, EF::zero());
+            la.valid = false;
             rbase.assign(round + 1, 0);
             for (unsigned sr = 1; sr <= round; sr++) rbase[sr] = (2 * Rchain[sr + 1].lo) & ~uint64_t(31);
             split_m = 0;
@@ -1213,61 +1234,123 @@ struct Prover {
             if (sr == 0) return layer_at(round + 1, 2 * y);
             return recs(sr).at(2 * (y - rbase[sr]));
         }
+        // the weights of sub-round sr's pairs, positioned at global pair y_first
+        EqSplit eq_for(unsigned round, unsigned sr, uint64_t y_first) const {
+            const unsigned d = round - 1 - sr;
+            EqSplit eq{EFPlanes{nullptr, 0}, EFPlanes{nullptr, 0}, EQ_WHOLE, y_first};
+            if (!split_m) {
+                eq.lo = EFPlanes{eq_buf.p + hp.at(d, y_first), eq_stride};
+                return eq;
+            }
+            const unsigned n_hi = round - split_m;
+            if (sr + 1 < split_m) {
+                const unsigned d_lo = split_m - sr - 1;
+                eq.lo = EFPlanes{eq_lo_buf.p + hp_lo.at(d_lo, 0), eq_lo_stride};
+                eq.hi = EFPlanes{eq_hi_buf.p + hp_hi.at(n_hi, 0), eq_hi_stride};
+                eq.lo_bits = d_lo;
+            } else {
+                eq.hi = EFPlanes{eq_hi_buf.p + hp_hi.at(d, 0), eq_hi_stride};
+                eq.lo_bits = 0;
+            }
+            return eq;
+        }
         void subround(unsigned round, unsigned sr, URange pairs, const uint64_t *edge_idx, unsigned n_edges, EF r_prev, EF lambda,
                       unsigned n_points, EF *S, GkrRec *edges) override {
             hipStream_t st = pr.cx.stream;
-            const bool leaf_layer = p_base && round + 1 == TR;
             const bool have_pairs = !pairs.empty();
+            if (sr > 0) r_hist[sr - 1] = r_prev;
+            // ---- served from the lookahead of the pass before: no launch, no round trip ----
+            if (la.valid && la.sr == sr && have_pairs && pairs.lo == la.pairs.lo && pairs.hi == la.pairs.hi && n_points == 2 && n_edges <= 2) {
+                bool ok = true;
+                for (unsigned k = 0; k < n_edges && ok; k++) {
+                    ok = false;
+                    for (unsigned j = 0; j < la.n_src; j++)
+                        if (la.src_pair[j] == edge_idx[k]) {
+                            edges[k] = rec_fold(la.src[j][0], la.src[j][1], r_prev);
+                            ok = true;
+                        }
+                }
+                if (ok) {
+                    // the quadratic through (0, v0), (1, v1), (2, v2) at r_prev
+                    const EF inv2 = EF::from_base(fp(2).inv());
+                    const EF rm1 = r_prev - EF::one(), rm2 = rm1 - EF::one();
+                    const EF l0 = rm1 * rm2 * inv2, l1 = EF::zero() - r_prev * rm2, l2 = r_prev * rm1 * inv2;
+                    for (int x = 0; x < 2; x++) S[x] = la.v[0][x] * l0 + la.v[1][x] * l1 + la.v[2][x] * l2;
+                    la.valid = false;
+                    la_hits++;
+                    return;
+                }
+            }
+            la.valid = false;
+            // ---- a pass over the latest table that exists: table(sr) is its 0- / 1- / 2-fold ----
+            const unsigned folds = sr - mat_sr;
+            if (folds > 2 || (sr == 0) != (folds == 0)) throw OvmFail(1, "internal: GKR sub-round too far from the last written table");
+            const EF r1 = folds == 2 ? r_hist[sr - 2] : r_prev, r2 = r_prev;
+            const bool src_leaf = p_base && round + 1 == TR && mat_sr == 0;  // the source is the leaf layer (base-field numerators)
+            const unsigned L = round + 1;
             if (n_edges) {
                 // (first: when a sums kernel follows, it is the one that raises the flag)
                 RedOut ro = pr.mb.arm(nullptr, 8);
                 if (have_pairs) ro.flag = nullptr;
-                // record e of table(sr): two fractions of the layer (sr == 0), or the fold by r_prev of records
-                // 2e, 2e+1 of table(sr-1) = four fractions of the layer (sr == 1) / of the previous buffer
-                // split the indices into (at most two) runs of consecutive records
+                // record e of table(sr) = the `folds`-fold of records e 2^folds .. of the source table; the indices are at
+                // most two runs of consecutive records
                 uint32_t n0 = 1;
                 while (n0 < n_edges && edge_idx[n0] == edge_idx[n0 - 1] + 1) n0++;
                 const uint32_t n1 = n_edges - n0;
                 for (uint32_t k = n0 + 1; k < n_edges; k++)
                     if (edge_idx[k] != edge_idx[k - 1] + 1) throw OvmFail(1, "internal: more than two runs of edge records");
-                const unsigned L = round + 1;
-                const FracPlanes base = sr <= 1 ? layer_planes(L) : recs(sr - 1);
+                const FracPlanes base = mat_sr == 0 ? layer_planes(L) : recs(mat_sr);
                 auto at_of = [&](uint64_t e) -> uint64_t {
-                    return sr == 0 ? 2 * e - fb[L] : sr == 1 ? 4 * e - fb[L] : 2 * (2 * e - rbase[sr - 1]);
+                    const uint64_t src_rec = e << folds;  // first source record
+                    return mat_sr == 0 ? 2 * src_rec - fb[L] : 2 * (src_rec - rbase[mat_sr]);
                 };
-                OVM_THROW_IF(gkr_edge_records(base, at_of(edge_idx[0]), n1 ? at_of(edge_idx[n0]) : 0, n0, n1, leaf_layer && sr <= 1, sr != 0,
-                                              r_prev, ro, st));
+                OVM_THROW_IF(gkr_edge_records(base, at_of(edge_idx[0]), n1 ? at_of(edge_idx[n0]) : 0, n0, n1, src_leaf, (int)folds, r1, r2, ro, st));
             }
+            bool use_la = false;
             if (have_pairs) {
                 const uint64_t y0 = pairs.lo, n_pairs = pairs.size();
-                const unsigned d = round - 1 - sr;
-                EqSplit eq{EFPlanes{nullptr, 0}, EFPlanes{nullptr, 0}, EQ_WHOLE, y0};
-                if (!split_m) eq.lo = EFPlanes{eq_buf.p + hp.at(d, y0), eq_stride};
-                if (split_m) {
-                    const unsigned n_hi = round - split_m;
-                    if (sr + 1 < split_m) {
-                        const unsigned d_lo = split_m - sr - 1;
-                        eq.lo = EFPlanes{eq_lo_buf.p + hp_lo.at(d_lo, 0), eq_lo_stride};
-                        eq.hi = EFPlanes{eq_hi_buf.p + hp_hi.at(n_hi, 0), eq_hi_stride};
-                        eq.lo_bits = d_lo;
-                    } else {
-                        eq.lo = EFPlanes{nullptr, 0};
-                        eq.hi = EFPlanes{eq_hi_buf.p + hp_hi.at(d, 0), eq_hi_stride};
-                        eq.lo_bits = 0;
-                    }
+                // lookahead: sub-round sr + 1 must be an ordinary one (it exists, my table is still above the host-tail size
+                // there, two evaluation points) and ask for exactly the pairs the chain predicts
+                use_la = tuning().gkr_lookahead && !tuning().gkr_three_points && n_points == 2 && sr + 1 < round &&
+                         sr + 2 < Rchain.size() && Rchain[sr + 1].lo == pairs.lo && Rchain[sr + 1].hi == pairs.hi &&
+                         Rchain[sr + 1].size() > GKR_HOST_TAIL && !Rchain[sr + 2].empty();
+                uint64_t want[2] = {~0ull, ~0ull};
+                EqSplit eq_n = eq_for(round, sr, y0);
+                if (use_la) {
+                    la.n_src = range_edges(Rchain[sr + 1], la.src_pair);  // sub-round sr + 1's unpaired records = pairs of table(sr)
+                    for (unsigned k = 0; k < la.n_src; k++) want[k] = la.src_pair[k] - y0;
+                    eq_n = eq_for(round, sr + 1, Rchain[sr + 2].lo);
+                    if (Rchain[sr + 2].lo != (y0 + 1) / 2) throw OvmFail(1, "internal: GKR lookahead range mismatch");
                 }
-                if (sr == 0) {
-                    OVM_THROW_IF(gkr_round(table_at(round, 0, 2 * y0), leaf_layer, eq, n_pairs, lambda, n_points, pr.mb.arm(partials.p), st));
-                } else {
-                    // fold sub-round sr-1 with r_prev and get this sub-round's sums in one pass
-                    OVM_THROW_IF(gkr_fold_round(table_at(round, sr - 1, 4 * y0), leaf_layer && sr == 1, eq, table_at(round, sr, 2 * y0), n_pairs,
-                                                r_prev, lambda, n_points, pr.mb.arm(partials.p), st));
+                const FracPlanes in = mat_sr == 0 ? layer_at(L, (2 * y0) << (folds + 1)) : recs(mat_sr).at(2 * (((2 * y0) << folds) - rbase[mat_sr]));
+                FracPlanes out = in;
+                if (folds) {
+                    tbuf[sr] = mat_sr == 0 ? 0 : (uint8_t)(1 - tbuf[mat_sr]);
+                    out = recs(sr).at(2 * (2 * y0 - rbase[sr]));
                 }
+                OVM_THROW_IF(gkr_pass(in, src_leaf, (int)folds, eq_for(round, sr, y0), eq_n, out, n_pairs, r1, r2, lambda, n_points, use_la,
+                                      use_la ? point[sr + 1] : EF::zero(), want[0], want[1], pr.mb.slot_ptr(LA_DUMP_SLOT),
+                                      pr.mb.arm(partials.p), st));
+                (use_la ? la_passes : plain_passes)++;
             }
             pr.mb.wait(st);
             if (have_pairs) {
-                auto v = pr.mb.read(0, n_points);
+                auto v = pr.mb.read(0, use_la ? 8 : n_points);
                 for (unsigned k = 0; k < n_points; k++) S[k] = v[k];
+                if (folds) mat_sr = sr;
+                if (use_la) {
+                    la.valid = true;
+                    la.sr = sr + 1;
+                    la.pairs = Rchain[sr + 2];
+                    for (int j = 0; j < 3; j++)
+                        for (int x = 0; x < 2; x++) la.v[j][x] = v[2 + 2 * j + x];
+                    if (la.n_src) {
+                        auto d = pr.mb.read(LA_DUMP_SLOT, 16);
+                        for (unsigned k = 0; k < la.n_src; k++)
+                            for (int h2 = 0; h2 < 2; h2++)
+                                for (int c = 0; c < 4; c++) la.src[k][h2].v[c] = d[8 * k + 4 * h2 + c];
+                    }
+                }
             }
             if (n_edges) {
                 auto v = pr.mb.read(8, 4 * n_edges);
@@ -1437,7 +1520,11 @@ struct Prover {
         drv.force_three_points = force_three_points;
         drv.observe = [this](const EF &e) { ts.observe_ext(e); };
         drv.sample = [this]() { return ts.sample_ext(); };
-        return drv.run();
+        GkrOutput gout = drv.run();
+        if (tuning().trace)
+            fprintf(stderr, "[ovm] gkr sub-rounds on this rank: %llu passes with lookahead, %llu plain passes, %llu served from a lookahead\n",
+                    (unsigned long long)gd.la_passes, (unsigned long long)gd.plain_passes, (unsigned long long)gd.la_hits);
+        return gout;
     }
 
     // The univariate round of the batch sumcheck, host algebra on a few dozen extension-field elements
@@ -3471,6 +3558,7 @@ Tuning ovm::Tuning::from_env() {
     t.download_kernel = !off("OVM_DOWNLOAD_KERNEL");
     t.early_lde = !off("OVM_EARLY_LDE");
     t.gkr_split_eq = !off("OVM_GKR_SPLIT_EQ");
+    t.gkr_lookahead = !off("OVM_GKR_LOOKAHEAD");
     t.gkr_split_min_round = (uint32_t)std::max(3, num("OVM_GKR_SPLIT_MIN", 14));
     t.staged_forward = !off("OVM_STAGED_FWD");
     t.stacked_tail_device = std::max(0, std::min(2, num("OVM_STACKED_TAIL_DEVICE", 1)));

@@ -2003,14 +2003,49 @@ int gkr_read_list(FracPlanes t, const uint64_t *d_pos, const uint32_t *d_pbase, 
 // starting at plane offset at0, records n0..n0+n1-1 consecutive from at1 (two unpaired edge records, or one
 // run = a rank's whole remaining table). fold == 0: a record is the two fractions there; fold != 0: it is the
 // fold by r of two records = four fractions (the gkr_fold_final of round 1, at any index).
-__global__ void gkr_edge_kernel(FracPlanes src, uint64_t at0, uint64_t at1, uint32_t n0, uint32_t n1, int p_base, int fold, EF r,
-                                RedOut ro) {
+// One fold step on an array of fractions: records (f[4i], f[4i+1]) and (f[4i+2], f[4i+3]) -> record (g[2i], g[2i+1]).
+template <int N>
+__device__ __forceinline__ void fold_fracs(const EF (&f)[N], EF (&g)[N / 2], const EF::Pre &r) {
+#pragma unroll
+    for (int i = 0; i < N / 4; i++) {
+        g[2 * i] = f[4 * i] + (f[4 * i + 2] - f[4 * i]) * r;
+        g[2 * i + 1] = f[4 * i + 1] + (f[4 * i + 3] - f[4 * i + 1]) * r;
+    }
+}
+// folds = 0: a record is the two fractions there; 1: the fold by r1 of two records (four fractions); 2: the fold by r2 of
+// two such folds (eight fractions) -- the table the record belongs to was never written (a sub-round served from the
+// lookahead of the pass before it, see gkr_pass_kernel).
+__global__ void gkr_edge_kernel(FracPlanes src, uint64_t at0, uint64_t at1, uint32_t n0, uint32_t n1, int p_base, int folds, EF r1_in,
+                                EF r2_in, RedOut ro) {
     const uint32_t k = threadIdx.x;
     if (k < n0 + n1) {
-        const uint64_t step = fold ? 4 : 2;
+        const uint64_t step = 2ull << folds;
         const uint64_t at = k < n0 ? at0 + step * k : at1 + step * (k - n0);
         EF *out = ro.out + 4 * k;
-        if (fold) {
+        if (folds == 2) {
+            const EF::Pre r1 = r1_in.pre(), r2 = r2_in.pre();
+            EF f[8], g[4], pq[2][2];
+#pragma unroll
+            for (int isq = 0; isq < 2; isq++) {
+                EF lo[4], hi[4];
+                if (!isq && p_base) {
+                    ldp4_base(src.P(), at, lo);
+                    ldp4_base(src.P(), at + 4, hi);
+                } else {
+                    ldp4(isq ? src.Q() : src.P(), src.stride, at, lo);
+                    ldp4(isq ? src.Q() : src.P(), src.stride, at + 4, hi);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; i++) f[i] = lo[i], f[4 + i] = hi[i];
+                fold_fracs<8>(f, g, r1);
+                fold_fracs<4>(g, pq[isq], r2);
+            }
+            st_ef_sys(out + 0, pq[0][0]);
+            st_ef_sys(out + 1, pq[1][0]);
+            st_ef_sys(out + 2, pq[0][1]);
+            st_ef_sys(out + 3, pq[1][1]);
+        } else if (folds == 1) {
+            const EF r = r1_in;
             EF p[4], q[4];
             if (p_base)
                 ldp4_base(src.P(), at, p);
@@ -2038,10 +2073,10 @@ __global__ void gkr_edge_kernel(FracPlanes src, uint64_t at0, uint64_t at1, uint
     __syncthreads();
     if (k == 0) publish(ro);
 }
-int gkr_edge_records(FracPlanes src, uint64_t at0, uint64_t at1, uint32_t n0, uint32_t n1, bool p_base, bool fold, EF r,
+int gkr_edge_records(FracPlanes src, uint64_t at0, uint64_t at1, uint32_t n0, uint32_t n1, bool p_base, int folds, EF r1, EF r2,
                      const RedOut &ro, hipStream_t s) {
-    if (n0 + n1 == 0 || n0 + n1 > 64) return (int)hipErrorInvalidValue;
-    OVM_LAUNCH(gkr_edge_kernel, dim3(1), dim3(64), 0, s, src, at0, at1, n0, n1, p_base ? 1 : 0, fold ? 1 : 0, r, ro);
+    if (n0 + n1 == 0 || n0 + n1 > 64 || folds < 0 || folds > 2) return (int)hipErrorInvalidValue;
+    OVM_LAUNCH(gkr_edge_kernel, dim3(1), dim3(64), 0, s, src, at0, at1, n0, n1, p_base ? 1 : 0, folds, r1, r2, ro);
     OVM_CHECK_LAUNCH();
     return 0;
 }
@@ -2155,6 +2190,155 @@ int gkr_fold_round(FracPlanes in, bool in_p_base, EqSplit eq, FracPlanes out, ui
 #undef CALL
     OVM_CHECK_LAUNCH();
     return red_finish(ro, grid, grid, n_points, s);
+}
+
+// ---- two sub-rounds per pass ----------------------------------------------------------------------------------------
+// A layer's sumcheck used to make one pass over its table per sub-round: read table(s-1), fold it by r_{s-1} into
+// table(s), sum S_s over the pairs of table(s) -- 4 n records of traffic for a layer of n records and one host round
+// trip per sub-round (189 of them at config D). But S_{s+1} needs nothing the pass at s does not already
+// hold except the challenge r_s, and it is a QUADRATIC in r_s: table(s+1)[j] = T[2j] + r_s (T[2j+1] - T[2j]) is linear
+// in r_s, the pair expression p0 q1 + p1 q0 + lambda q0 q1 bilinear in its records. So the pass at s also sums
+// S_{s+1}(X; r) at r = 0, 1, 2 for X = 1, 2 (LA = "lookahead": six more sums per lane), the host interpolates at the
+// r_s it samples, and sub-round s+1 costs NO pass and NO launch; the pass at s+2 then folds table(s) TWICE (FOLDS = 2:
+// r_s, r_{s+1}) -- table(s+1) is never written. Traffic per layer 2.67 n instead of 4 n, half the round trips. Every
+// identity is exact in the field: the proof bytes do not change (fractional_sumcheck_gkr.rs:121-196 is the protocol;
+// how many of its rounds one sweep over the data serves is this backend's business).
+//
+// Work item of the LA form: pair z of table(s+1) = pairs 2z, 2z+1 of table(s); a pair range that starts or ends on an
+// odd pair leaves one stray pair at either end, which lanes 0 / 1 of the grid take in the plain form. `want`: up to two
+// pairs (relative to the first) whose two records the host will need as the SOURCES of sub-round s+1's unpaired edge
+// records; the lane that makes them stores them to `dump`.
+template <bool PBASE, int FOLDS>
+__device__ __forceinline__ void gkr_load_pair(const FracPlanes &in, uint64_t p, const EF::Pre &r1, const EF::Pre &r2, EF (&fp)[4],
+                                              EF (&fq)[4]) {
+    constexpr int N = 4 << FOLDS;
+    const uint64_t at = (uint64_t)N * p;
+#pragma unroll
+    for (int isq = 0; isq < 2; isq++) {
+        EF f[N];
+        EF(&dst)[4] = isq ? fq : fp;
+#pragma unroll
+        for (int c = 0; c < N / 4; c++) {
+            EF t[4];
+            if (!isq && PBASE)
+                ldp4_base(in.P(), at + 4 * c, t);
+            else
+                ldp4(isq ? in.Q() : in.P(), in.stride, at + 4 * c, t);
+#pragma unroll
+            for (int i = 0; i < 4; i++) f[4 * c + i] = t[i];
+        }
+        if constexpr (FOLDS == 0) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) dst[i] = f[i];
+        } else if constexpr (FOLDS == 1) {
+            fold_fracs<8>(f, dst, r1);
+        } else {
+            EF g[8];
+            fold_fracs<16>(f, g, r1);
+            fold_fracs<8>(g, dst, r2);
+        }
+    }
+}
+template <bool PBASE, int FOLDS, int NP>
+__device__ __forceinline__ void gkr_do_pair(const FracPlanes &in, const FracPlanes &out, uint64_t p, const EF::Pre &r1, const EF::Pre &r2,
+                                            const EF::Pre &lambda, const EF &e, EF (&a)[4], EF (&b)[4], EF *sums, uint64_t want0,
+                                            uint64_t want1, EF *dump) {
+    EF fp[4], fq[4];
+    gkr_load_pair<PBASE, FOLDS>(in, p, r1, r2, fp, fq);
+    if constexpr (FOLDS > 0) {
+        stp4(out.P(), out.stride, 4 * p, fp);
+        stp4(out.Q(), out.stride, 4 * p, fq);
+    }
+    a[0] = fp[0], a[1] = fq[0], a[2] = fp[1], a[3] = fq[1];
+    b[0] = fp[2], b[1] = fq[2], b[2] = fp[3], b[3] = fq[3];
+    if (p == want0 || p == want1) {
+        EF *d = dump + (p == want0 ? 0 : 8);
+#pragma unroll
+        for (int i = 0; i < 4; i++) st_ef_sys(d + i, a[i]), st_ef_sys(d + 4 + i, b[i]);
+        release_to_host();
+    }
+    EF t[4] = {a[0], a[1], a[2], a[3]}, s2[NP];
+#pragma unroll
+    for (int i = 0; i < NP; i++) s2[i] = EF::zero();
+    gkr_pair_sums<NP>(t, b, e, lambda, s2);
+#pragma unroll
+    for (int i = 0; i < NP; i++) sums[i] = sums[i] + s2[i];
+}
+template <bool PBASE, int FOLDS, int NP, bool LA>
+__global__ __launch_bounds__(RED_THREADS) void gkr_pass_kernel(FracPlanes in, EqSplit eq_s, EqSplit eq_n, FracPlanes out, uint64_t n_pairs,
+                                                               EF r1_in, EF r2_in, EF lambda_in, EF xi_in, uint64_t want0, uint64_t want1,
+                                                               EF *dump, RedOut ro) {
+    constexpr int K = LA ? NP + 6 : NP;
+    const uint64_t stride = (uint64_t)gridDim.x * RED_THREADS;
+    const uint64_t gid = (uint64_t)blockIdx.x * RED_THREADS + threadIdx.x;
+    const EF::Pre r1 = r1_in.pre(), r2 = r2_in.pre(), lambda = lambda_in.pre();
+    EF sums[K];
+#pragma unroll
+    for (int i = 0; i < K; i++) sums[i] = EF::zero();
+    EF a[4], b[4];
+    if constexpr (!LA) {
+        for (uint64_t y = gid; y < n_pairs; y += stride)
+            gkr_do_pair<PBASE, FOLDS, NP>(in, out, y, r1, r2, lambda, eq_weight(eq_s, y), a, b, sums, want0, want1, dump);
+    } else {
+        // global pair index of relative pair 0 = eq_s.y_first: odd -> the head pair is a stray
+        const uint64_t skip = eq_s.y_first & 1;
+        const uint64_t n_la = (n_pairs - skip) >> 1;
+        const bool tail = ((n_pairs - skip) & 1) != 0;
+        if (gid == 0 && skip) gkr_do_pair<PBASE, FOLDS, NP>(in, out, 0, r1, r2, lambda, eq_weight(eq_s, 0), a, b, sums, want0, want1, dump);
+        if (gid == 1 && tail)
+            gkr_do_pair<PBASE, FOLDS, NP>(in, out, n_pairs - 1, r1, r2, lambda, eq_weight(eq_s, n_pairs - 1), a, b, sums, want0, want1, dump);
+        const EF::Pre xi = xi_in.pre();
+        for (uint64_t z = gid; z < n_la; z += stride) {
+            const EF en = eq_weight(eq_n, z);
+            const EF e1 = en * xi, e0 = en - e1;  // eq1(xi, 1) = xi, eq1(xi, 0) = 1 - xi
+            EF a1[4], b1[4], a2[4], b2[4];
+            gkr_do_pair<PBASE, FOLDS, NP>(in, out, skip + 2 * z, r1, r2, lambda, e0, a1, b1, sums, want0, want1, dump);
+            gkr_do_pair<PBASE, FOLDS, NP>(in, out, skip + 2 * z + 1, r1, r2, lambda, e1, a2, b2, sums, want0, want1, dump);
+            // table(s+1) records 2z, 2z+1 at r = 0, 1, 2: (a1, a2), (b1, b2), (2 b1 - a1, 2 b2 - a2)
+            EF la0[2] = {EF::zero(), EF::zero()}, la1[2] = {EF::zero(), EF::zero()}, la2[2] = {EF::zero(), EF::zero()};
+            EF u[4], v[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) u[i] = b1[i].dbl() - a1[i], v[i] = b2[i].dbl() - a2[i];
+            gkr_pair_sums<2>(a1, a2, en, lambda, la0);
+            gkr_pair_sums<2>(b1, b2, en, lambda, la1);
+            gkr_pair_sums<2>(u, v, en, lambda, la2);
+            sums[NP + 0] = sums[NP + 0] + la0[0], sums[NP + 1] = sums[NP + 1] + la0[1];
+            sums[NP + 2] = sums[NP + 2] + la1[0], sums[NP + 3] = sums[NP + 3] + la1[1];
+            sums[NP + 4] = sums[NP + 4] + la2[0], sums[NP + 5] = sums[NP + 5] + la2[1];
+        }
+    }
+    block_sum_out<K>(sums, ro, (size_t)blockIdx.x * K);
+    finish_reduction<8>(ro, gridDim.x, K);
+}
+int gkr_pass(FracPlanes in, bool in_p_base, int folds, EqSplit eq_s, EqSplit eq_n, FracPlanes out, uint64_t n_pairs, EF r1, EF r2,
+             EF lambda, uint32_t n_points, bool lookahead, EF xi_next, uint64_t want0, uint64_t want1, EF *dump, const RedOut &ro,
+             hipStream_t s) {
+    if ((n_points != 2 && n_points != 3) || folds < 0 || folds > 2 || (lookahead && n_points != 2) || n_pairs == 0)
+        return (int)hipErrorInvalidValue;
+    const uint32_t K = lookahead ? n_points + 6 : n_points;
+    const uint32_t grid = red_grid(lookahead ? std::max<uint64_t>(n_pairs / 2, 2) : n_pairs);
+#define CALL(PB, F, NP, LA)                                                                                                          \
+    OVM_LAUNCH((gkr_pass_kernel<PB, F, NP, LA>), dim3(grid), dim3(RED_THREADS), 0, s, in, eq_s, eq_n, out, n_pairs, r1, r2, lambda, \
+               xi_next, want0, want1, dump, red_inline(ro, grid, K))
+#define CALL_F(PB, NP, LA)                  \
+    do {                                    \
+        if (folds == 0) CALL(PB, 0, NP, LA); \
+        else if (folds == 1) CALL(PB, 1, NP, LA); \
+        else CALL(PB, 2, NP, LA);           \
+    } while (0)
+    if (in_p_base) {
+        if (lookahead) CALL_F(true, 2, true);
+        else if (n_points == 2) CALL_F(true, 2, false);
+        else CALL_F(true, 3, false);
+    } else {
+        if (lookahead) CALL_F(false, 2, true);
+        else if (n_points == 2) CALL_F(false, 2, false);
+        else CALL_F(false, 3, false);
+    }
+#undef CALL_F
+#undef CALL
+    OVM_CHECK_LAUNCH();
+    return red_finish(ro, grid, grid, K, s);
 }
 
 // ---- stacked reduction -----------------------------------------------------------------------

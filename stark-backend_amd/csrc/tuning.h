@@ -41,6 +41,9 @@ struct Tuning {
     bool staged_forward = true;    // OVM_STAGED_FWD=0: the staged VM reads every operand from LDS and stores every result
     bool gkr_split_eq = true;      // OVM_GKR_SPLIT_EQ=0: every GKR layer builds and reads its whole eq table
     uint32_t gkr_split_min_round = 14;  // OVM_GKR_SPLIT_MIN: layers of at least 2^this records use split tables (>= 3; parity tests lower it)
+    // OVM_GKR_LOOKAHEAD=0: one pass over a layer's table per sumcheck sub-round (rounds 1-3). Default: a pass also sums the NEXT
+    // sub-round as a quadratic in its challenge, so every second sub-round costs no pass and no launch (stages.hip).
+    bool gkr_lookahead = true;
     bool lazy_w_accumulate = true;  // OVM_LAZY_W=0: whir_w_accumulate reduces every product (the parity tests compare the two)
     bool download_kernel = true;   // OVM_DOWNLOAD_KERNEL=0: small downloads through the runtime's copy + stream synchronisation
     bool trace = false;            // OVM_TRACE: wall-clock trace of the stages on stderr

@@ -122,6 +122,28 @@ def test_gkr_three_point_fallback(dev, pkg, orc, monkeypatch):
     run_case(dev, pkg, orc, params, [airs.uniform_runner_air(20)], [(0, tr, h, [])])
 
 
+@pytest.mark.parametrize("lookahead", ["0", "1"])
+def test_gkr_passes_with_and_without_lookahead(dev, pkg, orc, monkeypatch, lookahead):
+    """Round 4: a pass over a GKR layer's table also sums the NEXT sub-round as a quadratic in its challenge, so every
+    second sub-round is served without a launch and the pass after it folds twice (stages.hip: gkr_pass_kernel).
+    OVM_GKR_LOOKAHEAD=0 is one pass per sub-round as in rounds 1-3. Both must give the oracle's bytes -- on a tall
+    single AIR (base-field leaf numerators, split eq tables from 2^3 records), on mixed heights with a padding run that
+    starts on an odd pair, and with the three-point fallback (which turns the lookahead off by itself)."""
+    monkeypatch.setenv("OVM_GKR_LOOKAHEAD", lookahead)
+    monkeypatch.setenv("OVM_GKR_SPLIT_MIN", "3")
+    params = airs.test_params(l_skip=4, n_stack=10, k_whir=4)
+    h = 1 << 12
+    run_case(dev, pkg, orc, params, [airs.uniform_runner_air(24)], [(0, airs.splitmix64_bits(0xA11CE, 24 * h), h, [])])
+    monkeypatch.delenv("OVM_GKR_SPLIT_MIN")
+    bench, wide = airs.uniform_runner_air(8), airs.uniform_runner_air(20)
+    t1, pv = airs.fibonacci_trace(0, 1, 16)
+    run_case(dev, pkg, orc, airs.test_params(l_skip=2, n_stack=9, k_whir=2), [airs.fibonacci_air(), bench, wide, bench],
+             [(0, t1, 16, pv), (1, airs.splitmix64_bits(1, 8 * 512), 512, []), (2, airs.splitmix64_bits(2, 20 * 256), 256, []),
+              (3, airs.splitmix64_bits(3, 8 * 2), 2, [])])
+    monkeypatch.setenv("OVM_GKR_THREE_POINTS", "1")
+    run_case(dev, pkg, orc, params, [airs.uniform_runner_air(24)], [(0, airs.splitmix64_bits(0xA11CE, 24 * h), h, [])])
+
+
 def sponge_before_openings(pkg, orc, raw):
     import ctypes
     s = pkg.SpongeState()

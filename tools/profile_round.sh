@@ -28,4 +28,6 @@ rocprofv3 --pmc SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_W
 SA=$(find "$OUT/sqa" -name "*_results.db" | head -1)
 SB=$(find "$OUT/sqb" -name "*_results.db" | head -1)
 python3 tools/rocpd_sq.py "$SA" "$SB" --json "$OUT/sq_valu.json" > "$OUT/sq_counters.txt" 2>&1
+# the raw rocpd databases are tens of MB each and gpurun brings back at most 64 MiB: keep the summaries only
+[ "${KEEP_RAW:-0}" = 1 ] || rm -rf "$OUT/kt" "$OUT/fetch" "$OUT/write" "$OUT/sqa" "$OUT/sqb"
 ls -la "$OUT"
