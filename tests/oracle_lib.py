@@ -167,7 +167,7 @@ def _prove(self, blob, traces, proof_cap=1 << 26):
     arrs = [np.ascontiguousarray(t[1], dtype=np.uint32) for t in traces]
     # small cases: a handful of threads (a 256-thread team per tiny loop costs more than the loop)
     cells = sum(a.size for a in arrs) + sum(np.size(t[4]) for t in traces if len(t) > 4 and t[4] is not None)
-    lib.orc_set_num_threads(c_int(8 if cells < (1 << 22) else 0))
+    lib.orc_set_num_threads(c_int(int(os.environ.get("ORC_THREADS", "0")) or (8 if cells < (1 << 22) else 0)))
     pvs = [np.ascontiguousarray(t[3], dtype=np.uint32) if len(t[3]) else np.zeros(1, np.uint32) for t in traces]
     air_idx = np.array([t[0] for t in traces], dtype=np.uint32)
     heights = np.array([t[2] for t in traces], dtype=np.uint64)
