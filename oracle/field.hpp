@@ -11,6 +11,7 @@
 //   crates/cuda-common/include/fpext.h:28-44   EF = F[X]/(X^4 - 11), basis 1,X,X^2,X^3
 //   p3-baby-bear =0.4.3 (absent from the tree): multiplicative generator GENERATOR = 31
 #pragma once
+#include <algorithm>
 #include <array>
 #include <cassert>
 #include <cstdint>
@@ -211,10 +212,34 @@ inline EF operator*(Fp a, const EF &b) { return b * a; }
 template <class T>
 inline std::vector<T> powers(T base, size_t n) {
     std::vector<T> out(n);
+    constexpr size_t BLOCK = size_t(1) << 12;
+    if (n < 16 * BLOCK) {
+        T cur = T::one();
+        for (size_t i = 0; i < n; i++) {
+            out[i] = cur;
+            cur = cur * base;
+        }
+        return out;
+    }
+    // long tables (the twiddles of a 2^25-point transform): the first entry of every block serially, the blocks in
+    // parallel -- exact arithmetic, so the entries are the same field elements
+    T step = T::one();
+    for (size_t i = 0; i < BLOCK; i++) step = step * base;
+    const size_t n_blocks = (n + BLOCK - 1) / BLOCK;
+    std::vector<T> first(n_blocks);
     T cur = T::one();
-    for (size_t i = 0; i < n; i++) {
-        out[i] = cur;
-        cur = cur * base;
+    for (size_t b = 0; b < n_blocks; b++) {
+        first[b] = cur;
+        cur = cur * step;
+    }
+#pragma omp parallel for schedule(static)
+    for (size_t b = 0; b < n_blocks; b++) {
+        T c = first[b];
+        const size_t hi = std::min(n, (b + 1) * BLOCK);
+        for (size_t i = b * BLOCK; i < hi; i++) {
+            out[i] = c;
+            c = c * base;
+        }
     }
     return out;
 }

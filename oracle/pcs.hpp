@@ -10,6 +10,7 @@
 //   crates/stark-backend/src/prover/stacked_pcs.rs:413-485   MerkleTree::new (strided first layers)
 //   crates/stark-backend/src/prover/stacked_pcs.rs:516-540   get_opened_rows
 #pragma once
+#include <omp.h>
 #include <stdexcept>
 
 #include "poly.hpp"
@@ -122,7 +123,10 @@ inline std::pair<ColMat<Fp>, StackedLayout> stacked_matrix(
 inline ColMat<Fp> rs_code_matrix(unsigned l_skip, unsigned log_blowup, const ColMat<Fp> &evals) {
     size_t height = evals.height, rs_height = height << log_blowup;
     std::vector<Fp> out(rs_height * evals.width);
-#pragma omp parallel for schedule(dynamic)
+    // many columns: one thread per column; FEW TALL columns (config D: 25 of 2^25 points on 256 cores): column after column,
+    // each transform spread over the cores (poly.hpp: dft_generic)
+    const bool by_column = evals.width >= (size_t)omp_get_max_threads() || rs_height < (size_t(1) << 16);
+#pragma omp parallel for schedule(dynamic) if (by_column)
     for (size_t j = 0; j < evals.width; j++) {
         std::vector<Fp> coeffs = eval_to_coeff_rs_message(l_skip, evals.column(j), height);
         coeffs.resize(rs_height, Fp::zero());

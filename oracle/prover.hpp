@@ -164,6 +164,7 @@ inline ColMat<EF> fold_mle_evals(const ColMat<EF> &mat, EF r) {
     size_t h2 = mat.height / 2;
     std::vector<EF> vals(mat.width * h2);
     for (size_t c = 0; c < mat.width; c++)
+#pragma omp parallel for schedule(static) if (h2 >= 4096)
         for (size_t y = 0; y < h2; y++) {
             EF t0 = mat.at(2 * y, c), t1 = mat.at(2 * y + 1, c);
             vals[c * h2 + y] = t0 + (t1 - t0) * r;
@@ -197,8 +198,13 @@ inline std::pair<FracSumcheckProof, std::vector<EF>> fractional_sumcheck(Transcr
     unsigned total_rounds = log2_strict(evals.size());
     std::vector<Frac> tree(size_t(2) << total_rounds);
     std::copy(evals.begin(), evals.end(), tree.begin() + (size_t(1) << total_rounds));
-    for (size_t i = (size_t(1) << total_rounds) - 1; i >= 1; i--)
-        tree[i] = frac_add(tree[2 * i], tree[2 * i + 1]);
+    // (layer by layer, each layer in parallel: the same sums as the reference's single descending loop,
+    // fractional_sumcheck_gkr.rs:80-86 -- a node only reads its two children)
+    for (unsigned j = total_rounds; j-- > 0;) {
+        const size_t lo = size_t(1) << j;
+#pragma omp parallel for schedule(static) if (lo >= 4096)
+        for (size_t i = lo; i < 2 * lo; i++) tree[i] = frac_add(tree[2 * i], tree[2 * i + 1]);
+    }
     Frac sum = tree[1];
     if (assert_zero) {
         if (!sum.p.is_zero()) throw std::runtime_error("NonZeroRootSum");
@@ -223,6 +229,7 @@ inline std::pair<FracSumcheckProof, std::vector<EF>> fractional_sumcheck(Transcr
         EF lambda = ts.sample_ext();
         std::vector<EF> pq(4 * eval_size);
         const Frac *seg = &tree[2 * eval_size];
+#pragma omp parallel for schedule(static) if (eval_size >= 4096)
         for (size_t x = 0; x < eval_size; x++) {
             pq[x] = seg[2 * x].p;
             pq[eval_size + x] = seg[2 * x].q;
@@ -379,12 +386,14 @@ inline ConstraintsResult prove_zerocheck_and_logup(Transcript &ts, const MultiPk
             size_t height = pq.size(), len = sc.slice.len(0);
             Fp norm = Fp((uint64_t)(len / height)).inv();
             for (size_t off = 0; off < len; off += height)
+#pragma omp parallel for schedule(static) if (height >= 4096)
                 for (size_t i = 0; i < height; i++) {
                     auto [numer, denom] = pq[i][sc.col_idx];
                     gkr_input[sc.slice.row_idx + off + i] = Frac{EF(numer * norm), denom};
                 }
         }
-        for (auto &f : gkr_input) f.q += alpha_logup;
+#pragma omp parallel for schedule(static) if (gkr_input.size() >= 4096)
+        for (size_t i = 0; i < gkr_input.size(); i++) gkr_input[i].q += alpha_logup;
     }
     auto [frac_proof, xi] = fractional_sumcheck(ts, gkr_input, true);
     gkr_input.clear();
@@ -988,6 +997,7 @@ inline WhirProof prove_whir_opening(Transcript &ts, const SystemParams &params,
             for (size_t c = 0; c < d->matrix.width; c++, j++) {
                 std::vector<Fp> x = eval_to_coeff_rs_message(l_skip, d->matrix.column(c), height);
                 mle_coeffs_to_evals_inplace(x.data(), x.size());
+#pragma omp parallel for schedule(static) if (height >= 4096)
                 for (size_t i = 0; i < height; i++) f_evals[i] += mu_powers[j] * x[i];
             }
     }
@@ -1004,10 +1014,18 @@ inline WhirProof prove_whir_opening(Transcript &ts, const SystemParams &params,
             for (unsigned xi = 1; xi <= 2; xi++) {
                 Fp x = Fp((uint64_t)xi);
                 EF acc = EF::zero();
-                for (size_t y = 0; y < half; y++) {
-                    EF f0 = f_evals[2 * y], f1 = f_evals[2 * y + 1];
-                    EF w0 = w_evals[2 * y], w1 = w_evals[2 * y + 1];
-                    acc += (f0 + (f1 - f0) * x) * (w0 + (w1 - w0) * x);
+                // (per-thread partial sums: field addition is exact, the order of the terms does not matter)
+#pragma omp parallel if (half >= 4096)
+                {
+                    EF local = EF::zero();
+#pragma omp for schedule(static) nowait
+                    for (size_t y = 0; y < half; y++) {
+                        EF f0 = f_evals[2 * y], f1 = f_evals[2 * y + 1];
+                        EF w0 = w_evals[2 * y], w1 = w_evals[2 * y + 1];
+                        local += (f0 + (f1 - f0) * x) * (w0 + (w1 - w0) * x);
+                    }
+#pragma omp critical
+                    acc += local;
                 }
                 s_evals[xi - 1] = acc;
             }
@@ -1015,15 +1033,20 @@ inline WhirProof prove_whir_opening(Transcript &ts, const SystemParams &params,
             proof.whir_sumcheck_polys.push_back(s_evals);
             proof.folding_pow_witnesses.push_back(ts.grind(params.folding_pow_bits));
             EF alpha = ts.sample_ext();
-            for (size_t y = 0; y < half; y++) {
-                EF e0 = f_evals[2 * y], e1 = f_evals[2 * y + 1];
-                f_evals[y] = e0 + alpha * (e1 - e0);
-                e0 = w_evals[2 * y];
-                e1 = w_evals[2 * y + 1];
-                w_evals[y] = e0 + alpha * (e1 - e0);
+            {
+                // (out of place: a parallel in-place fold would let iteration y overwrite what iteration y / 2 still reads)
+                std::vector<EF> f2(half), w2(half);
+#pragma omp parallel for schedule(static) if (half >= 4096)
+                for (size_t y = 0; y < half; y++) {
+                    EF e0 = f_evals[2 * y], e1 = f_evals[2 * y + 1];
+                    f2[y] = e0 + alpha * (e1 - e0);
+                    e0 = w_evals[2 * y];
+                    e1 = w_evals[2 * y + 1];
+                    w2[y] = e0 + alpha * (e1 - e0);
+                }
+                f_evals = std::move(f2);
+                w_evals = std::move(w2);
             }
-            f_evals.resize(half);
-            w_evals.resize(half);
         }
         std::vector<EF> g_coeffs = f_evals;
         mle_evals_to_coeffs_inplace(g_coeffs.data(), g_coeffs.size());

@@ -1085,7 +1085,7 @@ struct Prover {
             leaf_stride = std::max<uint64_t>(lr.empty() ? 0 : up64(lr.hi - fb[TR]), 64) + PLANE_SKEW;
             alloc_leaves();
             drop_leaves = prover_config().gkr_drop_leaves && TR >= 3;
-            partials.alloc(RED_BLOCKS * 4);
+            partials.alloc(RED_BLOCKS * 8);  // (a pass with lookahead leaves 2 + 6 sums per workgroup)
             // (memory-bounded mode: the sumcheck buffers come when the build is over, sized for the layers above the
             // leaves, and again -- with the tree gone -- for the leaf layer: begin_layer)
             if (!drop_leaves) alloc_round_buffers(TR >= 1 ? TR - 1 : 0);
@@ -1313,7 +1313,8 @@ struct Prover {
                 // there, two evaluation points) and ask for exactly the pairs the chain predicts
                 use_la = tuning().gkr_lookahead && !tuning().gkr_three_points && n_points == 2 && sr + 1 < round &&
                          sr + 2 < Rchain.size() && Rchain[sr + 1].lo == pairs.lo && Rchain[sr + 1].hi == pairs.hi &&
-                         Rchain[sr + 1].size() > GKR_HOST_TAIL && !Rchain[sr + 2].empty();
+                         Rchain[sr + 1].size() > GKR_HOST_TAIL && !Rchain[sr + 2].empty() &&
+                         n_pairs <= (uint64_t(1) << std::min(tuning().gkr_la_max_log, 40u));
                 uint64_t want[2] = {~0ull, ~0ull};
                 EqSplit eq_n = eq_for(round, sr, y0);
                 if (use_la) {
@@ -3530,6 +3531,13 @@ using namespace ovm;
 
 static thread_local std::string g_last_error;
 
+bool ovm::Tuning::live() {
+    static const bool on = [] {
+        const char *e = getenv("OVM_TUNING_LIVE");
+        return e && *e && *e != '0';
+    }();
+    return on;
+}
 Tuning ovm::Tuning::from_env() {
     Tuning t;
     auto num = [](const char *name, int dflt) {
@@ -3558,7 +3566,9 @@ Tuning ovm::Tuning::from_env() {
     t.download_kernel = !off("OVM_DOWNLOAD_KERNEL");
     t.early_lde = !off("OVM_EARLY_LDE");
     t.gkr_split_eq = !off("OVM_GKR_SPLIT_EQ");
-    t.gkr_lookahead = !off("OVM_GKR_LOOKAHEAD");
+    t.gkr_lookahead = num("OVM_GKR_LOOKAHEAD", 0) != 0;
+    t.poseidon_lds_kib = (uint32_t)std::min(64, std::max(0, num("OVM_POSEIDON_LDS_KIB", 0)));
+    t.gkr_la_max_log = (uint32_t)std::max(0, num("OVM_GKR_LA_MAX_LOG", 17));
     t.gkr_split_min_round = (uint32_t)std::max(3, num("OVM_GKR_SPLIT_MIN", 14));
     t.staged_forward = !off("OVM_STAGED_FWD");
     t.stacked_tail_device = std::max(0, std::min(2, num("OVM_STACKED_TAIL_DEVICE", 1)));
@@ -3625,7 +3635,7 @@ void sponge_out(const Prover &pr, ovm_sponge_t *sponge) {
 template <class F>
 int guarded(F &&f, bool needs_device = true) {
     try {
-        Tuning::refresh();  // the environment overrides are read here, once per call, and nowhere else
+        Tuning::refresh();  // (test processes only, OVM_TUNING_LIVE=1: the overrides are re-read here, once per call, and nowhere else)
         if (needs_device && !twiddles()) return (int)hipErrorInitializationError;
         const int rc = f();
         flush_uploads(nullptr);  // (nothing staged is left behind for a later call to trip over)

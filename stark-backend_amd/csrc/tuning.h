@@ -41,15 +41,34 @@ struct Tuning {
     bool staged_forward = true;    // OVM_STAGED_FWD=0: the staged VM reads every operand from LDS and stores every result
     bool gkr_split_eq = true;      // OVM_GKR_SPLIT_EQ=0: every GKR layer builds and reads its whole eq table
     uint32_t gkr_split_min_round = 14;  // OVM_GKR_SPLIT_MIN: layers of at least 2^this records use split tables (>= 3; parity tests lower it)
-    // OVM_GKR_LOOKAHEAD=0: one pass over a layer's table per sumcheck sub-round (rounds 1-3). Default: a pass also sums the NEXT
-    // sub-round as a quadratic in its challenge, so every second sub-round costs no pass and no launch (stages.hip).
-    bool gkr_lookahead = true;
+    // OVM_GKR_LOOKAHEAD=1: a pass over a GKR layer's table also sums the NEXT sub-round as a quadratic in its challenge, so
+    // every second sub-round costs no pass and no launch (stages.hip: gkr_pass_kernel). Built and byte-exact in round 4, and
+    // OFF by default: measured no faster at any size limit (profiles/r04/gkr_lookahead_sweep/).
+    bool gkr_lookahead = false;
+    // OVM_GKR_LA_MAX_LOG: only passes over at most 2^this pairs carry a lookahead. The six extra sums make a pass over a BIG
+    // table ALU-bound (2.6x the extension-field products) and its double fold reads 256 B per lane and plane (3.2x the HBM
+    // fetch, measured: profiles/r04/gkr_lookahead_all_layers_*.txt): +2.7 ms of kernel time at config D for 100 round trips
+    // saved. The SMALL sub-rounds are the latency-bound ones -- a table that sits in L2, a kernel of a few microseconds -- and
+    // there the saved launch + mailbox round trip is all gain.
+    uint32_t gkr_la_max_log = 17;
+    // OVM_POSEIDON_LDS_KIB: LDS every workgroup of the Poseidon2 kernels (row hash, compress layers) claims without using it,
+    // i.e. a cap on their resident waves: 160 / this workgroups per CU = waves per SIMD. These kernels are VALU-issue bound
+    // and two waves per SIMD already saturate the issue port, so fewer resident waves cost them nothing -- and
+    // leave wave slots to the memory-bound kernels of ANOTHER prover thread (the reference's throughput mode: K engines on one
+    // GPU, bench.py --engines). 0 = no cap (8 waves per SIMD).
+    uint32_t poseidon_lds_kib = 0;
     bool lazy_w_accumulate = true;  // OVM_LAZY_W=0: whir_w_accumulate reduces every product (the parity tests compare the two)
     bool download_kernel = true;   // OVM_DOWNLOAD_KERNEL=0: small downloads through the runtime's copy + stream synchronisation
     bool trace = false;            // OVM_TRACE: wall-clock trace of the stages on stderr
     int test_fail_rank = -1;       // OVM_TEST_FAIL_RANK: this rank of a sharded proof throws after its commitment (tests)
     static Tuning from_env();
-    static void refresh() { current() = from_env(); }
+    // The environment is read ONCE per thread (first use). Test processes set OVM_TUNING_LIVE=1 (tests/conftest.py, the
+    // fuzzers): then every prover entry re-reads it, so a test can switch a knob between two proofs. Production callers
+    // never pay for ~40 getenv calls per proof, and a knob exported by accident after start-up changes nothing mid-run.
+    static bool live();
+    static void refresh() {
+        if (live()) current() = from_env();
+    }
     static Tuning &current() {
         static thread_local Tuning t = from_env();
         return t;

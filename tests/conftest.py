@@ -5,6 +5,9 @@ import sys
 
 import pytest
 
+# the library reads its OVM_* test hooks once per thread; tests switch them between proofs of one process (csrc/tuning.h)
+os.environ.setdefault("OVM_TUNING_LIVE", "1")
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 

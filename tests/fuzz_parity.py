@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--max-width", type=int, default=20)
     args = ap.parse_args()
     os.environ["ORC_SKIP_DEBUG_ASSERTS"] = "1"
+    os.environ["OVM_TUNING_LIVE"] = "1"  # (the knobs drawn per case are re-read at every prover entry)
     import importlib
     import airs
     import oracle_lib
@@ -36,7 +37,7 @@ def main():
              "OVM_GKR_THREE_POINTS": ["", "", "1"], "OVM_MERKLE_COOP": ["", "0"], "OVM_LAZY_W": ["", "0"],
              "OVM_EARLY_LDE": ["", "", "0"], "OVM_MLE_BATCH_LDS_MIN_LOG": ["", "1", "3", "31"],
              "OVM_STACKED_TAIL_DEVICE": ["", "0", "2", "2"], "OVM_STAGED_FWD": ["", "", "0"], "OVM_GKR_SPLIT_MIN": ["", "3", "4", "7"],
-             "OVM_GKR_SPLIT_EQ": ["", "", "0"], "OVM_GKR_LOOKAHEAD": ["", "", "0"]}
+             "OVM_GKR_SPLIT_EQ": ["", "", "0"], "OVM_GKR_LOOKAHEAD": ["", "1", "1"], "OVM_GKR_LA_MAX_LOG": ["", "4", "40"]}
     bad = 0
     with_absent = 0
     for case in range(args.cases):

@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--seed", type=int, default=1)
     args = ap.parse_args()
     os.environ["ORC_SKIP_DEBUG_ASSERTS"] = "1"
+    os.environ["OVM_TUNING_LIVE"] = "1"  # (the knobs drawn per case are re-read at every prover entry)
     import airs
     import oracle_lib
     import shard_cases
