@@ -25,14 +25,21 @@ inline void bit_reverse_inplace(std::vector<T> &a) {
     // (a LARGE transform called from serial code spreads over the cores itself: the BASELINE-size commitments are 25 columns
     // of 2^25 points on a 256-core host, and one thread per column left 90 % of the machine idle. Same arithmetic, same order
     // within every butterfly: results are bit-identical.)
-    const bool par = n >= (size_t(1) << 16) && !omp_in_parallel();
-#pragma omp parallel for schedule(static) if (par)
-    for (size_t i = 0; i < n; i++) {
+    // (an `if` CLAUSE on the pragma still enters the OpenMP runtime for a team of one -- a fraction of a microsecond that the
+    // 16-point transforms of eval_to_coeff pay a hundred million times at config D: 130 s of oracle time became 460 s on the
+    // 256-core host. Small sizes take a plain loop, no pragma in sight.)
+    auto body = [&](size_t i) {
         size_t j = 0;
         for (unsigned b = 0; b < lg; b++)
             if (i >> b & 1) j |= size_t(1) << (lg - 1 - b);
         if (i < j) std::swap(a[i], a[j]);  // (each unordered pair {i, j} is touched by the iteration i < j only)
+    };
+    if (n < (size_t(1) << 16) || omp_in_parallel()) {
+        for (size_t i = 0; i < n; i++) body(i);
+        return;
     }
+#pragma omp parallel for schedule(static)
+    for (size_t i = 0; i < n; i++) body(i);
 }
 
 // out[k] = sum_i a[i] * w^{ik}, w = two_adic_generator(log n) (or its inverse), natural order.
@@ -49,8 +56,18 @@ inline std::vector<T> dft_generic(std::vector<T> a, bool inverse) {
         size_t m = size_t(1) << s, h = m >> 1;
         Fp wm = w.exp_power_of_2(lg - s);
         std::vector<Fp> tw = powers(wm, h);
+        if (!par) {
+            for (size_t k = 0; k < n; k += m)
+                for (size_t j = 0; j < h; j++) {
+                    T t = a[k + j + h] * tw[j];
+                    T u = a[k + j];
+                    a[k + j] = u + t;
+                    a[k + j + h] = u - t;
+                }
+            continue;
+        }
         // n / 2 independent butterflies per stage: butterfly b = (block b / h, offset b % h)
-#pragma omp parallel for schedule(static) if (par)
+#pragma omp parallel for schedule(static)
         for (size_t b = 0; b < n / 2; b++) {
             const size_t k = (b / h) * m, j = b % h;
             T t = a[k + j + h] * tw[j];
@@ -61,8 +78,12 @@ inline std::vector<T> dft_generic(std::vector<T> a, bool inverse) {
     }
     if (inverse) {
         Fp ninv = Fp((uint64_t)n).inv();
-#pragma omp parallel for schedule(static) if (par)
-        for (size_t i = 0; i < n; i++) a[i] = a[i] * ninv;
+        if (!par) {
+            for (auto &x : a) x = x * ninv;
+        } else {
+#pragma omp parallel for schedule(static)
+            for (size_t i = 0; i < n; i++) a[i] = a[i] * ninv;
+        }
     }
     return a;
 }
@@ -91,8 +112,13 @@ inline void mle_evals_to_coeffs_inplace(T *a, size_t len) {
     unsigned n = log2_strict(len);
     for (unsigned ls = 0; ls < n; ls++) {
         size_t step = size_t(1) << ls, span = step << 1;
+        if (len < (size_t(1) << 16) || omp_in_parallel()) {
+            for (size_t i = 0; i < len; i += span)
+                for (size_t j = 0; j < step; j++) a[i + j + step] = a[i + j + step] - a[i + j];
+            continue;
+        }
         // len / 2 independent updates per level: update u = (block u / step, offset u % step)
-#pragma omp parallel for schedule(static) if (len >= (size_t(1) << 16) && !omp_in_parallel())
+#pragma omp parallel for schedule(static)
         for (size_t u = 0; u < len / 2; u++) {
             const size_t i = (u / step) * span, j = u % step;
             a[i + j + step] = a[i + j + step] - a[i + j];
@@ -105,8 +131,13 @@ inline void mle_coeffs_to_evals_inplace(T *a, size_t len) {
     unsigned n = log2_strict(len);
     for (unsigned b = 0; b < n; b++) {
         size_t step = size_t(1) << b, span = step << 1;
+        if (len < (size_t(1) << 16) || omp_in_parallel()) {
+            for (size_t i = 0; i < len; i += span)
+                for (size_t j = 0; j < step; j++) a[i + j + step] = a[i + j + step] + a[i + j];
+            continue;
+        }
         // len / 2 independent updates per level: update u = (block u / step, offset u % step)
-#pragma omp parallel for schedule(static) if (len >= (size_t(1) << 16) && !omp_in_parallel())
+#pragma omp parallel for schedule(static)
         for (size_t u = 0; u < len / 2; u++) {
             const size_t i = (u / step) * span, j = u % step;
             a[i + j + step] = a[i + j + step] + a[i + j];
@@ -136,7 +167,15 @@ inline std::vector<T> evals_eq_hypercube(const std::vector<T> &x) {
     out[0] = T::one();
     for (size_t i = 0; i < n; i++) {
         const size_t half = size_t(1) << i;
-#pragma omp parallel for schedule(static) if (half >= 4096 && !omp_in_parallel())
+        if (half < 4096 || omp_in_parallel()) {
+            for (size_t y = 0; y < half; y++) {
+                T lo = out[y];
+                out[y + half] = lo * x[i];
+                out[y] = lo * (T::one() - x[i]);
+            }
+            continue;
+        }
+#pragma omp parallel for schedule(static)
         for (size_t y = 0; y < half; y++) {
             T lo = out[y];
             out[y + half] = lo * x[i];
@@ -153,7 +192,15 @@ inline std::vector<EF> evals_mobius_eq_hypercube(const std::vector<EF> &u) {
     out[0] = EF::one();
     for (size_t i = 0; i < n; i++) {
         EF w0 = EF::one() - u[i].dbl(), w1 = u[i];
-#pragma omp parallel for schedule(static) if ((size_t(1) << i) >= 4096 && !omp_in_parallel())
+        if ((size_t(1) << i) < 4096 || omp_in_parallel()) {
+            for (size_t y = 0; y < (size_t(1) << i); y++) {
+                EF prev = out[y];
+                out[y + (size_t(1) << i)] = prev * w1;
+                out[y] = prev * w0;
+            }
+            continue;
+        }
+#pragma omp parallel for schedule(static)
         for (size_t y = 0; y < (size_t(1) << i); y++) {
             EF prev = out[y];
             out[y + (size_t(1) << i)] = prev * w1;
@@ -277,7 +324,8 @@ inline std::vector<Fp> eval_to_coeff_rs_message(unsigned l_skip, const Fp *evals
     size_t chunk = size_t(1) << l_skip;
     assert(len % chunk == 0);
     std::vector<Fp> buf(len);
-#pragma omp parallel for schedule(static) if (len >= (size_t(1) << 16) && !omp_in_parallel())
+    // (the chunks of ONE tall column over the cores when the caller is serial; inside, every transform is tiny and serial)
+#pragma omp parallel for schedule(static) if (len >= (size_t(1) << 20) && !omp_in_parallel())
     for (size_t off = 0; off < len; off += chunk) {
         std::vector<Fp> c(evals + off, evals + off + chunk);
         c = idft(std::move(c));

@@ -163,12 +163,20 @@ inline ColMat<EF> fold_mle_evals(const ColMat<EF> &mat, EF r) {
     if (mat.height <= 1) return mat;
     size_t h2 = mat.height / 2;
     std::vector<EF> vals(mat.width * h2);
-    for (size_t c = 0; c < mat.width; c++)
-#pragma omp parallel for schedule(static) if (h2 >= 4096)
+    for (size_t c = 0; c < mat.width; c++) {
+        if (h2 < 4096) {
+            for (size_t y = 0; y < h2; y++) {
+                EF t0 = mat.at(2 * y, c), t1 = mat.at(2 * y + 1, c);
+                vals[c * h2 + y] = t0 + (t1 - t0) * r;
+            }
+            continue;
+        }
+#pragma omp parallel for schedule(static)
         for (size_t y = 0; y < h2; y++) {
             EF t0 = mat.at(2 * y, c), t1 = mat.at(2 * y + 1, c);
             vals[c * h2 + y] = t0 + (t1 - t0) * r;
         }
+    }
     return ColMat<EF>(std::move(vals), mat.width);
 }
 

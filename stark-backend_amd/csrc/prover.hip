@@ -1329,9 +1329,16 @@ struct Prover {
                     tbuf[sr] = mat_sr == 0 ? 0 : (uint8_t)(1 - tbuf[mat_sr]);
                     out = recs(sr).at(2 * (2 * y0 - rbase[sr]));
                 }
-                OVM_THROW_IF(gkr_pass(in, src_leaf, (int)folds, eq_for(round, sr, y0), eq_n, out, n_pairs, r1, r2, lambda, n_points, use_la,
-                                      use_la ? point[sr + 1] : EF::zero(), want[0], want[1], pr.mb.slot_ptr(LA_DUMP_SLOT),
-                                      pr.mb.arm(partials.p), st));
+                // (the plain one-fold passes keep the kernels of rounds 1-3: the generic pass kernel measured 0.34 ms per proof
+                // slower in that role -- 4.90 against 4.56 ms over the 189 fold passes of config D, profiles/r04/)
+                if (!use_la && folds == 0)
+                    OVM_THROW_IF(gkr_round(in, src_leaf, eq_for(round, sr, y0), n_pairs, lambda, n_points, pr.mb.arm(partials.p), st));
+                else if (!use_la && folds == 1)
+                    OVM_THROW_IF(gkr_fold_round(in, src_leaf, eq_for(round, sr, y0), out, n_pairs, r1, lambda, n_points, pr.mb.arm(partials.p), st));
+                else
+                    OVM_THROW_IF(gkr_pass(in, src_leaf, (int)folds, eq_for(round, sr, y0), eq_n, out, n_pairs, r1, r2, lambda, n_points, use_la,
+                                          use_la ? point[sr + 1] : EF::zero(), want[0], want[1], pr.mb.slot_ptr(LA_DUMP_SLOT),
+                                          pr.mb.arm(partials.p), st));
                 (use_la ? la_passes : plain_passes)++;
             }
             pr.mb.wait(st);

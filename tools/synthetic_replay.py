@@ -82,7 +82,7 @@ def replay_engines(args, verify):
         blob = airs.pk_blob(params, air_list)
         pk = pkg.ProvingKey(blob)
         traces = [(i, torch.zeros(w << lh, dtype=torch.int32, device="cuda:0"), 1 << lh, []) for i, lh, w in shapes]
-        torch.cuda.synchronize()
+        torch.cuda.current_stream().synchronize()  # (this thread's fills only: a device-wide wait would stall behind the engines)
         work.put((si, blob, pk, traces, sum(w << lh for _, lh, w in shapes), len(air_list)))
     for _ in threads:
         work.put(None)
