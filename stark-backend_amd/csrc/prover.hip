@@ -702,2582 +702,11 @@ struct Prover {
         return a < dk.pre.size() ? dk.pre[a].get() : nullptr;
     }
 
-    // -----------------------------------------------------------------------------------------
-    // Stage 1: commit (TraceCommitter::commit)
-    // -----------------------------------------------------------------------------------------
-    struct MatIn {
-        const Fp *ptr;
-        size_t w, h;
-    };
-    PcsData commit() {
-        std::vector<MatIn> mats;
-        for (size_t t = 0; t < traces.size(); t++) mats.push_back({traces[t].d_trace, air(t).common_main_width, traces[t].height});
-        return commit_mats(mats);
-    }
-    // stacked_commit (stacked_pcs.rs:103-140) of column-major device matrices sorted by height (descending)
-    PcsData commit_mats(const std::vector<MatIn> &mats, bool distributed_tree = false) {
-        const unsigned l_skip = P().l_skip, lh = l_skip + P().n_stack;
-        PcsData d;
-        std::vector<std::pair<size_t, unsigned>> meta;
-        size_t total_cells = 0;
-        for (auto &m : mats) {
-            meta.push_back({m.w, log2_strict(m.h)});
-            total_cells += std::max(m.h, size_t(1) << l_skip) * m.w;
-        }
-        if (mats.size() == 1) {
-            d.mat_ptr = mats[0].ptr;
-            d.mat_w = mats[0].w;
-            d.mat_h = mats[0].h;
-        }
-        d.layout = Layout(l_skip, lh, meta);
-        const size_t H = size_t(1) << lh, width = (total_cells + H - 1) / H;
-        if (width != d.layout.width) throw OvmFail(1, "stacked width mismatch");
-        d.log_height = lh;
-        ProfScope *ps_stack = new ProfScope("commit.stack", cx.stream);
-        // Column-major traces stack by concatenation, so ONE trace that fills the matrix exactly already is
-        // the stacked matrix (config D: 100 columns of 2^22 = 25 columns of 2^24): no copy, the trace is
-        // only ever read. Otherwise: one device copy per trace into a zero-padded buffer.
-        const bool alias = mats.size() == 1 && mats[0].h >= (size_t(1) << l_skip) && mats[0].h * mats[0].w == width * H;
-        if (alias) {
-            d.stacked_view = mats[0].ptr;
-        } else {
-            d.stacked.alloc(width * H);
-            d.stacked_view = d.stacked.p;
-            OVM_THROW_IF(hipMemsetAsync(d.stacked.p, 0, width * H * sizeof(Fp), cx.stream));
-        }
-        std::vector<StackJob> jobs;
-        auto add_job = [&](const Fp *src, Fp *dst, uint64_t n, uint64_t stride) {
-            if (!n) return;
-            StackJob j{src, dst, n, stride, jobs.empty() ? 0u : jobs.back().wg0 + jobs.back().gx, (uint32_t)ceil_div(n, (uint64_t)STACK_WG_ELEMS)};
-            jobs.push_back(j);
-        };
-        for (size_t t = 0; t < mats.size() && !alias; t++) {
-            size_t w = mats[t].w, h = mats[t].h;
-            if (w == 0) continue;
-            const Slice &s0 = d.layout.cols[d.layout.mat_starts[t]].slice;
-            if (s0.log_height >= l_skip) {
-                // the columns of one trace occupy one contiguous range of the stacked buffer
-                add_job(mats[t].ptr, d.stacked.p + s0.col_idx * H + s0.row_idx, (uint64_t)w * h, 1);
-            } else {
-                const size_t stride = s0.stride(l_skip);
-                for (size_t j = 0; j < w; j++) {
-                    const Slice &sl = d.layout.cols[d.layout.mat_starts[t] + j].slice;
-                    add_job(mats[t].ptr + j * h, d.stacked.p + sl.col_idx * H + sl.row_idx, (uint64_t)h, (uint64_t)stride);
-                }
-            }
-        }
-        if (!jobs.empty()) {
-            auto d_jobs = cx.upload(jobs);
-            OVM_LAUNCH(stack_batched_kernel, dim3(jobs.back().wg0 + jobs.back().gx), dim3(256), 0, cx.stream, d_jobs.p,
-                               (uint32_t)jobs.size());
-            OVM_THROW_IF(hipGetLastError());
-        }
-        delete ps_stack;
-        d.msg.alloc(width * H);
-        OVM_THROW_IF(ovm_hip_eval_to_coeff((const uint32_t *)d.stacked_view, (uint32_t *)d.msg.p, width, lh, l_skip, cx.stream));
-        d.log_rows = lh + P().log_blowup;
-        d.k = P().k_whir;
-        d.codeword.alloc(width << d.log_rows);
-        OVM_THROW_IF(ovm_hip_ntt_dif((const uint32_t *)d.msg.p, (uint32_t *)d.codeword.p, width, d.log_rows, lh, cx.stream));
-        build_tree(d, (const uint32_t *)d.codeword.p, width, false, distributed_tree);
-        if (!prover_config().cache_rs_code_matrix) d.codeword.release();  // re-encoded from `msg` when rows are opened
-        return d;
-    }
-
-    // distributed (sharded proving, and only for data every rank holds): the ranks hash a share of the query groups
-    // each and exchange the shares' roots; rank r < dist_n takes the groups g with g mod dist_n == r. In the
-    // bit-reversed layer order of merkle.hip entry p of the layer with dist_n entries covers exactly those groups, so
-    // a share is a tree of its own and the layers above are dist_n - 1 compressions on the host.
-    void build_tree(PcsData &d, const uint32_t *matrix, size_t width, bool ext, bool distributed = false) {
-        uint32_t n = 1;
-        if (distributed && !sh.single()) {
-            while (n * 2 <= sh.world && n * 2 <= (1u << (d.log_rows - d.k))) n *= 2;
-        }
-        if (n == 1) {
-            DevBuf<uint32_t> scratch(std::max<uint64_t>(1, ovm_hip_merkle_scratch_words(d.log_rows, d.k)));
-            d.layers.alloc(ovm_hip_merkle_layers_words(d.log_rows, d.k) / 8);
-            if (ext)
-                OVM_THROW_IF(ovm_hip_merkle_tree_ext(matrix, width, d.log_rows, d.k, scratch.p, (uint32_t *)d.layers.p, cx.stream));
-            else
-                OVM_THROW_IF(ovm_hip_merkle_tree(matrix, width, d.log_rows, d.k, scratch.p, (uint32_t *)d.layers.p, cx.stream));
-            d.root = cx.download(d.layers.p + d.layers.n - 1, 1)[0];
-            return;
-        }
-        d.dist_n = n;
-        d.dist_member = sh.rank < n;
-        d.dist_r = d.dist_member ? sh.rank : 0;
-        const unsigned log_share = d.log_rows - log2_strict(n);
-        p2::Digest mine{};
-        if (d.dist_member) {
-            DevBuf<uint32_t> scratch(std::max<uint64_t>(1, ovm_hip_merkle_scratch_words(log_share, d.k)));
-            d.layers.alloc(ovm_hip_merkle_layers_words(log_share, d.k) / 8);
-            OVM_THROW_IF(merkle_tree_share(matrix, width, log_share, d.k, scratch.p, (uint32_t *)d.layers.p, cx.stream, ext, n, d.dist_r));
-            mine = cx.download(d.layers.p + d.layers.n - 1, 1)[0];
-        }
-        std::vector<p2::Digest> all(sh.world);
-        sh.allgather(&mine, all.data(), sizeof(p2::Digest));
-        d.top.assign(all.begin(), all.begin() + n);
-        for (size_t lo = 0, size = n; size > 1; lo += size, size /= 2)
-            for (size_t o = 0; o < size / 2; o++) d.top.push_back(p2::compress(d.top[lo + o], d.top[lo + o + size / 2]));
-        d.root = d.top.back();
-    }
-
-    // -----------------------------------------------------------------------------------------
-    // Per-trace device view
-    // -----------------------------------------------------------------------------------------
-    struct TraceView {
-        ColumnMap cm;
-        unsigned log_height = 0, log_lifted = 0, n_lift = 0;
-        int n = 0;
-        DevBuf<Fp> sels;
-        DevBuf<ColDesc> cols;
-        DevBuf<int32_t> twins;  // per flat column: index of its rotated view / -2 for the views / -1 (fold_ple)
-        // folded matrices (EF, column-major, all flat columns), ping-pong
-        DevBuf<EF> mats_a, mats_b;
-        bool mats_in_a = true;
-        unsigned cur_log_h = 0;
-        std::vector<EF> final_row;  // once height 1
-    };
-
-    struct ProgDev {
-        Program prog;
-        DevBuf<Instr> code;
-        DevBuf<EF> weights;
-        // round-0 and leaf programs also carry their staged form (program.h: stage_program), one
-        // device buffer: [blocks | accs | code | loads]
-        DevBuf<uint32_t> st_words;
-        DevStaged staged;
-        DevProgram dev() const { return DevProgram{code.p, (uint32_t)prog.code.size(), prog.num_slots, weights.p}; }
-    };
-    // staged: also build the staged form, laid out for the round-0 launch on 2^log_lifted rows with
-    // n_out outputs (log_lifted 0: one row per lane, the leaves kernel). The plain code is then only
-    // uploaded if staging does not fit.
-    ProgDev make_prog(Program p, const std::vector<EF> &weights, bool staged = false, uint32_t log_lifted = 0,
-                      uint32_t n_out = 1) {
-        ProgDev d;
-        d.weights = cx.upload(weights);
-        HostTime ht_all("make_prog");
-        const StagedPlan plan = staged ? round0_staged_plan(log_lifted, n_out, p.num_slots, (uint32_t)p.code.size()) : StagedPlan();
-        if (plan.rows == 0) {
-            d.code = cx.upload(p.code);
-            d.prog = std::move(p);
-            return d;
-        }
-        StagedLayout layout;
-        layout.stage_rows = plan.stage_rows;
-        layout.acc_rows = plan.acc_rows;
-        StagedProgram sp;
-        {
-            HostTime ht("make_prog.stage_program");
-            sp = stage_program(p, weights, layout, tuning().staged_forward);
-            sp.scale_rows(plan.rows);
-        }
-        static_assert(sizeof(StagedBlock) == 32 && sizeof(StagedAcc) == 32 && sizeof(StagedInstr) == 16, "staged layout");
-        const size_t w_blocks = sp.blocks.size() * 8, w_accs = sp.accs.size() * 8, w_code = sp.code.size() * 4;
-        std::vector<uint32_t> words(w_blocks + w_accs + w_code + sp.loads.size());
-        memcpy(words.data(), sp.blocks.data(), w_blocks * 4);
-        memcpy(words.data() + w_blocks, sp.accs.data(), w_accs * 4);
-        memcpy(words.data() + w_blocks + w_accs, sp.code.data(), w_code * 4);
-        memcpy(words.data() + w_blocks + w_accs + w_code, sp.loads.data(), sp.loads.size() * 4);
-        d.st_words = cx.upload(words);
-        const uint32_t *base = d.st_words.p;
-        d.staged = DevStaged{(const StagedBlock *)base, base + w_blocks + w_accs + w_code,
-                             (const StagedInstr *)(base + w_blocks + w_accs), (const StagedAcc *)(base + w_blocks),
-                             (uint32_t)sp.blocks.size(), sp.num_rows, plan.rows, layout.stage_rows};
-        d.prog = std::move(p);
-        return d;
-    }
-
-    // A grouped program (disjoint sets of accumulation roots, the same groups the multilinear rounds use)
-    // with every group staged on its own: round 0 of a LONG program on a SHORT trace runs the groups as
-    // extra workgroups of one job instead of walking thousands of instructions in a few lanes.
-    struct StagedGroups {
-        DevBuf<uint32_t> words;
-        DevBuf<DevStaged> descs;
-        std::vector<DevStaged> host;
-        uint32_t rows = 0, max_num_rows = 0;
-    };
-    // want_groups <= the program's groups: consecutive groups are merged (their codes are self-contained, so
-    // running one after the other in a lane is the sum of their accumulations)
-    std::unique_ptr<StagedGroups> make_staged_groups(const GroupedProgram &gp, const std::vector<EF> &weights,
-                                                     uint32_t log_lifted, uint32_t n_out, size_t want_groups) {
-        const StagedPlan plan = round0_staged_plan(log_lifted, n_out, gp.max_slots);
-        const size_t src_groups = gp.off.size() - 1;
-        const size_t n_groups = std::min(src_groups, want_groups);
-        if (plan.rows == 0 || n_groups < 2) return nullptr;
-        StagedLayout layout;
-        layout.stage_rows = plan.stage_rows;
-        layout.acc_rows = plan.acc_rows;
-        auto sg = std::make_unique<StagedGroups>();
-        sg->rows = plan.rows;
-        std::vector<uint32_t> words;
-        struct Off {
-            size_t blocks, accs, code, loads, n_blocks, num_rows;
-        };
-        std::vector<Off> offs;
-        for (size_t k = 0; k < n_groups; k++) {
-            Program pg;
-            pg.code.assign(gp.code.begin() + gp.off[src_groups * k / n_groups], gp.code.begin() + gp.off[src_groups * (k + 1) / n_groups]);
-            pg.num_slots = gp.max_slots;
-            StagedProgram sp = stage_program(pg, weights, layout, tuning().staged_forward);
-            sp.scale_rows(plan.rows);
-            while (words.size() % 8) words.push_back(0);  // 32-byte alignment of the block / entry arrays
-            const size_t w_blocks = sp.blocks.size() * 8, w_accs = sp.accs.size() * 8, w_code = sp.code.size() * 4;
-            const size_t base = words.size();
-            words.resize(base + w_blocks + w_accs + w_code + sp.loads.size());
-            memcpy(words.data() + base, sp.blocks.data(), w_blocks * 4);
-            memcpy(words.data() + base + w_blocks, sp.accs.data(), w_accs * 4);
-            memcpy(words.data() + base + w_blocks + w_accs, sp.code.data(), w_code * 4);
-            memcpy(words.data() + base + w_blocks + w_accs + w_code, sp.loads.data(), sp.loads.size() * 4);
-            offs.push_back({base, base + w_blocks, base + w_blocks + w_accs, base + w_blocks + w_accs + w_code, sp.blocks.size(),
-                            sp.num_rows});
-            sg->max_num_rows = std::max(sg->max_num_rows, sp.num_rows);
-        }
-        sg->words = cx.upload(words);
-        const uint32_t *b = sg->words.p;
-        for (auto &o : offs)
-            sg->host.push_back(DevStaged{(const StagedBlock *)(b + o.blocks), b + o.loads, (const StagedInstr *)(b + o.code),
-                                         (const StagedAcc *)(b + o.accs), (uint32_t)o.n_blocks, (uint32_t)o.num_rows, plan.rows,
-                                         layout.stage_rows});
-        sg->descs = cx.upload(sg->host);
-        return sg;
-    }
-
-    // host evaluation of a program on one row (tail rounds)
-    static void host_eval(const Program &p, const std::vector<EF> &weights, const std::vector<EF> &row, EF add_const,
-                          EF out[2]) {
-        std::vector<EF> slots(p.num_slots);
-        auto fetch = [&](uint32_t col) { return row[col]; };
-        out[0] = EF::zero();
-        out[1] = add_const;
-        run_program_acc<EF>(p.code.data(), (uint32_t)p.code.size(), weights.data(), slots.data(), fetch, out);
-    }
-
-    // The register programs of every trace (they depend on the key and the public values only, not on
-    // any challenge): in the one-call prove they are compiled on a helper thread while the device
-    // commits the traces -- ~7 ms of host work for a 46-AIR segment that the device used to wait for.
-    // (splitting the roots of the short rounds four times finer -- 64 groups -- was measured slower:
-    // batched kernel 174 -> 210 ms over the 21-segment replay sample; per-workgroup overhead dominates)
-    static constexpr uint32_t MLE_GROUPS = 16;
-    // long programs are split finer: a lane's walk through its group is what a short round takes, and a
-    // 10 K-instruction program in 16 groups is 600 instructions per lane (OVM_MLE_GROUPS_MAX caps it)
-    static constexpr uint32_t MLE_GROUP_INSTRS = 128, MLE_GROUPS_MAX = 128;
-    static uint32_t mle_groups_for(size_t n_instr) {
-        const uint32_t cap = tuning().mle_groups_max;
-        return (uint32_t)std::min<size_t>(std::max<size_t>(MLE_GROUPS, n_instr / MLE_GROUP_INSTRS), std::max(cap, MLE_GROUPS));
-    }
-    struct TracePrograms {
-        Program zc, lg, leaves;
-        GroupedProgram zc_g, lg_g;
-    };
-    std::future<std::vector<TracePrograms>> programs_future;
-    std::vector<TracePrograms> compile_all_programs() const {
-        std::vector<TracePrograms> out(traces.size());
-        for (size_t t = 0; t < traces.size(); t++) {
-            if (!mine(t)) continue;
-            const AirKey &a = air(t);
-            const ColumnMap cm = column_map_of(a);
-            const std::vector<Fp> &pv = traces[t].public_values;
-            const bool tall = traces[t].height > (size_t(1) << P().l_skip);  // has multilinear rounds
-            {
-                const std::vector<Root> roots = roots_zerocheck(a);
-                out[t].zc = compile_program(a, cm, pv, roots, 0);
-                if (tall) out[t].zc_g = compile_grouped(a, cm, pv, roots, 0, mle_groups_for(out[t].zc.code.size()),
-                                                        mle_slot_target(pk.params.max_constraint_degree));
-            }
-            if (!a.interactions.empty()) {
-                const std::vector<Root> roots = roots_logup(a);
-                out[t].lg = compile_program(a, cm, pv, roots, 0);
-                if (tall) out[t].lg_g = compile_grouped(a, cm, pv, roots, 0, mle_groups_for(out[t].lg.code.size()),
-                                                        mle_slot_target(pk.params.max_constraint_degree));
-                out[t].leaves = compile_program(a, cm, pv, roots_leaves(a), 0);
-            }
-        }
-        return out;
-    }
-
-    // Sharded proving: vecs[i] was computed by rank owner_of(i) only; afterwards every rank holds all of them.
-    template <class OwnerOf>
-    void share_vectors(std::vector<std::vector<EF>> &vecs, OwnerOf owner_of) {
-        if (sh.single()) return;
-        Packer pk_;
-        for (size_t i = 0; i < vecs.size(); i++)
-            if (owner_of(i) == sh.rank) {
-                pk_.put<uint64_t>(i);
-                pk_.put_vec(vecs[i]);
-            }
-        const auto all = sh.allgatherv(pk_.buf);
-        for (uint32_t r = 0; r < sh.world; r++) {
-            if (r == sh.rank) continue;
-            Unpacker u(all[r]);
-            while (!u.done()) {
-                const uint64_t i = u.get<uint64_t>();
-                if (i >= vecs.size() || owner_of(i) != r) throw OvmFail(1, "shard exchange: unexpected vector");
-                vecs[i] = u.get_vec<EF>();
-            }
-        }
-    }
-
-    // -----------------------------------------------------------------------------------------
-    // The device side of the LogUp-GKR driver (gkr_shard.h): this rank's window of every tree layer,
-    // of the folded tables and of the eq heap. With one rank and no padding the windows are the
-    // whole arrays and the launches are the ones a single-device prover makes.
-    // -----------------------------------------------------------------------------------------
-    static constexpr uint64_t PLANE_SKEW = 1088;  // words: 4 KiB + 256 B
-    struct GkrDevice : GkrDeviceOps {
-        Prover &pr;
-        const GkrPlan &plan;
-        const uint32_t me;
-        const unsigned TR;
-        const bool p_base;  // big trees: only limb 0 of the leaf numerators exists
-        std::vector<uint64_t> toff, fb;  // per layer: plane offset of my window, global index of its element 0
-        uint64_t tree_stride = 0, leaf_stride = 0, wcap = 0;
-        // The layers above the leaves share one buffer (a window per layer); the leaf layer has its own: with
-        // base-field numerators it is 5 planes, not 8, and in the memory-bounded mode it is dropped once the layer
-        // above exists and generated again for the last layer's sumcheck (make_leaves).
-        DevBuf<uint32_t> tree_buf, leaf_buf, rec_a, rec_b, eq_buf;
-        // split eq tables of the big layers (begin_layer): grown on demand, a few hundred KiB
-        DevBuf<uint32_t> eq_lo_buf, eq_hi_buf;
-        uint64_t eq_lo_stride = 0, eq_hi_stride = 0;
-        EqHeapPlan hp_lo, hp_hi;
-        unsigned split_m = 0;  // 0: this layer reads its weights from the whole heap
-        DevBuf<EF> partials;
-        EqHeapPlan hp;
-        uint64_t eq_stride = 0;
-        std::vector<uint64_t> rbase;  // rbase[sr]: global record index of element 0 of table(sr)'s buffer (sr >= 1)
-        std::vector<URange> Rchain;   // Rchain[s] = my records of table(s) of the current layer
-        // Two sub-rounds per pass (stages.hip: gkr_pass_kernel). Not every table(s) is written any more:
-        std::vector<EF> point;        // the current layer's eq point
-        unsigned mat_sr = 0;          // the latest table of the current layer that exists on the device (0 = the tree layer)
-        std::vector<uint8_t> tbuf;    // tbuf[s]: which of rec_a / rec_b holds table(s)
-        std::vector<EF> r_hist;       // r_hist[s] = the challenge that folds table(s) into table(s + 1)
-        struct Lookahead {            // what the pass at sub-round sr - 1 left for sub-round sr
-            bool valid = false;
-            unsigned sr = 0;
-            URange pairs;
-            EF v[3][2];               // S(X; r) at r = 0, 1, 2 (first index) and X = 1, 2
-            unsigned n_src = 0;       // source pairs of table(sr - 1) dumped for sub-round sr's unpaired edge records
-            uint64_t src_pair[2] = {0, 0};
-            GkrRec src[2][2];
-        } la;
-        uint64_t la_hits = 0, la_passes = 0, plain_passes = 0;
-        static constexpr size_t LA_DUMP_SLOT = 1024;  // mailbox slots of the dumped source records (sums: 0.., edges: 8..)
-        bool drop_leaves = false;             // ProverConfig::gkr_drop_leaves (and a tree of at least two layers)
-        std::function<void()> make_leaves;    // enqueues the leaf kernels into leaves()
-
-        static uint64_t up64(uint64_t x) { return (x + 63) & ~uint64_t(63); }
-        GkrDevice(Prover &pr_, const GkrPlan &pl, bool p_base_)
-            : pr(pr_), plan(pl), me(pr_.sh.rank), TR(pl.TR), p_base(p_base_), toff(pl.TR + 1, 0), fb(pl.TR + 1, 0) {
-            uint64_t cur = 0;
-            for (unsigned j = 0; j < TR; j++) {
-                const URange &r = plan.F[j][me];
-                toff[j] = cur;
-                if (r.empty()) continue;
-                fb[j] = r.lo & ~uint64_t(63);
-                cur += up64(r.hi - fb[j]);
-            }
-            // (+ PLANE_SKEW words: limb planes a power of two apart put the 8-20 streams of a wave on the same
-            // HBM channels)
-            tree_stride = std::max<uint64_t>(cur, 64) + PLANE_SKEW;
-            tree_buf.alloc(8 * tree_stride);
-            const URange &lr = plan.F[TR][me];
-            if (!lr.empty()) fb[TR] = lr.lo & ~uint64_t(63);
-            leaf_stride = std::max<uint64_t>(lr.empty() ? 0 : up64(lr.hi - fb[TR]), 64) + PLANE_SKEW;
-            alloc_leaves();
-            drop_leaves = prover_config().gkr_drop_leaves && TR >= 3;
-            partials.alloc(RED_BLOCKS * 8);  // (a pass with lookahead leaves 2 + 6 sums per workgroup)
-            // (memory-bounded mode: the sumcheck buffers come when the build is over, sized for the layers above the
-            // leaves, and again -- with the tree gone -- for the leaf layer: begin_layer)
-            if (!drop_leaves) alloc_round_buffers(TR >= 1 ? TR - 1 : 0);
-        }
-        // the folded tables and the eq heap of the layer sumchecks up to `last_round`
-        void alloc_round_buffers(unsigned last_round) {
-            rec_a.release(), rec_b.release(), eq_buf.release();
-            // folded tables: table(1) holds at most half of the layer's records (+ alignment slack), 2 fractions each
-            wcap = up64(plan.F[std::min(last_round + 1, TR)][me].size() / 2 + 128) + PLANE_SKEW;
-            rec_a.alloc(8 * wcap);
-            rec_b.alloc(8 * wcap);
-            uint64_t eq_total = 64;
-            // (the layers that take split tables -- begin_layer -- never touch this buffer: at config D it shrinks from
-            // 1.1 GB to a megabyte)
-            const bool split = tuning().gkr_split_eq;
-            for (unsigned round = 1; round <= last_round && round < TR; round++)
-                if (!split || round < tuning().gkr_split_min_round) eq_total = std::max(eq_total, heap_plan_for(round).total);
-            eq_stride = up64(eq_total) + PLANE_SKEW;
-            eq_buf.alloc(4 * eq_stride);
-        }
-        void alloc_leaves() { leaf_buf.alloc((p_base ? 5 : 8) * leaf_stride); }
-        FracPlanes tree() const { return FracPlanes::make(tree_buf.p, tree_stride); }
-        // element 0 = global leaf fb[TR]; base-field numerators: ONE numerator plane, the denominator planes follow it
-        FracPlanes leaves() const {
-            if (!leaf_buf.p) throw OvmFail(1, "internal: the leaf layer is not resident");
-            return p_base ? FracPlanes{leaf_buf.p, leaf_stride, leaf_stride} : FracPlanes::make(leaf_buf.p, leaf_stride);
-        }
-        // planes positioned at element 0 of my window of layer j
-        FracPlanes layer_planes(unsigned j) const { return j == TR ? leaves() : tree().at(toff[j]); }
-        // planes positioned at global fraction i of layer j (i inside my window)
-        FracPlanes layer_at(unsigned j, uint64_t i) const { return layer_planes(j).at(i - fb[j]); }
-        uint64_t leaf_origin() const { return fb[TR]; }
-        FracPlanes recs(unsigned sr) const { return FracPlanes::make(tbuf[sr] ? rec_b.p : rec_a.p, wcap); }
-
-        // my record ranges of a layer's tables: chain[0] = records of the layer, chain[s + 1] = up(chain[s])
-        std::vector<URange> chain_for(unsigned round) const {
-            std::vector<URange> c(round + 2);
-            c[0] = up(plan.F[round + 1][me]);
-            for (unsigned s2 = 0; s2 <= round; s2++) c[s2 + 1] = up(c[s2]);
-            return c;
-        }
-        EqHeapPlan heap_plan_for(unsigned round) const {
-            const std::vector<URange> c = chain_for(round);
-            std::vector<std::pair<uint64_t, uint64_t>> need(round);
-            for (unsigned d = 0; d < round; d++) need[d] = {c[round - d].lo, c[round - d].hi};  // pairs of sub-round round-1-d
-            return eq_heap_plan(round, need);
-        }
-
-        // limb planes 1..3 of my leaf numerators (small trees only: big ones never read them)
-        void clear_leaf_numerators() {
-            const URange &r = plan.F[TR][me];
-            if (p_base || r.empty()) return;
-            for (int k = 1; k < 4; k++)
-                OVM_THROW_IF(hipMemsetAsync(leaves().p + k * leaf_stride + (r.lo - fb[TR]), 0, r.size() * sizeof(uint32_t), pr.cx.stream));
-        }
-        void build() {
-            for (unsigned j = TR; j-- > 0;) {
-                const URange &r = plan.F[j][me];
-                if (r.empty()) continue;
-                OVM_THROW_IF(gkr_build_layer(layer_at(j + 1, 2 * r.lo), layer_at(j, r.lo), r.size(), p_base && j + 1 == TR, pr.cx.stream));
-            }
-        }
-        void read_layer_edges(std::vector<std::array<Frac, 2>> &out) override {
-            // (the leaf layer lives in its own buffer: its two edge fractions are a list of their own)
-            for (int part = 0; part < 2; part++) {
-                std::vector<uint64_t> pos;
-                std::vector<uint32_t> pb;
-                std::vector<std::pair<unsigned, int>> where;
-                for (unsigned j = part ? TR : 0; j < (part ? TR + 1 : TR); j++) {
-                    const URange &r = plan.F[j][me];
-                    if (r.empty()) continue;
-                    for (int e = 0; e < 2; e++) {
-                        pos.push_back((j == TR ? 0 : toff[j]) + ((e ? r.hi - 1 : r.lo) - fb[j]));
-                        pb.push_back(p_base && j == TR ? 1 : 0);
-                        where.push_back({j, e});
-                    }
-                }
-                if (pos.empty()) continue;
-                const FracPlanes planes = part ? leaves() : tree();
-                for (size_t at = 0; at < pos.size(); at += 32) {
-                    const uint32_t n = (uint32_t)std::min<size_t>(32, pos.size() - at);
-                    auto d_pos = pr.cx.upload(std::vector<uint64_t>(pos.begin() + at, pos.begin() + at + n));
-                    auto d_pb = pr.cx.upload(std::vector<uint32_t>(pb.begin() + at, pb.begin() + at + n));
-                    OVM_THROW_IF(gkr_read_list(planes, d_pos.p, d_pb.p, n, pr.mb.arm(nullptr), pr.cx.stream));
-                    auto v = pr.mb.take(2 * n, pr.cx.stream);
-                    for (uint32_t i = 0; i < n; i++) out[where[at + i].first][where[at + i].second] = Frac{v[2 * i], v[2 * i + 1]};
-                }
-            }
-            // memory-bounded mode: every layer above exists and the edges are with the host -- the leaves can go
-            // (the mailbox reads above have drained the stream: nothing in flight reads them)
-            if (drop_leaves) leaf_buf.release();
-        }
-        void begin_layer(unsigned round, const std::vector<EF> &pt_in) override {
-            if (drop_leaves && round == 1) alloc_round_buffers(TR - 2);
-            if (drop_leaves && round + 1 == TR) {
-                // the last layer's sumcheck reads the leaves and nothing above them: the rest of the tree makes room
-                // for the leaves, which are generated a second time (0.7 ms at config D), and for tables of their size
-                OVM_THROW_IF(hipStreamSynchronize(pr.cx.stream));
-                tree_buf.release();
-                alloc_round_buffers(TR - 1);
-                alloc_leaves();
-                clear_leaf_numerators();
-                make_leaves();
-            }
-            Rchain = chain_for(round);
-            hp = heap_plan_for(round);
-            point = pt_in;
-            mat_sr = 0;
-            tbuf.assign(round + 2, 0);
-            r_hist.assign(round + 2, EF::zero());
-            la.valid = false;
-            rbase.assign(round + 1, 0);
-            for (unsigned sr = 1; sr <= round; sr++) rbase[sr] = (2 * Rchain[sr + 1].lo) & ~uint64_t(31);
-            split_m = 0;
-            if (hp.empty) return;
-            if (tuning().gkr_split_eq && round >= tuning().gkr_split_min_round) {
-                // Two small heaps instead of the layer's whole one (device_common.h: EqSplit): variables [0, M) of the
-                // point and variables [M, round). Depth d of a heap = the table over the LAST d entries of its point, so
-                // the hi heap is built on point[M-1 ..) (its first entry belongs to no table) and its depth round - M is
-                // the full hi table; sub-round sr takes depth M - sr - 1 of the lo heap.
-                split_m = round / 2;
-                auto full = [](uint32_t n) {
-                    std::vector<std::pair<uint64_t, uint64_t>> need(n);
-                    for (uint32_t d = 0; d < n; d++) need[d] = {0, uint64_t(1) << d};
-                    return need;
-                };
-                hp_lo = eq_heap_plan(split_m, full(split_m));
-                hp_hi = eq_heap_plan(round - split_m + 1, full(round - split_m + 1));
-                auto fit = [&](DevBuf<uint32_t> &buf, uint64_t &stride, const EqHeapPlan &pl) {
-                    const uint64_t need = up64(pl.total) + PLANE_SKEW;
-                    if (stride < need) {
-                        stride = need;
-                        buf.alloc(4 * stride);
-                    }
-                };
-                fit(eq_lo_buf, eq_lo_stride, hp_lo);
-                fit(eq_hi_buf, eq_hi_stride, hp_hi);
-                OVM_THROW_IF(eq_heap_run(point.data(), hp_lo, EFPlanes{eq_lo_buf.p, eq_lo_stride}, pr.cx.stream));
-                OVM_THROW_IF(eq_heap_run(point.data() + split_m - 1, hp_hi, EFPlanes{eq_hi_buf.p, eq_hi_stride}, pr.cx.stream));
-                return;
-            }
-            OVM_THROW_IF(eq_heap_run(point.data(), hp, EFPlanes{eq_buf.p, eq_stride}, pr.cx.stream));
-        }
-        // planes positioned at record y of table(sr) (sr == 0: the tree layer)
-        FracPlanes table_at(unsigned round, unsigned sr, uint64_t y) const {
-            if (sr == 0) return layer_at(round + 1, 2 * y);
-            return recs(sr).at(2 * (y - rbase[sr]));
-        }
-        // the weights of sub-round sr's pairs, positioned at global pair y_first
-        EqSplit eq_for(unsigned round, unsigned sr, uint64_t y_first) const {
-            const unsigned d = round - 1 - sr;
-            EqSplit eq{EFPlanes{nullptr, 0}, EFPlanes{nullptr, 0}, EQ_WHOLE, y_first};
-            if (!split_m) {
-                eq.lo = EFPlanes{eq_buf.p + hp.at(d, y_first), eq_stride};
-                return eq;
-            }
-            const unsigned n_hi = round - split_m;
-            if (sr + 1 < split_m) {
-                const unsigned d_lo = split_m - sr - 1;
-                eq.lo = EFPlanes{eq_lo_buf.p + hp_lo.at(d_lo, 0), eq_lo_stride};
-                eq.hi = EFPlanes{eq_hi_buf.p + hp_hi.at(n_hi, 0), eq_hi_stride};
-                eq.lo_bits = d_lo;
-            } else {
-                eq.hi = EFPlanes{eq_hi_buf.p + hp_hi.at(d, 0), eq_hi_stride};
-                eq.lo_bits = 0;
-            }
-            return eq;
-        }
-        void subround(unsigned round, unsigned sr, URange pairs, const uint64_t *edge_idx, unsigned n_edges, EF r_prev, EF lambda,
-                      unsigned n_points, EF *S, GkrRec *edges) override {
-            hipStream_t st = pr.cx.stream;
-            const bool have_pairs = !pairs.empty();
-            if (sr > 0) r_hist[sr - 1] = r_prev;
-            // ---- served from the lookahead of the pass before: no launch, no round trip ----
-            if (la.valid && la.sr == sr && have_pairs && pairs.lo == la.pairs.lo && pairs.hi == la.pairs.hi && n_points == 2 && n_edges <= 2) {
-                bool ok = true;
-                for (unsigned k = 0; k < n_edges && ok; k++) {
-                    ok = false;
-                    for (unsigned j = 0; j < la.n_src; j++)
-                        if (la.src_pair[j] == edge_idx[k]) {
-                            edges[k] = rec_fold(la.src[j][0], la.src[j][1], r_prev);
-                            ok = true;
-                        }
-                }
-                if (ok) {
-                    // the quadratic through (0, v0), (1, v1), (2, v2) at r_prev
-                    const EF inv2 = EF::from_base(fp(2).inv());
-                    const EF rm1 = r_prev - EF::one(), rm2 = rm1 - EF::one();
-                    const EF l0 = rm1 * rm2 * inv2, l1 = EF::zero() - r_prev * rm2, l2 = r_prev * rm1 * inv2;
-                    for (int x = 0; x < 2; x++) S[x] = la.v[0][x] * l0 + la.v[1][x] * l1 + la.v[2][x] * l2;
-                    la.valid = false;
-                    la_hits++;
-                    return;
-                }
-            }
-            la.valid = false;
-            // ---- a pass over the latest table that exists: table(sr) is its 0- / 1- / 2-fold ----
-            const unsigned folds = sr - mat_sr;
-            if (folds > 2 || (sr == 0) != (folds == 0)) throw OvmFail(1, "internal: GKR sub-round too far from the last written table");
-            const EF r1 = folds == 2 ? r_hist[sr - 2] : r_prev, r2 = r_prev;
-            const bool src_leaf = p_base && round + 1 == TR && mat_sr == 0;  // the source is the leaf layer (base-field numerators)
-            const unsigned L = round + 1;
-            if (n_edges) {
-                // (first: when a sums kernel follows, it is the one that raises the flag)
-                RedOut ro = pr.mb.arm(nullptr, 8);
-                if (have_pairs) ro.flag = nullptr;
-                // record e of table(sr) = the `folds`-fold of records e 2^folds .. of the source table; the indices are at
-                // most two runs of consecutive records
-                uint32_t n0 = 1;
-                while (n0 < n_edges && edge_idx[n0] == edge_idx[n0 - 1] + 1) n0++;
-                const uint32_t n1 = n_edges - n0;
-                for (uint32_t k = n0 + 1; k < n_edges; k++)
-                    if (edge_idx[k] != edge_idx[k - 1] + 1) throw OvmFail(1, "internal: more than two runs of edge records");
-                const FracPlanes base = mat_sr == 0 ? layer_planes(L) : recs(mat_sr);
-                auto at_of = [&](uint64_t e) -> uint64_t {
-                    const uint64_t src_rec = e << folds;  // first source record
-                    return mat_sr == 0 ? 2 * src_rec - fb[L] : 2 * (src_rec - rbase[mat_sr]);
-                };
-                OVM_THROW_IF(gkr_edge_records(base, at_of(edge_idx[0]), n1 ? at_of(edge_idx[n0]) : 0, n0, n1, src_leaf, (int)folds, r1, r2, ro, st));
-            }
-            bool use_la = false;
-            if (have_pairs) {
-                const uint64_t y0 = pairs.lo, n_pairs = pairs.size();
-                // lookahead: sub-round sr + 1 must be an ordinary one (it exists, my table is still above the host-tail size
-                // there, two evaluation points) and ask for exactly the pairs the chain predicts
-                use_la = tuning().gkr_lookahead && !tuning().gkr_three_points && n_points == 2 && sr + 1 < round &&
-                         sr + 2 < Rchain.size() && Rchain[sr + 1].lo == pairs.lo && Rchain[sr + 1].hi == pairs.hi &&
-                         Rchain[sr + 1].size() > GKR_HOST_TAIL && !Rchain[sr + 2].empty() &&
-                         n_pairs <= (uint64_t(1) << std::min(tuning().gkr_la_max_log, 40u));
-                uint64_t want[2] = {~0ull, ~0ull};
-                EqSplit eq_n = eq_for(round, sr, y0);
-                if (use_la) {
-                    la.n_src = range_edges(Rchain[sr + 1], la.src_pair);  // sub-round sr + 1's unpaired records = pairs of table(sr)
-                    for (unsigned k = 0; k < la.n_src; k++) want[k] = la.src_pair[k] - y0;
-                    eq_n = eq_for(round, sr + 1, Rchain[sr + 2].lo);
-                    if (Rchain[sr + 2].lo != (y0 + 1) / 2) throw OvmFail(1, "internal: GKR lookahead range mismatch");
-                }
-                const FracPlanes in = mat_sr == 0 ? layer_at(L, (2 * y0) << (folds + 1)) : recs(mat_sr).at(2 * (((2 * y0) << folds) - rbase[mat_sr]));
-                FracPlanes out = in;
-                if (folds) {
-                    tbuf[sr] = mat_sr == 0 ? 0 : (uint8_t)(1 - tbuf[mat_sr]);
-                    out = recs(sr).at(2 * (2 * y0 - rbase[sr]));
-                }
-                // (the plain one-fold passes keep the kernels of rounds 1-3: the generic pass kernel measured 0.34 ms per proof
-                // slower in that role -- 4.90 against 4.56 ms over the 189 fold passes of config D, profiles/r04/)
-                if (!use_la && folds == 0)
-                    OVM_THROW_IF(gkr_round(in, src_leaf, eq_for(round, sr, y0), n_pairs, lambda, n_points, pr.mb.arm(partials.p), st));
-                else if (!use_la && folds == 1)
-                    OVM_THROW_IF(gkr_fold_round(in, src_leaf, eq_for(round, sr, y0), out, n_pairs, r1, lambda, n_points, pr.mb.arm(partials.p), st));
-                else
-                    OVM_THROW_IF(gkr_pass(in, src_leaf, (int)folds, eq_for(round, sr, y0), eq_n, out, n_pairs, r1, r2, lambda, n_points, use_la,
-                                          use_la ? point[sr + 1] : EF::zero(), want[0], want[1], pr.mb.slot_ptr(LA_DUMP_SLOT),
-                                          pr.mb.arm(partials.p), st));
-                (use_la ? la_passes : plain_passes)++;
-            }
-            pr.mb.wait(st);
-            if (have_pairs) {
-                auto v = pr.mb.read(0, use_la ? 8 : n_points);
-                for (unsigned k = 0; k < n_points; k++) S[k] = v[k];
-                if (folds) mat_sr = sr;
-                if (use_la) {
-                    la.valid = true;
-                    la.sr = sr + 1;
-                    la.pairs = Rchain[sr + 2];
-                    for (int j = 0; j < 3; j++)
-                        for (int x = 0; x < 2; x++) la.v[j][x] = v[2 + 2 * j + x];
-                    if (la.n_src) {
-                        auto d = pr.mb.read(LA_DUMP_SLOT, 16);
-                        for (unsigned k = 0; k < la.n_src; k++)
-                            for (int h2 = 0; h2 < 2; h2++)
-                                for (int c = 0; c < 4; c++) la.src[k][h2].v[c] = d[8 * k + 4 * h2 + c];
-                    }
-                }
-            }
-            if (n_edges) {
-                auto v = pr.mb.read(8, 4 * n_edges);
-                for (unsigned k = 0; k < n_edges; k++)
-                    for (int c = 0; c < 4; c++) edges[k].v[c] = v[4 * k + c];
-            }
-        }
-    };
-
-    // -----------------------------------------------------------------------------------------
-    // Stage 2: zerocheck + LogUp (MultiRapProver::prove_rap_constraints)
-    // -----------------------------------------------------------------------------------------
-    // Per trace: heights, the column map of its view (selectors, preprocessed, cached mains, common main, each with
-    // its rotated twin when the AIR needs it) -- on every rank -- and, on the owner, the device descriptors.
-    // imeta / total_interactions: the interaction layout's input (one entry per trace).
-    std::vector<TraceView> build_trace_views(uint64_t &total_interactions, std::vector<std::pair<size_t, unsigned>> &imeta) {
-        const unsigned l_skip = P().l_skip;
-        const size_t T = traces.size();
-        std::vector<TraceView> tv(T);
-        for (size_t t = 0; t < T; t++) {
-            TraceView &v = tv[t];
-            v.log_height = log2_strict(traces[t].height);
-            v.log_lifted = std::max(v.log_height, l_skip);
-            v.n = (int)v.log_height - (int)l_skip;
-            v.n_lift = (unsigned)std::max(v.n, 0);
-            v.cm.need_rot = air(t).need_rot;
-            v.cm.pre_width = air(t).preprocessed_width;
-            v.cm.part_width = air(t).cached_widths;
-            v.cm.part_width.push_back(air(t).common_main_width);
-            v.cm.finish();
-            size_t ni = air(t).interactions.size();
-            total_interactions += (uint64_t)ni << v.log_lifted;
-            imeta.push_back({ni, v.log_lifted});
-            if (!mine(t)) continue;
-            // device view: selectors + columns
-            v.sels.alloc(size_t(3) << v.log_lifted);
-            OVM_THROW_IF(build_selectors(v.sels.p, v.log_lifted, v.log_height, cx.stream));
-            std::vector<ColDesc> cd(v.cm.total);
-            std::vector<int32_t> twin(v.cm.total, -1);
-            for (int sidx = 0; sidx < 3; sidx++) cd[sidx] = ColDesc{v.sels.p + ((size_t)sidx << v.log_lifted), v.log_lifted, 0};
-            const size_t h = traces[t].height;
-            auto put_mat = [&](const Fp *ptr, size_t w, uint32_t base) {
-                for (size_t c = 0; c < w; c++) {
-                    cd[base + c] = ColDesc{ptr + c * h, v.log_height, 0};
-                    if (v.cm.need_rot) {
-                        cd[base + w + c] = ColDesc{ptr + c * h, v.log_height, 1};
-                        // (a chunk and its rotated view share cells only when the trace has whole 16-row chunks)
-                        if (v.log_height >= 4) twin[base + c] = (int32_t)(base + w + c), twin[base + w + c] = -2;
-                    }
-                }
-            };
-            if (v.cm.pre_width) {
-                const PcsData *pp = pre_of(t);
-                if (!pp || pp->mat_h != h || pp->mat_w != v.cm.pre_width)
-                    throw OvmFail(1, "preprocessed trace missing or of the wrong shape");
-                put_mat(pp->mat_ptr, pp->mat_w, v.cm.pre_col(0, 0));
-            }
-            const size_t n_cached = air(t).cached_widths.size();
-            if (traces[t].cached.size() != n_cached) throw OvmFail(1, "cached main partitions: wrong count");
-            for (size_t k = 0; k < n_cached; k++) {
-                const PcsData *cp = traces[t].cached[k];
-                if (!cp || cp->mat_h != h || cp->mat_w != air(t).cached_widths[k] || !cp->mat_ptr)
-                    throw OvmFail(1, "cached main partition of the wrong shape");
-                put_mat(cp->mat_ptr, cp->mat_w, v.cm.col((uint32_t)k, 0, 0));
-            }
-            put_mat(traces[t].d_trace, air(t).common_main_width, v.cm.col((uint32_t)n_cached, 0, 0));
-            v.cols = cx.upload(cd);
-            v.twins = cx.upload(twin);
-        }
-        return tv;
-    }
-
-    // LogUp-GKR (prover/logup_zerocheck/fractional_sumcheck_gkr.rs:60-213): this rank's leaves on its device, the
-    // tree over them, the layer sumchecks through the driver of gkr_shard.h (padding and cross-rank records on the host).
-    GkrOutput prove_gkr(const std::vector<TraceView> &tv, std::vector<TracePrograms> &progs, const Layout &ilayout, unsigned TR,
-                        EF alpha, const std::vector<EF> &beta_pows, const std::function<void()> &after_build) {
-        const size_t T = traces.size();
-        const uint64_t n_leaves = uint64_t(1) << TR;
-        // The interaction slices are packed from row 0 with no gaps (descending powers of two) in sorted
-        // trace order, so the leaves of a rank (a block of consecutive traces) are one run; what is left
-        // above the last slice is padding.
-        uint64_t used_leaves = 0;
-        std::vector<URange> rank_leaves(sh.world);
-        for (size_t t = 0; t < T; t++)
-            for (size_t k = 0; k < air(t).interactions.size(); k++) {
-                const Slice &sl = ilayout.cols[ilayout.mat_starts[t] + k].slice;
-                const uint64_t lo = sl.row_idx, hi = sl.row_idx + (uint64_t(1) << sl.log_height);
-                used_leaves = std::max(used_leaves, hi);
-                URange &r = rank_leaves[owner[t]];
-                r = r.empty() ? URange{lo, hi} : URange{std::min(r.lo, lo), std::max(r.hi, hi)};
-            }
-        if (used_leaves > n_leaves) throw OvmFail(1, "internal: interaction layout exceeds the tree");
-        const GkrPlan plan(TR, rank_leaves, used_leaves);
-        // big trees: only limb 0 of the leaf numerators exists (small ones are read through generic paths)
-        const bool p_base = TR >= 12;
-        GkrDevice gd(*this, plan, p_base);
-        // What the leaf kernels of this rank's traces need, kept until the tree no longer wants its leaves (the
-        // memory-bounded mode launches them a second time); traces of fewer than 2^20 rows share one launch.
-        struct LeafKeep {
-            ProgDev pd;
-            DevBuf<EF> lc;
-            DevBuf<uint64_t> lb;
-            DevBuf<uint32_t> ll;
-            Fp norm;
-            size_t t;
-            bool batched;
-        };
-        auto leaf_keep = std::make_shared<std::vector<LeafKeep>>();
-        auto leaf_jobs = std::make_shared<std::vector<LeavesJob>>();
-        for (size_t t = 0; t < T; t++) {
-            const AirKey &a = air(t);
-            if (a.interactions.empty() || !mine(t)) continue;
-            std::vector<EF> leaf_const;
-            std::vector<uint64_t> leaf_base;
-            std::vector<uint32_t> leaf_log_len;
-            for (size_t k = 0; k < a.interactions.size(); k++) {
-                const Interaction &it = a.interactions[k];
-                leaf_const.push_back(beta_pows[it.message.size()] * fp((uint64_t)it.bus_index + 1) + alpha);
-                const Slice &s = ilayout.cols[ilayout.mat_starts[t] + k].slice;
-                leaf_base.push_back(s.row_idx - gd.leaf_origin());  // (relative to this rank's leaf window)
-                leaf_log_len.push_back(s.log_height);
-            }
-            auto d_lc = cx.upload(leaf_const);
-            auto d_lb = cx.upload(leaf_base);
-            auto d_ll = cx.upload(leaf_log_len);
-            Fp norm = fp(uint64_t(1) << (tv[t].log_lifted - tv[t].log_height)).inv();
-            // staged for one row per lane (log_lifted 0 selects that plan)
-            ProgDev pd = make_prog(std::move(progs[t].leaves), beta_pows, true, 0, 1);
-            const bool batched = pd.staged.blocks && tv[t].log_height < 20;
-            if (batched) {
-                LeavesJob j{};
-                j.prog = pd.staged, j.leaf_const = d_lc.p, j.cols = tv[t].cols.p, j.leaf_base = d_lb.p;
-                j.leaf_log_len = d_ll.p, j.norm = norm, j.log_height = tv[t].log_height;
-                j.gx = (uint32_t)ceil_div(1ull << tv[t].log_height, 256);
-                j.wg0 = leaf_jobs->empty() ? 0 : leaf_jobs->back().wg0 + leaf_jobs->back().gx;
-                leaf_jobs->push_back(j);
-            }
-            leaf_keep->push_back(LeafKeep{std::move(pd), std::move(d_lc), std::move(d_lb), std::move(d_ll), norm, t, batched});
-        }
-        gd.make_leaves = [this, &gd, &tv, leaf_keep, leaf_jobs]() {
-            for (const LeafKeep &k : *leaf_keep)
-                if (!k.batched)
-                    OVM_THROW_IF(gkr_eval_leaves(k.pd.dev(), k.pd.staged, k.lc.p, tv[k.t].cols.p, tv[k.t].log_height, k.lb.p, k.ll.p,
-                                                 k.norm, gd.leaves(), cx.stream));
-            if (!leaf_jobs->empty()) {
-                auto d_jobs = cx.upload(*leaf_jobs);
-                OVM_THROW_IF(gkr_eval_leaves_batched(d_jobs.p, leaf_jobs->data(), (uint32_t)leaf_jobs->size(), gd.leaves(), cx.stream));
-            }
-        };
-        {
-            OVM_PROF("gkr.leaves", cx.stream);
-            gd.clear_leaf_numerators();
-            gd.make_leaves();
-            // no synchronisation: the temporaries go back to the block cache and are only ever reused
-            // by later work on this same stream
-            if (!gd.drop_leaves) leaf_keep->clear(), leaf_jobs->clear();
-        }
-        {
-            OVM_PROF("gkr.build_tree", cx.stream);
-            wt.mark("rap.gkr.leaves");
-            gd.build();
-        }
-        wt.mark("rap.gkr.build");
-        if (after_build) after_build();  // (the tree is enqueued: what follows is latency-bound for its first dozen layers)
-        OVM_PROF("gkr.layer_sumchecks", cx.stream);
-        GkrSharded drv(plan, sh, gd, alpha);
-        drv.force_three_points = force_three_points;
-        drv.observe = [this](const EF &e) { ts.observe_ext(e); };
-        drv.sample = [this]() { return ts.sample_ext(); };
-        GkrOutput gout = drv.run();
-        if (tuning().trace)
-            fprintf(stderr, "[ovm] gkr sub-rounds on this rank: %llu passes with lookahead, %llu plain passes, %llu served from a lookahead\n",
-                    (unsigned long long)gd.la_passes, (unsigned long long)gd.plain_passes, (unsigned long long)gd.la_hits);
-        return gout;
-    }
-
-    // The univariate round of the batch sumcheck, host algebra on a few dozen extension-field elements
-    // (reference: cpu-backend/src/logup_zerocheck/mod.rs:1468-1563): sp0[2t], sp0[2t+1] = the LogUp numerator /
-    // denominator polynomials of trace t, sp0[2T + t] its zerocheck quotient part. Observes the per-trace sum
-    // claims, samples mu, observes the coefficients of s_0.
-    struct S0 {
-        std::vector<EF> numer_terms, denom_terms, mu_pows, s0;
-    };
-    S0 assemble_s0(const std::vector<std::vector<EF>> &sp0, const std::vector<EF> &xi) {
-        const unsigned l_skip = P().l_skip, cdeg_global = P().max_constraint_degree;
-        const size_t N = size_t(1) << l_skip, T = traces.size();
-        const unsigned sp0_deg = cdeg_global * (unsigned)(N - 1), s_deg = cdeg_global + 1, s0_deg = s_deg * (unsigned)(N - 1);
-        const size_t large = size_t(1) << log2_ceil(s0_deg + 1);
-        // product with the degree-(N-1) eq polynomial. The reference multiplies on a domain of size
-        // `large` (no wrap-around: deg <= s0_deg < large), i.e. a plain polynomial product; with tens of
-        // AIRs the N-term schoolbook product is much cheaper on the host than two size-`large` DFTs.
-        auto mul_by = [&](const std::vector<EF> &a, const std::vector<EF> &eq_coeffs) {
-            std::vector<EF> out(large, EF::zero());
-            for (size_t j = 0; j < eq_coeffs.size(); j++) {
-                if (is_zero(eq_coeffs[j])) continue;
-                const EF::Pre e = eq_coeffs[j].pre();
-                for (size_t i = 0; i < a.size() && i + j < large; i++) out[i + j] += a[i] * e;
-            }
-            return out;
-        };
-        std::vector<std::vector<EF>> s0_logup(2 * T);
-        {
-            std::vector<EF> eqc = small_dft(eq_hypercube(std::vector<EF>(xi.begin(), xi.begin() + l_skip)), true);
-            for (size_t i = 0; i < 2 * T; i++) {
-                std::vector<EF> c(sp0[i].begin(), sp0[i].begin() + std::min(sp0[i].size(), (size_t)sp0_deg + 1));
-                s0_logup[i] = mul_by(c, eqc);
-            }
-        }
-        std::vector<EF> numer_terms, denom_terms;
-        for (size_t t = 0; t < T; t++) {
-            EF sums[2];
-            for (int dnm = 0; dnm < 2; dnm++) {
-                EF s = EF::zero();
-                for (size_t j = 0; j <= s0_deg; j += N) s += s0_logup[2 * t + dnm][j];
-                sums[dnm] = s * fp(N);
-            }
-            ts.observe_ext(sums[0]);
-            ts.observe_ext(sums[1]);
-            numer_terms.push_back(sums[0]);
-            denom_terms.push_back(sums[1]);
-        }
-        EF mu = ts.sample_ext();
-        std::vector<EF> mu_pows = powers_of(mu, 3 * T);
-        std::vector<EF> s0_zc;
-        {
-            Fp n_inv = Fp::one().halve().pow(l_skip);
-            std::vector<EF> eqc(N);
-            EF xp = xi[0];
-            for (size_t i = 0; i < N; i++) {
-                eqc[i] = xp * n_inv;
-                xp = xp * xi[0];
-            }
-            std::reverse(eqc.begin(), eqc.end());
-            eqc[0] = ef(n_inv);
-            std::vector<EF> c(sp0_deg + 1, EF::zero());
-            for (size_t j = 0; j <= sp0_deg; j++)
-                for (size_t t = 0; t < T; t++)
-                    if (j < sp0[2 * T + t].size()) c[j] += mu_pows[2 * T + t] * sp0[2 * T + t][j];
-            s0_zc = mul_by(c, eqc);
-        }
-        std::vector<EF> s0(s0_deg + 1);
-        for (size_t j = 0; j <= s0_deg; j++) {
-            EF c = s0_zc[j];
-            for (size_t i = 0; i < 2 * T; i++) c += mu_pows[i] * s0_logup[i][j];
-            ts.observe_ext(c);
-            s0[j] = c;
-        }
-        return S0{std::move(numer_terms), std::move(denom_terms), std::move(mu_pows), std::move(s0)};
-    }
-
-    std::vector<EF> prove_rap_constraints() {
-        std::vector<TracePrograms> progs = programs_future.valid() ? programs_future.get() : compile_all_programs();
-        const unsigned l_skip = P().l_skip;
-        const size_t N = size_t(1) << l_skip, T = traces.size();
-        const unsigned cdeg_global = P().max_constraint_degree;
-        uint64_t total_interactions = 0;
-        std::vector<std::pair<size_t, unsigned>> imeta;
-        std::vector<TraceView> tv = build_trace_views(total_interactions, imeta);
-        const unsigned n_max = tv[0].n_lift;
-        unsigned n_logup = 0;
-        if (total_interactions) n_logup = (64 - (unsigned)__builtin_clzll(total_interactions)) - l_skip;
-        Layout ilayout(0, l_skip + n_logup, imeta);
-
-        ByteWriter &w = out;
-        Fp logup_pow = ts.grind(P().logup_pow_bits);
-        EF alpha = ts.sample_ext(), beta = ts.sample_ext();
-        size_t max_msg = 0, max_constraints = 0;
-        for (size_t t = 0; t < T; t++)
-            for (auto &it : air(t).interactions) max_msg = std::max(max_msg, it.message.size());
-        for (auto &a : pk.airs) max_constraints = std::max(max_constraints, a.constraint_idx.size());
-        std::vector<EF> beta_pows = powers_of(beta, max_msg + 1);
-
-        // shift^i / N per coset (the iDFT scale is folded in): the same for every trace
-        const Fp g = fp(bb::GENERATOR), omega_skip = bb::two_adic_generator(l_skip);
-        std::vector<Fp> shift_pows(MAX_COSETS * N);
-        for (unsigned k = 0; k < MAX_COSETS; k++) {
-            Fp sh = g.pow(k + 1), cur = fp((uint64_t)N).inv();
-            for (size_t i = 0; i < N; i++) {
-                shift_pows[k * N + i] = cur;
-                cur *= sh;
-            }
-        }
-        auto d_sp_all = cx.upload(shift_pows);
-
-        // ---- round 0's coset LDE, early ----
-        // The extension of a trace to the cosets depends on no challenge. Once the GKR tree is enqueued the device
-        // has ~3 ms of layer sumchecks ahead in which it mostly waits for the host (tables of a few pairs, one mailbox
-        // round trip per sub-round): the LDE (1.6 ms at config D) runs beside them on the library's low-priority side
-        // stream and round 0 finds it done. Not with zerocheck_save_memory (the LDE buffer is a slab there, reused),
-        // and not when the buffer cannot be had (round 0 then allocates it after the tree has been freed).
-        struct EarlyLde {
-            DevBuf<Fp> lde;
-            DevBuf<uint32_t> d_used;
-            std::vector<uint32_t> used;
-            unsigned n_cosets = 0;
-            bool done = false;
-        };
-        struct EarlyLdeSet {  // (a proof that fails between fork and join must not hand the buffers back while the kernel runs)
-            std::vector<EarlyLde> per_trace;
-            bool in_flight = false;
-            ~EarlyLdeSet() {
-                if (in_flight) (void)hipStreamSynchronize(side_stream().s);
-            }
-        } early;
-        early.per_trace.resize(T);
-        auto used_columns = [&](size_t t, const std::vector<uint32_t> &zc_used, const std::vector<uint32_t> *lg_used) {
-            std::vector<char> usedm(tv[t].cm.total, 0);
-            for (auto c : zc_used) usedm[c] = 1;
-            if (lg_used)
-                for (auto c : *lg_used) usedm[c] = 1;
-            std::vector<uint32_t> used;
-            for (size_t c = 0; c < usedm.size(); c++)
-                if (usedm[c]) used.push_back((uint32_t)c);
-            return used;
-        };
-        std::function<void()> enqueue_early_lde;
-        if (tuning().early_lde && !prover_config().zerocheck_save_memory) {
-            for (size_t t = 0; t < T; t++) {
-                if (!mine(t)) continue;
-                const AirKey &a = air(t);
-                EarlyLde &e = early.per_trace[t];
-                const unsigned cdeg = a.max_constraint_degree;
-                e.n_cosets = std::max(cdeg ? cdeg - 1 : 0u, a.interactions.empty() ? 0u : cdeg);
-                if (!e.n_cosets || e.n_cosets > MAX_COSETS) continue;
-                e.used = used_columns(t, progs[t].zc.used_cols, a.interactions.empty() ? nullptr : &progs[t].lg.used_cols);
-            }
-            enqueue_early_lde = [&]() {
-                SideStream &ss = side_stream();
-                try {
-                    ss.init();
-                } catch (const OvmFail &) {
-                    return;  // (no second stream to be had: round 0 extends the traces where it uses them)
-                }
-                bool any = false;
-                for (size_t t = 0; t < T; t++) {
-                    EarlyLde &e = early.per_trace[t];
-                    if (e.used.empty()) continue;
-                    try {
-                        e.lde.alloc((size_t)e.n_cosets * tv[t].cm.total << tv[t].log_lifted);
-                    } catch (const OvmFail &) {
-                        continue;
-                    }
-                    e.d_used = cx.upload(e.used);
-                    e.done = true;
-                    any = true;
-                }
-                if (!any) return;
-                flush_uploads(cx.stream);
-                OVM_THROW_IF(hipEventRecord(ss.fork, cx.stream));
-                OVM_THROW_IF(hipStreamWaitEvent(ss.s, ss.fork, 0));
-                early.in_flight = true;
-                {
-                    OVM_PROF("round0.coset_lde", ss.s);
-                    for (size_t t = 0; t < T; t++) {
-                        EarlyLde &e = early.per_trace[t];
-                        if (!e.done) continue;
-                        OVM_THROW_IF(coset_lde(tv[t].cols.p, e.d_used.p, (uint32_t)e.used.size(), (uint32_t)tv[t].cm.total, tv[t].log_lifted,
-                                               l_skip, e.n_cosets, d_sp_all.p, e.lde.p, ss.s, 0, tuning().early_lde_lds_kib << 10));
-                    }
-                }
-                OVM_THROW_IF(hipEventRecord(ss.join, ss.s));
-            };
-        }
-
-        // ---- GKR ----
-        const unsigned TR = l_skip + n_logup;
-        GkrOutput gk;
-        if (!ilayout.cols.empty()) gk = prove_gkr(tv, progs, ilayout, TR, alpha, beta_pows, enqueue_early_lde);
-        std::vector<EF> xi = std::move(gk.xi);
-        const EF q0_claim = gk.q0_claim;
-        const std::vector<std::array<EF, 4>> &claims = gk.claims;               // p0,p1,q0,q1 per layer
-        const std::vector<std::vector<std::array<EF, 3>>> &gkr_polys = gk.polys;
-        wt.mark("rap.gkr");
-        const unsigned n_global = std::max(n_max, n_logup);
-        while (xi.size() != l_skip + n_global) xi.push_back(ts.sample_ext());
-        // l_skip = 0 with every trace one row tall and no interactions: xi is EMPTY and the protocol has no round-0 variable
-        // to bind -- the reference indexes `prover.xi[0]` and panics (prover/logup_zerocheck/mod.rs:255); refused here.
-        if (xi.empty()) throw OvmFail((int)hipErrorInvalidValue, "degenerate context: l_skip = 0 and no trace taller than one row (xi is empty; the reference panics at logup_zerocheck/mod.rs:255)");
-
-        // gkr proof bytes
-        w.f(logup_pow);
-        w.e(q0_claim);
-        w.usize(claims.size());
-        for (auto &c : claims)
-            for (auto &x : c) w.e(x);
-        for (auto &round : gkr_polys)
-            for (auto &arr : round)
-                for (auto &x : arr) w.e(x);
-        section_offsets.push_back(w.buf.size());
-
-        EF lambda = ts.sample_ext();
-        std::vector<EF> lambda_pows = powers_of(lambda, std::max<size_t>(max_constraints, 1));
-        std::vector<Fp> omega_pows = powers_of(omega_skip, N);
-
-        // ---- programs, eq weights, round 0 ----
-        struct GroupedDev {
-            GroupedProgram gp;
-            DevBuf<Instr> code;
-            DevBuf<uint32_t> off;
-        };
-        auto make_grouped = [&](GroupedProgram gp) {
-            auto g = std::make_unique<GroupedDev>();
-            g->code = cx.upload(gp.code);
-            g->off = cx.upload(gp.off);
-            g->gp = std::move(gp);
-            return g;
-        };
-        struct TraceProgs {
-            std::unique_ptr<ProgDev> zc, lg;
-            std::unique_ptr<GroupedDev> zc_g, lg_g;
-            std::unique_ptr<StagedGroups> zc_sg, lg_sg;  // round 0 of long programs on short traces
-            std::vector<EF> zc_w, lg_w;
-            EF lg_const = EF::zero();
-            std::vector<EF> eq3b;
-        };
-        std::vector<TraceProgs> tp(T);
-        std::vector<std::vector<EF>> sp0(3 * T);
-        // Phase A enqueues every trace's work (eq table, coset LDE, zerocheck and logup evaluation)
-        // without waiting; each reduction gets its own partial-sum buffer and mailbox slots. Phase B
-        // waits ONCE and does the host algebra. With tens of AIRs per proof a wait per AIR per
-        // reduction was most of this stage's time.
-        struct Round0Job {
-            unsigned cdeg = 0, zc_cosets = 0, lg_cosets = 0;
-            size_t zc_slot = 0, lg_slot = 0, zc_stride = 0, lg_stride = 0;
-            uint32_t n_slabs = 1;
-            DevBuf<EF> d_eq, zc_partials, lg_partials;
-            DevBuf<Fp> lde;
-            DevBuf<uint32_t> d_used;
-            DevBuf<Fp> d_sp;
-        };
-        std::vector<Round0Job> jobs(T);
-        // Staged round-0 evaluations of traces of fewer than 2^R0_BATCH_MAX_LOG rows are collected per
-        // (rows per lane, outputs) and run in one launch each after the loop: a many-AIR proof has dozens of
-        // them, each a few workgroups (OVM_R0_BATCH=0: every trace its own launch).
-        static constexpr uint32_t R0_BATCH_MAX_LOG = 20;
-        // (as many groups as keep the job within this many workgroups: on taller traces the lanes are there
-        // already, and the job's last workgroup sums workgroups x groups records)
-        static constexpr uint32_t R0_GROUP_JOB_WGS = 512;
-        const bool r0_batch = tuning().r0_batch;
-        std::vector<R0Job> r0_groups[3][2];  // [log2 rows][n_out - 1]
-        // long programs (more groups than the OVM_R0_GROUPS_MIN threshold, default: more than MLE_GROUPS, i.e.
-        // > ~2 K instructions) run their groups as extra workgroups of the job
-        const uint32_t r0_groups_min = tuning().r0_groups_min >= 0 ? (uint32_t)tuning().r0_groups_min : MLE_GROUPS + 1;
-        auto r0_batchable = [&](const DevStaged &staged, uint32_t log_lifted) {
-            // (a skip domain larger than a workgroup goes through round0_eval, which sizes its grid in whole domains)
-            return r0_batch && staged.blocks && log_lifted < R0_BATCH_MAX_LOG && N <= RED_THREADS;
-        };
-        // workgroups (= partial records) the job will use
-        auto r0_job_grid = [&](const DevStaged &staged, const StagedGroups *sg, uint32_t log_lifted) -> uint32_t {
-            if (!sg) return round0_staged_grid(staged, log_lifted);
-            DevStaged widest = sg->host[0];
-            widest.num_rows = sg->max_num_rows;
-            return round0_staged_grid(widest, log_lifted) * (uint32_t)sg->host.size();
-        };
-        auto r0_enqueue = [&](const DevStaged &staged, const StagedGroups *sg, const Fp *lde, uint32_t n_cols_total,
-                              uint32_t log_lifted, uint32_t n_cosets, uint32_t n_out, const EF *eq_xi, EF add_const,
-                              EF *partials, size_t slot) {
-            if (!r0_batchable(staged, log_lifted)) return false;
-            R0Job j{};
-            j.prog = sg ? sg->host[0] : staged;
-            j.lde = lde, j.eq_xi = eq_xi, j.partials = partials, j.out = mb.slot_ptr(slot);
-            j.add_const = add_const, j.n_cols_total = n_cols_total, j.log_lifted = log_lifted, j.n_cosets = n_cosets;
-            j.gx = r0_job_grid(staged, sg, log_lifted);
-            j.n_groups = sg ? (uint32_t)sg->host.size() : 1;
-            j.gx_group = j.gx / j.n_groups;
-            j.lds_rows = sg ? sg->max_num_rows : staged.num_rows;
-            j.progs = sg ? sg->descs.p : nullptr;
-            r0_groups[j.prog.rows == 4 ? 2 : j.prog.rows == 2 ? 1 : 0][n_out - 1].push_back(j);
-            return true;
-        };
-        size_t next_slot = 0;
-        auto d_xi = cx.upload(xi);
-        if (early.in_flight) {  // the early LDEs: round 0's kernels on the caller's stream come after them
-            OVM_THROW_IF(hipStreamWaitEvent(cx.stream, side_stream().join, 0));
-            early.in_flight = false;
-        }
-        // zerocheck_save_memory: the slab of every trace. Each slab's sums get mailbox slots of their own (all traces
-        // are enqueued before the one wait), so the configured slab size is a LOWER bound: while the slabs of all
-        // traces together would not fit the mailbox, the trace with the most slabs gets slabs twice as large.
-        std::vector<unsigned> slab_logs(T, 0);
-        {
-            const ProverConfig &pcfg = prover_config();
-            std::vector<size_t> per_slab(T, 0);
-            auto round64 = [](size_t x) { return (x + 63) & ~size_t(63); };
-            for (size_t t = 0; t < T; t++) {
-                slab_logs[t] = tv[t].log_lifted;
-                if (!mine(t)) continue;
-                const unsigned cdeg = air(t).max_constraint_degree;
-                const unsigned zc = cdeg ? cdeg - 1 : 0, lg = air(t).interactions.empty() ? 0 : cdeg;
-                per_slab[t] = (zc ? round64(zc * N) : 0) + (lg ? round64(lg * 2 * N) : 0);
-                if (pcfg.zerocheck_save_memory) slab_logs[t] = std::min(tv[t].log_lifted, std::max(pcfg.round0_slab_log_rows, l_skip));
-            }
-            const size_t budget = Mailbox::SLOTS - (4 * MAX_COSETS * N + 128);
-            for (;;) {
-                size_t total = 0, worst = T;
-                for (size_t t = 0; t < T; t++) {
-                    total += per_slab[t] << (tv[t].log_lifted - slab_logs[t]);
-                    if (per_slab[t] && slab_logs[t] < tv[t].log_lifted &&
-                        (worst == T || tv[t].log_lifted - slab_logs[t] > tv[worst].log_lifted - slab_logs[worst]))
-                        worst = t;
-                }
-                if (total <= budget || worst == T) break;
-                slab_logs[worst]++;
-            }
-        }
-        for (size_t t = 0; t < T; t++) {
-            if (!mine(t)) continue;
-            const AirKey &a = air(t);
-            TraceView &v = tv[t];
-            Round0Job &job = jobs[t];
-            unsigned cdeg = a.max_constraint_degree;
-            job.cdeg = cdeg;
-            // eq(xi_3, b) per interaction
-            for (size_t k = 0; k < a.interactions.size(); k++) {
-                const Slice &s = ilayout.cols[ilayout.mat_starts[t] + k].slice;
-                size_t b_int = s.row_idx >> (l_skip + v.n_lift);
-                EF e = EF::one();
-                for (unsigned j = l_skip + v.n_lift; j < l_skip + n_logup; j++) {
-                    e = e * eq1b(xi[j], b_int & 1);
-                    b_int >>= 1;
-                }
-                tp[t].eq3b.push_back(e);
-            }
-            HostTime ht_trace("round0.per_trace_setup");
-            {
-                tp[t].zc_w = lambda_pows;
-                tp[t].zc = std::make_unique<ProgDev>(make_prog(std::move(progs[t].zc), lambda_pows, true, v.log_lifted, 1));
-                if (v.n_lift > 0)
-                    tp[t].zc_g = make_grouped(std::move(progs[t].zc_g));
-            }
-            if (!a.interactions.empty()) {
-                std::vector<EF> wts;  // in the order roots_logup numbers them
-                for (size_t k = 0; k < a.interactions.size(); k++) {
-                    const Interaction &it = a.interactions[k];
-                    for (size_t j = 0; j < it.message.size(); j++) wts.push_back(tp[t].eq3b[k] * beta_pows[j]);
-                    wts.push_back(tp[t].eq3b[k]);
-                    tp[t].lg_const += tp[t].eq3b[k] * (beta_pows[it.message.size()] * fp((uint64_t)it.bus_index + 1));
-                }
-                tp[t].lg_w = wts;
-                tp[t].lg = std::make_unique<ProgDev>(make_prog(std::move(progs[t].lg), wts, true, v.log_lifted, 2));
-                if (v.n_lift > 0)
-                    tp[t].lg_g = make_grouped(std::move(progs[t].lg_g));
-            }
-            job.zc_cosets = cdeg ? cdeg - 1 : 0;
-            job.lg_cosets = tp[t].lg ? cdeg : 0;
-            const unsigned n_cosets = std::max(job.zc_cosets, job.lg_cosets);
-            if (n_cosets > MAX_COSETS) throw OvmFail(801, "constraint degree too large");
-            if (!n_cosets) continue;
-            // eq(xi[l_skip..l_skip+n_lift], x)
-            job.d_eq.alloc(size_t(1) << v.n_lift);
-            OVM_THROW_IF(eq_table(d_xi.p + l_skip, v.n_lift, job.d_eq.p, cx.stream));
-            EarlyLde &early_t = early.per_trace[t];
-            const bool lde_done = early_t.done && early_t.n_cosets == n_cosets;
-            const std::vector<uint32_t> used =
-                lde_done ? early_t.used : used_columns(t, tp[t].zc->prog.used_cols, tp[t].lg ? &tp[t].lg->prog.used_cols : nullptr);
-            if (lde_done) job.d_used = std::move(early_t.d_used);
-            else job.d_used = cx.upload(used);
-            // zerocheck_save_memory: a tall trace is extended and evaluated in slabs of 2^slab rows -- the LDE buffer
-            // (n_cosets x columns x rows words: 3.5 GB at config D, 14 GB at config E) shrinks to one slab; the slab
-            // sums are linear and are added up on the host. (The chunks of 2^l_skip rows are independent.)
-            const unsigned slab_log = slab_logs[t];
-            job.n_slabs = 1u << (v.log_lifted - slab_log);
-            if (lde_done) job.lde = std::move(early_t.lde);
-            else job.lde.alloc((size_t)n_cosets * v.cm.total << slab_log);
-            const size_t red_blocks = std::min<size_t>(RED_BLOCKS, ((size_t(1) << slab_log) + RED_THREADS - 1) / RED_THREADS);
-            const bool batch_zc = job.zc_cosets && job.n_slabs == 1 && r0_batchable(tp[t].zc->staged, v.log_lifted);
-            const bool batch_lg = job.lg_cosets && job.n_slabs == 1 && r0_batchable(tp[t].lg->staged, v.log_lifted);
-            if (job.zc_cosets) {
-                if (batch_zc && tp[t].zc_g && tp[t].zc_g->gp.off.size() - 1 >= r0_groups_min)
-                    tp[t].zc_sg = make_staged_groups(tp[t].zc_g->gp, tp[t].zc_w, v.log_lifted, 1,
-                                                     R0_GROUP_JOB_WGS / round0_staged_grid(tp[t].zc->staged, v.log_lifted));
-                const size_t zc_records = std::max<size_t>(red_blocks, batch_zc ? r0_job_grid(tp[t].zc->staged, tp[t].zc_sg.get(), v.log_lifted) : 0);
-                job.zc_partials.alloc(zc_records * job.zc_cosets * N + 64);
-                job.zc_slot = next_slot;
-                job.zc_stride = (job.zc_cosets * N + 63) & ~size_t(63);
-                next_slot += job.zc_stride * job.n_slabs;
-            }
-            if (job.lg_cosets) {
-                if (batch_lg && tp[t].lg_g && tp[t].lg_g->gp.off.size() - 1 >= r0_groups_min)
-                    tp[t].lg_sg = make_staged_groups(tp[t].lg_g->gp, tp[t].lg_w, v.log_lifted, 2,
-                                                     R0_GROUP_JOB_WGS / round0_staged_grid(tp[t].lg->staged, v.log_lifted));
-                const size_t lg_records = std::max<size_t>(red_blocks, batch_lg ? r0_job_grid(tp[t].lg->staged, tp[t].lg_sg.get(), v.log_lifted) : 0);
-                job.lg_partials.alloc(lg_records * job.lg_cosets * 2 * N + 64);
-                job.lg_slot = next_slot;
-                job.lg_stride = (job.lg_cosets * 2 * N + 63) & ~size_t(63);
-                next_slot += job.lg_stride * job.n_slabs;
-            }
-            if (next_slot + 4 * MAX_COSETS * N + 128 > Mailbox::SLOTS) throw OvmFail(801, "too many traces for the round-0 mailbox");
-            for (uint32_t sb = 0; sb < job.n_slabs; sb++) {
-                const uint64_t row0 = (uint64_t)sb << slab_log;
-                const EF *eq_slab = job.d_eq.p + (row0 >> l_skip);
-                if (!lde_done) {
-                    OVM_PROF("round0.coset_lde", cx.stream);
-                    OVM_THROW_IF(coset_lde(v.cols.p, job.d_used.p, (uint32_t)used.size(), (uint32_t)v.cm.total, slab_log, l_skip,
-                                           n_cosets, d_sp_all.p, job.lde.p, cx.stream, row0));
-                }
-                if (job.zc_cosets) {
-                    OVM_PROF("round0.zerocheck", cx.stream);
-                    const size_t slot = job.zc_slot + sb * job.zc_stride;
-                    if (!(batch_zc && r0_enqueue(tp[t].zc->staged, tp[t].zc_sg.get(), job.lde.p, (uint32_t)v.cm.total, v.log_lifted, job.zc_cosets, 1,
-                                                 job.d_eq.p, EF::zero(), job.zc_partials.p, slot)))
-                        OVM_THROW_IF(round0_eval(tp[t].zc->dev(), tp[t].zc->staged, job.lde.p, (uint32_t)v.cm.total, slab_log, l_skip,
-                                                 job.zc_cosets, 1, eq_slab, EF::zero(), mb.arm(job.zc_partials.p, slot), cx.stream));
-                }
-                if (job.lg_cosets) {
-                    OVM_PROF("round0.logup", cx.stream);
-                    const size_t slot = job.lg_slot + sb * job.lg_stride;
-                    if (!(batch_lg && r0_enqueue(tp[t].lg->staged, tp[t].lg_sg.get(), job.lde.p, (uint32_t)v.cm.total, v.log_lifted, job.lg_cosets, 2,
-                                                 job.d_eq.p, tp[t].lg_const, job.lg_partials.p, slot)))
-                        OVM_THROW_IF(round0_eval(tp[t].lg->dev(), tp[t].lg->staged, job.lde.p, (uint32_t)v.cm.total, slab_log, l_skip,
-                                                 job.lg_cosets, 2, eq_slab, tp[t].lg_const, mb.arm(job.lg_partials.p, slot), cx.stream));
-                }
-            }
-            if (next_slot + 4 * MAX_COSETS * N + 128 > Mailbox::SLOTS) throw OvmFail(801, "too many traces for the round-0 mailbox");
-        }
-        DevBuf<uint32_t> r0_counters(2 * T + 8);
-        {
-            size_t n_batched = 0;
-            for (auto &byrows : r0_groups)
-                for (auto &g : byrows) n_batched += g.size();
-            if (n_batched) {
-                OVM_PROF("round0.batched", cx.stream);
-                OVM_THROW_IF(hipMemsetAsync(r0_counters.p, 0, (2 * T + 8) * sizeof(uint32_t), cx.stream));
-                size_t counter_off = 0;
-                for (int lr = 0; lr < 3; lr++)
-                    for (int no = 0; no < 2; no++) {
-                        std::vector<R0Job> &g = r0_groups[lr][no];
-                        if (g.empty()) continue;
-                        uint32_t wg = 0;
-                        for (auto &j : g) {
-                            j.wg0 = wg;
-                            wg += j.gx;
-                        }
-                        auto d_jobs = cx.upload(g);
-                        OVM_THROW_IF(round0_eval_batched(d_jobs.p, g.data(), (uint32_t)g.size(), 1u << lr, (uint32_t)no + 1, l_skip,
-                                                         r0_counters.p + counter_off, mb.arm(nullptr, 0), cx.stream));
-                        counter_off += g.size() + 1;
-                    }
-            }
-        }
-        if (next_slot) mb.wait(cx.stream);
-        for (size_t t = 0; t < T; t++) {
-            if (!mine(t)) continue;
-            Round0Job &job = jobs[t];
-            TraceView &v = tv[t];
-            const unsigned cdeg = job.cdeg;
-            if (job.zc_cosets) {
-                auto ev = mb.read(job.zc_slot, (size_t)job.zc_cosets * N);
-                for (uint32_t sb = 1; sb < job.n_slabs; sb++) {
-                    const auto more = mb.read(job.zc_slot + sb * job.zc_stride, (size_t)job.zc_cosets * N);
-                    for (size_t i = 0; i < ev.size(); i++) ev[i] += more[i];
-                }
-                std::vector<std::vector<EF>> ce(job.zc_cosets, std::vector<EF>(N));
-                for (unsigned k = 0; k < job.zc_cosets; k++) {
-                    Fp zinv = (g.pow(k + 1).exp_power_of_2(l_skip) - Fp::one()).inv();
-                    for (size_t z = 0; z < N; z++) ce[k][z] = ev[k * N + z] * zinv;
-                }
-                std::vector<EF> q = from_coset_evals(ce, l_skip);
-                unsigned deg = cdeg * (unsigned)(N - 1);
-                std::vector<EF> coeffs(deg + 1);
-                for (size_t i = 0; i <= deg; i++) {
-                    EF c = i < q.size() ? -q[i] : EF::zero();
-                    if (i >= N && i - N < q.size()) c += q[i - N];
-                    coeffs[i] = c;
-                }
-                sp0[2 * T + t] = std::move(coeffs);
-            } else if (cdeg != 0 && !job.lg_cosets) {
-                sp0[2 * T + t] = std::vector<EF>(cdeg * (N - 1) + 1, EF::zero());
-            }
-            if (job.lg_cosets) {
-                auto ev = mb.read(job.lg_slot, (size_t)job.lg_cosets * 2 * N);
-                for (uint32_t sb = 1; sb < job.n_slabs; sb++) {
-                    const auto more = mb.read(job.lg_slot + sb * job.lg_stride, (size_t)job.lg_cosets * 2 * N);
-                    for (size_t i = 0; i < ev.size(); i++) ev[i] += more[i];
-                }
-                std::vector<std::vector<EF>> cn(job.lg_cosets, std::vector<EF>(N)), cden(job.lg_cosets, std::vector<EF>(N));
-                for (unsigned k = 0; k < job.lg_cosets; k++)
-                    for (size_t z = 0; z < N; z++) {
-                        cn[k][z] = ev[(k * 2 + 0) * N + z];
-                        cden[k][z] = ev[(k * 2 + 1) * N + z];
-                    }
-                Fp norm = fp(uint64_t(1) << (v.log_lifted - v.log_height)).inv();
-                std::vector<EF> pn = from_coset_evals(cn, l_skip), pd = from_coset_evals(cden, l_skip);
-                for (auto &x : pn) x = x * norm;
-                sp0[2 * t] = std::move(pn);
-                sp0[2 * t + 1] = std::move(pd);
-            }
-            job = Round0Job();  // release the LDE and scratch buffers
-        }
-
-        // (sharded: the coefficient vectors of a trace come from its owner)
-        share_vectors(sp0, [&](size_t i) { return owner[i < 2 * T ? i / 2 : i - 2 * T]; });
-        wt.mark("rap.round0");
-        if (wt.on) HostTime::report();
-        // ---- s_0 assembly (host) ----
-        const unsigned s_deg = cdeg_global + 1;
-        S0 s0r = assemble_s0(sp0, xi);
-        const std::vector<EF> &numer_terms = s0r.numer_terms, &denom_terms = s0r.denom_terms, &mu_pows = s0r.mu_pows, &s0 = s0r.s0;
-        std::vector<EF> r;
-        EF r0 = ts.sample_ext();
-        r.push_back(r0);
-        EF prev_s = horner(s0, r0);
-
-        wt.mark("rap.s0_host");
-        // ---- fold at r_0 ----
-        {
-            // barycentric weights: L_z(r) = omega^z (r^N - 1) / (N (r - omega^z))
-            EF rn = r0.exp_power_of_2(l_skip) - Fp::one();
-            Fp ninv = fp(N).inv();
-            std::vector<EF> wts(N);
-            for (size_t z = 0; z < N; z++) wts[z] = rn * (r0 - omega_pows[z]).inv() * (omega_pows[z] * ninv);
-            auto d_w = cx.upload(wts);
-            OVM_PROF("constraints.fold_ple", cx.stream);
-            for (size_t t = 0; t < T; t++) {
-                if (!mine(t)) continue;
-                TraceView &v = tv[t];
-                size_t h = size_t(1) << v.n_lift;
-                v.mats_a.alloc(v.cm.total * h);
-                v.mats_b.alloc(v.cm.total * std::max<size_t>(h / 2, 1));
-                OVM_THROW_IF(fold_ple(v.cols.p, v.twins.p, (uint32_t)v.cm.total, v.log_lifted, l_skip, d_w.p, v.mats_a.p, cx.stream));
-                v.cur_log_h = v.n_lift;
-                v.mats_in_a = true;
-                if (v.n_lift == 0) v.final_row = cx.download(v.mats_a.p, v.cm.total);
-            }
-        }
-        std::vector<EF> eq_ns{eq_uni(l_skip, xi[0], r0)};
-        EF eq_sharp0 = EF::zero();
-        {
-            std::vector<EF> eqx = eq_hypercube(std::vector<EF>(xi.begin(), xi.begin() + l_skip));
-            for (size_t z = 0; z < N; z++) eq_sharp0 += eq_uni(l_skip, r0, ef(omega_pows[z])) * eqx[z];
-        }
-        std::vector<EF> eq_sharp_ns{eq_sharp0};
-
-        wt.mark("rap.fold_ple");
-        // ---- MLE rounds ----
-        std::vector<EF> zc_tilde(T, EF::zero());
-        std::vector<std::array<EF, 2>> lg_tilde(T, {EF::zero(), EF::zero()});
-        std::vector<std::vector<EF>> round_polys;
-        // one eq table per distinct trace height and round (shared by all traces of that height);
-        // per trace and program its own partial-sum scratch and 8 mailbox slots
-        std::vector<DevBuf<EF>> d_eqr_by_nlift(n_max + 1);
-        std::vector<DevBuf<EF>> mle_partials(2 * T);
-        for (size_t t = 0; t < T; t++) {
-            if (tv[t].n_lift == 0 || !mine(t)) continue;
-            if (!d_eqr_by_nlift[tv[t].n_lift].p) d_eqr_by_nlift[tv[t].n_lift].alloc(size_t(1) << tv[t].n_lift);
-            // records of 8 sums per (workgroup, group); the batched kernel's lanes enumerate (pair, point), so it can
-            // run up to `degree` times the workgroups of the per-pair kernels
-            const size_t wgs = std::min<size_t>(RED_BLOCKS, (((size_t)cdeg_global << (tv[t].n_lift - 1)) + RED_THREADS - 1) / RED_THREADS);
-            // (every launcher keeps workgroups x groups within RED_BLOCKS records, or one workgroup per group)
-            auto records = [&](size_t groups) { return std::min(wgs * groups, std::max<size_t>(RED_BLOCKS, groups)); };
-            mle_partials[2 * t].alloc(records(tp[t].zc_g->gp.off.size() - 1) * 8 + 64);
-            if (!air(t).interactions.empty()) mle_partials[2 * t + 1].alloc(records(tp[t].lg_g->gp.off.size() - 1) * 8 + 64);
-        }
-        if (16 * T + 64 > Mailbox::SLOTS) throw OvmFail(801, "too many traces for the MLE-round mailbox");
-        // Jobs of at most MLE_BATCH_MAX_WGS workgroups go into one launch per round (the late rounds
-        // of a many-AIR proof are otherwise dozens of tiny launches serialised by the stream).
-        // (OVM_MLE_BATCH=0 launches every job on its own: parity tests of the unbatched kernels on small traces)
-        const uint32_t MLE_BATCH_MAX_WGS = tuning().mle_batch_wgs;  // (0: no batching)
-        // (two batches per round: the (pair, point)-per-lane kernel for the short jobs and the LDS-slot kernel for jobs of at
-        // least 2^mle_batch_lds_min_log pairs; each with its own arrival counters)
-        DevBuf<uint32_t> mle_counters(2 * (2 * T + 1));
-        OVM_THROW_IF(hipMemsetAsync(mle_counters.p, 0, 2 * (2 * T + 1) * sizeof(uint32_t), cx.stream));
-        const uint32_t batch_lds_min_log = tuning().mle_batch_lds_min_log;
-        OVM_PROF("constraints.mle_rounds", cx.stream);
-        for (unsigned round = 1; round <= n_max; round++) {
-            EF r_prev = r[round - 1];
-            std::vector<std::vector<EF>> sp(3 * T);
-            // phase A: enqueue the round sums of every trace that still has rows to fold
-            std::vector<char> eq_done(n_max + 1, 0);
-            bool any_launch = false;
-            std::vector<MleJob> jobs, jobs_lds;
-            auto enqueue = [&](const GroupedDev &gd, const EF *weights, const EF *mats, unsigned log_h, uint32_t n_out,
-                               const EF *eq, EF add_const, EF *partials, size_t partials_cap, size_t slot) {
-                const uint32_t n_groups = (uint32_t)gd.gp.off.size() - 1;
-                const bool lds = log_h > batch_lds_min_log && mle_lds_eligible(gd.gp.max_slots, cdeg_global);
-                const uint32_t gx = lds ? mle_round_gx(log_h, cdeg_global, n_groups, true) : mle_round_batched_gx(log_h, cdeg_global, n_groups);
-                if (gx * n_groups <= MLE_BATCH_MAX_WGS) {
-                    std::vector<MleJob> &into = lds ? jobs_lds : jobs;
-                    MleJob j{};
-                    j.code = gd.code.p, j.off = gd.off.p, j.weights = weights, j.mats = mats, j.eq = eq;
-                    j.partials = partials, j.out = mb.slot_ptr(slot), j.add_const = add_const;
-                    j.log_h = log_h, j.n_out = n_out, j.n_groups = n_groups, j.gx = gx;
-                    j.z0 = into.empty() ? 0 : into.back().z0 + into.back().n_groups;
-                    j.max_slots = gd.gp.max_slots;
-                    j.partials_cap = (uint32_t)partials_cap;
-                    into.push_back(j);
-                } else {
-                    OVM_THROW_IF(mle_round_eval_grouped(gd.code.p, gd.off.p, n_groups, gd.gp.max_slots, weights, mats, log_h,
-                                                        cdeg_global, n_out, eq, add_const, mb.arm(partials, slot), cx.stream));
-                }
-            };
-            for (size_t t = 0; t < T; t++) {
-                TraceView &v = tv[t];
-                if (round > v.n_lift || !mine(t)) continue;
-                const bool has_int = !air(t).interactions.empty();
-                const unsigned log_num_y = v.n_lift - round;
-                DevBuf<EF> &d_eqr = d_eqr_by_nlift[v.n_lift];
-                if (!eq_done[v.n_lift]) {
-                    // eq over xi[l_skip + round .. l_skip + n_lift]
-                    OVM_THROW_IF(eq_table(d_xi.p + l_skip + round, log_num_y, d_eqr.p, cx.stream));
-                    eq_done[v.n_lift] = 1;
-                }
-                const EF *mats = v.mats_in_a ? v.mats_a.p : v.mats_b.p;
-                enqueue(*tp[t].zc_g, tp[t].zc->weights.p, mats, v.cur_log_h, 1, d_eqr.p, EF::zero(), mle_partials[2 * t].p, mle_partials[2 * t].n, 16 * t);
-                if (has_int)
-                    enqueue(*tp[t].lg_g, tp[t].lg->weights.p, mats, v.cur_log_h, 2, d_eqr.p, tp[t].lg_const,
-                            mle_partials[2 * t + 1].p, mle_partials[2 * t + 1].n, 16 * t + 8);
-                any_launch = true;
-            }
-            if (!jobs_lds.empty()) {
-                auto d_jobs = cx.upload(jobs_lds);
-                OVM_THROW_IF(mle_round_eval_batched_lds(d_jobs.p, jobs_lds.data(), (uint32_t)jobs_lds.size(), cdeg_global,
-                                                        mle_counters.p + (2 * T + 1), mb.arm(nullptr, 0), cx.stream));
-            }
-            if (!jobs.empty()) {  // armed last: its flag means every reduction of the round is done
-                auto d_jobs = cx.upload(jobs);
-                OVM_THROW_IF(mle_round_eval_batched(d_jobs.p, jobs.data(), (uint32_t)jobs.size(), cdeg_global, mle_counters.p,
-                                                    mb.arm(nullptr, 0), cx.stream));
-            }
-            // While the round's kernels run: the traces that have just run out of rows (their last row came back with the
-            // previous round's fold) are evaluated on the host -- the whole constraint program on one row of extension-field
-            // values, 50-500 us for the wide AIRs of a reth segment, which used to happen after the wait, device idle.
-            for (size_t t = 0; t < T; t++) {
-                if (!mine(t) || round != tv[t].n_lift + 1) continue;
-                TraceView &v = tv[t];
-                const bool has_int = !air(t).interactions.empty();
-                const Fp norm = fp(uint64_t(1) << (v.log_lifted - v.log_height)).inv();
-                EF o[2];
-                host_eval(tp[t].zc->prog, tp[t].zc_w, v.final_row, EF::zero(), o);
-                zc_tilde[t] = eq_ns.back() * o[0];
-                if (has_int) {
-                    host_eval(tp[t].lg->prog, tp[t].lg_w, v.final_row, tp[t].lg_const, o);
-                    lg_tilde[t] = {eq_sharp_ns.back() * o[0] * norm, eq_sharp_ns.back() * o[1]};
-                }
-            }
-            if (any_launch) mb.wait(cx.stream);
-            // phase B: host (the owner of a trace evaluates its round polynomials; sharded: then all-gathered)
-            for (size_t t = 0; t < T; t++) {
-                if (!mine(t)) continue;
-                TraceView &v = tv[t];
-                const AirKey &a = air(t);
-                bool has_int = !a.interactions.empty();
-                Fp norm = fp(uint64_t(1) << (v.log_lifted - v.log_height)).inv();
-                if (round > v.n_lift) {
-                    if (round == v.n_lift + 1) {
-                        // (evaluated above, while the device was busy)
-                    } else {
-                        zc_tilde[t] *= r_prev;
-                        lg_tilde[t][0] *= r_prev;
-                        lg_tilde[t][1] *= r_prev;
-                    }
-                    sp[2 * T + t] = {zc_tilde[t]};
-                    sp[2 * t] = has_int ? std::vector<EF>{lg_tilde[t][0]} : std::vector<EF>(cdeg_global, EF::zero());
-                    sp[2 * t + 1] = has_int ? std::vector<EF>{lg_tilde[t][1]} : std::vector<EF>(cdeg_global, EF::zero());
-                } else {
-                    auto ev = mb.read(16 * t, 8);
-                    sp[2 * T + t].resize(cdeg_global);
-                    for (unsigned i = 0; i < cdeg_global; i++) sp[2 * T + t][i] = ev[2 * i];
-                    if (has_int) {
-                        auto e2 = mb.read(16 * t + 8, 8);
-                        sp[2 * t].resize(cdeg_global);
-                        sp[2 * t + 1].resize(cdeg_global);
-                        for (unsigned i = 0; i < cdeg_global; i++) {
-                            sp[2 * t][i] = e2[2 * i] * norm;
-                            sp[2 * t + 1][i] = e2[2 * i + 1];
-                        }
-                    } else {
-                        sp[2 * t] = std::vector<EF>(cdeg_global, EF::zero());
-                        sp[2 * t + 1] = std::vector<EF>(cdeg_global, EF::zero());
-                    }
-                }
-            }
-            share_vectors(sp, [&](size_t i) { return owner[i < 2 * T ? i / 2 : i - 2 * T]; });
-            size_t tail_start = T;
-            for (size_t t = 0; t < T; t++)
-                if ((int)round > tv[t].n) {
-                    tail_start = t;
-                    break;
-                }
-            std::vector<EF> head_zc(cdeg_global, EF::zero()), head_lg(cdeg_global, EF::zero());
-            EF sp_tail = EF::zero();
-            for (size_t t = 0; t < T; t++) {
-                size_t zi = 2 * T + t, ni = 2 * t, di = 2 * t + 1;
-                if (t < tail_start) {
-                    for (unsigned i = 0; i < cdeg_global; i++) {
-                        head_zc[i] += mu_pows[zi] * sp[zi][i];
-                        head_lg[i] += mu_pows[ni] * sp[ni][i] + mu_pows[di] * sp[di][i];
-                    }
-                } else {
-                    sp_tail += mu_pows[zi] * sp[zi][0] + mu_pows[ni] * sp[ni][0] + mu_pows[di] * sp[di][0];
-                }
-            }
-            std::vector<EF> head(s_deg, EF::zero());
-            for (unsigned i = 0; i < cdeg_global; i++) head[i + 1] = eq_ns[round - 1] * head_zc[i] + eq_sharp_ns[round - 1] * head_lg[i];
-            EF xi_cur = xi[l_skip + round - 1];
-            head[0] = (prev_s - xi_cur * head[1] - sp_tail) * (EF::one() - xi_cur).inv();
-            std::vector<Fp> pts(s_deg);
-            for (unsigned i = 0; i < s_deg; i++) pts[i] = fp(i);
-            std::vector<EF> coeffs = lagrange_coeffs(pts, head);
-            coeffs.push_back(EF::zero());
-            EF b = EF::one() - xi_cur, a2 = xi_cur - b;
-            for (size_t i = s_deg; i-- > 0;) coeffs[i + 1] = a2 * coeffs[i] + b * coeffs[i + 1];
-            coeffs[0] = coeffs[0] * b;
-            coeffs[1] += sp_tail;
-            std::vector<EF> be(s_deg);
-            for (unsigned i = 1; i <= s_deg; i++) {
-                be[i - 1] = horner(coeffs, ef_u64(i));
-                ts.observe_ext(be[i - 1]);
-            }
-            round_polys.push_back(be);
-            EF rr = ts.sample_ext();
-            r.push_back(rr);
-            prev_s = horner(coeffs, rr);
-            {
-                // matrices of at most 2^11 rows fold in one launch per round (as many as fit its grid)
-                std::vector<FoldJob> fj;
-                auto flush_folds = [&] {
-                    if (fj.empty()) return;
-                    if (fj.size() <= FoldJobsArg::MAX) {
-                        OVM_THROW_IF(fold_mle_batched(nullptr, fj.data(), (uint32_t)fj.size(), rr, cx.stream));
-                    } else {
-                        auto d_fj = cx.upload(fj);
-                        OVM_THROW_IF(fold_mle_batched(d_fj.p, fj.data(), (uint32_t)fj.size(), rr, cx.stream));
-                    }
-                    fj.clear();
-                };
-                for (size_t t = 0; t < T; t++) {
-                    TraceView &v = tv[t];
-                    if (v.cur_log_h == 0 || v.cm.total == 0) continue;
-                    const EF *in = v.mats_in_a ? v.mats_a.p : v.mats_b.p;
-                    EF *o = v.mats_in_a ? v.mats_b.p : v.mats_a.p;
-                    if (v.cur_log_h <= 11 && v.cm.total <= 32768) {
-                        const uint32_t y0 = fj.empty() ? 0 : fj.back().y0 + fj.back().n_cols;
-                        if (y0 + v.cm.total > 65535) flush_folds();
-                        fj.push_back(FoldJob{in, o, (uint32_t)v.cm.total, v.cur_log_h, fj.empty() ? 0 : fj.back().y0 + fj.back().n_cols, 0});
-                    } else {
-                        OVM_THROW_IF(fold_mle(in, o, (uint32_t)v.cm.total, v.cur_log_h, rr, cx.stream));
-                    }
-                }
-                flush_folds();
-                for (size_t t = 0; t < T; t++) {
-                    TraceView &v = tv[t];
-                    if (v.cur_log_h == 0) continue;
-                    v.mats_in_a = !v.mats_in_a;
-                    v.cur_log_h--;
-                    if (v.cur_log_h == 0) v.final_row = cx.download(v.mats_in_a ? v.mats_a.p : v.mats_b.p, v.cm.total);
-                }
-            }
-            EF eqr = eq1(xi_cur, rr);
-            eq_ns.push_back(eq_ns[round - 1] * eqr);
-            eq_sharp_ns.push_back(eq_sharp_ns[round - 1] * eqr);
-        }
-
-        wt.mark("rap.mle_rounds");
-        // ---- openings ---- (cpu.rs:644-694, mod.rs:408-424): per trace the parts [common main,
-        // preprocessed?, cached_0, ...], each as (claim, rotated claim) pairs when the AIR needs rotation
-        if (!sh.single()) {
-            std::vector<std::vector<EF>> rows(T);
-            for (size_t t = 0; t < T; t++)
-                if (mine(t)) rows[t] = tv[t].final_row;
-            share_vectors(rows, [&](size_t t) { return owner[t]; });
-            for (size_t t = 0; t < T; t++) {
-                if (rows[t].size() != tv[t].cm.total) throw OvmFail(1, "shard exchange: column openings of the wrong length");
-                tv[t].final_row = std::move(rows[t]);
-            }
-        }
-        std::vector<std::vector<std::vector<EF>>> openings(T);
-        for (size_t t = 0; t < T; t++) {
-            TraceView &v = tv[t];
-            auto part = [&](size_t wd, uint32_t base) {
-                std::vector<EF> o;
-                for (size_t c = 0; c < wd; c++) {
-                    o.push_back(v.final_row[base + c]);
-                    if (v.cm.need_rot) o.push_back(v.final_row[base + wd + c]);
-                }
-                return o;
-            };
-            const size_t n_cached = air(t).cached_widths.size();
-            openings[t].push_back(part(air(t).common_main_width, v.cm.col((uint32_t)n_cached, 0, 0)));
-            if (v.cm.pre_width) openings[t].push_back(part(v.cm.pre_width, v.cm.pre_col(0, 0)));
-            for (size_t k = 0; k < n_cached; k++)
-                openings[t].push_back(part(air(t).cached_widths[k], v.cm.col((uint32_t)k, 0, 0)));
-        }
-        auto observe_part = [&](const std::vector<EF> &o, bool rot) {
-            for (auto &x : o) {
-                ts.observe_ext(x);
-                if (!rot) ts.observe_ext(EF::zero());
-            }
-        };
-        for (size_t t = 0; t < T; t++) observe_part(openings[t][0], tv[t].cm.need_rot);  // common mains first
-        for (size_t t = 0; t < T; t++)
-            for (size_t k = 1; k < openings[t].size(); k++) observe_part(openings[t][k], tv[t].cm.need_rot);
-
-        // batch constraint proof bytes
-        w.e_slice(numer_terms);
-        for (auto &x : denom_terms) w.e(x);
-        w.e_slice(s0);
-        w.usize(round_polys.size());
-        if (!round_polys.empty()) {
-            w.usize(round_polys[0].size());
-            for (auto &rp : round_polys)
-                for (auto &x : rp) w.e(x);
-        }
-        for (size_t t = 0; t < T; t++) {
-            w.usize(openings[t].size());
-            for (auto &o : openings[t]) w.e_slice(o);
-        }
-        section_offsets.push_back(w.buf.size());
-        return r;
-    }
-
-    // -----------------------------------------------------------------------------------------
-    // Stage 3: stacked opening reduction + WHIR (OpeningProver::prove_openings)
-    // -----------------------------------------------------------------------------------------
-    // The commitments of a proof: the common main first, then per trace (sorted order) its preprocessed
-    // commitment (if any) and its cached mains (cpu-backend/src/device.rs:147-172). Layout, root and owner
-    // are known on every rank; the data (`pcs`) only on the owner -- rank 0 for the common main, the owner
-    // of the trace for the others.
-    struct CommitRef {
-        const PcsData *pcs = nullptr;
-        Layout layout;
-        p2::Digest root;
-        uint32_t owner = 0;
-        std::vector<bool> need_rot;  // per stacked matrix
-    };
-    Layout common_main_layout() const {
-        std::vector<std::pair<size_t, unsigned>> meta;
-        for (size_t t = 0; t < traces.size(); t++) meta.push_back({air(t).common_main_width, log2_strict(traces[t].height)});
-        return Layout(P().l_skip, P().l_skip + P().n_stack, meta);
-    }
-    std::vector<CommitRef> gather_commits(const PcsData *common, const p2::Digest &common_root) const {
-        const unsigned l_skip = P().l_skip, lh = l_skip + P().n_stack;
-        std::vector<CommitRef> commits(1);
-        commits[0].pcs = common;
-        commits[0].layout = common_main_layout();
-        commits[0].root = common_root;
-        commits[0].owner = 0;
-        for (size_t t = 0; t < traces.size(); t++) commits[0].need_rot.push_back(air(t).need_rot);
-        for (size_t t = 0; t < traces.size(); t++) {
-            const unsigned log_h = log2_strict(traces[t].height);
-            if (air(t).preprocessed_width) {
-                if (!pre_of(t)) throw OvmFail(1, "preprocessed commitment missing");
-                CommitRef c;
-                c.pcs = mine(t) ? pre_of(t) : nullptr;
-                c.layout = Layout(l_skip, lh, {{air(t).preprocessed_width, log_h}});
-                c.root = pre_of(t)->root;
-                c.owner = owner[t];
-                c.need_rot = {air(t).need_rot};
-                commits.push_back(std::move(c));
-            }
-            if (traces[t].cached_roots.size() != air(t).cached_widths.size()) throw OvmFail(1, "cached main partitions: wrong count");
-            for (size_t k = 0; k < air(t).cached_widths.size(); k++) {
-                CommitRef c;
-                c.pcs = mine(t) ? traces[t].cached[k] : nullptr;
-                c.layout = Layout(l_skip, lh, {{air(t).cached_widths[k], log_h}});
-                c.root = traces[t].cached_roots[k];
-                c.owner = owner[t];
-                c.need_rot = {air(t).need_rot};
-                commits.push_back(std::move(c));
-            }
-        }
-        for (auto &c : commits)
-            if (c.owner == sh.rank && (!c.pcs || c.pcs->log_height != lh || c.pcs->layout.width != c.layout.width))
-                throw OvmFail(1, "commitment missing or of a different stacked shape");
-        return commits;
-    }
-    // v += the same vector of every other rank (sharded proving; identity on one rank)
-    void share_sum(std::vector<EF> &v) {
-        if (sh.single() || v.empty()) return;
-        std::vector<EF> all(v.size() * sh.world);
-        sh.allgather(v.data(), all.data(), v.size() * sizeof(EF));
-        for (size_t i = 0; i < v.size(); i++) {
-            EF acc = EF::zero();
-            for (uint32_t r = 0; r < sh.world; r++) acc += all[r * v.size() + i];
-            v[i] = acc;
-        }
-    }
-
-    // Opened rows of one initial commitment at WHIR round-0 query indices (whir.rs: the rows {i + t * query_stride} of
-    // query i; physical order, see merkle.hip): vals[(q * 2^k + t) * width + c].
-    void open_rows(const PcsData &pcs, const std::vector<uint64_t> &qidx, unsigned lq, std::vector<Fp> &vals) {
-        const unsigned k_whir = P().k_whir;
-        std::vector<uint64_t> rows;
-        for (uint64_t i : qidx) {
-            uint64_t grp = bitrev64(i, lq);
-            for (uint64_t t = 0; t < (1ull << k_whir); t++) rows.push_back((grp << k_whir) + bitrev64(t, k_whir));
-        }
-        const size_t cw = pcs.layout.width;
-        auto d_rows = cx.upload(rows);
-        DevBuf<Fp> d_vals(std::max<size_t>(rows.size() * cw, 1));
-        const Fp *codeword = pcs.codeword.p;
-        DevBuf<Fp> recomputed;
-        if (!codeword) {  // cache_rs_code_matrix = false at commit time: encode again (one NTT of the commitment)
-            OVM_PROF("whir.reencode", cx.stream);
-            recomputed.alloc(cw << pcs.log_rows);
-            OVM_THROW_IF(ovm_hip_ntt_dif((const uint32_t *)pcs.msg.p, (uint32_t *)recomputed.p, cw, pcs.log_rows, pcs.log_height, cx.stream));
-            codeword = recomputed.p;
-        }
-        OVM_THROW_IF(ovm_hip_gather_rows((const uint32_t *)codeword, cw, 1ull << pcs.log_rows, 1, d_rows.p, rows.size(),
-                                         (uint32_t *)d_vals.p, cx.stream));
-        vals = cx.download(d_vals.p, rows.size() * cw);
-    }
-    // Where the Merkle-path siblings of the queries live, in proof order (query-major, bottom layer first): the
-    // sibling of query i at stored layer j is entry (i >> j) ^ 1, at physical position bitrev of it (merkle.hip).
-    // A tree built by one rank holds them all; in a tree built by dist_n ranks together (build_tree) the entry at
-    // physical position p of a layer with more than dist_n entries is in rank p mod dist_n's share at compact
-    // position p / dist_n, and the layers of at most dist_n entries are the host copy `top`.
-    struct PathRef {
-        int rank;      // -1: pcs.top[idx] (host, every rank); else: layers[idx] on that rank
-        uint64_t idx;
-    };
-    std::vector<PathRef> path_refs(const PcsData &pcs, int owner_rank, const std::vector<uint64_t> &qidx, unsigned lq) const {
-        const uint32_t n = pcs.dist_n;
-        const uint64_t qs_share = (1ull << lq) / n;
-        std::vector<PathRef> refs;
-        for (uint64_t i : qidx)
-            for (unsigned j = 0; j < lq; j++) {
-                const uint64_t size = 1ull << (lq - j), p = bitrev64((i >> j) ^ 1, lq - j);
-                if (n > 1 && size <= n) {
-                    refs.push_back({-1, (2ull * n - 2 * size) + p});
-                } else {
-                    uint64_t off = 0;
-                    for (unsigned m2 = 0; m2 < j; m2++) off += qs_share >> m2;
-                    refs.push_back({n > 1 ? (int)(p % n) : owner_rank, off + p / n});
-                }
-            }
-        return refs;
-    }
-    // the digests of `refs` that live in THIS rank's layers, in order
-    std::vector<p2::Digest> serve_paths(const PcsData &pcs, const std::vector<PathRef> &refs) {
-        std::vector<uint64_t> idx;
-        for (auto &r : refs)
-            if (r.rank == (int)sh.rank) idx.push_back(r.idx);
-        if (idx.empty()) return {};
-        auto d_idx = cx.upload(idx);
-        DevBuf<p2::Digest> d_dig(idx.size());
-        OVM_THROW_IF(ovm_hip_gather_digests((const uint32_t *)pcs.layers.p, d_idx.p, idx.size(), (uint32_t *)d_dig.p, cx.stream));
-        return cx.download(d_dig.p, idx.size());
-    }
-
-    // OpeningProver::prove_openings = the stacked opening reduction, then WHIR (the reference has the same two
-    // steps: prove_stacked_opening_reduction, prover/stacked_reduction.rs:65-128, and prove_whir_opening,
-    // prover/whir.rs:78-341). `common_main`: the common-main PCS data (sharded: on rank 0 only, null elsewhere);
-    // its root is known everywhere.
-    void prove_openings(const PcsData *common_main, const p2::Digest &common_root, const std::vector<EF> &r) {
-        const std::vector<CommitRef> commits = gather_commits(common_main, common_root);
-        // the stacked matrices of all commitments side by side: commitment c owns columns [coff[c], coff[c+1])
-        std::vector<size_t> coff{0};
-        for (auto &c : commits) coff.push_back(coff.back() + c.layout.width);
-        const std::vector<EF> u = prove_stacked_reduction(commits, coff, r);
-        wt.mark("openings.stacked");
-        prove_whir(commits, coff, u);
-    }
-
-    // Returns the sumcheck point u (u[0] for the univariate round, then one entry per stacked round).
-    std::vector<EF> prove_stacked_reduction(const std::vector<CommitRef> &commits, const std::vector<size_t> &coff_in,
-                                            const std::vector<EF> &r) {
-        const unsigned l_skip = P().l_skip, n_stack = P().n_stack;
-        const size_t N = size_t(1) << l_skip, H = size_t(1) << (l_skip + n_stack);
-        auto own = [&](size_t com) { return commits[com].owner == sh.rank; };
-        // this rank holds the columns of ITS commitments, side by side, at [loff[c], loff[c] + width_c)
-        const std::vector<size_t> &coff = coff_in;
-        std::vector<size_t> loff(commits.size(), 0);
-        size_t lwidth = 0;
-        for (size_t com = 0; com < commits.size(); com++) {
-            if (own(com)) {
-                loff[com] = lwidth;
-                lwidth += commits[com].layout.width;
-            }
-        }
-        const size_t width = coff.back();
-        ByteWriter &w = out;
-        const Fp g = fp(bb::GENERATOR), omega_skip = bb::two_adic_generator(l_skip);
-        std::vector<Fp> omega_pows = powers_of(omega_skip, N);
-
-        EF lambda = ts.sample_ext();
-        struct TV {
-            size_t com;
-            Slice s;
-            size_t leq;
-            long lrot;
-        };
-        std::vector<TV> tvs;
-        size_t li = 0;
-        for (size_t com = 0; com < commits.size(); com++)
-            for (auto &sc : commits[com].layout.cols) {
-                TV t{com, sc.slice, li, -1};
-                li++;
-                if (commits[com].need_rot[sc.mat_idx]) t.lrot = (long)li;
-                li++;
-                tvs.push_back(t);
-            }
-        std::vector<EF> lam = powers_of(lambda, li);
-        // windows: runs of slices of one height inside one commitment (contiguous in that stacked matrix)
-        std::vector<size_t> win;
-        for (size_t i = 0; i < tvs.size(); i++)
-            if (i == 0 || tvs[i].s.log_height != tvs[i - 1].s.log_height || tvs[i].com != tvs[i - 1].com) win.push_back(i);
-        win.push_back(tvs.size());
-        const size_t W = win.size() - 1;
-        const EF r0 = r[0];
-        const EF eq_const = eq_uni_at_one(l_skip, r0 * omega_skip);
-
-        struct Window {
-            unsigned log_height, n_lift, cur_log_h;
-            int n;
-            DevBuf<EF> eq_cube, vec_a, vec_b;
-            bool in_a = true, own = false;
-            EF eq_fin = EF::zero(), krot_fin = EF::zero();
-        };
-        std::vector<Window> ws(W);
-        DevBuf<EF> partials((size_t)RED_BLOCKS * 3 * N + 64);
-        const unsigned s0_deg = 2 * (unsigned)(N - 1);
-        std::vector<EF> s0(s0_deg + 1, EF::zero());
-        ProfScope *ps_st0 = new ProfScope("stacked.round0", cx.stream);
-        // phase A: the round-0 sums of every window are enqueued (own partial records, own mailbox slots);
-        // phase B: one wait, then the host algebra per window
-        // mailbox slots of a window: its 3 N round-0 sums (64 used to be assumed, which 3 * 16 fits: with l_skip >= 5 the
-        // windows of a proof with several of them overwrote each other -- found by the reference's l_skip 6 / 9 tests)
-        const size_t wslots = (3 * N + 63) & ~size_t(63);
-        if (wslots * W + 64 > Mailbox::SLOTS) throw OvmFail(801, "too many stacking windows for the mailbox");
-        std::vector<DevBuf<EF>> r0_partials(W);
-        bool any_own_window = false;
-        for (size_t wi = 0; wi < W; wi++) {
-            Window &wd = ws[wi];
-            size_t w0 = win[wi], w1 = win[wi + 1];
-            wd.log_height = tvs[w0].s.log_height;
-            wd.n = (int)wd.log_height - (int)l_skip;
-            wd.n_lift = (unsigned)std::max(wd.n, 0);
-            wd.own = own(tvs[w0].com);
-            if (!wd.own) continue;
-            any_own_window = true;
-            wd.eq_cube.alloc(size_t(1) << wd.n_lift);
-            {
-                std::vector<EF> pt(r.begin() + 1, r.begin() + 1 + wd.n_lift);
-                auto d_pt = cx.upload(pt);
-                OVM_THROW_IF(eq_table(d_pt.p, wd.n_lift, wd.eq_cube.p, cx.stream));
-            }
-            std::vector<EF> leq, lrot;
-            for (size_t i = w0; i < w1; i++) {
-                leq.push_back(lam[tvs[i].leq]);
-                lrot.push_back(tvs[i].lrot >= 0 ? lam[(size_t)tvs[i].lrot] : EF::zero());
-            }
-            auto d_leq = cx.upload(leq);
-            auto d_lrot = cx.upload(lrot);
-            unsigned log_len = std::max(wd.log_height, l_skip);
-            const Fp *base = commits[tvs[w0].com].pcs->stacked_view + tvs[w0].s.col_idx * H + tvs[w0].s.row_idx;
-            bool any_rot = false;
-            for (auto &x : lrot) any_rot |= !is_zero(x);
-            r0_partials[wi].alloc((size_t)RED_BLOCKS * 3 * N + 64);  // (grid * slice chunks <= RED_BLOCKS records)
-            OVM_THROW_IF(stacked_round0(base, (uint32_t)(w1 - w0), log_len, l_skip, d_leq.p, any_rot ? d_lrot.p : nullptr, wd.eq_cube.p,
-                                        mb.arm(r0_partials[wi].p, wslots * wi), cx.stream));
-        }
-        if (any_own_window) mb.wait(cx.stream);
-        r0_partials.clear();
-        for (size_t wi = 0; wi < W; wi++) {
-            Window &wd = ws[wi];
-            if (!wd.own) continue;
-            auto R = mb.read(wslots * wi, 3 * N);
-            // host: chunk-aggregated vectors -> coset evaluations with the univariate factors
-            std::vector<std::vector<EF>> coef(3);
-            for (int v = 0; v < 3; v++) coef[v] = small_dft(std::vector<EF>(R.begin() + v * N, R.begin() + (v + 1) * N), true);
-            std::vector<std::vector<EF>> e0(2, std::vector<EF>(N)), e1(2, std::vector<EF>(N));
-            for (unsigned k = 0; k < 2; k++) {
-                Fp shift = g.pow(k + 1);
-                for (size_t z = 0; z < N; z++) {
-                    Fp zp = shift * omega_pows[z];
-                    EF lde[3];
-                    for (int v = 0; v < 3; v++) lde[v] = horner_fp(coef[v], zp);
-                    unsigned l = l_skip;
-                    Fp omega = omega_skip;
-                    EF r_uni = r0;
-                    if (wd.n < 0) {
-                        l = l_skip + wd.n;
-                        omega = omega_skip.exp_power_of_2((unsigned)(-wd.n));
-                        r_uni = r0.exp_power_of_2((unsigned)(-wd.n));
-                    }
-                    Fp ind = in_uni(l_skip, wd.n, zp);
-                    EF equ = eq_uni(l, ef(zp), r_uni), equ_rot = eq_uni(l, ef(zp), r_uni * omega);
-                    Fp equ1 = eq_uni_at_one(l_skip, zp);
-                    e0[k][z] = equ * lde[0] * ind;
-                    e1[k][z] = (equ_rot * lde[1] + eq_const * equ1 * lde[2]) * ind;
-                }
-            }
-            std::vector<EF> p0 = from_coset_evals(e0, l_skip), p1 = from_coset_evals(e1, l_skip);
-            for (size_t i = 0; i <= s0_deg; i++) s0[i] += p0[i] + p1[i];
-        }
-        share_sum(s0);  // (sharded: every rank has summed its own windows)
-        delete ps_st0;
-        wt.mark("openings.stacked.round0");
-        for (auto &c : s0) ts.observe_ext(c);
-        std::vector<EF> u;
-        EF u0 = ts.sample_ext();
-        u.push_back(u0);
-
-        // fold the stacked matrix at u_0
-        DevBuf<EF> q_a(std::max<size_t>(lwidth, 1) << n_stack), q_b(std::max<size_t>(lwidth, 1) << (n_stack ? n_stack - 1 : 0));
-        bool q_in_a = true;
-        unsigned q_log_h = n_stack;
-        ProfScope *ps_stf = new ProfScope("stacked.fold_ple", cx.stream);
-        {
-            EF un = u0.exp_power_of_2(l_skip) - Fp::one();
-            Fp ninv = fp(N).inv();
-            std::vector<EF> wts(N);
-            for (size_t z = 0; z < N; z++) wts[z] = un * (u0 - omega_pows[z]).inv() * (omega_pows[z] * ninv);
-            auto d_w = cx.upload(wts);
-            std::vector<ColDesc> cd(lwidth);
-            for (size_t com = 0; com < commits.size(); com++)
-                for (size_t c = 0; own(com) && c < commits[com].layout.width; c++)
-                    cd[loff[com] + c] = ColDesc{commits[com].pcs->stacked_view + c * H, l_skip + n_stack, 0};
-            auto d_cd = cx.upload(cd);
-            if (lwidth)
-                OVM_THROW_IF(fold_ple(d_cd.p, nullptr, (uint32_t)lwidth, l_skip + n_stack, l_skip, d_w.p, q_a.p, cx.stream));
-            // (no synchronisation: the temporaries go back to the block cache and are only ever reused by later
-            // work on this same stream)
-        }
-        // per-window tables and combined vectors
-        std::vector<EF> tail_d(tvs.size(), EF::zero());  // D_i of the finished slices (see the round loop)
-        std::vector<char> tail_ready(tvs.size(), 0);
-        // The finished slices on the device (stages.hip: stacked_tail_kernel; OVM_STACKED_TAIL_DEVICE=0: the host loop):
-        // their D_i are uploaded once, when their window's last fold has produced (eq_fin, krot_fin).
-        // (from STACKED_TAIL_DEVICE_MIN slices on: below that the host loop is a few microseconds and a kernel per round
-        // is not -- a 2^12 x 20 proof was 0.4 ms slower with its 20 slices on the device; OVM_STACKED_TAIL_DEVICE=2: always)
-        static constexpr size_t STACKED_TAIL_DEVICE_MIN = 1024;
-        const bool tail_on_device = !tvs.empty() && (tuning().stacked_tail_device == 2 ||
-                                                     (tuning().stacked_tail_device == 1 && tvs.size() >= STACKED_TAIL_DEVICE_MIN));
-        DevBuf<TailSlice> d_tail_slices;
-        DevBuf<EF> d_tail, tail_partials;
-        if (tail_on_device) {
-            std::vector<TailSlice> ts_host(tvs.size());
-            for (size_t i = 0; i < tvs.size(); i++) {
-                const unsigned nl = tvs[i].s.log_height > l_skip ? tvs[i].s.log_height - l_skip : 0;
-                ts_host[i] = TailSlice{(uint64_t)tvs[i].s.row_idx, own(tvs[i].com) ? (uint32_t)(loff[tvs[i].com] + tvs[i].s.col_idx) : 0u,
-                                       own(tvs[i].com) ? nl : ~0u};
-            }
-            d_tail_slices = cx.upload(ts_host);
-            d_tail.alloc(tvs.size());
-            tail_partials.alloc(2 * RED_BLOCKS + 64);
-        }
-        auto tail_init_window = [&](size_t wi) {  // (eq_fin, krot_fin) of window wi are known: D_i of its slices
-            if (!tail_on_device) return;
-            const Window &wd = ws[wi];
-            std::vector<EF> init;
-            for (size_t i = win[wi]; i < win[wi + 1]; i++) {
-                EF dd = lam[tvs[i].leq] * wd.eq_fin;
-                if (tvs[i].lrot >= 0) dd += lam[(size_t)tvs[i].lrot] * wd.krot_fin;
-                init.push_back(dd);
-            }
-            auto d_init = cx.upload(init);
-            flush_uploads(cx.stream);
-            OVM_THROW_IF(hipMemcpyAsync(d_tail.p + win[wi], d_init.p, init.size() * sizeof(EF), hipMemcpyDeviceToDevice, cx.stream));
-        };
-        {
-            EF eq_u0r0 = eq_uni(l_skip, u0, r0), eq_u0r0_rot = eq_uni(l_skip, u0, r0 * omega_skip), eq_u01 = eq_uni_at_one(l_skip, u0);
-            for (size_t wi = 0; wi < W; wi++) {
-                Window &wd = ws[wi];
-                if (!wd.own) continue;
-                size_t w0 = win[wi], w1 = win[wi + 1], hw = size_t(1) << wd.n_lift;
-                EF ind = in_uni(l_skip, wd.n, u0), equ = eq_u0r0, equ_rot = eq_u0r0_rot;
-                if (wd.n < 0) {
-                    Fp omega = omega_skip.exp_power_of_2((unsigned)(-wd.n));
-                    EF rr = r0.exp_power_of_2((unsigned)(-wd.n));
-                    unsigned l = l_skip + wd.n;
-                    equ = eq_uni(l, u0, rr);
-                    equ_rot = eq_uni(l, u0, rr * omega);
-                }
-                wd.vec_a.alloc(4 * hw);
-                wd.vec_b.alloc(4 * std::max<size_t>(hw / 2, 1));
-                OVM_LAUNCH(stacked_tables_kernel, dim3(ceil_div(hw, 256)), dim3(256), 0, cx.stream, wd.eq_cube.p,
-                                   (uint64_t)hw, ind * equ, ind * equ_rot, ind * eq_const * eq_u01, wd.vec_a.p + 2 * hw,
-                                   wd.vec_a.p + 3 * hw);
-                std::vector<uint64_t> off;
-                std::vector<EF> ce, cr;
-                for (size_t i = w0; i < w1; i++) {
-                    off.push_back(((uint64_t)(loff[tvs[i].com] + tvs[i].s.col_idx) << n_stack) + (tvs[i].s.row_idx >> l_skip));
-                    ce.push_back(lam[tvs[i].leq]);
-                    cr.push_back(tvs[i].lrot >= 0 ? lam[(size_t)tvs[i].lrot] : EF::zero());
-                }
-                auto d_off = cx.upload(off);
-                auto coef_pre = [](const std::vector<EF> &cs) {
-                    const Fp eleven = fp(11);
-                    std::vector<uint32_t> w(8 * cs.size());
-                    for (size_t i = 0; i < cs.size(); i++)
-                        for (int k = 0; k < 4; k++) {
-                            w[8 * i + k] = cs[i].c[k].v;
-                            w[8 * i + 4 + k] = k ? (cs[i].c[k] * eleven).v : 0;
-                        }
-                    return w;
-                };
-                auto d_ce = cx.upload(coef_pre(ce));
-                auto d_cr = cx.upload(coef_pre(cr));
-                const uint32_t chunks = stacked_round0_chunks((uint32_t)(w1 - w0), wd.n_lift);
-                DevBuf<EF> scratch(chunks > 1 ? (size_t)chunks * 2 * hw : 0);
-                OVM_THROW_IF(stacked_combine(q_a.p, d_off.p, (uint32_t)(w1 - w0), wd.n_lift, d_ce.p, d_cr.p, wd.vec_a.p,
-                                             wd.vec_a.p + hw, scratch.p, chunks, cx.stream));
-                // (no synchronisation per window: the host prepares the next window while this one runs)
-                wd.cur_log_h = wd.n_lift;
-                wd.in_a = true;
-                if (wd.n_lift == 0) {
-                    auto fin = cx.download(wd.vec_a.p, 4);
-                    wd.eq_fin = fin[2];
-                    wd.krot_fin = fin[3];
-                    tail_init_window(wi);
-                }
-            }
-        }
-        delete ps_stf;
-        wt.mark("openings.stacked.setup");
-        ProfScope *ps_str = new ProfScope("stacked.mle_rounds", cx.stream);
-        std::vector<std::array<EF, 2>> st_polys;
-        DevBuf<EF> d_gout(2 * tvs.size() + 2);
-        // per window its own partial records and 8 mailbox slots: the sums of all live windows of a round are
-        // enqueued together and waited for once
-        std::vector<DevBuf<EF>> round_partials(W);
-        for (size_t wi = 0; wi < W; wi++)
-            if (ws[wi].n_lift && ws[wi].own) round_partials[wi].alloc(std::min<size_t>(RED_BLOCKS, ((size_t(1) << (ws[wi].n_lift - 1)) + RED_THREADS - 1) / RED_THREADS) * 2 + 64);
-        for (unsigned round = 1; round <= n_stack; round++) {
-            std::array<EF, 2> batch{EF::zero(), EF::zero()};
-            const EF *q_cur = q_in_a ? q_a.p : q_b.p;
-            bool any_window_launch = false;
-            for (size_t wi = 0; wi < W; wi++) {
-                Window &wd = ws[wi];
-                if (round > wd.n_lift || !wd.own) continue;
-                const EF *vec = wd.in_a ? wd.vec_a.p : wd.vec_b.p;
-                OVM_THROW_IF(stacked_round(vec, wd.cur_log_h, mb.arm(round_partials[wi].p, 8 * wi), cx.stream));
-                any_window_launch = true;
-            }
-            // tail slices: their sums on the device, or (host loop) gather their two entries
-            bool any_tail = false;
-            for (size_t wi = 0; wi < W; wi++) any_tail |= round > ws[wi].n_lift && ws[wi].own;
-            if (tail_on_device && any_tail) {
-                OVM_THROW_IF(stacked_tail(q_cur, q_log_h, d_tail_slices.p, d_tail.p, (uint32_t)tvs.size(), l_skip, round,
-                                          round > 1 ? u.back() : EF::zero(), mb.arm(tail_partials.p, 8 * W), cx.stream));
-                any_window_launch = true;
-            }
-            std::vector<uint64_t> gidx;
-            std::vector<size_t> gslice;
-            for (size_t wi = 0; wi < W; wi++)
-                if (!tail_on_device && round > ws[wi].n_lift && ws[wi].own)
-                    for (size_t i = win[wi]; i < win[wi + 1]; i++) {
-                        uint64_t row_start = (tvs[i].s.row_idx >> (l_skip + round)) << 1;
-                        const uint64_t gcol = loff[tvs[i].com] + tvs[i].s.col_idx;
-                        gidx.push_back((gcol << q_log_h) + row_start);
-                        gidx.push_back((gcol << q_log_h) + row_start + 1);
-                        gslice.push_back(i);
-                    }
-            std::vector<EF> gv;
-            if (!gidx.empty()) {
-                auto d_gi = cx.upload(gidx);
-                OVM_THROW_IF(gather_ef(q_cur, d_gi.p, gidx.size(), d_gout.p, cx.stream));
-                gv = cx.download(d_gout.p, gidx.size());
-            }
-            if (any_window_launch) mb.wait(cx.stream);
-            size_t gi = 0;
-            for (size_t wi = 0; wi < W; wi++) {
-                Window &wd = ws[wi];
-                if (!wd.own) continue;
-                if (round <= wd.n_lift) {
-                    auto sv = mb.read(8 * wi, 2);
-                    batch[0] += sv[0];
-                    batch[1] += sv[1];
-                } else if (tail_on_device) {
-                    continue;  // (summed below, all finished slices at once)
-                } else {
-                    // A finished slice contributes q(X) * eq1b(X, b) * D_i with
-                    //   D_i = eq_ub_i * (lambda_eq * eq_fin + lambda_rot * krot_fin)   (constant in X),
-                    //   q(1) = t1, q(2) = 2 t1 - t0,  eq1b(1, b) = b,  eq1b(2, b) = b ? 2 : -1
-                    // -- two extension-field multiplies per slice and round (this loop runs over every
-                    // stacked column of a many-AIR proof, with the device idle).
-                    for (size_t i = win[wi]; i < win[wi + 1]; i++, gi++) {
-                        const EF t0 = gv[2 * gi], t1 = gv[2 * gi + 1];
-                        const size_t b = (tvs[i].s.row_idx >> (l_skip + round - 1)) & 1;
-                        if (!tail_ready[i]) {
-                            tail_d[i] = lam[tvs[i].leq] * wd.eq_fin;
-                            if (tvs[i].lrot >= 0) tail_d[i] += lam[(size_t)tvs[i].lrot] * wd.krot_fin;
-                            tail_ready[i] = 1;
-                        }
-                        const EF v2 = (t1 + t1 - t0) * tail_d[i];
-                        if (b) {
-                            batch[0] += t1 * tail_d[i];
-                            batch[1] += v2 + v2;
-                        } else {
-                            batch[1] -= v2;
-                        }
-                    }
-                }
-            }
-            if (tail_on_device && any_tail) {
-                auto sv = mb.read(8 * W, 2);
-                batch[0] += sv[0];
-                batch[1] += sv[1];
-            }
-            if (!sh.single()) {  // every rank has summed its own windows and finished slices
-                std::vector<EF> bv{batch[0], batch[1]};
-                share_sum(bv);
-                batch = {bv[0], bv[1]};
-            }
-            for (auto &e : batch) ts.observe_ext(e);
-            st_polys.push_back(batch);
-            EF ur = ts.sample_ext();
-            u.push_back(ur);
-            {
-                EF *qo = q_in_a ? q_b.p : q_a.p;
-                if (lwidth) OVM_THROW_IF(fold_mle(q_cur, qo, (uint32_t)lwidth, q_log_h, ur, cx.stream));
-                q_in_a = !q_in_a;
-                q_log_h--;
-            }
-            {
-                // the four vectors of every live window fold in one launch (big windows on their own)
-                std::vector<FoldJob> fj;
-                for (size_t wi = 0; wi < W; wi++) {
-                    Window &wd = ws[wi];
-                    if (wd.cur_log_h == 0 || !wd.own) continue;
-                    const EF *in = wd.in_a ? wd.vec_a.p : wd.vec_b.p;
-                    EF *o = wd.in_a ? wd.vec_b.p : wd.vec_a.p;
-                    if (wd.cur_log_h <= 11)
-                        fj.push_back(FoldJob{in, o, 4, wd.cur_log_h, fj.empty() ? 0 : fj.back().y0 + fj.back().n_cols, 0});
-                    else
-                        OVM_THROW_IF(fold_mle(in, o, 4, wd.cur_log_h, ur, cx.stream));
-                }
-                if (!fj.empty() && fj.size() <= FoldJobsArg::MAX) {
-                    OVM_THROW_IF(fold_mle_batched(nullptr, fj.data(), (uint32_t)fj.size(), ur, cx.stream));
-                } else if (!fj.empty()) {
-                    auto d_fj = cx.upload(fj);
-                    OVM_THROW_IF(fold_mle_batched(d_fj.p, fj.data(), (uint32_t)fj.size(), ur, cx.stream));
-                }
-                for (size_t wi = 0; wi < W; wi++) {
-                    Window &wd = ws[wi];
-                    if (wd.cur_log_h == 0 || !wd.own) continue;
-                    EF *o = wd.in_a ? wd.vec_b.p : wd.vec_a.p;
-                    wd.in_a = !wd.in_a;
-                    wd.cur_log_h--;
-                    if (wd.cur_log_h == 0) {
-                        auto fin = cx.download(o, 4);
-                        wd.eq_fin = fin[2];
-                        wd.krot_fin = fin[3];
-                        tail_init_window(wi);
-                    }
-                }
-            }
-            for (size_t i = 0; i < tvs.size() && !tail_on_device; i++) {
-                unsigned n_lift = tvs[i].s.log_height > l_skip ? tvs[i].s.log_height - l_skip : 0;
-                if (round > n_lift && tail_ready[i]) tail_d[i] = tail_d[i] * eq1b(ur, (tvs[i].s.row_idx >> (l_skip + round - 1)) & 1);
-            }
-        }
-        delete ps_str;
-        wt.mark("openings.stacked.rounds");
-        std::vector<EF> stacking_openings(width, EF::zero());
-        {
-            std::vector<EF> local = cx.download(q_in_a ? q_a.p : q_b.p, lwidth);
-            std::vector<std::vector<EF>> per_commit(commits.size());
-            for (size_t com = 0; com < commits.size(); com++)
-                if (own(com)) per_commit[com].assign(local.begin() + loff[com], local.begin() + loff[com] + commits[com].layout.width);
-            share_vectors(per_commit, [&](size_t com) { return commits[com].owner; });
-            for (size_t com = 0; com < commits.size(); com++) {
-                if (per_commit[com].size() != commits[com].layout.width) throw OvmFail(1, "shard exchange: stacking openings of the wrong length");
-                std::copy(per_commit[com].begin(), per_commit[com].end(), stacking_openings.begin() + coff[com]);
-            }
-        }
-        for (auto &c : stacking_openings) ts.observe_ext(c);
-        q_a.release();
-        q_b.release();
-        for (auto &wd : ws) {
-            wd.vec_a.release();
-            wd.vec_b.release();
-            wd.eq_cube.release();
-        }
-        // stacking proof bytes
-        w.e_slice(s0);
-        w.usize(st_polys.size());
-        for (auto &a : st_polys)
-            for (auto &x : a) w.e(x);
-        w.usize(commits.size());
-        for (size_t com = 0; com < commits.size(); com++)
-            w.e_slice(std::vector<EF>(stacking_openings.begin() + coff[com], stacking_openings.begin() + coff[com + 1]));
-        section_offsets.push_back(w.buf.size());
-        return u;
-    }
-
-    // WHIR over the mu-batch of every commitment's columns. Sharded: every rank batches ITS columns, the vectors
-    // are all-gathered and summed, rank 0 runs the protocol and collects the rows the first round opens.
-    void prove_whir(const std::vector<CommitRef> &commits, const std::vector<size_t> &coff, const std::vector<EF> &u) {
-        const unsigned l_skip = P().l_skip, n_stack = P().n_stack;
-        const bool root_rank = sh.rank == 0;
-        auto own = [&](size_t com) { return commits[com].owner == sh.rank; };
-        const size_t width = coff.back();
-        ByteWriter &w = out;
-        std::vector<EF> u_cube;
-        {
-            EF cur = u[0];
-            for (unsigned i = 0; i < l_skip; i++) {
-                u_cube.push_back(cur);
-                cur = cur.square();
-            }
-            u_cube.insert(u_cube.end(), u.begin() + 1, u.end());
-        }
-        const unsigned k_whir = P().k_whir, log_blowup = P().log_blowup;
-        const size_t n_rounds = P().whir_num_queries.size();
-        Fp mu_pow_witness = ts.grind(P().mu_pow_bits);
-        wt.mark("openings.whir.mu_pow");
-        EF mu = ts.sample_ext();
-        unsigned m = l_skip + n_stack;
-        // (sharded with an all-to-all: the vector is exchanged in `world` slices of ceil(2^m / world) elements)
-        const size_t mu_slice = sh.has_alltoall() ? ((size_t(1) << m) + sh.world - 1) / sh.world : 0;
-        const size_t mu_padded = std::max(size_t(1) << m, mu_slice * sh.world);
-        DevBuf<EF> f_a(mu_padded), f_b(size_t(1) << (m - 1)), w_a, w_b;
-        {
-            ProfScope ps_mu("whir.mu_batch", cx.stream);
-            std::vector<EF> mu_pows = powers_of(mu, width);
-            auto d_mu = cx.upload(mu_pows);
-            bool first = true;
-            for (size_t com = 0; com < commits.size(); com++) {
-                if (!own(com)) continue;
-                OVM_THROW_IF(whir_mu_batch(commits[com].pcs->msg.p, (uint32_t)commits[com].layout.width, m, d_mu.p,
-                                           (uint32_t)coff[com], f_a.p, first ? 0 : 1, cx.stream));
-                first = false;
-            }
-            if (first) OVM_THROW_IF(hipMemsetAsync(f_a.p, 0, sizeof(EF) << m, cx.stream));  // (a rank without commitments)
-        }
-        if (wt.on) cx.sync();
-        wt.mark("openings.whir.mu_batch");
-        if (!sh.single()) {
-            // THE bulk exchange of a sharded proof (north_star: "RCCL allgather only at the FRI batch-opening
-            // step"; prover/whir.rs:95-132 batches all commitments into one vector): every rank holds the
-            // mu-weighted sum of ITS columns and every rank needs the sum over the ranks (modular addition is not
-            // an RCCL reduction). EVERY rank then runs the WHIR rounds on the sum (the folds are cheap; the
-            // transcript stays replicated) so that the rounds' Merkle trees -- half of WHIR's time -- can be built
-            // by all ranks together (build_tree); rank 0 alone assembles the proof.
-            OVM_PROF("whir.mu_allgather", cx.stream);
-            if (sh.has_alltoall()) {
-                // all-to-all (rank r receives slice r of every rank's vector) + add + all-gather of the summed
-                // slices: 2 (N-1)/N vectors through every GPU's links instead of N-1, and xGMI is a full mesh of
-                // point-to-point links, which is the pattern an all-to-all uses best
-                if (mu_padded > (size_t(1) << m))
-                    OVM_THROW_IF(hipMemsetAsync(f_a.p + (size_t(1) << m), 0, (mu_padded - (size_t(1) << m)) * sizeof(EF), cx.stream));
-                DevBuf<EF> recv(mu_padded), red(mu_slice);
-                sh.alltoall_device(f_a.p, recv.p, mu_slice * sizeof(EF), (ovm_stream_t)cx.stream);
-                OVM_THROW_IF(ef_sum_blocks(recv.p, sh.world, mu_slice, red.p, cx.stream));
-                sh.allgather_device(red.p, f_a.p, mu_slice * sizeof(EF), (ovm_stream_t)cx.stream);
-            } else {
-                DevBuf<EF> gathered((size_t)sh.world << m);
-                sh.allgather_device(f_a.p, gathered.p, sizeof(EF) << m, (ovm_stream_t)cx.stream);
-                OVM_THROW_IF(ef_sum_blocks(gathered.p, sh.world, uint64_t(1) << m, f_a.p, cx.stream));
-            }
-        }
-        if (wt.on) cx.sync();
-        wt.mark("openings.whir.mu_exchange");
-        w_a.alloc(size_t(1) << m);
-        w_b.alloc(size_t(1) << (m - 1));
-        {
-            OVM_PROF("whir.mu_batch", cx.stream);
-            OVM_THROW_IF(zeta_transform(f_a.p, m, +1, cx.stream));
-            auto d_u = cx.upload(u_cube);
-            OVM_THROW_IF(mobius_eq_table(d_u.p, m, w_a.p, cx.stream));
-            cx.sync();
-        }
-        bool fw_in_a = true;
-        std::vector<std::array<EF, 2>> whir_polys;
-        std::vector<p2::Digest> codeword_commits;
-        std::vector<EF> ood_values, final_poly;
-        std::vector<Fp> folding_pows, query_pows;
-        // per commitment, per query: 2^k rows x that commitment's width / the Merkle path
-        std::vector<std::vector<std::vector<std::vector<Fp>>>> init_rows(commits.size());
-        std::vector<std::vector<std::vector<p2::Digest>>> init_proofs(commits.size());
-        std::vector<std::vector<std::vector<EF>>> cw_values;        // per round, per query: 2^k
-        std::vector<std::vector<std::vector<p2::Digest>>> cw_proofs;
-        unsigned log_rs = m + log_blowup;
-        PcsData g_prev;  // previous round's codeword tree (EF, width 1)
-        DevBuf<EF> d_red((size_t)RED_BLOCKS * 2 + 8);
-        for (size_t wr = 0; wr < n_rounds; wr++) {
-            const bool is_last = wr + 1 == n_rounds;
-            ProfScope *ps_ws = new ProfScope("whir.sumcheck_fold", cx.stream);
-            EF al = EF::zero();
-            for (unsigned rd = 0; rd < k_whir; rd++) {
-                const EF *f = fw_in_a ? f_a.p : f_b.p, *wv = fw_in_a ? w_a.p : w_b.p;
-                uint64_t half = 1ull << (m - rd - 1);
-                if (rd == 0) {
-                    OVM_THROW_IF(whir_round(f, wv, half, mb.arm(d_red.p), cx.stream));
-                } else {
-                    // fold round rd-1 with its alpha and get this round's sums in the same pass
-                    OVM_THROW_IF(whir_fold_round(f, wv, fw_in_a ? f_b.p : f_a.p, fw_in_a ? w_b.p : w_a.p, half, al,
-                                                 mb.arm(d_red.p), cx.stream));
-                    fw_in_a = !fw_in_a;
-                }
-                auto sv = mb.take(2, cx.stream);
-                ts.observe_ext(sv[0]);
-                ts.observe_ext(sv[1]);
-                whir_polys.push_back({sv[0], sv[1]});
-                folding_pows.push_back(ts.grind(P().folding_pow_bits));
-                al = ts.sample_ext();
-            }
-            {
-                // the last fold of this WHIR round
-                const EF *f = fw_in_a ? f_a.p : f_b.p, *wv = fw_in_a ? w_a.p : w_b.p;
-                OVM_THROW_IF(whir_fold(f, wv, fw_in_a ? f_b.p : f_a.p, fw_in_a ? w_b.p : w_a.p, 1ull << (m - k_whir), al, cx.stream));
-                fw_in_a = !fw_in_a;
-            }
-            delete ps_ws;
-            ProfScope *ps_wc = new ProfScope("whir.rs_commit", cx.stream);
-            const unsigned m_new = m - k_whir;
-            EF *f_cur = fw_in_a ? f_a.p : f_b.p, *w_cur = fw_in_a ? w_a.p : w_b.p;
-            // g = f(alpha, .) in coefficient form
-            DevBuf<EF> g_coeffs(size_t(1) << m_new);
-            OVM_THROW_IF(hipMemcpyAsync(g_coeffs.p, f_cur, sizeof(EF) << m_new, hipMemcpyDeviceToDevice, cx.stream));
-            OVM_THROW_IF(zeta_transform(g_coeffs.p, m_new, -1, cx.stream));
-            PcsData g_tree;
-            EF z0 = EF::zero();
-            if (!is_last) {
-                g_tree.log_rows = log_rs - 1;
-                g_tree.k = k_whir;
-                DevBuf<EF> g_rs(size_t(1) << g_tree.log_rows);
-                OVM_THROW_IF(ovm_hip_ntt_dif_ext((const uint32_t *)g_coeffs.p, (uint32_t *)g_rs.p, 1, g_tree.log_rows, m_new, cx.stream));
-                build_tree(g_tree, (const uint32_t *)g_rs.p, 1, true, /*distributed=*/true);
-                g_tree.codeword = DevBuf<Fp>();
-                g_tree_codeword = std::move(g_rs);
-                ts.observe_digest(g_tree.root);
-                codeword_commits.push_back(g_tree.root);
-                z0 = ts.sample_ext();
-                OVM_THROW_IF(horner_eval(g_coeffs.p, 1ull << m_new, z0, mb.arm(d_red.p), cx.stream));
-                EF opened = mb.take(1, cx.stream)[0];
-                ts.observe_ext(opened);
-                ood_values.push_back(opened);
-            } else {
-                final_poly = cx.download(g_coeffs.p, size_t(1) << m_new);
-                for (auto &c : final_poly) ts.observe_ext(c);
-            }
-            delete ps_wc;
-            const unsigned lq = log_rs - k_whir;
-            Fp omega = bb::two_adic_generator(lq);
-            size_t nq = P().whir_num_queries[wr];
-            query_pows.push_back(ts.grind(P().query_phase_pow_bits));
-            std::vector<uint64_t> qidx(nq);
-            for (auto &q : qidx) q = ts.sample_bits(lq);
-            // opened rows + Merkle paths. Rows come from their commitment's owner (round 0) or from this rank's own copy
-            // of the previous round's codeword; path digests from whichever ranks' layers hold them (path_refs).
-            {
-                OVM_PROF("whir.queries", cx.stream);
-                // per tree that is opened in this round: [rank] -> the digests that rank's layers hold
-                auto exchange = [&](const Packer &mine) -> std::vector<std::vector<uint8_t>> {
-                    if (sh.single()) return {};
-                    return sh.allgatherv(root_rank ? std::vector<uint8_t>() : mine.buf);
-                };
-                auto assemble = [&](const PcsData &pcs, const std::vector<PathRef> &refs, std::vector<std::vector<p2::Digest>> &served) {
-                    std::vector<p2::Digest> digs;
-                    std::vector<size_t> at(sh.world, 0);
-                    for (auto &rf : refs) {
-                        if (rf.rank < 0) {
-                            digs.push_back(pcs.top.at(rf.idx));
-                        } else {
-                            auto &q = served.at(rf.rank);
-                            if (at[rf.rank] >= q.size()) throw OvmFail(1, "shard exchange: Merkle path digests missing");
-                            digs.push_back(q[at[rf.rank]++]);
-                        }
-                    }
-                    return digs;
-                };
-                if (wr == 0) {
-                    // this rank's part: the rows of its commitments, the digests its layers hold of every tree
-                    Packer mine;
-                    std::vector<std::vector<Fp>> vals_of(commits.size());
-                    std::vector<std::vector<std::vector<p2::Digest>>> served(commits.size(), std::vector<std::vector<p2::Digest>>(sh.world));
-                    std::vector<std::vector<PathRef>> refs_of(commits.size());
-                    for (size_t com = 0; com < commits.size(); com++) {
-                        const PcsData *pcs = commits[com].pcs;
-                        if (!pcs || !(own(com) || pcs->dist_n > 1)) continue;
-                        if (own(com)) open_rows(*pcs, qidx, lq, vals_of[com]);
-                        refs_of[com] = path_refs(*pcs, (int)commits[com].owner, qidx, lq);
-                        served[com][sh.rank] = serve_paths(*pcs, refs_of[com]);
-                        mine.put<uint64_t>(com);
-                        mine.put_vec(vals_of[com]);
-                        mine.put_vec(served[com][sh.rank]);
-                    }
-                    const auto remote = exchange(mine);
-                    if (root_rank) {
-                        for (uint32_t rk = 1; rk < sh.world; rk++) {
-                            Unpacker un(remote[rk]);
-                            while (!un.done()) {
-                                const uint64_t com = un.get<uint64_t>();
-                                if (com >= commits.size()) throw OvmFail(1, "shard exchange: unexpected opened rows");
-                                std::vector<Fp> v = un.get_vec<Fp>();
-                                if (commits[com].owner == rk) vals_of[com] = std::move(v);
-                                served[com][rk] = un.get_vec<p2::Digest>();
-                            }
-                        }
-                        for (size_t com = 0; com < commits.size(); com++) {
-                            const PcsData *pcs = commits[com].pcs;
-                            const size_t cw = commits[com].layout.width;
-                            // a tree held whole by its (remote) owner: its paths arrive complete
-                            const std::vector<p2::Digest> digs = (!own(com) && !(pcs && pcs->dist_n > 1))
-                                                                     ? std::move(served[com][commits[com].owner])
-                                                                     : assemble(*pcs, refs_of[com], served[com]);
-                            const auto &vals = vals_of[com];
-                            if (vals.size() != (nq << k_whir) * cw || digs.size() != nq * lq) throw OvmFail(1, "opened rows of the wrong size");
-                            for (size_t q = 0; q < nq; q++) {
-                                std::vector<std::vector<Fp>> qr;
-                                for (size_t t = 0; t < (size_t(1) << k_whir); t++) {
-                                    size_t ro = (q << k_whir) + t;
-                                    qr.emplace_back(vals.begin() + ro * cw, vals.begin() + (ro + 1) * cw);
-                                }
-                                init_rows[com].push_back(std::move(qr));
-                                init_proofs[com].emplace_back(digs.begin() + q * lq, digs.begin() + (q + 1) * lq);
-                            }
-                        }
-                    }
-                } else {
-                    const std::vector<PathRef> refs = path_refs(g_prev, 0, qidx, lq);
-                    std::vector<std::vector<p2::Digest>> served(sh.world);
-                    served[sh.rank] = serve_paths(g_prev, refs);
-                    Packer mine;
-                    mine.put_vec(served[sh.rank]);
-                    const auto remote = g_prev.dist_n > 1 ? exchange(mine) : std::vector<std::vector<uint8_t>>();
-                    if (root_rank) {
-                        for (uint32_t rk = 1; rk < sh.world && !remote.empty(); rk++) {
-                            Unpacker un(remote[rk]);
-                            served[rk] = un.get_vec<p2::Digest>();
-                        }
-                        const std::vector<p2::Digest> digs = assemble(g_prev, refs, served);
-                        std::vector<uint64_t> rows;
-                        for (uint64_t i : qidx) {
-                            uint64_t grp = bitrev64(i, lq);
-                            for (uint64_t t = 0; t < (1ull << k_whir); t++) rows.push_back((grp << k_whir) + bitrev64(t, k_whir));
-                        }
-                        auto d_rows = cx.upload(rows);
-                        DevBuf<EF> d_vals(std::max<size_t>(rows.size(), 1));
-                        OVM_THROW_IF(gather_ef(prev_codeword.p, d_rows.p, rows.size(), d_vals.p, cx.stream));
-                        auto vals = cx.download(d_vals.p, rows.size());
-                        std::vector<std::vector<EF>> rv;
-                        std::vector<std::vector<p2::Digest>> rp;
-                        for (size_t q = 0; q < nq; q++) {
-                            rv.emplace_back(vals.begin() + (q << k_whir), vals.begin() + ((q + 1) << k_whir));
-                            rp.emplace_back(digs.begin() + q * lq, digs.begin() + (q + 1) * lq);
-                        }
-                        cw_values.push_back(std::move(rv));
-                        cw_proofs.push_back(std::move(rp));
-                    }
-                }
-            }
-            g_prev = std::move(g_tree);
-            prev_codeword = std::move(g_tree_codeword);
-            EF gamma = ts.sample_ext();
-            if (!is_last) {
-                // w += gamma * eq(., pow(z0)) + sum_i gamma^(i+2) * eq(., pow(z_i))
-                OVM_PROF("whir.w_accumulate", cx.stream);
-                const size_t n_q = nq + 1;
-                std::vector<EF> zp(n_q * m_new), scale(n_q);
-                {
-                    EF cur = z0;
-                    for (unsigned j = 0; j < m_new; j++) {
-                        zp[j] = cur;
-                        cur = cur.square();
-                    }
-                    scale[0] = gamma;
-                    EF gp = gamma * gamma;
-                    for (size_t q = 0; q < nq; q++) {
-                        Fp zc = omega.pow(qidx[q]);
-                        for (unsigned j = 0; j < m_new; j++) {
-                            zp[(q + 1) * m_new + j] = ef(zc);
-                            zc = zc.square();
-                        }
-                        scale[q + 1] = gp;
-                        gp = gp * gamma;
-                    }
-                }
-                unsigned log_lo = m_new / 2, log_hi = m_new - log_lo;
-                auto d_zp = cx.upload(zp);
-                auto d_sc = cx.upload(scale);
-                DevBuf<EF> tlo(n_q << log_lo), thi(n_q << log_hi);
-                OVM_LAUNCH(whir_eq_tables_kernel, dim3(ceil_div((uint64_t)n_q << log_lo, 256)), dim3(256), 0, cx.stream,
-                                   d_zp.p, m_new, 0u, log_lo, d_sc.p, (uint32_t)n_q, tlo.p);
-                OVM_LAUNCH(whir_eq_tables_kernel, dim3(ceil_div((uint64_t)n_q << log_hi, 256)), dim3(256), 0, cx.stream,
-                                   d_zp.p, m_new, log_lo, log_hi, (const EF *)nullptr, (uint32_t)n_q, thi.p);
-                OVM_THROW_IF(whir_w_accumulate(w_cur, m_new, tlo.p, thi.p, log_lo, (uint32_t)n_q, cx.stream));
-                cx.sync();
-            }
-            m = m_new;
-            log_rs -= 1;
-        }
-        if (!root_rank) {  // (the proof is assembled on rank 0)
-            section_offsets.push_back(w.buf.size());
-            return;
-        }
-        // whir proof bytes
-        w.f(mu_pow_witness);
-        w.usize(whir_polys.size());
-        for (auto &a : whir_polys)
-            for (auto &x : a) w.e(x);
-        w.usize(codeword_commits.size());
-        for (auto &d : codeword_commits) w.digest(d);
-        for (auto &x : ood_values) w.e(x);
-        for (auto &x : folding_pows) w.f(x);
-        for (auto &x : query_pows) w.f(x);
-        w.usize(commits.size());
-        w.usize(init_rows[0].size());
-        if (!init_rows[0].empty()) {
-            w.usize(init_proofs[0][0].size());
-            for (auto &c : commits) w.usize(c.layout.width);
-            for (auto &cr : init_rows)
-                for (auto &qr : cr)
-                    for (auto &row : qr)
-                        for (auto &x : row) w.f(x);
-            for (auto &cp : init_proofs)
-                for (auto &pr : cp)
-                    for (auto &d : pr) w.digest(d);
-        }
-        for (auto &round : cw_values) {
-            w.usize(round.size());
-            for (auto &q : round)
-                for (auto &x : q) w.e(x);
-        }
-        size_t first_depth = 0;
-        if (n_rounds > 1 && !init_rows[0].empty()) first_depth = cw_proofs[0][0].size();
-        w.usize(first_depth);
-        for (auto &round : cw_proofs)
-            for (auto &pr : round)
-                for (auto &d : pr) w.digest(d);
-        w.e_slice(final_poly);
-        section_offsets.push_back(w.buf.size());
-    }
-    DevBuf<EF> g_tree_codeword, prev_codeword;
-
+#include "prover_commit.inc"
+#include "prover_programs.inc"
+#include "prover_gkr.inc"
+#include "prover_constraints.inc"
+#include "prover_openings.inc"
     // -----------------------------------------------------------------------------------------
     // Coordinator::prove
     // -----------------------------------------------------------------------------------------
