@@ -123,9 +123,10 @@ inline std::pair<ColMat<Fp>, StackedLayout> stacked_matrix(
 inline ColMat<Fp> rs_code_matrix(unsigned l_skip, unsigned log_blowup, const ColMat<Fp> &evals) {
     size_t height = evals.height, rs_height = height << log_blowup;
     std::vector<Fp> out(rs_height * evals.width);
-    // many columns: one thread per column; FEW TALL columns (config D: 25 of 2^25 points on 256 cores): column after column,
-    // each transform spread over the cores (poly.hpp: dft_generic)
-    const bool by_column = evals.width >= (size_t)omp_get_max_threads() || rs_height < (size_t(1) << 16);
+    // one thread per column -- except for a handful of tall columns (the 1-column common main of a partitioned AIR), whose
+    // transforms spread over the cores themselves (poly.hpp: dft_generic). Measured on the 256-core host at config D
+    // (25 columns of 2^25 points): by column 26 s, column after column with 256-thread transforms 55 s.
+    const bool by_column = evals.width >= 4 || rs_height < (size_t(1) << 16);
 #pragma omp parallel for schedule(dynamic) if (by_column)
     for (size_t j = 0; j < evals.width; j++) {
         std::vector<Fp> coeffs = eval_to_coeff_rs_message(l_skip, evals.column(j), height);
@@ -157,12 +158,16 @@ struct MerkleTree {
         size_t num_leaves = size_t(1) << log2_ceil(height);
         if (rpq > num_leaves) throw std::runtime_error("MerkleTreeRowsPerQueryExceeded");
         std::vector<Digest> row_hashes(num_leaves);
-#pragma omp parallel for
-        for (size_t r = 0; r < num_leaves; r++) {
-            std::vector<Fp> in;
-            for (size_t c = 0; c < backing.width; c++)
-                push_coeffs(in, r < height ? backing.at(r, c) : T());
-            row_hashes[r] = hash_slice(in);
+#pragma omp parallel
+        {
+            std::vector<Fp> in;  // (one buffer per thread: an allocation per row is 2^25 trips through malloc on 256 threads)
+#pragma omp for schedule(static)
+            for (size_t r = 0; r < num_leaves; r++) {
+                in.clear();
+                for (size_t c = 0; c < backing.width; c++)
+                    push_coeffs(in, r < height ? backing.at(r, c) : T());
+                row_hashes[r] = hash_slice(in);
+            }
         }
         size_t query_stride = num_leaves / rpq;
         std::vector<Digest> layer = std::move(row_hashes);

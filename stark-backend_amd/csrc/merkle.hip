@@ -227,8 +227,8 @@ static void launch_compress(const Digest *in, Digest *out, uint64_t n_out, uint3
         OVM_LAUNCH(compress_layer_coop_kernel, dim3(ceil_div(n_out * 16, HASH_THREADS)), dim3(HASH_THREADS), 0, stream, in,
                            out, n_out, log_half);
     else
-        OVM_LAUNCH(compress_layer_kernel, dim3(ceil_div(n_out, HASH_THREADS)), dim3(HASH_THREADS), tuning().poseidon_lds_kib * 1024u, stream,
-                   in, out, n_out, log_half);
+        OVM_LAUNCH(compress_layer_kernel, dim3(ceil_div(n_out, HASH_THREADS)), dim3(HASH_THREADS), 0, stream, in, out,
+                           n_out, log_half);
 }
 
 // log_rows: rows THIS launch hashes (= all rows of the matrix / map.n); the matrix's columns are rows * map.n apart
@@ -247,7 +247,7 @@ static int merkle_tree_impl(const uint32_t *d_matrix, uint64_t width, uint32_t l
         // kept apart so that "merkle.hash_rows" stays the wide codeword hash the roofline is quoted on)
         OVM_PROF(WORDS != 1 ? "merkle.hash_rows_ext" : width <= 8 ? "merkle.hash_rows_narrow" : "merkle.hash_rows", stream);
         OVM_LAUNCH(hash_rows_kernel<WORDS>, dim3(ceil_div(rows, HASH_THREADS)),
-                           dim3(HASH_THREADS), tuning().poseidon_lds_kib * 1024u, stream, (const Fp *)d_matrix, width, rows, rows * map.n,
+                           dim3(HASH_THREADS), 0, stream, (const Fp *)d_matrix, width, rows, rows * map.n,
                            log_rows_per_query == 0 ? layers : leaf, map);
         OVM_CHECK_LAUNCH();
     }

@@ -51,12 +51,6 @@ struct Tuning {
     // saved. The SMALL sub-rounds are the latency-bound ones -- a table that sits in L2, a kernel of a few microseconds -- and
     // there the saved launch + mailbox round trip is all gain.
     uint32_t gkr_la_max_log = 17;
-    // OVM_POSEIDON_LDS_KIB: LDS every workgroup of the Poseidon2 kernels (row hash, compress layers) claims without using it,
-    // i.e. a cap on their resident waves: 160 / this workgroups per CU = waves per SIMD. These kernels are VALU-issue bound
-    // and two waves per SIMD already saturate the issue port, so fewer resident waves cost them nothing -- and
-    // leave wave slots to the memory-bound kernels of ANOTHER prover thread (the reference's throughput mode: K engines on one
-    // GPU, bench.py --engines). 0 = no cap (8 waves per SIMD).
-    uint32_t poseidon_lds_kib = 0;
     bool lazy_w_accumulate = true;  // OVM_LAZY_W=0: whir_w_accumulate reduces every product (the parity tests compare the two)
     bool download_kernel = true;   // OVM_DOWNLOAD_KERNEL=0: small downloads through the runtime's copy + stream synchronisation
     bool trace = false;            // OVM_TRACE: wall-clock trace of the stages on stderr
