@@ -114,7 +114,9 @@ def roofline_classes(prof, steps, rows, width, cells, log_stacked, gkr_leaves, n
             if insts:
                 ent["valu_wave_insts"] = int(insts)
                 ent["issue_frac"] = round(insts / (tot * 1e-3) / issue_peak, 4)
-                ent["bound"] = "valu issue" if ent["issue_frac"] > ent["frac"] else "hbm"
+                top = max(ent["issue_frac"], ent["frac"])
+                ent["bound"] = ("valu issue" if ent["issue_frac"] > ent["frac"] else "hbm") if top >= 0.5 else \
+                    "latency (neither roof above one half: sequential small launches and host round trips)"
         out[name] = ent
     if sq:
         out["_issue_roof"] = {"peak_wave_valu_per_s": round(issue_peak, 1), "cycles_per_wave_valu": ISSUE_CYCLES_PER_WAVE_VALU,
@@ -282,6 +284,9 @@ def main():
                          "(committed inside the timed region) + a 1-column common main, i.e. exactly what each rank of an N > 1 "
                          "run proves. Without the flag the N = 1 line still reports it as `n1_partitioned_form`, so that the "
                          "N = 1 point of a scaling curve can be read in the same units as N >= 2")
+    ap.add_argument("--no-other-form", action="store_true",
+                    help="N = 1: skip the few extra steps that measure the OTHER form (partitioned beside plain, or plain beside "
+                         "--partitioned): tools/profile_round.sh uses it so that the process makes exactly warmup + steps proofs")
     ap.add_argument("--engines", type=int, default=0,
                     help="N = 1: after the timed region, K host threads x K streams prove the same resident trace concurrently "
                          "(the reference's throughput mode, crates/cuda-backend/examples/keccakf.rs:55-131); reported as the "
@@ -444,7 +449,7 @@ def main():
         prof_detail = pkg.profile_report_detail()
     pkg.profile_enable(0)
     other_form = None
-    if world == 1 and step_partitioned is not None:
+    if world == 1 and step_partitioned is not None and not args.no_other_form:
         # the N = 1 point in the units of N >= 2 (or, with --partitioned, the plain form beside it): a few more steps
         other = step_plain if args.partitioned else step_partitioned
         other()
@@ -507,8 +512,8 @@ def main():
             algo_bytes = 4 * rows * width + 32 * rows // rows_per_query
             achieved = algo_bytes / (avg_ms * 1e-3) / 1e9
             traffic, src = None, None
-            pmc = next((q for q in (os.path.join(ROOT, "profiles", "r03", "pmc_hbm_traffic_r03.json"),
-                                    os.path.join(ROOT, "profiles", "r02", "pmc_hbm_traffic_r02.json")) if os.path.exists(q)), "")
+            pmc = next((q for q in (os.path.join(ROOT, "profiles", "r04", "pmc_hbm_traffic_r04.json"),
+                                    os.path.join(ROOT, "profiles", "r03", "pmc_hbm_traffic_r03.json")) if os.path.exists(q)), "")
             if world == 1 and (log_rows, cols, args.log_stacked_height, args.log_blowup) == (22, 100, 24, 1) and os.path.exists(pmc):
                 k = json.load(open(pmc))["kernels"].get("hash_rows_kernel<1>")
                 if k:

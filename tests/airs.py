@@ -269,20 +269,16 @@ def uniform_runner_air(cols, constraints_per_col=2.0, interactions_per_col=0.25)
 
 
 def splitmix64_bits(seed, n):
-    """Seeded boolean trace (SURVEY §8d config D value distribution R)."""
-    out = np.empty(n, dtype=np.uint32)
-    x = seed & 0xFFFFFFFFFFFFFFFF
-    i = 0
-    while i < n:
-        x = (x + 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF
-        z = x
-        z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & 0xFFFFFFFFFFFFFFFF
-        z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & 0xFFFFFFFFFFFFFFFF
-        z ^= z >> 31
-        k = min(64, n - i)
-        out[i:i + k] = [(z >> b) & 1 for b in range(k)]
-        i += k
-    return out
+    """Seeded boolean trace (SURVEY §8d config D value distribution R): the bits, least significant first, of the
+    splitmix64 stream from `seed`. Vectorised (the full-size sharded comparison draws 8.5e8 of them)."""
+    n64 = (n + 63) // 64
+    with np.errstate(over="ignore"):
+        x = np.uint64(seed & 0xFFFFFFFFFFFFFFFF) + np.arange(1, n64 + 1, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15)
+        z = (x ^ (x >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z ^= z >> np.uint64(31)
+    bits = np.unpackbits(z.view(np.uint8).reshape(-1, 8), axis=1, bitorder="little").reshape(-1)
+    return bits[:n].astype(np.uint32)
 
 
 # ---------------------------------------------------------------------------------------------

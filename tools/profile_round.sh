@@ -9,7 +9,7 @@ set -u
 OUT=${1:-gpurun_out/prof}
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-BENCH="python3 bench.py --steps 1 --warmup 1 --profile-steps 0 --no-cpu-baseline"
+BENCH="python3 bench.py --steps 1 --warmup 1 --profile-steps 0 --no-cpu-baseline --no-other-form"
 rocprofv3 --kernel-trace --stats -d "$OUT/kt" -o run --output-format rocpd csv -- $BENCH > "$OUT/kt.log" 2>&1
 KT=$(find "$OUT/kt" -name "*_results.db" | head -1)
 python3 tools/rocpd_stats.py "$KT" --second-half --csv "$OUT/prove_kernel_stats.csv" > "$OUT/prove_kernel_stats.txt" 2>&1
