@@ -1005,7 +1005,6 @@ Tuning ovm::Tuning::from_env() {
     t.gkr_lookahead = num("OVM_GKR_LOOKAHEAD", 0) != 0;
     t.gkr_la_max_log = (uint32_t)std::max(0, num("OVM_GKR_LA_MAX_LOG", 17));
     t.gkr_la_min_log = (uint32_t)std::max(0, num("OVM_GKR_LA_MIN_LOG", 0));
-    t.gkr_la_wide_min_log = (uint32_t)std::max(6, num("OVM_GKR_LA_WIDE_MIN_LOG", 14));
     t.gkr_split_min_round = (uint32_t)std::max(3, num("OVM_GKR_SPLIT_MIN", 14));
     t.staged_forward = !off("OVM_STAGED_FWD");
     t.stacked_tail_device = std::max(0, std::min(2, num("OVM_STACKED_TAIL_DEVICE", 1)));

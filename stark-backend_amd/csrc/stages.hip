@@ -2310,138 +2310,6 @@ __global__ __launch_bounds__(RED_THREADS) void gkr_pass_kernel(FracPlanes in, Eq
     block_sum_out<K>(sums, ro, (size_t)blockIdx.x * K);
     finish_reduction<8>(ro, gridDim.x, K);
 }
-// The same pass for BIG tables, with wave-wide loads. In gkr_pass_kernel a lane reads its item's 2 N fractions of a plane as
-// N / 2 consecutive dwordx4 -- 256 contiguous bytes per lane when FOLDS = 2, neighbouring lanes 256 B apart: every load
-// instruction of the wave touches 64 different 256-byte stripes and the HBM fetch counter shows 3.2x the table's bytes
-// (profiles/r04/gkr_lookahead_all_layers_*). Here the 64 items of a wave-iteration are ONE contiguous span of each plane:
-// instruction c loads chunk c * 64 + lane of the span (a kilobyte, fully coalesced), the chunks go through a per-wave LDS
-// tile (one chunk of skew per item: conflict-free both ways) and every lane reads back the chunks of ITS item. Lookahead
-// form only (it is what a big pass runs); the stray pairs at odd range ends take the per-lane path.
-template <bool PBASE, int FOLDS>
-__global__ __launch_bounds__(RED_THREADS) void gkr_pass_wide_kernel(FracPlanes in, EqSplit eq_s, EqSplit eq_n, FracPlanes out, uint64_t n_pairs,
-                                                                    EF r1_in, EF r2_in, EF lambda_in, EF xi_in, uint64_t want0, uint64_t want1,
-                                                                    EF *dump, RedOut ro) {
-    constexpr int NP = 2, K = NP + 6;
-    constexpr int N = 4 << FOLDS;  // source fractions per pair
-    constexpr int CH = N / 2;      // dwordx4 chunks per item (two pairs) and plane
-    constexpr int TILE = 64 * CH + 64;
-    extern __shared__ uint4 wide_tile[];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    uint4 *wl = wide_tile + wave * TILE;
-    const uint64_t gid = (uint64_t)blockIdx.x * RED_THREADS + threadIdx.x;
-    const EF::Pre r1 = r1_in.pre(), r2 = r2_in.pre(), lambda = lambda_in.pre(), xi = xi_in.pre();
-    EF sums[K];
-#pragma unroll
-    for (int i = 0; i < K; i++) sums[i] = EF::zero();
-    const uint64_t skip = eq_s.y_first & 1;
-    const uint64_t n_la = (n_pairs - skip) >> 1;
-    const bool tail = ((n_pairs - skip) & 1) != 0;
-    {
-        EF a[4], b[4];
-        if (gid == 0 && skip) gkr_do_pair<PBASE, FOLDS, NP>(in, out, 0, r1, r2, lambda, eq_weight(eq_s, 0), a, b, sums, want0, want1, dump);
-        if (gid == 1 && tail)
-            gkr_do_pair<PBASE, FOLDS, NP>(in, out, n_pairs - 1, r1, r2, lambda, eq_weight(eq_s, n_pairs - 1), a, b, sums, want0, want1, dump);
-    }
-    const uint64_t step = (uint64_t)gridDim.x * RED_THREADS;
-    // (every wave of a workgroup makes the same number of iterations: the barriers below are uniform)
-    for (uint64_t blk = (uint64_t)blockIdx.x * RED_THREADS; blk < n_la; blk += step) {
-        const uint64_t base = blk + (uint64_t)wave * 64;  // first item of this wave's batch
-        const bool wave_live = base < n_la;
-        const uint64_t z = base + lane;
-        const bool live = z < n_la;
-        const uint64_t f0 = (uint64_t)N * (skip + 2 * base);  // first fraction of the wave's span (relative to `in`)
-        const uint32_t valid = wave_live ? (uint32_t)((n_la - base < 64 ? n_la - base : 64) * CH) : 0;
-        EF fp[8], fq[8];  // the item's two pairs, four folded fractions each
-#pragma unroll
-        for (int isq = 0; isq < 2; isq++) {
-            EF f[2 * N];
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                if (PBASE && !isq && k > 0) break;
-                const uint32_t *plane = (isq ? in.Q() : in.P()) + (uint64_t)k * in.stride + f0;
-#pragma unroll
-                for (int c = 0; c < CH; c++) {
-                    const uint32_t g = (uint32_t)c * 64 + lane;
-                    uint4 v = make_uint4(0, 0, 0, 0);
-                    if (g < valid) v = *reinterpret_cast<const uint4 *>(plane + 4ull * g);
-                    wl[g + g / CH] = v;
-                }
-                __syncthreads();
-#pragma unroll
-                for (int c = 0; c < CH; c++) {
-                    const uint4 v = wl[lane * CH + c + lane];
-                    f[4 * c + 0].c[k] = Fp::raw(v.x);
-                    f[4 * c + 1].c[k] = Fp::raw(v.y);
-                    f[4 * c + 2].c[k] = Fp::raw(v.z);
-                    f[4 * c + 3].c[k] = Fp::raw(v.w);
-                }
-                __syncthreads();
-            }
-            if (PBASE && !isq) {
-#pragma unroll
-                for (int i = 0; i < 2 * N; i++) f[i].c[1] = Fp::zero(), f[i].c[2] = Fp::zero(), f[i].c[3] = Fp::zero();
-            }
-            EF(&dst)[8] = isq ? fq : fp;
-            if constexpr (FOLDS == 0) {
-#pragma unroll
-                for (int i = 0; i < 8; i++) dst[i] = f[i];
-            } else if constexpr (FOLDS == 1) {
-                fold_fracs<16>(f, dst, r1);
-            } else {
-                EF g2[16];
-                fold_fracs<32>(f, g2, r1);
-                fold_fracs<16>(g2, dst, r2);
-            }
-        }
-        if (!live) continue;  // (no barrier after this point of the iteration)
-        const uint64_t p0 = skip + 2 * z;
-        if constexpr (FOLDS > 0) {
-            const EF p_lo[4] = {fp[0], fp[1], fp[2], fp[3]}, p_hi[4] = {fp[4], fp[5], fp[6], fp[7]};
-            const EF q_lo[4] = {fq[0], fq[1], fq[2], fq[3]}, q_hi[4] = {fq[4], fq[5], fq[6], fq[7]};
-            stp4(out.P(), out.stride, 4 * p0, p_lo);
-            stp4(out.P(), out.stride, 4 * p0 + 4, p_hi);
-            stp4(out.Q(), out.stride, 4 * p0, q_lo);
-            stp4(out.Q(), out.stride, 4 * p0 + 4, q_hi);
-        }
-        // records: pair 1 = (a1, b1), pair 2 = (a2, b2)
-        EF a1[4] = {fp[0], fq[0], fp[1], fq[1]}, b1[4] = {fp[2], fq[2], fp[3], fq[3]};
-        EF a2[4] = {fp[4], fq[4], fp[5], fq[5]}, b2[4] = {fp[6], fq[6], fp[7], fq[7]};
-#pragma unroll
-        for (int h2 = 0; h2 < 2; h2++) {
-            const uint64_t p = p0 + h2;
-            if (p == want0 || p == want1) {
-                EF *d = dump + (p == want0 ? 0 : 8);
-                const EF(&ra)[4] = h2 ? a2 : a1;
-                const EF(&rb)[4] = h2 ? b2 : b1;
-#pragma unroll
-                for (int i = 0; i < 4; i++) st_ef_sys(d + i, ra[i]), st_ef_sys(d + 4 + i, rb[i]);
-                release_to_host();
-            }
-        }
-        const EF en = eq_weight(eq_n, z);
-        const EF e1 = en * xi, e0 = en - e1;
-        EF u[4], v[4];
-#pragma unroll
-        for (int i = 0; i < 4; i++) u[i] = b1[i].dbl() - a1[i], v[i] = b2[i].dbl() - a2[i];
-        {
-            EF t1[4] = {a1[0], a1[1], a1[2], a1[3]}, t2[4] = {a2[0], a2[1], a2[2], a2[3]};
-            EF s1[2] = {EF::zero(), EF::zero()}, s2[2] = {EF::zero(), EF::zero()};
-            gkr_pair_sums<2>(t1, b1, e0, lambda, s1);
-            gkr_pair_sums<2>(t2, b2, e1, lambda, s2);
-            sums[0] = sums[0] + s1[0] + s2[0];
-            sums[1] = sums[1] + s1[1] + s2[1];
-        }
-        EF la0[2] = {EF::zero(), EF::zero()}, la1[2] = {EF::zero(), EF::zero()}, la2[2] = {EF::zero(), EF::zero()};
-        gkr_pair_sums<2>(a1, a2, en, lambda, la0);
-        gkr_pair_sums<2>(b1, b2, en, lambda, la1);
-        gkr_pair_sums<2>(u, v, en, lambda, la2);
-        sums[NP + 0] = sums[NP + 0] + la0[0], sums[NP + 1] = sums[NP + 1] + la0[1];
-        sums[NP + 2] = sums[NP + 2] + la1[0], sums[NP + 3] = sums[NP + 3] + la1[1];
-        sums[NP + 4] = sums[NP + 4] + la2[0], sums[NP + 5] = sums[NP + 5] + la2[1];
-    }
-    block_sum_out<K>(sums, ro, (size_t)blockIdx.x * K);
-    finish_reduction<8>(ro, gridDim.x, K);
-}
 int gkr_pass(FracPlanes in, bool in_p_base, int folds, EqSplit eq_s, EqSplit eq_n, FracPlanes out, uint64_t n_pairs, EF r1, EF r2,
              EF lambda, uint32_t n_points, bool lookahead, EF xi_next, uint64_t want0, uint64_t want1, EF *dump, const RedOut &ro,
              hipStream_t s) {
@@ -2449,20 +2317,6 @@ int gkr_pass(FracPlanes in, bool in_p_base, int folds, EqSplit eq_s, EqSplit eq_
         return (int)hipErrorInvalidValue;
     const uint32_t K = lookahead ? n_points + 6 : n_points;
     const uint32_t grid = red_grid(lookahead ? std::max<uint64_t>(n_pairs / 2, 2) : n_pairs);
-    if (lookahead && n_pairs >= (uint64_t(1) << tuning().gkr_la_wide_min_log)) {
-        const size_t lds = (size_t)(RED_THREADS / 64) * (64 * ((4 << folds) / 2) + 64) * sizeof(uint4);
-#define WIDE(PB, F)                                                                                                                   \
-    OVM_LAUNCH((gkr_pass_wide_kernel<PB, F>), dim3(grid), dim3(RED_THREADS), lds, s, in, eq_s, eq_n, out, n_pairs, r1, r2, lambda, xi_next, \
-               want0, want1, dump, red_inline(ro, grid, K))
-        if (in_p_base) {
-            if (folds == 0) WIDE(true, 0); else if (folds == 1) WIDE(true, 1); else WIDE(true, 2);
-        } else {
-            if (folds == 0) WIDE(false, 0); else if (folds == 1) WIDE(false, 1); else WIDE(false, 2);
-        }
-#undef WIDE
-        OVM_CHECK_LAUNCH();
-        return red_finish(ro, grid, grid, K, s);
-    }
 #define CALL(PB, F, NP, LA)                                                                                                          \
     OVM_LAUNCH((gkr_pass_kernel<PB, F, NP, LA>), dim3(grid), dim3(RED_THREADS), 0, s, in, eq_s, eq_n, out, n_pairs, r1, r2, lambda, \
                xi_next, want0, want1, dump, red_inline(ro, grid, K))

@@ -51,9 +51,8 @@ struct Tuning {
     // saved. The SMALL sub-rounds are the latency-bound ones -- a table that sits in L2, a kernel of a few microseconds -- and
     // there the saved launch + mailbox round trip is all gain.
     uint32_t gkr_la_max_log = 17;
-    // OVM_GKR_LA_MIN_LOG: ... and only passes over at least 2^this pairs (0 = no lower limit); OVM_GKR_LA_WIDE_MIN_LOG:
-    // lookahead passes over at least 2^this pairs take the wave-wide-load kernel (gkr_pass_wide_kernel)
-    uint32_t gkr_la_min_log = 0, gkr_la_wide_min_log = 14;
+    // OVM_GKR_LA_MIN_LOG: ... and only passes over at least 2^this pairs (0 = no lower limit)
+    uint32_t gkr_la_min_log = 0;
     bool lazy_w_accumulate = true;  // OVM_LAZY_W=0: whir_w_accumulate reduces every product (the parity tests compare the two)
     bool download_kernel = true;   // OVM_DOWNLOAD_KERNEL=0: small downloads through the runtime's copy + stream synchronisation
     bool trace = false;            // OVM_TRACE: wall-clock trace of the stages on stderr

@@ -122,17 +122,13 @@ def test_gkr_three_point_fallback(dev, pkg, orc, monkeypatch):
     run_case(dev, pkg, orc, params, [airs.uniform_runner_air(20)], [(0, tr, h, [])])
 
 
-@pytest.mark.parametrize("lookahead", ["0", "1", "wide"])
+@pytest.mark.parametrize("lookahead", ["0", "1"])
 def test_gkr_passes_with_and_without_lookahead(dev, pkg, orc, monkeypatch, lookahead):
     """Round 4: a pass over a GKR layer's table also sums the NEXT sub-round as a quadratic in its challenge, so every
     second sub-round is served without a launch and the pass after it folds twice (stages.hip: gkr_pass_kernel).
     OVM_GKR_LOOKAHEAD=0 is one pass per sub-round as in rounds 1-3. Both must give the oracle's bytes -- on a tall
     single AIR (base-field leaf numerators, split eq tables from 2^3 records), on mixed heights with a padding run that
     starts on an odd pair, and with the three-point fallback (which turns the lookahead off by itself)."""
-    if lookahead == "wide":  # the wave-wide-load kernel of the big passes (gkr_pass_wide_kernel), forced down to 2^6 pairs
-        monkeypatch.setenv("OVM_GKR_LA_WIDE_MIN_LOG", "6")
-        monkeypatch.setenv("OVM_GKR_LA_MAX_LOG", "40")
-        lookahead = "1"
     monkeypatch.setenv("OVM_GKR_LOOKAHEAD", lookahead)
     monkeypatch.setenv("OVM_GKR_SPLIT_MIN", "3")
     params = airs.test_params(l_skip=4, n_stack=10, k_whir=4)
