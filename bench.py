@@ -214,6 +214,8 @@ def engines_run(args, pkg, torch, pk, traces, cells, barrier, local_rank):
                     d.prove(pk, traces)            # this thread's pools, mailboxes and twiddles: outside the timing
                     torch.cuda.current_stream().synchronize()
                     start.wait()
+                    if args.engines_stagger_ms > 0 and i > 0:
+                        time.sleep(i * args.engines_stagger_ms * 1e-3)
                     t0 = time.perf_counter()
                     for _ in range(steps):
                         proofs[i], _ = d.prove(pk, traces)
@@ -238,8 +240,10 @@ def engines_run(args, pkg, torch, pk, traces, cells, barrier, local_rank):
             t.join()
         wall = time.perf_counter() - t0
         barrier()
-        rec = {"engines": k, "steps_per_engine": steps, "wall_ms": round(wall * 1e3, 2),
+        rec = {"engines": k, "steps_per_engine": steps, "stagger_ms": args.engines_stagger_ms, "wall_ms": round(wall * 1e3, 2),
                "cells_per_s": round(k * steps * cells / wall, 1), "per_engine_prove_ms": [round(x, 3) for x in per_engine],
+               # every engine's own rate added up (what a long-running pipeline sees; `cells_per_s` also pays the start-up stagger)
+               "cells_per_s_steady": round(sum(cells / (x * 1e-3) for x in per_engine if x > 0), 1),
                "identical_proofs": len({hashlib.sha256(p or b"").hexdigest() for p in proofs}) == 1}
         if errors:
             rec["errors"] = errors
@@ -284,6 +288,10 @@ def main():
                          "(committed inside the timed region) + a 1-column common main, i.e. exactly what each rank of an N > 1 "
                          "run proves. Without the flag the N = 1 line still reports it as `n1_partitioned_form`, so that the "
                          "N = 1 point of a scaling curve can be read in the same units as N >= 2")
+    ap.add_argument("--engines-stagger-ms", type=float, default=0.0,
+                    help="--engines K: engine i starts its timed proofs i x this many milliseconds after engine 0 (two provers in "
+                         "lock step hash at the same time; half a proof apart, one's VALU-bound hashing runs beside the other's "
+                         "memory- and latency-bound stages)")
     ap.add_argument("--no-other-form", action="store_true",
                     help="N = 1: skip the few extra steps that measure the OTHER form (partitioned beside plain, or plain beside "
                          "--partitioned): tools/profile_round.sh uses it so that the process makes exactly warmup + steps proofs")
