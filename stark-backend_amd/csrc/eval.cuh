@@ -1,7 +1,6 @@
 // Constraint-evaluation kernel bodies, parameterised by the program that evaluates one row:
 // the register-program interpreter and the staged VM (stages.hip). Device code only.
 #pragma once
-#include <type_traits>
 #include "device_common.h"
 
 namespace ovm {
@@ -92,11 +91,6 @@ __device__ __forceinline__ void mac_weight(Acc96 &acc, const EF *weights, uint32
 #endif
 }
 
-template <class Prog, class = void>
-struct prog_lane_major : std::false_type {};
-template <class Prog>
-struct prog_lane_major<Prog, std::enable_if_t<Prog::LANE_MAJOR>> : std::true_type {};
-
 // ---- round 0: program values on the coset LDEs, weighted by eq and summed per (coset, z) ------
 // A lane evaluates Prog::ROWS rows per step (rows p, p + stride, ...: same z = p mod N).
 // Prog::operator()(const Fp *lde_k, uint32_t log_lifted, const uint64_t (&p)[ROWS], EF (&out)[ROWS][2])
@@ -111,7 +105,6 @@ __device__ __forceinline__ void round0_eval_body(const Prog &prog, const Fp *lde
     // (bx, gx: this workgroup's index and the number of workgroups of ITS job -- a batched launch runs
     // several jobs side by side; fence: device-scope release of the partial records for an in-kernel finish)
     constexpr int R = Prog::ROWS;
-    constexpr bool LM = prog_lane_major<Prog>::value;  // (stages.hip: StagedVM<4, true>)
     __shared__ EF sh[RED_THREADS];
     const uint32_t N = 1u << l_skip;
     const uint64_t total = 1ull << log_lifted;
@@ -123,21 +116,14 @@ __device__ __forceinline__ void round0_eval_body(const Prog &prog, const Fp *lde
     EF sums[MAX_COSETS * 2];
 #pragma unroll
     for (int i = 0; i < (int)(MAX_COSETS * 2); i++) sums[i] = EF::zero();
-    // Lane-major programs: lane index q = 16 g + z covers the rows of skip-domain position z in the chunks 4 g .. 4 g + 3
-    // (same z per lane, as everywhere; the column order of the LDE makes those four values contiguous).
-    for (uint64_t p0 = (uint64_t)bx * RED_THREADS + threadIdx.x; p0 < (LM ? total / R : total); p0 += LM ? stride : stride * R) {
+    for (uint64_t p0 = (uint64_t)bx * RED_THREADS + threadIdx.x; p0 < total; p0 += stride * R) {
         uint64_t p[R];
         bool live[R];
 #pragma unroll
         for (int r = 0; r < R; r++) {
-            if constexpr (LM) {
-                live[r] = true;
-                p[r] = ((((p0 >> 4) << 2) + (uint64_t)r) << 4) | (p0 & 15);
-            } else {
-                const uint64_t q = p0 + (uint64_t)r * stride;
-                live[r] = q < total;  // a row past the end is evaluated at p0 with weight zero
-                p[r] = live[r] ? q : p0;
-            }
+            const uint64_t q = p0 + (uint64_t)r * stride;
+            live[r] = q < total;  // a row past the end is evaluated at p0 with weight zero
+            p[r] = live[r] ? q : p0;
         }
         // (a runtime loop on purpose: unrolling it would replicate the whole row program per coset)
         for (uint32_t k = 0; k < n_cosets; k++) {

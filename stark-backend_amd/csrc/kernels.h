@@ -50,8 +50,7 @@ int mobius_eq_table(const EF *d_point, uint32_t n, EF *out, hipStream_t s);
 // into an lde buffer laid out for 2^log_lifted rows -- round 0 in slabs (zerocheck_save_memory)
 int coset_lde(const ColDesc *d_cols, const uint32_t *d_used, uint32_t n_used, uint32_t n_cols_total,
               uint32_t log_lifted, uint32_t l_skip, uint32_t n_cosets, const Fp *d_shift_pows, Fp *lde,
-              hipStream_t s, uint64_t row0 = 0, uint32_t pad_lds_bytes = 0, bool perm4 = false);
-// (perm4, l_skip = 4 only: the rows of every column in the order the lane-major staged VM reads them -- stages.hip)
+              hipStream_t s, uint64_t row0 = 0, uint32_t pad_lds_bytes = 0);
 // (pad_lds_bytes: LDS every workgroup claims without using it -- caps the workgroups per CU of a launch that runs beside
 // latency-critical kernels of another stream)
 
@@ -83,8 +82,7 @@ int round0_eval_batched(const R0Job *d_jobs, const R0Job *h_jobs, uint32_t n_job
 
 // `staged` (optional, blocks != nullptr): the same program in staged form; used when its LDS image fits.
 int round0_eval(const DevProgram &prog, const DevStaged &staged, const Fp *lde, uint32_t n_cols_total, uint32_t log_lifted, uint32_t l_skip,
-                uint32_t n_cosets, uint32_t n_out, const EF *d_eq_xi, EF add_const, const RedOut &ro, hipStream_t s,
-                bool lane_major = false);
+                uint32_t n_cosets, uint32_t n_out, const EF *d_eq_xi, EF add_const, const RedOut &ro, hipStream_t s);
 
 // out[col * (lifted >> l) + x] = sum_z w[z] * col(( x << l) + z)
 // d_twins (optional, n_cols entries): see fold_ple_kernel -- a column and its rotated view computed from one read

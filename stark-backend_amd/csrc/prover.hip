@@ -1003,7 +1003,6 @@ Tuning ovm::Tuning::from_env() {
     t.early_lde = !off("OVM_EARLY_LDE");
     t.gkr_split_eq = !off("OVM_GKR_SPLIT_EQ");
     t.gkr_lookahead = num("OVM_GKR_LOOKAHEAD", 0) != 0;
-    t.r0_lane_major = !off("OVM_R0_LANE_MAJOR");
     t.gkr_la_max_log = (uint32_t)std::max(0, num("OVM_GKR_LA_MAX_LOG", 17));
     t.gkr_la_min_log = (uint32_t)std::max(0, num("OVM_GKR_LA_MIN_LOG", 0));
     t.gkr_split_min_round = (uint32_t)std::max(3, num("OVM_GKR_SPLIT_MIN", 14));

@@ -375,10 +375,6 @@ __device__ __forceinline__ constexpr int bitrev4(int i) {
     return ((i & 1) << 3) | ((i & 2) << 1) | ((i & 4) >> 1) | ((i & 8) >> 3);
 }
 
-// PERM4: the rows of a column are written in the order the lane-major staged VM reads them (StagedVM<4, true>): the value of
-// chunk c (16 rows) at skip-domain position z goes to word ((c >> 2) * 16 + z) * 4 + (c & 3) -- the four values that ONE lane
-// of round 0 evaluates (same z, four consecutive chunks) are 16 contiguous bytes, and consecutive lanes follow each other.
-template <bool PERM4>
 __global__ __launch_bounds__(256) void coset_lde16_kernel(const ColDesc *cols, const uint32_t *used,
                                                           uint32_t n_cols_total, uint32_t log_lifted,
                                                           uint32_t n_cosets, const Fp *twist, Fp *lde, uint64_t row0) {
@@ -438,36 +434,24 @@ __global__ __launch_bounds__(256) void coset_lde16_kernel(const ColDesc *cols, c
                 }
             }
         }
-        if constexpr (PERM4) {
-            uint32_t *dst = reinterpret_cast<uint32_t *>(lde + (((uint64_t)c * n_cols_total + col) << log_lifted)) + ((chunk >> 2) << 6) +
-                            (chunk & 3);
+        uint4 *dst = reinterpret_cast<uint4 *>(lde + (((uint64_t)c * n_cols_total + col) << log_lifted) + base);
 #pragma unroll
-            for (int z = 0; z < 16; z++) dst[4 * z] = y[z].v;
-        } else {
-            uint4 *dst = reinterpret_cast<uint4 *>(lde + (((uint64_t)c * n_cols_total + col) << log_lifted) + base);
-#pragma unroll
-            for (int v = 0; v < 4; v++) dst[v] = make_uint4(y[4 * v].v, y[4 * v + 1].v, y[4 * v + 2].v, y[4 * v + 3].v);
-        }
+        for (int v = 0; v < 4; v++) dst[v] = make_uint4(y[4 * v].v, y[4 * v + 1].v, y[4 * v + 2].v, y[4 * v + 3].v);
     }
 }
 
 int coset_lde(const ColDesc *d_cols, const uint32_t *d_used, uint32_t n_used, uint32_t n_cols_total,
               uint32_t log_lifted, uint32_t l_skip, uint32_t n_cosets, const Fp *d_shift_pows, Fp *lde,
-              hipStream_t s, uint64_t row0, uint32_t pad_lds_bytes, bool perm4) {
+              hipStream_t s, uint64_t row0, uint32_t pad_lds_bytes) {
     if (n_used == 0 || n_cosets == 0) return 0;
     if (row0 & ((1ull << l_skip) - 1)) return (int)hipErrorInvalidValue;
-    if (perm4 && (l_skip != 4 || log_lifted < 6 || row0 != 0)) return (int)hipErrorInvalidValue;
     const Twiddles *tw = twiddles();
     if (!tw || l_skip > LDE_TILE_LOG || l_skip > log_lifted) return (int)hipErrorInvalidValue;
     // d_shift_pows[k * N + i] = shift_k^i / N (the caller folds 1/N in)
     if (l_skip == 4) {
         dim3 grid16((unsigned)ceil_div(1ull << (log_lifted - 4), 256), n_used);
-        if (perm4)
-            OVM_LAUNCH(coset_lde16_kernel<true>, grid16, dim3(256), pad_lds_bytes > 65536 ? 65536 : pad_lds_bytes, s, d_cols, d_used, n_cols_total,
-                       log_lifted, n_cosets, d_shift_pows, lde, row0);
-        else
-            OVM_LAUNCH(coset_lde16_kernel<false>, grid16, dim3(256), pad_lds_bytes > 65536 ? 65536 : pad_lds_bytes, s, d_cols, d_used, n_cols_total,
-                       log_lifted, n_cosets, d_shift_pows, lde, row0);
+        OVM_LAUNCH(coset_lde16_kernel, grid16, dim3(256), pad_lds_bytes > 65536 ? 65536 : pad_lds_bytes, s, d_cols, d_used, n_cols_total, log_lifted,
+                           n_cosets, d_shift_pows, lde, row0);
         OVM_CHECK_LAUNCH();
         return 0;
     }
@@ -629,24 +613,8 @@ __global__ __launch_bounds__(RED_THREADS) void round0_eval_kernel(DevProgram pro
 // accumulators live in this loop's control flow] [accumulation loop: branch-free 96-bit MACs].
 // LDS image of the workgroup: word (row * R + r) * 256 + lane. The program arrays are read through
 // the constant address space so that they stay scalar loads next to the LDS-DMA writes.
-// LM ("lane-major", R = 4 only; round 4): the lane's four values of an LDS row are 16 CONTIGUOUS bytes -- word
-// row * 1024 + lane * 4 + r instead of (row * 4 + r) * 256 + lane. An operand is then ONE ds_read_b128 (a result one
-// ds_write_b128) instead of four dword accesses, and a column is staged by ONE global_load_lds_dwordx4 per lane (a kilobyte
-// per wave-instruction) instead of four dword DMAs -- for which the lane's four rows must be contiguous in memory: the coset
-// LDE writes its columns in that order (coset_lde16_kernel<true>) and round0_eval_body maps lanes to rows accordingly.
-template <int R, bool LM = false>
+template <int R>
 struct StagedVM {
-    static_assert(!LM || R == 4, "lane-major layout: four rows per lane");
-    static constexpr int RSTRIDE = LM ? 1 : RED_THREADS;   // words between the lane's consecutive values of a row
-    static __device__ __forceinline__ void ld_row(const uint32_t *row, Fp (&v)[R]) {
-        if constexpr (LM) {
-            const uint4 q = *reinterpret_cast<const uint4 *>(row);
-            v[0] = Fp::raw(q.x), v[1] = Fp::raw(q.y), v[2] = Fp::raw(q.z), v[3] = Fp::raw(q.w);
-        } else {
-#pragma unroll
-            for (int r = 0; r < R; r++) v[r] = Fp::raw(row[r * RED_THREADS]);
-        }
-    }
 
     // entries are two 16-byte words: weight, then {row offset, -, -, -}
     static __device__ __forceinline__ void run_accs(const OVM_CONST_AS uint4 *list, uint32_t n, const uint32_t *mine,
@@ -656,11 +624,10 @@ struct StagedVM {
         for (uint32_t i = n; i != 0; --i) {
             list += 2;
             const uint4 w_next = list[0], e_next = list[1];
-            Fp rv[R];
-            ld_row(mine + e.x, rv);
+            const uint32_t *row = mine + e.x;
 #pragma unroll
             for (int r = 0; r < R; r++) {
-                const uint32_t a = rv[r].v;
+                const uint32_t a = row[r * RED_THREADS];
                 mac96(acc[r].lo[0], acc[r].hi[0], a, w.x);
                 mac96(acc[r].lo[1], acc[r].hi[1], a, w.y);
                 mac96(acc[r].lo[2], acc[r].hi[2], a, w.z);
@@ -680,7 +647,9 @@ struct StagedVM {
 #pragma unroll
             for (int r = 0; r < R; r++) a[r] = prev[r];
         } else {
-            ld_row(mine + in.z, a);
+            const uint32_t *arow = mine + in.z;
+#pragma unroll
+            for (int r = 0; r < R; r++) a[r] = Fp::raw(arow[r * RED_THREADS]);
         }
         if (op & S_B_CONST) {
 #pragma unroll
@@ -689,7 +658,9 @@ struct StagedVM {
 #pragma unroll
             for (int r = 0; r < R; r++) b[r] = prev[r];
         } else {
-            ld_row(mine + in.w, b);
+            const uint32_t *brow = mine + in.w;
+#pragma unroll
+            for (int r = 0; r < R; r++) b[r] = Fp::raw(brow[r * RED_THREADS]);
         }
 #define OVM_RESULT(EXPR)                                            \
     {                                                               \
@@ -705,12 +676,8 @@ struct StagedVM {
 #undef OVM_RESULT
         if (!(op & S_NOSTORE)) {
             uint32_t *drow = mine + in.y;
-            if constexpr (LM) {
-                *reinterpret_cast<uint4 *>(drow) = make_uint4(prev[0].v, prev[1].v, prev[2].v, prev[3].v);
-            } else {
 #pragma unroll
-                for (int r = 0; r < R; r++) drow[r * RED_THREADS] = prev[r].v;
-            }
+            for (int r = 0; r < R; r++) drow[r * RED_THREADS] = prev[r].v;
         }
     }
     // Runs every block. src(col, r) = address of the lane's r-th cell of column `col`;
@@ -719,7 +686,7 @@ struct StagedVM {
     template <class Src, class After>
     static __device__ __forceinline__ void run(const DevStaged &prog, uint32_t *lds_image, const Src &src, After &&after) {
 #if defined(__HIP_DEVICE_COMPILE__)
-        uint32_t *mine = lds_image + threadIdx.x * (LM ? 4 : 1);  // this lane's word(s) of row 0
+        uint32_t *mine = lds_image + threadIdx.x;  // this lane's word of row 0
         const OVM_CONST_AS uint4 *blocks = (const OVM_CONST_AS uint4 *)prog.blocks;
         const OVM_CONST_AS uint32_t *loads = (const OVM_CONST_AS uint32_t *)prog.loads;
         const OVM_CONST_AS uint4 *code = (const OVM_CONST_AS uint4 *)prog.code;
@@ -727,7 +694,7 @@ struct StagedVM {
         // the next LDS read (it cannot tell the two staging buffers apart); the waits are placed by hand.
         // Destination: wave-uniform base in M0, the hardware adds lane * 4.
         const uint32_t lds_base = (uint32_t)(size_t)(__attribute__((address_space(3))) uint32_t *)lds_image +
-                                  (__builtin_amdgcn_readfirstlane(threadIdx.x) & ~63u) * (LM ? 16 : 4);
+                                  (__builtin_amdgcn_readfirstlane(threadIdx.x) & ~63u) * 4;
         // M0 is the compiler's register too (it does not honour an "m0" clobber: -Winline-asm): ONE asm statement per
         // column saves it, issues the R loads of the lane's R cells -- M0 = destination row, advanced by one LDS row
         // (RED_THREADS words) between loads -- and restores it, so no compiler-visible instruction ever sees a changed M0 and
@@ -741,15 +708,7 @@ struct StagedVM {
                 uint32_t saved;
                 static_assert(R == 1 || R == 2 || R == 4, "one asm form per R");
                 static_assert(RED_THREADS * 4 == 0x400, "the asm advances M0 by one LDS row = 0x400 bytes");
-                if constexpr (LM) {
-                    // the lane's four values are 16 contiguous bytes of the (permuted) column: one 16-byte DMA, landing at
-                    // M0 + lane * 16
-                    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off\n\t"
-                                 "s_mov_b32 m0, %0"
-                                 : "=&s"(saved)
-                                 : "s"(d), "v"(src(col, 0))
-                                 : "memory");
-                } else if constexpr (R == 1) {
+                if constexpr (R == 1) {
                     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %2, off\n\t"
                                  "s_mov_b32 m0, %0"
                                  : "=&s"(saved)
@@ -803,28 +762,24 @@ struct StagedVM {
     }
 };
 
-template <int R, int NOUT, bool LM = false>
+template <int R, int NOUT>
 struct StagedRound0 {
     static constexpr int ROWS = R;
-    static constexpr bool LANE_MAJOR = LM;
     DevStaged prog;
     __device__ __forceinline__ void operator()(const Fp *lde_k, uint32_t log_lifted, const uint64_t (&p)[R],
                                                EF (&out)[R][2]) const {
 #if defined(__HIP_DEVICE_COMPILE__)
         extern __shared__ uint32_t lds_image[];
-        const uint32_t *mine = lds_image + threadIdx.x * (LM ? 4 : 1);
+        const uint32_t *mine = lds_image + threadIdx.x;
         const OVM_CONST_AS uint4 *accs = (const OVM_CONST_AS uint4 *)prog.accs;
         Acc96 acc0[R], acc1[R];
 #pragma unroll
         for (int r = 0; r < R; r++) acc0[r].clear(), acc1[r].clear();
-        // lane-major: rows p[r] = ((4 g + r) << 4) | z live at words 4 (16 g + z) + r of the permuted column
-        const uint64_t lm_at = LM ? (((p[0] >> 6) << 4) | (p[0] & 15)) << 2 : 0;
-        StagedVM<R, LM>::run(
-            prog, lds_image,
-            [&](uint32_t col, int r) { return lde_k + ((uint64_t)col << log_lifted) + (LM ? lm_at : p[r]); },
+        StagedVM<R>::run(
+            prog, lds_image, [&](uint32_t col, int r) { return lde_k + ((uint64_t)col << log_lifted) + p[r]; },
             [&](const uint4 hd2) {
-                StagedVM<R, LM>::run_accs(accs + 2 * hd2.x, hd2.y, mine, acc0);
-                if (NOUT > 1) StagedVM<R, LM>::run_accs(accs + 2 * (hd2.x + hd2.y), hd2.z, mine, acc1);
+                StagedVM<R>::run_accs(accs + 2 * hd2.x, hd2.y, mine, acc0);
+                if (NOUT > 1) StagedVM<R>::run_accs(accs + 2 * (hd2.x + hd2.y), hd2.z, mine, acc1);
             });
 #pragma unroll
         for (int r = 0; r < R; r++) {
@@ -834,12 +789,12 @@ struct StagedRound0 {
 #endif
     }
 };
-template <int R, int NOUT, bool LM = false>
+template <int R, int NOUT>
 __global__ __launch_bounds__(RED_THREADS) void round0_staged_kernel(DevStaged prog, const Fp *lde,
                                                                     uint32_t n_cols_total, uint32_t log_lifted,
                                                                     uint32_t l_skip, uint32_t n_cosets, uint32_t n_out,
                                                                     const EF *eq_xi, EF add_const, EF *partials) {
-    round0_eval_body(StagedRound0<R, NOUT, LM>{prog}, lde, n_cols_total, log_lifted, l_skip, n_cosets, n_out,
+    round0_eval_body(StagedRound0<R, NOUT>{prog}, lde, n_cols_total, log_lifted, l_skip, n_cosets, n_out,
                      eq_xi, add_const, partials);
 }
 
@@ -990,12 +945,10 @@ int round0_eval_batched(const R0Job *d_jobs, const R0Job *h_jobs, uint32_t n_job
 
 int round0_eval(const DevProgram &prog, const DevStaged &staged, const Fp *lde, uint32_t n_cols_total,
                 uint32_t log_lifted, uint32_t l_skip, uint32_t n_cosets, uint32_t n_out, const EF *d_eq_xi,
-                EF add_const, const RedOut &ro, hipStream_t s, bool lane_major) {
+                EF add_const, const RedOut &ro, hipStream_t s) {
     if (n_cosets == 0) return 0;
     if (n_cosets > MAX_COSETS || n_out < 1 || n_out > 2 || (1u << l_skip) > 4 * RED_THREADS || log_lifted < l_skip)
         return (int)hipErrorInvalidValue;
-    // lane-major (the coset LDE was written in PERM4 order): the staged VM at four rows per lane, one output, l_skip 4
-    if (lane_major && (!staged.blocks || staged.rows != 4 || n_out != 1 || l_skip != 4 || log_lifted < 6 + 8)) return (int)hipErrorInvalidValue;
     // a skip domain larger than a workgroup (l_skip 9, 10): the grid is a multiple of N / RED_THREADS (eval.cuh)
     const uint32_t wg_per_domain = (1u << l_skip) > RED_THREADS ? (1u << l_skip) / RED_THREADS : 1;
     auto whole_domains = [&](uint32_t g) { return (g + wg_per_domain - 1) / wg_per_domain * wg_per_domain; };
@@ -1008,10 +961,7 @@ int round0_eval(const DevProgram &prog, const DevStaged &staged, const Fp *lde, 
 #define LAUNCH(R, NOUT)                                                                                             \
     OVM_LAUNCH((round0_staged_kernel<R, NOUT>), dim3(grid), dim3(RED_THREADS), lds_bytes, s, staged, lde, \
                        n_cols_total, log_lifted, l_skip, n_cosets, n_out, d_eq_xi, add_const, ro.partials)
-            if (lane_major) {
-                OVM_LAUNCH((round0_staged_kernel<4, 1, true>), dim3(grid), dim3(RED_THREADS), lds_bytes, s, staged, lde, n_cols_total, log_lifted,
-                           l_skip, n_cosets, n_out, d_eq_xi, add_const, ro.partials);
-            } else if (n_out == 1) {
+            if (n_out == 1) {
                 if (rows == 4) LAUNCH(4, 1);
                 else if (rows == 2) LAUNCH(2, 1);
                 else LAUNCH(1, 1);

@@ -53,10 +53,6 @@ struct Tuning {
     uint32_t gkr_la_max_log = 17;
     // OVM_GKR_LA_MIN_LOG: ... and only passes over at least 2^this pairs (0 = no lower limit)
     uint32_t gkr_la_min_log = 0;
-    // OVM_R0_LANE_MAJOR=0: the staged round 0 at four rows per lane keeps the [row][r][lane] LDS image and four dword DMAs
-    // per column (rounds 1-3). Default: [row][lane][r] -- 128-bit LDS operands, one 16-byte DMA per column and lane -- for
-    // traces whose coset LDE has the zerocheck as its only reader (stages.hip: StagedVM<4, true>).
-    bool r0_lane_major = true;
     bool lazy_w_accumulate = true;  // OVM_LAZY_W=0: whir_w_accumulate reduces every product (the parity tests compare the two)
     bool download_kernel = true;   // OVM_DOWNLOAD_KERNEL=0: small downloads through the runtime's copy + stream synchronisation
     bool trace = false;            // OVM_TRACE: wall-clock trace of the stages on stderr

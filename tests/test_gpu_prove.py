@@ -144,28 +144,6 @@ def test_gkr_passes_with_and_without_lookahead(dev, pkg, orc, monkeypatch, looka
     run_case(dev, pkg, orc, params, [airs.uniform_runner_air(24)], [(0, airs.splitmix64_bits(0xA11CE, 24 * h), h, [])])
 
 
-@pytest.mark.parametrize("lane_major", ["1", "0"])
-def test_round0_lane_major_staged_vm(dev, pkg, orc, monkeypatch, lane_major):
-    """Round 4: the staged round 0 at four rows per lane on 128-bit LDS operands -- the coset LDE written in the permuted row
-    order, one 16-byte LDS-DMA per column and lane, lane q = 16 g + z evaluating position z of chunks 4 g .. 4 g + 3
-    (stages.hip: StagedVM<4, true>). It applies to traces whose LDE only the zerocheck reads (no interactions) and that
-    get a launch of their own; OVM_R0_BATCH=0 + OVM_R0_ROWS=4 bring small traces there. Byte-identical to the oracle with
-    the layout on and off: a plain AIR with rotations (Fibonacci), a wide boolean AIR, and both in one proof next to an
-    AIR WITH interactions (which keeps the classic layout)."""
-    monkeypatch.setenv("OVM_R0_LANE_MAJOR", lane_major)
-    monkeypatch.setenv("OVM_R0_BATCH", "0")
-    monkeypatch.setenv("OVM_R0_ROWS", "4")
-    params = airs.test_params(l_skip=4, n_stack=12, k_whir=4)
-    h = 1 << 14
-    tr, pv = airs.fibonacci_trace(3, 5, h)
-    run_case(dev, pkg, orc, params, [airs.fibonacci_air()], [(0, tr, h, pv)])
-    plain = airs.benchmark_air(24, 48, 0)   # boolean constraints only: no interactions
-    run_case(dev, pkg, orc, params, [plain], [(0, airs.splitmix64_bits(0x1A4E, 24 * h), h, [])])
-    with_int = airs.uniform_runner_air(8)
-    run_case(dev, pkg, orc, params, [airs.fibonacci_air(), plain, with_int],
-             [(0, tr, h, pv), (1, airs.splitmix64_bits(0x1A4F, 24 * (h << 1)), h << 1, []), (2, airs.splitmix64_bits(7, 8 * h), h, [])])
-
-
 def sponge_before_openings(pkg, orc, raw):
     import ctypes
     s = pkg.SpongeState()

@@ -120,17 +120,6 @@ def test_gpu_keccak_reference_bench_instance_byte_identical(dev, pkg, orc):
 
 
 @pytest.mark.gpu
-def test_gpu_keccak_lane_major_round0_byte_identical(dev, pkg, orc, monkeypatch):
-    """The same instance with round 0 FORCED onto the lane-major staged VM (four rows per lane, its own launch: what the
-    2^20-row config B takes by default): the real 42.5 K-instruction Keccak-f program, 2 859 columns, two cosets, with
-    rotated columns -- byte for byte against the oracle."""
-    monkeypatch.setenv("OVM_R0_BATCH", "0")
-    monkeypatch.setenv("OVM_R0_ROWS", "4")
-    got, want = _hip_and_oracle(dev, pkg, orc, 1 << 10, 15, 21)
-    assert got == want
-
-
-@pytest.mark.gpu
 def test_gpu_keccak_flipped_bit_is_rejected(dev, pkg, orc):
     """A proof made by the HIP prover from a trace with ONE flipped bit must not verify."""
     import torch
