@@ -103,6 +103,35 @@ impl BulkExchange for IpcBulk {
         true
     }
 }
+/// Which carrier the library's IPC exchange is on (`ovm_hip_ipc_comm_status`): mapped peer buffers, or -- after a failed or
+/// overdue `hipIpcOpenMemHandle`, agreed by all ranks -- staged through host memory, and why.
+#[derive(Debug, Clone)]
+pub struct IpcStatus {
+    pub degraded: bool,
+    pub mappings: u32,
+    pub opens: u64,
+    pub exchanges: u64,
+    pub staged_exchanges: u64,
+    pub reason: String,
+}
+
+impl IpcBulk {
+    pub fn status(&self) -> Result<IpcStatus, HipError> {
+        // SAFETY: `ipc` is a live communicator; the library fills the POD it is handed.
+        let mut st: ffi::OvmIpcStatus = unsafe { std::mem::zeroed() };
+        HipError::from_result("ovm_hip_ipc_comm_status", unsafe { ffi::ovm_hip_ipc_comm_status(self.ipc, &mut st) })?;
+        let reason = unsafe { std::ffi::CStr::from_ptr(st.reason.as_ptr()) }.to_string_lossy().into_owned();
+        Ok(IpcStatus {
+            degraded: st.degraded != 0,
+            mappings: st.mappings,
+            opens: st.opens,
+            exchanges: st.exchanges,
+            staged_exchanges: st.staged_exchanges,
+            reason,
+        })
+    }
+}
+
 impl Drop for IpcBulk {
     fn drop(&mut self) {
         // SAFETY: created by ovm_hip_ipc_comm_create, destroyed once -- before the shared-memory communicator it
