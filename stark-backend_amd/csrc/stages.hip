@@ -2360,14 +2360,12 @@ __global__ __launch_bounds__(RED_THREADS) void stacked_round0_kernel(const Fp *b
         le.clear();
         lr.clear();
         if (lam_rot) {
-#pragma unroll 8
             for (uint32_t i = i0; i < i1; i++) {
                 const uint32_t v = base[((uint64_t)i << log_len) + p].v;
                 mac_weight(le, lam_eq, i, v);
                 mac_weight(lr, lam_rot, i, v);
             }
         } else {  // no slice of this window has a rotated opening: its weights are all zero
-#pragma unroll 8
             for (uint32_t i = i0; i < i1; i++) mac_weight(le, lam_eq, i, base[((uint64_t)i << log_len) + p].v);
         }
         const EF qe = le.finish(), qr = lr.finish();
@@ -2558,7 +2556,6 @@ __global__ void whir_mu_batch_kernel(const Fp *msg, uint32_t width, uint32_t log
     if (i >= (1ull << log_h)) return;
     Acc96 lazy;
     lazy.clear();
-#pragma unroll 8
     for (uint32_t j = 0; j < width; j++) mac_weight(lazy, mu_pows, mu_offset + j, msg[((uint64_t)j << log_h) + i].v);
     const EF sum = lazy.finish();
     st_ef(f + i, accumulate ? ld_ef(f + i) + sum : sum);
