@@ -46,6 +46,7 @@ pub struct OvmIpcStatus {
     pub opens: u64,
     pub exchanges: u64,
     pub staged_exchanges: u64,
+    pub bounced_exchanges: u64,
     pub reason: [c_char; 192],
 }
 

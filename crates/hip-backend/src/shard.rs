@@ -112,6 +112,8 @@ pub struct IpcStatus {
     pub opens: u64,
     pub exchanges: u64,
     pub staged_exchanges: u64,
+    /// exchanges whose send buffer lay in an allocation the runtime cannot map (bit 31 of its size) and went out as a copy
+    pub bounced_exchanges: u64,
     pub reason: String,
 }
 
@@ -127,6 +129,7 @@ impl IpcBulk {
             opens: st.opens,
             exchanges: st.exchanges,
             staged_exchanges: st.staged_exchanges,
+            bounced_exchanges: st.bounced_exchanges,
             reason,
         })
     }

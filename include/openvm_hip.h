@@ -449,13 +449,18 @@ int ovm_hip_ipc_abort(void *comm, int code);
  * map IN TURN (never two processes inside hipIpcOpenMemHandle at once), every open has a deadline (OVM_IPC_OPEN_TIMEOUT_S,
  * default 20 s), and a failed or overdue open -- agreed by all ranks -- DEGRADES the communicator: this and every later
  * bulk exchange is staged through pinned host memory and the shared-memory all-gather (slow, never stuck); the proof in
- * flight completes. ovm_hip_ipc_comm_status reports which carrier a communicator is on and why. */
+ * flight completes. ovm_hip_ipc_comm_status reports which carrier a communicator is on and why.
+ * One cause is known and avoided outright: on this runtime (ROCm 7.2, dmabuf IPC) hipIpcOpenMemHandle never returns for an
+ * allocation whose SIZE has bit 31 set (2-4 GiB, 6-8 GiB, ...: tools/ipc_repro.py). A send buffer inside such an allocation
+ * is copied device-to-device into a buffer of the library's own with a safe size, and that one is exported
+ * (`bounced_exchanges`; OVM_IPC_NO_BOUNCE=1 turns the rule off for the reproducer). */
 typedef struct {
     uint32_t degraded;          /* 1: bulk exchanges are staged through host memory */
     uint32_t mappings;          /* peer allocations currently mapped */
     uint64_t opens;             /* hipIpcOpenMemHandle calls made so far */
     uint64_t exchanges;         /* bulk exchanges that went through the mapped path's set-up */
     uint64_t staged_exchanges;  /* bulk exchanges staged through host memory */
+    uint64_t bounced_exchanges; /* exchanges whose send buffer was exported as a device-side copy (see below) */
     char reason[192];           /* why it degraded (empty otherwise) */
 } ovm_ipc_status_t;
 int ovm_hip_ipc_comm_status(const ovm_ipc_comm_t *comm, ovm_ipc_status_t *out);

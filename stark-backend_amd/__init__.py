@@ -66,7 +66,7 @@ class ProverConfigStruct(Structure):
 class IpcStatusStruct(Structure):
     """ovm_ipc_status_t"""
     _fields_ = [("degraded", c_uint32), ("mappings", c_uint32), ("opens", c_uint64), ("exchanges", c_uint64),
-                ("staged_exchanges", c_uint64), ("reason", ctypes.c_char * 192)]
+                ("staged_exchanges", c_uint64), ("bounced_exchanges", c_uint64), ("reason", ctypes.c_char * 192)]
 
 
 class SpongeState(Structure):
@@ -509,7 +509,7 @@ class Shard:
         st = IpcStatusStruct()
         check(_lib().ovm_hip_ipc_comm_status(self.ipc, ctypes.byref(st)), "ovm_hip_ipc_comm_status")
         return {"degraded": bool(st.degraded), "mappings": int(st.mappings), "opens": int(st.opens), "exchanges": int(st.exchanges),
-                "staged_exchanges": int(st.staged_exchanges), "reason": st.reason.decode(errors="replace")}
+                "staged_exchanges": int(st.staged_exchanges), "bounced_exchanges": int(st.bounced_exchanges), "reason": st.reason.decode(errors="replace")}
 
     def _set_abi(self):
         """(Re)build the ovm_shard_t for the current ``bulk`` mode. alltoall=False hands the library a null all-to-all:

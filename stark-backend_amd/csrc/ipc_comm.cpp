@@ -89,7 +89,44 @@ struct ovm_ipc_comm {
     std::string why;
     double open_timeout_s = 20.0;
     int force_open = 0;
-    uint64_t opens = 0, staged_exchanges = 0;
+    uint64_t opens = 0, staged_exchanges = 0, bounced_exchanges = 0;
+    // The runtime of this image (ROCm 7.2, dmabuf IPC) never returns from hipIpcOpenMemHandle when BIT 31 OF THE EXPORTED
+    // ALLOCATION'S SIZE is set -- 2.0-3.99 GiB, 6.0-7.99 GiB, 11 GiB hang; 1.9, 4.0, 5.99, 12 GiB map in 2 ms, whatever else
+    // the processes hold (tools/ipc_repro.py, profiles/r04/ipc_repro_sizes_r04.log). An owner whose send buffer lies in such
+    // an allocation exports a COPY instead: a bounce buffer of its own with a safe size (one device-to-device copy per
+    // exchange, ~0.1 ms per 256 MB; nothing to wait out, no host staging). The deadline stays for what this rule misses.
+    uint8_t *d_bounce = nullptr;
+    uint64_t d_bounce_cap = 0;
+    bool no_bounce = false;  // OVM_IPC_NO_BOUNCE=1: export the caller's allocation whatever its size (the reproducer)
+    static bool unsafe_size(uint64_t size) { return (size >> 31) & 1; }
+    static uint64_t safe_size_for(uint64_t need) {
+        uint64_t cap = (need + (2u << 20) - 1) & ~uint64_t((2u << 20) - 1);
+        if (unsafe_size(cap)) cap = ((cap >> 32) + 1) << 32;
+        return cap;
+    }
+    // a bounce buffer of at least `need` bytes whose allocation has a safe size; false: none to be had (export the original)
+    bool ensure_bounce(uint64_t need) {
+        if (d_bounce_cap >= need) return true;
+        if (d_bounce) (void)hipFree(d_bounce);
+        d_bounce = nullptr;
+        d_bounce_cap = 0;
+        const uint64_t cap = safe_size_for(need);
+        void *p = nullptr;
+        if (hipMalloc(&p, cap) != hipSuccess) {
+            (void)hipGetLastError();
+            return false;
+        }
+        void *base = nullptr;
+        size_t size = 0;
+        if (hipMemGetAddressRange((hipDeviceptr_t *)&base, &size, (hipDeviceptr_t)p) != hipSuccess || base != p || unsafe_size(size)) {
+            (void)hipGetLastError();
+            (void)hipFree(p);
+            return false;
+        }
+        d_bounce = (uint8_t *)p;
+        d_bounce_cap = cap;
+        return true;
+    }
     uint8_t *h_send = nullptr, *h_recv = nullptr;  // pinned staging of the degraded mode
     uint64_t h_send_cap = 0, h_recv_cap = 0;
     // mappings of peers' allocations, by (owner rank, handle bytes), with the owner's BUFFER ID of the allocation and the
@@ -126,10 +163,18 @@ struct ovm_ipc_comm {
         void *base = nullptr;
         size_t size = 0;
         if (e == hipSuccess) e = hipMemGetAddressRange((hipDeviceptr_t *)&base, &size, (hipDeviceptr_t)d_send);
+        const uint8_t *exported = (const uint8_t *)d_send;
+        if (e == hipSuccess && unsafe_size(size) && !no_bounce && ensure_bounce(send_bytes)) {
+            e = hipMemcpyAsync(d_bounce, d_send, send_bytes, hipMemcpyDeviceToDevice, stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(stream);
+            base = d_bounce;
+            exported = d_bounce;
+            bounced_exchanges++;
+        }
         if (e == hipSuccess) {
             // (asked for every time: a segment that went back to the driver may have a successor at the same address)
             e = hipIpcGetMemHandle(&m.handle, base);
-            m.offset = (uint64_t)((const uint8_t *)d_send - (const uint8_t *)base);
+            m.offset = (uint64_t)(exported - (const uint8_t *)base);
             unsigned long long id = 0;
             if (hipPointerGetAttribute(&id, HIP_POINTER_ATTRIBUTE_BUFFER_ID, (hipDeviceptr_t)base) == hipSuccess) m.buffer_id = id;
             else (void)hipGetLastError();
@@ -350,6 +395,7 @@ int ovm_hip_ipc_comm_create(ovm_shm_comm_t *shm, uint32_t rank, uint32_t world, 
     c->rank = rank;
     c->world = world;
     if (const char *e = getenv("OVM_IPC_OPEN_TIMEOUT_S")) c->open_timeout_s = std::max(0.05, atof(e));
+    if (const char *e = getenv("OVM_IPC_NO_BOUNCE")) c->no_bounce = atoi(e) != 0;
     if (const char *e = getenv("OVM_IPC_FORCE_OPEN_FAIL")) c->force_open = atoi(e) ? 1 : 0;
     if (const char *e = getenv("OVM_IPC_FORCE_OPEN_HANG")) c->force_open = atoi(e) ? 2 : c->force_open;
     *out = c;
@@ -359,6 +405,7 @@ int ovm_hip_ipc_comm_create(ovm_shm_comm_t *shm, uint32_t rank, uint32_t world, 
 void ovm_hip_ipc_comm_destroy(ovm_ipc_comm_t *c) {
     if (!c) return;
     for (auto &kv : c->opened) (void)hipIpcCloseMemHandle(kv.second.p);
+    if (c->d_bounce) (void)hipFree(c->d_bounce);
     if (c->h_send) (void)hipHostFree(c->h_send);
     if (c->h_recv) (void)hipHostFree(c->h_recv);
     delete c;
@@ -372,6 +419,7 @@ int ovm_hip_ipc_comm_status(const ovm_ipc_comm_t *c, ovm_ipc_status_t *out) {
     out->opens = c->opens;
     out->exchanges = c->exchanges;
     out->staged_exchanges = c->staged_exchanges;
+    out->bounced_exchanges = c->bounced_exchanges;
     snprintf(out->reason, sizeof out->reason, "%s", c->why.c_str());
     return 0;
 }

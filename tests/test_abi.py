@@ -139,7 +139,7 @@ def test_struct_layouts_match_header(pkg):
     assert ctypes.sizeof(pkg.ShardStruct) == 48 and pkg.ShardStruct.allgather_device.offset == 24
     assert pkg.ShardStruct.alltoall_device.offset == 32 and pkg.ShardStruct.abort.offset == 40
     assert ctypes.sizeof(pkg.ProverConfigStruct) == 24 and pkg.ProverConfigStruct.cache_limit_bytes.offset == 16
-    assert ctypes.sizeof(pkg.IpcStatusStruct) == 224 and pkg.IpcStatusStruct.reason.offset == 32
+    assert ctypes.sizeof(pkg.IpcStatusStruct) == 232 and pkg.IpcStatusStruct.reason.offset == 40
 
 
 def test_rust_crate_only_calls_declared_entries():
