@@ -164,7 +164,7 @@ struct ovm_ipc_comm {
         size_t size = 0;
         if (e == hipSuccess) e = hipMemGetAddressRange((hipDeviceptr_t *)&base, &size, (hipDeviceptr_t)d_send);
         const uint8_t *exported = (const uint8_t *)d_send;
-        if (e == hipSuccess && unsafe_size(size) && !no_bounce && ensure_bounce(send_bytes)) {
+        if (e == hipSuccess && world > 1 && unsafe_size(size) && !no_bounce && ensure_bounce(send_bytes)) {
             e = hipMemcpyAsync(d_bounce, d_send, send_bytes, hipMemcpyDeviceToDevice, stream);
             if (e == hipSuccess) e = hipStreamSynchronize(stream);
             base = d_bounce;

@@ -238,10 +238,12 @@ def test_config_e_two_shards_on_one_gpu_verifies(orc, tmp_path):
     free, _ = torch.cuda.mem_get_info()
     if free < 200 * (1 << 30):
         pytest.skip("needs ~200 GB of free HBM")
-    # (bulk exchange staged through shared memory: with two 85 GB processes on ONE GPU, hipIpcOpenMemHandle of the
-    # peer's segment did not return -- observed at this size only, 184 GB of the 288 in use; the IPC carrier is what
-    # every other logical-shard test runs, and on real hardware each rank has a GPU of its own)
-    got = run_sharded("gen:24:100:24:2", 2, tmp_path, bulk="shm")
+    # (round 3 ran this with the bulk exchange staged through shared memory: hipIpcOpenMemHandle of the peer's 3.2 GB segment
+    # did not return. Root cause, round 4: bit 31 of that allocation's size -- csrc/ipc_comm.cpp exports a safe-sized copy in
+    # that case, so the test is back on the IPC carrier every other logical-shard test runs; should an open stall for another
+    # reason, the exchange degrades to host staging after its deadline and the proof still has to verify. pytest -s shows
+    # which carrier ran: "[shard_worker rank r] ipc: {...}")
+    got = run_sharded("gen:24:100:24:2", 2, tmp_path, bulk="ipc")
     blob = airs.pk_blob(airs.stress_params(24, 2), [airs.uniform_runner_air_partitioned(100)] * 2)
     orc.verify(blob, got)
     bad = bytearray(got)

@@ -13,7 +13,7 @@ BENCH="python3 bench.py --steps 1 --warmup 1 --profile-steps 0 --no-cpu-baseline
 rocprofv3 --kernel-trace --stats -d "$OUT/kt" -o run --output-format rocpd csv -- $BENCH > "$OUT/kt.log" 2>&1
 KT=$(find "$OUT/kt" -name "*_results.db" | head -1)
 python3 tools/rocpd_stats.py "$KT" --second-half --csv "$OUT/prove_kernel_stats.csv" > "$OUT/prove_kernel_stats.txt" 2>&1
-python3 tools/rocpd_gaps.py "$KT" --second-half > "$OUT/idle_gaps.txt" 2>&1
+python3 tools/rocpd_gaps.py "$KT" --second-half --list-over 25 > "$OUT/idle_gaps.txt" 2>&1
 rocprofv3 --pmc FETCH_SIZE -d "$OUT/fetch" -o run --output-format rocpd -- $BENCH > "$OUT/fetch.log" 2>&1
 rocprofv3 --pmc WRITE_SIZE -d "$OUT/write" -o run --output-format rocpd -- $BENCH > "$OUT/write.log" 2>&1
 FE=$(find "$OUT/fetch" -name "*_results.db" | head -1)

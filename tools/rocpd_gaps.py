@@ -3,7 +3,10 @@
 database: total, histogram, and the idle attributed to the kernel that PRECEDES each gap (i.e. which
 stage's host round trip the device was waiting for).
 
-    python tools/rocpd_gaps.py run_results.db [--second-half]
+    python tools/rocpd_gaps.py run_results.db [--second-half] [--list-over MICROSECONDS]
+
+--list-over N: also lists every gap longer than N us in time order (offset into the prove, kernel before -> kernel after):
+where the host does enough work between two launches for the device to notice.
 """
 import collections
 import sqlite3
@@ -54,12 +57,16 @@ def main():
     kernel_time = sum(e - s for _, s, e in rows)
     per = collections.defaultdict(lambda: [0, 0])
     hist = collections.Counter()
+    list_over = float(sys.argv[sys.argv.index("--list-over") + 1]) * 1e3 if "--list-over" in sys.argv else None
+    long_gaps = []
     busy, cur_end, last_name = 0, rows[0][1], rows[0][0]
     for n, s0, e0 in rows:
         if s0 > cur_end:
             g = s0 - cur_end
             per[last_name][0] += g
             per[last_name][1] += 1
+            if list_over is not None and g > list_over:
+                long_gaps.append((cur_end - rows[0][1], g, last_name, n))
             b = 0
             while (2 << b) * 1000 < g:
                 b += 1
@@ -82,6 +89,12 @@ def main():
     print("idle after kernel (top 15):")
     for n, (g, c) in sorted(per.items(), key=lambda kv: -kv[1][0])[:15]:
         print(f"  {n[:44]:44s} {g / 1e6:7.3f} ms over {c:4d} gaps ({g / max(c, 1) / 1e3:6.1f} us each)")
+
+
+    if long_gaps:
+        print(f"gaps over {list_over / 1e3:.0f} us in time order ({sum(g for _, g, _, _ in long_gaps) / 1e6:.3f} ms in {len(long_gaps)} gaps):")
+        for at, g, a, b in long_gaps:
+            print(f"  at {at / 1e6:7.3f} ms  {g / 1e3:7.1f} us   {a[:40]:40s} -> {b[:40]}")
 
 
 if __name__ == "__main__":
