@@ -150,6 +150,9 @@ def test_ipc_open_of_a_2_5_gib_allocation_still_hangs_without_the_rule_and_the_d
     """The rule switched off (OVM_IPC_NO_BOUNCE=1): the open of the peer's 2.5 GiB allocation does not return, the 3 s deadline
     fires on both ranks in turn and the exchanges are staged through host memory -- data intact. If a later runtime fixes the
     open, this test skips and says so."""
+    if os.environ.get("OVM_IPC_RAW_HANG_TEST", "0") != "1":
+        pytest.skip("opt-in (OVM_IPC_RAW_HANG_TEST=1): provokes the runtime's hang on purpose; its last run is "
+                    "profiles/r04/gputest_ipc_r04n.log and the reproducer logs beside it")
     recs = _ipc_repro(2.5, {"OVM_IPC_OPEN_TIMEOUT_S": "3", "OVM_IPC_NO_BOUNCE": "1"})
     if not any(st["ipc"]["degraded"] for st in recs):
         pytest.skip("this runtime maps a 2.5 GiB allocation: the size rule of csrc/ipc_comm.cpp is no longer needed here")
