@@ -173,6 +173,7 @@ struct Mail {
     volatile uint32_t r[4];
     volatile uint32_t r_seq;    // host -> device: the challenge of sub-round r_seq
 };
+template <bool FENCED>
 __global__ void k_server(const Rec *table, const EF *eq, uint32_t log_n, uint32_t layers, Mail *mail, uint32_t *out_state) {
     extern __shared__ uint8_t lds[];
     const uint32_t n = 1u << log_n;
@@ -194,9 +195,18 @@ __global__ void k_server(const Rec *table, const EF *eq, uint32_t log_n, uint32_
             if (threadIdx.x == 0) {
                 const uint32_t *w = (const uint32_t *)S;
                 for (int k = 0; k < 8; k++) __hip_atomic_store((uint32_t *)&mail->sums[k], w[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                __hip_atomic_store((uint32_t *)&mail->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-                // (bounded: a host that went away must not leave a kernel spinning on the box)
-                for (uint32_t spins = 0; __hip_atomic_load((uint32_t *)&mail->r_seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != seq && spins < (1u << 22); spins++) {
+                // (bounded polls: a host that went away must not leave a kernel spinning on the box)
+                if (FENCED) {
+                    __hip_atomic_store((uint32_t *)&mail->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+                    for (uint32_t spins = 0; __hip_atomic_load((uint32_t *)&mail->r_seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != seq && spins < (1u << 22); spins++) {
+                    }
+                } else {
+                    // the library's fence-free form (device_common.h): write-through stores, wait for their acknowledgement,
+                    // then the flag; the poll and the challenge are system-scope loads, which never hit a cache
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __hip_atomic_store((uint32_t *)&mail->seq, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    for (uint32_t spins = 0; __hip_atomic_load((uint32_t *)&mail->r_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != seq && spins < (1u << 22); spins++) {
+                    }
                 }
                 for (int k = 0; k < 4; k++) r_sh->c[k].v = __hip_atomic_load((uint32_t *)&mail->r[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             }
@@ -236,7 +246,8 @@ __global__ void k_round(const Rec *in, Rec *out, const EF *eq_l, uint32_t pairs,
     if (threadIdx.x == 0) {
         const uint32_t *w = (const uint32_t *)(scratch + 32);
         for (int k = 0; k < 8; k++) __hip_atomic_store((uint32_t *)&mail->sums[k], w[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        __hip_atomic_store((uint32_t *)&mail->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the prover's fence-free mailbox)
+        __hip_atomic_store((uint32_t *)&mail->seq, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
@@ -288,32 +299,36 @@ int main() {
     hipStream_t st;
     CHECK(hipStreamCreate(&st));
     CHECK(hipFuncSetAttribute((const void *)k_device, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-    CHECK(hipFuncSetAttribute((const void *)k_server, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-    printf("records  threads   device us/sub-round   server us/sub-round   launches us/sub-round   (host work %.1f us in the last two)\n", HOST_WORK_US);
+    CHECK(hipFuncSetAttribute((const void *)k_server<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+    CHECK(hipFuncSetAttribute((const void *)k_server<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+    printf("records  threads   device us/sub-round          server (fences)   server (fence-free)   launches us/sub-round   (host work %.1f us in the last three)\n", HOST_WORK_US);
     for (uint32_t log_n = 7; log_n <= max_log; log_n++) {
         for (uint32_t threads : {256u, 1024u}) {
             const size_t lds = (sizeof(Rec) << (log_n + 1)) + 1024;
             const uint32_t rounds = layers * log_n;
-            double us_dev = 0, us_srv = 0, us_launch = 0;
+            double us_dev = 0, us_srv = 0, us_srv_ff = 0, us_launch = 0;
             for (int rep = 0; rep < 3; rep++) {  // (the last repetition counts)
                 // device
                 auto t0 = std::chrono::steady_clock::now();
                 hipLaunchKernelGGL(k_device, dim3(1), dim3(threads), lds, st, d_table, d_eq, log_n, layers, d_state, d_ticks);
                 CHECK(hipStreamSynchronize(st));
                 us_dev = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / rounds;
-                // server
-                mail->seq = 0;
-                mail->r_seq = 0;
-                t0 = std::chrono::steady_clock::now();
-                hipLaunchKernelGGL(k_server, dim3(1), dim3(threads), lds, st, d_table, d_eq, log_n, layers, mail, d_state);
-                for (uint32_t s = 1; s <= rounds; s++) {
-                    wait_seq(mail, s);
-                    host_work();
-                    for (int k = 0; k < 4; k++) mail->r[k] = (mail->sums[k] ^ (s * 2654435761u)) % bb::P;
-                    __atomic_store_n((uint32_t *)&mail->r_seq, s, __ATOMIC_RELEASE);
+                // server, with fences and without
+                for (int fenced = 1; fenced >= 0; fenced--) {
+                    mail->seq = 0;
+                    mail->r_seq = 0;
+                    t0 = std::chrono::steady_clock::now();
+                    if (fenced) hipLaunchKernelGGL(k_server<true>, dim3(1), dim3(threads), lds, st, d_table, d_eq, log_n, layers, mail, d_state);
+                    else hipLaunchKernelGGL(k_server<false>, dim3(1), dim3(threads), lds, st, d_table, d_eq, log_n, layers, mail, d_state);
+                    for (uint32_t s = 1; s <= rounds; s++) {
+                        wait_seq(mail, s);
+                        host_work();
+                        for (int k = 0; k < 4; k++) mail->r[k] = (mail->sums[k] ^ (s * 2654435761u)) % bb::P;
+                        __atomic_store_n((uint32_t *)&mail->r_seq, s, __ATOMIC_RELEASE);
+                    }
+                    CHECK(hipStreamSynchronize(st));
+                    (fenced ? us_srv : us_srv_ff) = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / rounds;
                 }
-                CHECK(hipStreamSynchronize(st));
-                us_srv = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / rounds;
                 // launches
                 mail->seq = 0;
                 uint32_t seq = 0;
@@ -342,8 +357,8 @@ int main() {
             }
             long long ticks = 0;
             CHECK(hipMemcpy(&ticks, d_ticks, 8, hipMemcpyDeviceToHost));
-            printf("2^%-2u     %5u     %8.2f (in-kernel %6.2f)   %8.2f              %8.2f\n", log_n, threads, us_dev, ticks / 100.0 / rounds, us_srv,
-                   us_launch);
+            printf("2^%-2u     %5u     %8.2f (in-kernel %6.2f)   %8.2f          %8.2f              %8.2f\n", log_n, threads, us_dev, ticks / 100.0 / rounds,
+                   us_srv, us_srv_ff, us_launch);
         }
     }
     return 0;
