@@ -2359,14 +2359,34 @@ __global__ __launch_bounds__(RED_THREADS) void stacked_round0_kernel(const Fp *b
         Acc96 le, lr;
         le.clear();
         lr.clear();
+        // Four slices' loads in flight per lane (unrolled by hand: the compiler leaves a loop around the multiply-add asm
+        // alone, `#pragma unroll` or not, and then every load's latency is exposed -- the sums are exact integers, any order)
+        const Fp *col = base + p;
+        uint32_t i = i0;
         if (lam_rot) {
-            for (uint32_t i = i0; i < i1; i++) {
-                const uint32_t v = base[((uint64_t)i << log_len) + p].v;
+            for (; i + 4 <= i1; i += 4) {
+                const uint32_t v0 = col[(uint64_t)i << log_len].v, v1 = col[(uint64_t)(i + 1) << log_len].v;
+                const uint32_t v2 = col[(uint64_t)(i + 2) << log_len].v, v3 = col[(uint64_t)(i + 3) << log_len].v;
+                mac_weight(le, lam_eq, i, v0), mac_weight(lr, lam_rot, i, v0);
+                mac_weight(le, lam_eq, i + 1, v1), mac_weight(lr, lam_rot, i + 1, v1);
+                mac_weight(le, lam_eq, i + 2, v2), mac_weight(lr, lam_rot, i + 2, v2);
+                mac_weight(le, lam_eq, i + 3, v3), mac_weight(lr, lam_rot, i + 3, v3);
+            }
+            for (; i < i1; i++) {
+                const uint32_t v = col[(uint64_t)i << log_len].v;
                 mac_weight(le, lam_eq, i, v);
                 mac_weight(lr, lam_rot, i, v);
             }
         } else {  // no slice of this window has a rotated opening: its weights are all zero
-            for (uint32_t i = i0; i < i1; i++) mac_weight(le, lam_eq, i, base[((uint64_t)i << log_len) + p].v);
+            for (; i + 4 <= i1; i += 4) {
+                const uint32_t v0 = col[(uint64_t)i << log_len].v, v1 = col[(uint64_t)(i + 1) << log_len].v;
+                const uint32_t v2 = col[(uint64_t)(i + 2) << log_len].v, v3 = col[(uint64_t)(i + 3) << log_len].v;
+                mac_weight(le, lam_eq, i, v0);
+                mac_weight(le, lam_eq, i + 1, v1);
+                mac_weight(le, lam_eq, i + 2, v2);
+                mac_weight(le, lam_eq, i + 3, v3);
+            }
+            for (; i < i1; i++) mac_weight(le, lam_eq, i, col[(uint64_t)i << log_len].v);
         }
         const EF qe = le.finish(), qr = lr.finish();
         uint64_t x = p >> l_skip, xp = x == 0 ? nx - 1 : x - 1;
@@ -2556,7 +2576,18 @@ __global__ void whir_mu_batch_kernel(const Fp *msg, uint32_t width, uint32_t log
     if (i >= (1ull << log_h)) return;
     Acc96 lazy;
     lazy.clear();
-    for (uint32_t j = 0; j < width; j++) mac_weight(lazy, mu_pows, mu_offset + j, msg[((uint64_t)j << log_h) + i].v);
+    // (four columns' loads in flight per lane: unrolled by hand, see stacked_round0_kernel)
+    const Fp *col = msg + i;
+    uint32_t j = 0;
+    for (; j + 4 <= width; j += 4) {
+        const uint32_t v0 = col[(uint64_t)j << log_h].v, v1 = col[(uint64_t)(j + 1) << log_h].v;
+        const uint32_t v2 = col[(uint64_t)(j + 2) << log_h].v, v3 = col[(uint64_t)(j + 3) << log_h].v;
+        mac_weight(lazy, mu_pows, mu_offset + j, v0);
+        mac_weight(lazy, mu_pows, mu_offset + j + 1, v1);
+        mac_weight(lazy, mu_pows, mu_offset + j + 2, v2);
+        mac_weight(lazy, mu_pows, mu_offset + j + 3, v3);
+    }
+    for (; j < width; j++) mac_weight(lazy, mu_pows, mu_offset + j, col[(uint64_t)j << log_h].v);
     const EF sum = lazy.finish();
     st_ef(f + i, accumulate ? ld_ef(f + i) + sum : sum);
 }
