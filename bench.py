@@ -209,7 +209,9 @@ def engines_run(args, pkg, torch, pk, traces, cells, barrier, local_rank):
 
         def worker(i):
             try:
-                with torch.cuda.stream(torch.cuda.Stream(device=local_rank)):
+                # --engines-priority first-high: engine 0's stream gets the high dispatch priority, the others the default one
+                prio = -1 if (args.engines_priority == "first-high" and i == 0) else 0
+                with torch.cuda.stream(torch.cuda.Stream(device=local_rank, priority=prio)):
                     d = pkg.Device(local_rank)
                     d.prove(pk, traces)            # this thread's pools, mailboxes and twiddles: outside the timing
                     torch.cuda.current_stream().synchronize()
@@ -240,7 +242,8 @@ def engines_run(args, pkg, torch, pk, traces, cells, barrier, local_rank):
             t.join()
         wall = time.perf_counter() - t0
         barrier()
-        rec = {"engines": k, "steps_per_engine": steps, "stagger_ms": args.engines_stagger_ms, "wall_ms": round(wall * 1e3, 2),
+        rec = {"engines": k, "steps_per_engine": steps, "stagger_ms": args.engines_stagger_ms, "stream_priority": args.engines_priority,
+               "wall_ms": round(wall * 1e3, 2),
                "cells_per_s": round(k * steps * cells / wall, 1), "per_engine_prove_ms": [round(x, 3) for x in per_engine],
                # every engine's own rate added up (what a long-running pipeline sees; `cells_per_s` also pays the start-up stagger)
                "cells_per_s_steady": round(sum(cells / (x * 1e-3) for x in per_engine if x > 0), 1),
@@ -292,6 +295,9 @@ def main():
                     help="--engines K: engine i starts its timed proofs i x this many milliseconds after engine 0 (two provers in "
                          "lock step hash at the same time; half a proof apart, one's VALU-bound hashing runs beside the other's "
                          "memory- and latency-bound stages)")
+    ap.add_argument("--engines-priority", default="equal", choices=["equal", "first-high"],
+                    help="--engines K: 'first-high' gives engine 0's stream the high dispatch priority (one proof at nearly full "
+                         "speed, the others in what it leaves free) instead of K equal streams")
     ap.add_argument("--no-other-form", action="store_true",
                     help="N = 1: skip the few extra steps that measure the OTHER form (partitioned beside plain, or plain beside "
                          "--partitioned): tools/profile_round.sh uses it so that the process makes exactly warmup + steps proofs")
