@@ -200,6 +200,9 @@ int gkr_eval_leaves(const DevProgram &prog, const DevStaged &staged, const EF *d
                     const uint64_t *d_leaf_base, const uint32_t *d_leaf_log_len, Fp norm, FracPlanes leaves,
                     hipStream_t s);
 int gkr_build_layer(FracPlanes child, FracPlanes parent, uint64_t n_parent, bool child_p_base, hipStream_t s);
+// two levels in one pass (parents and grandparents of `child`); edge_*: the parents without a sibling in the range
+int gkr_build_two_layers(FracPlanes child, FracPlanes parent, FracPlanes grand, uint64_t n_grand, const FracPlanes *edge_child,
+                         const FracPlanes *edge_parent, uint32_t n_edges, bool child_p_base, hipStream_t s);
 // out[X-1] = sum_y eq[y] * (p0 q1 + p1 q0 + lambda q0 q1)(X, y), X = 1..n_points (2 or 3; eq: n_pairs weights)
 int gkr_round(FracPlanes rec, bool p_base, EqSplit eq, uint64_t n_pairs, EF lambda, uint32_t n_points,
               const RedOut &ro, hipStream_t s);

@@ -1816,6 +1816,56 @@ __global__ void gkr_build_kernel(FracPlanes child, FracPlanes parent, uint64_t n
     stp(parent.P(), parent.stride, i, p0 * q1 + q0 * p1);
     stp(parent.Q(), parent.stride, i, q0 * q1);
 }
+// Two levels per pass: grandparent i and its two parents 2i, 2i+1 from children 4i..4i+3 -- the parents are written (their
+// layer's sumcheck reads them) but never read back by the build: 1.75 n of traffic per pair of levels instead of 2.25 n
+// (the build runs at the HBM ceiling: 5.6-5.7 TB/s). The same three products per fraction sum as gkr_build_kernel, so every
+// value is the one the one-level passes compute. Lanes n_grand and n_grand + 1 take the (at most two) parents of the range
+// that have no sibling inside it: edge e = parent edge_parent[e] from the two children at edge_child[e].
+template <bool PBASE>
+__global__ void gkr_build2_kernel(FracPlanes child, FracPlanes parent, FracPlanes grand, uint64_t n_grand, FracPlanes edge_child0,
+                                  FracPlanes edge_parent0, FracPlanes edge_child1, FracPlanes edge_parent1, uint32_t n_edges) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_grand) {
+        const uint64_t e = i - n_grand;
+        if (e >= n_edges) return;
+        const FracPlanes c = e ? edge_child1 : edge_child0, p = e ? edge_parent1 : edge_parent0;
+        EF p0, p1, q0, q1;
+        if (PBASE)
+            ldp2_base(c.P(), 0, p0, p1);
+        else
+            ldp2(c.P(), c.stride, 0, p0, p1);
+        ldp2(c.Q(), c.stride, 0, q0, q1);
+        stp(p.P(), p.stride, 0, p0 * q1 + q0 * p1);
+        stp(p.Q(), p.stride, 0, q0 * q1);
+        return;
+    }
+    EF cp[4], cq[4];
+    if (PBASE)
+        ldp4_base(child.P(), 4 * i, cp);
+    else
+        ldp4(child.P(), child.stride, 4 * i, cp);
+    ldp4(child.Q(), child.stride, 4 * i, cq);
+    const EF pp0 = cp[0] * cq[1] + cq[0] * cp[1], pq0 = cq[0] * cq[1];
+    const EF pp1 = cp[2] * cq[3] + cq[2] * cp[3], pq1 = cq[2] * cq[3];
+    stp2(parent.P(), parent.stride, 2 * i, pp0, pp1);
+    stp2(parent.Q(), parent.stride, 2 * i, pq0, pq1);
+    stp(grand.P(), grand.stride, i, pp0 * pq1 + pq0 * pp1);
+    stp(grand.Q(), grand.stride, i, pq0 * pq1);
+}
+int gkr_build_two_layers(FracPlanes child, FracPlanes parent, FracPlanes grand, uint64_t n_grand, const FracPlanes *edge_child,
+                         const FracPlanes *edge_parent, uint32_t n_edges, bool child_p_base, hipStream_t s) {
+    if (n_edges > 2 || n_grand + n_edges == 0) return (int)hipErrorInvalidValue;
+    const FracPlanes none{nullptr, 0, 0};
+    const FracPlanes c0 = n_edges > 0 ? edge_child[0] : none, p0 = n_edges > 0 ? edge_parent[0] : none;
+    const FracPlanes c1 = n_edges > 1 ? edge_child[1] : none, p1 = n_edges > 1 ? edge_parent[1] : none;
+    const dim3 grid(ceil_div(n_grand + n_edges, 256));
+    if (child_p_base)
+        OVM_LAUNCH(gkr_build2_kernel<true>, grid, dim3(256), 0, s, child, parent, grand, n_grand, c0, p0, c1, p1, n_edges);
+    else
+        OVM_LAUNCH(gkr_build2_kernel<false>, grid, dim3(256), 0, s, child, parent, grand, n_grand, c0, p0, c1, p1, n_edges);
+    OVM_CHECK_LAUNCH();
+    return 0;
+}
 int gkr_build_layer(FracPlanes child, FracPlanes parent, uint64_t n_parent, bool child_p_base, hipStream_t s) {
     if (child_p_base)
         OVM_LAUNCH(gkr_build_kernel<true>, dim3(ceil_div(n_parent, 256)), dim3(256), 0, s, child, parent,

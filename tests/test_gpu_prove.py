@@ -144,6 +144,24 @@ def test_gkr_passes_with_and_without_lookahead(dev, pkg, orc, monkeypatch, looka
     run_case(dev, pkg, orc, params, [airs.uniform_runner_air(24)], [(0, airs.splitmix64_bits(0xA11CE, 24 * h), h, [])])
 
 
+@pytest.mark.parametrize("fused", ["1", "0"])
+def test_gkr_tree_built_two_levels_per_pass_or_one(dev, pkg, orc, monkeypatch, fused):
+    """Round 4: the fraction tree is built two levels per pass (stages.hip: gkr_build2_kernel -- parents written, never read
+    back); OVM_GKR_BUILD_FUSED=0 is one level per pass as before. Both must give the oracle's bytes: a tall single AIR
+    (base-field leaf numerators: the PBASE form, even and odd tree heights), mixed heights whose leaf runs start and end on odd
+    indices (parents without a sibling in the range: the edge lanes), a tree of a single interaction on a two-row trace."""
+    monkeypatch.setenv("OVM_GKR_BUILD_FUSED", fused)
+    for n_stack, cols, h in ((10, 24, 1 << 12), (9, 12, 1 << 11)):
+        params = airs.test_params(l_skip=4, n_stack=n_stack, k_whir=4)
+        run_case(dev, pkg, orc, params, [airs.uniform_runner_air(cols)], [(0, airs.splitmix64_bits(0xB01D + cols, cols * h), h, [])])
+    bench, wide = airs.uniform_runner_air(8), airs.uniform_runner_air(20)
+    t1, pv = airs.fibonacci_trace(0, 1, 16)
+    run_case(dev, pkg, orc, airs.test_params(l_skip=2, n_stack=9, k_whir=2), [airs.fibonacci_air(), bench, wide, bench],
+             [(0, t1, 16, pv), (1, airs.splitmix64_bits(1, 8 * 512), 512, []), (2, airs.splitmix64_bits(2, 20 * 256), 256, []),
+              (3, airs.splitmix64_bits(3, 8 * 2), 2, [])])
+    run_case(dev, pkg, orc, airs.test_params(l_skip=1, n_stack=4, k_whir=1), [bench], [(0, airs.splitmix64_bits(5, 8 * 2), 2, [])])
+
+
 def sponge_before_openings(pkg, orc, raw):
     import ctypes
     s = pkg.SpongeState()
