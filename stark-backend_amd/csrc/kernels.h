@@ -201,6 +201,11 @@ int gkr_eval_leaves(const DevProgram &prog, const DevStaged &staged, const EF *d
                     hipStream_t s);
 int gkr_build_layer(FracPlanes child, FracPlanes parent, uint64_t n_parent, bool child_p_base, hipStream_t s);
 // two levels in one pass (parents and grandparents of `child`); edge_*: the parents without a sibling in the range
+// three levels in one pass; pair_*: grandparents without a sibling in the range (with their two parents), lone_*: parents without one
+int gkr_build_three_layers(FracPlanes child, FracPlanes parent, FracPlanes grand, FracPlanes great, uint64_t n_great,
+                           const FracPlanes *pair_child, const FracPlanes *pair_parent, const FracPlanes *pair_grand, uint32_t n_pair,
+                           const FracPlanes *lone_child, const FracPlanes *lone_parent, uint32_t n_lone, bool child_p_base,
+                           hipStream_t s);
 int gkr_build_two_layers(FracPlanes child, FracPlanes parent, FracPlanes grand, uint64_t n_grand, const FracPlanes *edge_child,
                          const FracPlanes *edge_parent, uint32_t n_edges, bool child_p_base, hipStream_t s);
 // out[X-1] = sum_y eq[y] * (p0 q1 + p1 q0 + lambda q0 q1)(X, y), X = 1..n_points (2 or 3; eq: n_pairs weights)

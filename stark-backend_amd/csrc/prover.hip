@@ -1002,7 +1002,8 @@ Tuning ovm::Tuning::from_env() {
     t.download_kernel = !off("OVM_DOWNLOAD_KERNEL");
     t.early_lde = !off("OVM_EARLY_LDE");
     t.gkr_split_eq = !off("OVM_GKR_SPLIT_EQ");
-    t.gkr_build_fused = !off("OVM_GKR_BUILD_FUSED");
+    t.gkr_build_fused = num("OVM_GKR_BUILD_FUSED", 3);
+    if (t.gkr_build_fused == 1) t.gkr_build_fused = 0;
     t.gkr_lookahead = num("OVM_GKR_LOOKAHEAD", 0) != 0;
     t.gkr_la_max_log = (uint32_t)std::max(0, num("OVM_GKR_LA_MAX_LOG", 17));
     t.gkr_la_min_log = (uint32_t)std::max(0, num("OVM_GKR_LA_MIN_LOG", 0));

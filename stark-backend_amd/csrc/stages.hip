@@ -1852,6 +1852,90 @@ __global__ void gkr_build2_kernel(FracPlanes child, FracPlanes parent, FracPlane
     stp(grand.P(), grand.stride, i, pp0 * pq1 + pq0 * pp1);
     stp(grand.Q(), grand.stride, i, pq0 * pq1);
 }
+// Three levels per pass: 1.875 n of traffic per three levels instead of 3 x 1.125 n. Lane i: children 8i..8i+7 -> parents
+// 4i..4i+3, grandparents 2i, 2i+1, great-grandparent i. What the range holds outside those aligned blocks goes to extra lanes
+// of the same launch: at most two grandparents whose sibling is outside the range (each with its two parents, from four
+// children: the two-level form) and at most two lone parents (from two children).
+struct BuildEdges {
+    FracPlanes pair_child[2], pair_parent[2], pair_grand[2];
+    FracPlanes lone_child[2], lone_parent[2];
+    uint32_t n_pair, n_lone;
+};
+template <bool PBASE>
+__device__ __forceinline__ void build_lone(const FracPlanes &c, const FracPlanes &p) {
+    EF p0, p1, q0, q1;
+    if (PBASE)
+        ldp2_base(c.P(), 0, p0, p1);
+    else
+        ldp2(c.P(), c.stride, 0, p0, p1);
+    ldp2(c.Q(), c.stride, 0, q0, q1);
+    stp(p.P(), p.stride, 0, p0 * q1 + q0 * p1);
+    stp(p.Q(), p.stride, 0, q0 * q1);
+}
+template <bool PBASE>
+__global__ void gkr_build3_kernel(FracPlanes child, FracPlanes parent, FracPlanes grand, FracPlanes great, uint64_t n_great,
+                                  BuildEdges edges) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_great) {
+        const uint64_t e = i - n_great;
+        if (e < edges.n_pair) {
+            const FracPlanes c = edges.pair_child[e], p = edges.pair_parent[e], g = edges.pair_grand[e];
+            EF cp[4], cq[4];
+            if (PBASE)
+                ldp4_base(c.P(), 0, cp);
+            else
+                ldp4(c.P(), c.stride, 0, cp);
+            ldp4(c.Q(), c.stride, 0, cq);
+            const EF pp0 = cp[0] * cq[1] + cq[0] * cp[1], pq0 = cq[0] * cq[1];
+            const EF pp1 = cp[2] * cq[3] + cq[2] * cp[3], pq1 = cq[2] * cq[3];
+            stp2(p.P(), p.stride, 0, pp0, pp1);
+            stp2(p.Q(), p.stride, 0, pq0, pq1);
+            stp(g.P(), g.stride, 0, pp0 * pq1 + pq0 * pp1);
+            stp(g.Q(), g.stride, 0, pq0 * pq1);
+        } else if (e - edges.n_pair < edges.n_lone) {
+            const uint32_t k = (uint32_t)(e - edges.n_pair);
+            build_lone<PBASE>(edges.lone_child[k], edges.lone_parent[k]);
+        }
+        return;
+    }
+    EF pp[4], pq[4];
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        EF cp[4], cq[4];
+        if (PBASE)
+            ldp4_base(child.P(), 8 * i + 4 * h, cp);
+        else
+            ldp4(child.P(), child.stride, 8 * i + 4 * h, cp);
+        ldp4(child.Q(), child.stride, 8 * i + 4 * h, cq);
+        pp[2 * h] = cp[0] * cq[1] + cq[0] * cp[1], pq[2 * h] = cq[0] * cq[1];
+        pp[2 * h + 1] = cp[2] * cq[3] + cq[2] * cp[3], pq[2 * h + 1] = cq[2] * cq[3];
+    }
+    stp4(parent.P(), parent.stride, 4 * i, pp);
+    stp4(parent.Q(), parent.stride, 4 * i, pq);
+    const EF gp0 = pp[0] * pq[1] + pq[0] * pp[1], gq0 = pq[0] * pq[1];
+    const EF gp1 = pp[2] * pq[3] + pq[2] * pp[3], gq1 = pq[2] * pq[3];
+    stp2(grand.P(), grand.stride, 2 * i, gp0, gp1);
+    stp2(grand.Q(), grand.stride, 2 * i, gq0, gq1);
+    stp(great.P(), great.stride, i, gp0 * gq1 + gq0 * gp1);
+    stp(great.Q(), great.stride, i, gq0 * gq1);
+}
+int gkr_build_three_layers(FracPlanes child, FracPlanes parent, FracPlanes grand, FracPlanes great, uint64_t n_great,
+                           const FracPlanes *pair_child, const FracPlanes *pair_parent, const FracPlanes *pair_grand, uint32_t n_pair,
+                           const FracPlanes *lone_child, const FracPlanes *lone_parent, uint32_t n_lone, bool child_p_base,
+                           hipStream_t s) {
+    if (n_pair > 2 || n_lone > 2 || n_great + n_pair + n_lone == 0) return (int)hipErrorInvalidValue;
+    BuildEdges e{};
+    e.n_pair = n_pair, e.n_lone = n_lone;
+    for (uint32_t k = 0; k < n_pair; k++) e.pair_child[k] = pair_child[k], e.pair_parent[k] = pair_parent[k], e.pair_grand[k] = pair_grand[k];
+    for (uint32_t k = 0; k < n_lone; k++) e.lone_child[k] = lone_child[k], e.lone_parent[k] = lone_parent[k];
+    const dim3 grid(ceil_div(n_great + n_pair + n_lone, 256));
+    if (child_p_base)
+        OVM_LAUNCH(gkr_build3_kernel<true>, grid, dim3(256), 0, s, child, parent, grand, great, n_great, e);
+    else
+        OVM_LAUNCH(gkr_build3_kernel<false>, grid, dim3(256), 0, s, child, parent, grand, great, n_great, e);
+    OVM_CHECK_LAUNCH();
+    return 0;
+}
 int gkr_build_two_layers(FracPlanes child, FracPlanes parent, FracPlanes grand, uint64_t n_grand, const FracPlanes *edge_child,
                          const FracPlanes *edge_parent, uint32_t n_edges, bool child_p_base, hipStream_t s) {
     if (n_edges > 2 || n_grand + n_edges == 0) return (int)hipErrorInvalidValue;

@@ -40,7 +40,7 @@ struct Tuning {
     int stacked_tail_device = 1;
     bool staged_forward = true;    // OVM_STAGED_FWD=0: the staged VM reads every operand from LDS and stores every result
     bool gkr_split_eq = true;      // OVM_GKR_SPLIT_EQ=0: every GKR layer builds and reads its whole eq table
-    bool gkr_build_fused = true;   // OVM_GKR_BUILD_FUSED=0: the fraction tree is built one level per pass (two: stages.hip gkr_build2_kernel)
+    int gkr_build_fused = 3;       // OVM_GKR_BUILD_FUSED=0|2|3: levels of the fraction tree built per pass (0 = 1; stages.hip gkr_build2/3_kernel)
     uint32_t gkr_split_min_round = 14;  // OVM_GKR_SPLIT_MIN: layers of at least 2^this records use split tables (>= 3; parity tests lower it)
     // OVM_GKR_LOOKAHEAD=1: a pass over a GKR layer's table also sums the NEXT sub-round as a quadratic in its challenge, so
     // every second sub-round costs no pass and no launch (stages.hip: gkr_pass_kernel). Built and byte-exact in round 4, and

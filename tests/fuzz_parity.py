@@ -37,7 +37,7 @@ def main():
              "OVM_GKR_THREE_POINTS": ["", "", "1"], "OVM_MERKLE_COOP": ["", "0"], "OVM_LAZY_W": ["", "0"],
              "OVM_EARLY_LDE": ["", "", "0"], "OVM_MLE_BATCH_LDS_MIN_LOG": ["", "1", "3", "31"],
              "OVM_STACKED_TAIL_DEVICE": ["", "0", "2", "2"], "OVM_STAGED_FWD": ["", "", "0"], "OVM_GKR_SPLIT_MIN": ["", "3", "4", "7"],
-             "OVM_GKR_SPLIT_EQ": ["", "", "0"], "OVM_GKR_BUILD_FUSED": ["", "", "0"], "OVM_GKR_LOOKAHEAD": ["", "1", "1"], "OVM_GKR_LA_MAX_LOG": ["", "4", "40"], "OVM_GKR_LA_MIN_LOG": ["", "", "5"]}
+             "OVM_GKR_SPLIT_EQ": ["", "", "0"], "OVM_GKR_BUILD_FUSED": ["", "", "0", "2"], "OVM_GKR_LOOKAHEAD": ["", "1", "1"], "OVM_GKR_LA_MAX_LOG": ["", "4", "40"], "OVM_GKR_LA_MIN_LOG": ["", "", "5"]}
     bad = 0
     with_absent = 0
     for case in range(args.cases):

@@ -144,14 +144,15 @@ def test_gkr_passes_with_and_without_lookahead(dev, pkg, orc, monkeypatch, looka
     run_case(dev, pkg, orc, params, [airs.uniform_runner_air(24)], [(0, airs.splitmix64_bits(0xA11CE, 24 * h), h, [])])
 
 
-@pytest.mark.parametrize("fused", ["1", "0"])
-def test_gkr_tree_built_two_levels_per_pass_or_one(dev, pkg, orc, monkeypatch, fused):
-    """Round 4: the fraction tree is built two levels per pass (stages.hip: gkr_build2_kernel -- parents written, never read
-    back); OVM_GKR_BUILD_FUSED=0 is one level per pass as before. Both must give the oracle's bytes: a tall single AIR
-    (base-field leaf numerators: the PBASE form, even and odd tree heights), mixed heights whose leaf runs start and end on odd
-    indices (parents without a sibling in the range: the edge lanes), a tree of a single interaction on a two-row trace."""
+@pytest.mark.parametrize("fused", ["3", "2", "0"])
+def test_gkr_tree_built_three_two_or_one_levels_per_pass(dev, pkg, orc, monkeypatch, fused):
+    """Round 4: the fraction tree is built three levels per pass (stages.hip: gkr_build3_kernel -- parents and grandparents
+    written, never read back; OVM_GKR_BUILD_FUSED=2: two levels, =0: one level per pass as before). All must give the oracle's
+    bytes: a tall single AIR (base-field leaf numerators: the PBASE form; tree heights 0, 1 and 2 mod 3), mixed heights whose
+    leaf runs start and end on odd indices (parents / grandparents without a sibling in the range: the edge lanes), a tree of
+    a single interaction on a two-row trace."""
     monkeypatch.setenv("OVM_GKR_BUILD_FUSED", fused)
-    for n_stack, cols, h in ((10, 24, 1 << 12), (9, 12, 1 << 11)):
+    for n_stack, cols, h in ((10, 24, 1 << 12), (9, 12, 1 << 11), (8, 12, 1 << 10)):
         params = airs.test_params(l_skip=4, n_stack=n_stack, k_whir=4)
         run_case(dev, pkg, orc, params, [airs.uniform_runner_air(cols)], [(0, airs.splitmix64_bits(0xB01D + cols, cols * h), h, [])])
     bench, wide = airs.uniform_runner_air(8), airs.uniform_runner_air(20)
