@@ -36,6 +36,21 @@ struct StagedPlan {
 };
 StagedPlan round0_staged_plan(uint32_t log_lifted, uint32_t n_out, uint32_t num_slots, uint32_t n_instr = 0);
 
+// Cached-column round-0 program (program.h: stage_cached), device arrays.
+struct DevCached {
+    const StagedInstr *words = nullptr;  // n_words (a multiple of 8) + one more group of four
+    const uint32_t *loads = nullptr;     // records of CachedProgram::MAX_LOADS (column, row offset) pairs
+    uint32_t n_words = 0;
+    uint32_t num_rows = 0;    // LDS rows: cache + slots
+    uint32_t rows = 0;        // trace rows per lane the offsets were scaled for
+    uint32_t cache_rows = 0;
+};
+// Rows per lane and LDS layout for the cached form; rows == 0: the image does not fit (plain interpreter).
+struct CachedPlan {
+    uint32_t rows = 0, cache_rows = 0, max_loads = 0;
+};
+CachedPlan round0_cached_plan(uint32_t log_lifted, uint32_t n_out, uint32_t num_slots, uint32_t n_instr = 0);
+
 // ro.out[k] = sum_b ro.partials[b * K + k], then the flag (for reductions with many outputs)
 int sum_partials(const RedOut &ro, uint32_t n_blocks, uint32_t K, hipStream_t s);
 
@@ -61,7 +76,7 @@ int coset_lde(const ColDesc *d_cols, const uint32_t *d_used, uint32_t n_used, ui
 // n_cosets * n_out << l_skip mailbox slots), the last job raises ro.flag. d_counters: n_jobs + 1
 // words, zero on entry and on exit.
 struct R0Job {
-    DevStaged prog;
+    DevCached prog;
     const Fp *lde;
     const EF *eq_xi;
     EF *partials;
@@ -73,15 +88,15 @@ struct R0Job {
     // roots, the sums add): workgroup bx of the job runs group bx / gx_group; progs = device array of their
     // staged forms (n_groups == 1: `prog` alone). lds_rows = the largest num_rows among them.
     uint32_t n_groups, gx_group, lds_rows;
-    const DevStaged *progs;
+    const DevCached *progs;
 };
-// workgroups round0_eval gives a staged program on a trace of 2^log_lifted rows
-uint32_t round0_staged_grid(const DevStaged &staged, uint32_t log_lifted);
+// workgroups round0_eval gives a cached-form program on a trace of 2^log_lifted rows
+uint32_t round0_cached_grid(const DevCached &staged, uint32_t log_lifted);
 int round0_eval_batched(const R0Job *d_jobs, const R0Job *h_jobs, uint32_t n_jobs, uint32_t rows, uint32_t n_out,
                         uint32_t l_skip, uint32_t *d_counters, const RedOut &ro, hipStream_t s);
 
-// `staged` (optional, blocks != nullptr): the same program in staged form; used when its LDS image fits.
-int round0_eval(const DevProgram &prog, const DevStaged &staged, const Fp *lde, uint32_t n_cols_total, uint32_t log_lifted, uint32_t l_skip,
+// `staged` (optional, words != nullptr): the same program in cached-column form; used when its LDS image fits.
+int round0_eval(const DevProgram &prog, const DevCached &staged, const Fp *lde, uint32_t n_cols_total, uint32_t log_lifted, uint32_t l_skip,
                 uint32_t n_cosets, uint32_t n_out, const EF *d_eq_xi, EF add_const, const RedOut &ro, hipStream_t s);
 
 // out[col * (lifted >> l) + x] = sum_z w[z] * col(( x << l) + z)

@@ -13,6 +13,7 @@
 //   DEN  w, x      :  den += W[w] * x             (LogUp-GKR leaf mode)
 //   LEAF k, x      :  emit leaf k = (x, den + C[k]); den = 0
 #pragma once
+#include <iterator>
 #include <vector>
 
 #include "host.h"
@@ -73,6 +74,7 @@ struct ColumnMap {
     }
 };
 
+static constexpr uint32_t ROOT_ONE_NODE = 0xFFFFFFFFu;  // Root::node: the constant one (a term of linear_terms)
 struct Root {
     uint32_t node;
     uint8_t op;      // OP_ACC / OP_DEN / OP_LEAF
@@ -138,7 +140,8 @@ inline Program compile_program_with(const AirKey &air, const ColumnMap &cm, cons
                                     const std::vector<Root> &roots, uint32_t num_weights, uint32_t remat_limit,
                                     CompileStats *stats = nullptr) {
     size_t n = 0;
-    for (auto &r : roots) n = std::max(n, (size_t)r.node + 1);
+    for (auto &r : roots)
+        if (r.node != ROOT_ONE_NODE) n = std::max(n, (size_t)r.node + 1);
     if (n > air.nodes.size()) throw OvmFail(1, "program compiler: root out of range");
     auto is_op = [&](uint32_t i) { return air.nodes[i].kind >= N_ADD; };
     auto binary = [&](uint32_t i) { return air.nodes[i].kind != N_NEG; };
@@ -148,7 +151,7 @@ inline Program compile_program_with(const AirKey &air, const ColumnMap &cm, cons
     {
         std::vector<uint32_t> stack;
         for (auto &r : roots)
-            if (!need[r.node]) need[r.node] = 1, stack.push_back(r.node);
+            if (r.node != ROOT_ONE_NODE && !need[r.node]) need[r.node] = 1, stack.push_back(r.node);
         while (!stack.empty()) {
             const uint32_t i = stack.back();
             stack.pop_back();
@@ -178,7 +181,7 @@ inline Program compile_program_with(const AirKey &air, const ColumnMap &cm, cons
         if (binary((uint32_t)i) && is_op(nd.right)) uses[nd.right]++;
     }
     for (auto &r : roots)
-        if (is_op(r.node)) uses[r.node]++;
+        if (r.node != ROOT_ONE_NODE && is_op(r.node)) uses[r.node]++;
 
     Program prog;
     prog.num_weights = num_weights;
@@ -319,7 +322,7 @@ inline Program compile_program_with(const AirKey &air, const ColumnMap &cm, cons
         return result;
     };
     for (const Root &r : roots) {
-        const Operand o = value_of(r.node);
+        const Operand o = r.node == ROOT_ONE_NODE ? Operand{K_CONST, Fp::one().v, -1} : value_of(r.node);
         Instr in{};
         in.op = r.op;
         in.acc = r.acc;
@@ -638,6 +641,536 @@ inline void staged_host_eval(const StagedProgram &sp, const std::vector<Fp> &row
         }
     }
     out[0] += den;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Cached-column staged form of an ACC program (round 0; cached_vm.cuh: CachedRound0).
+//
+// The block form above stages every column a block reads, every block. Here the LDS image holds a CACHE of `cache_rows`
+// columns that survives from block to block: a block's load list names only the columns that are not cached (column ->
+// LDS row), chosen against the program's own future -- the column evicted is the one whose next read is farthest away.
+// The loads of block b + 1 are requested when block b starts, into REGISTERS, and written to their rows when block b + 1
+// starts: nothing in LDS is reserved for data in flight, so the whole image is cache + slots.
+// The program is ONE stream of 16-byte words (the kernel fetches them four at a time, one group ahead):
+//   arithmetic   {StagedOp | flags, dst row, a row, b row | constant}: the first operand is the RESULT REGISTER (the value
+//                of the word before: S_FWD_A) or row a, the second the constant b (S_B_CONST), the result register
+//                (S_FWD_B, only beside S_FWD_A) or row b; S_NOSTORE: the result stays in the result register only.
+//                A value forwarded as the SECOND operand of the compiled instruction is commuted here (b - result
+//                becomes S_RSUB), a negation is 0 - x: the kernel has no S_NEG
+//   C_ACC        {C_ACC | w0, acc << 31 | w1, w2, w3}     accumulator acc += W * (result register); the weight's
+//                Montgomery words are below 2^31, bit 31 of the first two is free
+//   C_BLOCK      {C_BLOCK | n_land | n_issue << 8, record, 0, 0}   write the columns requested by the block word before
+//                to their rows, request the next block's; a record is MAX_LOADS row offsets (of the columns to write)
+//                followed by MAX_LOADS flat columns (to request). Always the first word of a group of four (the
+//                group before is padded with no-ops)
+// An accumulation reads the value it weighs from the result register: what it weighs is computed right before it, or
+// brought there by a move (a column, a slot, a constant).
+// ---------------------------------------------------------------------------------------------
+static constexpr uint32_t C_ACC = 0x80000000u, C_BLOCK = 0x40000000u;
+struct CachedLayout {
+    uint32_t cache_rows = 8;
+    uint32_t max_loads = 8;  // columns a block may bring (<= CachedProgram::MAX_LOADS: the kernel's landing registers)
+};
+struct CachedProgram {
+    static constexpr uint32_t MAX_LOADS = 8;
+    std::vector<StagedInstr> words;  // a multiple of 8 (padded with no-ops) + one more group of four
+    std::vector<uint32_t> loads;     // one record per block word: MAX_LOADS LDS rows to write, MAX_LOADS flat columns to request
+    uint32_t num_rows = 0, cache_rows = 0, n_blocks = 0;
+    uint64_t n_loads = 0;  // columns brought per evaluation (statistics)
+    // operand rows -> word offsets for `rows_per_lane` trace rows per lane
+    void scale_rows(uint32_t rows_per_lane) {
+        const uint32_t k = rows_per_lane * 256;
+        for (auto &in : words) {
+            if (in.op & (C_ACC | C_BLOCK)) continue;
+            in.dst *= k;
+            in.a *= k;
+            if (!(in.op & S_B_CONST)) in.b *= k;
+        }
+        for (size_t i = 0; i < loads.size(); i++)
+            if (i % (2 * MAX_LOADS) < MAX_LOADS) loads[i] *= k;
+    }
+};
+
+inline CachedProgram stage_cached(const Program &p, const std::vector<FpExt> &weights, const CachedLayout &layout = CachedLayout()) {
+    const uint32_t C = layout.cache_rows, L = std::min(layout.max_loads, CachedProgram::MAX_LOADS);
+    if (C < 2 || L < 2) throw OvmFail(1, "stage_cached: the cache needs two rows and two loads per block");
+    CachedProgram cp;
+    cp.cache_rows = C;
+    cp.num_rows = C + p.num_slots;
+    const size_t n = p.code.size();
+    auto is_binary = [](const Instr &in) { return in.op == OP_ADD || in.op == OP_SUB || in.op == OP_MUL; };
+    // the columns instruction i reads, and per column the instructions that read it (for the eviction choice)
+    auto cols_of = [&](const Instr &in, uint32_t (&c)[2]) {
+        int k = 0;
+        if (in.ak == K_COL) c[k++] = in.a;
+        if (is_binary(in) && in.bk == K_COL && !(k && c[0] == in.b)) c[k++] = in.b;
+        return k;
+    };
+    uint32_t max_col = 0;
+    for (const Instr &in : p.code) {
+        if (in.op > OP_ACC) throw OvmFail(1, "stage_cached: accumulation programs only");
+        uint32_t c[2];
+        for (int k = cols_of(in, c); k-- > 0;) max_col = std::max(max_col, c[k]);
+    }
+    std::vector<std::vector<uint32_t>> readers(max_col + 1);
+    for (size_t i = 0; i < n; i++) {
+        uint32_t c[2];
+        for (int k = cols_of(p.code[i], c), j = 0; j < k; j++) readers[c[j]].push_back((uint32_t)i);
+    }
+    auto next_read = [&](uint32_t col, size_t from) -> size_t {  // first reader at or after `from` (n: none)
+        const auto &r = readers[col];
+        auto it = std::lower_bound(r.begin(), r.end(), (uint32_t)from);
+        return it == r.end() ? n : *it;
+    };
+    // ---- blocks: runs of instructions that read at most C distinct columns, at most L of them not cached ----
+    std::vector<int32_t> row_of(max_col + 1, -1);  // LDS row of a cached column
+    std::vector<uint32_t> col_in_row(C, ~0u);
+    struct Block {
+        size_t first, last;                                // instructions [first, last)
+        std::vector<std::pair<uint32_t, uint32_t>> loads;  // (column, row) to bring
+        std::vector<std::pair<uint32_t, uint32_t>> rows;   // (column, row) of every column the block reads
+    };
+    std::vector<Block> blocks;
+    std::vector<uint32_t> stamp(max_col + 1, 0);
+    for (size_t first = 0; first < n;) {
+        const uint32_t id = (uint32_t)blocks.size() + 1;
+        std::vector<uint32_t> used, fresh;
+        size_t last = first;
+        for (; last < n; last++) {
+            uint32_t c[2];
+            const int k = cols_of(p.code[last], c);
+            uint32_t add_used = 0, add_fresh = 0;
+            for (int j = 0; j < k; j++)
+                if (stamp[c[j]] != id) add_used++, add_fresh += row_of[c[j]] < 0;
+            if (used.size() + add_used > C || fresh.size() + add_fresh > L) break;
+            for (int j = 0; j < k; j++)
+                if (stamp[c[j]] != id) {
+                    stamp[c[j]] = id;
+                    used.push_back(c[j]);
+                    if (row_of[c[j]] < 0) fresh.push_back(c[j]);
+                }
+        }
+        if (last == first) throw OvmFail(1, "stage_cached: an instruction does not fit a block");
+        // rows for the fresh columns: free rows, then the cached columns this block does not read, farthest next read first
+        Block blk{first, last, {}, {}};
+        std::vector<std::pair<size_t, uint32_t>> victims;  // (next read, row)
+        for (uint32_t r = 0; r < C; r++) {
+            const uint32_t col = col_in_row[r];
+            if (col == ~0u) victims.push_back({n + 1, r});
+            else if (stamp[col] != id) victims.push_back({next_read(col, last), r});
+        }
+        std::sort(victims.begin(), victims.end(),
+                  [](const std::pair<size_t, uint32_t> &x, const std::pair<size_t, uint32_t> &y) { return x.first != y.first ? x.first > y.first : x.second < y.second; });
+        if (victims.size() < fresh.size()) throw OvmFail(1, "stage_cached: internal (no row for a column)");
+        for (size_t j = 0; j < fresh.size(); j++) {
+            const uint32_t r = victims[j].second;
+            if (col_in_row[r] != ~0u) row_of[col_in_row[r]] = -1;
+            col_in_row[r] = fresh[j];
+            row_of[fresh[j]] = (int32_t)r;
+            blk.loads.push_back({fresh[j], r});
+        }
+        for (uint32_t c : used) blk.rows.push_back({c, (uint32_t)row_of[c]});
+        cp.n_loads += fresh.size();
+        blocks.push_back(std::move(blk));
+        first = last;
+    }
+    cp.n_blocks = (uint32_t)blocks.size();
+    // ---- words ----
+    // (a no-op keeps the result register: a forwarded move that stores nothing)
+    const StagedInstr nop{S_MOV | S_B_CONST | S_FWD_A | S_NOSTORE, 0, 0, 0};
+    const size_t npos = ~size_t(0);
+    auto block_word = [&](size_t land, size_t issue) {  // write the loads of block `land`, request those of block `issue` (npos: none)
+        while (cp.words.size() % 4) cp.words.push_back(nop);  // a block word is the first word of a group of four
+        const uint32_t nl = land < blocks.size() ? (uint32_t)blocks[land].loads.size() : 0;
+        const uint32_t ni = issue < blocks.size() ? (uint32_t)blocks[issue].loads.size() : 0;
+        const uint32_t rec = (uint32_t)(cp.loads.size() / (2 * CachedProgram::MAX_LOADS));
+        for (uint32_t j = 0; j < CachedProgram::MAX_LOADS; j++) cp.loads.push_back(j < nl ? blocks[land].loads[j].second : 0);
+        for (uint32_t j = 0; j < CachedProgram::MAX_LOADS; j++) cp.loads.push_back(j < ni ? blocks[issue].loads[j].first : 0);
+        cp.words.push_back(StagedInstr{C_BLOCK | nl | (ni << 8), rec, 0, 0});
+    };
+    if (!blocks.empty()) block_word(npos, 0);
+    std::vector<int32_t> cur_row(max_col + 1, -1);
+    for (size_t b = 0; b < blocks.size(); b++) {
+        block_word(b, b + 1 < blocks.size() ? b + 1 : npos);
+        for (auto &cr : blocks[b].rows) cur_row[cr.first] = (int32_t)cr.second;
+        for (size_t idx = blocks[b].first; idx < blocks[b].last; idx++) {
+            const Instr &in = p.code[idx];
+            struct Opnd {
+                bool is_const;
+                uint32_t v;
+            };
+            auto opnd = [&](uint8_t kind, uint32_t payload) -> Opnd {
+                if (kind == K_SLOT) return {false, C + payload};
+                if (kind == K_COL) {
+                    if (cur_row[payload] < 0) throw OvmFail(1, "stage_cached: internal (column not cached)");
+                    return {false, (uint32_t)cur_row[payload]};
+                }
+                if (kind == K_CONST) return {true, payload};
+                throw OvmFail(1, "stage_cached: bad operand kind");
+            };
+            auto emit = [&](uint32_t op, uint32_t dst, uint32_t a, uint32_t b2) { cp.words.push_back(StagedInstr{op, dst, a, b2}); };
+            const Opnd a = opnd(in.ak, in.a);
+            if (in.op == OP_ACC) {
+                if (in.b >= weights.size()) throw OvmFail(1, "stage_cached: weight index out of range");
+                if (in.acc > 1) throw OvmFail(1, "stage_cached: accumulator out of range");
+                // the value must be in the result register: forwarded from the instruction before, or moved there
+                if (!(in.fwd & FWD_A)) {
+                    if (a.is_const) emit(S_MOVC | S_B_CONST | S_NOSTORE, 0, 0, a.v);
+                    else emit(S_MOV | S_B_CONST | S_NOSTORE, 0, a.v, 0);
+                }
+                const FpExt &w = weights[in.b];
+                emit(C_ACC | w.c[0].v, ((uint32_t)in.acc << 31) | w.c[1].v, w.c[2].v, w.c[3].v);
+                continue;
+            }
+            const uint32_t dst = C + in.dst;
+            // the result stays in the register only when the one reader is the next instruction (arithmetic or accumulation)
+            const bool next_takes_it = idx + 1 < n && (p.code[idx + 1].fwd & (FWD_A | FWD_B));
+            const uint32_t f_ns = ((in.fwd & FWD_NOSTORE) && next_takes_it) ? S_NOSTORE : 0;
+            const bool f_a = (in.fwd & FWD_A) != 0, f_b = (in.fwd & FWD_B) != 0;
+            if (in.op == OP_NEG) {  // 0 - x
+                if (a.is_const) emit(S_MOVC | S_B_CONST | f_ns, dst, 0, (-Fp::raw(a.v)).v);
+                else emit(S_RSUB | S_B_CONST | (f_a ? S_FWD_A : 0) | f_ns, dst, a.v, 0);
+                continue;
+            }
+            const Opnd bo = opnd(in.bk, in.b);
+            if (a.is_const && bo.is_const) {
+                const Fp x = Fp::raw(a.v), y = Fp::raw(bo.v);
+                const Fp r = in.op == OP_ADD ? x + y : in.op == OP_SUB ? x - y : x * y;
+                emit(S_MOVC | S_B_CONST | f_ns, dst, 0, r.v);
+            } else if (a.is_const) {  // constant on the left: commute, or b - a reversed (the program's b is the word's first operand)
+                emit((in.op == OP_ADD ? S_ADD : in.op == OP_MUL ? S_MUL : S_RSUB) | S_B_CONST | (f_b ? S_FWD_A : 0) | f_ns, dst, bo.v, a.v);
+            } else if (bo.is_const) {
+                emit((in.op == OP_ADD ? S_ADD : in.op == OP_MUL ? S_MUL : S_SUB) | S_B_CONST | (f_a ? S_FWD_A : 0) | f_ns, dst, a.v, bo.v);
+            } else if (f_b && !f_a) {  // the forwarded value is the SECOND operand: it becomes the first (a - result = S_RSUB)
+                emit((in.op == OP_ADD ? S_ADD : in.op == OP_MUL ? S_MUL : S_RSUB) | S_FWD_A | f_ns, dst, 0, a.v);
+            } else {
+                emit((in.op == OP_ADD ? S_ADD : in.op == OP_MUL ? S_MUL : S_SUB) | (f_a ? S_FWD_A : 0) | ((f_a && f_b) ? S_FWD_B : 0) | f_ns,
+                     dst, a.v, bo.v);
+            }
+        }
+    }
+    while (cp.words.size() % 8) cp.words.push_back(nop);  // (the kernel runs the groups of four two at a time)
+    for (int k = 0; k < 4; k++) cp.words.push_back(nop);  // (... and fetches one group past the end)
+    return cp;
+}
+
+// Host execution of a cached program on one row (self-test of stage_cached, no device; rows not scaled). Mirrors
+// cached_vm.cuh word for word: the loads of a block word are requested (read from `row`) when the block word before it
+// runs and are written when it runs itself; the first operand of an arithmetic word is LOADED INTO the result register.
+inline void cached_host_eval(const CachedProgram &cp, const std::vector<Fp> &row, FpExt out[2]) {
+    std::vector<Fp> lds(cp.num_rows, Fp::zero());
+    Fp landing[CachedProgram::MAX_LOADS];
+    Fp prev = Fp::zero();
+    const Fp poison = Fp::from_canonical(0x5eed);
+    const size_t n_words = cp.words.size() - 4;
+    for (size_t i = 0; i < n_words; i++) {
+        const StagedInstr &in = cp.words[i];
+        if (in.op & C_ACC) {
+            FpExt w;
+            w.c[0] = Fp::raw(in.op & 0x7fffffffu), w.c[1] = Fp::raw(in.dst & 0x7fffffffu), w.c[2] = Fp::raw(in.a), w.c[3] = Fp::raw(in.b);
+            out[in.dst >> 31] += w * prev;
+        } else if (in.op & C_BLOCK) {
+            if (i % 4) throw OvmFail(1, "cached_host_eval: block word inside a group");
+            const uint32_t n_land = in.op & 0xff, n_issue = (in.op >> 8) & 0xff;
+            const uint32_t *rec = cp.loads.data() + (size_t)in.dst * 2 * CachedProgram::MAX_LOADS;
+            for (uint32_t j = 0; j < n_land; j++) lds.at(rec[j]) = landing[j];
+            for (uint32_t j = 0; j < n_issue; j++) landing[j] = row.at(rec[CachedProgram::MAX_LOADS + j]);
+        } else {
+            if ((in.op & S_FWD_B) && !(in.op & S_FWD_A)) throw OvmFail(1, "cached_host_eval: second operand forwarded alone");
+            if (in.op & S_NEG) throw OvmFail(1, "cached_host_eval: the cached form has no negation");
+            if (!(in.op & S_FWD_A) && !(in.op & S_MOVC)) prev = lds.at(in.a);
+            const Fp a = prev;
+            const Fp bv = (in.op & S_B_CONST) ? Fp::raw(in.b) : (in.op & S_FWD_B) ? prev : lds.at(in.b);
+            Fp r;
+            if (in.op & S_MUL) r = a * bv;
+            else if (in.op & S_ADD) r = a + bv;
+            else if (in.op & S_SUB) r = a - bv;
+            else if (in.op & S_RSUB) r = bv - a;
+            else if (in.op & S_MOV) r = a;
+            else r = bv;
+            if (!(in.op & S_NOSTORE)) lds.at(in.dst) = r;
+            else if (in.dst) lds.at(in.dst) = poison;
+            prev = r;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Linear terms of an accumulation program, clustered by the columns they read.
+//
+// A round-0 program is a weighted sum  sum_i W[i] * root_i  and the roots of a real AIR are themselves sums: a 16-bit
+// limb of Keccak-f's theta step is  sum_z 2^z * xor3(A'[z], C[z], C'[z]) - a, one root reading 49 columns, and each of
+// those columns is read again by four or five other roots hundreds of constraints away (the real Keccak-f AIR: 2 859
+// columns, 16 400 column reads per row). Whatever the executor stages per block is staged again for every root -- round 4
+// measured 5.6x the coset LDE's bytes and showed that NO order of the ROOTS changes it.
+// The sum is linear, so it is regrouped here: every root is pushed down through +, -, negation and multiplication by
+// constants while the node it reaches still reads more than `support_cap` columns; what is left are TERMS (a product, a
+// short expression, a column) with a base-field coefficient each, term t weighs  W'[t] = sum coef * W[i]  (one term can
+// serve many roots), and the terms are ordered so that consecutive ones share columns: greedily, the next term is the
+// one that brings the fewest columns not among the last `cache_rows` staged ones. The result is exact in the field --
+// the same sum in another order -- and the Keccak-f program reads 4 600 columns per row instead of 16 000 with a cache
+// of eight. Programs whose roots are all small come back unchanged (one term per root, in root order).
+// ---------------------------------------------------------------------------------------------
+struct TermPart {
+    uint32_t term, weight;  // W'[term] += coef * W[weight]
+    Fp coef;
+};
+struct TermRoots {
+    std::vector<Root> roots;  // one OP_ACC root per term, clustered order; Root::weight = the term's index
+    std::vector<TermPart> parts;
+    bool split = false;  // some root was taken apart (else: the roots as they came)
+    template <class E>
+    std::vector<E> weights(const std::vector<E> &W) const {
+        std::vector<E> out(std::max<size_t>(roots.size(), 1), E::zero());
+        for (const TermPart &p : parts) {
+            if (p.weight >= W.size()) throw OvmFail(1, "term weights: weight index out of range");
+            out[p.term] = out[p.term] + W[p.weight] * p.coef;
+        }
+        return out;
+    }
+};
+static constexpr uint32_t TERM_SUPPORT_CAP = 6, TERM_CLUSTER_ROWS = 8;
+inline TermRoots linear_terms(const AirKey &air, const ColumnMap &cm, const std::vector<Fp> &public_values,
+                              const std::vector<Root> &roots, uint32_t support_cap = TERM_SUPPORT_CAP,
+                              uint32_t cache_rows = TERM_CLUSTER_ROWS) {
+    TermRoots out;
+    size_t n = 0;
+    for (auto &r : roots) {
+        if (r.op != OP_ACC || r.node == ROOT_ONE_NODE) throw OvmFail(1, "linear_terms: accumulation roots only");
+        n = std::max(n, (size_t)r.node + 1);
+    }
+    if (n > air.nodes.size()) throw OvmFail(1, "linear_terms: root out of range");
+    auto is_op = [&](uint32_t i) { return air.nodes[i].kind >= N_ADD; };
+    auto binary = [&](uint32_t i) { return air.nodes[i].kind != N_NEG; };
+    // reachable nodes
+    std::vector<char> need(n, 0);
+    {
+        std::vector<uint32_t> stack;
+        for (auto &r : roots)
+            if (!need[r.node]) need[r.node] = 1, stack.push_back(r.node);
+        while (!stack.empty()) {
+            const uint32_t i = stack.back();
+            stack.pop_back();
+            if (!is_op(i)) continue;
+            const Node &nd = air.nodes[i];
+            if (nd.left >= i || (binary(i) && nd.right >= i)) throw OvmFail(1, "linear_terms: DAG not topological");
+            if (!need[nd.left]) need[nd.left] = 1, stack.push_back(nd.left);
+            if (binary(i) && !need[nd.right]) need[nd.right] = 1, stack.push_back(nd.right);
+        }
+    }
+    // per node: compile-time constant (value), or the columns it reads while they are at most support_cap (else `big`)
+    auto column_of = [&](const Node &nd) -> int64_t {
+        switch (nd.kind) {
+            case N_VAR:
+                if (nd.entry == E_MAIN) {
+                    if (nd.part_index >= cm.part_width.size() || nd.index >= cm.part_width[nd.part_index] || (nd.offset && !cm.need_rot))
+                        throw OvmFail(1, "main variable out of range");
+                    return cm.col(nd.part_index, nd.offset, nd.index);
+                }
+                if (nd.entry == E_PREPROCESSED) {
+                    if (nd.index >= cm.pre_width || (nd.offset && !cm.need_rot)) throw OvmFail(1, "preprocessed variable out of range");
+                    return cm.pre_col(nd.offset, nd.index);
+                }
+                if (nd.entry == E_PUBLIC) return -1;
+                throw OvmFail(801, "challenge variables not supported");
+            case N_IS_FIRST: return 0;
+            case N_IS_TRANSITION: return 1;
+            case N_IS_LAST: return 2;
+            default: return -1;
+        }
+    };
+    std::vector<char> is_const(n, 0), big(n, 0);
+    std::vector<Fp> cval(n, Fp::zero());
+    std::vector<std::vector<uint32_t>> sup(n);
+    for (size_t i = 0; i < n; i++) {
+        if (!need[i]) continue;
+        const Node &nd = air.nodes[i];
+        if (!is_op((uint32_t)i)) {
+            const int64_t c = column_of(nd);
+            if (c >= 0) {
+                sup[i].push_back((uint32_t)c);
+            } else {
+                is_const[i] = 1;
+                cval[i] = nd.kind == N_CONST ? nd.constant : public_values.at(nd.index);
+            }
+            continue;
+        }
+        const bool bin = binary((uint32_t)i);
+        if (is_const[nd.left] && (!bin || is_const[nd.right])) {
+            is_const[i] = 1;
+            const Fp x = cval[nd.left], y = bin ? cval[nd.right] : Fp::zero();
+            cval[i] = nd.kind == N_ADD ? x + y : nd.kind == N_SUB ? x - y : nd.kind == N_MUL ? x * y : -x;
+            continue;
+        }
+        big[i] = big[nd.left] || (bin && big[nd.right]);
+        if (!big[i]) {
+            if (bin) std::set_union(sup[nd.left].begin(), sup[nd.left].end(), sup[nd.right].begin(), sup[nd.right].end(), std::back_inserter(sup[i]));
+            else sup[i] = sup[nd.left];
+            if (sup[i].size() > support_cap) big[i] = 1, sup[i].clear();
+        }
+    }
+    // a big node that is a sum, a negation or a product with a constant is taken apart
+    auto splittable = [&](uint32_t i) {
+        if (!big[i]) return false;
+        const Node &nd = air.nodes[i];
+        return nd.kind == N_ADD || nd.kind == N_SUB || nd.kind == N_NEG || (nd.kind == N_MUL && (is_const[nd.left] || is_const[nd.right]));
+    };
+    bool any_split = false;
+    for (auto &r : roots) any_split |= splittable(r.node);
+    if (!any_split) {
+        for (size_t k = 0; k < roots.size(); k++) {
+            out.roots.push_back(Root{roots[k].node, OP_ACC, roots[k].acc, (uint32_t)k});
+            out.parts.push_back(TermPart{(uint32_t)k, roots[k].weight, Fp::one()});
+        }
+        return out;
+    }
+    out.split = true;
+    // terms in first-appearance order: key (node, accumulator); the constant-one term per accumulator
+    struct Term {
+        uint32_t node;
+        uint8_t acc;
+        std::vector<uint32_t> cols;
+    };
+    std::vector<Term> terms;
+    std::vector<int32_t> term_of[2] = {std::vector<int32_t>(n, -1), std::vector<int32_t>(n, -1)};
+    int32_t one_term[2] = {-1, -1};
+    std::vector<TermPart> parts;
+    std::vector<Fp> coef(n, Fp::zero());
+    std::vector<char> queued(n, 0);
+    std::vector<uint32_t> heap;  // max-heap of node indices: a node is handled after everything that can feed it
+    auto feed = [&](uint32_t i, Fp c) {
+        coef[i] = coef[i] + c;
+        if (!queued[i]) {
+            queued[i] = 1;
+            heap.push_back(i);
+            std::push_heap(heap.begin(), heap.end());
+        }
+    };
+    for (auto &r : roots) {
+        if (r.acc > 1) throw OvmFail(1, "linear_terms: accumulator out of range");
+        feed(r.node, Fp::one());
+        while (!heap.empty()) {
+            std::pop_heap(heap.begin(), heap.end());
+            const uint32_t i = heap.back();
+            heap.pop_back();
+            const Fp c = coef[i];
+            coef[i] = Fp::zero();
+            queued[i] = 0;
+            if (c.v == 0) continue;
+            const Node &nd = air.nodes[i];
+            if (is_const[i]) {
+                if (cval[i].v == 0) continue;
+                if (one_term[r.acc] < 0) {
+                    one_term[r.acc] = (int32_t)terms.size();
+                    terms.push_back(Term{ROOT_ONE_NODE, r.acc, {}});
+                }
+                parts.push_back(TermPart{(uint32_t)one_term[r.acc], r.weight, c * cval[i]});
+            } else if (splittable(i)) {
+                if (nd.kind == N_MUL) {
+                    const bool lc = is_const[nd.left];
+                    feed(lc ? nd.right : nd.left, c * cval[lc ? nd.left : nd.right]);
+                } else {
+                    feed(nd.left, nd.kind == N_NEG ? -c : c);
+                    if (nd.kind != N_NEG) feed(nd.right, nd.kind == N_SUB ? -c : c);
+                }
+            } else {
+                int32_t &t = term_of[r.acc][i];
+                if (t < 0) {
+                    t = (int32_t)terms.size();
+                    terms.push_back(Term{i, r.acc, {}});
+                }
+                parts.push_back(TermPart{(uint32_t)t, r.weight, c});
+            }
+        }
+    }
+    // the columns a term reads (a big term: collected from its expression)
+    {
+        std::vector<uint32_t> seen(n, 0), stack;
+        for (size_t t = 0; t < terms.size(); t++) {
+            Term &tm = terms[t];
+            if (tm.node == ROOT_ONE_NODE) continue;
+            if (!big[tm.node]) {
+                tm.cols = sup[tm.node];
+                continue;
+            }
+            stack.assign(1, tm.node);
+            while (!stack.empty()) {
+                const uint32_t i = stack.back();
+                stack.pop_back();
+                if (seen[i] == t + 1) continue;
+                seen[i] = (uint32_t)t + 1;
+                const Node &nd = air.nodes[i];
+                if (!is_op(i)) {
+                    const int64_t c = column_of(nd);
+                    if (c >= 0) tm.cols.push_back((uint32_t)c);
+                } else {
+                    stack.push_back(nd.left);
+                    if (binary(i)) stack.push_back(nd.right);
+                }
+            }
+            std::sort(tm.cols.begin(), tm.cols.end());
+            tm.cols.erase(std::unique(tm.cols.begin(), tm.cols.end()), tm.cols.end());
+        }
+    }
+    // greedy order: the next term is the undone one, among those that read a cached column, with the fewest columns to
+    // bring (ties: the one whose cached columns are closest to their last use); nothing cached is read any more -> the
+    // next undone term in first-appearance order. The cache model is least-recently-used over `cache_rows` columns.
+    const size_t T = terms.size();
+    std::vector<uint32_t> order;
+    order.reserve(T);
+    {
+        std::vector<uint32_t> remaining(cm.total, 0);
+        std::vector<std::vector<uint32_t>> col_terms(cm.total);
+        for (size_t t = 0; t < T; t++)
+            for (uint32_t c : terms[t].cols) remaining[c]++, col_terms[c].push_back((uint32_t)t);
+        std::vector<char> done(T, 0), cached(cm.total, 0);
+        std::vector<uint32_t> cache;  // least recently used first
+        std::vector<uint32_t> stamp(T, 0);
+        size_t cursor = 0;
+        for (size_t step = 1; step <= T; step++) {
+            int64_t best = -1;
+            uint32_t best_new = ~0u;
+            double best_score = -1;
+            for (uint32_t c : cache)
+                for (uint32_t t : col_terms[c]) {
+                    if (done[t] || stamp[t] == step) continue;
+                    stamp[t] = (uint32_t)step;
+                    uint32_t fresh = 0;
+                    double score = 0;
+                    for (uint32_t x : terms[t].cols) {
+                        if (cached[x]) score += 1.0 / remaining[x];
+                        else fresh++;
+                    }
+                    if (fresh < best_new || (fresh == best_new && score > best_score)) best = t, best_new = fresh, best_score = score;
+                }
+            if (best < 0) {
+                while (done[cursor]) cursor++;
+                best = (int64_t)cursor;
+            }
+            done[best] = 1;
+            order.push_back((uint32_t)best);
+            for (uint32_t x : terms[best].cols) {
+                remaining[x]--;
+                if (cached[x]) cache.erase(std::find(cache.begin(), cache.end(), x));
+                cache.push_back(x);
+                cached[x] = 1;
+            }
+            // columns nothing will read again leave first, then the least recently used
+            for (size_t k = 0; k < cache.size();) {
+                if (remaining[cache[k]] == 0) cached[cache[k]] = 0, cache.erase(cache.begin() + k);
+                else k++;
+            }
+            while (cache.size() > cache_rows) cached[cache.front()] = 0, cache.erase(cache.begin());
+        }
+    }
+    std::vector<uint32_t> new_index(T);
+    for (size_t k = 0; k < T; k++) {
+        new_index[order[k]] = (uint32_t)k;
+        out.roots.push_back(Root{terms[order[k]].node, OP_ACC, terms[order[k]].acc, (uint32_t)k});
+    }
+    for (TermPart &p : parts) p.term = new_index[p.term];
+    out.parts = std::move(parts);
+    return out;
 }
 
 // The same roots split into `n_groups` independent sub-programs (consecutive runs of roots). All

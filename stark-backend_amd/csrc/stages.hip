@@ -13,6 +13,7 @@
 // finishes. Field addition is exact, so the result does not depend on the schedule.
 #include "kernels.h"
 #include "eval.cuh"
+#include "cached_vm.cuh"
 
 namespace ovm {
 
@@ -762,39 +763,13 @@ struct StagedVM {
     }
 };
 
+// ---- cached-column round-0 interpreter (program.h: stage_cached; cached_vm.cuh) -----------------
 template <int R, int NOUT>
-struct StagedRound0 {
-    static constexpr int ROWS = R;
-    DevStaged prog;
-    __device__ __forceinline__ void operator()(const Fp *lde_k, uint32_t log_lifted, const uint64_t (&p)[R],
-                                               EF (&out)[R][2]) const {
-#if defined(__HIP_DEVICE_COMPILE__)
-        extern __shared__ uint32_t lds_image[];
-        const uint32_t *mine = lds_image + threadIdx.x;
-        const OVM_CONST_AS uint4 *accs = (const OVM_CONST_AS uint4 *)prog.accs;
-        Acc96 acc0[R], acc1[R];
-#pragma unroll
-        for (int r = 0; r < R; r++) acc0[r].clear(), acc1[r].clear();
-        StagedVM<R>::run(
-            prog, lds_image, [&](uint32_t col, int r) { return lde_k + ((uint64_t)col << log_lifted) + p[r]; },
-            [&](const uint4 hd2) {
-                StagedVM<R>::run_accs(accs + 2 * hd2.x, hd2.y, mine, acc0);
-                if (NOUT > 1) StagedVM<R>::run_accs(accs + 2 * (hd2.x + hd2.y), hd2.z, mine, acc1);
-            });
-#pragma unroll
-        for (int r = 0; r < R; r++) {
-            out[r][0] = out[r][0] + acc0[r].finish();
-            if (NOUT > 1) out[r][1] = out[r][1] + acc1[r].finish();
-        }
-#endif
-    }
-};
-template <int R, int NOUT>
-__global__ __launch_bounds__(RED_THREADS) void round0_staged_kernel(DevStaged prog, const Fp *lde,
+__global__ __launch_bounds__(RED_THREADS) void round0_cached_kernel(DevCached prog, const Fp *lde,
                                                                     uint32_t n_cols_total, uint32_t log_lifted,
                                                                     uint32_t l_skip, uint32_t n_cosets, uint32_t n_out,
                                                                     const EF *eq_xi, EF add_const, EF *partials) {
-    round0_eval_body(StagedRound0<R, NOUT>{prog}, lde, n_cols_total, log_lifted, l_skip, n_cosets, n_out,
+    round0_eval_body(CachedRound0<R, NOUT>{prog}, lde, n_cols_total, log_lifted, l_skip, n_cosets, n_out,
                      eq_xi, add_const, partials);
 }
 
@@ -826,7 +801,7 @@ static int round0_rows(uint32_t log_lifted, uint32_t n_out) {
 // the larger image is 0.3 ms slower, hence the threshold (profiles/r03/round0_layout_sweep.txt).
 // The larger image is taken only when it buys MORE ROWS PER LANE than the 36 KiB plan has (the Keccak-shaped stand-in,
 // 2 slots, already runs R = 4 at 36 KiB and loses 2.6 ms of 9.7 with the larger image).
-static constexpr uint32_t R0_LONG_PROGRAM = 4096, R0_LONG_PROGRAM_KIB = 72;
+static constexpr uint32_t R0_LONG_PROGRAM = 4096, R0_LONG_PROGRAM_KIB = 72, R0_CACHE_ROWS_MAX = 12;
 static StagedPlan staged_plan_for_budget(uint32_t log_lifted, uint32_t n_out, uint32_t num_slots, uint32_t first_budget) {
     StagedPlan plan;
     const Tuning &tn = tuning();  // (tuning / parity-test overrides)
@@ -853,9 +828,36 @@ StagedPlan round0_staged_plan(uint32_t log_lifted, uint32_t n_out, uint32_t num_
     return large.rows > small.rows ? large : small;
 }
 
-uint32_t round0_staged_grid(const DevStaged &staged, uint32_t log_lifted) {
-    const size_t lds_bytes = (size_t)staged.num_rows * staged.rows * RED_THREADS * 4;
-    uint64_t lanes = (1ull << log_lifted) / staged.rows;
+// Layout policy of the cached-column interpreter (round 0): rows per lane R as above; the image is cache rows + slots,
+// R KiB per row. `budget` KiB per workgroup decide the workgroups per CU.
+static CachedPlan cached_plan_for_budget(uint32_t log_lifted, uint32_t n_out, uint32_t num_slots, uint32_t first_budget) {
+    CachedPlan plan;
+    const Tuning &tn = tuning();  // (tuning / parity-test overrides)
+    for (int rows = round0_rows(log_lifted, n_out); rows >= 1; rows >>= 1) {
+        for (uint32_t budget_kib : {first_budget, 64u}) {
+            if (budget_kib > first_budget && rows > 1) continue;  // a larger image only as the last resort
+            const uint32_t budget_rows = budget_kib / (uint32_t)rows;
+            if (budget_rows < num_slots + 4) continue;
+            plan.rows = (uint32_t)rows;
+            plan.cache_rows = tn.stage_rows ? (uint32_t)std::max(2, tn.stage_rows) : std::min<uint32_t>(budget_rows - num_slots, R0_CACHE_ROWS_MAX);
+            plan.max_loads = tn.acc_rows ? (uint32_t)std::min<int>(std::max(2, tn.acc_rows), (int)CachedProgram::MAX_LOADS)
+                                         : std::min<uint32_t>(plan.cache_rows, CachedProgram::MAX_LOADS);
+            return plan;
+        }
+    }
+    return plan;  // rows == 0: does not fit, use the plain interpreter
+}
+CachedPlan round0_cached_plan(uint32_t log_lifted, uint32_t n_out, uint32_t num_slots, uint32_t n_instr) {
+    if (tuning().stage_kib) return cached_plan_for_budget(log_lifted, n_out, num_slots, tuning().stage_kib);
+    const CachedPlan small = cached_plan_for_budget(log_lifted, n_out, num_slots, 36);
+    if (n_instr < R0_LONG_PROGRAM || log_lifted < 18) return small;
+    const CachedPlan large = cached_plan_for_budget(log_lifted, n_out, num_slots, R0_LONG_PROGRAM_KIB);
+    return large.rows > small.rows ? large : small;
+}
+
+uint32_t round0_cached_grid(const DevCached &prog, uint32_t log_lifted) {
+    const size_t lds_bytes = (size_t)prog.num_rows * prog.rows * RED_THREADS * 4;
+    uint64_t lanes = (1ull << log_lifted) / prog.rows;
     if (lanes < RED_THREADS) lanes = RED_THREADS;
     // as many workgroups as are resident at once (LDS-bound), and every lane the same number of passes
     const uint32_t resident = 256u * (uint32_t)std::max<size_t>(1, std::min<size_t>(8, (160u << 10) / (lds_bytes + (5u << 10))));
@@ -865,7 +867,7 @@ uint32_t round0_staged_grid(const DevStaged &staged, uint32_t log_lifted) {
 }
 
 template <int R, int NOUT>
-__global__ __launch_bounds__(RED_THREADS) void round0_staged_batched_kernel(const R0Job *jobs, uint32_t n_jobs,
+__global__ __launch_bounds__(RED_THREADS) void round0_cached_batched_kernel(const R0Job *jobs, uint32_t n_jobs,
                                                                             uint32_t l_skip, uint32_t *counters,
                                                                             RedOut ro) {
     uint32_t j = 0;
@@ -876,15 +878,15 @@ __global__ __launch_bounds__(RED_THREADS) void round0_staged_batched_kernel(cons
     if (job.n_groups > 1) {
         const uint32_t grp = bx / job.gx_group;
 #if defined(__HIP_DEVICE_COMPILE__)  // (scalar load of the group's descriptor: it feeds scalar operands of the VM)
-        const DevStaged gprog = ((const OVM_CONST_AS DevStaged *)job.progs)[grp];
+        const DevCached gprog = ((const OVM_CONST_AS DevCached *)job.progs)[grp];
 #else
-        const DevStaged gprog = job.progs[grp];
+        const DevCached gprog = job.progs[grp];
 #endif
-        round0_eval_body(StagedRound0<R, NOUT>{gprog}, job.lde, job.n_cols_total, job.log_lifted, l_skip,
+        round0_eval_body(CachedRound0<R, NOUT>{gprog}, job.lde, job.n_cols_total, job.log_lifted, l_skip,
                          job.n_cosets, NOUT, job.eq_xi, grp == 0 ? job.add_const : EF::zero(),
                          job.partials + (size_t)grp * job.gx_group * K, bx - grp * job.gx_group, job.gx_group, true);
     } else {
-        round0_eval_body(StagedRound0<R, NOUT>{job.prog}, job.lde, job.n_cols_total, job.log_lifted, l_skip, job.n_cosets,
+        round0_eval_body(CachedRound0<R, NOUT>{job.prog}, job.lde, job.n_cols_total, job.log_lifted, l_skip, job.n_cosets,
                          NOUT, job.eq_xi, job.add_const, job.partials, bx, job.gx, true);
     }
     // the job's last workgroup sums the job's records; the last job raises the flag
@@ -918,7 +920,7 @@ int round0_eval_batched(const R0Job *d_jobs, const R0Job *h_jobs, uint32_t n_job
     size_t lds_bytes = 0;
     for (uint32_t j = 0; j < n_jobs; j++) {
         const R0Job &job = h_jobs[j];
-        if (!job.prog.blocks || job.prog.rows != rows || job.wg0 != grid || job.gx == 0 || job.n_cosets == 0 ||
+        if (!job.prog.words || job.prog.rows != rows || job.wg0 != grid || job.gx == 0 || job.n_cosets == 0 ||
             job.n_cosets > MAX_COSETS || job.n_groups < 1 || (job.n_groups > 1 && (!job.progs || job.gx != job.gx_group * job.n_groups)) ||
             job.lds_rows < job.prog.num_rows)
             return (int)hipErrorInvalidValue;
@@ -926,7 +928,7 @@ int round0_eval_batched(const R0Job *d_jobs, const R0Job *h_jobs, uint32_t n_job
         lds_bytes = std::max(lds_bytes, (size_t)job.lds_rows * rows * RED_THREADS * 4);
     }
 #define LAUNCH(R, NOUT)                                                                                                 \
-    OVM_LAUNCH((round0_staged_batched_kernel<R, NOUT>), dim3(grid), dim3(RED_THREADS), lds_bytes, s, d_jobs, n_jobs, \
+    OVM_LAUNCH((round0_cached_batched_kernel<R, NOUT>), dim3(grid), dim3(RED_THREADS), lds_bytes, s, d_jobs, n_jobs, \
                        l_skip, d_counters, ro)
     if (n_out == 1) {
         if (rows == 4) LAUNCH(4, 1);
@@ -943,7 +945,7 @@ int round0_eval_batched(const R0Job *d_jobs, const R0Job *h_jobs, uint32_t n_job
     return 0;
 }
 
-int round0_eval(const DevProgram &prog, const DevStaged &staged, const Fp *lde, uint32_t n_cols_total,
+int round0_eval(const DevProgram &prog, const DevCached &staged, const Fp *lde, uint32_t n_cols_total,
                 uint32_t log_lifted, uint32_t l_skip, uint32_t n_cosets, uint32_t n_out, const EF *d_eq_xi,
                 EF add_const, const RedOut &ro, hipStream_t s) {
     if (n_cosets == 0) return 0;
@@ -953,13 +955,13 @@ int round0_eval(const DevProgram &prog, const DevStaged &staged, const Fp *lde, 
     const uint32_t wg_per_domain = (1u << l_skip) > RED_THREADS ? (1u << l_skip) / RED_THREADS : 1;
     auto whole_domains = [&](uint32_t g) { return (g + wg_per_domain - 1) / wg_per_domain * wg_per_domain; };
     int rows = round0_rows(log_lifted, n_out);
-    if (staged.blocks) {
-        rows = (int)staged.rows;  // fixed when the program was staged (round0_staged_rows)
+    if (staged.words) {
+        rows = (int)staged.rows;  // fixed when the program was staged (round0_cached_plan)
         const size_t lds_bytes = (size_t)staged.num_rows * rows * RED_THREADS * 4;
         {
-            const uint32_t grid = whole_domains(round0_staged_grid(staged, log_lifted));
+            const uint32_t grid = whole_domains(round0_cached_grid(staged, log_lifted));
 #define LAUNCH(R, NOUT)                                                                                             \
-    OVM_LAUNCH((round0_staged_kernel<R, NOUT>), dim3(grid), dim3(RED_THREADS), lds_bytes, s, staged, lde, \
+    OVM_LAUNCH((round0_cached_kernel<R, NOUT>), dim3(grid), dim3(RED_THREADS), lds_bytes, s, staged, lde, \
                        n_cols_total, log_lifted, l_skip, n_cosets, n_out, d_eq_xi, add_const, ro.partials)
             if (n_out == 1) {
                 if (rows == 4) LAUNCH(4, 1);
