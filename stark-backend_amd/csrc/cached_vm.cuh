@@ -168,6 +168,7 @@ static_assert(RED_THREADS * 4 == 1024, "the asm addresses row r of an operand at
 template <int R, int NOUT>
 struct CachedRound0 {
     static constexpr int ROWS = R;
+    static constexpr bool REDUCE_IN_IMAGE = true;  // (eval.cuh: the launch gives the image at least RED_THREADS * 16 bytes)
     static_assert(R == 1 || R == 2 || R == 4, "one asm form per R");
     static_assert(NOUT == 1 || (NOUT == 2 && R <= 2), "two accumulator sets for at most two rows per lane");
     static_assert(CachedProgram::MAX_LOADS == 8, "the block statement lands / requests 8 columns");

@@ -105,7 +105,16 @@ __device__ __forceinline__ void round0_eval_body(const Prog &prog, const Fp *lde
     // (bx, gx: this workgroup's index and the number of workgroups of ITS job -- a batched launch runs
     // several jobs side by side; fence: device-scope release of the partial records for an in-kernel finish)
     constexpr int R = Prog::ROWS;
-    __shared__ EF sh[RED_THREADS];
+    // Scratch of the final reduction over the workgroup. A program that keeps an LDS image of its own (cached_vm.cuh)
+    // lends it: 4 KiB of static LDS on top of a 32 KiB image is the difference between four and five workgroups per CU.
+    EF *sh;
+    if constexpr (Prog::REDUCE_IN_IMAGE) {
+        extern __shared__ uint32_t lds_image[];
+        sh = reinterpret_cast<EF *>(lds_image);
+    } else {
+        __shared__ EF sh_static[RED_THREADS];
+        sh = sh_static;
+    }
     const uint32_t N = 1u << l_skip;
     const uint64_t total = 1ull << log_lifted;
     // A lane's rows all have the same z = row mod N: the stride is a multiple of N -- for N <= RED_THREADS always, for a
@@ -144,6 +153,7 @@ __device__ __forceinline__ void round0_eval_body(const Prog &prog, const Fp *lde
         }
     }
     // reduce over lanes with equal z = tid mod N
+    if constexpr (Prog::REDUCE_IN_IMAGE) __syncthreads();  // (every wave is done with the image before it is overwritten)
     for (uint32_t k = 0; k < n_cosets; k++)
         for (uint32_t o = 0; o < n_out; o++) {
             sh[threadIdx.x] = sums[2 * k + o];

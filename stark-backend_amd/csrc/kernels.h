@@ -41,15 +41,15 @@ struct DevCached {
     const StagedInstr *words = nullptr;  // n_words (a multiple of 8) + one more group of four
     const uint32_t *loads = nullptr;     // records of CachedProgram::MAX_LOADS (column, row offset) pairs
     uint32_t n_words = 0;
-    uint32_t num_rows = 0;    // LDS rows: cache + slots
+    uint32_t num_rows = 0;    // LDS rows of the image (cached columns and live values share them)
     uint32_t rows = 0;        // trace rows per lane the offsets were scaled for
-    uint32_t cache_rows = 0;
 };
 // Rows per lane and LDS layout for the cached form; rows == 0: the image does not fit (plain interpreter).
 struct CachedPlan {
-    uint32_t rows = 0, cache_rows = 0, max_loads = 0;
+    uint32_t rows = 0, image_rows = 0, max_loads = 0;
 };
-CachedPlan round0_cached_plan(uint32_t log_lifted, uint32_t n_out, uint32_t num_slots, uint32_t n_instr = 0);
+// min_rows: the rows the program cannot do without (program.h: cached_liveness)
+CachedPlan round0_cached_plan(uint32_t log_lifted, uint32_t n_out, uint32_t min_rows, uint32_t n_instr = 0);
 
 // ro.out[k] = sum_b ro.partials[b * K + k], then the flag (for reductions with many outputs)
 int sum_partials(const RedOut &ro, uint32_t n_blocks, uint32_t K, hipStream_t s);
@@ -63,9 +63,13 @@ int mobius_eq_table(const EF *d_point, uint32_t n, EF *out, hipStream_t s);
 //   d_shift_pows[k * 2^l_skip + i] = shift_k^i / 2^l_skip
 // row0 != 0: the slab of rows [row0, row0 + 2^log_lifted) of the columns (a multiple of 2^l_skip) is extended
 // into an lde buffer laid out for 2^log_lifted rows -- round 0 in slabs (zerocheck_save_memory)
+// l_skip = 4 (the register kernel): an entry of d_used with bit 31 set also produces the column's rotated view
+// d_twins[col] from the same read (d_lag[k * 16 + z] = L_15(shift_k * omega^z), see coset_lde16_kernel); such views are
+// then left out of the list. (rotated_lde_list builds it; other l_skip: plain list, the views extended on their own.)
 int coset_lde(const ColDesc *d_cols, const uint32_t *d_used, uint32_t n_used, uint32_t n_cols_total,
               uint32_t log_lifted, uint32_t l_skip, uint32_t n_cosets, const Fp *d_shift_pows, Fp *lde,
-              hipStream_t s, uint64_t row0 = 0, uint32_t pad_lds_bytes = 0);
+              hipStream_t s, uint64_t row0 = 0, uint32_t pad_lds_bytes = 0, const int32_t *d_twins = nullptr,
+              const Fp *d_lag = nullptr);
 // (pad_lds_bytes: LDS every workgroup claims without using it -- caps the workgroups per CU of a launch that runs beside
 // latency-critical kernels of another stream)
 

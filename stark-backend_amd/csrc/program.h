@@ -646,11 +646,13 @@ inline void staged_host_eval(const StagedProgram &sp, const std::vector<Fp> &row
 // ---------------------------------------------------------------------------------------------
 // Cached-column staged form of an ACC program (round 0; cached_vm.cuh: CachedRound0).
 //
-// The block form above stages every column a block reads, every block. Here the LDS image holds a CACHE of `cache_rows`
-// columns that survives from block to block: a block's load list names only the columns that are not cached (column ->
-// LDS row), chosen against the program's own future -- the column evicted is the one whose next read is farthest away.
+// The block form above stages every column a block reads, every block. Here the LDS image is ONE pool of rows shared by
+// a CACHE of columns that survives from block to block and by the program's live values (a slot needs a row only from
+// where its value is computed to its last read: the real Keccak-f program has 8 slots and, nine instructions in ten, at
+// most three live values). A block's load list names only the columns that are not cached (column -> LDS row), chosen
+// against the program's own future -- the column evicted is the one whose next read is farthest away.
 // The loads of block b + 1 are requested when block b starts, into REGISTERS, and written to their rows when block b + 1
-// starts: nothing in LDS is reserved for data in flight, so the whole image is cache + slots.
+// starts: nothing in LDS is reserved for data in flight.
 // The program is ONE stream of 16-byte words (the kernel fetches them four at a time, one group ahead):
 //   arithmetic   {StagedOp | flags, dst row, a row, b row | constant}: the first operand is the RESULT REGISTER (the value
 //                of the word before: S_FWD_A) or row a, the second the constant b (S_B_CONST), the result register
@@ -668,14 +670,14 @@ inline void staged_host_eval(const StagedProgram &sp, const std::vector<Fp> &row
 // ---------------------------------------------------------------------------------------------
 static constexpr uint32_t C_ACC = 0x80000000u, C_BLOCK = 0x40000000u;
 struct CachedLayout {
-    uint32_t cache_rows = 8;
+    uint32_t rows = 12;      // LDS rows of the image: shared by the cached columns and the program's live values
     uint32_t max_loads = 8;  // columns a block may bring (<= CachedProgram::MAX_LOADS: the kernel's landing registers)
 };
 struct CachedProgram {
     static constexpr uint32_t MAX_LOADS = 8;
     std::vector<StagedInstr> words;  // a multiple of 8 (padded with no-ops) + one more group of four
     std::vector<uint32_t> loads;     // one record per block word: MAX_LOADS LDS rows to write, MAX_LOADS flat columns to request
-    uint32_t num_rows = 0, cache_rows = 0, n_blocks = 0;
+    uint32_t num_rows = 0, n_blocks = 0;
     uint64_t n_loads = 0;  // columns brought per evaluation (statistics)
     // operand rows -> word offsets for `rows_per_lane` trace rows per lane
     void scale_rows(uint32_t rows_per_lane) {
@@ -691,12 +693,58 @@ struct CachedProgram {
     }
 };
 
+// What stage_cached decides per instruction before it lays the rows out: is the result written to LDS at all (a value
+// read only by the next instruction stays in the result register), and until which instruction is it read from there.
+struct CachedLiveness {
+    std::vector<char> stored;        // arithmetic instruction i writes its result to a row
+    std::vector<int32_t> last_read;  // ... which is read from LDS for the last time by this instruction (< i: never)
+    std::vector<uint32_t> live;      // stored values alive while instruction i runs (its own result included)
+    uint32_t min_rows = 2;           // rows the program cannot do without: max over i of live[i] + columns read by i
+};
+inline CachedLiveness cached_liveness(const Program &p) {
+    const size_t n = p.code.size();
+    CachedLiveness lv;
+    lv.stored.assign(n, 0);
+    lv.last_read.assign(n, -1);
+    lv.live.assign(n, 0);
+    std::vector<int32_t> def(p.num_slots + 1, -1);  // the instruction whose result a slot holds
+    auto is_binary = [](const Instr &in) { return in.op == OP_ADD || in.op == OP_SUB || in.op == OP_MUL; };
+    for (size_t i = 0; i < n; i++) {
+        const Instr &in = p.code[i];
+        if (in.op > OP_ACC) throw OvmFail(1, "stage_cached: accumulation programs only");
+        // reads from LDS: slot operands that are not forwarded from the instruction before
+        if (in.ak == K_SLOT && !(in.fwd & FWD_A) && def.at(in.a) >= 0) lv.last_read[def[in.a]] = (int32_t)i;
+        if (is_binary(in) && in.bk == K_SLOT && !(in.fwd & FWD_B) && def.at(in.b) >= 0) lv.last_read[def[in.b]] = (int32_t)i;
+        if (in.op <= OP_NEG) {
+            const bool next_takes_it = i + 1 < n && (p.code[i + 1].fwd & (FWD_A | FWD_B));
+            lv.stored[i] = !((in.fwd & FWD_NOSTORE) && next_takes_it);
+            def.at(in.dst) = (int32_t)i;
+        }
+    }
+    std::vector<int32_t> delta(n + 1, 0);
+    for (size_t i = 0; i < n; i++)
+        if (lv.stored[i]) {
+            delta[i]++;
+            delta[std::max<size_t>(i, lv.last_read[i] < 0 ? 0 : (size_t)lv.last_read[i]) + 1]--;
+        }
+    int32_t cur = 0;
+    for (size_t i = 0; i < n; i++) {
+        cur += delta[i];
+        lv.live[i] = (uint32_t)cur;
+        const Instr &in = p.code[i];
+        uint32_t cols = in.ak == K_COL ? 1 : 0;
+        if (is_binary(in) && in.bk == K_COL && !(in.ak == K_COL && in.a == in.b)) cols++;
+        lv.min_rows = std::max(lv.min_rows, lv.live[i] + cols);
+    }
+    return lv;
+}
+
 inline CachedProgram stage_cached(const Program &p, const std::vector<FpExt> &weights, const CachedLayout &layout = CachedLayout()) {
-    const uint32_t C = layout.cache_rows, L = std::min(layout.max_loads, CachedProgram::MAX_LOADS);
-    if (C < 2 || L < 2) throw OvmFail(1, "stage_cached: the cache needs two rows and two loads per block");
+    const CachedLiveness lv = cached_liveness(p);
+    const uint32_t T = layout.rows, L = std::min(layout.max_loads, CachedProgram::MAX_LOADS);
+    if (T < lv.min_rows || L < 2) throw OvmFail(1, "stage_cached: the image is too small for this program");
     CachedProgram cp;
-    cp.cache_rows = C;
-    cp.num_rows = C + p.num_slots;
+    cp.num_rows = T;
     const size_t n = p.code.size();
     auto is_binary = [](const Instr &in) { return in.op == OP_ADD || in.op == OP_SUB || in.op == OP_MUL; };
     // the columns instruction i reads, and per column the instructions that read it (for the eviction choice)
@@ -708,7 +756,6 @@ inline CachedProgram stage_cached(const Program &p, const std::vector<FpExt> &we
     };
     uint32_t max_col = 0;
     for (const Instr &in : p.code) {
-        if (in.op > OP_ACC) throw OvmFail(1, "stage_cached: accumulation programs only");
         uint32_t c[2];
         for (int k = cols_of(in, c); k-- > 0;) max_col = std::max(max_col, c[k]);
     }
@@ -722,9 +769,15 @@ inline CachedProgram stage_cached(const Program &p, const std::vector<FpExt> &we
         auto it = std::lower_bound(r.begin(), r.end(), (uint32_t)from);
         return it == r.end() ? n : *it;
     };
-    // ---- blocks: runs of instructions that read at most C distinct columns, at most L of them not cached ----
+    // ---- rows: ONE pool for cached columns and live values ----
+    // A block is a run of instructions with  columns read + most values alive at once <= T  and at most L columns to
+    // bring. Its columns keep (or get, at its start) their rows for the whole block; a value takes, where it is computed, a
+    // row that holds neither a column of the block nor a live value: a free one, or the cached column read again last.
+    static constexpr uint32_t FREE = ~0u, VALUE = ~0u - 1;
     std::vector<int32_t> row_of(max_col + 1, -1);  // LDS row of a cached column
-    std::vector<uint32_t> col_in_row(C, ~0u);
+    std::vector<uint32_t> holds(T, FREE);          // a column, VALUE, or FREE
+    std::vector<int32_t> value_row(n, -1);         // row of the result of instruction i while it is alive
+    std::vector<std::vector<uint32_t>> dying(n + 1);  // values whose last read is instruction i
     struct Block {
         size_t first, last;                                // instructions [first, last)
         std::vector<std::pair<uint32_t, uint32_t>> loads;  // (column, row) to bring
@@ -735,6 +788,7 @@ inline CachedProgram stage_cached(const Program &p, const std::vector<FpExt> &we
     for (size_t first = 0; first < n;) {
         const uint32_t id = (uint32_t)blocks.size() + 1;
         std::vector<uint32_t> used, fresh;
+        uint32_t peak = 0;
         size_t last = first;
         for (; last < n; last++) {
             uint32_t c[2];
@@ -742,7 +796,8 @@ inline CachedProgram stage_cached(const Program &p, const std::vector<FpExt> &we
             uint32_t add_used = 0, add_fresh = 0;
             for (int j = 0; j < k; j++)
                 if (stamp[c[j]] != id) add_used++, add_fresh += row_of[c[j]] < 0;
-            if (used.size() + add_used > C || fresh.size() + add_fresh > L) break;
+            if (used.size() + add_used + std::max(peak, lv.live[last]) > T || fresh.size() + add_fresh > L) break;
+            peak = std::max(peak, lv.live[last]);
             for (int j = 0; j < k; j++)
                 if (stamp[c[j]] != id) {
                     stamp[c[j]] = id;
@@ -751,25 +806,38 @@ inline CachedProgram stage_cached(const Program &p, const std::vector<FpExt> &we
                 }
         }
         if (last == first) throw OvmFail(1, "stage_cached: an instruction does not fit a block");
-        // rows for the fresh columns: free rows, then the cached columns this block does not read, farthest next read first
+        // the row a newcomer takes: a free one, else the cached column outside this block that is read again last
+        auto take_row = [&](size_t from) -> uint32_t {
+            uint32_t best = FREE;
+            size_t best_next = 0;
+            for (uint32_t r = 0; r < T; r++) {
+                if (holds[r] == FREE) return r;
+                if (holds[r] == VALUE || stamp[holds[r]] == id) continue;
+                const size_t nx = next_read(holds[r], from) + 1;
+                if (nx > best_next) best = r, best_next = nx;
+            }
+            if (best == FREE) throw OvmFail(1, "stage_cached: internal (no row left)");
+            row_of[holds[best]] = -1;
+            return best;
+        };
         Block blk{first, last, {}, {}};
-        std::vector<std::pair<size_t, uint32_t>> victims;  // (next read, row)
-        for (uint32_t r = 0; r < C; r++) {
-            const uint32_t col = col_in_row[r];
-            if (col == ~0u) victims.push_back({n + 1, r});
-            else if (stamp[col] != id) victims.push_back({next_read(col, last), r});
-        }
-        std::sort(victims.begin(), victims.end(),
-                  [](const std::pair<size_t, uint32_t> &x, const std::pair<size_t, uint32_t> &y) { return x.first != y.first ? x.first > y.first : x.second < y.second; });
-        if (victims.size() < fresh.size()) throw OvmFail(1, "stage_cached: internal (no row for a column)");
-        for (size_t j = 0; j < fresh.size(); j++) {
-            const uint32_t r = victims[j].second;
-            if (col_in_row[r] != ~0u) row_of[col_in_row[r]] = -1;
-            col_in_row[r] = fresh[j];
-            row_of[fresh[j]] = (int32_t)r;
-            blk.loads.push_back({fresh[j], r});
+        for (uint32_t col : fresh) {
+            const uint32_t r = take_row(last);
+            holds[r] = col;
+            row_of[col] = (int32_t)r;
+            blk.loads.push_back({col, r});
         }
         for (uint32_t c : used) blk.rows.push_back({c, (uint32_t)row_of[c]});
+        // the values of the block: rows taken where they are computed, given back after their last read
+        for (size_t i = first; i < last; i++) {
+            if (lv.stored[i]) {
+                const uint32_t r = take_row(last);
+                holds[r] = VALUE;
+                value_row[i] = (int32_t)r;
+                dying[std::max<size_t>(i, lv.last_read[i] < 0 ? 0 : (size_t)lv.last_read[i])].push_back((uint32_t)i);
+            }
+            for (uint32_t v : dying[i]) holds[(size_t)value_row[v]] = FREE;
+        }
         cp.n_loads += fresh.size();
         blocks.push_back(std::move(blk));
         first = last;
@@ -790,6 +858,7 @@ inline CachedProgram stage_cached(const Program &p, const std::vector<FpExt> &we
     };
     if (!blocks.empty()) block_word(npos, 0);
     std::vector<int32_t> cur_row(max_col + 1, -1);
+    std::vector<int32_t> slot_value(p.num_slots + 1, -1);  // the instruction whose result a slot holds
     for (size_t b = 0; b < blocks.size(); b++) {
         block_word(b, b + 1 < blocks.size() ? b + 1 : npos);
         for (auto &cr : blocks[b].rows) cur_row[cr.first] = (int32_t)cr.second;
@@ -799,8 +868,14 @@ inline CachedProgram stage_cached(const Program &p, const std::vector<FpExt> &we
                 bool is_const;
                 uint32_t v;
             };
-            auto opnd = [&](uint8_t kind, uint32_t payload) -> Opnd {
-                if (kind == K_SLOT) return {false, C + payload};
+            // (a forwarded slot operand is never read from LDS: its row field is left 0)
+            auto opnd = [&](uint8_t kind, uint32_t payload, bool forwarded) -> Opnd {
+                if (kind == K_SLOT) {
+                    if (forwarded) return {false, 0};
+                    const int32_t v = slot_value.at(payload);
+                    if (v < 0 || value_row[(size_t)v] < 0) throw OvmFail(1, "stage_cached: internal (value not in a row)");
+                    return {false, (uint32_t)value_row[(size_t)v]};
+                }
                 if (kind == K_COL) {
                     if (cur_row[payload] < 0) throw OvmFail(1, "stage_cached: internal (column not cached)");
                     return {false, (uint32_t)cur_row[payload]};
@@ -809,12 +884,13 @@ inline CachedProgram stage_cached(const Program &p, const std::vector<FpExt> &we
                 throw OvmFail(1, "stage_cached: bad operand kind");
             };
             auto emit = [&](uint32_t op, uint32_t dst, uint32_t a, uint32_t b2) { cp.words.push_back(StagedInstr{op, dst, a, b2}); };
-            const Opnd a = opnd(in.ak, in.a);
+            const bool f_a = (in.fwd & FWD_A) != 0, f_b = (in.fwd & FWD_B) != 0;
+            const Opnd a = opnd(in.ak, in.a, f_a);
             if (in.op == OP_ACC) {
                 if (in.b >= weights.size()) throw OvmFail(1, "stage_cached: weight index out of range");
                 if (in.acc > 1) throw OvmFail(1, "stage_cached: accumulator out of range");
                 // the value must be in the result register: forwarded from the instruction before, or moved there
-                if (!(in.fwd & FWD_A)) {
+                if (!f_a) {
                     if (a.is_const) emit(S_MOVC | S_B_CONST | S_NOSTORE, 0, 0, a.v);
                     else emit(S_MOV | S_B_CONST | S_NOSTORE, 0, a.v, 0);
                 }
@@ -822,17 +898,15 @@ inline CachedProgram stage_cached(const Program &p, const std::vector<FpExt> &we
                 emit(C_ACC | w.c[0].v, ((uint32_t)in.acc << 31) | w.c[1].v, w.c[2].v, w.c[3].v);
                 continue;
             }
-            const uint32_t dst = C + in.dst;
-            // the result stays in the register only when the one reader is the next instruction (arithmetic or accumulation)
-            const bool next_takes_it = idx + 1 < n && (p.code[idx + 1].fwd & (FWD_A | FWD_B));
-            const uint32_t f_ns = ((in.fwd & FWD_NOSTORE) && next_takes_it) ? S_NOSTORE : 0;
-            const bool f_a = (in.fwd & FWD_A) != 0, f_b = (in.fwd & FWD_B) != 0;
+            const uint32_t f_ns = lv.stored[idx] ? 0 : S_NOSTORE;
+            const uint32_t dst = lv.stored[idx] ? (uint32_t)value_row[idx] : 0;
+            const Opnd bo = in.op == OP_NEG ? Opnd{true, 0} : opnd(in.bk, in.b, f_b);
+            slot_value.at(in.dst) = (int32_t)idx;  // (after the operands were looked up: they name the values before)
             if (in.op == OP_NEG) {  // 0 - x
                 if (a.is_const) emit(S_MOVC | S_B_CONST | f_ns, dst, 0, (-Fp::raw(a.v)).v);
                 else emit(S_RSUB | S_B_CONST | (f_a ? S_FWD_A : 0) | f_ns, dst, a.v, 0);
                 continue;
             }
-            const Opnd bo = opnd(in.bk, in.b);
             if (a.is_const && bo.is_const) {
                 const Fp x = Fp::raw(a.v), y = Fp::raw(bo.v);
                 const Fp r = in.op == OP_ADD ? x + y : in.op == OP_SUB ? x - y : x * y;

@@ -1282,9 +1282,9 @@ int ovm_hip_staged_selftest(const uint32_t *blob, uint64_t words, uint32_t stage
                 // the cached-column form (round 0), of the program as compiled and of its linear terms: the roots taken
                 // apart down to expressions of at most `cap` columns and re-ordered (cap 0: every sum, down to the products)
                 CachedLayout cl;
-                cl.cache_rows = std::max<uint32_t>(2, stage_rows);
                 cl.max_loads = std::max<uint32_t>(2, std::min<uint32_t>(acc_rows, CachedProgram::MAX_LOADS));
                 {
+                    cl.rows = std::max(cached_liveness(p).min_rows, stage_rows);  // (stage_rows small: the image at its minimum)
                     const CachedProgram cp = stage_cached(p, w, cl);
                     n_blocks += cp.n_blocks;
                     EF c[2] = {EF::zero(), EF::zero()};
@@ -1292,13 +1292,14 @@ int ovm_hip_staged_selftest(const uint32_t *blob, uint64_t words, uint32_t stage
                     if (!(c[0] == want[0]) || !(c[1] == want[1])) fail("cached form");
                 }
                 for (uint32_t cap : {0u, 1u, 2u, TERM_SUPPORT_CAP}) {
-                    const TermRoots tr = linear_terms(air, cm, pv, roots, cap, cl.cache_rows);
+                    const TermRoots tr = linear_terms(air, cm, pv, roots, cap, std::max<uint32_t>(2, stage_rows));
                     const std::vector<EF> tw = tr.weights(w);
                     const Program q = compile_program(air, cm, pv, tr.roots, (uint32_t)tw.size());
                     EF alt[2] = {EF::zero(), EF::zero()};
                     std::vector<Fp> sl(q.num_slots);
                     run_program_acc<Fp>(q.code.data(), (uint32_t)q.code.size(), tw.data(), sl.data(), fetch, alt);
                     if (!(alt[0] == want[0]) || !(alt[1] == want[1])) fail("linear terms");
+                    cl.rows = std::max(cached_liveness(q).min_rows, stage_rows);
                     const CachedProgram cp = stage_cached(q, tw, cl);
                     n_blocks += cp.n_blocks;
                     EF c[2] = {EF::zero(), EF::zero()};

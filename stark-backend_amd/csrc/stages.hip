@@ -376,12 +376,20 @@ __device__ __forceinline__ constexpr int bitrev4(int i) {
     return ((i & 1) << 3) | ((i & 2) << 1) | ((i & 4) >> 1) | ((i & 8) >> 3);
 }
 
-__global__ __launch_bounds__(256) void coset_lde16_kernel(const ColDesc *cols, const uint32_t *used,
+// A list entry with bit 31 set also produces the column's ROTATED view (column twins[col]) from the same registers:
+// the rotated chunk is the chunk's polynomial at omega * X, corrected in its last point -- it holds T(x + 1, 0) where
+// P(omega X) holds T(x, 0) again -- so on the coset point s * omega^z
+//     rot(z) = plain((z + 1) mod 16) + (T(x + 1, 0) - T(x, 0)) * L_15(s * omega^z),
+// L_15 the Lagrange polynomial of the chunk's last point (lag[c * 16 + z], host-computed): 16 multiply-adds per coset
+// instead of a second interpolation and extension from 16 unaligned loads.
+__global__ __launch_bounds__(256) void coset_lde16_kernel(const ColDesc *cols, const uint32_t *used, const int32_t *twins,
                                                           uint32_t n_cols_total, uint32_t log_lifted,
-                                                          uint32_t n_cosets, const Fp *twist, Fp *lde, uint64_t row0) {
+                                                          uint32_t n_cosets, const Fp *twist, const Fp *lag, Fp *lde,
+                                                          uint64_t row0) {
     const uint64_t chunk = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (chunk >= (1ull << (log_lifted - 4))) return;
-    const uint32_t col = used[blockIdx.y];
+    const uint32_t entry = used[blockIdx.y], col = entry & 0x7fffffffu;
+    const bool with_twin = entry >> 31;
     const ColDesc cd = cols[col];
     // (row0: the slab of rows [row0, row0 + 2^log_lifted) of the columns is extended -- round 0 in slabs)
     const uint64_t hmask = (1ull << cd.log_height) - 1, base = chunk << 4, sbase = base + row0;
@@ -399,6 +407,12 @@ __global__ __launch_bounds__(256) void coset_lde16_kernel(const ColDesc *cols, c
     } else {
 #pragma unroll
         for (int z = 0; z < 16; z++) x[z] = cd.ptr[(sbase + z + cd.rot) & hmask];
+    }
+    Fp delta = Fp::zero();
+    uint32_t twin_col = 0;
+    if (with_twin) {
+        delta = cd.ptr[(sbase + 16) & hmask] - x[0];
+        twin_col = (uint32_t)twins[col];
     }
     // inverse DIF, natural -> bit-reversed coefficients (unscaled; 1/16 is folded into `twist`)
 #pragma unroll
@@ -438,12 +452,20 @@ __global__ __launch_bounds__(256) void coset_lde16_kernel(const ColDesc *cols, c
         uint4 *dst = reinterpret_cast<uint4 *>(lde + (((uint64_t)c * n_cols_total + col) << log_lifted) + base);
 #pragma unroll
         for (int v = 0; v < 4; v++) dst[v] = make_uint4(y[4 * v].v, y[4 * v + 1].v, y[4 * v + 2].v, y[4 * v + 3].v);
+        if (with_twin) {
+            Fp w[16];
+#pragma unroll
+            for (int z = 0; z < 16; z++) w[z] = y[(z + 1) & 15] + delta * lag[c * 16 + z];
+            uint4 *dst2 = reinterpret_cast<uint4 *>(lde + (((uint64_t)c * n_cols_total + twin_col) << log_lifted) + base);
+#pragma unroll
+            for (int v = 0; v < 4; v++) dst2[v] = make_uint4(w[4 * v].v, w[4 * v + 1].v, w[4 * v + 2].v, w[4 * v + 3].v);
+        }
     }
 }
 
 int coset_lde(const ColDesc *d_cols, const uint32_t *d_used, uint32_t n_used, uint32_t n_cols_total,
               uint32_t log_lifted, uint32_t l_skip, uint32_t n_cosets, const Fp *d_shift_pows, Fp *lde,
-              hipStream_t s, uint64_t row0, uint32_t pad_lds_bytes) {
+              hipStream_t s, uint64_t row0, uint32_t pad_lds_bytes, const int32_t *d_twins, const Fp *d_lag) {
     if (n_used == 0 || n_cosets == 0) return 0;
     if (row0 & ((1ull << l_skip) - 1)) return (int)hipErrorInvalidValue;
     const Twiddles *tw = twiddles();
@@ -451,8 +473,8 @@ int coset_lde(const ColDesc *d_cols, const uint32_t *d_used, uint32_t n_used, ui
     // d_shift_pows[k * N + i] = shift_k^i / N (the caller folds 1/N in)
     if (l_skip == 4) {
         dim3 grid16((unsigned)ceil_div(1ull << (log_lifted - 4), 256), n_used);
-        OVM_LAUNCH(coset_lde16_kernel, grid16, dim3(256), pad_lds_bytes > 65536 ? 65536 : pad_lds_bytes, s, d_cols, d_used, n_cols_total, log_lifted,
-                           n_cosets, d_shift_pows, lde, row0);
+        OVM_LAUNCH(coset_lde16_kernel, grid16, dim3(256), pad_lds_bytes > 65536 ? 65536 : pad_lds_bytes, s, d_cols, d_used, d_twins,
+                           n_cols_total, log_lifted, n_cosets, d_shift_pows, d_lag, lde, row0);
         OVM_CHECK_LAUNCH();
         return 0;
     }
@@ -490,6 +512,7 @@ struct LdeFetch {
 template <int NS, int R, int NOUT>
 struct InterpRound0 {
     static constexpr int ROWS = R;
+    static constexpr bool REDUCE_IN_IMAGE = false;
     static constexpr int PREFETCH = 8 / ROWS;
     static constexpr bool LDS_SLOTS = NS * ROWS <= 32;  // <= 32 KiB per workgroup
     DevProgram prog;
@@ -801,7 +824,7 @@ static int round0_rows(uint32_t log_lifted, uint32_t n_out) {
 // the larger image is 0.3 ms slower, hence the threshold (profiles/r03/round0_layout_sweep.txt).
 // The larger image is taken only when it buys MORE ROWS PER LANE than the 36 KiB plan has (the Keccak-shaped stand-in,
 // 2 slots, already runs R = 4 at 36 KiB and loses 2.6 ms of 9.7 with the larger image).
-static constexpr uint32_t R0_LONG_PROGRAM = 4096, R0_LONG_PROGRAM_KIB = 72, R0_CACHE_ROWS_MAX = 12;
+static constexpr uint32_t R0_LONG_PROGRAM = 4096, R0_LONG_PROGRAM_KIB = 72;
 static StagedPlan staged_plan_for_budget(uint32_t log_lifted, uint32_t n_out, uint32_t num_slots, uint32_t first_budget) {
     StagedPlan plan;
     const Tuning &tn = tuning();  // (tuning / parity-test overrides)
@@ -828,31 +851,29 @@ StagedPlan round0_staged_plan(uint32_t log_lifted, uint32_t n_out, uint32_t num_
     return large.rows > small.rows ? large : small;
 }
 
-// Layout policy of the cached-column interpreter (round 0): rows per lane R as above; the image is cache rows + slots,
-// R KiB per row. `budget` KiB per workgroup decide the workgroups per CU.
-static CachedPlan cached_plan_for_budget(uint32_t log_lifted, uint32_t n_out, uint32_t num_slots, uint32_t first_budget) {
+// Layout policy of the cached-column interpreter (round 0): rows per lane R as above; the image is ONE pool of rows for
+// cached columns and live values, R KiB per row, and it is sized for FOUR workgroups per CU (40 KiB): on the real Keccak-f
+// program (2^20 rows, R = 4: 1 024 workgroups, exactly four per CU) 8 / 9 / 10 rows take 21.9 / 21.9 / 21.5 ms and 12 or 16
+// rows -- three or two resident workgroups, a second wave of workgroups over the chip -- 34 ms; R = 2 takes 30-32 ms at
+// every image from 16 to 32 KiB and R = 1 55 ms: with two rows per lane the scalar work per cell, not the wait for LDS,
+// is what is left (profiles/r05/round0_cached_layout_sweep.txt). More rows than the program needs buy fewer column
+// loads (7 100 per row with 4 spare rows, 5 400 with 6, 5 000 with 8).
+static constexpr uint32_t R0_IMAGE_KIB = 40, R0_IMAGE_ROWS_MAX = 12;
+CachedPlan round0_cached_plan(uint32_t log_lifted, uint32_t n_out, uint32_t min_rows, uint32_t /*n_instr*/) {
     CachedPlan plan;
     const Tuning &tn = tuning();  // (tuning / parity-test overrides)
+    const uint32_t budget_kib = tn.stage_kib ? tn.stage_kib : R0_IMAGE_KIB;
     for (int rows = round0_rows(log_lifted, n_out); rows >= 1; rows >>= 1) {
-        for (uint32_t budget_kib : {first_budget, 64u}) {
-            if (budget_kib > first_budget && rows > 1) continue;  // a larger image only as the last resort
-            const uint32_t budget_rows = budget_kib / (uint32_t)rows;
-            if (budget_rows < num_slots + 4) continue;
-            plan.rows = (uint32_t)rows;
-            plan.cache_rows = tn.stage_rows ? (uint32_t)std::max(2, tn.stage_rows) : std::min<uint32_t>(budget_rows - num_slots, R0_CACHE_ROWS_MAX);
-            plan.max_loads = tn.acc_rows ? (uint32_t)std::min<int>(std::max(2, tn.acc_rows), (int)CachedProgram::MAX_LOADS)
-                                         : std::min<uint32_t>(plan.cache_rows, CachedProgram::MAX_LOADS);
-            return plan;
-        }
+        // (one row per lane may take what is left of a CU's LDS: better one resident workgroup than the plain interpreter)
+        const uint32_t budget_rows = (rows > 1 ? budget_kib : std::max(budget_kib, 128u)) / (uint32_t)rows;
+        if (budget_rows < min_rows) continue;
+        plan.rows = (uint32_t)rows;
+        plan.image_rows = tn.stage_rows ? std::min(budget_rows, std::max<uint32_t>(min_rows, (uint32_t)tn.stage_rows))
+                                        : std::max(min_rows, std::min(budget_rows, R0_IMAGE_ROWS_MAX));
+        plan.max_loads = tn.acc_rows ? (uint32_t)std::min<int>(std::max(2, tn.acc_rows), (int)CachedProgram::MAX_LOADS) : CachedProgram::MAX_LOADS;
+        return plan;
     }
     return plan;  // rows == 0: does not fit, use the plain interpreter
-}
-CachedPlan round0_cached_plan(uint32_t log_lifted, uint32_t n_out, uint32_t num_slots, uint32_t n_instr) {
-    if (tuning().stage_kib) return cached_plan_for_budget(log_lifted, n_out, num_slots, tuning().stage_kib);
-    const CachedPlan small = cached_plan_for_budget(log_lifted, n_out, num_slots, 36);
-    if (n_instr < R0_LONG_PROGRAM || log_lifted < 18) return small;
-    const CachedPlan large = cached_plan_for_budget(log_lifted, n_out, num_slots, R0_LONG_PROGRAM_KIB);
-    return large.rows > small.rows ? large : small;
 }
 
 uint32_t round0_cached_grid(const DevCached &prog, uint32_t log_lifted) {
@@ -860,7 +881,7 @@ uint32_t round0_cached_grid(const DevCached &prog, uint32_t log_lifted) {
     uint64_t lanes = (1ull << log_lifted) / prog.rows;
     if (lanes < RED_THREADS) lanes = RED_THREADS;
     // as many workgroups as are resident at once (LDS-bound), and every lane the same number of passes
-    const uint32_t resident = 256u * (uint32_t)std::max<size_t>(1, std::min<size_t>(8, (160u << 10) / (lds_bytes + (5u << 10))));
+    const uint32_t resident = 256u * (uint32_t)std::max<size_t>(1, std::min<size_t>(8, (160u << 10) / std::max<size_t>(lds_bytes, 4096)));
     const uint32_t needed = (uint32_t)((lanes + RED_THREADS - 1) / RED_THREADS);
     const uint32_t passes = (needed + resident - 1) / resident;
     return (needed + passes - 1) / passes;
@@ -927,6 +948,7 @@ int round0_eval_batched(const R0Job *d_jobs, const R0Job *h_jobs, uint32_t n_job
         grid += job.gx;
         lds_bytes = std::max(lds_bytes, (size_t)job.lds_rows * rows * RED_THREADS * 4);
     }
+    lds_bytes = std::max(lds_bytes, sizeof(EF) * RED_THREADS);  // (the image doubles as the reduction's scratch)
 #define LAUNCH(R, NOUT)                                                                                                 \
     OVM_LAUNCH((round0_cached_batched_kernel<R, NOUT>), dim3(grid), dim3(RED_THREADS), lds_bytes, s, d_jobs, n_jobs, \
                        l_skip, d_counters, ro)
@@ -957,7 +979,7 @@ int round0_eval(const DevProgram &prog, const DevCached &staged, const Fp *lde, 
     int rows = round0_rows(log_lifted, n_out);
     if (staged.words) {
         rows = (int)staged.rows;  // fixed when the program was staged (round0_cached_plan)
-        const size_t lds_bytes = (size_t)staged.num_rows * rows * RED_THREADS * 4;
+        const size_t lds_bytes = std::max((size_t)staged.num_rows * rows * RED_THREADS * 4, sizeof(EF) * RED_THREADS);
         {
             const uint32_t grid = whole_domains(round0_cached_grid(staged, log_lifted));
 #define LAUNCH(R, NOUT)                                                                                             \
