@@ -68,8 +68,21 @@ CLASS_KERNELS = {
 }
 
 
+def checked_digest_verdict(args, world, digest):
+    """Does the proof this run timed equal the one the GPU suite compares byte for byte with the oracle
+    (tests/test_gpu_parity_at_scale.py::test_config_d_full_byte_identical pins its sha256 in
+    tests/golden/config_d_proof_sha256.txt)? true / false for the headline workload in its plain form with the seeded
+    trace; null for any other workload (no checked digest exists for it)."""
+    headline = (world == 1 and not args.partitioned and not args.zero_trace and args.num_airs == 1 and
+                (args.log_rows, args.cols, args.log_stacked_height, args.log_blowup) == (22, 100, 24, 1))
+    path = os.path.join(ROOT, "tests", "golden", "config_d_proof_sha256.txt")
+    if not headline or not os.path.exists(path):
+        return None
+    return open(path).read().strip() == digest
+
+
 def load_sq_valu():
-    for rel in (("profiles", "r04", "sq_valu_r04.json"), ("profiles", "r03", "sq_valu_r03.json")):
+    for rel in (("profiles", "r05", "sq_valu_r05.json"), ("profiles", "r04", "sq_valu_r04.json"), ("profiles", "r03", "sq_valu_r03.json")):
         q = os.path.join(ROOT, *rel)
         if os.path.exists(q):
             return json.load(open(q))["kernels"], os.path.join(*rel)
@@ -526,7 +539,8 @@ def main():
             algo_bytes = 4 * rows * width + 32 * rows // rows_per_query
             achieved = algo_bytes / (avg_ms * 1e-3) / 1e9
             traffic, src = None, None
-            pmc = next((q for q in (os.path.join(ROOT, "profiles", "r04", "pmc_hbm_traffic_r04.json"),
+            pmc = next((q for q in (os.path.join(ROOT, "profiles", "r05", "pmc_hbm_traffic_r05.json"),
+                                    os.path.join(ROOT, "profiles", "r04", "pmc_hbm_traffic_r04.json"),
                                     os.path.join(ROOT, "profiles", "r03", "pmc_hbm_traffic_r03.json")) if os.path.exists(q)), "")
             if world == 1 and (log_rows, cols, args.log_stacked_height, args.log_blowup) == (22, 100, 24, 1) and os.path.exists(pmc):
                 k = json.load(open(pmc))["kernels"].get("hash_rows_kernel<1>")
@@ -586,6 +600,22 @@ def main():
             cpu = {"value": round((cols << lr) / cdt, 1), "unit": "cells/s", "cores": os.cpu_count(), "kind": "port",
                    "sample": f"C++ oracle (OpenMP restatement, not the reference's Rust backend: no cargo here), one prove of "
                              f"2^{lr} x {cols} BenchmarkAir, app params with log_stacked_height {small}, {cdt:.1f} s"}
+            # The bounded sample understates even the port (fixed costs: the oracle proves the FULL 2^22 x 100 workload at
+            # about twice this rate). The full-size figure is measured once per round by the always-on byte-parity test of
+            # config D (tests/test_gpu_parity_at_scale.py writes gpurun_out/cpu_baseline_full_size.json) and committed.
+            # A box with cargo replaces both by the reference itself: tools/run_on_cargo_box.sh times
+            # BabyBearPoseidon2CpuEngine on this workload (kind "reference").
+            ref = os.path.join(ROOT, "profiles", "cargo_box", "cpu_baseline_reference.json")
+            if os.path.exists(ref):  # (tools/run_on_cargo_box.sh step 4: the reference's CPU engine on this very workload)
+                cpu["reference"] = dict(json.load(open(ref)), source="profiles/cargo_box/cpu_baseline_reference.json")
+            for rel in (("gpurun_out", "cpu_baseline_full_size.json"), ("profiles", "r05", "cpu_baseline_full_size.json")):
+                q = os.path.join(ROOT, *rel)
+                if os.path.exists(q):
+                    full = json.load(open(q))
+                    cpu["full_size"] = {"value": full["cells_per_s"], "unit": "cells/s", "seconds": full["seconds"],
+                                        "cores": full.get("cores"), "workload": full["workload"],
+                                        "source": os.path.join(*rel) + " (the oracle's prove inside test_config_d_full_byte_identical)"}
+                    break
         # ~60 algorithmic HBM bytes per trace cell end to end for this configuration
         # (6 trace passes + codeword write/read at blowup 2 + the 2^27-leaf fraction tree)
         e2e_gbs = 60.0 * world * cells / (elapsed / args.steps) / 1e9
@@ -611,7 +641,9 @@ def main():
                                    + ("all-zero trace" if args.zero_trace else "seeded random boolean trace")
                                    + ("" if world == 1 else "; per AIR: 100 columns as a cached-main commitment (committed inside the "
                                       "timed region) + a 1-column common main (not counted in cells)"),
-                       "proof_bytes": len(proof), "proof_sha256": hashlib.sha256(proof).hexdigest(), "parallelism": par,
+                       "proof_bytes": len(proof), "proof_sha256": hashlib.sha256(proof).hexdigest(),
+                       "proof_matches_checked_digest": checked_digest_verdict(args, world, hashlib.sha256(proof).hexdigest()),
+                       "parallelism": par,
                        "host_affinity": host_affinity, "host_placement": placement_rec,
                        "form": ("partitioned (cached-main commitment inside the step + 1-column common main)"
                                 if (world > 1 or (args.partitioned and step_partitioned is not None)) else "plain (one common-main commitment)")},

@@ -50,12 +50,7 @@ struct RedOut {
     EF *out;            // device-visible address of the K results (host-mapped)
     uint32_t *flag;     // device-visible address of the completion flag (host-mapped), may be null
     uint32_t seq;       // value stored to *flag once out[] is visible to the host
-    // 64-bit accumulators (device, zero before the launch, reset by the last workgroup), or null. Non-null = the
-    // "atomic finish" of a LARGE grid: every workgroup adds the Montgomery words of its K totals into acc[4K] with
-    // device-scope atomics instead of storing a record; the last workgroup reduces the sums mod P into out[].
-    unsigned long long *acc;
 };
-static constexpr unsigned RED_ATOMIC_MAX_K = 16;
 
 // ---- stores another agent waits for, without a release FENCE ------------------------------------------------------
 // `__threadfence_system()` / `__threadfence()` compile to `buffer_wbl2` + `s_waitcnt` + `buffer_inv`: the wave waits for
@@ -127,7 +122,7 @@ __device__ __forceinline__ void release_to_device() {
 #else
     stores_performed();
 #endif
-}  // acc[] holds 4 * 16 words
+}
 
 static constexpr unsigned MAX_COSETS = 4;
 static constexpr unsigned RED_BLOCKS = 2048;  // grid cap of the partial-sum kernels (8 workgroups per CU)

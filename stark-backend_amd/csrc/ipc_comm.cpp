@@ -37,7 +37,9 @@ extern "C" int ovm_hip_shm_comm_abort(void *comm, int code);
 //      A call that misses it is abandoned (the thread is detached; if it ever returns, its mapping is closed), the
 //      failure is agreed by all ranks, and the communicator DEGRADES for good: this and every later bulk exchange is
 //      staged through pinned host memory and the shared-memory all-gather -- slow (a few GB/s), never stuck.
-// Test hooks: OVM_IPC_FORCE_OPEN_FAIL=1 (every open fails), OVM_IPC_FORCE_OPEN_HANG=1 (the helper never returns).
+// Test hooks (the test twin of the library only, -DOVM_TEST_HOOKS=1): OVM_IPC_FORCE_OPEN_FAIL=1 (every open fails with
+// hipErrorMapFailed; =2: with hipErrorInvalidValue, the code a stale handle or a non-hipMalloc buffer really produces),
+// OVM_IPC_FORCE_OPEN_HANG=1 (the helper never returns), OVM_IPC_NO_BOUNCE=1 (export an allocation of an unsafe size as it is).
 namespace {
 struct OpenJob {
     std::mutex m;
@@ -47,10 +49,11 @@ struct OpenJob {
     void *p = nullptr;
 };
 
-hipError_t open_with_deadline(void **out, const hipIpcMemHandle_t &handle, double timeout_s, int force /*0 none, 1 fail, 2 hang*/,
-                              bool &timed_out) {
+hipError_t open_with_deadline(void **out, const hipIpcMemHandle_t &handle, double timeout_s,
+                              int force /*0 none, 1 fail, 2 hang, 3 fail with hipErrorInvalidValue*/, bool &timed_out) {
     timed_out = false;
     if (force == 1) return hipErrorMapFailed;
+    if (force == 3) return hipErrorInvalidValue;
     int device = 0;
     (void)hipGetDevice(&device);
     auto job = std::make_shared<OpenJob>();
@@ -97,7 +100,9 @@ struct ovm_ipc_comm {
     // exchange, ~0.1 ms per 256 MB; nothing to wait out, no host staging). The deadline stays for what this rule misses.
     uint8_t *d_bounce = nullptr;
     uint64_t d_bounce_cap = 0;
-    bool no_bounce = false;  // OVM_IPC_NO_BOUNCE=1: export the caller's allocation whatever its size (the reproducer)
+    bool no_bounce = false;  // (test hook: export the caller's allocation whatever its size -- the reproducer)
+    // The size rule above was found on ROCm 7.2 and is a property of THAT runtime: re-validate it per runtime version
+    // (tools/ipc_repro.py; the opt-in raw-hang test of tests/test_gpu_shard.py).
     static bool unsafe_size(uint64_t size) { return (size >> 31) & 1; }
     static uint64_t safe_size_for(uint64_t need) {
         uint64_t cap = (need + (2u << 20) - 1) & ~uint64_t((2u << 20) - 1);
@@ -153,6 +158,10 @@ struct ovm_ipc_comm {
     };
 
     int barrier() { return ovm_hip_shm_allgather(shm, nullptr, nullptr, 0); }
+    // The ranks disagree on the size of the exchange: a caller bug, reported as such -- with a code of its own, because
+    // hipErrorInvalidValue is also what hipIpcOpenMemHandle / hipIpcGetMemHandle / hipMemGetAddressRange return for a stale
+    // handle or a buffer that is not a hipMalloc allocation, and THOSE must degrade to host staging.
+    static constexpr int E_SIZE_MISMATCH = 0x4F564D53;  // (never a HIP error code)
 
     // every rank's send buffer, mapped into this process (own rank: the pointer itself)
     int publish_and_map(const void *d_send, uint64_t send_bytes, hipStream_t stream, std::vector<const uint8_t *> &src) {
@@ -196,7 +205,7 @@ struct ovm_ipc_comm {
         std::vector<std::string> keys(world);
         std::vector<uint32_t> to_open;
         for (uint32_t r = 0; r < world; r++) {
-            if (all[r].bytes != send_bytes) first_error = first_error ? first_error : (int)hipErrorInvalidValue;
+            if (all[r].bytes != send_bytes) first_error = first_error ? first_error : E_SIZE_MISMATCH;
             if (r == rank) {
                 src[r] = (const uint8_t *)d_send;
                 continue;
@@ -237,7 +246,17 @@ struct ovm_ipc_comm {
                         opened.emplace(keys[r], Mapping{p, exchanges, all[r].buffer_id});
                     }
                 }
-                if (int rc2 = barrier()) return rc2;
+                // (the barrier of the turn carries "somebody's open failed": the communicator degrades anyway, and every
+                // further open of a buffer that does not map could cost its rank the whole deadline again)
+                const uint32_t failed = first_error != 0 && first_error != E_SIZE_MISMATCH;
+                std::vector<uint32_t> fs(world);
+                if (int rc2 = ovm_hip_shm_allgather(shm, &failed, fs.data(), sizeof(uint32_t))) return rc2;
+                bool stop = false;
+                for (uint32_t f : fs) stop = stop || f != 0;
+                if (stop) {
+                    if (!first_error) first_error = (int)hipErrorMapFailed;
+                    break;
+                }
             }
         }
         for (uint32_t r = 0; r < world; r++) {
@@ -285,8 +304,8 @@ struct ovm_ipc_comm {
         }
         const int rc = agree(mine);
         if (rc == 0) return 0;
-        if (is_exchange_error(rc) || rc == (int)hipErrorInvalidValue) {  // (invalid value: the ranks disagree on the size -- a caller bug)
-            err = rc;
+        if (is_exchange_error(rc) || rc == E_SIZE_MISMATCH) {
+            err = rc == E_SIZE_MISMATCH ? (int)hipErrorInvalidValue : rc;
             return 2;
         }
         degraded = true;
@@ -395,9 +414,11 @@ int ovm_hip_ipc_comm_create(ovm_shm_comm_t *shm, uint32_t rank, uint32_t world, 
     c->rank = rank;
     c->world = world;
     if (const char *e = getenv("OVM_IPC_OPEN_TIMEOUT_S")) c->open_timeout_s = std::max(0.05, atof(e));
+#if defined(OVM_TEST_HOOKS)
     if (const char *e = getenv("OVM_IPC_NO_BOUNCE")) c->no_bounce = atoi(e) != 0;
-    if (const char *e = getenv("OVM_IPC_FORCE_OPEN_FAIL")) c->force_open = atoi(e) ? 1 : 0;
+    if (const char *e = getenv("OVM_IPC_FORCE_OPEN_FAIL")) c->force_open = atoi(e) == 2 ? 3 : atoi(e) ? 1 : 0;
     if (const char *e = getenv("OVM_IPC_FORCE_OPEN_HANG")) c->force_open = atoi(e) ? 2 : c->force_open;
+#endif
     *out = c;
     return 0;
 }

@@ -143,7 +143,7 @@ bool mle_lds_eligible(uint32_t max_slots, uint32_t degree);
 // workgroups per (job, group) of the batched kernel (lanes enumerate (pair, point))
 uint32_t mle_round_batched_gx(uint32_t log_h, uint32_t degree, uint32_t n_groups);
 // workgroups along y that mle_round_eval_grouped uses for 2^(log_h-1) pairs and this many groups
-uint32_t mle_round_gx(uint32_t log_h, uint32_t degree, uint32_t n_groups, bool points_in_lane = false);
+uint32_t mle_round_gx(uint32_t log_h, uint32_t degree, uint32_t n_groups);
 
 // out[c * h/2 + y] = in[c*h + 2y] + r * (in[c*h + 2y + 1] - in[c*h + 2y])
 int fold_mle(const EF *in, EF *out, uint32_t n_cols, uint32_t log_h, EF r, hipStream_t s);
@@ -219,30 +219,17 @@ int gkr_eval_leaves(const DevProgram &prog, const DevStaged &staged, const EF *d
                     const uint64_t *d_leaf_base, const uint32_t *d_leaf_log_len, Fp norm, FracPlanes leaves,
                     hipStream_t s);
 int gkr_build_layer(FracPlanes child, FracPlanes parent, uint64_t n_parent, bool child_p_base, hipStream_t s);
-// two levels in one pass (parents and grandparents of `child`); edge_*: the parents without a sibling in the range
 // three levels in one pass; pair_*: grandparents without a sibling in the range (with their two parents), lone_*: parents without one
 int gkr_build_three_layers(FracPlanes child, FracPlanes parent, FracPlanes grand, FracPlanes great, uint64_t n_great,
                            const FracPlanes *pair_child, const FracPlanes *pair_parent, const FracPlanes *pair_grand, uint32_t n_pair,
                            const FracPlanes *lone_child, const FracPlanes *lone_parent, uint32_t n_lone, bool child_p_base,
                            hipStream_t s);
-int gkr_build_two_layers(FracPlanes child, FracPlanes parent, FracPlanes grand, uint64_t n_grand, const FracPlanes *edge_child,
-                         const FracPlanes *edge_parent, uint32_t n_edges, bool child_p_base, hipStream_t s);
 // out[X-1] = sum_y eq[y] * (p0 q1 + p1 q0 + lambda q0 q1)(X, y), X = 1..n_points (2 or 3; eq: n_pairs weights)
 int gkr_round(FracPlanes rec, bool p_base, EqSplit eq, uint64_t n_pairs, EF lambda, uint32_t n_points,
               const RedOut &ro, hipStream_t s);
 // fold the previous round with r and return the NEXT round's sums over the n_pairs folded pairs
 int gkr_fold_round(FracPlanes in, bool in_p_base, EqSplit eq, FracPlanes out, uint64_t n_pairs, EF r, EF lambda,
                    uint32_t n_points, const RedOut &ro, hipStream_t s);
-
-// One pass of a layer's sumcheck (stages.hip "two sub-rounds per pass"): table(s) = the `folds`-fold (0, 1, 2; challenges
-// r1 then r2) of the source table `in`, written to `out` when folds > 0; sums of sub-round s at X = 1..n_points into the first
-// n_points results; `lookahead` (n_points = 2 only): six more results = sub-round s+1's sums at (r, X) = (0,1) (0,2) (1,1)
-// (1,2) (2,1) (2,2) for its challenge r still to come. eq_s / eq_n: the weights of sub-round s / s+1 (eq_n, xi_next used with
-// lookahead only; xi_next = the point's entry that separates the two). want0 / want1: pairs (relative to the first, ~0 = none)
-// whose two records are also stored to dump[0..8) / dump[8..16) (host-mapped).
-int gkr_pass(FracPlanes in, bool in_p_base, int folds, EqSplit eq_s, EqSplit eq_n, FracPlanes out, uint64_t n_pairs, EF r1, EF r2,
-             EF lambda, uint32_t n_points, bool lookahead, EF xi_next, uint64_t want0, uint64_t want1, EF *dump, const RedOut &ro,
-             hipStream_t s);
 
 // ---- stacked reduction ----
 // R[v * N + z] for v in {eq, rot1, rot2} over one window of `n_slices` contiguous slices of

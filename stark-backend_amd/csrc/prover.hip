@@ -298,7 +298,7 @@ struct Mailbox : ThreadResource {
         if (slot + 64 > SLOTS) throw OvmFail((int)hipErrorInvalidValue, "mailbox: slot out of range");
         ++seq;
         bumps_at_arm = pinned_stage().bumps;
-        return RedOut{partials, d_counter, d->data + slot, &d->flag, seq, (unsigned long long *)(d_counter + 16)};
+        return RedOut{partials, d_counter, d->data + slot, &d->flag, seq};
     }
     // device address of result slot `slot` (for kernels that finish several reductions, see mle_round_eval_batched)
     EF *slot_ptr(size_t slot) const {
@@ -811,7 +811,7 @@ struct Prover {
         } else {
             commit_common_sharded(pcs, common_root);
             exchange_trace_meta();
-            if (tuning().test_fail_rank == (int)sh.rank)  // (tests: a rank that dies in the middle of a joint proof)
+            if (TEST_HOOKS && tuning().test_fail_rank == (int)sh.rank)  // (test twin: a rank that dies in the middle of a joint proof)
                 throw OvmFail((int)hipErrorOutOfMemory, "test hook OVM_TEST_FAIL_RANK: simulated failure after the commitment");
         }
         wt.mark("commit");
@@ -968,14 +968,20 @@ using namespace ovm;
 static thread_local std::string g_last_error;
 
 bool ovm::Tuning::live() {
+#if defined(OVM_TEST_HOOKS)
     static const bool on = [] {
         const char *e = getenv("OVM_TUNING_LIVE");
         return e && *e && *e != '0';
     }();
     return on;
+#else
+    return false;
+#endif
 }
 Tuning ovm::Tuning::from_env() {
     Tuning t;
+    t.trace = getenv("OVM_TRACE") != nullptr;
+#if defined(OVM_TEST_HOOKS)
     auto num = [](const char *name, int dflt) {
         const char *e = getenv(name);
         return e && *e ? atoi(e) : dflt;
@@ -988,7 +994,6 @@ Tuning ovm::Tuning::from_env() {
     t.stage_rows = num("OVM_STAGE_ROWS", 0);
     t.acc_rows = num("OVM_ACC_ROWS", 0);
     t.stage_kib = (uint32_t)std::max(0, num("OVM_STAGE_KIB", 0));
-    t.mle_points_in_lane = !off("OVM_MLE_POINTS");
     t.r0_batch = !off("OVM_R0_BATCH");
     t.mle_lds_slots = !off("OVM_MLE_LDS");
     t.mle_forward = !off("OVM_MLE_FWD");
@@ -998,23 +1003,16 @@ Tuning ovm::Tuning::from_env() {
     t.gkr_three_points = getenv("OVM_GKR_THREE_POINTS") != nullptr;
     t.merkle_coop = !off("OVM_MERKLE_COOP");
     t.finish_inline_max = (uint32_t)std::max(1, num("OVM_FINISH_INLINE_MAX", 64));
-    t.finish_atomic_max = (uint32_t)std::max(0, num("OVM_FINISH_ATOMIC_MAX", 0));
     t.download_kernel = !off("OVM_DOWNLOAD_KERNEL");
     t.early_lde = !off("OVM_EARLY_LDE");
     t.gkr_split_eq = !off("OVM_GKR_SPLIT_EQ");
-    t.gkr_build_fused = num("OVM_GKR_BUILD_FUSED", 3);
-    if (t.gkr_build_fused == 1) t.gkr_build_fused = 0;
-    t.gkr_lookahead = num("OVM_GKR_LOOKAHEAD", 0) != 0;
-    t.gkr_la_max_log = (uint32_t)std::max(0, num("OVM_GKR_LA_MAX_LOG", 17));
-    t.gkr_la_min_log = (uint32_t)std::max(0, num("OVM_GKR_LA_MIN_LOG", 0));
     t.gkr_split_min_round = (uint32_t)std::max(3, num("OVM_GKR_SPLIT_MIN", 14));
-    t.staged_forward = !off("OVM_STAGED_FWD");
     t.stacked_tail_device = std::max(0, std::min(2, num("OVM_STACKED_TAIL_DEVICE", 1)));
     t.mle_batch_lds_min_log = (uint32_t)std::max(0, num("OVM_MLE_BATCH_LDS_MIN_LOG", 9));
     t.lazy_w_accumulate = !off("OVM_LAZY_W");
     t.early_lde_lds_kib = (uint32_t)std::max(0, num("OVM_EARLY_LDE_LDS_KIB", 64));
-    t.trace = getenv("OVM_TRACE") != nullptr;
     t.test_fail_rank = num("OVM_TEST_FAIL_RANK", -1);
+#endif
     return t;
 }
 

@@ -57,36 +57,6 @@ __device__ void block_sum_store(EF (&v)[K], EF *out, bool fence = true) {
     __syncthreads();
 }
 
-// The atomic finish of a large grid (RedOut::acc): the workgroup's K totals are added, word by word, into 64-bit
-// accumulators with device-scope atomics. A sum of up to 2^20 words < 2^31 fits 64 bits with room to spare, and
-// (sum of Montgomery words) mod P is the Montgomery word of the field sum. The atomics RETURN their old value and the
-// value is consumed: the wave's wait for it is what guarantees the addition has been performed before this workgroup
-// bumps the counter (a non-returning atomic and the counter's atomic go to different channels and may pass each other:
-// tools/ubench_finish.hip showed wrong sums at 2048 workgroups exactly then). No release fence, no records, no second
-// launch: measured 10-16 us faster per reduction than records + sum_partials for kernels with real work
-// (profiles/r03/ubench_finish.json); with K <= 16 only -- round 0's 32..96 values per workgroup would serialise.
-template <int K>
-__device__ void block_sum_atomic(EF (&v)[K], const RedOut &ro, uint32_t k_off) {
-    __shared__ EF sh_a[(RED_THREADS / 64) * K];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-    for (int k = 0; k < K; k++) {
-        EF s = wave_sum(v[k]);
-        if (lane == 0) sh_a[wave * K + k] = s;
-    }
-    __syncthreads();
-    if (threadIdx.x < 4 * K) {
-        const int k = threadIdx.x >> 2, c = threadIdx.x & 3;
-        uint32_t w = sh_a[k].c[c].v;
-        unsigned long long sum = w;
-        for (int wv = 1; wv < (int)(blockDim.x >> 6); wv++) sum += sh_a[wv * K + k].c[c].v;
-        const unsigned long long seen =
-            __hip_atomic_fetch_add(ro.acc + 4 * (k_off + k) + c, sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (seen == ~0ull) ro.counter[15] = 1;  // (never: keeps the returned value, and with it the wait, alive)
-    }
-    __syncthreads();
-}
-
 // Make everything this thread stored visible to the host, then raise the mailbox flag.
 __device__ __forceinline__ void publish(const RedOut &ro) {
     if (ro.flag) {
@@ -104,7 +74,7 @@ __device__ __forceinline__ void publish(const RedOut &ro) {
 template <int KMAX>
 __device__ void finish_reduction(const RedOut &ro, uint32_t n_records, uint32_t K) {
     if (ro.counter == nullptr) return;  // large grid: sum_partials finishes (see red_finish)
-    if (gridDim.x * gridDim.y * gridDim.z == 1 && ro.acc == nullptr) {  // block_sum_out wrote the totals themselves
+    if (gridDim.x * gridDim.y * gridDim.z == 1) {  // block_sum_out wrote the totals themselves
         if (threadIdx.x == 0) publish(ro);
         return;
     }
@@ -115,19 +85,6 @@ __device__ void finish_reduction(const RedOut &ro, uint32_t n_records, uint32_t 
     }
     __syncthreads();
     if (!s_last) return;
-    if (ro.acc) {  // atomic finish: the sums are complete (every workgroup's atomics were performed before its counter bump)
-        if (threadIdx.x < 4 * K) {
-            const unsigned long long sum = __hip_atomic_exchange(ro.acc + threadIdx.x, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            st_word_sys((uint32_t *)ro.out + threadIdx.x, (uint32_t)(sum % bb::P));
-        }
-        release_to_host();
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            __hip_atomic_store(ro.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            publish(ro);
-        }
-        return;
-    }
     acquire_from_device();
     EF acc[KMAX];
 #pragma unroll
@@ -173,39 +130,26 @@ int sum_partials(const RedOut &ro, uint32_t n_blocks, uint32_t K, hipStream_t s)
 // (Round 2 tried storing the records through to memory instead -- agent-scope atomic stores + s_waitcnt, no
 // release fence -- with the in-kernel finish for every grid: correct, 159 tests green, and no faster:
 // 78.1 vs 77.3-78.1 ms per proof; the last workgroup's pass over 2048 records costs what the launch did.)
-// Round 3 built a third way to finish a large grid: 64-bit atomic accumulators (block_sum_atomic), no records and no second
-// launch. In isolation it wins (tools/ubench_finish.hip: launch-to-flag 80 vs 96 us for 2048 workgroups of real work, 11 vs
-// 23 us for 256 empty ones); inside the prover it does not: gkr.layer_sumchecks 10.19 ms with the second launch, 10.21 /
-// 10.70 / 10.53 ms with the atomic finish for grids up to 256 / 512 / 2048 workgroups, the other sumcheck stages likewise
-// (profiles/r03/finish_atomic_sweep.json) -- a workgroup of a streaming kernel waits for its stores to drain before its
-// atomics return, which the fire-and-forget record store never did. It stays behind OVM_FINISH_ATOMIC_MAX (default 0 = off)
-// with a parity test.
-static inline bool red_atomic(const RedOut &ro, uint32_t total_blocks, uint32_t K) {
-    return total_blocks > tuning().finish_inline_max && total_blocks <= tuning().finish_atomic_max && K <= RED_ATOMIC_MAX_K &&
-           ro.acc != nullptr;
-}
+// (Round 3 built a third way, 64-bit atomic accumulators instead of records: faster in isolation, not in the prover --
+// profiles/r03/finish_atomic_sweep.json, ubench_finish.json -- and removed in round 5.)
 static inline RedOut red_inline(const RedOut &ro, uint32_t total_blocks, uint32_t K) {
     RedOut r = ro;
-    if (red_atomic(ro, total_blocks, K)) return r;
-    r.acc = nullptr;
     if (total_blocks > tuning().finish_inline_max) r.counter = nullptr;
     return r;
 }
 static inline int red_finish(const RedOut &ro, uint32_t total_blocks, uint32_t n_records, uint32_t K, hipStream_t s) {
-    if (red_atomic(ro, total_blocks, K)) return 0;
     if (total_blocks > tuning().finish_inline_max) return sum_partials(ro, n_records, K, s);
     return 0;
 }
 __device__ __forceinline__ bool solo_workgroup(const RedOut &ro) {
-    return gridDim.x * gridDim.y * gridDim.z == 1 && ro.counter != nullptr && ro.acc == nullptr;
+    return gridDim.x * gridDim.y * gridDim.z == 1 && ro.counter != nullptr;
 }
-// a workgroup's K totals: into the accumulators (atomic finish) or as its record
+// a workgroup's K totals as its record
 template <int K>
-__device__ __forceinline__ void block_sum_out(EF (&v)[K], const RedOut &ro, size_t record_off, uint32_t k_off = 0) {
+__device__ __forceinline__ void block_sum_out(EF (&v)[K], const RedOut &ro, size_t record_off) {
     // (a launch of ONE workgroup -- most sub-rounds of the small GKR layers, the tails of every sumcheck -- has no
     // records to combine: its totals go straight to the mailbox, and finish_reduction only raises the flag)
-    if (ro.acc) block_sum_atomic<K>(v, ro, k_off);
-    else if (solo_workgroup(ro)) block_sum_store<K, true>(v, ro.out + record_off);
+    if (solo_workgroup(ro)) block_sum_store<K, true>(v, ro.out + record_off);
     else block_sum_store<K>(v, ro.partials + record_off, ro.counter != nullptr);
 }
 
@@ -1100,30 +1044,6 @@ struct MleFetch {
     }
 };
 
-template <int NS>
-__global__ __launch_bounds__(RED_THREADS) void mle_round_grouped_kernel(const Instr *code, const uint32_t *off,
-                                                                        const EF *weights, const EF *mats,
-                                                                        uint32_t log_h, uint32_t n_out, const EF *eq,
-                                                                        EF add_const, RedOut ro) {
-    const uint64_t n_y = 1ull << (log_h - 1);
-    const uint64_t stride = (uint64_t)gridDim.x * RED_THREADS;
-    const uint32_t xi = blockIdx.y + 1, grp = blockIdx.z, K = 2 * gridDim.y;
-    const Instr *gcode = code + off[grp];
-    const uint32_t n_instr = off[grp + 1] - off[grp];
-    EF sums[2] = {EF::zero(), EF::zero()};
-    EF slots[NS];
-    for (uint64_t y = (uint64_t)blockIdx.x * RED_THREADS + threadIdx.x; y < n_y; y += stride) {
-        EF e = ld_ef(eq + y);
-        MleFetch fetch{mats, log_h, y, Fp::from_canonical(xi)};
-        EF out[2] = {EF::zero(), grp == 0 ? add_const : EF::zero()};
-        run_program_acc<EF>(gcode, n_instr, weights, slots, fetch, out);
-        sums[0] = sums[0] + e * out[0];
-        if (n_out > 1) sums[1] = sums[1] + e * out[1];
-    }
-    block_sum_out<2>(sums, ro, ((size_t)(blockIdx.x * gridDim.z + grp)) * K + 2 * blockIdx.y, 2 * blockIdx.y);
-    finish_reduction<8>(ro, gridDim.x * gridDim.z, K);
-}
-
 // ---- the same rounds with all D evaluation points in one lane ----------------------------------
 // A lane owns one pair y and evaluates the program at X = 1..D together: one instruction decode and
 // ONE fetch of the pair (t0, t1) per column operand serve all points -- the values at X = 1, 2, ...
@@ -1378,13 +1298,10 @@ __global__ __launch_bounds__(RED_THREADS) void mle_round_points_lds_kernel(const
     finish_reduction<8>(ro, gridDim.x * gridDim.z, 2 * D);
 }
 
-// OVM_MLE_POINTS=0 selects the one-point-per-lane kernel for the large rounds too (A/B and parity tests)
-static bool mle_points_in_lane() { return tuning().mle_points_in_lane; }
-
-uint32_t mle_round_gx(uint32_t log_h, uint32_t degree, uint32_t n_groups, bool points_in_lane) {
+uint32_t mle_round_gx(uint32_t log_h, uint32_t /*degree*/, uint32_t n_groups) {
     uint32_t gx = red_grid(1ull << (log_h - 1));
     // keep the total grid near RED_BLOCKS workgroups
-    uint32_t cap = RED_BLOCKS / ((points_in_lane ? 1 : degree) * n_groups);
+    uint32_t cap = RED_BLOCKS / n_groups;
     if (cap < 1) cap = 1;
     return gx > cap ? cap : gx;
 }
@@ -1545,15 +1462,15 @@ int mle_round_eval_batched_lds(const MleJob *d_jobs, const MleJob *h_jobs, uint3
     return 0;
 }
 bool mle_lds_eligible(uint32_t max_slots, uint32_t degree) {
-    return mle_points_in_lane() && tuning().mle_lds_slots && max_slots * degree <= MLE_LDS_MAX_ROWS;
+    return tuning().mle_lds_slots && max_slots * degree <= MLE_LDS_MAX_ROWS;
 }
 
 int mle_round_eval_grouped(const Instr *d_code, const uint32_t *d_off, uint32_t n_groups, uint32_t max_slots,
                            const EF *d_weights, const EF *mats, uint32_t log_h, uint32_t degree, uint32_t n_out,
                            const EF *d_eq, EF add_const, const RedOut &ro, hipStream_t s) {
     if (degree == 0 || degree > 4 || n_out > 2 || log_h == 0 || n_groups == 0) return (int)hipErrorInvalidValue;
-    const uint32_t gx = mle_round_gx(log_h, degree, n_groups, mle_points_in_lane());
-    if (mle_points_in_lane() && tuning().mle_lds_slots && max_slots * degree <= MLE_LDS_MAX_ROWS) {
+    const uint32_t gx = mle_round_gx(log_h, degree, n_groups);
+    if (mle_lds_eligible(max_slots, degree)) {
         dim3 grid(gx, 1, n_groups);
         const size_t lds_bytes = (size_t)max_slots * degree * 4 * RED_THREADS * sizeof(uint32_t);
 #define CALLD(DD)                                                                                                        \
@@ -1568,8 +1485,8 @@ int mle_round_eval_grouped(const Instr *d_code, const uint32_t *d_off, uint32_t 
         OVM_CHECK_LAUNCH();
         return red_finish(ro, gx * n_groups, gx * n_groups, 2 * degree, s);
     }
-    if (mle_points_in_lane()) {
-        dim3 grid(gx, 1, n_groups);
+    // programs whose slots do not fit the LDS image: slots in private memory
+    dim3 grid(gx, 1, n_groups);
 #define CALLD(NS, DD)                                                                                                  \
     OVM_LAUNCH((mle_round_points_kernel<NS, DD>), grid, dim3(RED_THREADS), 0, s, d_code, d_off, d_weights, mats, \
                        log_h, n_out, d_eq, add_const, red_inline(ro, gx * n_groups, 2 * degree))
@@ -1583,18 +1500,8 @@ int mle_round_eval_grouped(const Instr *d_code, const uint32_t *d_off, uint32_t 
         DISPATCH_SLOTS(max_slots, CALL);
 #undef CALL
 #undef CALLD
-        OVM_CHECK_LAUNCH();
-        return red_finish(ro, gx * n_groups, gx * n_groups, 2 * degree, s);
-    }
-    dim3 grid(gx, degree, n_groups);
-#define CALL(NS)                                                                                               \
-    OVM_LAUNCH(mle_round_grouped_kernel<NS>, grid, dim3(RED_THREADS), 0, s, d_code, d_off, d_weights, mats, \
-                       log_h, n_out, d_eq, add_const, red_inline(ro, gx * degree * n_groups, 2 * degree))
-    DISPATCH_SLOTS(max_slots, CALL);
-#undef CALL
     OVM_CHECK_LAUNCH();
-    // only out[0 .. 2 * degree) is defined
-    return red_finish(ro, gx * degree * n_groups, gx * n_groups, 2 * degree, s);
+    return red_finish(ro, gx * n_groups, gx * n_groups, 2 * degree, s);
 }
 
 __global__ void fold_mle_kernel(const EF *in, EF *out, uint32_t log_h, EF r_in) {
@@ -1845,41 +1752,10 @@ __global__ void gkr_build_kernel(FracPlanes child, FracPlanes parent, uint64_t n
 // (the build runs at the HBM ceiling: 5.6-5.7 TB/s). The same three products per fraction sum as gkr_build_kernel, so every
 // value is the one the one-level passes compute. Lanes n_grand and n_grand + 1 take the (at most two) parents of the range
 // that have no sibling inside it: edge e = parent edge_parent[e] from the two children at edge_child[e].
-template <bool PBASE>
-__global__ void gkr_build2_kernel(FracPlanes child, FracPlanes parent, FracPlanes grand, uint64_t n_grand, FracPlanes edge_child0,
-                                  FracPlanes edge_parent0, FracPlanes edge_child1, FracPlanes edge_parent1, uint32_t n_edges) {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_grand) {
-        const uint64_t e = i - n_grand;
-        if (e >= n_edges) return;
-        const FracPlanes c = e ? edge_child1 : edge_child0, p = e ? edge_parent1 : edge_parent0;
-        EF p0, p1, q0, q1;
-        if (PBASE)
-            ldp2_base(c.P(), 0, p0, p1);
-        else
-            ldp2(c.P(), c.stride, 0, p0, p1);
-        ldp2(c.Q(), c.stride, 0, q0, q1);
-        stp(p.P(), p.stride, 0, p0 * q1 + q0 * p1);
-        stp(p.Q(), p.stride, 0, q0 * q1);
-        return;
-    }
-    EF cp[4], cq[4];
-    if (PBASE)
-        ldp4_base(child.P(), 4 * i, cp);
-    else
-        ldp4(child.P(), child.stride, 4 * i, cp);
-    ldp4(child.Q(), child.stride, 4 * i, cq);
-    const EF pp0 = cp[0] * cq[1] + cq[0] * cp[1], pq0 = cq[0] * cq[1];
-    const EF pp1 = cp[2] * cq[3] + cq[2] * cp[3], pq1 = cq[2] * cq[3];
-    stp2(parent.P(), parent.stride, 2 * i, pp0, pp1);
-    stp2(parent.Q(), parent.stride, 2 * i, pq0, pq1);
-    stp(grand.P(), grand.stride, i, pp0 * pq1 + pq0 * pp1);
-    stp(grand.Q(), grand.stride, i, pq0 * pq1);
-}
 // Three levels per pass: 1.875 n of traffic per three levels instead of 3 x 1.125 n. Lane i: children 8i..8i+7 -> parents
 // 4i..4i+3, grandparents 2i, 2i+1, great-grandparent i. What the range holds outside those aligned blocks goes to extra lanes
 // of the same launch: at most two grandparents whose sibling is outside the range (each with its two parents, from four
-// children: the two-level form) and at most two lone parents (from two children).
+// children) and at most two lone parents (from two children).
 struct BuildEdges {
     FracPlanes pair_child[2], pair_parent[2], pair_grand[2];
     FracPlanes lone_child[2], lone_parent[2];
@@ -1957,20 +1833,6 @@ int gkr_build_three_layers(FracPlanes child, FracPlanes parent, FracPlanes grand
         OVM_LAUNCH(gkr_build3_kernel<true>, grid, dim3(256), 0, s, child, parent, grand, great, n_great, e);
     else
         OVM_LAUNCH(gkr_build3_kernel<false>, grid, dim3(256), 0, s, child, parent, grand, great, n_great, e);
-    OVM_CHECK_LAUNCH();
-    return 0;
-}
-int gkr_build_two_layers(FracPlanes child, FracPlanes parent, FracPlanes grand, uint64_t n_grand, const FracPlanes *edge_child,
-                         const FracPlanes *edge_parent, uint32_t n_edges, bool child_p_base, hipStream_t s) {
-    if (n_edges > 2 || n_grand + n_edges == 0) return (int)hipErrorInvalidValue;
-    const FracPlanes none{nullptr, 0, 0};
-    const FracPlanes c0 = n_edges > 0 ? edge_child[0] : none, p0 = n_edges > 0 ? edge_parent[0] : none;
-    const FracPlanes c1 = n_edges > 1 ? edge_child[1] : none, p1 = n_edges > 1 ? edge_parent[1] : none;
-    const dim3 grid(ceil_div(n_grand + n_edges, 256));
-    if (child_p_base)
-        OVM_LAUNCH(gkr_build2_kernel<true>, grid, dim3(256), 0, s, child, parent, grand, n_grand, c0, p0, c1, p1, n_edges);
-    else
-        OVM_LAUNCH(gkr_build2_kernel<false>, grid, dim3(256), 0, s, child, parent, grand, n_grand, c0, p0, c1, p1, n_edges);
     OVM_CHECK_LAUNCH();
     return 0;
 }
@@ -2171,8 +2033,7 @@ __device__ __forceinline__ void fold_fracs(const EF (&f)[N], EF (&g)[N / 2], con
     }
 }
 // folds = 0: a record is the two fractions there; 1: the fold by r1 of two records (four fractions); 2: the fold by r2 of
-// two such folds (eight fractions) -- the table the record belongs to was never written (a sub-round served from the
-// lookahead of the pass before it, see gkr_pass_kernel).
+// two such folds (eight fractions).
 __global__ void gkr_edge_kernel(FracPlanes src, uint64_t at0, uint64_t at1, uint32_t n0, uint32_t n1, int p_base, int folds, EF r1_in,
                                 EF r2_in, RedOut ro) {
     const uint32_t k = threadIdx.x;
@@ -2348,155 +2209,6 @@ int gkr_fold_round(FracPlanes in, bool in_p_base, EqSplit eq, FracPlanes out, ui
 #undef CALL
     OVM_CHECK_LAUNCH();
     return red_finish(ro, grid, grid, n_points, s);
-}
-
-// ---- two sub-rounds per pass ----------------------------------------------------------------------------------------
-// A layer's sumcheck used to make one pass over its table per sub-round: read table(s-1), fold it by r_{s-1} into
-// table(s), sum S_s over the pairs of table(s) -- 4 n records of traffic for a layer of n records and one host round
-// trip per sub-round (189 of them at config D). But S_{s+1} needs nothing the pass at s does not already
-// hold except the challenge r_s, and it is a QUADRATIC in r_s: table(s+1)[j] = T[2j] + r_s (T[2j+1] - T[2j]) is linear
-// in r_s, the pair expression p0 q1 + p1 q0 + lambda q0 q1 bilinear in its records. So the pass at s also sums
-// S_{s+1}(X; r) at r = 0, 1, 2 for X = 1, 2 (LA = "lookahead": six more sums per lane), the host interpolates at the
-// r_s it samples, and sub-round s+1 costs NO pass and NO launch; the pass at s+2 then folds table(s) TWICE (FOLDS = 2:
-// r_s, r_{s+1}) -- table(s+1) is never written. Traffic per layer 2.67 n instead of 4 n, half the round trips. Every
-// identity is exact in the field: the proof bytes do not change (fractional_sumcheck_gkr.rs:121-196 is the protocol;
-// how many of its rounds one sweep over the data serves is this backend's business).
-//
-// Work item of the LA form: pair z of table(s+1) = pairs 2z, 2z+1 of table(s); a pair range that starts or ends on an
-// odd pair leaves one stray pair at either end, which lanes 0 / 1 of the grid take in the plain form. `want`: up to two
-// pairs (relative to the first) whose two records the host will need as the SOURCES of sub-round s+1's unpaired edge
-// records; the lane that makes them stores them to `dump`.
-template <bool PBASE, int FOLDS>
-__device__ __forceinline__ void gkr_load_pair(const FracPlanes &in, uint64_t p, const EF::Pre &r1, const EF::Pre &r2, EF (&fp)[4],
-                                              EF (&fq)[4]) {
-    constexpr int N = 4 << FOLDS;
-    const uint64_t at = (uint64_t)N * p;
-#pragma unroll
-    for (int isq = 0; isq < 2; isq++) {
-        EF f[N];
-        EF(&dst)[4] = isq ? fq : fp;
-#pragma unroll
-        for (int c = 0; c < N / 4; c++) {
-            EF t[4];
-            if (!isq && PBASE)
-                ldp4_base(in.P(), at + 4 * c, t);
-            else
-                ldp4(isq ? in.Q() : in.P(), in.stride, at + 4 * c, t);
-#pragma unroll
-            for (int i = 0; i < 4; i++) f[4 * c + i] = t[i];
-        }
-        if constexpr (FOLDS == 0) {
-#pragma unroll
-            for (int i = 0; i < 4; i++) dst[i] = f[i];
-        } else if constexpr (FOLDS == 1) {
-            fold_fracs<8>(f, dst, r1);
-        } else {
-            EF g[8];
-            fold_fracs<16>(f, g, r1);
-            fold_fracs<8>(g, dst, r2);
-        }
-    }
-}
-template <bool PBASE, int FOLDS, int NP>
-__device__ __forceinline__ void gkr_do_pair(const FracPlanes &in, const FracPlanes &out, uint64_t p, const EF::Pre &r1, const EF::Pre &r2,
-                                            const EF::Pre &lambda, const EF &e, EF (&a)[4], EF (&b)[4], EF *sums, uint64_t want0,
-                                            uint64_t want1, EF *dump) {
-    EF fp[4], fq[4];
-    gkr_load_pair<PBASE, FOLDS>(in, p, r1, r2, fp, fq);
-    if constexpr (FOLDS > 0) {
-        stp4(out.P(), out.stride, 4 * p, fp);
-        stp4(out.Q(), out.stride, 4 * p, fq);
-    }
-    a[0] = fp[0], a[1] = fq[0], a[2] = fp[1], a[3] = fq[1];
-    b[0] = fp[2], b[1] = fq[2], b[2] = fp[3], b[3] = fq[3];
-    if (p == want0 || p == want1) {
-        EF *d = dump + (p == want0 ? 0 : 8);
-#pragma unroll
-        for (int i = 0; i < 4; i++) st_ef_sys(d + i, a[i]), st_ef_sys(d + 4 + i, b[i]);
-        release_to_host();
-    }
-    EF t[4] = {a[0], a[1], a[2], a[3]}, s2[NP];
-#pragma unroll
-    for (int i = 0; i < NP; i++) s2[i] = EF::zero();
-    gkr_pair_sums<NP>(t, b, e, lambda, s2);
-#pragma unroll
-    for (int i = 0; i < NP; i++) sums[i] = sums[i] + s2[i];
-}
-template <bool PBASE, int FOLDS, int NP, bool LA>
-__global__ __launch_bounds__(RED_THREADS) void gkr_pass_kernel(FracPlanes in, EqSplit eq_s, EqSplit eq_n, FracPlanes out, uint64_t n_pairs,
-                                                               EF r1_in, EF r2_in, EF lambda_in, EF xi_in, uint64_t want0, uint64_t want1,
-                                                               EF *dump, RedOut ro) {
-    constexpr int K = LA ? NP + 6 : NP;
-    const uint64_t stride = (uint64_t)gridDim.x * RED_THREADS;
-    const uint64_t gid = (uint64_t)blockIdx.x * RED_THREADS + threadIdx.x;
-    const EF::Pre r1 = r1_in.pre(), r2 = r2_in.pre(), lambda = lambda_in.pre();
-    EF sums[K];
-#pragma unroll
-    for (int i = 0; i < K; i++) sums[i] = EF::zero();
-    EF a[4], b[4];
-    if constexpr (!LA) {
-        for (uint64_t y = gid; y < n_pairs; y += stride)
-            gkr_do_pair<PBASE, FOLDS, NP>(in, out, y, r1, r2, lambda, eq_weight(eq_s, y), a, b, sums, want0, want1, dump);
-    } else {
-        // global pair index of relative pair 0 = eq_s.y_first: odd -> the head pair is a stray
-        const uint64_t skip = eq_s.y_first & 1;
-        const uint64_t n_la = (n_pairs - skip) >> 1;
-        const bool tail = ((n_pairs - skip) & 1) != 0;
-        if (gid == 0 && skip) gkr_do_pair<PBASE, FOLDS, NP>(in, out, 0, r1, r2, lambda, eq_weight(eq_s, 0), a, b, sums, want0, want1, dump);
-        if (gid == 1 && tail)
-            gkr_do_pair<PBASE, FOLDS, NP>(in, out, n_pairs - 1, r1, r2, lambda, eq_weight(eq_s, n_pairs - 1), a, b, sums, want0, want1, dump);
-        const EF::Pre xi = xi_in.pre();
-        for (uint64_t z = gid; z < n_la; z += stride) {
-            const EF en = eq_weight(eq_n, z);
-            const EF e1 = en * xi, e0 = en - e1;  // eq1(xi, 1) = xi, eq1(xi, 0) = 1 - xi
-            EF a1[4], b1[4], a2[4], b2[4];
-            gkr_do_pair<PBASE, FOLDS, NP>(in, out, skip + 2 * z, r1, r2, lambda, e0, a1, b1, sums, want0, want1, dump);
-            gkr_do_pair<PBASE, FOLDS, NP>(in, out, skip + 2 * z + 1, r1, r2, lambda, e1, a2, b2, sums, want0, want1, dump);
-            // table(s+1) records 2z, 2z+1 at r = 0, 1, 2: (a1, a2), (b1, b2), (2 b1 - a1, 2 b2 - a2)
-            EF la0[2] = {EF::zero(), EF::zero()}, la1[2] = {EF::zero(), EF::zero()}, la2[2] = {EF::zero(), EF::zero()};
-            EF u[4], v[4];
-#pragma unroll
-            for (int i = 0; i < 4; i++) u[i] = b1[i].dbl() - a1[i], v[i] = b2[i].dbl() - a2[i];
-            gkr_pair_sums<2>(a1, a2, en, lambda, la0);
-            gkr_pair_sums<2>(b1, b2, en, lambda, la1);
-            gkr_pair_sums<2>(u, v, en, lambda, la2);
-            sums[NP + 0] = sums[NP + 0] + la0[0], sums[NP + 1] = sums[NP + 1] + la0[1];
-            sums[NP + 2] = sums[NP + 2] + la1[0], sums[NP + 3] = sums[NP + 3] + la1[1];
-            sums[NP + 4] = sums[NP + 4] + la2[0], sums[NP + 5] = sums[NP + 5] + la2[1];
-        }
-    }
-    block_sum_out<K>(sums, ro, (size_t)blockIdx.x * K);
-    finish_reduction<8>(ro, gridDim.x, K);
-}
-int gkr_pass(FracPlanes in, bool in_p_base, int folds, EqSplit eq_s, EqSplit eq_n, FracPlanes out, uint64_t n_pairs, EF r1, EF r2,
-             EF lambda, uint32_t n_points, bool lookahead, EF xi_next, uint64_t want0, uint64_t want1, EF *dump, const RedOut &ro,
-             hipStream_t s) {
-    if ((n_points != 2 && n_points != 3) || folds < 0 || folds > 2 || (lookahead && n_points != 2) || n_pairs == 0)
-        return (int)hipErrorInvalidValue;
-    const uint32_t K = lookahead ? n_points + 6 : n_points;
-    const uint32_t grid = red_grid(lookahead ? std::max<uint64_t>(n_pairs / 2, 2) : n_pairs);
-#define CALL(PB, F, NP, LA)                                                                                                          \
-    OVM_LAUNCH((gkr_pass_kernel<PB, F, NP, LA>), dim3(grid), dim3(RED_THREADS), 0, s, in, eq_s, eq_n, out, n_pairs, r1, r2, lambda, \
-               xi_next, want0, want1, dump, red_inline(ro, grid, K))
-#define CALL_F(PB, NP, LA)                  \
-    do {                                    \
-        if (folds == 0) CALL(PB, 0, NP, LA); \
-        else if (folds == 1) CALL(PB, 1, NP, LA); \
-        else CALL(PB, 2, NP, LA);           \
-    } while (0)
-    if (in_p_base) {
-        if (lookahead) CALL_F(true, 2, true);
-        else if (n_points == 2) CALL_F(true, 2, false);
-        else CALL_F(true, 3, false);
-    } else {
-        if (lookahead) CALL_F(false, 2, true);
-        else if (n_points == 2) CALL_F(false, 2, false);
-        else CALL_F(false, 3, false);
-    }
-#undef CALL_F
-#undef CALL
-    OVM_CHECK_LAUNCH();
-    return red_finish(ro, grid, grid, K, s);
 }
 
 // ---- stacked reduction -----------------------------------------------------------------------

@@ -24,20 +24,20 @@ def main():
     args = ap.parse_args()
     os.environ["ORC_SKIP_DEBUG_ASSERTS"] = "1"
     os.environ["OVM_TUNING_LIVE"] = "1"  # (the knobs drawn per case are re-read at every prover entry)
-    import importlib
     import airs
+    import conftest
     import oracle_lib
-    pkg = importlib.import_module("stark-backend_amd")
+    pkg = conftest.load_pkg(hooks=True)  # the TEST TWIN of the library: the product reads none of the hooks drawn below
     orc = oracle_lib.load()
     dev = pkg.Device(0)
     rng = np.random.default_rng(args.seed)
     knobs = {"OVM_R0_ROWS": ["", "1", "2", "4"], "OVM_STAGE_ROWS": ["", "2", "3", "8"], "OVM_ACC_ROWS": ["", "1", "4"],
-             "OVM_R0_BATCH": ["", "0"], "OVM_MLE_BATCH": ["", "0", "64"], "OVM_MLE_POINTS": ["", "0"],
+             "OVM_R0_BATCH": ["", "0"], "OVM_MLE_BATCH": ["", "0", "64"], "OVM_MLE_LDS": ["", "", "0"], "OVM_MLE_FWD": ["", "", "0"],
              "OVM_R0_GROUPS_MIN": ["", "2", "4"], "OVM_MLE_GROUPS_MAX": ["", "16", "32"],
              "OVM_GKR_THREE_POINTS": ["", "", "1"], "OVM_MERKLE_COOP": ["", "0"], "OVM_LAZY_W": ["", "0"],
              "OVM_EARLY_LDE": ["", "", "0"], "OVM_MLE_BATCH_LDS_MIN_LOG": ["", "1", "3", "31"],
-             "OVM_STACKED_TAIL_DEVICE": ["", "0", "2", "2"], "OVM_STAGED_FWD": ["", "", "0"], "OVM_GKR_SPLIT_MIN": ["", "3", "4", "7"],
-             "OVM_GKR_SPLIT_EQ": ["", "", "0"], "OVM_GKR_BUILD_FUSED": ["", "", "0", "2"], "OVM_GKR_LOOKAHEAD": ["", "1", "1"], "OVM_GKR_LA_MAX_LOG": ["", "4", "40"], "OVM_GKR_LA_MIN_LOG": ["", "", "5"]}
+             "OVM_STACKED_TAIL_DEVICE": ["", "0", "2", "2"], "OVM_GKR_SPLIT_MIN": ["", "3", "4", "7"],
+             "OVM_GKR_SPLIT_EQ": ["", "", "0"], "OVM_FINISH_INLINE_MAX": ["", "", "1"], "OVM_DOWNLOAD_KERNEL": ["", "", "0"]}
     bad = 0
     with_absent = 0
     for case in range(args.cases):

@@ -69,11 +69,12 @@ def test_internal_like_parameters(dev, pkg, orc):
 
 @pytest.mark.parametrize("stage,acc,rows", [(2, 1, 1), (2, 1, 4), (3, 2, 2), (4, 8, 1), (8, 3, 2), (5, 5, 4)])
 @pytest.mark.parametrize("seed", range(4))
-def test_staged_interpreter_layouts(dev, pkg, orc, monkeypatch, stage, acc, rows, seed):
-    """The round-0 staged interpreter (program.h stage_program, stages.hip StagedRound0) under forced
-    layouts: tiny staging buffers and accumulation lists (a block boundary every instruction or two),
-    1 / 2 / 4 trace rows per lane. Wider AIRs with more constraints than the cases above so that
-    programs span many blocks."""
+def test_round0_interpreter_layouts(dev_hooks, pkg_hooks, orc, monkeypatch, stage, acc, rows, seed):
+    """The cached-column round-0 interpreter (program.h stage_cached, csrc/cached_vm.cuh) under forced layouts (test twin of
+    the library): the LDS image at the program's minimum or a few rows above it, 2..8 columns brought per block (a block
+    boundary every instruction or two), 1 / 2 / 4 trace rows per lane. Wider AIRs with more constraints than the cases
+    above so that programs span many blocks."""
+    dev, pkg = dev_hooks, pkg_hooks
     monkeypatch.setenv("OVM_STAGE_ROWS", str(stage))
     monkeypatch.setenv("OVM_ACC_ROWS", str(acc))
     monkeypatch.setenv("OVM_R0_ROWS", str(rows))
@@ -94,7 +95,9 @@ def test_many_live_slots(dev, pkg, orc, monkeypatch, live):
     """Programs with many simultaneously live intermediates: `live` products are created by the first
     constraint and consumed by the second, so the register program needs that many slots. 20 fits
     the staged VM's default LDS image, 40 its last-resort 56 KiB image, 70 and 200 fall back to the plain
-    interpreter (slots in private memory, NS 128 / 512)."""
+    interpreter (slots in private memory, NS 128 / 512).
+    (Round 5: round 0's image is one pool of rows for cached columns and live values; on this short trace -- one row per
+    lane -- it may take up to 128 KiB, so 20, 40 and 70 run on the cached interpreter and 200 on the plain one.)"""
     rng = np.random.default_rng(4000 + live)
     width = 8
     a = airs.Air("ManyLiveSlots", width)
@@ -116,14 +119,15 @@ def test_many_live_slots(dev, pkg, orc, monkeypatch, live):
     _run(dev, pkg, orc, params, [air], [(0, tr, h, [])])
 
 
-@pytest.mark.parametrize("points", ["1", "0"])
+@pytest.mark.parametrize("lds", ["1", "0"])
 @pytest.mark.parametrize("seed", range(4))
-def test_unbatched_mle_round_kernels(dev, pkg, orc, monkeypatch, points, seed):
-    """The kernels of the LARGE multilinear rounds on small traces: with OVM_MLE_BATCH=0 every
-    (trace, program) job is its own launch, through the all-points-in-one-lane kernel (default) or the
-    one-point-per-lane kernel (OVM_MLE_POINTS=0). Degree-3 and degree-4 keys."""
+def test_unbatched_mle_round_kernels(dev_hooks, pkg_hooks, orc, monkeypatch, lds, seed):
+    """The kernels of the LARGE multilinear rounds on small traces: with OVM_MLE_BATCH=0 every (trace, program) job is its
+    own launch, through the LDS-slot kernel (default) or the private-memory kernel programs with many slots fall back to
+    (OVM_MLE_LDS=0). Degree-3 and degree-4 keys."""
+    dev, pkg = dev_hooks, pkg_hooks
     monkeypatch.setenv("OVM_MLE_BATCH", "0")
-    monkeypatch.setenv("OVM_MLE_POINTS", points)
+    monkeypatch.setenv("OVM_MLE_LDS", lds)
     rng = np.random.default_rng(5000 + seed)
     l_skip = int(rng.integers(2, 4))
     params = airs.test_params(l_skip=l_skip, n_stack=9, k_whir=2)
@@ -140,10 +144,11 @@ def test_unbatched_mle_round_kernels(dev, pkg, orc, monkeypatch, points, seed):
 
 
 @pytest.mark.parametrize("seed", range(6))
-def test_round0_program_groups(dev, pkg, orc, monkeypatch, seed):
+def test_round0_program_groups(dev_hooks, pkg_hooks, orc, monkeypatch, seed):
     """Round 0 with the program split into root groups that run as extra workgroups of the batched job
     (the path long programs take on short traces), forced here for every program with at least two
-    groups; also with two rows per lane and tiny staging buffers."""
+    groups; also with two rows per lane and a minimal image."""
+    dev, pkg = dev_hooks, pkg_hooks
     monkeypatch.setenv("OVM_R0_GROUPS_MIN", "2")
     if seed % 2:
         monkeypatch.setenv("OVM_R0_ROWS", "2")
@@ -162,29 +167,12 @@ def test_round0_program_groups(dev, pkg, orc, monkeypatch, seed):
     _run(dev, pkg, orc, params, air_list, traces)
 
 
-@pytest.mark.parametrize("seed", range(3))
-def test_atomic_finish_of_large_reductions(dev, pkg, orc, monkeypatch, seed):
-    """The opt-in third way to finish a reduction (stages.hip: block_sum_atomic -- 64-bit atomic accumulators instead of
-    records + a second launch), forced for every grid of more than ONE workgroup: the same proof."""
-    monkeypatch.setenv("OVM_FINISH_ATOMIC_MAX", "1000000")
-    monkeypatch.setenv("OVM_FINISH_INLINE_MAX", "1")
-    monkeypatch.setenv("OVM_MLE_BATCH", "0")
-    rng = np.random.default_rng(8100 + seed)
-    params = airs.test_params(l_skip=3, n_stack=11, k_whir=2)
-    air_list, traces = [], []
-    for i in range(2):
-        width = int(rng.integers(3, 10))
-        air_list.append(airs.random_air(rng, width, int(rng.integers(4, 20)), int(rng.integers(1, 3))))
-        h = 1 << int(rng.integers(10, 13))
-        traces.append((i, rng.integers(0, airs.P, size=width * h, dtype=np.uint64).astype(np.uint32), h, []))
-    _run(dev, pkg, orc, params, air_list, traces)
-
-
 @pytest.mark.parametrize("lazy", ["1", "0"])
-def test_whir_w_accumulate_lazy_and_reduced(dev, pkg, orc, monkeypatch, lazy):
+def test_whir_w_accumulate_lazy_and_reduced(dev_hooks, pkg_hooks, orc, monkeypatch, lazy):
     """WHIR's  w += sum_q gamma_q eq(., z_q)  with the products accumulated unreduced in 96-bit words (stages.hip:
     whir_w_accumulate_lazy_kernel, taken when the folded polynomial has >= 2^12 coefficients) and with every product
     reduced (OVM_LAZY_W=0): the same proof as the oracle's either way."""
+    dev, pkg = dev_hooks, pkg_hooks
     monkeypatch.setenv("OVM_LAZY_W", lazy)
     rng = np.random.default_rng(9200)
     params = airs.test_params(l_skip=3, n_stack=12, k_whir=2)

@@ -112,9 +112,11 @@ def test_config_c_shape_verifies(dev, pkg, orc):
     orc.verify(blob, proof)
 
 
-def test_gkr_three_point_fallback(dev, pkg, orc, monkeypatch):
+def test_gkr_three_point_fallback(dev_hooks, pkg_hooks, orc, monkeypatch):
     """The GKR sub-rounds normally take two evaluation points from the device and derive the third
-    from the running claim; the fallback for degenerate challenges must give the same bytes."""
+    from the running claim; the fallback for degenerate challenges must give the same bytes (forced through the test
+    twin of the library)."""
+    dev, pkg = dev_hooks, pkg_hooks
     monkeypatch.setenv("OVM_GKR_THREE_POINTS", "1")
     params = airs.test_params(l_skip=4, n_stack=8, k_whir=4)
     h = 1 << 8
@@ -122,14 +124,14 @@ def test_gkr_three_point_fallback(dev, pkg, orc, monkeypatch):
     run_case(dev, pkg, orc, params, [airs.uniform_runner_air(20)], [(0, tr, h, [])])
 
 
-@pytest.mark.parametrize("lookahead", ["0", "1"])
-def test_gkr_passes_with_and_without_lookahead(dev, pkg, orc, monkeypatch, lookahead):
-    """Round 4: a pass over a GKR layer's table also sums the NEXT sub-round as a quadratic in its challenge, so every
-    second sub-round is served without a launch and the pass after it folds twice (stages.hip: gkr_pass_kernel).
-    OVM_GKR_LOOKAHEAD=0 is one pass per sub-round as in rounds 1-3. Both must give the oracle's bytes -- on a tall
-    single AIR (base-field leaf numerators, split eq tables from 2^3 records), on mixed heights with a padding run that
-    starts on an odd pair, and with the three-point fallback (which turns the lookahead off by itself)."""
-    monkeypatch.setenv("OVM_GKR_LOOKAHEAD", lookahead)
+@pytest.mark.parametrize("three_points", [False, True])
+def test_gkr_layer_sumchecks_on_split_tables_and_mixed_heights(dev_hooks, pkg_hooks, orc, monkeypatch, three_points):
+    """The GKR layer sumchecks on a tall single AIR (base-field leaf numerators, split eq tables from 2^3 records on: forced
+    through the test twin), on mixed heights with a padding run that starts on an odd pair, and with the three-point
+    fallback."""
+    dev, pkg = dev_hooks, pkg_hooks
+    if three_points:
+        monkeypatch.setenv("OVM_GKR_THREE_POINTS", "1")
     monkeypatch.setenv("OVM_GKR_SPLIT_MIN", "3")
     params = airs.test_params(l_skip=4, n_stack=10, k_whir=4)
     h = 1 << 12
@@ -140,18 +142,14 @@ def test_gkr_passes_with_and_without_lookahead(dev, pkg, orc, monkeypatch, looka
     run_case(dev, pkg, orc, airs.test_params(l_skip=2, n_stack=9, k_whir=2), [airs.fibonacci_air(), bench, wide, bench],
              [(0, t1, 16, pv), (1, airs.splitmix64_bits(1, 8 * 512), 512, []), (2, airs.splitmix64_bits(2, 20 * 256), 256, []),
               (3, airs.splitmix64_bits(3, 8 * 2), 2, [])])
-    monkeypatch.setenv("OVM_GKR_THREE_POINTS", "1")
-    run_case(dev, pkg, orc, params, [airs.uniform_runner_air(24)], [(0, airs.splitmix64_bits(0xA11CE, 24 * h), h, [])])
 
 
-@pytest.mark.parametrize("fused", ["3", "2", "0"])
-def test_gkr_tree_built_three_two_or_one_levels_per_pass(dev, pkg, orc, monkeypatch, fused):
-    """Round 4: the fraction tree is built three levels per pass (stages.hip: gkr_build3_kernel -- parents and grandparents
-    written, never read back; OVM_GKR_BUILD_FUSED=2: two levels, =0: one level per pass as before). All must give the oracle's
-    bytes: a tall single AIR (base-field leaf numerators: the PBASE form; tree heights 0, 1 and 2 mod 3), mixed heights whose
-    leaf runs start and end on odd indices (parents / grandparents without a sibling in the range: the edge lanes), a tree of
-    a single interaction on a two-row trace."""
-    monkeypatch.setenv("OVM_GKR_BUILD_FUSED", fused)
+def test_gkr_tree_built_three_levels_per_pass(dev, pkg, orc):
+    """The fraction tree is built three levels per pass (stages.hip: gkr_build3_kernel -- parents and grandparents written,
+    never read back; the one or two layers left under the root one level per launch). The oracle's bytes on: a tall
+    single AIR (base-field leaf numerators: the PBASE form; tree heights 0, 1 and 2 mod 3), mixed heights whose leaf runs
+    start and end on odd indices (parents / grandparents without a sibling in the range: the edge lanes), a tree of a
+    single interaction on a two-row trace."""
     for n_stack, cols, h in ((10, 24, 1 << 12), (9, 12, 1 << 11), (8, 12, 1 << 10)):
         params = airs.test_params(l_skip=4, n_stack=n_stack, k_whir=4)
         run_case(dev, pkg, orc, params, [airs.uniform_runner_air(cols)], [(0, airs.splitmix64_bits(0xB01D + cols, cols * h), h, [])])

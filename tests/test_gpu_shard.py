@@ -25,11 +25,20 @@ def _free_port():
         return s.getsockname()[1]
 
 
+def hooks_env():
+    """The workers of a fault-injection test load the TEST TWIN of the library (tools/build_hooks.sh): the product reads no hook."""
+    import conftest
+    conftest.load_pkg(hooks=True)  # (builds the twin if it is missing)
+    return {"OVM_HIP_LIB": conftest.HOOKS_LIB, "OVM_TUNING_LIVE": "1"}
+
+
 def run_sharded(case, world, tmp_path, repeat=1, save_memory=False, alltoall=True, bulk="ipc", fail_mode="none", fail_rank=1,
                 extra_env=None, expect_ipc="any"):
     port, shm, out = _free_port(), f"/ovm-test-{uuid.uuid4().hex[:12]}", str(tmp_path / "proof.bin")
-    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "OVM_HIP_LIB")}
     env["OVM_SHARD_TIMEOUT_S"] = "60"  # a rank that died must not hold the others for minutes
+    if fail_mode == "midproof":
+        env.update(hooks_env())  # (the worker arms OVM_TEST_FAIL_RANK)
     env.update(extra_env or {})
     procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "shard_worker.py"), "--rank", str(r), "--world", str(world),
                                "--port", str(port), "--case", case, "--shm", shm, "--out", out, "--repeat", str(repeat)]
@@ -97,16 +106,20 @@ def test_bulk_exchange_staged_through_shared_memory(orc, tmp_path, case, world):
     assert run_sharded(case, world, tmp_path, bulk="shm") == want
 
 
-@pytest.mark.parametrize("hook,world", [("OVM_IPC_FORCE_OPEN_FAIL", 2), ("OVM_IPC_FORCE_OPEN_FAIL", 4), ("OVM_IPC_FORCE_OPEN_HANG", 3)])
-def test_ipc_exchange_degrades_to_host_staging_instead_of_hanging(orc, tmp_path, hook, world):
+@pytest.mark.parametrize("hook,value,world", [("OVM_IPC_FORCE_OPEN_FAIL", "1", 2), ("OVM_IPC_FORCE_OPEN_FAIL", "1", 4),
+                                              ("OVM_IPC_FORCE_OPEN_FAIL", "2", 3), ("OVM_IPC_FORCE_OPEN_HANG", "1", 3)])
+def test_ipc_exchange_degrades_to_host_staging_instead_of_hanging(orc, tmp_path, hook, value, world):
     """`hipIpcOpenMemHandle` once did not return (two 85 GB processes on one GPU). Every open now has
     a deadline and the ranks map in turn; a failed (FAIL hook) or overdue (HANG hook: the helper thread never returns,
     deadline 1 s) open is agreed by all ranks and the communicator stages this and every later bulk exchange through
-    host memory: the proof in flight completes, byte-identical, and a second proof over the same communicator too."""
+    host memory: the proof in flight completes, byte-identical, and a second proof over the same communicator too.
+    FAIL = 2 fails the open with hipErrorInvalidValue -- what a stale handle or a buffer that is not a hipMalloc allocation
+    really produces, and once mistaken for "the ranks disagree on the size" (ADVICE r4): it degrades like any other."""
     import time
     blob, want = oracle_proof(orc, "bench_app", world)
     t0 = time.time()
-    got = run_sharded("bench_app", world, tmp_path, repeat=2, extra_env={hook: "1", "OVM_IPC_OPEN_TIMEOUT_S": "1"}, expect_ipc="degraded")
+    got = run_sharded("bench_app", world, tmp_path, repeat=2, extra_env=dict(hooks_env(), **{hook: value, "OVM_IPC_OPEN_TIMEOUT_S": "1"}),
+                      expect_ipc="degraded")
     assert got == want
     assert time.time() - t0 < 120
 
@@ -153,7 +166,7 @@ def test_ipc_open_of_a_2_5_gib_allocation_still_hangs_without_the_rule_and_the_d
     if os.environ.get("OVM_IPC_RAW_HANG_TEST", "0") != "1":
         pytest.skip("opt-in (OVM_IPC_RAW_HANG_TEST=1): provokes the runtime's hang on purpose; its last run is "
                     "profiles/r04/gputest_ipc_r04n.log and the reproducer logs beside it")
-    recs = _ipc_repro(2.5, {"OVM_IPC_OPEN_TIMEOUT_S": "3", "OVM_IPC_NO_BOUNCE": "1"})
+    recs = _ipc_repro(2.5, dict(hooks_env(), **{"OVM_IPC_OPEN_TIMEOUT_S": "3", "OVM_IPC_NO_BOUNCE": "1"}))
     if not any(st["ipc"]["degraded"] for st in recs):
         pytest.skip("this runtime maps a 2.5 GiB allocation: the size rule of csrc/ipc_comm.cpp is no longer needed here")
     for st in recs:

@@ -13,6 +13,10 @@
 #                      tests/test_gpu_prove.py::test_reference_golden_proofs (the HIP prover reproduces them).
 # 3. conformance:      drops crates/hip-backend into the checkout's workspace, builds it against libopenvm_hip.so and runs
 #                      `backend_test_suite!(HipEngine)` + the bit-identity tests (crates/hip-backend/tests/integration.rs).
+# 4. CPU baseline:     the reference's uniform_runner proves config D with BabyBearPoseidon2CpuEngine on this box's cores ->
+#                      profiles/cargo_box/cpu_baseline_reference.json (bench.py then reports cpu_baseline.kind "reference").
+# 5. header:           cbindgen regenerates the C declarations from crates/hip-backend/src/ffi.rs (crates/hip-backend/cbindgen.toml)
+#                      and tools/abi_cmp.py diffs them against include/openvm_hip.h.
 # Nothing here has been run by the builder of this repository (no cargo in that image): expect to fix import paths in
 # gen_golden.rs / the crate on first contact and say so in the commit that adds tests/golden/reference/.
 set -euo pipefail
@@ -48,4 +52,43 @@ if [ "$GPU" = 1 ]; then
   ( cd "$REF" && OPENVM_HIP_LIB_DIR="$HERE/stark-backend_amd" RAYON_NUM_THREADS=1 \
       cargo test --release -p openvm-hip-backend -- --test-threads=1 )
 fi
-echo "done: commit tests/golden/reference/ (the documents are data: inputs and the reference's outputs)"
+echo "== 4. the reference's CPU backend timed on the headline workload (bench.py's cpu_baseline, kind \"reference\")"
+# The reference's own bench binary (benchmarks/synthetic/src/bin/uniform_runner.rs:119-162) proves BASELINE config D --
+# one BenchmarkAir, 2^22 rows x 100 columns, 200 boolean constraints, 13 send/receive pairs, app parameters with
+# log_stacked_height 24 -- with BabyBearPoseidon2CpuEngine (crates/stark-sdk/src/config/baby_bear_poseidon2.rs:213-253)
+# on every host core (rayon default) and prints its prove time; METRICS_OUTPUT carries stark_prove_excluding_trace_time_ms.
+mkdir -p "$HERE/profiles/cargo_box"
+( cd "$REF" && RUSTFLAGS="-Ctarget-cpu=native" METRICS_OUTPUT="$HERE/profiles/cargo_box/uniform_runner_cpu_metrics.json" \
+    cargo run --release -p openvm-benchmark-synthetic --bin uniform_runner -- --num-airs 1 --cols-per-air 100 \
+      --constraints-per-col 2 --interactions-per-col 0.25 --log-rows-per-air 22 --log-stacked-height 24 \
+    2>&1 | tee "$HERE/profiles/cargo_box/uniform_runner_cpu.log" )
+python3 - "$HERE" <<'PY'
+import json, os, re, sys
+here = sys.argv[1]
+log = open(os.path.join(here, "profiles", "cargo_box", "uniform_runner_cpu.log")).read()
+m = re.search(r"prove[^\n]*?([0-9.]+)\s*ms", log)
+ms = float(m.group(1)) if m else None
+try:
+    met = json.load(open(os.path.join(here, "profiles", "cargo_box", "uniform_runner_cpu_metrics.json")))
+    for k, v in (met.items() if isinstance(met, dict) else []):
+        if "stark_prove_excluding_trace_time_ms" in str(k):
+            ms = float(v if not isinstance(v, list) else v[0])
+except Exception:
+    pass
+if ms:
+    out = {"workload": "2^22 x 100 BenchmarkAir, app params (config D): the reference's uniform_runner with the CPU engine",
+           "seconds": round(ms / 1e3, 2), "cells_per_s": round(100 * (1 << 22) / (ms / 1e3), 1), "cores": os.cpu_count(), "kind": "reference"}
+    json.dump(out, open(os.path.join(here, "profiles", "cargo_box", "cpu_baseline_reference.json"), "w"))
+    print("reference CPU baseline:", out)
+else:
+    print("could not read the prove time from the log: read profiles/cargo_box/uniform_runner_cpu.log")
+PY
+
+echo "== 5. the C header regenerated from the Rust declarations and compared (scripts/cbindgen.toml + scripts/abi_cmp.py's role)"
+if command -v cbindgen >/dev/null; then
+  ( cd "$HERE/crates/hip-backend" && cbindgen -c cbindgen.toml . -o /tmp/openvm_hip_from_rust.h )
+  python3 "$HERE/tools/abi_cmp.py" /tmp/openvm_hip_from_rust.h "$HERE/include/openvm_hip.h"
+else
+  echo "cbindgen not installed (cargo install cbindgen): skipped; tests/test_abi.py compares ffi.rs with the header textually"
+fi
+echo "done: commit tests/golden/reference/ (the documents are data: inputs and the reference's outputs) and profiles/cargo_box/"
