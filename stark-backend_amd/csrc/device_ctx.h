@@ -65,6 +65,8 @@ const Twiddles *twiddles();
 
 // Optional per-stage timing with HIP events recorded on the launching stream (bench.py reads it
 // through ovm_hip_profile_*). Off by default: no events are created.
+// the library's side stream of the calling thread (prover.hip: SideStream): scopes recorded on it are reported apart
+void prof_register_side_stream(hipStream_t s);
 struct ProfScope {
     int slot = -1;
     bool ranged = false;  // a roctx range is open (OVM_ROCTX=1)

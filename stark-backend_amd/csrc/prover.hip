@@ -427,6 +427,7 @@ struct SideStream : ThreadResource {
         if (fork) (void)hipEventDestroy(fork);
         if (s) (void)hipStreamDestroy(s);
         s = nullptr, fork = join = nullptr;
+        prof_register_side_stream(nullptr);
     }
     ~SideStream() override {
         if (!runtime_exiting()) release();
@@ -444,6 +445,7 @@ struct SideStream : ThreadResource {
             release();  // (all or nothing: a half-made set would pass the `if (s)` above next time)
             throw OvmFail((int)hipErrorUnknown, "side stream");
         }
+        prof_register_side_stream(s);
     }
 };
 inline SideStream &side_stream() {

@@ -22,10 +22,14 @@ struct ProfRec {
     hipEvent_t a, b;
     int depth;           // number of scopes open on this thread when this one started (0 = a top-level stage)
     hipStream_t stream;  // the stream the events were recorded on
+    bool side;           // ... which is the library's side stream of the recording thread
 };
 thread_local int g_prof_depth = 0;
+thread_local hipStream_t g_prof_side = nullptr;
+thread_local bool g_prof_has_side = false;
 int g_prof_mode = 0;  // 0 off, 1 every stage, 2 the dominant kernel's label only
 std::vector<ProfRec> g_prof;
+std::mutex g_prof_mutex;  // (the engines of a throughput run record from several threads)
 
 // roctx ranges under the same labels (reference: the NVTX layer of crates/stark-sdk/src/nvtx_tracing.rs:9-33).
 // OVM_ROCTX=1 in the environment turns them on; the marker library is looked up at run time, so the product has no
@@ -77,6 +81,10 @@ ThreadResource::~ThreadResource() {
         }
 }
 
+void prof_register_side_stream(hipStream_t s) {
+    g_prof_side = s;
+    g_prof_has_side = s != nullptr;
+}
 ProfScope::ProfScope(const char *label, hipStream_t s) : stream(s) {
     if (roctx().push) {
         roctx().push(label);
@@ -84,16 +92,24 @@ ProfScope::ProfScope(const char *label, hipStream_t s) : stream(s) {
     }
     if (!g_prof_mode) return;
     if (g_prof_mode == 2 && strcmp(label, "merkle.hash_rows") != 0) return;
-    ProfRec r{label, nullptr, nullptr, g_prof_depth, s};
+    ProfRec r{label, nullptr, nullptr, g_prof_depth, s, g_prof_has_side && g_prof_side == s};
     if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return;
     (void)hipEventRecord(r.a, s);
-    slot = (int)g_prof.size();
-    g_prof.push_back(r);
+    {
+        std::lock_guard<std::mutex> lk(g_prof_mutex);
+        slot = (int)g_prof.size();
+        g_prof.push_back(r);
+    }
     g_prof_depth++;
 }
 ProfScope::~ProfScope() {
     if (slot >= 0) {
-        (void)hipEventRecord(g_prof[slot].b, stream);
+        hipEvent_t b;
+        {
+            std::lock_guard<std::mutex> lk(g_prof_mutex);
+            b = slot < (int)g_prof.size() ? g_prof[slot].b : nullptr;  // (profile_enable may have cleared the records)
+        }
+        if (b) (void)hipEventRecord(b, stream);
         g_prof_depth--;
     }
     if (ranged) roctx().pop();
@@ -103,6 +119,7 @@ ProfScope::~ProfScope() {
 extern "C" {
 
 int ovm_hip_profile_enable(int on) {
+    std::lock_guard<std::mutex> lk(ovm::g_prof_mutex);
     for (auto &r : ovm::g_prof) {
         (void)hipEventDestroy(r.a);
         (void)hipEventDestroy(r.b);
@@ -114,8 +131,9 @@ int ovm_hip_profile_enable(int on) {
 
 // Writes "label calls total_ms nested_ms side_ms\n" lines (aggregated per label) into buf; returns bytes needed.
 // nested_ms: the part of total_ms measured while ANOTHER scope was open on the thread (e.g. the Merkle and NTT labels inside
-// whir.rs_commit); side_ms: the part measured on a stream other than the first one seen (the early coset LDE beside the GKR
-// layers). total - nested - side summed over the labels is additive: it cannot exceed the step's time.
+// whir.rs_commit); side_ms: the part measured on the library's own side stream of the recording thread (the early coset
+// LDE beside the GKR layers) -- decided when the scope is recorded, not by which stream happened to be seen first
+// (ADVICE r4). total - nested - side summed over the labels is additive: it cannot exceed the step's time.
 uint64_t ovm_hip_profile_report(char *buf, uint64_t cap) {
     (void)hipDeviceSynchronize();
     struct Agg {
@@ -124,7 +142,7 @@ uint64_t ovm_hip_profile_report(char *buf, uint64_t cap) {
     };
     std::map<std::string, Agg> agg;
     std::vector<std::string> order;
-    const hipStream_t main_stream = ovm::g_prof.empty() ? nullptr : ovm::g_prof.front().stream;
+    std::lock_guard<std::mutex> lk(ovm::g_prof_mutex);
     for (auto &r : ovm::g_prof) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, r.a, r.b) != hipSuccess) continue;
@@ -132,7 +150,7 @@ uint64_t ovm_hip_profile_report(char *buf, uint64_t cap) {
         auto &e = agg[r.label];
         e.calls++;
         e.ms += ms;
-        if (r.stream != main_stream) e.side += ms;
+        if (r.side) e.side += ms;
         else if (r.depth > 0) e.nested += ms;
     }
     std::string out;

@@ -98,8 +98,41 @@ def pick_cores(local_rank, gpu_bdfs, allowed_cpus, sysfs="/sys", skip=SKIP_CORES
     return pair, {"numa_node": node, "slot_on_node": slot, "physical_cores_on_node": len(cores), "basis": why}
 
 
+def kfd_gpu_bdfs(sysfs="/sys"):
+    """PCI addresses of the GPUs in HIP's device order WITHOUT touching the runtime: the KFD topology lists the GPU nodes
+    (simd_count > 0) in the order the runtime enumerates them, with `domain` and `location_id` (bus << 8 | device << 3 |
+    function). HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES given as plain index lists are honoured; anything else (UUIDs)
+    returns None and the caller asks torch. None also when the topology is not readable."""
+    base = os.path.join(sysfs, "class", "kfd", "kfd", "topology", "nodes")
+    try:
+        nodes = sorted((int(n) for n in os.listdir(base) if n.isdigit()))
+    except OSError:
+        return None
+    gpus = []
+    for n in nodes:
+        try:
+            props = dict(line.split()[:2] for line in open(os.path.join(base, str(n), "properties")) if len(line.split()) >= 2)
+        except OSError:
+            return None
+        if int(props.get("simd_count", "0")) == 0:
+            continue
+        loc, dom = int(props.get("location_id", "0")), int(props.get("domain", "0"))
+        gpus.append(f"{dom:04x}:{(loc >> 8) & 0xff:02x}:{(loc >> 3) & 0x1f:02x}.{loc & 7}")
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is None or v == "":
+            continue
+        try:
+            gpus = [gpus[int(i)] for i in v.split(",")]
+        except (ValueError, IndexError):
+            return None
+    return gpus or None
+
+
 def torch_gpu_bdfs():
-    """PCI addresses of the visible GPUs by device index, from torch's device properties (no context is created)."""
+    """PCI addresses of the visible GPUs by device index, from torch's device properties. This INITIALISES the HIP / HSA
+    runtime: its helper threads start with the mask the process has at that moment (pin_this_process re-pins every thread
+    of the process afterwards)."""
     import torch
     out = []
     for i in range(torch.cuda.device_count()):
@@ -110,15 +143,21 @@ def torch_gpu_bdfs():
 
 
 def pin_this_process(local_rank, gpu_bdfs=None, sysfs="/sys", slot_rank=None):
-    """Pins the calling process (all its current threads' future children inherit the mask) and returns the JSON-able record
-    of what was done: {"cpus": [a, b], ...facts} or {"cpus": None, "reason": ...}. `slot_rank`: ranks that share one GPU
-    (bench.py --one-gpu) pass their own rank so that they do not share cores."""
+    """Pins EVERY thread of the calling process (threads created later inherit the mask) and returns the JSON-able record of
+    what was done: {"cpus": [a, b], ...facts} or {"cpus": None, "reason": ...}. The GPUs' PCI addresses come from the KFD
+    topology in sysfs -- no runtime call, so the HIP / HSA helper threads are created AFTER the pinning and inherit the pair
+     -- and from torch only if sysfs does not have them; either way the threads that already exist (the runtime's,
+    an OpenMP pool's) are pinned one by one through /proc/self/task. `slot_rank`: ranks that share one GPU (bench.py
+    --one-gpu) pass their own rank so that they do not share cores."""
     if not hasattr(os, "sched_setaffinity"):
         return {"cpus": None, "reason": "no sched_setaffinity on this platform"}
     try:
         allowed = sorted(os.sched_getaffinity(0))
+        source = "caller"
         if gpu_bdfs is None:
-            gpu_bdfs = torch_gpu_bdfs()
+            gpu_bdfs, source = kfd_gpu_bdfs(sysfs), "kfd topology (sysfs)"
+        if gpu_bdfs is None:
+            gpu_bdfs, source = torch_gpu_bdfs(), "torch device properties (the runtime was initialised before the pinning)"
         if slot_rank is not None:  # several ranks on GPU `local_rank`: one pair each, as if each had its own GPU there
             gpu_bdfs = [gpu_bdfs[local_rank] if local_rank < len(gpu_bdfs) else None] * (slot_rank + 1)
             local_rank = slot_rank
@@ -126,6 +165,16 @@ def pin_this_process(local_rank, gpu_bdfs=None, sysfs="/sys", slot_rank=None):
         if pair is None:
             return {"cpus": None, "reason": facts}
         os.sched_setaffinity(0, set(pair))
-        return dict({"cpus": pair, "all_cpus": len(allowed)}, **facts)
+        repinned = 0
+        try:  # the threads that already exist keep their own masks: pin them too
+            for tid in os.listdir("/proc/self/task"):
+                try:
+                    os.sched_setaffinity(int(tid), set(pair))
+                    repinned += 1
+                except (OSError, ValueError):
+                    pass
+        except OSError:
+            pass
+        return dict({"cpus": pair, "all_cpus": len(allowed), "gpu_addresses_from": source, "threads_pinned": repinned}, **facts)
     except (OSError, ValueError) as e:
         return {"cpus": None, "reason": repr(e)}
