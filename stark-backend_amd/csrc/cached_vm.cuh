@@ -143,6 +143,13 @@ static_assert(RED_THREADS * 4 == 1024, "the asm addresses row r of an operand at
 #define OVM_REQ_1(j, SC) OVM_COLADDR(SC) "global_load_dword %[g" #j "0], %[o0], s[80:81]\n\t"
 #define OVM_REQ_2(j, SC) OVM_REQ_1(j, SC) "global_load_dword %[g" #j "1], %[o1], s[80:81]\n\t"
 #define OVM_REQ_4(j, SC) OVM_REQ_2(j, SC) "global_load_dword %[g" #j "2], %[o2], s[80:81]\n\tglobal_load_dword %[g" #j "3], %[o3], s[80:81]\n\t"
+// The leaf kernel reads trace columns, not a coset LDE: the record's second half is four (pointer lo, pointer hi | rotated
+// << 31) pairs -- s[92:93] .. s[98:99] -- and the lane has two offsets, its row (o0) and the row after it (o1).
+#define OVM_REQ_LEAF(j, LO, HI)                                                                        \
+    "s_bitcmp1_b32 s" HI ", 31\n\ts_bitset0_b32 s" HI ", 31\n\ts_cbranch_scc1 1f\n\t"                    \
+    "global_load_dword %[g" #j "0], %[o0], s[" LO ":" HI "]\n\ts_branch 2f\n"                          \
+    "1:\n\tglobal_load_dword %[g" #j "0], %[o1], s[" LO ":" HI "]\n"                                   \
+    "2:\n\t"
 #define OVM_NEXT(S, j1, L) "s_cmp_lt_u32 " S ", " #j1 "\n\ts_cbranch_scc1 " L "\n\t"
 #define OVM_BLOCK_ASM(LAND, REQ)                                                                                     \
     "s_lshr_b32 s82, %[wx], 30\n\ts_cmp_lg_u32 s82, 1\n\ts_cbranch_scc1 90f\n\t"                                      \
@@ -160,21 +167,37 @@ static_assert(RED_THREADS * 4 == 1024, "the asm addresses row r of an operand at
     REQ(3, "s95") OVM_NEXT("s83", 5, "90f") REQ(4, "s96") OVM_NEXT("s83", 6, "90f") REQ(5, "s97") OVM_NEXT("s83", 7, "90f")     \
     REQ(6, "s98") OVM_NEXT("s83", 8, "90f") REQ(7, "s99")                                                            \
     "90:"
+#define OVM_BLOCK_LEAF_ASM(LAND)                                                                                      \
+    "s_lshr_b32 s82, %[wx], 29\n\ts_cmp_lg_u32 s82, 2\n\ts_cbranch_scc1 90f\n\t"                                      \
+    "s_lshl_b32 s80, %[wy], 6\n\ts_load_dwordx16 s[84:99], %[recs], s80\n\t"                                          \
+    "s_and_b32 s82, %[wx], 0xff\n\ts_bfe_u32 s83, %[wx], 0x80008\n\t"                                                 \
+    "s_waitcnt lgkmcnt(0)\n\t"                                                                                       \
+    "s_cmp_eq_u32 s82, 0\n\ts_cbranch_scc1 50f\n\t"                                                                   \
+    "s_waitcnt vmcnt(0)\n\t"                                                                                         \
+    LAND(0, "s84") OVM_NEXT("s82", 2, "50f") LAND(1, "s85") OVM_NEXT("s82", 3, "50f") LAND(2, "s86") OVM_NEXT("s82", 4, "50f")  \
+    LAND(3, "s87")                                                                                                   \
+    "50:\n\t"                                                                                                        \
+    "s_cmp_eq_u32 s83, 0\n\ts_cbranch_scc1 90f\n\t"                                                                   \
+    OVM_REQ_LEAF(0, "92", "93") OVM_NEXT("s83", 2, "90f") OVM_REQ_LEAF(1, "94", "95") OVM_NEXT("s83", 3, "90f")         \
+    OVM_REQ_LEAF(2, "96", "97") OVM_NEXT("s83", 4, "90f") OVM_REQ_LEAF(3, "98", "99")                                 \
+    "90:"
 #define OVM_BLOCK_CLOBBERS                                                                                               \
     "memory", "scc", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", \
         "s95", "s96", "s97", "s98", "s99"
 #endif  // __HIP_DEVICE_COMPILE__
 
-template <int R, int NOUT>
-struct CachedRound0 {
-    static constexpr int ROWS = R;
-    static constexpr bool REDUCE_IN_IMAGE = true;  // (eval.cuh: the launch gives the image at least RED_THREADS * 16 bytes)
+// The interpreter proper. LEAVES = false: round 0 (columns of a coset LDE: base + column * pow + o[r]); LEAVES = true: the
+// LogUp-GKR leaf program (R = 1; trace columns by pointer, o[0] = this row, o[1] = the row after it; `leaf(k)` is called where
+// the program closes interaction k, with the result register = its numerator and accumulator 0 = its denominator sum).
+template <int R, int NOUT, bool LEAVES>
+struct CachedCore {
     static_assert(R == 1 || R == 2 || R == 4, "one asm form per R");
     static_assert(NOUT == 1 || (NOUT == 2 && R <= 2), "two accumulator sets for at most two rows per lane");
+    static_assert(!LEAVES || (R == 1 && NOUT == 1), "the leaf program runs one row per lane");
     static_assert(CachedProgram::MAX_LOADS == 8, "the block statement lands / requests 8 columns");
-    DevCached prog;
-    __device__ __forceinline__ void operator()(const Fp *lde_k, uint32_t log_lifted, const uint64_t (&p)[R],
-                                               EF (&out)[R][2]) const {
+    template <class Leaf>
+    static __device__ __forceinline__ void run(const DevCached &prog, uint64_t base_addr, uint32_t pow_in, const uint32_t (&o)[4],
+                                               Acc96 (&acc0)[R], Acc96 (&acc1)[R], Leaf &&leaf) {
 #if defined(__HIP_DEVICE_COMPILE__)
         extern __shared__ uint32_t lds_image[];
         // LDS byte address of this lane's word of row 0 (the asm adds operand offsets and r * 1024)
@@ -186,16 +209,10 @@ struct CachedRound0 {
         const OVM_CONST_AS uint4 *wp = (const OVM_CONST_AS uint4 *)uni64((uint64_t)(uintptr_t)prog.words);
         const OVM_CONST_AS uint32_t *recs = (const OVM_CONST_AS uint32_t *)uni64((uint64_t)(uintptr_t)prog.loads);
         const uint32_t n_words = uni(prog.n_words);
-        const uint64_t lde_addr = uni64((uint64_t)(uintptr_t)lde_k);
+        const uint64_t lde_addr = uni64(base_addr);
         const uint32_t lde_lo = (uint32_t)lde_addr, lde_hi = (uint32_t)(lde_addr >> 32);
-        const uint32_t pow = 1u << (uni(log_lifted) + 2);  // bytes per column (log_lifted <= 27)
+        const uint32_t pow = uni(pow_in);
         const uint32_t kP = bb::P, kM = bb::MONTY_M;
-        uint32_t o[4];  // byte offset of the lane's r-th cell inside a column
-#pragma unroll
-        for (int r = 0; r < 4; r++) o[r] = r < R ? (uint32_t)p[r < R ? r : 0] << 2 : 0;
-        Acc96 acc0[R], acc1[R];
-#pragma unroll
-        for (int r = 0; r < R; r++) acc0[r].clear(), acc1[r].clear();
         uint32_t g[8][R];  // landing registers
 #pragma unroll
         for (int j = 0; j < 8; j++)
@@ -251,7 +268,12 @@ struct CachedRound0 {
     [wx] "s"(W.x), [wy] "s"(W.y), [mine] "v"(mine), [recs] "s"(recs), [pow] "s"(pow), [ldelo] "s"(lde_lo), [ldehi] "s"(lde_hi), \
         [o0] "v"(o[0]), [o1] "v"(o[1]), [o2] "v"(o[2]), [o3] "v"(o[3])
         auto block = [&](const uint4 w) {
-            if constexpr (R == 4) {
+            if constexpr (LEAVES) {
+                asm volatile(OVM_BLOCK_LEAF_ASM(OVM_LAND_1)
+                             : OVM_G1(0), OVM_G1(1), OVM_G1(2), OVM_G1(3), [ad] "=&v"(ad)
+                             : OVM_BLOCK_IN(w)
+                             : OVM_BLOCK_CLOBBERS);
+            } else if constexpr (R == 4) {
                 asm volatile(OVM_BLOCK_ASM(OVM_LAND_4, OVM_REQ_4)
                              : OVM_G4(0), OVM_G4(1), OVM_G4(2), OVM_G4(3), OVM_G4(4), OVM_G4(5), OVM_G4(6), OVM_G4(7), [ad] "=&v"(ad)
                              : OVM_BLOCK_IN(w)
@@ -281,6 +303,20 @@ struct CachedRound0 {
             word(w1);
             word(w2);
             word(w3);
+            if constexpr (LEAVES) {
+                // a leaf marker is the LAST word of its group: emit, then clear accumulator 0 -- in an asm statement of its
+                // own with an internal skip, like every other write to the accumulators (no phi, no copies)
+                if ((w3.x >> 29) == 3u) leaf(w3.y, Fp::raw(pr[0]), acc0[0]);
+                asm volatile("s_lshr_b32 %[ts0], %[wx], 29\n\ts_cmp_lg_u32 %[ts0], 3\n\ts_cbranch_scc1 1f\n\t"
+                             "v_mov_b32 %[h0], 0\n\tv_mov_b32 %[h1], 0\n\tv_mov_b32 %[h2], 0\n\tv_mov_b32 %[h3], 0\n\t"
+                             "v_mov_b64 %[l0], 0\n\tv_mov_b64 %[l1], 0\n\tv_mov_b64 %[l2], 0\n\tv_mov_b64 %[l3], 0\n"
+                             "1:"
+                             : [l0] "+v"(acc0[0].lo[0]), [l1] "+v"(acc0[0].lo[1]), [l2] "+v"(acc0[0].lo[2]), [l3] "+v"(acc0[0].lo[3]),
+                               [h0] "+v"(acc0[0].hi[0]), [h1] "+v"(acc0[0].hi[1]), [h2] "+v"(acc0[0].hi[2]), [h3] "+v"(acc0[0].hi[3]),
+                               [ts0] "=&s"(ts0)
+                             : [wx] "s"(w3.x)
+                             : "scc");
+            }
         };
         asm volatile("s_load_dwordx16 %0, %1, 0x0" : "=s"(A) : "s"(wp) : "memory");
         for (uint32_t i = n_words; i != 0; i -= 8) {
@@ -293,11 +329,6 @@ struct CachedRound0 {
         // (the last block word requests nothing: no column load is in flight; the group fetched past the end and the stores to
         // LDS are waited for here)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-        for (int r = 0; r < R; r++) {
-            out[r][0] = out[r][0] + acc0[r].finish();
-            if (NOUT > 1) out[r][1] = out[r][1] + acc1[r].finish();
-        }
 #undef OVM_ACC_OPS
 #undef OVM_WORD_IN
 #undef OVM_WORD_TMP
@@ -306,6 +337,30 @@ struct CachedRound0 {
 #undef OVM_G4
 #undef OVM_BLOCK_IN
 #endif
+    }
+};
+
+// Round 0: the program's accumulators at the lane's R rows of coset k (eval.cuh: round0_eval_body).
+template <int R, int NOUT>
+struct CachedRound0 {
+    static constexpr int ROWS = R;
+    static constexpr bool REDUCE_IN_IMAGE = true;  // (eval.cuh: the launch gives the image at least RED_THREADS * 16 bytes)
+    DevCached prog;
+    __device__ __forceinline__ void operator()(const Fp *lde_k, uint32_t log_lifted, const uint64_t (&p)[R],
+                                               EF (&out)[R][2]) const {
+        uint32_t o[4];  // byte offset of the lane's r-th cell inside a column
+#pragma unroll
+        for (int r = 0; r < 4; r++) o[r] = r < R ? (uint32_t)p[r < R ? r : 0] << 2 : 0;
+        Acc96 acc0[R], acc1[R];
+#pragma unroll
+        for (int r = 0; r < R; r++) acc0[r].clear(), acc1[r].clear();
+        CachedCore<R, NOUT, false>::run(prog, (uint64_t)(uintptr_t)lde_k, 1u << (log_lifted + 2) /* bytes per column (log_lifted <= 27) */, o,
+                                        acc0, acc1, [](uint32_t, Fp, const Acc96 &) {});
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            out[r][0] = out[r][0] + acc0[r].finish();
+            if (NOUT > 1) out[r][1] = out[r][1] + acc1[r].finish();
+        }
     }
 };
 

@@ -18,25 +18,7 @@ struct DevProgram {
     const EF *weights;
 };
 
-// Staged round-0 program (program.h: stage_program), device arrays.
-struct DevStaged {
-    const StagedBlock *blocks = nullptr;
-    const uint32_t *loads = nullptr;
-    const StagedInstr *code = nullptr;
-    const StagedAcc *accs = nullptr;
-    uint32_t n_blocks = 0;
-    uint32_t num_rows = 0;
-    uint32_t rows = 0;  // trace rows per lane the offsets were scaled for
-    uint32_t stage_rows = 0;  // rows of one staging buffer
-};
-// Rows per lane and LDS layout for staging a program of `num_slots` slots on a trace of 2^log_lifted
-// rows; rows == 0: its LDS image does not fit (use the plain interpreter).
-struct StagedPlan {
-    uint32_t rows = 0, stage_rows = 0, acc_rows = 0;
-};
-StagedPlan round0_staged_plan(uint32_t log_lifted, uint32_t n_out, uint32_t num_slots, uint32_t n_instr = 0);
-
-// Cached-column round-0 program (program.h: stage_cached), device arrays.
+// Cached-column program (program.h: stage_cached), device arrays: round 0 and the LogUp-GKR leaves.
 struct DevCached {
     const StagedInstr *words = nullptr;  // n_words (a multiple of 8) + one more group of four
     const uint32_t *loads = nullptr;     // records of CachedProgram::MAX_LOADS (column, row offset) pairs
@@ -50,6 +32,8 @@ struct CachedPlan {
 };
 // min_rows: the rows the program cannot do without (program.h: cached_liveness)
 CachedPlan round0_cached_plan(uint32_t log_lifted, uint32_t n_out, uint32_t min_rows, uint32_t n_instr = 0);
+// the leaf program: one row per lane, at most 4 columns brought per block (cached_vm.cuh: the leaf block statement)
+CachedPlan leaves_cached_plan(uint32_t min_rows);
 
 // ro.out[k] = sum_b ro.partials[b * K + k], then the flag (for reductions with many outputs)
 int sum_partials(const RedOut &ro, uint32_t n_blocks, uint32_t K, hipStream_t s);
@@ -204,7 +188,7 @@ int gkr_edge_records(FracPlanes src, uint64_t at0, uint64_t at1, uint32_t n0, ui
 // The leaf kernels of many traces in one launch (staged programs, one row per lane): job j owns
 // workgroups [wg0, wg0 + gx).
 struct LeavesJob {
-    DevStaged prog;
+    DevCached prog;
     const EF *leaf_const;
     const ColDesc *cols;
     const uint64_t *leaf_base;
@@ -215,7 +199,7 @@ struct LeavesJob {
 int gkr_eval_leaves_batched(const LeavesJob *d_jobs, const LeavesJob *h_jobs, uint32_t n_jobs, FracPlanes leaves,
                             hipStream_t s);
 // `staged` (optional): the DEN/LEAF program in staged form, laid out for one row per lane
-int gkr_eval_leaves(const DevProgram &prog, const DevStaged &staged, const EF *d_leaf_const, const ColDesc *d_cols, uint32_t log_height,
+int gkr_eval_leaves(const DevProgram &prog, const DevCached &staged, const EF *d_leaf_const, const ColDesc *d_cols, uint32_t log_height,
                     const uint64_t *d_leaf_base, const uint32_t *d_leaf_log_len, Fp norm, FracPlanes leaves,
                     hipStream_t s);
 int gkr_build_layer(FracPlanes child, FracPlanes parent, uint64_t n_parent, bool child_p_base, hipStream_t s);

@@ -364,289 +364,31 @@ inline Program compile_program(const AirKey &air, const ColumnMap &cm, const std
 }
 
 // ---------------------------------------------------------------------------------------------
-// Staged form of an ACC program for the round-0 kernel (stages.hip, StagedRound0).
-//
-// The plain interpreter above decodes operand kinds per instruction and loads trace cells where
-// they are used; on gfx950 that is bound by scalar/branch issue and by the serial
-// decode -> load -> use chain, not by arithmetic. The staged form moves the decisions to the host:
-//   * the program is cut into blocks; a block first brings the (distinct) columns it reads into
-//     LDS staging rows -- asynchronous loads straight into LDS, all in flight together -- then
-//     runs its arithmetic instructions, then its accumulations (a second, branch-free loop);
-//   * every operand is an LDS row or, for `b` only, an immediate constant: constants in `a` are
-//     swapped / folded / materialised here;
-//   * an accumulation `out[o] += W[w] * x` becomes an entry (row of x, w) of the block's list; x is
-//     made to live in a row nothing overwrites before the block ends (a staging row, or an
-//     accumulation row the producing instruction writes directly).
-// LDS rows: two staging buffers of stage_rows rows (block b's columns are requested while block
-// b - 1 runs), acc_rows accumulation operands, then the program's slots. Row r is the words lds[r * 256 + lane] of the workgroup.
+// Words of the cached-column interpreter (cached_vm.cuh). The plain interpreter further down decodes operand kinds per
+// instruction and loads trace cells where they are used; on gfx950 that is bound by scalar / branch issue and by the serial
+// decode -> load -> use chain, not by arithmetic. The staged form moves every decision to the host, once per proof: every
+// operand is an LDS row, the result register or an immediate (constants on the left are commuted, folded or
+// materialised), operand fields are pre-multiplied word offsets, the operation is one bit per kind.
 // ---------------------------------------------------------------------------------------------
-// (one bit per operation: the kernel tests them in order of frequency; an enum would be compiled
-// into a balanced compare tree that reaches the multiply last)
 enum StagedOp : uint32_t {
-    S_MUL = 1, S_ADD = 2, S_SUB = 4, S_RSUB = 8 /* b - a */, S_NEG = 16, S_MOV = 32 /* dst = a */, S_MOVC = 64 /* dst = b */
-};
-struct StagedLayout {
-    uint32_t stage_rows = 8, acc_rows = 8;
-    // two staging buffers: block b's columns land in rows [(b & 1) * stage_rows, ...) while block b - 1 runs
-    uint32_t acc_row0() const { return 2 * stage_rows; }
-    uint32_t slot_row0() const { return 2 * stage_rows + acc_rows; }
+    S_MUL = 1, S_ADD = 2, S_SUB = 4, S_RSUB = 8 /* b - a */, S_MOV = 32 /* dst = a */, S_MOVC = 64 /* dst = b */
 };
 static constexpr uint32_t S_B_CONST = 0x100;
-// Forwarding (the compiler's FWD_* hints carried into the staged form): operand a / b is the result of the staged
-// instruction right before this one and comes from a register, not from its LDS row; S_NOSTORE: the result is read by the
-// next instruction only, through that register -- no LDS store. A staged instruction moves up to 3 R words of LDS per
-// lane, and the LDS port, not the ALU, is what bounds the interpreter on long programs.
+// Forwarding (the compiler's FWD_* hints): operand a / b is the result of the word right before this one and comes from the
+// result register, not from an LDS row; S_NOSTORE: the result is read by the next word only, through that register.
 static constexpr uint32_t S_FWD_A = 0x200, S_FWD_B = 0x400, S_NOSTORE = 0x800;
 
-
 struct StagedInstr {
-    uint32_t op;   // StagedOp | S_B_CONST
+    uint32_t op;   // StagedOp | flags
     uint32_t dst;  // LDS row
     uint32_t a;    // LDS row
     uint32_t b;    // LDS row / Montgomery constant
 };
-struct StagedAcc {  // 32 bytes: one scalar load brings the weight and the row
-    uint32_t w[4];  // the extension-field weight W[w], inlined (the staged form is built per proof)
-    uint32_t row, pad[3];
-};
-
-struct StagedBlock {
-    uint32_t load_off, n_loads, instr_off, n_instr;
-    // ACC programs: entries of output 0 first, then output 1; leaf = 0.
-    // DEN/LEAF programs (LogUp-GKR leaves): n_acc1 = row of the leaf's numerator, leaf = interaction
-    // index + 1 when the block ends with that interaction's LEAF (at most one per block).
-    uint32_t acc_off, n_acc0, n_acc1, leaf;
-};
-struct StagedProgram {
-    std::vector<StagedBlock> blocks;
-    std::vector<uint32_t> loads;  // flat column of staging row j of its block
-    std::vector<StagedInstr> code;
-    std::vector<StagedAcc> accs;
-    uint32_t num_rows = 0;  // SLOT_ROW0 + slots
-    uint32_t stage_rows = 0;  // rows of one staging buffer
-    // operand rows -> word offsets for `rows_per_lane` trace rows per lane
-    void scale_rows(uint32_t rows_per_lane) {
-        const uint32_t k = rows_per_lane * 256;
-        for (auto &in : code) {
-            in.dst *= k;
-            in.a *= k;
-            if (!(in.op & S_B_CONST)) in.b *= k;
-        }
-        for (auto &e : accs) e.row *= k;
-        for (auto &b : blocks)
-            if (b.leaf) b.n_acc1 *= k;
-    }
-};
-
-inline StagedProgram stage_program(const Program &p, const std::vector<FpExt> &weights,
-                                   const StagedLayout &layout = StagedLayout(), bool forward = true) {
-    const uint32_t STAGE_ROWS = layout.stage_rows, ACC_ROWS = layout.acc_rows, SLOT_ROW0 = layout.slot_row0();
-    StagedProgram sp;
-    sp.num_rows = SLOT_ROW0 + p.num_slots;
-    sp.stage_rows = STAGE_ROWS;
-    // dead_after[i]: the slot instruction i reads as `a` is not read again before it is rewritten
-    std::vector<char> dead_after(p.code.size(), 0);
-    {
-        std::vector<char> read_later(p.num_slots + 1, 0);
-        for (size_t i = p.code.size(); i-- > 0;) {
-            const Instr &in = p.code[i];
-            const bool binary = in.op == OP_ADD || in.op == OP_SUB || in.op == OP_MUL;
-            if (in.op < OP_ACC) read_later[in.dst] = 0;  // (reads of this instruction are marked below)
-            if (in.ak == K_SLOT) {
-                dead_after[i] = !read_later[in.a];
-                read_later[in.a] = 1;
-            }
-            if (binary && in.bk == K_SLOT) read_later[in.b] = 1;
-        }
-    }
-    std::vector<uint32_t> cur_cols;  // columns staged by the open block
-    std::vector<StagedAcc> acc0, acc1;
-    StagedBlock blk{};
-    size_t blk_first_instr = 0;
-    auto flush = [&] {
-        if (blk.n_instr == 0 && cur_cols.empty() && acc0.empty() && acc1.empty() && !blk.leaf) return;
-        blk.n_loads = (uint32_t)cur_cols.size();
-        sp.loads.insert(sp.loads.end(), cur_cols.begin(), cur_cols.end());
-        blk.acc_off = (uint32_t)sp.accs.size();
-        blk.n_acc0 = (uint32_t)acc0.size();
-        if (!blk.leaf) blk.n_acc1 = (uint32_t)acc1.size();  // (a leaf block keeps its numerator row there)
-        sp.accs.insert(sp.accs.end(), acc0.begin(), acc0.end());
-        sp.accs.insert(sp.accs.end(), acc1.begin(), acc1.end());
-        sp.blocks.push_back(blk);
-        cur_cols.clear();
-        acc0.clear();
-        acc1.clear();
-        blk = StagedBlock{};
-        blk.load_off = (uint32_t)sp.loads.size();
-        blk.instr_off = (uint32_t)sp.code.size();
-        blk_first_instr = sp.code.size();
-    };
-    auto staged_row = [&](uint32_t col) -> int {
-        for (size_t j = 0; j < cur_cols.size(); j++)
-            if (cur_cols[j] == col) return (int)(j + (sp.blocks.size() & 1) * STAGE_ROWS);
-        return -1;
-    };
-    auto emit = [&](uint32_t op, uint32_t dst, uint32_t a, uint32_t b) {
-        sp.code.push_back(StagedInstr{op, dst, a, b});
-        blk.n_instr++;
-    };
-    for (size_t idx = 0; idx < p.code.size(); idx++) {
-        const Instr &in = p.code[idx];
-        const bool binary = in.op == OP_ADD || in.op == OP_SUB || in.op == OP_MUL;
-        const bool accumulates = in.op == OP_ACC || in.op == OP_DEN || in.op == OP_LEAF;
-        // columns this instruction needs that the open block has not staged yet
-        auto needs = [&](uint32_t (&need)[2]) {
-            int n = 0;
-            if (in.ak == K_COL && staged_row(in.a) < 0) need[n++] = in.a;
-            if (binary && in.bk == K_COL && staged_row(in.b) < 0 && !(n && need[0] == in.b)) need[n++] = in.b;
-            return n;
-        };
-        uint32_t need[2];
-        int n_need = needs(need);
-        if (cur_cols.size() + n_need > STAGE_ROWS || (accumulates && acc0.size() + acc1.size() == ACC_ROWS)) {
-            flush();
-            n_need = needs(need);
-        }
-        for (int i = 0; i < n_need; i++) cur_cols.push_back(need[i]);
-        struct Opnd {
-            bool is_const;
-            uint32_t v;
-        };
-        auto acc_entry = [&](uint32_t row, uint32_t w) {
-            if (w >= weights.size()) throw OvmFail(1, "stage_program: weight index out of range");
-            StagedAcc e{};
-            for (int k = 0; k < 4; k++) e.w[k] = weights[w].c[k].v;
-            e.row = row;
-            return e;
-        };
-        auto opnd = [&](uint8_t kind, uint32_t payload) -> Opnd {
-            if (kind == K_SLOT) return {false, SLOT_ROW0 + payload};
-            if (kind == K_COL) return {false, (uint32_t)staged_row(payload)};
-            if (kind == K_CONST) return {true, payload};
-            throw OvmFail(1, "stage_program: bad operand kind");
-        };
-        const Opnd a = opnd(in.ak, in.a);
-        const uint32_t dst = SLOT_ROW0 + in.dst;
-        if (in.op == OP_LEAF) {  // numerator = a; closes the interaction's denominator sum
-            uint32_t row = a.v;
-            if (a.is_const) {
-                row = layout.acc_row0() + (uint32_t)acc0.size();
-                emit(S_MOVC | S_B_CONST, row, 0, a.v);
-            }
-            blk.n_acc1 = row;
-            blk.leaf = in.b + 1;
-            flush();
-        } else if (accumulates) {
-            std::vector<StagedAcc> &list = (in.op == OP_ACC && in.acc) ? acc1 : acc0;
-            const uint32_t acc_row = layout.acc_row0() + (uint32_t)(acc0.size() + acc1.size());
-            if (in.ak == K_COL) {
-                list.push_back(acc_entry(a.v, in.b));  // a staging row stays put until the block ends
-            } else if (a.is_const) {
-                emit(S_MOVC | S_B_CONST, acc_row, 0, a.v);
-                list.push_back(acc_entry(acc_row, in.b));
-            } else if (dead_after[idx] && sp.code.size() > blk_first_instr && sp.code.back().dst == a.v) {
-                sp.code.back().dst = acc_row;  // the producer writes the accumulation row directly
-                list.push_back(acc_entry(acc_row, in.b));
-            } else {
-                emit(S_MOV | S_B_CONST, acc_row, a.v, 0);
-                list.push_back(acc_entry(acc_row, in.b));
-            }
-        } else {
-            // Forwarding flags of this (arithmetic) instruction. The producer the compiler means is the program's previous
-            // instruction, which is arithmetic and therefore exactly the staged instruction emitted last. The store is
-            // dropped only when the one reader is the NEXT arithmetic instruction, by register: an accumulation reads its
-            // operand from an LDS row in the block's accumulation loop, so its producer always stores.
-            uint32_t f_a = 0, f_b = 0, f_ns = 0;
-            if (forward) {
-                f_a = (in.fwd & FWD_A) ? 1 : 0;
-                f_b = (in.fwd & FWD_B) ? 1 : 0;
-                const bool next_takes_it = idx + 1 < p.code.size() && p.code[idx + 1].op <= OP_NEG &&
-                                           (p.code[idx + 1].fwd & (FWD_A | FWD_B));
-                f_ns = ((in.fwd & FWD_NOSTORE) && next_takes_it) ? S_NOSTORE : 0;
-            }
-            if (in.op == OP_NEG) {
-                if (a.is_const) emit(S_MOVC | S_B_CONST | f_ns, dst, 0, (-Fp::raw(a.v)).v);
-                else emit(S_NEG | S_B_CONST | (f_a ? S_FWD_A : 0) | f_ns, dst, a.v, 0);
-            } else {
-                const Opnd b = opnd(in.bk, in.b);
-                if (a.is_const && b.is_const) {
-                    const Fp x = Fp::raw(a.v), y = Fp::raw(b.v);
-                    const Fp r = in.op == OP_ADD ? x + y : in.op == OP_SUB ? x - y : x * y;
-                    emit(S_MOVC | S_B_CONST | f_ns, dst, 0, r.v);
-                } else if (a.is_const) {  // constant on the left: commute, or b - a reversed (the program's b is the staged a)
-                    emit((in.op == OP_ADD ? S_ADD : in.op == OP_MUL ? S_MUL : S_RSUB) | S_B_CONST | (f_b ? S_FWD_A : 0) | f_ns, dst,
-                         b.v, a.v);
-                } else {
-                    emit((in.op == OP_ADD ? S_ADD : in.op == OP_MUL ? S_MUL : S_SUB) | (b.is_const ? S_B_CONST : 0) |
-                             (f_a ? S_FWD_A : 0) | ((f_b && !b.is_const) ? S_FWD_B : 0) | f_ns,
-                         dst, a.v, b.v);
-                }
-            }
-        }
-    }
-    flush();
-    // the kernel prefetches one instruction / one entry past the block it runs
-    sp.code.push_back(StagedInstr{S_MOV | S_B_CONST, 0, 0, 0});
-    sp.accs.push_back(StagedAcc{});
-    return sp;
-}
-
-// Host execution of a staged program on one row (self-test of stage_program, no device): `row[col]`
-// are the trace cells; ACC programs add into out[0], out[1]; DEN/LEAF programs call
-// leaf(k, numerator, denominator sum). Mirrors stages.hip StagedVM block for block (rows not
-// scaled: call before scale_rows).
-template <class Leaf>
-inline void staged_host_eval(const StagedProgram &sp, const std::vector<Fp> &row, FpExt out[2], Leaf &&leaf) {
-    std::vector<Fp> lds(sp.num_rows, Fp::zero());
-    FpExt den = FpExt::zero();
-    const uint32_t stage_rows = sp.stage_rows;
-    Fp prev = Fp::zero();  // the result of the staged instruction before (S_FWD_*), kept across blocks as the kernel does
-    const Fp poison = Fp::from_canonical(0x5eed);  // what an LDS row holds after an S_NOSTORE "store": never the value
-    for (size_t b = 0; b < sp.blocks.size(); b++) {
-        const StagedBlock &blk = sp.blocks[b];
-        for (uint32_t j = 0; j < blk.n_loads; j++) lds.at((b & 1) * stage_rows + j) = row.at(sp.loads[blk.load_off + j]);
-        for (uint32_t i = 0; i < blk.n_instr; i++) {
-            const StagedInstr &in = sp.code[blk.instr_off + i];
-            const Fp a = (in.op & S_FWD_A) ? prev : lds.at(in.a);
-            const Fp bv = (in.op & S_B_CONST) ? Fp::raw(in.b) : (in.op & S_FWD_B) ? prev : lds.at(in.b);
-            Fp r;
-            if (in.op & S_MUL) r = a * bv;
-            else if (in.op & S_ADD) r = a + bv;
-            else if (in.op & S_SUB) r = a - bv;
-            else if (in.op & S_RSUB) r = bv - a;
-            else if (in.op & S_NEG) r = -a;
-            else if (in.op & S_MOV) r = a;
-            else r = bv;
-            lds.at(in.dst) = (in.op & S_NOSTORE) ? poison : r;
-            prev = r;
-        }
-        auto weight = [&](const StagedAcc &e) {
-            FpExt w;
-            for (int k = 0; k < 4; k++) w.c[k] = Fp::raw(e.w[k]);
-            return w;
-        };
-        // accumulator 0 lives across blocks (the kernel's Acc96): a LEAF block emits and clears it
-        for (uint32_t i = 0; i < blk.n_acc0; i++) {
-            const StagedAcc &e = sp.accs[blk.acc_off + i];
-            den += weight(e) * lds.at(e.row);
-        }
-        if (blk.leaf) {
-            leaf(blk.leaf - 1, lds.at(blk.n_acc1), den);
-            den = FpExt::zero();
-        } else {
-            for (uint32_t i = 0; i < blk.n_acc1; i++) {
-                const StagedAcc &e = sp.accs[blk.acc_off + blk.n_acc0 + i];
-                out[1] += weight(e) * lds.at(e.row);
-            }
-        }
-    }
-    out[0] += den;
-}
 
 // ---------------------------------------------------------------------------------------------
-// Cached-column staged form of an ACC program (round 0; cached_vm.cuh: CachedRound0).
+// Cached-column form of a program (round 0's accumulation programs and the LogUp-GKR leaf programs; cached_vm.cuh).
 //
-// The block form above stages every column a block reads, every block. Here the LDS image is ONE pool of rows shared by
+// The block-staged VM of rounds 2-4 staged every column a block read, every block. Here the LDS image is ONE pool of rows shared by
 // a CACHE of columns that survives from block to block and by the program's live values (a slot needs a row only from
 // where its value is computed to its last read: the real Keccak-f program has 8 slots and, nine instructions in ten, at
 // most three live values). A block's load list names only the columns that are not cached (column -> LDS row), chosen
@@ -669,6 +411,11 @@ inline void staged_host_eval(const StagedProgram &sp, const std::vector<Fp> &row
 // brought there by a move (a column, a slot, a constant).
 // ---------------------------------------------------------------------------------------------
 static constexpr uint32_t C_ACC = 0x80000000u, C_BLOCK = 0x40000000u;
+// DEN / LEAF programs (the LogUp-GKR leaves): a denominator term is an accumulation into accumulator 0; a LEAF brings its
+// numerator into the result register and is followed by a marker word {C_BLOCK | C_LEAF, interaction, 0, 0} in the LAST
+// position of its group of four (the asm skips it like any block-kind word that is not first; the kernel's C++ loop sees it
+// after the group, emits (numerator, accumulator 0 + constant) and clears the accumulator).
+static constexpr uint32_t C_LEAF = 0x20000000u;
 struct CachedLayout {
     uint32_t rows = 12;      // LDS rows of the image: shared by the cached columns and the program's live values
     uint32_t max_loads = 8;  // columns a block may bring (<= CachedProgram::MAX_LOADS: the kernel's landing registers)
@@ -677,7 +424,7 @@ struct CachedProgram {
     static constexpr uint32_t MAX_LOADS = 8;
     std::vector<StagedInstr> words;  // a multiple of 8 (padded with no-ops) + one more group of four
     std::vector<uint32_t> loads;     // one record per block word: MAX_LOADS LDS rows to write, MAX_LOADS flat columns to request
-    uint32_t num_rows = 0, n_blocks = 0;
+    uint32_t num_rows = 0, n_blocks = 0, n_leaves = 0;
     uint64_t n_loads = 0;  // columns brought per evaluation (statistics)
     // operand rows -> word offsets for `rows_per_lane` trace rows per lane
     void scale_rows(uint32_t rows_per_lane) {
@@ -711,7 +458,7 @@ inline CachedLiveness cached_liveness(const Program &p) {
     auto is_binary = [](const Instr &in) { return in.op == OP_ADD || in.op == OP_SUB || in.op == OP_MUL; };
     for (size_t i = 0; i < n; i++) {
         const Instr &in = p.code[i];
-        if (in.op > OP_ACC) throw OvmFail(1, "stage_cached: accumulation programs only");
+        if (in.op > OP_LEAF) throw OvmFail(1, "stage_cached: unknown operation");
         // reads from LDS: slot operands that are not forwarded from the instruction before
         if (in.ak == K_SLOT && !(in.fwd & FWD_A) && def.at(in.a) >= 0) lv.last_read[def[in.a]] = (int32_t)i;
         if (is_binary(in) && in.bk == K_SLOT && !(in.fwd & FWD_B) && def.at(in.b) >= 0) lv.last_read[def[in.b]] = (int32_t)i;
@@ -886,16 +633,23 @@ inline CachedProgram stage_cached(const Program &p, const std::vector<FpExt> &we
             auto emit = [&](uint32_t op, uint32_t dst, uint32_t a, uint32_t b2) { cp.words.push_back(StagedInstr{op, dst, a, b2}); };
             const bool f_a = (in.fwd & FWD_A) != 0, f_b = (in.fwd & FWD_B) != 0;
             const Opnd a = opnd(in.ak, in.a, f_a);
-            if (in.op == OP_ACC) {
-                if (in.b >= weights.size()) throw OvmFail(1, "stage_cached: weight index out of range");
-                if (in.acc > 1) throw OvmFail(1, "stage_cached: accumulator out of range");
+            if (in.op >= OP_ACC) {  // ACC, DEN (accumulator 0), LEAF
                 // the value must be in the result register: forwarded from the instruction before, or moved there
                 if (!f_a) {
                     if (a.is_const) emit(S_MOVC | S_B_CONST | S_NOSTORE, 0, 0, a.v);
                     else emit(S_MOV | S_B_CONST | S_NOSTORE, 0, a.v, 0);
                 }
+                if (in.op == OP_LEAF) {
+                    while (cp.words.size() % 4 != 3) cp.words.push_back(nop);
+                    emit(C_BLOCK | C_LEAF, in.b, 0, 0);
+                    cp.n_leaves++;
+                    continue;
+                }
+                if (in.b >= weights.size()) throw OvmFail(1, "stage_cached: weight index out of range");
+                const uint32_t acc = in.op == OP_ACC ? in.acc : 0;
+                if (acc > 1) throw OvmFail(1, "stage_cached: accumulator out of range");
                 const FpExt &w = weights[in.b];
-                emit(C_ACC | w.c[0].v, ((uint32_t)in.acc << 31) | w.c[1].v, w.c[2].v, w.c[3].v);
+                emit(C_ACC | w.c[0].v, (acc << 31) | w.c[1].v, w.c[2].v, w.c[3].v);
                 continue;
             }
             const uint32_t f_ns = lv.stored[idx] ? 0 : S_NOSTORE;
@@ -931,7 +685,8 @@ inline CachedProgram stage_cached(const Program &p, const std::vector<FpExt> &we
 // Host execution of a cached program on one row (self-test of stage_cached, no device; rows not scaled). Mirrors
 // cached_vm.cuh word for word: the loads of a block word are requested (read from `row`) when the block word before it
 // runs and are written when it runs itself; the first operand of an arithmetic word is LOADED INTO the result register.
-inline void cached_host_eval(const CachedProgram &cp, const std::vector<Fp> &row, FpExt out[2]) {
+template <class Leaf>
+inline void cached_host_eval(const CachedProgram &cp, const std::vector<Fp> &row, FpExt out[2], Leaf &&leaf) {
     std::vector<Fp> lds(cp.num_rows, Fp::zero());
     Fp landing[CachedProgram::MAX_LOADS];
     Fp prev = Fp::zero();
@@ -943,6 +698,10 @@ inline void cached_host_eval(const CachedProgram &cp, const std::vector<Fp> &row
             FpExt w;
             w.c[0] = Fp::raw(in.op & 0x7fffffffu), w.c[1] = Fp::raw(in.dst & 0x7fffffffu), w.c[2] = Fp::raw(in.a), w.c[3] = Fp::raw(in.b);
             out[in.dst >> 31] += w * prev;
+        } else if ((in.op & C_BLOCK) && (in.op & C_LEAF)) {
+            if (i % 4 != 3) throw OvmFail(1, "cached_host_eval: leaf marker not last in its group");
+            leaf(in.dst, prev, out[0]);
+            out[0] = FpExt::zero();
         } else if (in.op & C_BLOCK) {
             if (i % 4) throw OvmFail(1, "cached_host_eval: block word inside a group");
             const uint32_t n_land = in.op & 0xff, n_issue = (in.op >> 8) & 0xff;
@@ -951,7 +710,6 @@ inline void cached_host_eval(const CachedProgram &cp, const std::vector<Fp> &row
             for (uint32_t j = 0; j < n_issue; j++) landing[j] = row.at(rec[CachedProgram::MAX_LOADS + j]);
         } else {
             if ((in.op & S_FWD_B) && !(in.op & S_FWD_A)) throw OvmFail(1, "cached_host_eval: second operand forwarded alone");
-            if (in.op & S_NEG) throw OvmFail(1, "cached_host_eval: the cached form has no negation");
             if (!(in.op & S_FWD_A) && !(in.op & S_MOVC)) prev = lds.at(in.a);
             const Fp a = prev;
             const Fp bv = (in.op & S_B_CONST) ? Fp::raw(in.b) : (in.op & S_FWD_B) ? prev : lds.at(in.b);
@@ -967,6 +725,9 @@ inline void cached_host_eval(const CachedProgram &cp, const std::vector<Fp> &row
             prev = r;
         }
     }
+}
+inline void cached_host_eval(const CachedProgram &cp, const std::vector<Fp> &row, FpExt out[2]) {
+    cached_host_eval(cp, row, out, [](uint32_t, Fp, const FpExt &) { throw OvmFail(1, "cached_host_eval: unexpected LEAF"); });
 }
 
 // ---------------------------------------------------------------------------------------------

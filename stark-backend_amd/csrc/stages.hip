@@ -575,161 +575,6 @@ __global__ __launch_bounds__(RED_THREADS) void round0_eval_kernel(DevProgram pro
                      add_const, partials);
 }
 
-// ---- staged round-0 interpreter (program.h: stage_program) -----------------------------------
-// Per block: [bring the block's columns into LDS rows 0..n_loads: LDS-DMA, all in flight together,
-// no VGPR staging] [arithmetic loop: operands are LDS rows, `b` may be an immediate; no
-// accumulators live in this loop's control flow] [accumulation loop: branch-free 96-bit MACs].
-// LDS image of the workgroup: word (row * R + r) * 256 + lane. The program arrays are read through
-// the constant address space so that they stay scalar loads next to the LDS-DMA writes.
-template <int R>
-struct StagedVM {
-
-    // entries are two 16-byte words: weight, then {row offset, -, -, -}
-    static __device__ __forceinline__ void run_accs(const OVM_CONST_AS uint4 *list, uint32_t n, const uint32_t *mine,
-                                                    Acc96 (&acc)[R]) {
-#if defined(__HIP_DEVICE_COMPILE__)  // (address-space-qualified loads do not parse in the host pass)
-        uint4 w = list[0], e = list[1];  // (the list is padded: reading one entry past the end is fine)
-        for (uint32_t i = n; i != 0; --i) {
-            list += 2;
-            const uint4 w_next = list[0], e_next = list[1];
-            const uint32_t *row = mine + e.x;
-#pragma unroll
-            for (int r = 0; r < R; r++) {
-                const uint32_t a = row[r * RED_THREADS];
-                mac96(acc[r].lo[0], acc[r].hi[0], a, w.x);
-                mac96(acc[r].lo[1], acc[r].hi[1], a, w.y);
-                mac96(acc[r].lo[2], acc[r].hi[2], a, w.z);
-                mac96(acc[r].lo[3], acc[r].hi[3], a, w.w);
-            }
-            w = w_next;
-            e = e_next;
-        }
-#endif
-    }
-    // prev: the result of the instruction before, per row of the lane (S_FWD_A / S_FWD_B read it instead of an LDS row,
-    // S_NOSTORE leaves the result there only)
-    static __device__ __forceinline__ void exec(const uint4 in, uint32_t *mine, Fp (&prev)[R]) {
-        const uint32_t op = in.x;  // op | flags, dst, a, b: operand fields are word offsets of LDS rows
-        Fp a[R], b[R];
-        if (op & S_FWD_A) {
-#pragma unroll
-            for (int r = 0; r < R; r++) a[r] = prev[r];
-        } else {
-            const uint32_t *arow = mine + in.z;
-#pragma unroll
-            for (int r = 0; r < R; r++) a[r] = Fp::raw(arow[r * RED_THREADS]);
-        }
-        if (op & S_B_CONST) {
-#pragma unroll
-            for (int r = 0; r < R; r++) b[r] = Fp::raw(in.w);
-        } else if (op & S_FWD_B) {
-#pragma unroll
-            for (int r = 0; r < R; r++) b[r] = prev[r];
-        } else {
-            const uint32_t *brow = mine + in.w;
-#pragma unroll
-            for (int r = 0; r < R; r++) b[r] = Fp::raw(brow[r * RED_THREADS]);
-        }
-#define OVM_RESULT(EXPR)                                            \
-    {                                                               \
-        _Pragma("unroll") for (int r = 0; r < R; r++) prev[r] = (EXPR); \
-    }
-        if (op & S_MUL) OVM_RESULT(a[r] * b[r])
-        else if (op & S_ADD) OVM_RESULT(a[r] + b[r])
-        else if (op & S_SUB) OVM_RESULT(a[r] - b[r])
-        else if (op & S_RSUB) OVM_RESULT(b[r] - a[r])
-        else if (op & S_NEG) OVM_RESULT(-a[r])
-        else if (op & S_MOV) OVM_RESULT(a[r])
-        else OVM_RESULT(b[r])  // S_MOVC
-#undef OVM_RESULT
-        if (!(op & S_NOSTORE)) {
-            uint32_t *drow = mine + in.y;
-#pragma unroll
-            for (int r = 0; r < R; r++) drow[r * RED_THREADS] = prev[r].v;
-        }
-    }
-    // Runs every block. src(col, r) = address of the lane's r-th cell of column `col`;
-    // after(second header word: acc_off, n_acc0, n_acc1 | numerator row, leaf) runs once the block's
-    // arithmetic is done.
-    template <class Src, class After>
-    static __device__ __forceinline__ void run(const DevStaged &prog, uint32_t *lds_image, const Src &src, After &&after) {
-#if defined(__HIP_DEVICE_COMPILE__)
-        uint32_t *mine = lds_image + threadIdx.x;  // this lane's word of row 0
-        const OVM_CONST_AS uint4 *blocks = (const OVM_CONST_AS uint4 *)prog.blocks;
-        const OVM_CONST_AS uint32_t *loads = (const OVM_CONST_AS uint32_t *)prog.loads;
-        const OVM_CONST_AS uint4 *code = (const OVM_CONST_AS uint4 *)prog.code;
-        // LDS-DMA through inline asm: the compiler would otherwise drain every outstanding DMA before
-        // the next LDS read (it cannot tell the two staging buffers apart); the waits are placed by hand.
-        // Destination: wave-uniform base in M0, the hardware adds lane * 4.
-        const uint32_t lds_base = (uint32_t)(size_t)(__attribute__((address_space(3))) uint32_t *)lds_image +
-                                  (__builtin_amdgcn_readfirstlane(threadIdx.x) & ~63u) * 4;
-        // M0 is the compiler's register too (it does not honour an "m0" clobber: -Winline-asm): ONE asm statement per
-        // column saves it, issues the R loads of the lane's R cells -- M0 = destination row, advanced by one LDS row
-        // (RED_THREADS words) between loads -- and restores it, so no compiler-visible instruction ever sees a changed M0 and
-        // nothing can be scheduled between a `s_mov_b32 m0` and the DMA that reads it.
-        auto request = [&](uint32_t blk) {
-            const uint4 hd = blocks[2 * blk];
-            uint32_t dst = lds_base + (blk & 1) * prog.stage_rows * (R * RED_THREADS * 4);
-            for (uint32_t j = 0; j < hd.y; j++) {
-                const uint32_t col = loads[hd.x + j];
-                const uint32_t d = __builtin_amdgcn_readfirstlane(dst);
-                uint32_t saved;
-                static_assert(R == 1 || R == 2 || R == 4, "one asm form per R");
-                static_assert(RED_THREADS * 4 == 0x400, "the asm advances M0 by one LDS row = 0x400 bytes");
-                if constexpr (R == 1) {
-                    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %2, off\n\t"
-                                 "s_mov_b32 m0, %0"
-                                 : "=&s"(saved)
-                                 : "s"(d), "v"(src(col, 0))
-                                 : "memory");
-                } else if constexpr (R == 2) {
-                    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %2, off\n\t"
-                                 "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dword %3, off\n\t"
-                                 "s_mov_b32 m0, %0"
-                                 : "=&s"(saved)
-                                 : "s"(d), "v"(src(col, 0)), "v"(src(col, 1))
-                                 : "memory", "scc");
-                } else {
-                    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %2, off\n\t"
-                                 "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dword %3, off\n\t"
-                                 "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dword %4, off\n\t"
-                                 "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dword %5, off\n\t"
-                                 "s_mov_b32 m0, %0"
-                                 : "=&s"(saved)
-                                 : "s"(d), "v"(src(col, 0)), "v"(src(col, 1)), "v"(src(col, 2)), "v"(src(col, 3))
-                                 : "memory", "scc");
-                }
-                dst += R * RED_THREADS * 4;
-            }
-        };
-        Fp prev[R];
-#pragma unroll
-        for (int r = 0; r < R; r++) prev[r] = Fp::zero();
-        request(0);
-        for (uint32_t blk = 0; blk < prog.n_blocks; blk++) {
-            const uint4 hd = blocks[2 * blk];       // load_off, n_loads, instr_off, n_instr
-            const uint4 hd2 = blocks[2 * blk + 1];  // acc_off, n_acc0, n_acc1, tag
-            __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this block's columns have landed
-            asm volatile("" ::: "memory");
-            if (blk + 1 < prog.n_blocks) request(blk + 1);  // in flight while this block runs
-            // four instructions per scalar load where the block has them (one SMEM latency per four:
-            // an outstanding scalar load would be waited for by every LDS wait, the counter is shared)
-            const OVM_CONST_AS uint4 *ip = code + hd.z;
-            uint32_t i = hd.w;
-            for (; i >= 4; i -= 4, ip += 4) {
-                const uint4 g0 = ip[0], g1 = ip[1], g2 = ip[2], g3 = ip[3];
-                exec(g0, mine, prev);
-                exec(g1, mine, prev);
-                exec(g2, mine, prev);
-                exec(g3, mine, prev);
-            }
-            for (; i != 0; --i, ++ip) exec(*ip, mine, prev);
-            after(hd2);
-        }
-#endif
-    }
-};
-
 // ---- cached-column round-0 interpreter (program.h: stage_cached; cached_vm.cuh) -----------------
 template <int R, int NOUT>
 __global__ __launch_bounds__(RED_THREADS) void round0_cached_kernel(DevCached prog, const Fp *lde,
@@ -758,43 +603,6 @@ static int round0_rows(uint32_t log_lifted, uint32_t n_out) {
     return rows;
 }
 
-// Layout policy of the staged interpreter. What it trades: rows per lane R (halves / quarters the
-// scalar work per field operation) against LDS per workgroup (R KiB per LDS row), i.e. resident
-// waves. Measured on the Keccak-shaped program: 4 workgroups per CU (<= 36 KiB of image) with R = 2
-// and the rest of the budget split between the two staging buffers and the accumulation rows.
-// A LONG program on a tall trace gets twice the image (2 workgroups per CU instead of 4) so that it runs R = 4 rows per
-// lane with room for staging: measured on the real Keccak-f AIR (42.5 K instructions, 6 slots, 2^20 rows) round 0 takes
-// 66.2 ms with 36 KiB, 52.8 with 72-80 KiB and 101 with 104+ (one workgroup per CU); on config D's 300-instruction program
-// the larger image is 0.3 ms slower, hence the threshold (profiles/r03/round0_layout_sweep.txt).
-// The larger image is taken only when it buys MORE ROWS PER LANE than the 36 KiB plan has (the Keccak-shaped stand-in,
-// 2 slots, already runs R = 4 at 36 KiB and loses 2.6 ms of 9.7 with the larger image).
-static constexpr uint32_t R0_LONG_PROGRAM = 4096, R0_LONG_PROGRAM_KIB = 72;
-static StagedPlan staged_plan_for_budget(uint32_t log_lifted, uint32_t n_out, uint32_t num_slots, uint32_t first_budget) {
-    StagedPlan plan;
-    const Tuning &tn = tuning();  // (tuning / parity-test overrides)
-    for (int rows = round0_rows(log_lifted, n_out); rows >= 1; rows >>= 1) {
-        for (uint32_t budget_kib : {first_budget, 56u}) {
-            if (budget_kib > first_budget && rows > 1) continue;  // a larger image only as the last resort
-            const uint32_t budget_rows = budget_kib / (uint32_t)rows;
-            if (budget_rows < num_slots + 6) continue;
-            uint32_t each = (budget_rows - num_slots) / 3;  // 2 staging buffers + accumulation rows
-            if (each > 8) each = 8;
-            plan.rows = (uint32_t)rows;
-            plan.stage_rows = tn.stage_rows ? (uint32_t)std::max(2, tn.stage_rows) : each;
-            plan.acc_rows = tn.acc_rows ? (uint32_t)std::max(1, tn.acc_rows) : each;
-            return plan;
-        }
-    }
-    return plan;  // rows == 0: does not fit, use the plain interpreter
-}
-StagedPlan round0_staged_plan(uint32_t log_lifted, uint32_t n_out, uint32_t num_slots, uint32_t n_instr) {
-    if (tuning().stage_kib) return staged_plan_for_budget(log_lifted, n_out, num_slots, tuning().stage_kib);
-    const StagedPlan small = staged_plan_for_budget(log_lifted, n_out, num_slots, 36);
-    if (n_instr < R0_LONG_PROGRAM || log_lifted < 18) return small;
-    const StagedPlan large = staged_plan_for_budget(log_lifted, n_out, num_slots, R0_LONG_PROGRAM_KIB);
-    return large.rows > small.rows ? large : small;
-}
-
 // Layout policy of the cached-column interpreter (round 0): rows per lane R as above; the image is ONE pool of rows for
 // cached columns and live values, R KiB per row, and it is sized for FOUR workgroups per CU (40 KiB): on the real Keccak-f
 // program (2^20 rows, R = 4: 1 024 workgroups, exactly four per CU) 8 / 9 / 10 rows take 21.9 / 21.9 / 21.5 ms and 12 or 16
@@ -818,6 +626,20 @@ CachedPlan round0_cached_plan(uint32_t log_lifted, uint32_t n_out, uint32_t min_
         return plan;
     }
     return plan;  // rows == 0: does not fit, use the plain interpreter
+}
+
+// The leaf program: one row per lane; a small image (the programs are a handful of instructions per interaction) so that
+// the launch keeps eight workgroups per CU -- it streams 4 B per cell in and 20 B per leaf out.
+CachedPlan leaves_cached_plan(uint32_t min_rows) {
+    CachedPlan plan;
+    const Tuning &tn = tuning();
+    const uint32_t budget_rows = tn.stage_kib ? tn.stage_kib : 64;
+    if (budget_rows < min_rows) return plan;  // rows == 0: the plain interpreter
+    plan.rows = 1;
+    plan.image_rows = tn.stage_rows ? std::min(budget_rows, std::max<uint32_t>(min_rows, (uint32_t)tn.stage_rows))
+                                    : std::max(min_rows, std::min(budget_rows, R0_IMAGE_ROWS_MAX));
+    plan.max_loads = tn.acc_rows ? (uint32_t)std::min(std::max(2, tn.acc_rows), 4) : 4;
+    return plan;
 }
 
 uint32_t round0_cached_grid(const DevCached &prog, uint32_t log_lifted) {
@@ -1646,56 +1468,39 @@ __global__ void gkr_leaves_kernel(DevProgram prog, const EF *leaf_const, const C
                                   FracPlanes leaves) {
     gkr_leaves_body(InterpLeaves<NS>{prog, leaf_const}, cols, log_height, leaf_base, leaf_log_len, norm, leaves);
 }
-// Staged form (program.h: stage_program on the DEN/LEAF program): a block's DENs are its
-// accumulation list; a block that ends an interaction carries the LEAF (numerator row, index).
-__device__ __forceinline__ void gkr_leaves_staged_body(const DevStaged &prog, const EF *leaf_const, const ColDesc *cols,
-                                                       uint32_t log_height, const uint64_t *leaf_base,
-                                                       const uint32_t *leaf_log_len, Fp norm, FracPlanes leaves,
-                                                       uint32_t bx) {
+// Cached-column form (program.h: stage_cached on the DEN/LEAF program; cached_vm.cuh: CachedCore<1, 1, true>): one row per
+// lane, trace columns by pointer (the load records were resolved against the trace's column descriptors on the host:
+// Prover::make_leaf_prog), a denominator term is an accumulation, a LEAF marker emits.
+__device__ __forceinline__ void gkr_leaves_cached_body(const DevCached &prog, const EF *leaf_const, uint32_t log_height,
+                                                       const uint64_t *leaf_base, const uint32_t *leaf_log_len, Fp norm,
+                                                       FracPlanes leaves, uint32_t bx) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    extern __shared__ uint32_t lds_image[];
     const uint64_t row = (uint64_t)bx * blockDim.x + threadIdx.x;
     const bool live = row < (1ull << log_height);
-    const uint64_t at = live ? row : 0;  // (dead lanes of a short trace still feed the wave's LDS-DMA)
-    const uint32_t *mine = lds_image + threadIdx.x;
-    const OVM_CONST_AS uint4 *accs = (const OVM_CONST_AS uint4 *)prog.accs;
-    const OVM_CONST_AS uint4 *descs = (const OVM_CONST_AS uint4 *)cols;  // {ptr lo, ptr hi, log_height, rot}
-    static_assert(sizeof(ColDesc) == 16, "ColDesc is read as one 16-byte scalar load");
+    const uint64_t at = live ? row : 0;  // (dead lanes of a short trace read row 0 and emit nothing)
+    const uint64_t hmask = (1ull << log_height) - 1;
+    const uint32_t o[4] = {(uint32_t)at << 2, (uint32_t)((at + 1) & hmask) << 2, 0, 0};
     const LeafEmit emit{leaves, leaf_base, leaf_log_len, log_height, row, norm};
-    Acc96 acc[1];
-    acc[0].clear();
-    StagedVM<1>::run(
-        prog, lds_image,
-        [&](uint32_t col, int) {
-            const uint4 d = descs[col];
-            const Fp *ptr = (const Fp *)(((uint64_t)d.y << 32) | d.x);
-            return ptr + ((at + d.w) & ((1ull << d.z) - 1));
-        },
-        [&](const uint4 hd2) {
-            StagedVM<1>::run_accs(accs + 2 * hd2.x, hd2.y, mine, acc);
-            if (hd2.w) {
-                const uint32_t k = hd2.w - 1;
-                const EF den = acc[0].finish() + ld_ef(leaf_const + k);
-                const Fp numer = Fp::raw(mine[hd2.z]);
-                if (live) emit(k, numer, den);
-                acc[0].clear();
-            }
-        });
+    Acc96 acc0[1], acc1[1];
+    acc0[0].clear(), acc1[0].clear();
+    CachedCore<1, 1, true>::run(prog, 0, 0, o, acc0, acc1, [&](uint32_t k, Fp numer, const Acc96 &den_sum) {
+        const EF den = den_sum.finish() + ld_ef(leaf_const + k);
+        if (live) emit(k, numer, den);
+    });
 #endif
 }
-__global__ __launch_bounds__(256) void gkr_leaves_staged_kernel(DevStaged prog, const EF *leaf_const,
-                                                                const ColDesc *cols, uint32_t log_height,
+__global__ __launch_bounds__(256) void gkr_leaves_cached_kernel(DevCached prog, const EF *leaf_const, uint32_t log_height,
                                                                 const uint64_t *leaf_base, const uint32_t *leaf_log_len,
                                                                 Fp norm, FracPlanes leaves) {
-    gkr_leaves_staged_body(prog, leaf_const, cols, log_height, leaf_base, leaf_log_len, norm, leaves, blockIdx.x);
+    gkr_leaves_cached_body(prog, leaf_const, log_height, leaf_base, leaf_log_len, norm, leaves, blockIdx.x);
 }
-__global__ __launch_bounds__(256) void gkr_leaves_staged_batched_kernel(const LeavesJob *jobs, uint32_t n_jobs,
+__global__ __launch_bounds__(256) void gkr_leaves_cached_batched_kernel(const LeavesJob *jobs, uint32_t n_jobs,
                                                                         FracPlanes leaves) {
     uint32_t j = 0;
     j = find_job(n_jobs, blockIdx.x, [&](uint32_t i) { return jobs[i].wg0; });
     const LeavesJob job = jobs[j];
-    gkr_leaves_staged_body(job.prog, job.leaf_const, job.cols, job.log_height, job.leaf_base, job.leaf_log_len, job.norm,
-                           leaves, blockIdx.x - job.wg0);
+    gkr_leaves_cached_body(job.prog, job.leaf_const, job.log_height, job.leaf_base, job.leaf_log_len, job.norm, leaves,
+                           blockIdx.x - job.wg0);
 }
 int gkr_eval_leaves_batched(const LeavesJob *d_jobs, const LeavesJob *h_jobs, uint32_t n_jobs, FracPlanes leaves,
                             hipStream_t s) {
@@ -1703,24 +1508,24 @@ int gkr_eval_leaves_batched(const LeavesJob *d_jobs, const LeavesJob *h_jobs, ui
     uint32_t grid = 0;
     size_t lds_bytes = 0;
     for (uint32_t j = 0; j < n_jobs; j++) {
-        if (!h_jobs[j].prog.blocks || h_jobs[j].prog.rows != 1 || h_jobs[j].wg0 != grid || h_jobs[j].gx == 0)
+        if (!h_jobs[j].prog.words || h_jobs[j].prog.rows != 1 || h_jobs[j].wg0 != grid || h_jobs[j].gx == 0)
             return (int)hipErrorInvalidValue;
         grid += h_jobs[j].gx;
         lds_bytes = std::max(lds_bytes, (size_t)h_jobs[j].prog.num_rows * RED_THREADS * 4);
     }
-    OVM_LAUNCH(gkr_leaves_staged_batched_kernel, dim3(grid), dim3(256), lds_bytes, s, d_jobs, n_jobs, leaves);
+    OVM_LAUNCH(gkr_leaves_cached_batched_kernel, dim3(grid), dim3(256), lds_bytes, s, d_jobs, n_jobs, leaves);
     OVM_CHECK_LAUNCH();
     return 0;
 }
 
-int gkr_eval_leaves(const DevProgram &prog, const DevStaged &staged, const EF *d_leaf_const, const ColDesc *d_cols,
+int gkr_eval_leaves(const DevProgram &prog, const DevCached &staged, const EF *d_leaf_const, const ColDesc *d_cols,
                     uint32_t log_height, const uint64_t *d_leaf_base, const uint32_t *d_leaf_log_len, Fp norm,
                     FracPlanes leaves, hipStream_t s) {
     uint32_t grid = ceil_div(1ull << log_height, 256);
-    if (staged.blocks) {
+    if (staged.words) {
         const size_t lds_bytes = (size_t)staged.num_rows * RED_THREADS * 4;
-        OVM_LAUNCH(gkr_leaves_staged_kernel, dim3(grid), dim3(256), lds_bytes, s, staged, d_leaf_const, d_cols,
-                           log_height, d_leaf_base, d_leaf_log_len, norm, leaves);
+        OVM_LAUNCH(gkr_leaves_cached_kernel, dim3(grid), dim3(256), lds_bytes, s, staged, d_leaf_const, log_height, d_leaf_base,
+                           d_leaf_log_len, norm, leaves);
         OVM_CHECK_LAUNCH();
         return 0;
     }
@@ -1747,11 +1552,6 @@ __global__ void gkr_build_kernel(FracPlanes child, FracPlanes parent, uint64_t n
     stp(parent.P(), parent.stride, i, p0 * q1 + q0 * p1);
     stp(parent.Q(), parent.stride, i, q0 * q1);
 }
-// Two levels per pass: grandparent i and its two parents 2i, 2i+1 from children 4i..4i+3 -- the parents are written (their
-// layer's sumcheck reads them) but never read back by the build: 1.75 n of traffic per pair of levels instead of 2.25 n
-// (the build runs at the HBM ceiling: 5.6-5.7 TB/s). The same three products per fraction sum as gkr_build_kernel, so every
-// value is the one the one-level passes compute. Lanes n_grand and n_grand + 1 take the (at most two) parents of the range
-// that have no sibling inside it: edge e = parent edge_parent[e] from the two children at edge_child[e].
 // Three levels per pass: 1.875 n of traffic per three levels instead of 3 x 1.125 n. Lane i: children 8i..8i+7 -> parents
 // 4i..4i+3, grandparents 2i, 2i+1, great-grandparent i. What the range holds outside those aligned blocks goes to extra lanes
 // of the same launch: at most two grandparents whose sibling is outside the range (each with its two parents, from four

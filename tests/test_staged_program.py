@@ -1,10 +1,10 @@
-"""Host-side check of the staged constraint-program form (csrc/program.h: stage_program -- what the
-round-0 and GKR-leaf kernels of the HIP path execute). `ovm_hip_staged_selftest` stages the
-zerocheck, LogUp and GKR-leaf programs of every AIR of a key with a given LDS layout and runs them on
-a random row next to the plain register-program interpreter, entirely on the host: block cutting,
-double-buffered staging rows, operand normalisation (constants on the left, folding, RSUB/MOVC),
-deferred accumulation lists, producer redirection and one-LEAF-per-block are all exercised without a
-GPU. (The GPU parity tests then pin the kernels that execute this form.)"""
+"""Host-side check of the cached-column program form (csrc/program.h: linear_terms, stage_cached -- what the round-0 and
+GKR-leaf kernels of the HIP path execute, csrc/cached_vm.cuh). `ovm_hip_staged_selftest` compiles the zerocheck, LogUp and
+GKR-leaf programs of every AIR of a key, takes the accumulation roots apart into linear terms at several support caps, stages
+every form with a given image (rows shared by cached columns and live values; columns brought per block) and runs it on a
+random row next to the plain register-program interpreter and a direct evaluation of the DAG, entirely on the host: block
+cutting, the row pool, eviction, operand normalisation (constants on the left, commuted forwards, RSUB / MOVC), accumulation
+words, LEAF markers at group ends are all exercised without a GPU. (The GPU parity tests then pin the kernels.)"""
 import numpy as np
 import pytest
 
