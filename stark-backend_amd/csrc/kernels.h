@@ -95,7 +95,7 @@ int fold_ple(const ColDesc *d_cols, const int32_t *d_twins, uint32_t n_cols, uin
 // MLE round on folded EF matrices (n_cols x 2^log_h, column-major), node-grouped program:
 //   out[2*(X-1)+o] = sum_y eq[y] * program_o(row interpolated at X from rows 2y, 2y+1);
 //   grid = (y blocks, X = 1..degree, group).
-int mle_round_eval_grouped(const Instr *d_code, const uint32_t *d_off, uint32_t n_groups, uint32_t max_slots,
+int mle_round_eval_grouped(const Instr *d_code, const uint32_t *d_off, uint32_t n_groups, uint32_t max_slots, uint32_t lds_slots,
                            const EF *d_weights, const EF *mats, uint32_t log_h, uint32_t degree, uint32_t n_out,
                            const EF *d_eq, EF add_const, const RedOut &ro, hipStream_t s);
 
@@ -114,8 +114,8 @@ struct MleJob {
     EF *out;
     EF add_const;
     uint32_t log_h, n_out, n_groups, gx;
-    uint32_t z0, max_slots;
-    uint32_t partials_cap, pad;  // capacity of `partials` in EF (checked by the launcher)
+    uint32_t z0, max_slots;   // max_slots: what an executor that ignores the forwarding hints needs (program.h: compact_slots)
+    uint32_t partials_cap, lds_slots;  // capacity of `partials` in EF (checked by the launcher); slots of the stored values
 };
 int mle_round_eval_batched(const MleJob *d_jobs, const MleJob *h_jobs, uint32_t n_jobs, uint32_t degree,
                            uint32_t *d_counters, const RedOut &ro, hipStream_t s);
@@ -123,7 +123,10 @@ int mle_round_eval_batched(const MleJob *d_jobs, const MleJob *h_jobs, uint32_t 
 // lanes enumerate pairs, all points in the lane; job.gx from mle_round_gx(log_h, degree, n_groups, true).
 int mle_round_eval_batched_lds(const MleJob *d_jobs, const MleJob *h_jobs, uint32_t n_jobs, uint32_t degree,
                                uint32_t *d_counters, const RedOut &ro, hipStream_t s);
-bool mle_lds_eligible(uint32_t max_slots, uint32_t degree);
+bool mle_lds_eligible(uint32_t lds_slots, uint32_t degree);
+// LDS rows (of D x 4 KiB... one per slot) the LDS-slot kernel takes: the stored slots, or -- test hook OVM_MLE_FWD=0, every
+// result stored -- all of them
+uint32_t mle_lds_rows(uint32_t lds_slots, uint32_t max_slots);
 // workgroups per (job, group) of the batched kernel (lanes enumerate (pair, point))
 uint32_t mle_round_batched_gx(uint32_t log_h, uint32_t degree, uint32_t n_groups);
 // workgroups along y that mle_round_eval_grouped uses for 2^(log_h-1) pairs and this many groups

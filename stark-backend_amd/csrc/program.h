@@ -1016,8 +1016,98 @@ inline TermRoots linear_terms(const AirKey &air, const ColumnMap &cm, const std:
 struct GroupedProgram {
     std::vector<Instr> code;
     std::vector<uint32_t> off;  // n_groups + 1 offsets into code
-    uint32_t max_slots = 1;
+    uint32_t max_slots = 1;  // slots an executor that ignores the forwarding hints needs (the stored ones + one scratch slot)
+    uint32_t lds_slots = 1;  // slots of the values that are really stored: what an executor that honours the hints needs
 };
+
+// Slots renumbered by what is STORED. compile_program gives every result a slot, also the ones that live in the result
+// register only (FWD_NOSTORE: read by the next instruction through the register). An executor that honours the hints
+// (the LDS-slot kernel of the multilinear rounds: D x 4 KiB of LDS per slot and workgroup) needs rows only for values that
+// are written. Here the slots are re-coloured by live range: a stored value (from the instruction that computes it to its
+// last read that is not forwarded) takes the lowest free slot; a register-only value -- which an executor that ignores
+// the hints still writes and reads back one instruction later -- then goes into a slot no stored value occupies during
+// those two instructions, else into ONE scratch slot on top. Returns the number of slots of the stored values (what the
+// hint-honouring executor needs); p.num_slots becomes what an executor that ignores the hints needs (never more than
+// before). The real Keccak-f groups: 5 -> 4 stored.
+inline uint32_t compact_slots(Program &p) {
+    const size_t n = p.code.size();
+    auto is_binary = [](const Instr &in) { return in.op == OP_ADD || in.op == OP_SUB || in.op == OP_MUL; };
+    std::vector<int32_t> def(p.num_slots + 1, -1), last_read(n, -1);
+    for (size_t i = 0; i < n; i++) {
+        const Instr &in = p.code[i];
+        if (in.ak == K_SLOT && !(in.fwd & FWD_A) && def.at(in.a) >= 0) last_read[def[in.a]] = (int32_t)i;
+        if (is_binary(in) && in.bk == K_SLOT && !(in.fwd & FWD_B) && def.at(in.b) >= 0) last_read[def[in.b]] = (int32_t)i;
+        if (in.op <= OP_NEG) def.at(in.dst) = (int32_t)i;
+    }
+    // pass 1: the stored values, lowest free slot first
+    std::vector<uint32_t> new_of_value(n, ~0u);  // the new slot of the value instruction i computes
+    std::vector<size_t> dies(n, 0);
+    uint32_t stored = 0;
+    {
+        std::vector<std::vector<uint32_t>> dying(n + 1);
+        std::vector<uint32_t> free_ids;
+        for (size_t i = 0; i < n; i++) {
+            const Instr &in = p.code[i];
+            if (in.op <= OP_NEG && !(in.fwd & FWD_NOSTORE)) {
+                uint32_t id;
+                if (free_ids.empty()) {
+                    id = stored++;
+                } else {
+                    auto it = std::min_element(free_ids.begin(), free_ids.end());
+                    id = *it;
+                    free_ids.erase(it);
+                }
+                new_of_value[i] = id;
+                dies[i] = std::max<size_t>(i, last_read[i] < 0 ? 0 : (size_t)last_read[i]);
+                dying[dies[i]].push_back(id);
+            }
+            for (uint32_t id : dying[i]) free_ids.push_back(id);
+        }
+    }
+    // pass 2: a register-only value (written at i, read back at i + 1 by an executor that ignores the hints) goes where no
+    // stored value lives during those two instructions -- the highest such slot --, else into one scratch slot on top
+    std::vector<std::vector<std::pair<size_t, size_t>>> busy(stored);
+    for (size_t i = 0; i < n; i++)
+        if (new_of_value[i] != ~0u) busy[new_of_value[i]].push_back({i, dies[i]});
+    bool scratch = false;
+    for (size_t i = 0; i < n; i++) {
+        const Instr &in = p.code[i];
+        if (!(in.op <= OP_NEG && (in.fwd & FWD_NOSTORE))) continue;
+        uint32_t id = stored;
+        for (uint32_t k = stored; k-- > 0;) {
+            bool free_here = true;
+            for (auto &iv : busy[k])
+                if (iv.first <= i + 1 && iv.second >= i) {
+                    free_here = false;
+                    break;
+                }
+            if (free_here) {
+                id = k;
+                break;
+            }
+        }
+        scratch |= id == stored;
+        new_of_value[i] = id;
+    }
+    // rename
+    std::vector<int32_t> value_in(p.num_slots + 1, -1);  // the instruction whose result an OLD slot holds
+    for (size_t i = 0; i < n; i++) {
+        Instr &in = p.code[i];
+        auto renamed = [&](uint32_t old) -> uint32_t {
+            const int32_t v = value_in.at(old);
+            return v < 0 ? 0 : new_of_value[(size_t)v];
+        };
+        if (in.ak == K_SLOT) in.a = renamed(in.a);
+        if (is_binary(in) && in.bk == K_SLOT) in.b = renamed(in.b);
+        if (in.op <= OP_NEG) {
+            value_in.at(in.dst) = (int32_t)i;
+            in.dst = (uint16_t)new_of_value[i];
+        }
+    }
+    p.num_slots = std::max<uint32_t>(stored + (scratch ? 1 : 0), 1);
+    return std::max<uint32_t>(stored, 1);
+}
+
 // `slot_target`: the groups are what the multilinear rounds interpret on extension-field values, D points at a time,
 // with their slots in LDS (stages.hip: mle_round_points_lds_kernel): a group qualifies with at most 19 / D slots, so the
 // compiler is asked for that few (it recomputes cheap shared nodes until the group fits or its code would double).
@@ -1072,6 +1162,7 @@ inline GroupedProgram compile_grouped(const AirKey &air, const ColumnMap &cm, co
         }
         std::vector<Root> sub(roots.begin() + lo, roots.begin() + hi);
         Program p = compile_program(air, cm, public_values, sub, num_weights, slot_target);
+        g.lds_slots = std::max(g.lds_slots, compact_slots(p));
         g.code.insert(g.code.end(), p.code.begin(), p.code.end());
         g.off.push_back((uint32_t)g.code.size());
         g.max_slots = std::max(g.max_slots, p.num_slots);

@@ -1274,6 +1274,45 @@ int ovm_hip_staged_selftest(const uint32_t *blob, uint64_t words, uint32_t stage
                     if (!(alt[0] == want[0]) || !(alt[1] == want[1])) fail("recomputing");
                 }
                 (void)got;
+                // the grouped form of the multilinear rounds with its slots re-coloured by what is stored (compact_slots): the
+                // groups' sums add up to the program's, for an executor that ignores the forwarding hints (every result
+                // stored, register-only values in the shared scratch slot) and for one that honours them (result register;
+                // a value flagged register-only is poisoned in its slot)
+                for (uint32_t n_groups : {1u, 3u, 16u}) {
+                    const GroupedProgram gp = compile_grouped(air, cm, pv, roots, nw, n_groups, 3);
+                    EF plain[2] = {EF::zero(), EF::zero()}, fwd[2] = {EF::zero(), EF::zero()};
+                    for (size_t g = 0; g + 1 < gp.off.size(); g++) {
+                        std::vector<Fp> sl(gp.max_slots + 1);
+                        run_program_acc<Fp>(gp.code.data() + gp.off[g], gp.off[g + 1] - gp.off[g], w.data(), sl.data(), fetch, plain);
+                        std::vector<Fp> st(gp.lds_slots + 1, Fp::from_canonical(0x5eed));
+                        Fp prev = Fp::zero();
+                        for (uint32_t pc = gp.off[g]; pc < gp.off[g + 1]; pc++) {
+                            const Instr &in = gp.code[pc];
+                            auto opnd = [&](uint8_t kind, uint32_t payload, bool forwarded) {
+                                if (forwarded) return prev;
+                                if (kind == K_SLOT) {
+                                    if (payload >= gp.lds_slots) fail("grouped form (a stored slot beyond lds_slots)");
+                                    return st[payload];
+                                }
+                                return kind == K_COL ? row[payload] : Fp::raw(payload);
+                            };
+                            const Fp a = opnd(in.ak, in.a, in.fwd & FWD_A);
+                            if (in.op == OP_ACC) {
+                                fwd[in.acc] = fwd[in.acc] + w[in.b] * a;
+                                continue;
+                            }
+                            const Fp b = in.op == OP_NEG ? Fp::zero() : opnd(in.bk, in.b, in.fwd & FWD_B);
+                            const Fp r = in.op == OP_ADD ? a + b : in.op == OP_SUB ? a - b : in.op == OP_MUL ? a * b : -a;
+                            if (!(in.fwd & FWD_NOSTORE)) {
+                                if (in.dst >= gp.lds_slots) fail("grouped form (a stored result beyond lds_slots)");
+                                st[in.dst] = r;
+                            }
+                            prev = r;
+                        }
+                    }
+                    if (!(plain[0] == want[0]) || !(plain[1] == want[1])) fail("grouped form, hints ignored");
+                    if (!(fwd[0] == want[0]) || !(fwd[1] == want[1])) fail("grouped form, hints honoured");
+                }
                 // the cached-column form (round 0), of the program as compiled and of its linear terms: the roots taken
                 // apart down to expressions of at most `cap` columns and re-ordered (cap 0: every sum, down to the products)
                 CachedLayout cl;

@@ -1108,7 +1108,7 @@ __device__ __forceinline__ void mle_points_lds_body(const Instr *gcode, uint32_t
     }
 }
 template <int D>
-__global__ __launch_bounds__(RED_THREADS) void mle_round_points_lds_kernel(const Instr *code, const uint32_t *off,
+__global__ __launch_bounds__(RED_THREADS, 3) void mle_round_points_lds_kernel(const Instr *code, const uint32_t *off,
                                                                            const EF *weights, const EF *mats,
                                                                            uint32_t log_h, uint32_t n_out, const EF *eq,
                                                                            EF add_const, RedOut ro, uint32_t fwd_mask) {
@@ -1204,7 +1204,7 @@ __global__ __launch_bounds__(RED_THREADS) void mle_round_batched_kernel(const Ml
 // multilinear rounds (9.6 of 23 ms); here the operands of four instructions are in flight together and a pair is
 // fetched once.
 template <int D>
-__global__ __launch_bounds__(RED_THREADS) void mle_round_batched_lds_kernel(const MleJob *jobs, uint32_t n_jobs,
+__global__ __launch_bounds__(RED_THREADS, 3) void mle_round_batched_lds_kernel(const MleJob *jobs, uint32_t n_jobs,
                                                                             uint32_t *counters, RedOut ro, uint32_t fwd_mask) {
     const uint32_t j = find_job(n_jobs, blockIdx.z, [&](uint32_t i) { return jobs[i].z0; });
     const MleJob job = jobs[j];
@@ -1262,13 +1262,14 @@ int mle_round_eval_batched_lds(const MleJob *d_jobs, const MleJob *h_jobs, uint3
     if (degree == 0 || degree > 4) return (int)hipErrorInvalidValue;
     uint32_t gx = 1, gz = 0, max_slots = 1;
     for (uint32_t j = 0; j < n_jobs; j++) {
+        const uint32_t rows = mle_lds_rows(h_jobs[j].lds_slots, h_jobs[j].max_slots);
         if (h_jobs[j].log_h == 0 || h_jobs[j].n_groups == 0 || h_jobs[j].n_out > 2 || h_jobs[j].z0 != gz ||
-            h_jobs[j].max_slots * degree > MLE_LDS_MAX_ROWS ||
+            rows * degree > MLE_LDS_MAX_ROWS ||
             (uint64_t)h_jobs[j].gx * h_jobs[j].n_groups * 2 * degree > h_jobs[j].partials_cap)
             return (int)hipErrorInvalidValue;
         gx = std::max(gx, h_jobs[j].gx);
         gz += h_jobs[j].n_groups;
-        max_slots = std::max(max_slots, h_jobs[j].max_slots);
+        max_slots = std::max(max_slots, rows);
     }
     dim3 grid(gx, 1, gz);
     const size_t lds_bytes = (size_t)max_slots * degree * 4 * RED_THREADS * sizeof(uint32_t);
@@ -1283,18 +1284,19 @@ int mle_round_eval_batched_lds(const MleJob *d_jobs, const MleJob *h_jobs, uint3
     OVM_CHECK_LAUNCH();
     return 0;
 }
-bool mle_lds_eligible(uint32_t max_slots, uint32_t degree) {
-    return tuning().mle_lds_slots && max_slots * degree <= MLE_LDS_MAX_ROWS;
+bool mle_lds_eligible(uint32_t lds_slots, uint32_t degree) {
+    return tuning().mle_lds_slots && lds_slots * degree <= MLE_LDS_MAX_ROWS;
 }
+uint32_t mle_lds_rows(uint32_t lds_slots, uint32_t max_slots) { return tuning().mle_forward ? lds_slots : max_slots; }
 
-int mle_round_eval_grouped(const Instr *d_code, const uint32_t *d_off, uint32_t n_groups, uint32_t max_slots,
+int mle_round_eval_grouped(const Instr *d_code, const uint32_t *d_off, uint32_t n_groups, uint32_t max_slots, uint32_t lds_slots,
                            const EF *d_weights, const EF *mats, uint32_t log_h, uint32_t degree, uint32_t n_out,
                            const EF *d_eq, EF add_const, const RedOut &ro, hipStream_t s) {
     if (degree == 0 || degree > 4 || n_out > 2 || log_h == 0 || n_groups == 0) return (int)hipErrorInvalidValue;
     const uint32_t gx = mle_round_gx(log_h, degree, n_groups);
-    if (mle_lds_eligible(max_slots, degree)) {
+    if (mle_lds_eligible(mle_lds_rows(lds_slots, max_slots), degree)) {
         dim3 grid(gx, 1, n_groups);
-        const size_t lds_bytes = (size_t)max_slots * degree * 4 * RED_THREADS * sizeof(uint32_t);
+        const size_t lds_bytes = (size_t)mle_lds_rows(lds_slots, max_slots) * degree * 4 * RED_THREADS * sizeof(uint32_t);
 #define CALLD(DD)                                                                                                        \
     OVM_LAUNCH((mle_round_points_lds_kernel<DD>), grid, dim3(RED_THREADS), lds_bytes, s, d_code, d_off, d_weights, mats, \
                        log_h, n_out, d_eq, add_const, red_inline(ro, gx * n_groups, 2 * degree),               \
