@@ -95,9 +95,12 @@ int fold_ple(const ColDesc *d_cols, const int32_t *d_twins, uint32_t n_cols, uin
 // MLE round on folded EF matrices (n_cols x 2^log_h, column-major), node-grouped program:
 //   out[2*(X-1)+o] = sum_y eq[y] * program_o(row interpolated at X from rows 2y, 2y+1);
 //   grid = (y blocks, X = 1..degree, group).
-int mle_round_eval_grouped(const Instr *d_code, const uint32_t *d_off, uint32_t n_groups, uint32_t max_slots, uint32_t lds_slots,
-                           const EF *d_weights, const EF *mats, uint32_t log_h, uint32_t degree, uint32_t n_out,
-                           const EF *d_eq, EF add_const, const RedOut &ro, hipStream_t s);
+// d_words / d_woff / lds_rows / d_weights_pre: the same groups in accumulator form (program.h: MleWords, MleWeight) for the
+// LDS-slot executor, taken when lds_rows x degree fits (mle_lds_eligible); d_words may be null (slots in private memory).
+int mle_round_eval_grouped(const Instr *d_code, const uint32_t *d_off, uint32_t n_groups, uint32_t max_slots, const MleWord *d_words,
+                           const uint32_t *d_woff, uint32_t lds_rows, const EF *d_weights, const MleWeight *d_weights_pre,
+                           const EF *mats, uint32_t log_h, uint32_t degree, uint32_t n_out, const EF *d_eq, EF add_const,
+                           const RedOut &ro, hipStream_t s);
 
 // The same for many (trace, program) jobs in ONE launch: the late rounds of a many-AIR proof are
 // dozens of launches of a handful of workgroups each, serialised by the stream; batched they run
@@ -115,7 +118,11 @@ struct MleJob {
     EF add_const;
     uint32_t log_h, n_out, n_groups, gx;
     uint32_t z0, max_slots;   // max_slots: what an executor that ignores the forwarding hints needs (program.h: compact_slots)
-    uint32_t partials_cap, lds_slots;  // capacity of `partials` in EF (checked by the launcher); slots of the stored values
+    uint32_t partials_cap, lds_slots;  // capacity of `partials` in EF (checked by the launcher); LDS rows of the words
+    // the accumulator form for the LDS-slot kernel (program.h: MleWords; null for jobs of the other kernel)
+    const MleWord *words;
+    const uint32_t *woff;
+    const MleWeight *weights_pre;
 };
 int mle_round_eval_batched(const MleJob *d_jobs, const MleJob *h_jobs, uint32_t n_jobs, uint32_t degree,
                            uint32_t *d_counters, const RedOut &ro, hipStream_t s);
@@ -124,9 +131,6 @@ int mle_round_eval_batched(const MleJob *d_jobs, const MleJob *h_jobs, uint32_t 
 int mle_round_eval_batched_lds(const MleJob *d_jobs, const MleJob *h_jobs, uint32_t n_jobs, uint32_t degree,
                                uint32_t *d_counters, const RedOut &ro, hipStream_t s);
 bool mle_lds_eligible(uint32_t lds_slots, uint32_t degree);
-// LDS rows (of D x 4 KiB... one per slot) the LDS-slot kernel takes: the stored slots, or -- test hook OVM_MLE_FWD=0, every
-// result stored -- all of them
-uint32_t mle_lds_rows(uint32_t lds_slots, uint32_t max_slots);
 // workgroups per (job, group) of the batched kernel (lanes enumerate (pair, point))
 uint32_t mle_round_batched_gx(uint32_t log_h, uint32_t degree, uint32_t n_groups);
 // workgroups along y that mle_round_eval_grouped uses for 2^(log_h-1) pairs and this many groups

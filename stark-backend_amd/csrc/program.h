@@ -1209,6 +1209,115 @@ BB_HD void run_program_acc(const Instr *code, uint32_t n_instr, const FpExt *wei
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Accumulator form of a grouped program (the LDS-slot kernels of the multilinear rounds, stages.hip: mle_words_body).
+// One RESULT REGISTER set holds the value of the word before; every word has at most one memory operand:
+//     LOAD  acc = operand                     ADD / SUB / MUL  acc = acc op operand        RSUB  acc = operand - acc
+//     ACC   out[k] += W[z] * (operand | acc)  NOP
+// operand: a slot (an LDS row), a column (the pair of the lane's row, all points made from it), a base-field constant
+// (only limb 0 is touched: no broadcast), or the result register itself. An instruction whose first operand is the
+// result before it (FWD_A) is one word; with FWD_B the operands change places (SUB becomes RSUB); otherwise a LOAD word
+// goes in front. `store`: the result is also written to its slot (absent on FWD_NOSTORE results). What the compiler
+// made of the same machine written over Instr -- a copy of the result registers into `prev` and back per instruction,
+// byte-wide instruction fetches through the vector memory path with a wait for ALL loads in flight in front of every
+// decode, a 4 x D-word broadcast per constant -- was 178 VALU instructions per Keccak-f instruction where the arithmetic
+// needs about 100.
+// A group's words: a multiple of MLE_WORD_GROUP x 2 (NOP-padded; the executor alternates two landing register sets over
+// groups of MLE_WORD_GROUP words), followed by 2 groups of NOPs (the word fetch runs two groups ahead).
+// ---------------------------------------------------------------------------------------------
+struct MleWord {
+    uint32_t x;  // [2:0] op, [4:3] operand kind, [5] store, [6] accumulator index, [31:16] destination slot
+    uint32_t y;  // operand payload: slot / flat column / Montgomery constant
+    uint32_t z;  // ACC: weight index
+    uint32_t w;
+};
+enum : uint32_t { W_LOAD = 0, W_ADD, W_SUB, W_RSUB, W_MUL, W_ACC, W_NOP = 7 };
+enum : uint32_t { WK_SLOT = 0, WK_COL, WK_CONST, WK_SELF };
+static constexpr uint32_t MLE_WORD_GROUP = 4;
+struct MleWords {
+    std::vector<MleWord> words;
+    std::vector<uint32_t> off;  // n_groups + 1 offsets into words (a group's executable words: off[g+1] - off[g] - 2 groups)
+    uint32_t rows = 1;          // slots the executor needs
+};
+// a weight in the form the executor's multiply-adds take it: b0..b3, 11 b1..11 b3 (bb31.h FpExt::Pre); 32 bytes = one
+// s_load_dwordx8
+struct MleWeight {
+    uint32_t b[4], w[3], pad;
+};
+inline MleWeight mle_weight_of(const FpExt &e) {
+    const FpExt::Pre p = e.pre();
+    return MleWeight{{p.b[0].v, p.b[1].v, p.b[2].v, p.b[3].v}, {p.w[0].v, p.w[1].v, p.w[2].v}, 0};
+}
+inline MleWords encode_mle_words(const GroupedProgram &gp, bool honour_hints = true) {
+    MleWords out;
+    out.rows = honour_hints ? gp.lds_slots : gp.max_slots;
+    out.off.push_back(0);
+    auto word = [](uint32_t op, uint32_t kind, uint32_t payload, bool store = false, uint32_t dst = 0, uint32_t k = 0,
+                   uint32_t widx = 0) {
+        return MleWord{op | kind << 3 | (store ? 32u : 0u) | (k & 1) << 6 | dst << 16, payload, widx, 0};
+    };
+    auto kind_of = [](uint8_t k) -> uint32_t { return k == K_SLOT ? WK_SLOT : k == K_COL ? WK_COL : WK_CONST; };
+    for (size_t g = 0; g + 1 < gp.off.size(); g++) {
+        for (uint32_t i = gp.off[g]; i < gp.off[g + 1]; i++) {
+            const Instr &in = gp.code[i];
+            const uint16_t fwd = honour_hints ? in.fwd : 0;
+            const bool fa = fwd & FWD_A, fb = in.op <= OP_MUL && (fwd & FWD_B);
+            const bool store = !(fwd & FWD_NOSTORE);
+            if (in.op == OP_ACC) {
+                out.words.push_back(fa ? word(W_ACC, WK_SELF, 0, false, 0, in.acc, in.b)
+                                       : word(W_ACC, kind_of(in.ak), in.a, false, 0, in.acc, in.b));
+            } else if (in.op == OP_NEG) {  // -a = 0 - a
+                if (!fa) out.words.push_back(word(W_LOAD, kind_of(in.ak), in.a));
+                out.words.push_back(word(W_RSUB, WK_CONST, 0, store, in.dst));
+            } else if (in.op <= OP_MUL) {
+                const uint32_t op = in.op == OP_ADD ? W_ADD : in.op == OP_SUB ? W_SUB : W_MUL;
+                const uint32_t rop = in.op == OP_SUB ? W_RSUB : op;  // the operands changed places
+                if (fa && fb) {
+                    out.words.push_back(word(op, WK_SELF, 0, store, in.dst));
+                } else if (fa) {
+                    out.words.push_back(word(op, kind_of(in.bk), in.b, store, in.dst));
+                } else if (fb) {
+                    out.words.push_back(word(rop, kind_of(in.ak), in.a, store, in.dst));
+                } else if (in.ak == K_CONST && in.bk != K_CONST) {  // the constant as the word's operand: limb 0 only
+                    out.words.push_back(word(W_LOAD, kind_of(in.bk), in.b));
+                    out.words.push_back(word(rop, WK_CONST, in.a, store, in.dst));
+                } else {
+                    out.words.push_back(word(W_LOAD, kind_of(in.ak), in.a));
+                    out.words.push_back(word(op, kind_of(in.bk), in.b, store, in.dst));
+                }
+            } else {
+                throw OvmFail(1, "encode_mle_words: not an accumulation program");
+            }
+        }
+        // (an empty group still runs one pair of word groups: the executor counts down from at least two)
+        while (out.words.size() == out.off.back() || (out.words.size() - out.off.back()) % (2 * MLE_WORD_GROUP))
+            out.words.push_back(word(W_NOP, WK_CONST, 0));
+        for (uint32_t k = 0; k < 2 * MLE_WORD_GROUP; k++) out.words.push_back(word(W_NOP, WK_CONST, 0));
+        out.off.push_back((uint32_t)out.words.size());
+    }
+    return out;
+}
+// Host evaluation of one group's words at one point (the self-test's check of the encoding; the device executor makes
+// D points of every column operand and is otherwise this loop).
+template <class T, class Fetch>
+inline void mle_words_host_eval(const MleWord *w, uint32_t n_words, const FpExt *weights, T *slots, Fetch &fetch, FpExt *out) {
+    T acc = Lift<T>::of(0);
+    for (uint32_t i = 0; i < n_words; i++) {
+        const uint32_t op = w[i].x & 7, kind = (w[i].x >> 3) & 3;
+        if (op == W_NOP) continue;
+        const T v = kind == WK_SLOT ? slots[w[i].y] : kind == WK_COL ? fetch(w[i].y) : kind == WK_CONST ? Lift<T>::of(w[i].y) : acc;
+        switch (op) {
+            case W_LOAD: acc = v; break;
+            case W_ADD: acc = acc + v; break;
+            case W_SUB: acc = acc - v; break;
+            case W_RSUB: acc = v - acc; break;
+            case W_MUL: acc = acc * v; break;
+            default: out[(w[i].x >> 6) & 1] += weights[w[i].z] * v; break;  // W_ACC
+        }
+        if (w[i].x & 32u) slots[w[i].x >> 16] = acc;
+    }
+}
+
 // The same for R rows per lane at once (base-field programs): one instruction decode -- the
 // interpreter's dominant cost, ~30 scalar instructions -- is amortised over R field operations.
 // slots[s][r], out[r][acc]; fetch(col, r) reads column `col` at the lane's r-th row.

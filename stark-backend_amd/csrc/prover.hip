@@ -1312,6 +1312,25 @@ int ovm_hip_staged_selftest(const uint32_t *blob, uint64_t words, uint32_t stage
                     }
                     if (!(plain[0] == want[0]) || !(plain[1] == want[1])) fail("grouped form, hints ignored");
                     if (!(fwd[0] == want[0]) || !(fwd[1] == want[1])) fail("grouped form, hints honoured");
+                    // the accumulator form of the LDS-slot executor (encode_mle_words), with and without the hints: slots
+                    // poisoned, rows as the encoding says, every group's words a whole number of pairs of word groups
+                    for (bool honour : {true, false}) {
+                        const MleWords mw = encode_mle_words(gp, honour);
+                        EF acc_form[2] = {EF::zero(), EF::zero()};
+                        for (size_t g = 0; g + 1 < mw.off.size(); g++) {
+                            const uint32_t n = mw.off[g + 1] - mw.off[g];
+                            if (n < 4 * MLE_WORD_GROUP || (n - 2 * MLE_WORD_GROUP) % (2 * MLE_WORD_GROUP)) fail("accumulator form (padding)");
+                            for (uint32_t i = mw.off[g]; i < mw.off[g + 1]; i++) {
+                                const MleWord &mwd = mw.words[i];
+                                if ((mwd.x & 7) == W_NOP) continue;
+                                if (((mwd.x >> 3) & 3) == WK_SLOT && mwd.y >= mw.rows) fail("accumulator form (slot operand beyond rows)");
+                                if ((mwd.x & 32u) && (mwd.x >> 16) >= mw.rows) fail("accumulator form (stored slot beyond rows)");
+                            }
+                            std::vector<Fp> st(mw.rows, Fp::from_canonical(0x5eed));
+                            mle_words_host_eval<Fp>(mw.words.data() + mw.off[g], n, w.data(), st.data(), fetch, acc_form);
+                        }
+                        if (!(acc_form[0] == want[0]) || !(acc_form[1] == want[1])) fail(honour ? "accumulator form" : "accumulator form, hints ignored");
+                    }
                 }
                 // the cached-column form (round 0), of the program as compiled and of its linear terms: the roots taken
                 // apart down to expressions of at most `cap` columns and re-ordered (cap 0: every sum, down to the products)

@@ -14,6 +14,7 @@
 #include "kernels.h"
 #include "eval.cuh"
 #include "cached_vm.cuh"
+#include "mle_vm.cuh"
 
 namespace ovm {
 
@@ -968,154 +969,25 @@ __global__ __launch_bounds__(RED_THREADS) void mle_round_points_kernel(const Ins
     finish_reduction<8>(ro, gridDim.x * gridDim.z, 2 * D);
 }
 
-// ---- the same kernel with its slots in LDS and the column operands of a block of instructions in flight together ------
+// ---- the same with the slots in LDS: the word executor of mle_vm.cuh ---------------------------------------------------
 // mle_eval_points keeps EF slots[NS][D] in a dynamically indexed array, which the compiler places in scratch memory:
 // every interpreted instruction then reads up to 2 x D x 16 bytes of scratch and writes D x 16 (400 B of private segment,
 // 150 VGPRs), and a column operand is a dependent global load issued where it is used. On the real Keccak-f AIR
-// (42 514 instructions, 6 slots, 2^20 rows: config B) that is ~600 GB of scratch traffic per proof and the multilinear
-// rounds took 113 ms of a 413 ms proof. Here:
-//   * slot s, point x, limb c of this lane is the LDS word ((s * D + x) * 4 + c) * RED_THREADS + lane (conflict-free,
-//     nothing in scratch); the image is num_slots x D KiB per workgroup, so programs of up to MLE_LDS_MAX_ROWS / D slots
-//     qualify (two workgroups per CU) -- the demand-driven compiler of round 3 gets the real programs there;
-//   * instructions go in blocks of MLE_BLOCK: first every column operand of the block is requested (t0, t1 of the pair,
-//     static register indices), then the block runs -- the loads of a block overlap each other and, with a second
-//     resident workgroup, the arithmetic of the other one.
-static constexpr int MLE_BLOCK = 4;
-static constexpr uint32_t MLE_LDS_MAX_ROWS = 19;  // num_slots * D (KiB of LDS per workgroup): 2 workgroups per CU
-// (bx, gx: this workgroup's index and the number of workgroups along y of ITS job -- a batched launch runs several jobs)
+// (42 514 instructions, 2^20 rows: config B) that was ~600 GB of scratch traffic per proof and 113 ms of multilinear
+// rounds. Here the program is in the accumulator form of program.h (MleWord) and runs on the assembly executor
+// MleVm<D>::run: slots are LDS rows of D x 4 KiB per workgroup (programs of up to MLE_LDS_MAX_ROWS / D stored slots
+// qualify -- the demand-driven compiler and compact_slots get the real programs there), three workgroups per CU up to
+// D = 3.
+static constexpr uint32_t MLE_LDS_MAX_ROWS = 19;  // stored slots x D (KiB of LDS per workgroup / 4)
 template <int D>
-__device__ __forceinline__ void mle_points_lds_body(const Instr *gcode, uint32_t n_instr, const EF *weights, const EF *mats,
-                                                    uint32_t log_h, uint32_t n_out, const EF *eq, EF first_const,
-                                                    uint32_t fwd_mask, uint32_t bx, uint32_t gx, EF (&sums)[2 * D]) {
-    extern __shared__ uint32_t mle_lds[];
-    uint32_t *mine = mle_lds + threadIdx.x;
-    auto slot_ld = [&](uint32_t s, EF (&v)[D]) {
-#pragma unroll
-        for (int x = 0; x < D; x++)
-#pragma unroll
-            for (int c = 0; c < 4; c++) v[x].c[c] = Fp::raw(mine[((s * D + x) * 4 + c) * RED_THREADS]);
-    };
-    auto slot_st = [&](uint32_t s, const EF (&v)[D]) {
-#pragma unroll
-        for (int x = 0; x < D; x++)
-#pragma unroll
-            for (int c = 0; c < 4; c++) mine[((s * D + x) * 4 + c) * RED_THREADS] = v[x].c[c].v;
-    };
-    const uint64_t n_y = 1ull << (log_h - 1);
-    const uint64_t stride = (uint64_t)gx * RED_THREADS;
-#pragma unroll
-    for (int k = 0; k < 2 * D; k++) sums[k] = EF::zero();
-    EF prev[D];  // the result of the instruction before (program.h FWD_*: forwarded operands skip the LDS round trip)
-#pragma unroll
-    for (int x = 0; x < D; x++) prev[x] = EF::zero();
-    for (uint64_t y = (uint64_t)bx * RED_THREADS + threadIdx.x; y < n_y; y += stride) {
-        EF out[D][2];
-#pragma unroll
-        for (int x = 0; x < D; x++) {
-            out[x][0] = EF::zero();
-            out[x][1] = first_const;
-        }
-        for (uint32_t pc0 = 0; pc0 < n_instr; pc0 += MLE_BLOCK) {
-            // phase 1: the pairs (t0, t1) of every column operand of the block
-            EF pa[MLE_BLOCK][2], pb[MLE_BLOCK][2];
-#pragma unroll
-            for (int j = 0; j < MLE_BLOCK; j++) {
-                if (pc0 + j < n_instr) {
-                    const Instr in = gcode[pc0 + j];
-                    if (in.ak == K_COL) {
-                        const EF *q = mats + ((uint64_t)in.a << log_h) + 2 * y;
-                        pa[j][0] = ld_ef(q), pa[j][1] = ld_ef(q + 1);
-                    }
-                    if (in.op <= OP_MUL && in.bk == K_COL) {
-                        const EF *q = mats + ((uint64_t)in.b << log_h) + 2 * y;
-                        pb[j][0] = ld_ef(q), pb[j][1] = ld_ef(q + 1);
-                    }
-                }
-            }
-            // phase 2: run the block
-#pragma unroll
-            for (int j = 0; j < MLE_BLOCK; j++) {
-                if (pc0 + j >= n_instr) break;
-                Instr in = gcode[pc0 + j];
-                in.fwd &= (uint16_t)fwd_mask;  // (OVM_MLE_FWD=0: ignore the forwarding hints)
-                EF a[D], b[D];
-                auto operand = [&](uint8_t kind, uint32_t payload, const EF (&pre)[2], EF (&v)[D]) {
-                    if (kind == K_SLOT) {
-                        slot_ld(payload, v);
-                    } else if (kind == K_COL) {
-                        const EF d = pre[1] - pre[0];
-                        v[0] = pre[1];
-#pragma unroll
-                        for (int x = 1; x < D; x++) v[x] = v[x - 1] + d;
-                    } else {
-                        const EF cst = EF::from_base(Fp::raw(payload));
-#pragma unroll
-                        for (int x = 0; x < D; x++) v[x] = cst;
-                    }
-                };
-                if (in.fwd & FWD_A) {
-#pragma unroll
-                    for (int x = 0; x < D; x++) a[x] = prev[x];
-                } else {
-                    operand(in.ak, in.a, pa[j], a);
-                }
-                if (in.op <= OP_MUL) {
-                    if (in.fwd & FWD_B) {
-#pragma unroll
-                        for (int x = 0; x < D; x++) b[x] = prev[x];
-                    } else {
-                        operand(in.bk, in.b, pb[j], b);
-                    }
-                    EF r[D];
-                    if (in.op == OP_ADD) {
-#pragma unroll
-                        for (int x = 0; x < D; x++) r[x] = a[x] + b[x];
-                    } else if (in.op == OP_SUB) {
-#pragma unroll
-                        for (int x = 0; x < D; x++) r[x] = a[x] - b[x];
-                    } else {
-#pragma unroll
-                        for (int x = 0; x < D; x++) r[x] = a[x] * b[x];
-                    }
-                    if (!(in.fwd & FWD_NOSTORE)) slot_st(in.dst, r);
-#pragma unroll
-                    for (int x = 0; x < D; x++) prev[x] = r[x];
-                } else if (in.op == OP_NEG) {
-                    EF r[D];
-#pragma unroll
-                    for (int x = 0; x < D; x++) r[x] = -a[x];
-                    if (!(in.fwd & FWD_NOSTORE)) slot_st(in.dst, r);
-#pragma unroll
-                    for (int x = 0; x < D; x++) prev[x] = r[x];
-                } else {  // OP_ACC
-                    const EF::Pre w = ld_ef(weights + in.b).pre();
-                    if (in.acc) {
-#pragma unroll
-                        for (int x = 0; x < D; x++) out[x][1] = out[x][1] + a[x] * w;
-                    } else {
-#pragma unroll
-                        for (int x = 0; x < D; x++) out[x][0] = out[x][0] + a[x] * w;
-                    }
-                }
-            }
-        }
-        const EF::Pre e = ld_ef(eq + y).pre();
-#pragma unroll
-        for (int x = 0; x < D; x++) {
-            sums[2 * x] = sums[2 * x] + out[x][0] * e;
-            if (n_out > 1) sums[2 * x + 1] = sums[2 * x + 1] + out[x][1] * e;
-        }
-    }
-}
-template <int D>
-__global__ __launch_bounds__(RED_THREADS, 3) void mle_round_points_lds_kernel(const Instr *code, const uint32_t *off,
-                                                                           const EF *weights, const EF *mats,
-                                                                           uint32_t log_h, uint32_t n_out, const EF *eq,
-                                                                           EF add_const, RedOut ro, uint32_t fwd_mask) {
+__global__ __launch_bounds__(RED_THREADS, D <= 3 ? 3 : 2) void mle_round_points_lds_kernel(
+    const MleWord *__restrict__ words, const uint32_t *__restrict__ woff, const MleWeight *__restrict__ weights,
+    const EF *__restrict__ mats, uint32_t log_h, uint32_t n_out, const EF *__restrict__ eq, EF add_const, RedOut ro) {
+    extern __shared__ uint4 mle_lds[];
     const uint32_t grp = blockIdx.z;
     EF sums[2 * D];
-    mle_points_lds_body<D>(code + off[grp], off[grp + 1] - off[grp], weights, mats, log_h, n_out, eq,
-                           grp == 0 ? add_const : EF::zero(), fwd_mask, blockIdx.x, gridDim.x, sums);
+    MleVm<D>::run(words + woff[grp], woff[grp + 1] - woff[grp] - 2 * MLE_WORD_GROUP, weights, mats, log_h, n_out, eq,
+                  grp == 0 ? add_const : EF::zero(), blockIdx.x, gridDim.x, mle_lds, sums);
     block_sum_out<2 * D>(sums, ro, ((size_t)(blockIdx.x * gridDim.z + grp)) * (2 * D));
     finish_reduction<8>(ro, gridDim.x * gridDim.z, 2 * D);
 }
@@ -1204,15 +1076,17 @@ __global__ __launch_bounds__(RED_THREADS) void mle_round_batched_kernel(const Ml
 // multilinear rounds (9.6 of 23 ms); here the operands of four instructions are in flight together and a pair is
 // fetched once.
 template <int D>
-__global__ __launch_bounds__(RED_THREADS, 3) void mle_round_batched_lds_kernel(const MleJob *jobs, uint32_t n_jobs,
-                                                                            uint32_t *counters, RedOut ro, uint32_t fwd_mask) {
+__global__ __launch_bounds__(RED_THREADS, D <= 3 ? 3 : 2) void mle_round_batched_lds_kernel(const MleJob *__restrict__ jobs,
+                                                                                          uint32_t n_jobs, uint32_t *counters,
+                                                                                          RedOut ro) {
+    extern __shared__ uint4 mle_lds[];
     const uint32_t j = find_job(n_jobs, blockIdx.z, [&](uint32_t i) { return jobs[i].z0; });
     const MleJob job = jobs[j];
     if (blockIdx.x >= job.gx) return;
     const uint32_t grp = blockIdx.z - job.z0;
     EF sums[2 * D];
-    mle_points_lds_body<D>(job.code + job.off[grp], job.off[grp + 1] - job.off[grp], job.weights, job.mats, job.log_h, job.n_out,
-                           job.eq, grp == 0 ? job.add_const : EF::zero(), fwd_mask, blockIdx.x, job.gx, sums);
+    MleVm<D>::run(job.words + job.woff[grp], job.woff[grp + 1] - job.woff[grp] - 2 * MLE_WORD_GROUP, job.weights_pre, job.mats,
+                  job.log_h, job.n_out, job.eq, grp == 0 ? job.add_const : EF::zero(), blockIdx.x, job.gx, mle_lds, sums);
     mle_job_finish<D>(sums, job, j, grp, n_jobs, counters, ro);
 }
 
@@ -1262,9 +1136,9 @@ int mle_round_eval_batched_lds(const MleJob *d_jobs, const MleJob *h_jobs, uint3
     if (degree == 0 || degree > 4) return (int)hipErrorInvalidValue;
     uint32_t gx = 1, gz = 0, max_slots = 1;
     for (uint32_t j = 0; j < n_jobs; j++) {
-        const uint32_t rows = mle_lds_rows(h_jobs[j].lds_slots, h_jobs[j].max_slots);
+        const uint32_t rows = h_jobs[j].lds_slots;  // (of the words: MleWords::rows)
         if (h_jobs[j].log_h == 0 || h_jobs[j].n_groups == 0 || h_jobs[j].n_out > 2 || h_jobs[j].z0 != gz ||
-            rows * degree > MLE_LDS_MAX_ROWS ||
+            rows * degree > MLE_LDS_MAX_ROWS || !h_jobs[j].words || !h_jobs[j].woff || !h_jobs[j].weights_pre ||
             (uint64_t)h_jobs[j].gx * h_jobs[j].n_groups * 2 * degree > h_jobs[j].partials_cap)
             return (int)hipErrorInvalidValue;
         gx = std::max(gx, h_jobs[j].gx);
@@ -1273,9 +1147,8 @@ int mle_round_eval_batched_lds(const MleJob *d_jobs, const MleJob *h_jobs, uint3
     }
     dim3 grid(gx, 1, gz);
     const size_t lds_bytes = (size_t)max_slots * degree * 4 * RED_THREADS * sizeof(uint32_t);
-    const uint32_t fwd_mask = tuning().mle_forward ? 0xFFFFu : 0u;
 #define CALLD(DD) \
-    OVM_LAUNCH((mle_round_batched_lds_kernel<DD>), grid, dim3(RED_THREADS), lds_bytes, s, d_jobs, n_jobs, d_counters, ro, fwd_mask)
+    OVM_LAUNCH((mle_round_batched_lds_kernel<DD>), grid, dim3(RED_THREADS), lds_bytes, s, d_jobs, n_jobs, d_counters, ro)
     if (degree == 1) CALLD(1);
     else if (degree == 2) CALLD(2);
     else if (degree == 3) CALLD(3);
@@ -1287,20 +1160,19 @@ int mle_round_eval_batched_lds(const MleJob *d_jobs, const MleJob *h_jobs, uint3
 bool mle_lds_eligible(uint32_t lds_slots, uint32_t degree) {
     return tuning().mle_lds_slots && lds_slots * degree <= MLE_LDS_MAX_ROWS;
 }
-uint32_t mle_lds_rows(uint32_t lds_slots, uint32_t max_slots) { return tuning().mle_forward ? lds_slots : max_slots; }
 
-int mle_round_eval_grouped(const Instr *d_code, const uint32_t *d_off, uint32_t n_groups, uint32_t max_slots, uint32_t lds_slots,
-                           const EF *d_weights, const EF *mats, uint32_t log_h, uint32_t degree, uint32_t n_out,
-                           const EF *d_eq, EF add_const, const RedOut &ro, hipStream_t s) {
+int mle_round_eval_grouped(const Instr *d_code, const uint32_t *d_off, uint32_t n_groups, uint32_t max_slots, const MleWord *d_words,
+                           const uint32_t *d_woff, uint32_t lds_rows, const EF *d_weights, const MleWeight *d_weights_pre,
+                           const EF *mats, uint32_t log_h, uint32_t degree, uint32_t n_out, const EF *d_eq, EF add_const,
+                           const RedOut &ro, hipStream_t s) {
     if (degree == 0 || degree > 4 || n_out > 2 || log_h == 0 || n_groups == 0) return (int)hipErrorInvalidValue;
     const uint32_t gx = mle_round_gx(log_h, degree, n_groups);
-    if (mle_lds_eligible(mle_lds_rows(lds_slots, max_slots), degree)) {
+    if (d_words && mle_lds_eligible(lds_rows, degree)) {
         dim3 grid(gx, 1, n_groups);
-        const size_t lds_bytes = (size_t)mle_lds_rows(lds_slots, max_slots) * degree * 4 * RED_THREADS * sizeof(uint32_t);
-#define CALLD(DD)                                                                                                        \
-    OVM_LAUNCH((mle_round_points_lds_kernel<DD>), grid, dim3(RED_THREADS), lds_bytes, s, d_code, d_off, d_weights, mats, \
-                       log_h, n_out, d_eq, add_const, red_inline(ro, gx * n_groups, 2 * degree),               \
-                       tuning().mle_forward ? 0xFFFFu : 0u)
+        const size_t lds_bytes = (size_t)lds_rows * degree * 4 * RED_THREADS * sizeof(uint32_t);
+#define CALLD(DD)                                                                                                         \
+    OVM_LAUNCH((mle_round_points_lds_kernel<DD>), grid, dim3(RED_THREADS), lds_bytes, s, d_words, d_woff, d_weights_pre, mats, \
+                       log_h, n_out, d_eq, add_const, red_inline(ro, gx * n_groups, 2 * degree))
         if (degree == 1) CALLD(1);
         else if (degree == 2) CALLD(2);
         else if (degree == 3) CALLD(3);
