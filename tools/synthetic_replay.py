@@ -111,6 +111,9 @@ def main(argv=None, verify=None):
     ap.add_argument("--max-log-height", type=int, default=22)
     ap.add_argument("--out", default=None)
     ap.add_argument("--segment", type=int, default=None, help="replay only this segment index, with the stage profile")
+    ap.add_argument("--profile", action="store_true",
+                    help="after each timed proof, prove the segment once more with the stage profile on and add the stage times up "
+                         "over the sweep (`stage_ms` in the card: where a whole block's proving time goes)")
     ap.add_argument("--engines", type=int, default=1,
                     help="K > 1: the reference's throughput mode (crates/cuda-backend/examples/keccakf.rs:55-131): K host threads, each "
                          "with its own stream and engine, prove the segments of the sweep concurrently (segments are independent "
@@ -130,6 +133,7 @@ def main(argv=None, verify=None):
     params["max_constraint_degree"] = 4
     picked = list(range(0, len(segs), args.every)) if args.segment is None else [args.segment]
     results, total_ms, total_cells = [], 0.0, 0
+    stage_ms = {}
     for n, si in enumerate(picked):
         air_list, shapes = airs.synthetic_segment(segs[si], args.max_log_height)
         blob = airs.pk_blob(params, air_list)
@@ -151,6 +155,13 @@ def main(argv=None, verify=None):
             for k, v in sorted(prof.items(), key=lambda kv: -kv[1][1])[:25]:
                 print(f"   {k:32s} calls {v[0]:5d}  {v[1]:9.3f} ms", file=sys.stderr)
             print(f"   sum of profiled device time: {sum(v[1] for v in prof.values()):.1f} ms", file=sys.stderr)
+        if args.profile and args.segment is None:
+            pkg.profile_enable(True)
+            dev.prove(pk, traces)
+            torch.cuda.synchronize()
+            for k, v in pkg.profile_report().items():
+                stage_ms[k] = stage_ms.get(k, 0.0) + v[1]
+            pkg.profile_enable(False)
         if verify is not None:
             verify(blob, proof)
         total_ms += ms
@@ -171,6 +182,8 @@ def main(argv=None, verify=None):
             "total_prove_ms": round(total_ms, 1), "total_main_cells": total_cells,
             "cells_per_sec": round(total_cells / (total_ms / 1e3), 1), "verified": verify is not None,
             "device": torch.cuda.get_device_name(0), "segments": results}
+    if stage_ms:
+        card["stage_ms"] = {k: round(v, 2) for k, v in sorted(stage_ms.items(), key=lambda kv: -kv[1])}
     text = json.dumps(card)
     if args.out:
         open(args.out, "w").write(text)
