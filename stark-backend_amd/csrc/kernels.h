@@ -191,6 +191,16 @@ int gkr_read_list(FracPlanes t, const uint64_t *d_pos, const uint32_t *d_pbase, 
 // (2: eight fractions per record)
 int gkr_edge_records(FracPlanes src, uint64_t at0, uint64_t at1, uint32_t n0, uint32_t n1, bool p_base, int folds, EF r1, EF r2,
                      const RedOut &ro, hipStream_t s);
+// The same records as a rider of the sub-round's sums kernel (gkr_round / gkr_fold_round): its workgroup 0 writes them to
+// `out` (mailbox slots, 4 EF per record) before its own pairs; the kernel's flag covers them. n0 + n1 = 0: none.
+struct GkrEdges {
+    FracPlanes src;
+    uint64_t at0 = 0, at1 = 0;
+    uint32_t n0 = 0, n1 = 0;
+    int p_base = 0, folds = 0;
+    EF r1, r2;
+    EF *out = nullptr;
+};
 // p_base: leaf numerators are base-field, only limb plane 0 of P is written / read (stages.hip)
 // The leaf kernels of many traces in one launch (staged programs, one row per lane): job j owns
 // workgroups [wg0, wg0 + gx).
@@ -217,10 +227,10 @@ int gkr_build_three_layers(FracPlanes child, FracPlanes parent, FracPlanes grand
                            hipStream_t s);
 // out[X-1] = sum_y eq[y] * (p0 q1 + p1 q0 + lambda q0 q1)(X, y), X = 1..n_points (2 or 3; eq: n_pairs weights)
 int gkr_round(FracPlanes rec, bool p_base, EqSplit eq, uint64_t n_pairs, EF lambda, uint32_t n_points,
-              const RedOut &ro, hipStream_t s);
+              const RedOut &ro, hipStream_t s, const GkrEdges &ed = GkrEdges());
 // fold the previous round with r and return the NEXT round's sums over the n_pairs folded pairs
 int gkr_fold_round(FracPlanes in, bool in_p_base, EqSplit eq, FracPlanes out, uint64_t n_pairs, EF r, EF lambda,
-                   uint32_t n_points, const RedOut &ro, hipStream_t s);
+                   uint32_t n_points, const RedOut &ro, hipStream_t s, const GkrEdges &ed = GkrEdges());
 
 // ---- stacked reduction ----
 // R[v * N + z] for v in {eq, rot1, rot2} over one window of `n_slices` contiguous slices of

@@ -426,6 +426,20 @@ struct CachedProgram {
     std::vector<uint32_t> loads;     // one record per block word: MAX_LOADS LDS rows to write, MAX_LOADS flat columns to request
     uint32_t num_rows = 0, n_blocks = 0, n_leaves = 0;
     uint64_t n_loads = 0;  // columns brought per evaluation (statistics)
+    // (word, weight index) of every accumulation word: the weights are inlined in the words, and a program staged before
+    // its weights exist (on the compile thread, while the device commits) gets them patched in (patch_weights)
+    std::vector<std::pair<uint32_t, uint32_t>> weight_at;
+    void patch_weights(const std::vector<FpExt> &weights) {
+        for (const auto &wa : weight_at) {
+            if (wa.second >= weights.size()) throw OvmFail(1, "patch_weights: weight index out of range");
+            const FpExt &w = weights[wa.second];
+            StagedInstr &in = words[wa.first];
+            in.op = C_ACC | w.c[0].v;
+            in.dst = (in.dst & 0x80000000u) | w.c[1].v;
+            in.a = w.c[2].v;
+            in.b = w.c[3].v;
+        }
+    }
     // operand rows -> word offsets for `rows_per_lane` trace rows per lane
     void scale_rows(uint32_t rows_per_lane) {
         const uint32_t k = rows_per_lane * 256;
@@ -486,7 +500,9 @@ inline CachedLiveness cached_liveness(const Program &p) {
     return lv;
 }
 
-inline CachedProgram stage_cached(const Program &p, const std::vector<FpExt> &weights, const CachedLayout &layout = CachedLayout()) {
+// (defer_weights: `weights` is not looked at; every accumulation word carries a zero weight until patch_weights)
+inline CachedProgram stage_cached(const Program &p, const std::vector<FpExt> &weights, const CachedLayout &layout = CachedLayout(),
+                                  bool defer_weights = false) {
     const CachedLiveness lv = cached_liveness(p);
     const uint32_t T = layout.rows, L = std::min(layout.max_loads, CachedProgram::MAX_LOADS);
     if (T < lv.min_rows || L < 2) throw OvmFail(1, "stage_cached: the image is too small for this program");
@@ -645,10 +661,11 @@ inline CachedProgram stage_cached(const Program &p, const std::vector<FpExt> &we
                     cp.n_leaves++;
                     continue;
                 }
-                if (in.b >= weights.size()) throw OvmFail(1, "stage_cached: weight index out of range");
+                if (!defer_weights && in.b >= weights.size()) throw OvmFail(1, "stage_cached: weight index out of range");
                 const uint32_t acc = in.op == OP_ACC ? in.acc : 0;
                 if (acc > 1) throw OvmFail(1, "stage_cached: accumulator out of range");
-                const FpExt &w = weights[in.b];
+                const FpExt w = defer_weights ? FpExt::zero() : weights[in.b];
+                cp.weight_at.push_back({(uint32_t)cp.words.size(), in.b});
                 emit(C_ACC | w.c[0].v, (acc << 31) | w.c[1].v, w.c[2].v, w.c[3].v);
                 continue;
             }

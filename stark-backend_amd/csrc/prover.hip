@@ -864,8 +864,10 @@ struct Prover {
         section_offsets.push_back(out.buf.size());
         std::vector<EF> r = prove_rap_constraints();
         wt.mark("rap_constraints.rest");
+        if (wt.on) HostTime::report();
         prove_openings(&pcs, common_root, r);
         wt.mark("openings.whir");
+        if (wt.on) HostTime::report();
     }
 };
 
@@ -1011,6 +1013,7 @@ Tuning ovm::Tuning::from_env() {
     t.gkr_split_min_round = (uint32_t)std::max(3, num("OVM_GKR_SPLIT_MIN", 14));
     t.stacked_tail_device = std::max(0, std::min(2, num("OVM_STACKED_TAIL_DEVICE", 1)));
     t.mle_batch_lds_min_log = (uint32_t)std::max(0, num("OVM_MLE_BATCH_LDS_MIN_LOG", 9));
+    t.lde_transposed = !off("OVM_LDE_XPOSE");
     t.lazy_w_accumulate = !off("OVM_LAZY_W");
     t.early_lde_lds_kib = (uint32_t)std::max(0, num("OVM_EARLY_LDE_LDS_KIB", 64));
     t.test_fail_rank = num("OVM_TEST_FAIL_RANK", -1);

@@ -327,19 +327,59 @@ __device__ __forceinline__ constexpr int bitrev4(int i) {
 //     rot(z) = plain((z + 1) mod 16) + (T(x + 1, 0) - T(x, 0)) * L_15(s * omega^z),
 // L_15 the Lagrange polynomial of the chunk's last point (lag[c * 16 + z], host-computed): 16 multiply-adds per coset
 // instead of a second interpolation and extension from 16 unaligned loads.
-__global__ __launch_bounds__(256) void coset_lde16_kernel(const ColDesc *cols, const uint32_t *used, const int32_t *twins,
-                                                          uint32_t n_cols_total, uint32_t log_lifted,
-                                                          uint32_t n_cosets, const Fp *twist, const Fp *lag, Fp *lde,
-                                                          uint64_t row0) {
+// XPOSE (tall traces: every wave owns 64 consecutive chunks = 4 KiB of the column): the chunks go through LDS so that the
+// global loads and stores of a wave are whole 1 KiB runs -- lane l moves bytes [16 l, 16 l + 16) of each quarter -- instead
+// of 16 bytes per lane 64 bytes apart (a lane's chunk is 64 contiguous bytes: four instructions that each touch 64
+// separate 64-byte segments). A chunk's four pieces sit 80 bytes apart in LDS (padded: both access patterns stay
+// off each other's banks). Within a wave the LDS operations are in order; no workgroup barrier.
+template <bool XPOSE>
+__global__ __launch_bounds__(256) void coset_lde16_kernel(const ColDesc *__restrict__ cols, const uint32_t *__restrict__ used,
+                                                          const int32_t *__restrict__ twins, uint32_t n_cols_total,
+                                                          uint32_t log_lifted, uint32_t n_cosets, const Fp *__restrict__ twist,
+                                                          const Fp *__restrict__ lag, Fp *__restrict__ lde, uint64_t row0) {
+    __shared__ uint4 tile[XPOSE ? 4 * 64 * 5 : 1];
     const uint64_t chunk = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (chunk >= (1ull << (log_lifted - 4))) return;
+    if (!XPOSE && chunk >= (1ull << (log_lifted - 4))) return;
     const uint32_t entry = used[blockIdx.y], col = entry & 0x7fffffffu;
     const bool with_twin = entry >> 31;
     const ColDesc cd = cols[col];
     // (row0: the slab of rows [row0, row0 + 2^log_lifted) of the columns is extended -- round 0 in slabs)
     const uint64_t hmask = (1ull << cd.log_height) - 1, base = chunk << 4, sbase = base + row0;
+    const uint32_t lane = threadIdx.x & 63;
+    uint4 *T = tile + (XPOSE ? (threadIdx.x >> 6) * (64 * 5) : 0);
+    const uint64_t wave_base = (chunk - lane) << 4;  // first row of the wave's 64 chunks (XPOSE)
+    // a wave's four pieces of 1 KiB: piece p = v * 64 + lane belongs to chunk p / 4, part p % 4
+    auto xpose_in = [&](const uint4 *src) {
+#pragma unroll
+        for (int v = 0; v < 4; v++) {
+            const uint32_t p = v * 64 + lane;
+            T[(p >> 2) * 5 + (p & 3)] = src[p];
+        }
+        __builtin_amdgcn_wave_barrier();
+    };
+    auto xpose_out = [&](uint4 *dst, const Fp (&y)[16]) {
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int v = 0; v < 4; v++) T[lane * 5 + v] = make_uint4(y[4 * v].v, y[4 * v + 1].v, y[4 * v + 2].v, y[4 * v + 3].v);
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int v = 0; v < 4; v++) {
+            const uint32_t p = v * 64 + lane;
+            dst[p] = T[(p >> 2) * 5 + (p & 3)];
+        }
+    };
     Fp x[16];
-    if (cd.rot == 0 && cd.log_height >= 4) {
+    if (XPOSE && cd.rot == 0) {
+        xpose_in(reinterpret_cast<const uint4 *>(cd.ptr + ((wave_base + row0) & hmask)));
+#pragma unroll
+        for (int v = 0; v < 4; v++) {
+            const uint4 q = T[lane * 5 + v];
+            x[4 * v] = Fp::raw(q.x);
+            x[4 * v + 1] = Fp::raw(q.y);
+            x[4 * v + 2] = Fp::raw(q.z);
+            x[4 * v + 3] = Fp::raw(q.w);
+        }
+    } else if (cd.rot == 0 && cd.log_height >= 4) {
         const uint4 *src = reinterpret_cast<const uint4 *>(cd.ptr + (sbase & hmask));
 #pragma unroll
         for (int v = 0; v < 4; v++) {
@@ -394,16 +434,26 @@ __global__ __launch_bounds__(256) void coset_lde16_kernel(const ColDesc *cols, c
                 }
             }
         }
-        uint4 *dst = reinterpret_cast<uint4 *>(lde + (((uint64_t)c * n_cols_total + col) << log_lifted) + base);
+        Fp *const out_col = lde + (((uint64_t)c * n_cols_total + col) << log_lifted);
+        if (XPOSE) {
+            xpose_out(reinterpret_cast<uint4 *>(out_col + wave_base), y);
+        } else {
+            uint4 *dst = reinterpret_cast<uint4 *>(out_col + base);
 #pragma unroll
-        for (int v = 0; v < 4; v++) dst[v] = make_uint4(y[4 * v].v, y[4 * v + 1].v, y[4 * v + 2].v, y[4 * v + 3].v);
+            for (int v = 0; v < 4; v++) dst[v] = make_uint4(y[4 * v].v, y[4 * v + 1].v, y[4 * v + 2].v, y[4 * v + 3].v);
+        }
         if (with_twin) {
             Fp w[16];
 #pragma unroll
             for (int z = 0; z < 16; z++) w[z] = y[(z + 1) & 15] + delta * lag[c * 16 + z];
-            uint4 *dst2 = reinterpret_cast<uint4 *>(lde + (((uint64_t)c * n_cols_total + twin_col) << log_lifted) + base);
+            Fp *const out_twin = lde + (((uint64_t)c * n_cols_total + twin_col) << log_lifted);
+            if (XPOSE) {
+                xpose_out(reinterpret_cast<uint4 *>(out_twin + wave_base), w);
+            } else {
+                uint4 *dst2 = reinterpret_cast<uint4 *>(out_twin + base);
 #pragma unroll
-            for (int v = 0; v < 4; v++) dst2[v] = make_uint4(w[4 * v].v, w[4 * v + 1].v, w[4 * v + 2].v, w[4 * v + 3].v);
+                for (int v = 0; v < 4; v++) dst2[v] = make_uint4(w[4 * v].v, w[4 * v + 1].v, w[4 * v + 2].v, w[4 * v + 3].v);
+            }
         }
     }
 }
@@ -418,8 +468,16 @@ int coset_lde(const ColDesc *d_cols, const uint32_t *d_used, uint32_t n_used, ui
     // d_shift_pows[k * N + i] = shift_k^i / N (the caller folds 1/N in)
     if (l_skip == 4) {
         dim3 grid16((unsigned)ceil_div(1ull << (log_lifted - 4), 256), n_used);
-        OVM_LAUNCH(coset_lde16_kernel, grid16, dim3(256), pad_lds_bytes > 65536 ? 65536 : pad_lds_bytes, s, d_cols, d_used, d_twins,
-                           n_cols_total, log_lifted, n_cosets, d_shift_pows, d_lag, lde, row0);
+        // (through LDS when every wave owns 64 whole chunks inside one period of the column: 2^12 rows up, slabs of 2^10)
+        // (log_lifted > l_skip: the columns are at least as tall as the rows extended here)
+        const bool xpose = tuning().lde_transposed && log_lifted >= 12 && (row0 & 1023) == 0;
+        const unsigned dyn = pad_lds_bytes > 65536 ? 65536 : pad_lds_bytes;
+        if (xpose)
+            OVM_LAUNCH(coset_lde16_kernel<true>, grid16, dim3(256), dyn, s, d_cols, d_used, d_twins, n_cols_total, log_lifted, n_cosets,
+                       d_shift_pows, d_lag, lde, row0);
+        else
+            OVM_LAUNCH(coset_lde16_kernel<false>, grid16, dim3(256), dyn, s, d_cols, d_used, d_twins, n_cols_total, log_lifted, n_cosets,
+                       d_shift_pows, d_lag, lde, row0);
         OVM_CHECK_LAUNCH();
         return 0;
     }
@@ -1708,13 +1766,12 @@ __device__ __forceinline__ void fold_fracs(const EF (&f)[N], EF (&g)[N / 2], con
 }
 // folds = 0: a record is the two fractions there; 1: the fold by r1 of two records (four fractions); 2: the fold by r2 of
 // two such folds (eight fractions).
-__global__ void gkr_edge_kernel(FracPlanes src, uint64_t at0, uint64_t at1, uint32_t n0, uint32_t n1, int p_base, int folds, EF r1_in,
-                                EF r2_in, RedOut ro) {
-    const uint32_t k = threadIdx.x;
+__device__ __forceinline__ void gkr_edge_body(uint32_t k, const FracPlanes &src, uint64_t at0, uint64_t at1, uint32_t n0, uint32_t n1,
+                                              int p_base, int folds, const EF &r1_in, const EF &r2_in, EF *out_all) {
     if (k < n0 + n1) {
         const uint64_t step = 2ull << folds;
         const uint64_t at = k < n0 ? at0 + step * k : at1 + step * (k - n0);
-        EF *out = ro.out + 4 * k;
+        EF *out = out_all + 4 * k;
         if (folds == 2) {
             const EF::Pre r1 = r1_in.pre(), r2 = r2_in.pre();
             EF f[8], g[4], pq[2][2];
@@ -1763,9 +1820,18 @@ __global__ void gkr_edge_kernel(FracPlanes src, uint64_t at0, uint64_t at1, uint
         }
         release_to_host();
     }
+}
+__global__ void gkr_edge_kernel(FracPlanes src, uint64_t at0, uint64_t at1, uint32_t n0, uint32_t n1, int p_base, int folds, EF r1_in,
+                                EF r2_in, RedOut ro) {
+    const uint32_t k = threadIdx.x;
+    gkr_edge_body(k, src, at0, at1, n0, n1, p_base, folds, r1_in, r2_in, ro.out);
     __syncthreads();
     if (k == 0) publish(ro);
 }
+// The same records written by a sub-round's sums kernel (its workgroup 0, before its own pairs): in a many-AIR proof most
+// sub-rounds have edge records, and a launch of their own was 3 us of kernel and 3.7 us of dispatch in front of a 9 us
+// sums kernel, 258 times per 46-AIR proof. n0 + n1 = 0: none. The records are released before the workgroup's arrival at
+// the reduction counter, the flag is raised after the last arrival.
 int gkr_edge_records(FracPlanes src, uint64_t at0, uint64_t at1, uint32_t n0, uint32_t n1, bool p_base, int folds, EF r1, EF r2,
                      const RedOut &ro, hipStream_t s) {
     if (n0 + n1 == 0 || n0 + n1 > 64 || folds < 0 || folds > 2) return (int)hipErrorInvalidValue;
@@ -1785,7 +1851,9 @@ __device__ __forceinline__ EF eq_weight(const EqSplit &eq, uint64_t y) {
 }
 template <bool PBASE, int NP>
 __global__ __launch_bounds__(RED_THREADS) void gkr_round_kernel(FracPlanes rec, EqSplit eq, uint64_t n_pairs,
-                                                                EF lambda_in, RedOut ro) {
+                                                                EF lambda_in, RedOut ro, GkrEdges ed) {
+    if (ed.n0 + ed.n1 && blockIdx.x == 0 && threadIdx.x < 64)
+        gkr_edge_body(threadIdx.x, ed.src, ed.at0, ed.at1, ed.n0, ed.n1, ed.p_base, ed.folds, ed.r1, ed.r2, ed.out);
     const uint64_t stride = (uint64_t)gridDim.x * RED_THREADS;
     const EF::Pre lambda = lambda_in.pre();
     EF sums[NP];
@@ -1807,12 +1875,13 @@ __global__ __launch_bounds__(RED_THREADS) void gkr_round_kernel(FracPlanes rec, 
     finish_reduction<NP>(ro, gridDim.x, NP);
 }
 int gkr_round(FracPlanes rec, bool p_base, EqSplit eq, uint64_t n_pairs, EF lambda, uint32_t n_points,
-              const RedOut &ro, hipStream_t s) {
+              const RedOut &ro, hipStream_t s, const GkrEdges &ed) {
     if (n_points != 2 && n_points != 3) return (int)hipErrorInvalidValue;
+    if (ed.n0 + ed.n1 > 64 || ed.folds < 0 || ed.folds > 2 || (ed.n0 + ed.n1 && !ed.out)) return (int)hipErrorInvalidValue;
     uint32_t grid = red_grid(n_pairs);
 #define CALL(PB, NP)                                                                                             \
     OVM_LAUNCH((gkr_round_kernel<PB, NP>), dim3(grid), dim3(RED_THREADS), 0, s, rec, eq, n_pairs, lambda, \
-                       red_inline(ro, grid, n_points))
+                       red_inline(ro, grid, n_points), ed)
     if (p_base) {
         if (n_points == 2) CALL(true, 2); else CALL(true, 3);
     } else {
@@ -1830,7 +1899,9 @@ int gkr_round(FracPlanes rec, bool p_base, EqSplit eq, uint64_t n_pairs, EF lamb
 template <bool PBASE, int NP>
 __global__ __launch_bounds__(RED_THREADS) void gkr_fold_round_kernel(FracPlanes in, EqSplit eq, FracPlanes out,
                                                                      uint64_t n_pairs, EF r_in, EF lambda_in,
-                                                                     RedOut ro) {
+                                                                     RedOut ro, GkrEdges ed) {
+    if (ed.n0 + ed.n1 && blockIdx.x == 0 && threadIdx.x < 64)
+        gkr_edge_body(threadIdx.x, ed.src, ed.at0, ed.at1, ed.n0, ed.n1, ed.p_base, ed.folds, ed.r1, ed.r2, ed.out);
     const uint64_t stride = (uint64_t)gridDim.x * RED_THREADS;
     const EF::Pre r = r_in.pre(), lambda = lambda_in.pre();
     EF sums[NP];
@@ -1869,12 +1940,13 @@ __global__ __launch_bounds__(RED_THREADS) void gkr_fold_round_kernel(FracPlanes 
     finish_reduction<NP>(ro, gridDim.x, NP);
 }
 int gkr_fold_round(FracPlanes in, bool in_p_base, EqSplit eq, FracPlanes out, uint64_t n_pairs, EF r, EF lambda,
-                   uint32_t n_points, const RedOut &ro, hipStream_t s) {
+                   uint32_t n_points, const RedOut &ro, hipStream_t s, const GkrEdges &ed) {
     if (n_points != 2 && n_points != 3) return (int)hipErrorInvalidValue;
+    if (ed.n0 + ed.n1 > 64 || ed.folds < 0 || ed.folds > 2 || (ed.n0 + ed.n1 && !ed.out)) return (int)hipErrorInvalidValue;
     uint32_t grid = red_grid(n_pairs);
 #define CALL(PB, NP)                                                                                               \
     OVM_LAUNCH((gkr_fold_round_kernel<PB, NP>), dim3(grid), dim3(RED_THREADS), 0, s, in, eq, out, n_pairs, r, \
-                       lambda, red_inline(ro, grid, n_points))
+                       lambda, red_inline(ro, grid, n_points), ed)
     if (in_p_base) {
         if (n_points == 2) CALL(true, 2); else CALL(true, 3);
     } else {

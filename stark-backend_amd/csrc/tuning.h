@@ -40,6 +40,7 @@ struct Tuning {
     // OVM_MLE_BATCH_LDS_MIN_LOG: batched multilinear-round jobs of at least 2^this pairs run on the LDS-slot interpreter
     // (all points of a pair in the lane); shorter ones keep one (pair, point) per lane. 31 = never.
     uint32_t mle_batch_lds_min_log = 9;
+    bool lde_transposed = true;    // OVM_LDE_XPOSE=0: the coset LDE of tall traces moves its chunks lane by lane, not through LDS
     // OVM_STACKED_TAIL_DEVICE: the finished slices of a stacked-reduction round are summed 0 = by the host, 1 = on the device
     // when there are at least 1 024 of them (a many-AIR proof), 2 = always on the device (parity tests)
     int stacked_tail_device = 1;

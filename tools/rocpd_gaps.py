@@ -3,7 +3,7 @@
 database: total, histogram, and the idle attributed to the kernel that PRECEDES each gap (i.e. which
 stage's host round trip the device was waiting for).
 
-    python tools/rocpd_gaps.py run_results.db [--second-half] [--list-over MICROSECONDS]
+    python tools/rocpd_gaps.py run_results.db [--second-half] [--list-over MICROSECONDS] [--timeline FROM_MS TO_MS]
 
 --list-over N: also lists every gap longer than N us in time order (offset into the prove, kernel before -> kernel after):
 where the host does enough work between two launches for the device to notice.
@@ -77,6 +77,16 @@ def main():
             if e0 > cur_end:
                 busy += e0 - cur_end
                 cur_end, last_name = e0, n
+    if "--timeline" in sys.argv:  # --timeline FROM_MS TO_MS: every kernel of the window (offset, gap before, duration, name)
+        i = sys.argv.index("--timeline")
+        lo, hi = float(sys.argv[i + 1]) * 1e6, float(sys.argv[i + 2]) * 1e6
+        prev_end = None
+        for n, s0, e0 in rows:
+            off = s0 - rows[0][1]
+            if lo <= off <= hi:
+                gap = (s0 - prev_end) / 1e3 if prev_end is not None else 0.0
+                print(f"  t {off / 1e6:9.4f} ms  gap {gap:8.1f} us  dur {(e0 - s0) / 1e3:8.1f} us  {n}")
+            prev_end = max(prev_end, e0) if prev_end is not None else e0
     print(f"kernels {len(rows)}, span {span / 1e6:.2f} ms, some kernel running {busy / 1e6:.2f} ms, idle {(span - busy) / 1e6:.2f} ms "
           f"(sum of kernel durations {kernel_time / 1e6:.2f} ms: {max(kernel_time - busy, 0) / 1e6:.2f} ms ran concurrently)")
     if streams:
