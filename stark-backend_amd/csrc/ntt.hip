@@ -19,6 +19,8 @@
 
 #include "device_ctx.h"
 #include "openvm_hip.h"
+#include "tuning.h"
+#include "wave_chunks.cuh"
 
 using bb::Fp;
 using bb::FpExt;
@@ -133,15 +135,28 @@ __global__ __launch_bounds__(NTT_THREADS) void eval_to_coeff_kernel(
 #define W16P(j) bb::cx_to_mont(bb::cx_powmod(bb::TWO_ADIC_GENERATORS[4], (j)))
 static constexpr uint32_t W16_INV[8] = {W16P(0), W16P(15), W16P(14), W16P(13), W16P(12), W16P(11), W16P(10), W16P(9)};
 #undef W16P
+// XPOSE (a whole number of workgroups of chunks): the chunks change lanes in LDS on the way in and out, so that a wave's
+// loads and stores are whole 1 KiB runs (wave_chunks.cuh).
+template <bool XPOSE>
 __global__ __launch_bounds__(256) void eval_to_coeff16_kernel(const Fp *__restrict__ in, Fp *__restrict__ out,
                                                               uint64_t n_chunks, Fp inv_chunk) {
+    __shared__ uint4 tile[XPOSE ? 4 * WAVE_CHUNK_TILE : 1];
     const uint64_t chunk = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (chunk >= n_chunks) return;
+    const uint32_t lane = threadIdx.x & 63;
+    uint4 *T = tile + (XPOSE ? (threadIdx.x >> 6) * WAVE_CHUNK_TILE : 0);
     Fp x[16];
     const uint4 *src = reinterpret_cast<const uint4 *>(in + (chunk << 4));
+    uint4 own[4];
+    if (XPOSE) {
+        wave_chunks_load(T, reinterpret_cast<const uint4 *>(in + ((chunk - lane) << 4)), lane, own);
+    } else {
+#pragma unroll
+        for (int v = 0; v < 4; v++) own[v] = src[v];
+    }
 #pragma unroll
     for (int v = 0; v < 4; v++) {
-        uint4 q = src[v];
+        uint4 q = own[v];
         x[4 * v] = Fp::raw(q.x);
         x[4 * v + 1] = Fp::raw(q.y);
         x[4 * v + 2] = Fp::raw(q.z);
@@ -171,8 +186,14 @@ __global__ __launch_bounds__(256) void eval_to_coeff16_kernel(const Fp *__restri
     uint4 *dst = reinterpret_cast<uint4 *>(out + (chunk << 4));
 #pragma unroll
     for (int v = 0; v < 4; v++)
-        dst[v] = make_uint4((x[br(4 * v)] * inv_chunk).v, (x[br(4 * v + 1)] * inv_chunk).v,
+        own[v] = make_uint4((x[br(4 * v)] * inv_chunk).v, (x[br(4 * v + 1)] * inv_chunk).v,
                             (x[br(4 * v + 2)] * inv_chunk).v, (x[br(4 * v + 3)] * inv_chunk).v);
+    if (XPOSE) {
+        wave_chunks_store(T, reinterpret_cast<uint4 *>(out + ((chunk - lane) << 4)), lane, own);
+    } else {
+#pragma unroll
+        for (int v = 0; v < 4; v++) dst[v] = own[v];
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -534,8 +555,12 @@ int ovm_hip_eval_to_coeff(const uint32_t *d_in, uint32_t *d_out, uint64_t width,
     if (l_skip == 4) {
         // columns are contiguous (column stride = 2^log_height), so the chunks of all columns form one array
         const uint64_t n_chunks = width << (log_height - 4);
-        OVM_LAUNCH(eval_to_coeff16_kernel, dim3((unsigned)((n_chunks + 255) / 256)), dim3(256), 0, stream,
-                           (const Fp *)d_in, (Fp *)d_out, n_chunks, Fp::from_canonical(16).inv());
+        if (tuning().lde_transposed && (n_chunks & 255) == 0)
+            OVM_LAUNCH(eval_to_coeff16_kernel<true>, dim3((unsigned)(n_chunks / 256)), dim3(256), 0, stream, (const Fp *)d_in,
+                       (Fp *)d_out, n_chunks, Fp::from_canonical(16).inv());
+        else
+            OVM_LAUNCH(eval_to_coeff16_kernel<false>, dim3((unsigned)((n_chunks + 255) / 256)), dim3(256), 0, stream,
+                       (const Fp *)d_in, (Fp *)d_out, n_chunks, Fp::from_canonical(16).inv());
         OVM_CHECK_LAUNCH();
         return 0;
     }

@@ -15,6 +15,7 @@
 #include "eval.cuh"
 #include "cached_vm.cuh"
 #include "mle_vm.cuh"
+#include "wave_chunks.cuh"
 
 namespace ovm {
 
@@ -327,17 +328,14 @@ __device__ __forceinline__ constexpr int bitrev4(int i) {
 //     rot(z) = plain((z + 1) mod 16) + (T(x + 1, 0) - T(x, 0)) * L_15(s * omega^z),
 // L_15 the Lagrange polynomial of the chunk's last point (lag[c * 16 + z], host-computed): 16 multiply-adds per coset
 // instead of a second interpolation and extension from 16 unaligned loads.
-// XPOSE (tall traces: every wave owns 64 consecutive chunks = 4 KiB of the column): the chunks go through LDS so that the
-// global loads and stores of a wave are whole 1 KiB runs -- lane l moves bytes [16 l, 16 l + 16) of each quarter -- instead
-// of 16 bytes per lane 64 bytes apart (a lane's chunk is 64 contiguous bytes: four instructions that each touch 64
-// separate 64-byte segments). A chunk's four pieces sit 80 bytes apart in LDS (padded: both access patterns stay
-// off each other's banks). Within a wave the LDS operations are in order; no workgroup barrier.
+// XPOSE (tall traces: every wave owns 64 consecutive chunks = 4 KiB of the column): the chunks change lanes in LDS so
+// that the global loads and stores of a wave are whole 1 KiB runs (wave_chunks.cuh).
 template <bool XPOSE>
 __global__ __launch_bounds__(256) void coset_lde16_kernel(const ColDesc *__restrict__ cols, const uint32_t *__restrict__ used,
                                                           const int32_t *__restrict__ twins, uint32_t n_cols_total,
                                                           uint32_t log_lifted, uint32_t n_cosets, const Fp *__restrict__ twist,
                                                           const Fp *__restrict__ lag, Fp *__restrict__ lde, uint64_t row0) {
-    __shared__ uint4 tile[XPOSE ? 4 * 64 * 5 : 1];
+    __shared__ uint4 tile[XPOSE ? 4 * WAVE_CHUNK_TILE : 1];
     const uint64_t chunk = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (!XPOSE && chunk >= (1ull << (log_lifted - 4))) return;
     const uint32_t entry = used[blockIdx.y], col = entry & 0x7fffffffu;
@@ -346,38 +344,24 @@ __global__ __launch_bounds__(256) void coset_lde16_kernel(const ColDesc *__restr
     // (row0: the slab of rows [row0, row0 + 2^log_lifted) of the columns is extended -- round 0 in slabs)
     const uint64_t hmask = (1ull << cd.log_height) - 1, base = chunk << 4, sbase = base + row0;
     const uint32_t lane = threadIdx.x & 63;
-    uint4 *T = tile + (XPOSE ? (threadIdx.x >> 6) * (64 * 5) : 0);
+    uint4 *T = tile + (XPOSE ? (threadIdx.x >> 6) * WAVE_CHUNK_TILE : 0);
     const uint64_t wave_base = (chunk - lane) << 4;  // first row of the wave's 64 chunks (XPOSE)
-    // a wave's four pieces of 1 KiB: piece p = v * 64 + lane belongs to chunk p / 4, part p % 4
-    auto xpose_in = [&](const uint4 *src) {
-#pragma unroll
-        for (int v = 0; v < 4; v++) {
-            const uint32_t p = v * 64 + lane;
-            T[(p >> 2) * 5 + (p & 3)] = src[p];
-        }
-        __builtin_amdgcn_wave_barrier();
-    };
     auto xpose_out = [&](uint4 *dst, const Fp (&y)[16]) {
-        __builtin_amdgcn_wave_barrier();
+        uint4 own[4];
 #pragma unroll
-        for (int v = 0; v < 4; v++) T[lane * 5 + v] = make_uint4(y[4 * v].v, y[4 * v + 1].v, y[4 * v + 2].v, y[4 * v + 3].v);
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int v = 0; v < 4; v++) {
-            const uint32_t p = v * 64 + lane;
-            dst[p] = T[(p >> 2) * 5 + (p & 3)];
-        }
+        for (int v = 0; v < 4; v++) own[v] = make_uint4(y[4 * v].v, y[4 * v + 1].v, y[4 * v + 2].v, y[4 * v + 3].v);
+        wave_chunks_store(T, dst, lane, own);
     };
     Fp x[16];
     if (XPOSE && cd.rot == 0) {
-        xpose_in(reinterpret_cast<const uint4 *>(cd.ptr + ((wave_base + row0) & hmask)));
+        uint4 own[4];
+        wave_chunks_load(T, reinterpret_cast<const uint4 *>(cd.ptr + ((wave_base + row0) & hmask)), lane, own);
 #pragma unroll
         for (int v = 0; v < 4; v++) {
-            const uint4 q = T[lane * 5 + v];
-            x[4 * v] = Fp::raw(q.x);
-            x[4 * v + 1] = Fp::raw(q.y);
-            x[4 * v + 2] = Fp::raw(q.z);
-            x[4 * v + 3] = Fp::raw(q.w);
+            x[4 * v] = Fp::raw(own[v].x);
+            x[4 * v + 1] = Fp::raw(own[v].y);
+            x[4 * v + 2] = Fp::raw(own[v].z);
+            x[4 * v + 3] = Fp::raw(own[v].w);
         }
     } else if (cd.rot == 0 && cd.log_height >= 4) {
         const uint4 *src = reinterpret_cast<const uint4 *>(cd.ptr + (sbase & hmask));
@@ -851,6 +835,8 @@ int round0_eval(const DevProgram &prog, const DevCached &staged, const Fp *lde, 
 // twins (optional): twins[j] = column index of the rotated view of column j when this lane should
 // produce it as well (same 17 cells, weights shifted by one row), -2 = column j is such a rotated view
 // and is skipped here, -1 = neither.
+// (The chunks as whole 1 KiB runs through LDS, wave_chunks.cuh, did nothing here: 2.95 -> 3.19 and 3.00 -> 2.96 ms for the
+// two launches of config B -- the 16-byte stores of the folded values and the weights are this kernel's other half.)
 __global__ void fold_ple_kernel(const ColDesc *cols, const int32_t *twins, uint32_t log_lifted, uint32_t l_skip,
                                 const EF *weights, EF *out) {
     const uint64_t nx = 1ull << (log_lifted - l_skip);
