@@ -143,6 +143,27 @@ def test_unbatched_mle_round_kernels(dev_hooks, pkg_hooks, orc, monkeypatch, lds
     _run(dev, pkg, orc, params, air_list, traces)
 
 
+@pytest.mark.parametrize("degree", [1, 2])
+@pytest.mark.parametrize("seed", range(2))
+def test_mle_executor_low_degree_keys(dev_hooks, pkg_hooks, orc, monkeypatch, degree, seed):
+    """Keys of constraint degree 1 and 2: the multilinear rounds' assembly executor has one statement per number of points
+    (csrc/mle_vm_asm.inc, D = 1..4) and the other GPU cases only reach D = 3 and 4. Unbatched, so that the traces of 2^4..2^10
+    rows all go through it. (Degree 1: no interactions -- a LogUp constraint has degree 2.)"""
+    dev, pkg = dev_hooks, pkg_hooks
+    monkeypatch.setenv("OVM_MLE_BATCH", "0")
+    rng = np.random.default_rng(7700 + 10 * degree + seed)
+    l_skip = 2
+    params = airs.test_params(l_skip=l_skip, n_stack=9, k_whir=2, max_constraint_degree=degree)
+    air_list, traces = [], []
+    for i in range(3):
+        width = int(rng.integers(3, 10))
+        air_list.append(airs.random_air(rng, width, int(rng.integers(4, 24)), 0 if degree == 1 else int(rng.integers(0, 3)),
+                                        max_degree=degree))
+        h = 1 << int(rng.integers(l_skip + 2, 11))
+        traces.append((i, rng.integers(0, airs.P, size=width * h, dtype=np.uint64).astype(np.uint32), h, []))
+    _run(dev, pkg, orc, params, air_list, traces)
+
+
 @pytest.mark.parametrize("seed", range(6))
 def test_round0_program_groups(dev_hooks, pkg_hooks, orc, monkeypatch, seed):
     """Round 0 with the program split into root groups that run as extra workgroups of the batched job
