@@ -198,7 +198,7 @@ struct GkrEdges {
     uint64_t at0 = 0, at1 = 0;
     uint32_t n0 = 0, n1 = 0;
     int p_base = 0, folds = 0;
-    EF r1, r2;
+    EF r1 = EF::zero(), r2 = EF::zero();
     EF *out = nullptr;
 };
 // p_base: leaf numerators are base-field, only limb plane 0 of P is written / read (stages.hip)
