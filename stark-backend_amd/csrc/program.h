@@ -1227,7 +1227,7 @@ BB_HD void run_program_acc(const Instr *code, uint32_t n_instr, const FpExt *wei
 }
 
 // ---------------------------------------------------------------------------------------------
-// Accumulator form of a grouped program (the LDS-slot kernels of the multilinear rounds, stages.hip: mle_words_body).
+// Accumulator form of a grouped program (the LDS-slot kernels of the multilinear rounds, mle_vm.cuh: MleVm<D>::run).
 // One RESULT REGISTER set holds the value of the word before; every word has at most one memory operand:
 //     LOAD  acc = operand                     ADD / SUB / MUL  acc = acc op operand        RSUB  acc = operand - acc
 //     ACC   out[k] += W[z] * (operand | acc)  NOP

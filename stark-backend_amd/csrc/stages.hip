@@ -1113,7 +1113,7 @@ __global__ __launch_bounds__(RED_THREADS) void mle_round_batched_kernel(const Ml
     mle_job_finish<D>(sums, job, j, grp, n_jobs, counters, ro);
 }
 
-// The same batch with the LDS-slot, points-in-lane interpreter of the large rounds (mle_points_lds_body): for jobs of at
+// The same batch on the accumulator-form executor of the large rounds (mle_vm.cuh: MleVm<D>::run): for jobs of at
 // least a workgroup's worth of pairs. A many-AIR proof has dozens of wide, short traces with programs of 1 000-10 000
 // instructions (a reth segment: 46 AIRs, 12 815 columns): in the kernel above every column operand of theirs is a dependent
 // global load in front of its instruction and four lanes fetch the same pair, and that kernel was the largest of the
