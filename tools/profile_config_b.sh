@@ -1,5 +1,5 @@
 #!/usr/bin/env bash
-# SQ counters + kernel stats of config B (the Keccak-f AIR) for the round-0 kernel: tools/_gpu_prof_b.sh <outdir> [ENV=VAL ...]
+# SQ counters + kernel stats of config B (the Keccak-f AIR) for the round-0 kernel: tools/profile_config_b.sh <outdir> [ENV=VAL ...]
 OUT=$1; shift
 mkdir -p "$OUT"
 export TMPDIR=/tmp

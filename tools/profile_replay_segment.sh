@@ -1,5 +1,5 @@
 #!/usr/bin/env bash
-# kernel trace + idle gaps of one replay segment: tools/_gpu_prof_seg.sh <outdir> <segment>
+# kernel trace + idle gaps of one replay segment: tools/profile_replay_segment.sh <outdir> <segment>
 OUT=$1; SEG=$2
 mkdir -p "$OUT"
 export TMPDIR=/tmp

@@ -25,7 +25,7 @@ timeout 900 bash tools/profile_round.sh "$O/prof" > "$O/profile_round.log" 2>&1
 timeout 600 python bench.py > "$O/bench_default_flags.json" 2> "$O/bench_default_flags.err"
 cat "$O/bench_default_flags.json" | cut -c1-300
 timeout 600 python tools/prove_config_b.py --reps 5 --profile > "$O/config_b_keccak.json" 2> "$O/config_b_keccak.err"
-timeout 900 bash tools/_gpu_prof_b.sh "$O/prof_b" > "$O/prof_b.log" 2>&1
+timeout 900 bash tools/profile_config_b.sh "$O/prof_b" > "$O/prof_b.log" 2>&1
 timeout 600 python bench.py --num-airs 4 --log-rows 20 --no-cpu-baseline > "$O/bench_config_c.json" 2> "$O/bench_config_c.err"
 timeout 600 python bench.py --log-rows 24 --log-blowup 2 --no-cpu-baseline --steps 5 --warmup 1 > "$O/bench_config_e.json" 2> "$O/bench_config_e.err"
 if [ "$MODE" != quick ]; then

@@ -1,5 +1,5 @@
 #!/usr/bin/env bash
-# interleaved A/B of the replay sample: tools/_gpu_ab.sh <outdir> <pairs>
+# interleaved A/B of the replay sample: tools/replay_ab.sh <outdir> <pairs>
 O=$1; N=${2:-4}
 mkdir -p $O
 PREV=$PWD/stark-backend_amd/build_prev/libopenvm_hip_prev.so

@@ -1,5 +1,7 @@
 #!/usr/bin/env bash
-# the WHOLE replay (209 segments, unverified) on one box, three libraries interleaved, twice
+# The WHOLE replay (209 segments, unverified) on one box, three libraries interleaved, twice: round 4's last library and the
+# mid-round one (built from their commits into stark-backend_amd/build_prev/, see docs/notebook/r05.md §8) against the tree's.
+#   git archive <commit> stark-backend_amd include | tar -x -C _old/<commit>; (cd _old/<commit>/stark-backend_amd && OVM_OUT=... ./build.sh)
 O=gpurun_out/r05/ab_full
 mkdir -p $O
 R04=$PWD/stark-backend_amd/build_prev/libopenvm_hip_6511fe3.so
