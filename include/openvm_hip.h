@@ -204,10 +204,10 @@ int ovm_hip_pk_preprocessed_commitment(const ovm_pk_t *pk, uint32_t air_idx, uin
  * CUDA peer: data_transporter.rs:44-51) without uploading and committing the trace a second time. */
 int ovm_hip_pk_preprocessed_data(const ovm_pk_t *pk, uint32_t air_idx, const uint32_t **d_trace_out, uint64_t *width_out,
                                  uint64_t *height_out, uint32_t commitment_out[8], ovm_pcs_t **pcs_out);
-/* Host-only self-test of the staged constraint-program form (csrc/program.h stage_program: what the
- * round-0 and GKR-leaf kernels execute): every program of every AIR of the key is staged with
- * `stage_rows` staging rows per buffer and `acc_rows` accumulation rows and run on one random row next
- * to the plain interpreter. Needs no device. 0 = all equal; `blocks_out` (optional) = blocks staged. */
+/* Host-only self-test of the forms the kernels execute (csrc/program.h: stage_cached + linear_terms for round 0 and
+ * the GKR leaves, compile_grouped + encode_mle_words for the multilinear rounds): every program of every AIR of the
+ * key, laid out with `stage_rows` / `acc_rows` rows, is evaluated on one random row next to a direct evaluation of
+ * the DAG. Needs no device. 0 = all equal; `blocks_out` (optional) = blocks staged. */
 int ovm_hip_staged_selftest(const uint32_t *blob, uint64_t words, uint32_t stage_rows, uint32_t acc_rows,
                             uint64_t seed, uint64_t *blocks_out);
 /* Host-only: size of the register program one AIR of the key compiles to (kind 0 zerocheck, 1 LogUp round sums,
