@@ -5,11 +5,13 @@
 // `BabyBear` is a `repr(transparent)` Montgomery u32, an extension element is `[u32; 4]`
 // (reference: crates/cuda-common/include/fp.h:52-60,184-194 and fpext.h:28-44).
 //
-// CDNA4 notes (measured with tools/ubench_int.hip on MI355X): v_mul_lo_u32 and v_mul_hi_u32 issue
-// at the same rate as v_lshl_add_u32 / v_min_u32 (~4.5 cycles per wave-instruction per SIMD);
-// v_mad_u64_u32 costs two of them. So a Montgomery multiply is priced by its INSTRUCTION COUNT:
-// 4 multiplies (a*b lo/hi, lo*M, hi(t*P)) + subtract + a 2-instruction branch-free correction
-// `min(r, r + P)`. No 64-bit compares, no vcc, no shift-add tricks (they are not cheaper here).
+// CDNA4 notes (measured on MI355X with tools/ubench_int64.hip, round 6): v_mad_u64_u32 / v_mad_i64_i32 and
+// v_lshl_add_u64 issue at the rate of v_mul_lo_u32 / v_mul_hi_u32 / v_min_u32 (~4.3-4.7 cycles per wave-instruction
+// per SIMD; v_add_u32, v_sub_u32 and the 32-bit shifts ~2.5-2.9). Rounds 1-5 priced the 64-bit multiply-add at two
+// slots from a microbenchmark that had an uncounted v_xor in its loop body; it costs ONE. So a Montgomery product is
+// THREE instructions: the 64-bit product (mad), lo * P^-1 (mul_lo), and product - m * P as a second 64-bit mad whose
+// high word is the result -- instead of two mul_lo, two mul_hi and a subtract. The compiler selects exactly these
+// from the 64-bit C++ expressions below.
 #pragma once
 #include <stdint.h>
 
@@ -41,65 +43,43 @@ constexpr uint32_t cx_powmod(uint32_t a, uint64_t e) {
 
 BB_HD uint32_t umin32(uint32_t a, uint32_t b) { return a < b ? a : b; }
 
-BB_HD uint32_t mulhi32(uint32_t a, uint32_t b) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    return __umulhi(a, b);
-#else
-    return (uint32_t)(((uint64_t)a * b) >> 32);
-#endif
-}
+static constexpr uint32_t MONTY_NEG_M = 0u - MONTY_M;  // -P^-1 mod 2^32
+static constexpr int32_t NEG_P = -(int32_t)P;
 
 // x < 2^32 * P  ->  x * 2^-32 mod P, in [0, P).
-//   t = lo(x) * M mod 2^32 ; u = t * P has the same low word as x, so (x - u) / 2^32 = hi(x) - hi(u),
-//   which lies in (-P, P); `min(r, r + P)` (unsigned, wrapping) adds P exactly when it is negative.
+//   m = lo(x) * (-P^-1) mod 2^32 ; x + m * P has a zero low word and is < 2^33 P < 2^64, so its high word is
+//   hi(x) + hi(m * P) (+ the carry), in [0, 2P): one 64-bit multiply-add, then `min(r, r - P)`.
 BB_HD uint32_t mont_reduce(uint64_t x) {
-    uint32_t lo = (uint32_t)x, xh = (uint32_t)(x >> 32);
-    uint32_t t = lo * MONTY_M;
-    uint32_t uh = mulhi32(t, P);
-    uint32_t r = xh - uh;
-    return umin32(r, r + P);
+    const uint32_t m = (uint32_t)x * MONTY_NEG_M;
+    const uint32_t r = (uint32_t)((x + (uint64_t)m * P) >> 32);
+    return umin32(r, r - P);
 }
 
 // Same, for x < 4*P^2 (a sum of up to four raw products): hi(x) may reach ~1.9 P, so it is
-// brought below P first (sub + min), after which the usual single correction applies.
+// brought below P first (sub + min), after which the sum above cannot overflow.
 BB_HD uint32_t mont_reduce_wide(uint64_t x) {
-    uint32_t lo = (uint32_t)x, xh = (uint32_t)(x >> 32);
+    uint32_t xh = (uint32_t)(x >> 32);
     xh = umin32(xh, xh - P);
-    uint32_t t = lo * MONTY_M;
-    uint32_t uh = mulhi32(t, P);
-    uint32_t r = xh - uh;
-    return umin32(r, r + P);
-}
-
-// a * b * 2^-32 mod P for a, b < P, from two 32-bit multiplies instead of one 64-bit one.
-BB_HD uint32_t mont_mul(uint32_t a, uint32_t b) {
-    uint32_t lo = a * b, xh = mulhi32(a, b);
-    uint32_t t = lo * MONTY_M;
-    uint32_t uh = mulhi32(t, P);
-    uint32_t r = xh - uh;
-    return umin32(r, r + P);
+    const uint32_t m = (uint32_t)x * MONTY_NEG_M;
+    const uint32_t r = (uint32_t)(((((uint64_t)xh) << 32 | (uint32_t)x) + (uint64_t)m * P) >> 32);
+    return umin32(r, r - P);
 }
 
 // Signed Montgomery product: a * b * 2^-32 mod P as a representative in (-P, P), for int32
-// |a| <= P, |b| < P. x = a*b = xh*2^32 + lo and t*P have equal low words, so xh - hi(t*P) is
-// exact; |xh| < 0.47 P and |hi(t*P)| <= P/2 bound the result without any correction step. Chains
-// of multiplies (the Poseidon2 S-box) run on these and canonicalise once at the end.
-BB_HD int32_t mulhi_i32(int32_t a, int32_t b) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    return __mulhi(a, b);
-#else
-    return (int32_t)(((int64_t)a * b) >> 32);
-#endif
+// |a| <= P, |b| < P. x = a*b and m*P (m = lo(x) * P^-1 as a SIGNED word) have equal low words, so
+// (x - m*P) >> 32 is exact; |hi(x)| < 0.47 P and |hi(m*P)| <= P/2 bound the result without any correction
+// step. Chains of multiplies (the Poseidon2 S-box) run on these and canonicalise once at the end.
+// In fact any int32 a, b are admissible: |hi(x)| <= 2^30 and |hi(m*P)| <= P/2 keep the result inside int32.
+BB_HD int32_t smont_redc(int64_t x) {
+    const int32_t m = (int32_t)((uint32_t)x * MONTY_M);
+    return (int32_t)((x + (int64_t)m * (int64_t)NEG_P) >> 32);
 }
-BB_HD int32_t smont_mul(int32_t a, int32_t b) {
-    uint32_t lo = (uint32_t)a * (uint32_t)b;
-    int32_t xh = mulhi_i32(a, b);
-    int32_t t = (int32_t)(lo * MONTY_M);
-    int32_t uh = mulhi_i32(t, (int32_t)P);
-    return xh - uh;
-}
+BB_HD int32_t smont_mul(int32_t a, int32_t b) { return smont_redc((int64_t)a * (int64_t)b); }
 // representative in (-P, P) -> canonical word
 BB_HD uint32_t from_signed(int32_t r) { return umin32((uint32_t)r, (uint32_t)r + P); }
+
+// a * b * 2^-32 mod P for a, b < P: the signed product (hi(a*b) < 0.47 P keeps it in (-P/2, P)), canonicalised.
+BB_HD uint32_t mont_mul(uint32_t a, uint32_t b) { return from_signed(smont_redc((int64_t)((uint64_t)a * b))); }
 
 struct Fp {
     uint32_t v;  // Montgomery word, < P
