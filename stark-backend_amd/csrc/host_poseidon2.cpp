@@ -210,6 +210,53 @@ extern "C" int ovm_hip_host_permute_selftest(uint32_t n, uint64_t seed) {
             st = st * 6364136223846793005ull + 1442695040888963407ull;
             a[i] = b[i] = p2::Fp::from_canonical((uint32_t)((st >> 33) % bb::P));
         }
+        if (it < 64) {  // edge states first: all zero, all P - 1, single extreme words, alternating extremes
+            for (int i = 0; i < 16; i++) {
+                const uint32_t hi = bb::P - 1;
+                a[i] = b[i] = p2::Fp::raw(it == 0 ? 0 : it == 1 ? hi : it < 18 ? (i == (int)it - 2 ? hi : 0) : it < 34 ? (i == (int)it - 18 ? 0 : hi)
+                                          : ((it >> (i & 3)) & 1) ? hi : (it & 32) ? bb::P / 2 + i : 0);
+            }
+        }
+        // the lazily reduced form the kernels run (p2::permute_lazy_t and its first / last layer variants, and the form
+        // that scales round constants as it reads them) against the plain statement of the layers
+        {
+            p2::Fp l[16], r[16];
+            for (int i = 0; i < 16; i++) l[i] = r[i] = a[i];
+            p2::permute_lazy_t<16, false>(l);
+            p2::permute_ref_t<16, false>(r);
+            for (int i = 0; i < 16; i++)
+                if (l[i].v != r[i].v) return 0;
+            for (int i = 0; i < 16; i++) l[i] = r[i] = a[i];
+            p2::permute_lazy_t<16, true>(l);
+            p2::permute_ref_t<16, true>(r);
+            for (int i = 0; i < 8; i++)
+                if (l[i].v != r[i].v) return 0;
+            for (int i = 0; i < 16; i++) l[i] = r[i] = i < 8 ? a[i] : p2::Fp::zero();
+            p2::permute_lazy_t<8, false>(l);
+            p2::permute_ref_t<8, false>(r);
+            for (int i = 0; i < 16; i++)
+                if (l[i].v != r[i].v) return 0;
+            for (int i = 0; i < 16; i++) l[i] = r[i] = i < 8 ? a[i] : p2::Fp::zero();
+            p2::permute_lazy_t<8, true>(l);
+            p2::permute_ref_t<8, true>(r);
+            for (int i = 0; i < 8; i++)
+                if (l[i].v != r[i].v) return 0;
+            for (int i = 0; i < 16; i++) l[i] = r[i] = i < 4 ? a[i] : p2::Fp::zero();
+            p2::permute_lazy_t<4, true>(l);
+            p2::permute_ref_t<4, true>(r);
+            for (int i = 0; i < 8; i++)
+                if (l[i].v != r[i].v) return 0;
+            uint32_t rc[141];
+            for (int i = 0; i < 64; i++) rc[i] = p2::RC_INITIAL[i], rc[64 + i] = p2::RC_TERMINAL[i];
+            for (int i = 0; i < 13; i++) rc[128 + i] = p2::RC_INTERNAL[i];
+            if (it & 1)  // (and with constants that are not the table's)
+                for (int i = 0; i < 141; i++) rc[i] = (uint32_t)(((uint64_t)rc[i] * 2654435761u + st) % bb::P);
+            for (int i = 0; i < 16; i++) l[i] = r[i] = a[i];
+            p2::lazy::permute<p2::lazy::MemoryRC, 16, false>(l, p2::lazy::MemoryRC{rc});
+            p2::permute_rc(r, rc);
+            for (int i = 0; i < 16; i++)
+                if (l[i].v != r[i].v) return 0;
+        }
         p2::permute(a);
         p2::host_permute(b);
         for (int i = 0; i < 16; i++)

@@ -150,8 +150,11 @@ BB_HD void internal_linear(Fp *s) {
 }
 
 // IN / OUT8: see external_linear (they describe the FIRST and the LAST linear layer only).
+// The permutation on canonical words, one modular reduction per addition: the plain statement of the layers. The host
+// runs it (scalar fallback of the transcript); the device runs permute_lazy_t below, which must equal it word for word
+// (ovm_hip_host_permute_selftest compares the two on the host, the GPU suite through the Merkle kernels).
 template <int IN = 16, bool OUT8 = false>
-BB_HD void permute_t(Fp *s) {
+BB_HD void permute_ref_t(Fp *s) {
     external_linear<IN, false>(s);
 #pragma unroll
     for (int r = 0; r < 4; r++) {
@@ -172,12 +175,243 @@ BB_HD void permute_t(Fp *s) {
         else external_linear(s);
     }
 }
+
+// ---- the permutation with lazily reduced linear layers (round 6) ------------------------------------------------------
+// What the kernels run. Measured on MI355X (tools/ubench_int64.hip): a 64-bit multiply-add (v_mad_i64_i32) and a 64-bit
+// add (v_lshl_add_u64) cost ONE issue slot each, like a 32-bit multiply. So the linear layers stop reducing after every
+// addition (3 VALU per modular add, ~3 900 of the 6 284 VALU of permute_ref_t): they add the signed 32-bit words into
+// 64-bit sums and every output word takes ONE signed Montgomery reduction (2 VALU: lo * P^-1, then a multiply-add whose
+// high word is the result).
+//
+// Scale bookkeeping. A word v stands for the field element X with v = X * R^e (mod P), R = 2^32; e is a compile-time
+// number, the same for all 16 words. The S-box (four signed Montgomery products) maps scale e to 7e - 6; a linear layer
+// with its reduction maps e to e - 1 (the reduction divides by R). Round constants are added as rc * R^e, computed at
+// compile time (LAZY below). The initial external rounds walk 1 -> 0 | -6 -> -7 | -55 -> -56 | -398 -> -399 | -2799 -> -2800;
+// one Montgomery product per word by R^2802 brings the state back to e = 1 (the usual Montgomery form), where the
+// internal rounds stay (the S-box fixes e = 1, and a diagonal entry times a word PLUS the sum is one multiply-add in
+// front of the reduction); the terminal rounds walk 1 -> 0 | ... | -398 -> -399 and the result is canonicalised by one
+// product with R^401. All of it is exact arithmetic on representatives of the same field elements: the canonical result
+// equals permute_ref_t's.
+//
+// Ranges (|.| of the int32 representatives; h = 2^32; 2^31 = 1.0667 P):
+//   smont_redc(x) = (x - m P) / h with a signed word m: |result| <= |x| / h + P/2, for |x| <= 2^62.
+//   S-box: |s| <= P + 33  ->  |s^2| <= .969 P, |s^3| <= .955 P, |s^4| <= .941 P, |s^7| <= .921 P.
+//   external layer: |column sums| <= 4 * .921 P, |z| <= 5 * .921 P, |y| <= 7 |z| < 33 P < 2^36; reduced |a| <= P/2 + 16;
+//     with the next round's constant (|c| <= P/2) the S-box input is within P + 16.
+//   internal round, words 1..15 bounded by b = .75 P, the S-box output by .921 P: |S| <= 12.2 P; S mod P as a centred
+//     word Sc (|Sc| <= .534 P: q = round(S / 2^27 / 15), Sc = S - q P); T = Sc * (R mod P), |T| <= .0334 P h;
+//     y_i = redc(x_i D_i + T) with |D_i| <= P/2: |y_i| <= .2344 b + .0334 P + P/2 <= .71 P (b holds). A word that is an
+//     S-box input next takes its round constant along as C = rc_m (R mod P) in [0, .0625 P h): word 0 (made from the
+//     S-box output) <= .2158 P + .0334 P + .0625 P + P/2 = .812 P, the others <= .772 P -- any int32 suits the S-box.
+namespace lazy {
+constexpr uint32_t R_MOD_P = 0x0ffffffeu;  // 2^32 mod P
+constexpr uint32_t rpow(int e) { return e >= 0 ? bb::cx_powmod(R_MOD_P, (uint64_t)e) : bb::cx_powmod(bb::cx_powmod(R_MOD_P, bb::P - 2), (uint64_t)(-e)); }
+constexpr int32_t centre(uint32_t canon) { return canon > bb::P / 2 ? (int32_t)canon - (int32_t)bb::P : (int32_t)canon; }
+// the constant that adds the round constant with Montgomery word rc_m (= rc R) to a state at scale e: rc R^e
+constexpr int32_t scaled(uint32_t rc_m, int e) { return centre(bb::cx_mulmod(rc_m, rpow(e - 1))); }
+static constexpr int E_INITIAL[4] = {0, -7, -56, -399};  // scale of the state the S-boxes of initial round r see
+static constexpr int E_AFTER_INITIAL = -2800;
+static constexpr int E_TERMINAL[4] = {1, 0, -7, -56};
+static constexpr int E_OUT = -399;
+static constexpr int32_t K_ENTER = centre(rpow(2 - E_AFTER_INITIAL));  // smont_mul(a, K) = a R^(1 - e): to Montgomery form
+static constexpr int32_t K_EXIT = centre(rpow(2 - E_OUT));
+static constexpr int32_t ROUND_15 = 4369, RM = (int32_t)R_MOD_P;  // 4369 / 2^16 = (1 / 15)(1 - 2^-16)
+#define P2_INV2K(k) bb::cx_powmod(bb::cx_powmod(2, bb::P - 2), (k))
+static constexpr uint32_t DIAG_CANON[16] = {
+    bb::P - 2, 1, 2, P2_INV2K(1), 3, 4, bb::P - P2_INV2K(1), bb::P - 3, bb::P - 4, P2_INV2K(8),
+    P2_INV2K(2), P2_INV2K(3), P2_INV2K(27), bb::P - P2_INV2K(8), bb::P - P2_INV2K(4), bb::P - P2_INV2K(27)};
+#undef P2_INV2K
+struct Tables {
+    int32_t c_initial[64];   // added in front of the S-boxes of the initial rounds
+    int32_t c_terminal[64];  // ... of the terminal rounds 1..3 (round 0's ride in the last internal round's sums)
+    int64_t C_terminal0[16]; // round constants of terminal round 0 at scale 2 (C / R is the Montgomery word)
+    int64_t C_internal[13];  // ... of internal round r (word 0)
+    int32_t diag[16];        // the internal diagonal as centred Montgomery words
+};
+constexpr Tables make_tables() {
+    Tables t{};
+    for (int r = 0; r < 4; r++)
+        for (int i = 0; i < 16; i++) {
+            t.c_initial[16 * r + i] = scaled(RC_INITIAL[16 * r + i], E_INITIAL[r]);
+            t.c_terminal[16 * r + i] = scaled(RC_TERMINAL[16 * r + i], E_TERMINAL[r]);
+        }
+    for (int i = 0; i < 16; i++) t.C_terminal0[i] = (int64_t)RC_TERMINAL[i] * RM;
+    for (int r = 0; r < 13; r++) t.C_internal[r] = (int64_t)RC_INTERNAL[r] * RM;
+    for (int i = 0; i < 16; i++) t.diag[i] = centre(bb::cx_to_mont(DIAG_CANON[i]));
+    return t;
+}
+static constexpr Tables LAZY = make_tables();
+
+// c + a with the sign extension done by the multiply-add itself (v_mad_i64_i32 a, 1, c: ONE instruction; written as
+// `c + (int64) a` the compiler extends first -- a shift and a move into a register pair -- and adds then; with an opaque
+// multiplier it factors sums of such terms into 64 x 32-bit products).
+BB_HD int64_t add_word(int64_t c, int32_t a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    int64_t r;
+    uint64_t carry;
+    asm("v_mad_i64_i32 %0, %1, %2, 1, %3" : "=v"(r), "=s"(carry) : "v"(a), "v"(c));
+    return r;
+#else
+    return c + (int64_t)a;
+#endif
+}
+BB_HD int64_t widen(int32_t a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    int64_t r;
+    uint64_t carry;
+    asm("v_mad_i64_i32 %0, %1, %2, 1, 0" : "=v"(r), "=s"(carry) : "v"(a));
+    return r;
+#else
+    return (int64_t)a;
+#endif
+}
+BB_HD int64_t mad(int32_t a, int32_t b, int64_t c) { return c + (int64_t)a * (int64_t)b; }
+// a wave-uniform constant the compiler may not reason about (it stays ONE multiply-add operand)
+BB_HD int32_t opaque(int32_t k) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm("" : "+s"(k));
+#endif
+    return k;
+}
+// s^7 R^-6 for any int32 s with |s| <= P + 33, as a representative within .921 P
+BB_HD int32_t sbox7(int32_t s) {
+    const int32_t s2 = bb::smont_mul(s, s), s3 = bb::smont_mul(s2, s), s4 = bb::smont_mul(s2, s2);
+    return bb::smont_mul(s4, s3);
+}
+// M4 of four 64-bit sums, reduced into four words
+BB_HD void mat4_redc(const int64_t *z, int32_t *out) {
+    const int64_t t01 = z[0] + z[1], t23 = z[2] + z[3], t0123 = t01 + t23, t01123 = t0123 + z[1], t01233 = t0123 + z[3];
+    out[3] = bb::smont_redc(t01233 + 2 * z[0]);
+    out[1] = bb::smont_redc(t01123 + 2 * z[2]);
+    out[0] = bb::smont_redc(t01123 + t01);
+    out[2] = bb::smont_redc(t01233 + t23);
+}
+// state <- M_E state / R.  out_b = M4 (x_b + X), X = the sum of the four blocks (circ(2 M4, M4, M4, M4) = M4 (I + J)).
+// IN / OUT8 as in external_linear.
+template <int IN = 16, bool OUT8 = false>
+BB_HD void external_linear(int32_t *s) {
+    static_assert(IN == 16 || IN == 8 || IN == 4, "IN");
+    int64_t X[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        X[j] = widen(s[j]);
+#pragma unroll
+        for (int b = 1; b < IN / 4; b++) X[j] = add_word(X[j], s[4 * b + j]);
+    }
+    int32_t zero_block[4];
+    if (IN < (OUT8 ? 8 : 16)) mat4_redc(X, zero_block);  // a block whose input is zero: M4 X, the same for all of them
+#pragma unroll
+    for (int b = 0; b < (OUT8 ? 2 : 4); b++) {
+        if (4 * b < IN) {
+            int64_t z[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) z[k] = add_word(X[k], s[4 * b + k]);
+            mat4_redc(z, s + 4 * b);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; k++) s[4 * b + k] = zero_block[k];
+        }
+    }
+}
+// One internal round on a state in Montgomery form: s[0] is the S-box INPUT (its round constant already added).
+// C0: what rides in word 0's sum (the next internal round's constant, or nothing); C (16 or null): the same for all
+// words (the constants of the first terminal round behind the last internal one).
+BB_HD void internal_round(int32_t *s, int64_t C0, const int64_t *C) {
+    s[0] = sbox7(s[0]);
+    int64_t S = widen(s[0]);
+#pragma unroll
+    for (int i = 1; i < 16; i++) S = add_word(S, s[i]);
+    const int32_t q = ((int32_t)(S >> 27) * ROUND_15 + 32768) >> 16;  // round(S / 2^27 / 15): |S / 2^27| < 200
+    const int32_t Sc = (int32_t)mad(q, bb::NEG_P, S);                 // S - q P, within .534 P
+    int64_t T = mad(Sc, opaque(RM), 0);  // (a literal 2^28 - 2 would be strength-reduced into 64-bit shifts and a subtract)
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm("" : "+v"(T));  // (or re-associated into a second multiply-add per word: x D + (Sc RM + 0))
+#endif
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        int64_t t = mad(s[i], opaque(LAZY.diag[i]), T);  // (opaque: powers of two would become 64-bit shifts and masks)
+        if (i == 0) t += C0;
+        if (C) t += C[i];
+        s[i] = bb::smont_redc(t);
+    }
+}
+}  // namespace lazy
+
+namespace lazy {
+// where the round constants come from: the default table (literals after unrolling) ...
+struct TableRC {
+    BB_HD int32_t c_initial(int r, int i) const { return LAZY.c_initial[16 * r + i]; }
+    BB_HD int32_t c_terminal(int r, int i) const { return LAZY.c_terminal[16 * r + i]; }
+    BB_HD int64_t C_terminal0(int i) const { return LAZY.C_terminal0[i]; }
+    BB_HD int64_t C_internal(int r) const { return LAZY.C_internal[r]; }
+};
+// ... or memory (`rc`: 64 initial, 64 terminal, 13 internal Montgomery words), scaled as they are read
+static constexpr uint32_t RPOW_INITIAL[4] = {rpow(E_INITIAL[0]), rpow(E_INITIAL[1]), rpow(E_INITIAL[2]), rpow(E_INITIAL[3])};
+static constexpr uint32_t RPOW_TERMINAL[4] = {rpow(E_TERMINAL[0]), rpow(E_TERMINAL[1]), rpow(E_TERMINAL[2]), rpow(E_TERMINAL[3])};
+struct MemoryRC {
+    const uint32_t *rc;
+    BB_HD static int32_t centre_rt(uint32_t v) { return v > bb::P / 2 ? (int32_t)v - (int32_t)bb::P : (int32_t)v; }
+    // rc_m * R^(e - 1) = mont_mul(rc_m, R^e)
+    BB_HD int32_t c_initial(int r, int i) const { return centre_rt(bb::mont_mul(rc[16 * r + i], RPOW_INITIAL[r])); }
+    BB_HD int32_t c_terminal(int r, int i) const { return centre_rt(bb::mont_mul(rc[64 + 16 * r + i], RPOW_TERMINAL[r])); }
+    BB_HD int64_t C_terminal0(int i) const { return (int64_t)rc[64 + i] * RM; }
+    BB_HD int64_t C_internal(int r) const { return (int64_t)rc[128 + r] * RM; }
+};
+template <class RC, int IN, bool OUT8>
+BB_HD void permute(Fp *st, const RC &rc) {
+    int32_t s[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) s[i] = (int32_t)st[i].v;
+    external_linear<IN, false>(s);
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+#pragma unroll
+        for (int i = 0; i < 16; i++) s[i] = sbox7(s[i] + rc.c_initial(r, i));
+        external_linear(s);
+    }
+    // to Montgomery form; word 0 takes the first internal constant with it (it is an S-box input next)
+    s[0] = bb::smont_redc(mad(s[0], K_ENTER, rc.C_internal(0)));
+#pragma unroll
+    for (int i = 1; i < 16; i++) s[i] = bb::smont_mul(s[i], K_ENTER);
+    int64_t Ct[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) Ct[i] = rc.C_terminal0(i);
+#pragma unroll
+    for (int r = 0; r < 13; r++) internal_round(s, r < 12 ? rc.C_internal(r + 1) : 0, r < 12 ? nullptr : Ct);
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+#pragma unroll
+        for (int i = 0; i < 16; i++) s[i] = sbox7(r == 0 ? s[i] : s[i] + rc.c_terminal(r, i));
+        if (r == 3) external_linear<16, OUT8>(s);
+        else external_linear(s);
+    }
+#pragma unroll
+    for (int i = 0; i < (OUT8 ? 8 : 16); i++) st[i] = Fp::raw(bb::from_signed(bb::smont_mul(s[i], K_EXIT)));
+}
+}  // namespace lazy
+
+template <int IN = 16, bool OUT8 = false>
+BB_HD void permute_lazy_t(Fp *st) { lazy::permute<lazy::TableRC, IN, OUT8>(st, lazy::TableRC{}); }
+
+template <int IN = 16, bool OUT8 = false>
+BB_HD void permute_t(Fp *s) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    permute_lazy_t<IN, OUT8>(s);
+#else
+    permute_ref_t<IN, OUT8>(s);
+#endif
+}
 BB_HD void permute(Fp *s) { permute_t<16, false>(s); }
 
 // The same layers over round constants read from memory (`rc`: 64 initial, 64 terminal, 13 internal Montgomery words).
 // Not used by the prover: it lets Plonky3's published known-answer vector -- whose constants come from a seeded RNG,
-// not the default table -- run through THIS file's S-box and linear layers (ovm_hip_poseidon2_permute_rc).
+// not the default table -- run through THIS file's S-box and linear layers (ovm_hip_poseidon2_permute_rc): on the
+// device the lazily reduced ones the kernels run (lazy::permute with the constants scaled as they are read).
 BB_HD void permute_rc(Fp *s, const uint32_t *rc) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    lazy::permute<lazy::MemoryRC, 16, false>(s, lazy::MemoryRC{rc});
+    return;
+#endif
     external_linear(s);
     for (int r = 0; r < 4; r++) {
 #pragma unroll
@@ -203,18 +437,13 @@ BB_HD void permute_rc(Fp *s, const uint32_t *rc) {
 // the LATENCY-bound uses of the permutation -- the small top layers of a Merkle tree, where a launch
 // has fewer nodes than the chip has SIMDs -- not for the bulk hashing (same arithmetic, more overhead).
 // Internal-layer diagonal as Montgomery constants, one per lane.
-#define P2_INV2K(k) bb::cx_powmod(bb::cx_powmod(2, bb::P - 2), (k))
-static constexpr uint32_t COOP_DIAG_CANON[16] = {
-    bb::P - 2, 1, 2, P2_INV2K(1), 3, 4, bb::P - P2_INV2K(1), bb::P - 3, bb::P - 4, P2_INV2K(8),
-    P2_INV2K(2), P2_INV2K(3), P2_INV2K(27), bb::P - P2_INV2K(8), bb::P - P2_INV2K(4), bb::P - P2_INV2K(27)};
-#undef P2_INV2K
 __device__ static const uint32_t COOP_DIAG[16] = {
-    bb::cx_to_mont(COOP_DIAG_CANON[0]),  bb::cx_to_mont(COOP_DIAG_CANON[1]),  bb::cx_to_mont(COOP_DIAG_CANON[2]),
-    bb::cx_to_mont(COOP_DIAG_CANON[3]),  bb::cx_to_mont(COOP_DIAG_CANON[4]),  bb::cx_to_mont(COOP_DIAG_CANON[5]),
-    bb::cx_to_mont(COOP_DIAG_CANON[6]),  bb::cx_to_mont(COOP_DIAG_CANON[7]),  bb::cx_to_mont(COOP_DIAG_CANON[8]),
-    bb::cx_to_mont(COOP_DIAG_CANON[9]),  bb::cx_to_mont(COOP_DIAG_CANON[10]), bb::cx_to_mont(COOP_DIAG_CANON[11]),
-    bb::cx_to_mont(COOP_DIAG_CANON[12]), bb::cx_to_mont(COOP_DIAG_CANON[13]), bb::cx_to_mont(COOP_DIAG_CANON[14]),
-    bb::cx_to_mont(COOP_DIAG_CANON[15])};
+    bb::cx_to_mont(lazy::DIAG_CANON[0]),  bb::cx_to_mont(lazy::DIAG_CANON[1]),  bb::cx_to_mont(lazy::DIAG_CANON[2]),
+    bb::cx_to_mont(lazy::DIAG_CANON[3]),  bb::cx_to_mont(lazy::DIAG_CANON[4]),  bb::cx_to_mont(lazy::DIAG_CANON[5]),
+    bb::cx_to_mont(lazy::DIAG_CANON[6]),  bb::cx_to_mont(lazy::DIAG_CANON[7]),  bb::cx_to_mont(lazy::DIAG_CANON[8]),
+    bb::cx_to_mont(lazy::DIAG_CANON[9]),  bb::cx_to_mont(lazy::DIAG_CANON[10]), bb::cx_to_mont(lazy::DIAG_CANON[11]),
+    bb::cx_to_mont(lazy::DIAG_CANON[12]), bb::cx_to_mont(lazy::DIAG_CANON[13]), bb::cx_to_mont(lazy::DIAG_CANON[14]),
+    bb::cx_to_mont(lazy::DIAG_CANON[15])};
 __device__ static const uint32_t COOP_RC_INITIAL[64] = {
     RC_INITIAL[0],  RC_INITIAL[1],  RC_INITIAL[2],  RC_INITIAL[3],  RC_INITIAL[4],  RC_INITIAL[5],  RC_INITIAL[6],  RC_INITIAL[7],
     RC_INITIAL[8],  RC_INITIAL[9],  RC_INITIAL[10], RC_INITIAL[11], RC_INITIAL[12], RC_INITIAL[13], RC_INITIAL[14], RC_INITIAL[15],
