@@ -69,6 +69,7 @@ const Twiddles *twiddles();
 void prof_register_side_stream(hipStream_t s);
 struct ProfScope {
     int slot = -1;
+    unsigned generation = 0;  // of the record list when the scope opened: profile_enable clears the list and bumps it
     bool ranged = false;  // a roctx range is open (OVM_ROCTX=1)
     hipStream_t stream;
     ProfScope(const char *label, hipStream_t s);

@@ -35,6 +35,9 @@ using p2::Digest;
 namespace ovm {
 
 static constexpr int HASH_THREADS = 256;
+#ifndef OVM_HASH_ROWS_WAVES
+#define OVM_HASH_ROWS_WAVES  // (", 8": cap the row hash at 64 VGPRs -- measured, see DESIGN)
+#endif
 
 // Which rows of the matrix a launch hashes: all of them (n = 1), or -- one rank's share of a tree that n ranks
 // build together (prover.hip: build_tree) -- the query groups g with g mod n == r, compacted: output row
@@ -46,7 +49,7 @@ struct RowMap {
 // One lane = one row. `words_per_elem` is 1 for base-field matrices and 4 for extension-field
 // matrices (stored as [u32;4] per entry); the row is absorbed coefficient-wise.
 template <int WORDS>
-__global__ __launch_bounds__(HASH_THREADS) void hash_rows_kernel(const Fp *__restrict__ mat,
+__global__ __launch_bounds__(HASH_THREADS OVM_HASH_ROWS_WAVES) void hash_rows_kernel(const Fp *__restrict__ mat,
                                                                  uint64_t width, uint64_t rows,
                                                                  uint64_t col_stride,
                                                                  Digest *__restrict__ out, RowMap map) {
@@ -84,31 +87,28 @@ __global__ __launch_bounds__(HASH_THREADS) void hash_rows_kernel(const Fp *__res
         s[0] = Fp::raw(v.x), s[1] = Fp::raw(v.y), s[2] = Fp::raw(v.z), s[3] = Fp::raw(v.w);
         p2::permute_t<4, true>(s);
     } else {
-        uint64_t cidx = 0;
-        const bool tail = width % CPB != 0;
-        if (width >= CPB) {
-            absorb_full(0);
-            cidx = CPB;
-            if (cidx == width) p2::permute_t<8, true>(s);
-            else p2::permute_t<8, false>(s);
-        }
-        for (; cidx + CPB <= width; cidx += CPB) {
-            absorb_full(cidx);
-            if (!tail && cidx + CPB == width) p2::permute_t<16, true>(s);
-            else p2::permute(s);
-        }
-        if (tail) {
-            // partial tail: overwrite the first words only, stale words stay (padding-free sponge)
+        // ONE permutation body in the kernel, in a loop that is not unrolled: a copy per position (first / middle / last
+        // permutation of the row, with the additions on known zeros and unused words left out) made the kernel 200 KB
+        // of straight-line code, three times the instruction cache two CUs share -- and the row hash stopped following
+        // the instruction count (round 6: 3 773 -> 3 676 VALU per permutation, 14.5 ms either way).
+        const uint64_t chunks = (width + CPB - 1) / CPB;
+#pragma nounroll
+        for (uint64_t c = 0; c < chunks; c++) {
+            const uint64_t c0 = c * CPB;
+            if (c0 + CPB <= width) {
+                absorb_full(c0);
+            } else {
+                // partial tail: overwrite the first words only, stale words stay (padding-free sponge)
 #pragma unroll
-            for (int j = 0; j < CPB; j++) {
-                if (cidx + j < width) {
-                    const Fp *p = src + (cidx + j) * cstride;
+                for (int j = 0; j < CPB; j++) {
+                    if (c0 + j < width) {
+                        const Fp *p = src + (c0 + j) * cstride;
 #pragma unroll
-                    for (int k = 0; k < WORDS; k++) s[WORDS * j + k] = p[k];
+                        for (int k = 0; k < WORDS; k++) s[WORDS * j + k] = p[k];
+                    }
                 }
             }
-            if (width < CPB) p2::permute_t<8, true>(s);  // (a row narrower than the rate: its only permutation)
-            else p2::permute_t<16, true>(s);
+            p2::permute(s);
         }
     }
     Digest d;

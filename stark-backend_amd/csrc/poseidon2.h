@@ -184,63 +184,102 @@ BB_HD void permute_ref_t(Fp *s) {
 // high word is the result).
 //
 // Scale bookkeeping. A word v stands for the field element X with v = X * R^e (mod P), R = 2^32; e is a compile-time
-// number, the same for all 16 words. The S-box (four signed Montgomery products) maps scale e to 7e - 6; a linear layer
-// with its reduction maps e to e - 1 (the reduction divides by R). Round constants are added as rc * R^e, computed at
-// compile time (LAZY below). The initial external rounds walk 1 -> 0 | -6 -> -7 | -55 -> -56 | -398 -> -399 | -2799 -> -2800;
-// one Montgomery product per word by R^2802 brings the state back to e = 1 (the usual Montgomery form), where the
-// internal rounds stay (the S-box fixes e = 1, and a diagonal entry times a word PLUS the sum is one multiply-add in
-// front of the reduction); the terminal rounds walk 1 -> 0 | ... | -398 -> -399 and the result is canonicalised by one
-// product with R^401. All of it is exact arithmetic on representatives of the same field elements: the canonical result
-// equals permute_ref_t's.
+// number (an exponent mod P - 1), the same for all 16 words. The S-box (four signed Montgomery products) maps scale e
+// to 7e - 6; an external layer with its reduction maps e to e - 1 (the reduction divides by R). Round constants are
+// added as rc * R^e, computed at compile time (LAZY below). The initial external rounds walk
+// 1 -> 0 | -6 -> -7 | -55 -> -56 | -398 -> -399 | -2799 -> -2800. An internal round is
+// y_i = redc(x_i * D_i + (S mod P) * K) -- a diagonal entry times a word PLUS the sum of the state is one multiply-add in
+// front of the reduction -- and the constants D_i, K hold whatever power of R the round has to apply: the first internal
+// round takes the state from -2800 to 1 (Montgomery form, which the S-box fixes: the middle rounds stay there), the last
+// one leaves it at the scale from which the four terminal rounds arrive at e = 1 (7 is a unit mod P - 1, so the walk
+// is solved backwards at compile time). No word is ever rescaled by a product of its own: the result of the last
+// external layer is the Montgomery word, up to `min(r, r + P)`. All of it is exact arithmetic on representatives of
+// the same field elements: the canonical result equals permute_ref_t's.
 //
 // Ranges (|.| of the int32 representatives; h = 2^32; 2^31 = 1.0667 P):
 //   smont_redc(x) = (x - m P) / h with a signed word m: |result| <= |x| / h + P/2, for |x| <= 2^62.
-//   S-box: |s| <= P + 33  ->  |s^2| <= .969 P, |s^3| <= .955 P, |s^4| <= .941 P, |s^7| <= .921 P.
+//   S-box: any int32 may enter. |s| <= P + 33 -> |s^2| <= .969 P, |s^3| <= .955 P, |s^4| <= .941 P, |s^7| <= .921 P.
 //   external layer: |column sums| <= 4 * .921 P, |z| <= 5 * .921 P, |y| <= 7 |z| < 33 P < 2^36; reduced |a| <= P/2 + 16;
 //     with the next round's constant (|c| <= P/2) the S-box input is within P + 16.
-//   internal round, words 1..15 bounded by b = .75 P, the S-box output by .921 P: |S| <= 12.2 P; S mod P as a centred
-//     word Sc (|Sc| <= .534 P: q = round(S / 2^27 / 15), Sc = S - q P); T = Sc * (R mod P), |T| <= .0334 P h;
-//     y_i = redc(x_i D_i + T) with |D_i| <= P/2: |y_i| <= .2344 b + .0334 P + P/2 <= .71 P (b holds). A word that is an
-//     S-box input next takes its round constant along as C = rc_m (R mod P) in [0, .0625 P h): word 0 (made from the
-//     S-box output) <= .2158 P + .0334 P + .0625 P + P/2 = .812 P, the others <= .772 P -- any int32 suits the S-box.
+//   internal round, words 1..15 bounded by b, the S-box output by .921 P (.95 P for the inputs below): |S| <= .95 P + 15 b;
+//     S mod P as a centred word Sc (|Sc| <= .534 P: q = round(S / 2^27 / 15), Sc = S - q P); T = Sc K, |K| <= P/2:
+//     |T| <= .125 P h (.0334 P h in the middle rounds, where K = R mod P < 2^28); y_i = redc(x_i D_i + T [+ C]) with
+//     |D_i| <= P/2 and a round constant C < P riding along in front of the next S-box:
+//       first round (b = P/2 + 16, and word 0's own term x_0 K0 <= .216 P h in every sum): |y_i| <= .117 P + .216 P +
+//         .125 P + P/2 = .958 P, word 0 <= .841 P;
+//       middle rounds: |y_i| <= .2344 b + .0334 P + P/2: .958 P -> .758 P -> .711 P -> ... (b <= .75 P from the third on),
+//         word 0 <= .2158 P + .0334 P + P/2 = .75 P;  |S| <= 15.3 P < 2^35 in the second round, <= 12.2 P afterwards;
+//       last round: |y_i| <= .2344 * .75 P + .125 P + P/2 = .80 P -- the inputs of the first terminal S-boxes.
 namespace lazy {
-constexpr uint32_t R_MOD_P = 0x0ffffffeu;  // 2^32 mod P
-constexpr uint32_t rpow(int e) { return e >= 0 ? bb::cx_powmod(R_MOD_P, (uint64_t)e) : bb::cx_powmod(bb::cx_powmod(R_MOD_P, bb::P - 2), (uint64_t)(-e)); }
+constexpr uint64_t N = bb::P - 1;           // exponents of R live mod P - 1
+constexpr uint32_t R_MOD_P = 0x0ffffffeu;   // 2^32 mod P
+constexpr uint64_t emod(int64_t e) { return (uint64_t)(((e % (int64_t)N) + (int64_t)N) % (int64_t)N); }
+constexpr uint32_t rpow(uint64_t e) { return bb::cx_powmod(R_MOD_P, e % N); }
 constexpr int32_t centre(uint32_t canon) { return canon > bb::P / 2 ? (int32_t)canon - (int32_t)bb::P : (int32_t)canon; }
-// the constant that adds the round constant with Montgomery word rc_m (= rc R) to a state at scale e: rc R^e
-constexpr int32_t scaled(uint32_t rc_m, int e) { return centre(bb::cx_mulmod(rc_m, rpow(e - 1))); }
-static constexpr int E_INITIAL[4] = {0, -7, -56, -399};  // scale of the state the S-boxes of initial round r see
-static constexpr int E_AFTER_INITIAL = -2800;
-static constexpr int E_TERMINAL[4] = {1, 0, -7, -56};
-static constexpr int E_OUT = -399;
-static constexpr int32_t K_ENTER = centre(rpow(2 - E_AFTER_INITIAL));  // smont_mul(a, K) = a R^(1 - e): to Montgomery form
-static constexpr int32_t K_EXIT = centre(rpow(2 - E_OUT));
-static constexpr int32_t ROUND_15 = 4369, RM = (int32_t)R_MOD_P;  // 4369 / 2^16 = (1 / 15)(1 - 2^-16)
+constexpr uint64_t inv7() {
+    for (uint64_t k = 0; k < 7; k++)
+        if ((1 + k * N) % 7 == 0) return (1 + k * N) / 7;
+    return 0;
+}
+static constexpr uint64_t INV7 = inv7();
+static_assert(7 * INV7 % N == 1, "7 is a unit mod P - 1");
+constexpr uint64_t before_sbox(uint64_t after) { return (after + 6) % N * INV7 % N; }  // e with 7e - 6 = after
+// scale of the state the S-boxes of external round r see
+static constexpr uint64_t E_INITIAL[4] = {0, emod(-7), emod(-56), emod(-399)};
+static constexpr uint64_t E_ENTER = emod(-2800);                 // ... the first internal round sees
+static constexpr uint64_t E_ENTER_SBOX = (7 * E_ENTER + N - 6) % N;  // ... its S-box output has
+static constexpr uint64_t E_T3 = before_sbox(2), E_T2 = before_sbox(E_T3 + 1), E_T1 = before_sbox(E_T2 + 1), E_T0 = before_sbox(E_T1 + 1);
+static constexpr uint64_t E_TERMINAL[4] = {E_T0, E_T1, E_T2, E_T3};
+static_assert((7 * E_T3 + N - 6) % N == 2 && (7 * E_T0 + N - 6) % N == (E_T1 + 1) % N, "the terminal rounds end in Montgomery form");
+static constexpr int32_t ROUND_15 = 4369;  // 4369 / 2^16 = (1 / 15)(1 - 2^-16)
 #define P2_INV2K(k) bb::cx_powmod(bb::cx_powmod(2, bb::P - 2), (k))
 static constexpr uint32_t DIAG_CANON[16] = {
     bb::P - 2, 1, 2, P2_INV2K(1), 3, 4, bb::P - P2_INV2K(1), bb::P - 3, bb::P - 4, P2_INV2K(8),
     P2_INV2K(2), P2_INV2K(3), P2_INV2K(27), bb::P - P2_INV2K(8), bb::P - P2_INV2K(4), bb::P - P2_INV2K(27)};
 #undef P2_INV2K
-struct Tables {
-    int32_t c_initial[64];   // added in front of the S-boxes of the initial rounds
-    int32_t c_terminal[64];  // ... of the terminal rounds 1..3 (round 0's ride in the last internal round's sums)
-    int64_t C_terminal0[16]; // round constants of terminal round 0 at scale 2 (C / R is the Montgomery word)
-    int64_t C_internal[13];  // ... of internal round r (word 0)
-    int32_t diag[16];        // the internal diagonal as centred Montgomery words
+// the multiplier constants of one internal round that takes words at scale e_in (word 0, after its S-box, at e_in0)
+// to scale e_out: y_i R^e_out = redc(x_i * d_i R^(e_out + 1 - e_in) + ...)
+struct RoundK {
+    int32_t diag[16];  // word i's multiplier (word 0: (d_0 + 1) R^(e_out + 1 - e_in0) in the first round, see internal_round_first)
+    int32_t k_sum;     // the multiplier of Sc
+    int32_t k_word0;   // first round only: x_0's share of the sum, R^(e_out + 1 - e_in0)
 };
+constexpr RoundK make_round(uint64_t e_in, uint64_t e_in0, uint64_t e_out, bool first) {
+    RoundK k{};
+    const uint32_t f = rpow(e_out + 1 + N - e_in), f0 = rpow(e_out + 1 + N - e_in0);
+    for (int i = 0; i < 16; i++) k.diag[i] = centre(bb::cx_mulmod(DIAG_CANON[i], i == 0 ? f0 : f));
+    if (first) k.diag[0] = centre(bb::P - f0);  // d_0 + 1 = -1
+    k.k_sum = centre(f);
+    k.k_word0 = centre(f0);
+    return k;
+}
+struct Tables {
+    int32_t c_initial[64];     // added in front of the S-boxes of the initial rounds
+    int32_t c_terminal[64];    // ... of the terminal rounds 1..3 (round 0's ride in the last internal round's sums)
+    int32_t c_internal0;       // ... of the first internal round (word 0)
+    uint32_t C_internal[13];   // the constant of internal round r >= 1 as it rides in round r - 1's sum: rc R^2 (canonical)
+    uint32_t C_terminal0[16];  // the constants of terminal round 0 as they ride in the last internal round's sums
+    RoundK first, middle, last;
+};
+// rc R^e from the Montgomery word rc_m = rc R
+constexpr uint32_t scaled(uint32_t rc_m, uint64_t e) { return bb::cx_mulmod(rc_m, rpow(e + N - 1)); }
 constexpr Tables make_tables() {
     Tables t{};
     for (int r = 0; r < 4; r++)
         for (int i = 0; i < 16; i++) {
-            t.c_initial[16 * r + i] = scaled(RC_INITIAL[16 * r + i], E_INITIAL[r]);
-            t.c_terminal[16 * r + i] = scaled(RC_TERMINAL[16 * r + i], E_TERMINAL[r]);
+            t.c_initial[16 * r + i] = centre(scaled(RC_INITIAL[16 * r + i], E_INITIAL[r]));
+            t.c_terminal[16 * r + i] = centre(scaled(RC_TERMINAL[16 * r + i], E_TERMINAL[r]));
         }
-    for (int i = 0; i < 16; i++) t.C_terminal0[i] = (int64_t)RC_TERMINAL[i] * RM;
-    for (int r = 0; r < 13; r++) t.C_internal[r] = (int64_t)RC_INTERNAL[r] * RM;
-    for (int i = 0; i < 16; i++) t.diag[i] = centre(bb::cx_to_mont(DIAG_CANON[i]));
+    t.c_internal0 = centre(scaled(RC_INTERNAL[0], E_ENTER));
+    for (int r = 0; r < 13; r++) t.C_internal[r] = scaled(RC_INTERNAL[r], 2);
+    for (int i = 0; i < 16; i++) t.C_terminal0[i] = scaled(RC_TERMINAL[i], E_T0 + 1);
+    t.first = make_round(E_ENTER, E_ENTER_SBOX, 1, true);
+    t.middle = make_round(1, 1, 1, false);
+    t.last = make_round(1, 1, E_T0, false);
     return t;
 }
 static constexpr Tables LAZY = make_tables();
+static_assert(LAZY.middle.k_sum == (int32_t)R_MOD_P && LAZY.middle.diag[1] == (int32_t)R_MOD_P, "a middle round multiplies by Montgomery words");
 
 // c + a with the sign extension done by the multiply-add itself (v_mad_i64_i32 a, 1, c: ONE instruction; written as
 // `c + (int64) a` the compiler extends first -- a shift and a move into a register pair -- and adds then; with an opaque
@@ -266,14 +305,22 @@ BB_HD int64_t widen(int32_t a) {
 #endif
 }
 BB_HD int64_t mad(int32_t a, int32_t b, int64_t c) { return c + (int64_t)a * (int64_t)b; }
-// a wave-uniform constant the compiler may not reason about (it stays ONE multiply-add operand)
+// a wave-uniform constant the compiler may not reason about: it stays ONE multiply-add operand (a literal 2^28 - 2 or a
+// power of two becomes 64-bit shifts, masks and a subtract)
 BB_HD int32_t opaque(int32_t k) {
 #if defined(__HIP_DEVICE_COMPILE__)
     asm("" : "+s"(k));
 #endif
     return k;
 }
-// s^7 R^-6 for any int32 s with |s| <= P + 33, as a representative within .921 P
+// (a 64-bit sum the compiler may not take apart: `x D + (Sc K + 0)` would be re-associated into a second multiply-add per word)
+BB_HD int64_t pin(int64_t t) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm("" : "+v"(t));
+#endif
+    return t;
+}
+// s^7 R^-6 for any int32 s, as a representative within .921 P (|s| <= P + 33) / .95 P (any s)
 BB_HD int32_t sbox7(int32_t s) {
     const int32_t s2 = bb::smont_mul(s, s), s3 = bb::smont_mul(s2, s), s4 = bb::smont_mul(s2, s2);
     return bb::smont_mul(s4, s3);
@@ -287,7 +334,7 @@ BB_HD void mat4_redc(const int64_t *z, int32_t *out) {
     out[2] = bb::smont_redc(t01233 + t23);
 }
 // state <- M_E state / R.  out_b = M4 (x_b + X), X = the sum of the four blocks (circ(2 M4, M4, M4, M4) = M4 (I + J)).
-// IN / OUT8 as in external_linear.
+// IN / OUT8 as in p2::external_linear.
 template <int IN = 16, bool OUT8 = false>
 BB_HD void external_linear(int32_t *s) {
     static_assert(IN == 16 || IN == 8 || IN == 4, "IN");
@@ -313,49 +360,64 @@ BB_HD void external_linear(int32_t *s) {
         }
     }
 }
-// One internal round on a state in Montgomery form: s[0] is the S-box INPUT (its round constant already added).
-// C0: what rides in word 0's sum (the next internal round's constant, or nothing); C (16 or null): the same for all
-// words (the constants of the first terminal round behind the last internal one).
-BB_HD void internal_round(int32_t *s, int64_t C0, const int64_t *C) {
+// S mod P as a centred word: q = round(S / 2^27 / 15) (|S / 2^27| < 250), Sc = S - q P within .534 P
+BB_HD int32_t centred_sum(int64_t S) {
+    const int32_t q = ((int32_t)(S >> 27) * ROUND_15 + 32768) >> 16;
+    return (int32_t)mad(q, bb::NEG_P, S);
+}
+// One internal round: s[0] is the S-box INPUT (its round constant already added); the words leave at the scale K is made
+// for. C0: the constant that rides in word 0's sum (the next internal round's), or 0; C (16 or null): the same for all
+// words (the first terminal round's constants behind the last internal round).
+BB_HD void internal_round(int32_t *s, const RoundK &K, uint32_t C0, const uint32_t *C) {
     s[0] = sbox7(s[0]);
     int64_t S = widen(s[0]);
 #pragma unroll
     for (int i = 1; i < 16; i++) S = add_word(S, s[i]);
-    const int32_t q = ((int32_t)(S >> 27) * ROUND_15 + 32768) >> 16;  // round(S / 2^27 / 15): |S / 2^27| < 200
-    const int32_t Sc = (int32_t)mad(q, bb::NEG_P, S);                 // S - q P, within .534 P
-    int64_t T = mad(Sc, opaque(RM), 0);  // (a literal 2^28 - 2 would be strength-reduced into 64-bit shifts and a subtract)
-#if defined(__HIP_DEVICE_COMPILE__)
-    asm("" : "+v"(T));  // (or re-associated into a second multiply-add per word: x D + (Sc RM + 0))
-#endif
+    const int64_t T = pin(mad(centred_sum(S), opaque(K.k_sum), 0));
 #pragma unroll
     for (int i = 0; i < 16; i++) {
-        int64_t t = mad(s[i], opaque(LAZY.diag[i]), T);  // (opaque: powers of two would become 64-bit shifts and masks)
-        if (i == 0) t += C0;
-        if (C) t += C[i];
+        int64_t t = mad(s[i], opaque(K.diag[i]), T);
+        if (C) t += (int64_t)C[i];
+        else if (i == 0 && C0) t += (int64_t)C0;
         s[i] = bb::smont_redc(t);
     }
 }
-}  // namespace lazy
+// The first internal round: the words arrive at scale E_ENTER, word 0 leaves its S-box at another one, so the sum of the
+// state is made of two terms: x_0 K0 + (the other fifteen mod P) K1. Word 0's own d_0 x_0 = -2 x_0 and its share of the
+// sum are one term, -x_0 K0.
+BB_HD void internal_round_first(int32_t *s, const RoundK &K, uint32_t C0) {
+    s[0] = sbox7(s[0]);
+    int64_t S = widen(s[1]);
+#pragma unroll
+    for (int i = 2; i < 16; i++) S = add_word(S, s[i]);
+    const int64_t U = pin(mad(centred_sum(S), opaque(K.k_sum), 0));
+    const int64_t T = pin(mad(s[0], opaque(K.k_word0), U));
+    s[0] = bb::smont_redc(mad(s[0], opaque(K.diag[0]), U) + (int64_t)C0);
+#pragma unroll
+    for (int i = 1; i < 16; i++) s[i] = bb::smont_redc(mad(s[i], opaque(K.diag[i]), T));
+}
 
-namespace lazy {
 // where the round constants come from: the default table (literals after unrolling) ...
 struct TableRC {
     BB_HD int32_t c_initial(int r, int i) const { return LAZY.c_initial[16 * r + i]; }
     BB_HD int32_t c_terminal(int r, int i) const { return LAZY.c_terminal[16 * r + i]; }
-    BB_HD int64_t C_terminal0(int i) const { return LAZY.C_terminal0[i]; }
-    BB_HD int64_t C_internal(int r) const { return LAZY.C_internal[r]; }
+    BB_HD int32_t c_internal0() const { return LAZY.c_internal0; }
+    BB_HD uint32_t C_internal(int r) const { return LAZY.C_internal[r]; }
+    BB_HD uint32_t C_terminal0(int i) const { return LAZY.C_terminal0[i]; }
 };
-// ... or memory (`rc`: 64 initial, 64 terminal, 13 internal Montgomery words), scaled as they are read
+// ... or memory (`rc`: 64 initial, 64 terminal, 13 internal Montgomery words), scaled as they are read:
+// rc * R^e = rc_m * R^(e - 1) = mont_mul(rc_m, R^e)
 static constexpr uint32_t RPOW_INITIAL[4] = {rpow(E_INITIAL[0]), rpow(E_INITIAL[1]), rpow(E_INITIAL[2]), rpow(E_INITIAL[3])};
 static constexpr uint32_t RPOW_TERMINAL[4] = {rpow(E_TERMINAL[0]), rpow(E_TERMINAL[1]), rpow(E_TERMINAL[2]), rpow(E_TERMINAL[3])};
+static constexpr uint32_t RPOW_ENTER = rpow(E_ENTER), RPOW_2 = rpow(2), RPOW_T0_1 = rpow(E_T0 + 1);
 struct MemoryRC {
     const uint32_t *rc;
     BB_HD static int32_t centre_rt(uint32_t v) { return v > bb::P / 2 ? (int32_t)v - (int32_t)bb::P : (int32_t)v; }
-    // rc_m * R^(e - 1) = mont_mul(rc_m, R^e)
     BB_HD int32_t c_initial(int r, int i) const { return centre_rt(bb::mont_mul(rc[16 * r + i], RPOW_INITIAL[r])); }
     BB_HD int32_t c_terminal(int r, int i) const { return centre_rt(bb::mont_mul(rc[64 + 16 * r + i], RPOW_TERMINAL[r])); }
-    BB_HD int64_t C_terminal0(int i) const { return (int64_t)rc[64 + i] * RM; }
-    BB_HD int64_t C_internal(int r) const { return (int64_t)rc[128 + r] * RM; }
+    BB_HD int32_t c_internal0() const { return centre_rt(bb::mont_mul(rc[128], RPOW_ENTER)); }
+    BB_HD uint32_t C_internal(int r) const { return bb::mont_mul(rc[128 + r], RPOW_2); }
+    BB_HD uint32_t C_terminal0(int i) const { return bb::mont_mul(rc[64 + i], RPOW_T0_1); }
 };
 template <class RC, int IN, bool OUT8>
 BB_HD void permute(Fp *st, const RC &rc) {
@@ -369,15 +431,14 @@ BB_HD void permute(Fp *st, const RC &rc) {
         for (int i = 0; i < 16; i++) s[i] = sbox7(s[i] + rc.c_initial(r, i));
         external_linear(s);
     }
-    // to Montgomery form; word 0 takes the first internal constant with it (it is an S-box input next)
-    s[0] = bb::smont_redc(mad(s[0], K_ENTER, rc.C_internal(0)));
+    s[0] += rc.c_internal0();
+    internal_round_first(s, LAZY.first, rc.C_internal(1));
 #pragma unroll
-    for (int i = 1; i < 16; i++) s[i] = bb::smont_mul(s[i], K_ENTER);
-    int64_t Ct[16];
+    for (int r = 1; r < 12; r++) internal_round(s, LAZY.middle, rc.C_internal(r + 1), nullptr);
+    uint32_t Ct[16];
 #pragma unroll
     for (int i = 0; i < 16; i++) Ct[i] = rc.C_terminal0(i);
-#pragma unroll
-    for (int r = 0; r < 13; r++) internal_round(s, r < 12 ? rc.C_internal(r + 1) : 0, r < 12 ? nullptr : Ct);
+    internal_round(s, LAZY.last, 0, Ct);
 #pragma unroll
     for (int r = 0; r < 4; r++) {
 #pragma unroll
@@ -386,7 +447,7 @@ BB_HD void permute(Fp *st, const RC &rc) {
         else external_linear(s);
     }
 #pragma unroll
-    for (int i = 0; i < (OUT8 ? 8 : 16); i++) st[i] = Fp::raw(bb::from_signed(bb::smont_mul(s[i], K_EXIT)));
+    for (int i = 0; i < (OUT8 ? 8 : 16); i++) st[i] = Fp::raw(bb::from_signed(s[i]));
 }
 }  // namespace lazy
 

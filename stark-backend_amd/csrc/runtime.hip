@@ -29,6 +29,7 @@ thread_local hipStream_t g_prof_side = nullptr;
 thread_local bool g_prof_has_side = false;
 int g_prof_mode = 0;  // 0 off, 1 every stage, 2 the dominant kernel's label only
 std::vector<ProfRec> g_prof;
+unsigned g_prof_generation = 0;  // bumped whenever the list is cleared (under g_prof_mutex)
 std::mutex g_prof_mutex;  // (the engines of a throughput run record from several threads)
 
 // roctx ranges under the same labels (reference: the NVTX layer of crates/stark-sdk/src/nvtx_tracing.rs:9-33).
@@ -98,6 +99,7 @@ ProfScope::ProfScope(const char *label, hipStream_t s) : stream(s) {
     {
         std::lock_guard<std::mutex> lk(g_prof_mutex);
         slot = (int)g_prof.size();
+        generation = g_prof_generation;
         g_prof.push_back(r);
     }
     g_prof_depth++;
@@ -107,7 +109,9 @@ ProfScope::~ProfScope() {
         hipEvent_t b;
         {
             std::lock_guard<std::mutex> lk(g_prof_mutex);
-            b = slot < (int)g_prof.size() ? g_prof[slot].b : nullptr;  // (profile_enable may have cleared the records)
+            // profile_enable may have cleared the records while this scope was open -- and another thread may have pushed
+            // new ones since: the slot then names somebody else's record, so the end is not recorded at all
+            b = generation == g_prof_generation && slot < (int)g_prof.size() ? g_prof[slot].b : nullptr;
         }
         if (b) (void)hipEventRecord(b, stream);
         g_prof_depth--;
@@ -125,6 +129,7 @@ int ovm_hip_profile_enable(int on) {
         (void)hipEventDestroy(r.b);
     }
     ovm::g_prof.clear();
+    ovm::g_prof_generation++;
     ovm::g_prof_mode = on < 0 || on > 2 ? 1 : on;
     return 0;
 }

@@ -98,35 +98,54 @@ def pick_cores(local_rank, gpu_bdfs, allowed_cpus, sysfs="/sys", skip=SKIP_CORES
     return pair, {"numa_node": node, "slot_on_node": slot, "physical_cores_on_node": len(cores), "basis": why}
 
 
-def kfd_gpu_bdfs(sysfs="/sys"):
-    """PCI addresses of the GPUs in HIP's device order WITHOUT touching the runtime: the KFD topology lists the GPU nodes
-    (simd_count > 0) in the order the runtime enumerates them, with `domain` and `location_id` (bus << 8 | device << 3 |
-    function). HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES given as plain index lists are honoured; anything else (UUIDs)
-    returns None and the caller asks torch. None also when the topology is not readable."""
+def kfd_gpu_bdfs_why(sysfs="/sys", dev="/dev", environ=None):
+    """(PCI addresses of the GPUs in HIP's device order, None) WITHOUT touching the runtime, or (None, reason). The KFD
+    topology lists the GPU nodes (simd_count > 0) in the order the runtime enumerates them, with `domain` and
+    `location_id` (bus << 8 | device << 3 | function). ROCR_VISIBLE_DEVICES, then HIP_VISIBLE_DEVICES (CUDA_VISIBLE_DEVICES
+    is its alias: read only when HIP_ is unset, never applied on top of it) are honoured as plain index lists; anything
+    else (UUIDs) gives up. In a container whose cgroup exposes fewer GPUs than the host has, the topology still lists
+    every GPU of the host while the runtime enumerates only the accessible ones: the number of render nodes the process
+    can open is compared with the topology's count, and a difference gives up too (the caller asks torch then)."""
+    environ = os.environ if environ is None else environ
     base = os.path.join(sysfs, "class", "kfd", "kfd", "topology", "nodes")
     try:
         nodes = sorted((int(n) for n in os.listdir(base) if n.isdigit()))
-    except OSError:
-        return None
+    except OSError as e:
+        return None, f"kfd topology not listable ({e.__class__.__name__})"
     gpus = []
     for n in nodes:
         try:
             props = dict(line.split()[:2] for line in open(os.path.join(base, str(n), "properties")) if len(line.split()) >= 2)
-        except OSError:
-            return None
+        except OSError as e:
+            return None, f"kfd node {n} properties unreadable ({e.__class__.__name__})"
         if int(props.get("simd_count", "0")) == 0:
             continue
         loc, dom = int(props.get("location_id", "0")), int(props.get("domain", "0"))
         gpus.append(f"{dom:04x}:{(loc >> 8) & 0xff:02x}:{(loc >> 3) & 0x1f:02x}.{loc & 7}")
-    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
-        v = os.environ.get(var)
+    if not gpus:
+        return None, "kfd topology lists no GPU node"
+    try:
+        render = [n for n in os.listdir(os.path.join(dev, "dri")) if n.startswith("renderD")]
+        usable = [n for n in render if os.access(os.path.join(dev, "dri", n), os.R_OK | os.W_OK)]
+    except OSError:
+        usable = None
+    if usable is not None and len(usable) != len(gpus):
+        return None, f"kfd topology lists {len(gpus)} GPUs, {len(usable)} render nodes are accessible (restricted container)"
+    hip = environ.get("HIP_VISIBLE_DEVICES")
+    if hip is None or hip == "":
+        hip = environ.get("CUDA_VISIBLE_DEVICES")
+    for name, v in (("ROCR_VISIBLE_DEVICES", environ.get("ROCR_VISIBLE_DEVICES")), ("HIP_VISIBLE_DEVICES", hip)):
         if v is None or v == "":
             continue
         try:
             gpus = [gpus[int(i)] for i in v.split(",")]
         except (ValueError, IndexError):
-            return None
-    return gpus or None
+            return None, f"{name}={v!r} is not a list of indices into {len(gpus)} GPUs"
+    return (gpus, None) if gpus else (None, "no GPU left after the visibility lists")
+
+
+def kfd_gpu_bdfs(sysfs="/sys", dev="/dev", environ=None):
+    return kfd_gpu_bdfs_why(sysfs, dev, environ)[0]
 
 
 def torch_gpu_bdfs():
@@ -154,10 +173,12 @@ def pin_this_process(local_rank, gpu_bdfs=None, sysfs="/sys", slot_rank=None):
     try:
         allowed = sorted(os.sched_getaffinity(0))
         source = "caller"
+        kfd_reason = None
         if gpu_bdfs is None:
-            gpu_bdfs, source = kfd_gpu_bdfs(sysfs), "kfd topology (sysfs)"
+            (gpu_bdfs, kfd_reason), source = kfd_gpu_bdfs_why(sysfs), "kfd topology (sysfs)"
         if gpu_bdfs is None:
-            gpu_bdfs, source = torch_gpu_bdfs(), "torch device properties (the runtime was initialised before the pinning)"
+            gpu_bdfs = torch_gpu_bdfs()
+            source = f"torch device properties (the runtime was initialised before the pinning; sysfs: {kfd_reason})"
         if slot_rank is not None:  # several ranks on GPU `local_rank`: one pair each, as if each had its own GPU there
             gpu_bdfs = [gpu_bdfs[local_rank] if local_rank < len(gpu_bdfs) else None] * (slot_rank + 1)
             local_rank = slot_rank

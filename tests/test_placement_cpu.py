@@ -95,3 +95,42 @@ def test_pin_this_process_states_what_it_did(tmp_path):
             assert os.sched_getaffinity(0) == set(rec["cpus"]) and len(set(rec["cpus"])) == 2
     finally:
         os.sched_setaffinity(0, before)
+
+
+def _fake_kfd(tmp_path, gpus, render_nodes):
+    """A sysfs + /dev tree with one CPU node and `gpus` GPU nodes (location ids), `render_nodes` accessible render nodes."""
+    base = tmp_path / "sys" / "class" / "kfd" / "kfd" / "topology" / "nodes"
+    (base / "0").mkdir(parents=True)
+    (base / "0" / "properties").write_text("simd_count 0\nlocation_id 0\ndomain 0\n")
+    for i, loc in enumerate(gpus):
+        (base / str(i + 1)).mkdir()
+        (base / str(i + 1) / "properties").write_text(f"simd_count 1024\nlocation_id {loc}\ndomain 0\n")
+    dri = tmp_path / "dev" / "dri"
+    dri.mkdir(parents=True)
+    for i in range(render_nodes):
+        (dri / f"renderD{128 + i}").write_text("")
+    return str(tmp_path / "sys"), str(tmp_path / "dev")
+
+
+def test_kfd_topology_visibility_lists_and_restricted_containers(tmp_path):
+    """HIP_ / CUDA_VISIBLE_DEVICES are ONE variable (HIP first, never applied twice); a topology that lists more
+    GPUs than the process can open (a cgroup-restricted container) is not trusted; every refusal says why."""
+    locs = [(0x05 << 8), (0x15 << 8), (0x65 << 8), (0x75 << 8)]
+    sysfs, dev = _fake_kfd(tmp_path, locs, 4)
+    all4 = ["0000:05:00.0", "0000:15:00.0", "0000:65:00.0", "0000:75:00.0"]
+    assert placement.kfd_gpu_bdfs_why(sysfs, dev, {}) == (all4, None)
+    # aliases: both set to the same list selects ONCE (applied twice, "2,3" of a 2-list would be out of range)
+    got, why = placement.kfd_gpu_bdfs_why(sysfs, dev, {"HIP_VISIBLE_DEVICES": "2,3", "CUDA_VISIBLE_DEVICES": "2,3"})
+    assert got == all4[2:] and why is None
+    # HIP wins over its alias; ROCR is applied first, HIP indexes into what ROCR left
+    assert placement.kfd_gpu_bdfs(sysfs, dev, {"HIP_VISIBLE_DEVICES": "1", "CUDA_VISIBLE_DEVICES": "3"}) == [all4[1]]
+    assert placement.kfd_gpu_bdfs(sysfs, dev, {"CUDA_VISIBLE_DEVICES": "3"}) == [all4[3]]
+    assert placement.kfd_gpu_bdfs(sysfs, dev, {"ROCR_VISIBLE_DEVICES": "2,3", "HIP_VISIBLE_DEVICES": "1"}) == [all4[3]]
+    got, why = placement.kfd_gpu_bdfs_why(sysfs, dev, {"HIP_VISIBLE_DEVICES": "GPU-abcdef"})
+    assert got is None and "HIP_VISIBLE_DEVICES" in why
+    # the host has 4 GPUs, the container sees one render node: index 0 of the topology may be another GPU's NUMA node
+    sysfs1, dev1 = _fake_kfd(tmp_path / "restricted", locs, 1)
+    got, why = placement.kfd_gpu_bdfs_why(sysfs1, dev1, {})
+    assert got is None and "render nodes" in why
+    got, why = placement.kfd_gpu_bdfs_why(str(tmp_path / "nothing"), dev, {})
+    assert got is None and "not listable" in why
