@@ -53,9 +53,11 @@ def launch_ranks(args):
     sys.exit(subprocess.run(cmd, env=env).returncode)
 
 
-# The ISSUE roof of the integer kernels: a wave64 integer VALU instruction occupies its SIMD for 4.05 shader
-# cycles at 2.4 GHz (measured, tools/ubench_poseidon2.hip + tools/ubench_int.hip; the guide's 2-cycle figure is for
-# v_fma_f32), so the chip issues at most CUs x 4 SIMDs x 2.4e9 / 4.05 wave-level VALU instructions per second.
+# The ISSUE roof of the integer kernels: a wave64 integer VALU instruction occupies its SIMD for ~4.05-4.1 shader
+# cycles at 2.4 GHz (measured on the Poseidon2 instruction stream, tools/ubench_poseidon2.hip; per instruction,
+# tools/ubench_int64.hip: multiplies, 64-bit multiply-adds and adds, min ~4.3-4.7 in a dependent-chain harness, v_add_u32 /
+# v_sub_u32 / 32-bit shifts ~2.5-2.9; the guide's 2-cycle figure is for v_fma_f32), so the chip issues about
+# CUs x 4 SIMDs x 2.4e9 / 4.05 wave-level VALU instructions per second -- a little more for a stream rich in plain adds.
 ISSUE_CYCLES_PER_WAVE_VALU = 4.05
 SHADER_CLOCK_HZ = 2.4e9
 # which kernels make up a class (prefixes of the demangled names in profiles/*/sq_valu*.json)
@@ -81,11 +83,19 @@ def checked_digest_verdict(args, world, digest):
     return open(path).read().strip() == digest
 
 
-def load_sq_valu():
-    for rel in (("profiles", "r05", "sq_valu_r05.json"), ("profiles", "r04", "sq_valu_r04.json"), ("profiles", "r03", "sq_valu_r03.json")):
-        q = os.path.join(ROOT, *rel)
+def newest_profile(pattern, rounds=(6, 5, 4, 3, 2)):
+    """The committed counter file of the newest round that has one: profiles/rNN/<pattern with {r} = rNN>, or ""."""
+    for n in rounds:
+        q = os.path.join(ROOT, "profiles", f"r{n:02d}", pattern.format(r=f"r{n:02d}"))
         if os.path.exists(q):
-            return json.load(open(q))["kernels"], os.path.join(*rel)
+            return q
+    return ""
+
+
+def load_sq_valu():
+    q = newest_profile("sq_valu_{r}.json")
+    if q:
+        return json.load(open(q))["kernels"], os.path.relpath(q, ROOT)
     return None, None
 
 
@@ -539,9 +549,7 @@ def main():
             algo_bytes = 4 * rows * width + 32 * rows // rows_per_query
             achieved = algo_bytes / (avg_ms * 1e-3) / 1e9
             traffic, src = None, None
-            pmc = next((q for q in (os.path.join(ROOT, "profiles", "r05", "pmc_hbm_traffic_r05.json"),
-                                    os.path.join(ROOT, "profiles", "r04", "pmc_hbm_traffic_r04.json"),
-                                    os.path.join(ROOT, "profiles", "r03", "pmc_hbm_traffic_r03.json")) if os.path.exists(q)), "")
+            pmc = newest_profile("pmc_hbm_traffic_{r}.json")
             if world == 1 and (log_rows, cols, args.log_stacked_height, args.log_blowup) == (22, 100, 24, 1) and os.path.exists(pmc):
                 k = json.load(open(pmc))["kernels"].get("hash_rows_kernel<1>")
                 if k:
@@ -551,25 +559,29 @@ def main():
                     "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": src,
                     "avg_launch_ms": round(avg_ms, 3), "algorithmic_bytes": algo_bytes, "launches_timed": calls}
-            # VALU view of the same kernel. VALU instructions per permutation (static counts of the four forms a row's
-            # permutations take, round 3: first one 7104 -- zero capacity --, middle ones 7218, last one 7194 -- only the
-            # digest words; 7233 each in round 2), averaged over the permutations of a row.
+            # VALU view of the same kernel. VALU instructions per permutation: the row hash runs ONE permutation body (round 6:
+            # p2::permute_lazy_t, 3 676 VALU by static count, tools/isa_count.py; 7 184 in rounds 3-5) for every permutation
+            # of a row; with a committed SQ counter pass the number is the kernel's own SQ_INSTS_VALU per permutation.
             # Peaks: (a) MI355X_MICROARCH.md's SIMD-32 figure, one wave64 VALU instruction per 2 cycles per SIMD
             # (256 CUs x 4 SIMDs x 32 lanes x 2.4 GHz); (b) the MEASURED ceiling of this instruction mix: the same
             # permutation code on register-resident states, no memory (tools/ubench_poseidon2.hip ->
-            # profiles/r02/poseidon2_mix_ceiling.json), which is what bounds the kernel in practice.
+            # profiles/r06/poseidon2_mix_ceiling.json), which is what bounds the kernel in practice.
             ppr = (width + 7) // 8
-            valu_pp = round((7104 + 7194 + 7218 * (ppr - 2)) / ppr) if ppr >= 2 else 7080
+            valu_pp, valu_src = 3676, "static count of p2::permute (tools/isa_count.py)"
+            sqk, sq_file = load_sq_valu()
+            if sqk and "hash_rows_kernel<1>" in sqk and (log_rows, cols, args.log_stacked_height, args.log_blowup, args.num_airs) == (22, 100, 24, 1, 1):
+                k1 = sqk["hash_rows_kernel<1>"]
+                valu_pp = round(k1["valu_wave_insts"] * 64 / max(1, k1.get("launches", 1)) / (rows * ppr))
+                valu_src = f"{sq_file}: SQ_INSTS_VALU of the kernel / permutations (loads, stores and sponge bookkeeping included)"
             perms = rows * ppr
             props = torch.cuda.get_device_properties(local_rank)
             guide_peak = props.multi_processor_count * 4 * 32 * 2.4e9
-            ib = {"valu_instr_per_permutation": valu_pp, "permutations_per_launch": perms,
+            ib = {"valu_instr_per_permutation": valu_pp, "valu_instr_source": valu_src, "permutations_per_launch": perms,
                   "achieved_Gperm_s": round(perms / (avg_ms * 1e-3) / 1e9, 3),
                   "achieved_Tlaneops": round(valu_pp * perms / (avg_ms * 1e-3) / 1e12, 2),
                   "guide_simd32_peak_Tlaneops": round(guide_peak / 1e12, 2),
                   "frac_of_guide_peak": round(valu_pp * perms / (avg_ms * 1e-3) / guide_peak, 3)}
-            ceil_path = next((q for q in (os.path.join(ROOT, "profiles", "r03", "poseidon2_mix_ceiling.json"),
-                                          os.path.join(ROOT, "profiles", "r02", "poseidon2_mix_ceiling.json")) if os.path.exists(q)), "")
+            ceil_path = newest_profile("poseidon2_mix_ceiling.json")
             if os.path.exists(ceil_path):
                 c = json.load(open(ceil_path))
                 ib["measured_mix_ceiling_Gperm_s"] = c["gperm_per_s"]
@@ -608,7 +620,8 @@ def main():
             ref = os.path.join(ROOT, "profiles", "cargo_box", "cpu_baseline_reference.json")
             if os.path.exists(ref):  # (tools/run_on_cargo_box.sh step 4: the reference's CPU engine on this very workload)
                 cpu["reference"] = dict(json.load(open(ref)), source="profiles/cargo_box/cpu_baseline_reference.json")
-            for rel in (("gpurun_out", "cpu_baseline_full_size.json"), ("profiles", "r05", "cpu_baseline_full_size.json")):
+            for rel in (("gpurun_out", "cpu_baseline_full_size.json"), ("profiles", "r06", "cpu_baseline_full_size.json"),
+                        ("profiles", "r05", "cpu_baseline_full_size.json")):
                 q = os.path.join(ROOT, *rel)
                 if os.path.exists(q):
                     full = json.load(open(q))

@@ -21,5 +21,7 @@ cp "$R/prof/idle_gaps.txt" "$P/idle_gaps_$TAG.txt"
 cp "$R/prof/pmc_hbm_traffic.json" "$P/pmc_hbm_traffic_$TAG.json"
 cp "$R/prof/sq_counters.txt" "$P/sq_counters_$TAG.txt"
 cp "$R/prof/sq_valu.json" "$P/sq_valu_$TAG.json"
+[ -f "$R/poseidon2_mix_ceiling.json" ] && cp "$R/poseidon2_mix_ceiling.json" "$R/poseidon2_mix_ceiling.txt" "$P/"
+[ -f gpurun_out/cpu_baseline_full_size.json ] && cp gpurun_out/cpu_baseline_full_size.json "$P/cpu_baseline_full_size.json"
 cp "$R/prof_b/kernel_stats.txt" "$R/prof_b/kernel_stats.csv" "$R/prof_b/sq_counters.txt" "$R/prof_b/pmc_hbm_traffic.json" "$P/prof_config_b_$TAG/"
 ls "$P" | wc -l

@@ -22,6 +22,9 @@ if [ "$MODE" != quick ]; then
   { nproc; grep -E "MemTotal|MemAvailable" /proc/meminfo; lscpu | grep -E "Model name|Socket|Thread"; } > "$O/box_host.txt" 2>&1
 fi
 timeout 900 bash tools/profile_round.sh "$O/prof" > "$O/profile_round.log" 2>&1
+# the ceiling of the permutation's own instruction stream (bench.py: roofline.issue_bound.measured_mix_ceiling_Gperm_s)
+[ -x tools/ubench_poseidon2 ] || hipcc --offload-arch=gfx950 -O3 -I stark-backend_amd/csrc -I include tools/ubench_poseidon2.hip -o tools/ubench_poseidon2 > /dev/null 2>&1
+timeout 120 ./tools/ubench_poseidon2 "$O/poseidon2_mix_ceiling.json" > "$O/poseidon2_mix_ceiling.txt" 2>&1
 timeout 600 python bench.py > "$O/bench_default_flags.json" 2> "$O/bench_default_flags.err"
 cat "$O/bench_default_flags.json" | cut -c1-300
 timeout 600 python tools/prove_config_b.py --reps 5 --profile > "$O/config_b_keccak.json" 2> "$O/config_b_keccak.err"

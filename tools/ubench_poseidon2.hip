@@ -17,7 +17,8 @@
 
 using bb::Fp;
 static constexpr int ITER = 256;
-static constexpr int VALU_PER_PERM = 7218;  // the full permutation (p2::permute), static count; round 2: 7233
+static constexpr int VALU_PER_PERM = 3676;  // the full permutation (p2::permute = permute_lazy_t on the device), static count (tools/isa_count.py);
+                                             // rounds 3-5: 7218 (one reduction per addition, five-instruction products)
 
 // ticks[0] = shader cycles (s_memtime), ticks[1] = 100 MHz reference ticks (s_memrealtime) of one wave's loop, taken in a
 // workgroup from the middle of the grid (every SIMD is full then): the clock the loop ran at is their ratio x 100 MHz
