@@ -357,6 +357,14 @@ __global__ __launch_bounds__(1 << (TL - 4)) void dif16_pass_kernel(const T *in, 
     auto l_of = [&](uint32_t v) -> uint32_t {
         return ((tid >> bl) << (bl + 4)) | (v << bl) | (tid & ((1u << bl) - 1));
     };
+    // LDS index of register v: bits [bl, bl + 4) of l_of(0) are clear, so l_of(v) = l_of(0) + (v << bl) without a carry and
+    // pad() splits: pad(l_of(v)) = pad(l_of(0)) + x + (x >> 4), x = v << bl -- a lane part computed once per window plus a
+    // WAVE-UNIFORM part (scalar registers), i.e. one vector add per access instead of the shifts, ors and the add of pad()
+    // on every one of the 32 accesses of a window (they were a third of the pass's vector instructions).
+    auto lds_of = [&](uint32_t a0, uint32_t v) -> uint32_t {
+        const uint32_t x = v << bl;
+        return a0 + x + (x >> 4);
+    };
     const uint32_t n_windows = n_full + (last_nb ? 1 : 0);
     for (uint32_t wdx = 0; wdx < n_windows; wdx++) {
         const bool is_last_partial = (last_nb != 0) && (wdx == n_full);
@@ -390,8 +398,9 @@ __global__ __launch_bounds__(1 << (TL - 4)) void dif16_pass_kernel(const T *in, 
                 }
             }
         } else {
+            const uint32_t a0 = pad(l_of(0));
 #pragma unroll
-            for (int v = 0; v < 16; v++) x[v] = tile[pad(l_of(v))];
+            for (int v = 0; v < 16; v++) x[v] = tile[lds_of(a0, v)];
             __syncthreads();
         }
         if (is_last_partial) {
@@ -409,16 +418,18 @@ __global__ __launch_bounds__(1 << (TL - 4)) void dif16_pass_kernel(const T *in, 
             radix_dif<T, 4, true>(x, w0);
         }
         if (wdx + 1 < n_windows) {
+            const uint32_t a0 = pad(l_of(0));
 #pragma unroll
-            for (int v = 0; v < 16; v++) tile[pad(l_of(v))] = x[v];
+            for (int v = 0; v < 16; v++) tile[lds_of(a0, v)] = x[v];
             __syncthreads();
         }
     }
     if (c == 0 && bl == 0) {
         // the last window left every lane with 16 CONSECUTIVE positions: transpose through LDS so
         // that consecutive lanes store consecutive positions (256 B per wave-store)
+        const uint32_t a0 = pad(l_of(0));
 #pragma unroll
-        for (int v = 0; v < 16; v++) tile[pad(l_of(v))] = x[v];
+        for (int v = 0; v < 16; v++) tile[lds_of(a0, v)] = x[v];
         __syncthreads();
 #pragma unroll
         for (int v = 0; v < 16; v++) {

@@ -14,6 +14,6 @@ for tag in ("prod","var"):
         try:
             d=json.load(open(f"{o}/{tag}_{i}.json"))
             st=d.get("stage_ms_additive",{}).get("top_level_on_the_callers_stream",{})
-            print(tag,i,d["ms_per_step"],d["config"].get("proof_matches_checked_digest"),"hash_rows",st.get("merkle.hash_rows"),"compress",st.get("merkle.compress_layers"),"whir.rs",st.get("whir.rs_commit"))
+            print(tag,i,d["ms_per_step"],d["config"].get("proof_matches_checked_digest"),"hash_rows",st.get("merkle.hash_rows"),"compress",st.get("merkle.compress_layers"),"whir.rs",st.get("whir.rs_commit"),"ntt",st.get("ntt.dif_passes"),"gkr",st.get("gkr.layer_sumchecks"))
         except Exception as e: print(tag,i,"failed",e)
 PY
