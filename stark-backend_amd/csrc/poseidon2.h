@@ -7,11 +7,13 @@
 // crates/cuda-backend/cuda/src/sponge.cu:24-62 and crates/stark-backend/src/transcript/
 // duplex_sponge.rs:62-83 (duplex sponge).
 //
-// CDNA4 notes: one lane owns one 16-word state in VGPRs (16 state + ~10 temps, well under the
-// 64-VGPR/8-waves-per-SIMD line); round constants are wave-uniform and compile to scalar
-// literals / s_load, costing no VALU issue. The external 4x4 circulant uses the additive form
-// (7 adds per 4 words); the internal diagonal uses halve/double/shift forms instead of
-// multiplies wherever the diagonal entry is +-2^k.
+// CDNA4 notes: one lane owns one 16-word state in VGPRs (64 VGPRs with the 64-bit sums of a layer); round constants are
+// wave-uniform literals / scalar registers. TWO statements of the permutation live here:
+//   permute_ref_t   the plain one -- canonical words, one modular reduction per addition (the host's scalar fallback, the
+//                   16-lane cooperative form and the yardstick of the self-test);
+//   lazy::permute   what the kernels run since round 6 (3 676 VALU instead of 6 284): linear layers summed unreduced in
+//                   64-bit registers, one signed Montgomery reduction per output word, the scale of the state tracked at
+//                   compile time. See the comment in front of `namespace lazy`.
 #pragma once
 #include "bb31.h"
 
@@ -58,8 +60,8 @@ static constexpr int RATE = 8;
 static constexpr int DIGEST = 8;
 
 // (x + rc)^7. The sum is taken as the signed representative x + rc - P in [-P, P) (one add, rc - P
-// is a literal) and the four multiplies stay in signed Montgomery form (5 instructions each, no
-// per-multiply correction); one min canonicalises the result: 23 VALU instead of 31.
+// is a literal) and the four multiplies stay in signed Montgomery form (3 instructions each, bb31.h: no
+// per-multiply correction); an add and a min canonicalise the result: 15 VALU.
 BB_HD Fp sbox7_add(Fp x, uint32_t rc) {
     int32_t s = (int32_t)(x.v + (rc - bb::P));
     int32_t s2 = bb::smont_mul(s, s);
