@@ -21,15 +21,29 @@ def brev(i, bits):
 
 
 def test_poseidon2_permute(dev, pkg, orc):
+    """The device permutation (poseidon2.h: lazy::permute -- linear layers summed unreduced in 64-bit registers, one signed
+    reduction per word, the state's scale tracked at compile time) against the oracle's plain canonical one on EVERY state
+    of: the range extremes the lazily reduced sums have to hold (all zero, all P - 1, one extreme word among zeros, one zero
+    among extremes, alternating patterns, words around P / 2) and 900 random states."""
     rng = np.random.default_rng(10)
     n = 1000
-    st = rand_fp(rng, 16 * n)
-    st[:16] = 0
-    d = dev.upload(pkg.to_mont(st))
+    st = rand_fp(rng, 16 * n).reshape(n, 16)
+    hi = P - 1
+    st[0] = 0
+    st[1] = hi
+    for i in range(16):
+        st[2 + i] = 0
+        st[2 + i][i] = hi
+        st[18 + i] = hi
+        st[18 + i][i] = 0
+    for k in range(34, 100):
+        pat = [(hi if (k >> (i & 3)) & 1 else (P // 2 + i if k & 32 else 0)) for i in range(16)]
+        st[k] = np.array(pat, dtype=np.uint32)
+    d = dev.upload(pkg.to_mont(st.reshape(-1)))
     dev.poseidon2_permute(d, n)
     got = pkg.from_mont(dev.download(d)).reshape(n, 16)
-    for i in list(range(8)) + [n - 1]:
-        assert np.array_equal(got[i], orc.permute(st[16 * i:16 * i + 16]))
+    for i in range(n):
+        assert np.array_equal(got[i], orc.permute(st[i])), i
 
 
 @pytest.mark.parametrize("l_skip,log_h", [(0, 5), (1, 3), (2, 2), (4, 10), (4, 15), (6, 14)])
