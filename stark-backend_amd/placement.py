@@ -112,10 +112,16 @@ def kfd_gpu_bdfs_why(sysfs="/sys", dev="/dev", environ=None):
         nodes = sorted((int(n) for n in os.listdir(base) if n.isdigit()))
     except OSError as e:
         return None, f"kfd topology not listable ({e.__class__.__name__})"
-    gpus = []
+    gpus, skipped = [], 0
     for n in nodes:
         try:
             props = dict(line.split()[:2] for line in open(os.path.join(base, str(n), "properties")) if len(line.split()) >= 2)
+        except PermissionError:
+            # a GPU of the host this container may not use (the pool's boxes: every node but the leased GPU's reads
+            # "permission denied"): the runtime does not enumerate it either, so it is skipped, not a reason to give up;
+            # the count of render nodes below still has to agree with what is left
+            skipped += 1
+            continue
         except OSError as e:
             return None, f"kfd node {n} properties unreadable ({e.__class__.__name__})"
         if int(props.get("simd_count", "0")) == 0:
@@ -123,7 +129,7 @@ def kfd_gpu_bdfs_why(sysfs="/sys", dev="/dev", environ=None):
         loc, dom = int(props.get("location_id", "0")), int(props.get("domain", "0"))
         gpus.append(f"{dom:04x}:{(loc >> 8) & 0xff:02x}:{(loc >> 3) & 0x1f:02x}.{loc & 7}")
     if not gpus:
-        return None, "kfd topology lists no GPU node"
+        return None, "kfd topology lists no GPU node" + (f" this process may read ({skipped} unreadable)" if skipped else "")
     try:
         render = [n for n in os.listdir(os.path.join(dev, "dri")) if n.startswith("renderD")]
         usable = [n for n in render if os.access(os.path.join(dev, "dri", n), os.R_OK | os.W_OK)]

@@ -134,3 +134,20 @@ def test_kfd_topology_visibility_lists_and_restricted_containers(tmp_path):
     assert got is None and "render nodes" in why
     got, why = placement.kfd_gpu_bdfs_why(str(tmp_path / "nothing"), dev, {})
     assert got is None and "not listable" in why
+    # the pool's boxes (BENCH r06: "kfd node 2 properties unreadable (PermissionError)"): the nodes of GPUs the container may
+    # not use cannot be read -- they are skipped, and the one readable GPU node matches the one accessible render node
+    sysfs2, dev2 = _fake_kfd(tmp_path / "pool", locs, 1)
+    base = os.path.join(sysfs2, "class", "kfd", "kfd", "topology", "nodes")
+    denied = {os.path.join(base, n, "properties") for n in ("1", "2", "4")}
+    real_open = open
+
+    def guarded_open(path, *a, **k):  # (root reads everything: permission bits on the fake tree would mean nothing to it)
+        if path in denied:
+            raise PermissionError(13, "Permission denied", path)
+        return real_open(path, *a, **k)
+
+    placement.open = guarded_open
+    try:
+        assert placement.kfd_gpu_bdfs_why(sysfs2, dev2, {}) == ([all4[2]], None)
+    finally:
+        del placement.open
