@@ -15,6 +15,7 @@
 
 #include <immintrin.h>
 
+#include <algorithm>
 #include <cstring>
 
 namespace p2 {
@@ -201,8 +202,77 @@ void host_permute(Fp *s) {
 
 }  // namespace p2
 
+// Worst-case ranges of the lazily reduced permutation (poseidon2.h: lazy::permute), re-derived from the ACTUAL constants
+// of its tables instead of the "|K| <= P/2" of the header comment: the magnitude of every 32-bit word and 64-bit sum is
+// propagated through the rounds for the worst input (every canonical word may be P - 1, every sign may conspire), and every
+// place where the code truncates to int32, multiplies two words or reduces a sum is checked against what that operation can
+// hold. false = some bound of the comment does not hold for these tables.
+static bool lazy_range_audit() {
+    using namespace p2::lazy;
+    const long double P = (long double)bb::P, H = 4294967296.0L, I32 = 2147483648.0L, REDC_MAX = 4611686018427387904.0L;  // 2^62
+    auto mag = [](int64_t v) { return (long double)(v < 0 ? -v : v); };
+    bool ok = true;
+    auto need = [&](bool c) { ok = ok && c; };
+    auto redc = [&](long double t) {  // |result| of smont_redc on a sum of magnitude t
+        need(t <= REDC_MAX);
+        return t / H + P / 2 + 1;
+    };
+    auto prod = [&](long double a, long double b) { return redc(a * b); };  // smont_mul: both words fit int32, the product 2^62
+    auto sbox = [&](long double s) {
+        need(s < I32);
+        const long double s2 = prod(s, s), s3 = prod(s2, s), s4 = prod(s2, s2);
+        need(s2 < I32 && s3 < I32 && s4 < I32);
+        const long double s7 = prod(s4, s3);
+        need(s7 < P);  // (the comment's .921 P / .95 P; what matters: it is a word)
+        return s7;
+    };
+    auto external = [&](long double b) {  // 16 words of magnitude b -> the reduced words
+        const long double y = 7 * (5 * b);
+        need(y < 9.0e18L);  // the 64-bit sums themselves
+        return redc(y);
+    };
+    auto maxabs = [&](const int32_t *t, int n) {
+        long double m = 0;
+        for (int i = 0; i < n; i++) m = std::max(m, mag(t[i]));
+        return m;
+    };
+    long double b = external(P - 1);  // the first layer on canonical words
+    for (int r = 0; r < 4; r++) b = external(sbox(b + maxabs(LAZY.c_initial + 16 * r, 16)));
+    // first internal round
+    const long double SC = (8.0L / 15.0L) * P + 32;  // centred_sum: |S - q P| < 8 * 2^27 + |q|
+    {
+        const long double x0 = sbox(b + mag(LAZY.c_internal0));
+        need(15 * b / 134217728.0L < 131072.0L);  // S >> 27 times 4369 stays in int32
+        const long double U = SC * mag(LAZY.first.k_sum), T = x0 * mag(LAZY.first.k_word0) + U;
+        long double w = 0;
+        for (int i = 1; i < 16; i++) w = std::max(w, redc(b * mag(LAZY.first.diag[i]) + T));
+        const long double w0 = redc(x0 * mag(LAZY.first.diag[0]) + U + P);  // (+ the round constant riding along, < P)
+        need(w < I32 && w0 < I32);
+        b = w;
+        // middle rounds and the last one: word 0 is the S-box input w0
+        long double in0 = w0;
+        for (int r = 1; r < 13; r++) {
+            const RoundK &K = r < 12 ? LAZY.middle : LAZY.last;
+            const long double y0 = sbox(in0);
+            need((y0 + 15 * b) / 134217728.0L < 131072.0L);
+            const long double Tm = SC * mag(K.k_sum);
+            long double wn = 0;
+            for (int i = 1; i < 16; i++) wn = std::max(wn, redc(b * mag(K.diag[i]) + Tm + (r == 12 ? P : 0)));
+            const long double wn0 = redc(y0 * mag(K.diag[0]) + Tm + P);
+            need(wn < I32 && wn0 < I32);
+            b = wn, in0 = wn0;
+        }
+        b = std::max(b, in0);  // the sixteen inputs of the first terminal S-boxes
+    }
+    b = external(sbox(b));  // terminal round 0: its constants rode in the last internal round
+    for (int r = 1; r < 4; r++) b = external(sbox(b + maxabs(LAZY.c_terminal + 16 * r, 16)));
+    need(b < P);  // from_signed: a representative in (-P, P)
+    return ok;
+}
+
 // Self-test hook (tests/test_abi.py): 1 if the dispatcher and the scalar permutation agree on n states
 extern "C" int ovm_hip_host_permute_selftest(uint32_t n, uint64_t seed) {
+    if (!lazy_range_audit()) return 0;
     uint64_t st = seed * 0x9E3779B97F4A7C15ull + 1;
     for (uint32_t it = 0; it < n; it++) {
         p2::Fp a[16], b[16];
