@@ -198,7 +198,9 @@ BB_HD void permute_ref_t(Fp *s) {
 // external layer is the Montgomery word, up to `min(r, r + P)`. All of it is exact arithmetic on representatives of
 // the same field elements: the canonical result equals permute_ref_t's.
 //
-// Ranges (|.| of the int32 representatives; h = 2^32; 2^31 = 1.0667 P):
+// Ranges (|.| of the int32 representatives; h = 2^32; 2^31 = 1.0667 P). The bounds below assume only |K| <= P/2 of a
+// constant; host_poseidon2.cpp: lazy_range_audit() re-derives them from the ACTUAL tables (words stay within .70 P) and runs
+// with the host self-test:
 //   smont_redc(x) = (x - m P) / h with a signed word m: |result| <= |x| / h + P/2, for |x| <= 2^62.
 //   S-box: any int32 may enter. |s| <= P + 33 -> |s^2| <= .969 P, |s^3| <= .955 P, |s^4| <= .941 P, |s^7| <= .921 P.
 //   external layer: |column sums| <= 4 * .921 P, |z| <= 5 * .921 P, |y| <= 7 |z| < 33 P < 2^36; reduced |a| <= P/2 + 16;
